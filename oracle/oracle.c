@@ -1,0 +1,416 @@
+/*
+ * oracle.c -- CPU restatement of the registration hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library; the product (lidarregistration_amd/) never does.
+ *
+ * What it restates (file:line relative to the reference tree):
+ *   orc_row_norms, orc_nn_top2     Experiments/algorithms/matching.py:22-65 (find_nn / knn_dist)
+ *   orc_feat_ratio                 Experiments/algorithms/matching.py:89-98
+ *   orc_elc                        GC-RANSAC/src/pygcransac/include/preemption/preemption_edge_length.h:71-128
+ *   orc_kabsch_points/_moments     Experiments/models/common.py:7-45, DGR/util/procrustes.py:34-56
+ *                                  (R = V diag(1,1,det) U^T, t = mu_B - R mu_A), solved here through
+ *                                  Horn's quaternion form + cyclic Jacobi so that it needs only + - * / sqrt
+ *   orc_ransac                     Experiments/algorithms/FR.py:122-139 -> Open3D 0.13.0
+ *                                  registration_ransac_based_on_correspondence (not vendored, pinned in
+ *                                  Requirements/conda_GC_full.yml:115): uniform sampling with replacement,
+ *                                  edge-length checker 0.9, inlier count then RMSE, threshold 0.6 m
+ *   orc_refit                      Experiments/algorithms/FR.py:99-111
+ *
+ * Parity status: NN / ratio / Kabsch are pinned by golden vectors generated from the importable
+ * reference (tests/golden/make_golden.py).  The RANSAC loop itself lives in un-vendored third-party
+ * code (Open3D / pygcransac): PARITY UNPINNED for that loop -- it is anchored on the reference's
+ * call-site parameters and on planted-model recovery properties only.
+ *
+ * Arithmetic contract (the HIP kernels implement exactly this; build with -ffp-contract=off):
+ *   norm(x)   = chain n = fmaf(x[k], x[k], n), k = 0..D-1, n0 = +0
+ *   dot(a,b)  = chain c = fmaf(a[k], b[k], c), k = 0..D-1, c0 = +0     (== v_mfma_f32_32x32x2_f32 order)
+ *   d2(i,j)   = fmaf(-2, dot, n0[i] + n1[j]);  s = sqrtf(fmaxf(d2, 1e-30f))
+ *   NN order  = ascending (s, j): first minimal value wins, as torch.min(dim=1) does.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------ NN ---- */
+
+ORC_API void orc_row_norms(const float *F, int n, int d, float *out)
+{
+    for (int i = 0; i < n; ++i) {
+        float acc = 0.0f;
+        for (int k = 0; k < d; ++k) acc = fmaf(F[(size_t)i * d + k], F[(size_t)i * d + k], acc);
+        out[i] = acc;
+    }
+}
+
+/* matching.py:25-41 + :43-65.  idx2/s2 may be NULL (return_2nd=False).
+ * Returns, per query row of F0, the first and second nearest rows of F1.          */
+ORC_API void orc_nn_top2(const float *F0, int n0, const float *F1, int n1, int d,
+                         int32_t *idx1, int32_t *idx2, float *s1, float *s2)
+{
+    float *nrm0 = (float *)malloc(sizeof(float) * (size_t)n0);
+    float *nrm1 = (float *)malloc(sizeof(float) * (size_t)n1);
+    /* F1 transposed [k][j] so the inner loop vectorises across j; each j keeps its own chain. */
+    float *F1T = (float *)malloc(sizeof(float) * (size_t)n1 * d);
+    orc_row_norms(F0, n0, d, nrm0);
+    orc_row_norms(F1, n1, d, nrm1);
+    for (int j = 0; j < n1; ++j)
+        for (int k = 0; k < d; ++k) F1T[(size_t)k * n1 + j] = F1[(size_t)j * d + k];
+
+#pragma omp parallel
+    {
+        enum { JB = 64 };
+        float acc[JB];
+#pragma omp for schedule(static)
+        for (int i = 0; i < n0; ++i) {
+            const float *a = F0 + (size_t)i * d;
+            float b1 = INFINITY, b2 = INFINITY;
+            int32_t i1 = -1, i2 = -1;
+            for (int j0 = 0; j0 < n1; j0 += JB) {
+                int jn = n1 - j0 < JB ? n1 - j0 : JB;
+                for (int jj = 0; jj < jn; ++jj) acc[jj] = 0.0f;
+                for (int k = 0; k < d; ++k) {
+                    const float ak = a[k];
+                    const float *brow = F1T + (size_t)k * n1 + j0;
+                    for (int jj = 0; jj < jn; ++jj) acc[jj] = fmaf(ak, brow[jj], acc[jj]);
+                }
+                for (int jj = 0; jj < jn; ++jj) {
+                    float t = nrm0[i] + nrm1[j0 + jj];
+                    float d2 = fmaf(-2.0f, acc[jj], t);
+                    float s = sqrtf(fmaxf(d2, 1e-30f));
+                    /* j ascends, so strict '<' keeps the first minimal value */
+                    if (s < b1) { b2 = b1; i2 = i1; b1 = s; i1 = j0 + jj; }
+                    else if (s < b2) { b2 = s; i2 = j0 + jj; }
+                }
+            }
+            idx1[i] = i1;
+            if (s1) s1[i] = b1;
+            if (idx2) idx2[i] = i2;
+            if (s2) s2[i] = b2;
+        }
+    }
+    free(nrm0); free(nrm1); free(F1T);
+}
+
+/* matching.py:89-98: ||A-B1|| / (||A-B2|| + 1e-6), direct differences, sequential k. */
+ORC_API void orc_feat_ratio(const float *F0, const float *F1, int d, int m,
+                            const int32_t *i0, const int32_t *i1, const int32_t *i2, float *out)
+{
+    for (int c = 0; c < m; ++c) {
+        const float *a = F0 + (size_t)i0[c] * d;
+        const float *b1 = F1 + (size_t)i1[c] * d;
+        const float *b2 = F1 + (size_t)i2[c] * d;
+        float s1 = 0.0f, s2 = 0.0f;
+        for (int k = 0; k < d; ++k) {
+            float e1 = a[k] - b1[k];
+            float e2 = a[k] - b2[k];
+            float q1 = e1 * e1, q2 = e2 * e2;
+            s1 = s1 + q1;
+            s2 = s2 + q2;
+        }
+        float d1 = sqrtf(s1), d2v = sqrtf(s2);
+        out[c] = d1 / (d2v + 1e-6f);
+    }
+}
+
+/* -------------------------------------------------------------- Philox ---- */
+
+static inline void philox4x32_10(uint32_t ctr[4], uint32_t k0, uint32_t k1)
+{
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * ctr[0];
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * ctr[2];
+        uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+        uint32_t n0 = hi1 ^ ctr[1] ^ k0;
+        uint32_t n2 = hi0 ^ ctr[3] ^ k1;
+        ctr[0] = n0; ctr[1] = lo1; ctr[2] = n2; ctr[3] = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+ORC_API void orc_philox(uint64_t seed, uint64_t h, uint32_t out[4])
+{
+    uint32_t c[4] = { (uint32_t)h, (uint32_t)(h >> 32), 0u, 0u };
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    memcpy(out, c, sizeof(c));
+}
+
+/* sample_size (<=4) correspondence indices in [0,m), uniform with replacement */
+static inline void draw_sample(uint64_t seed, uint64_t h, int m, int ns, int32_t *s)
+{
+    uint32_t w[4];
+    orc_philox(seed, h, w);
+    for (int k = 0; k < ns; ++k) s[k] = (int32_t)(((uint64_t)w[k] * (uint64_t)(uint32_t)m) >> 32);
+}
+
+/* ----------------------------------------------------------------- ELC ---- */
+
+/* preemption_edge_length.h:71-128: reject when any pair of sample edges differs by more than 0.9 */
+static int elc_ok(const float *src, const float *tgt, const int32_t *s, int ns)
+{
+    const double SIM = 0.9;
+    for (int i = 0; i < ns; ++i)
+        for (int j = i + 1; j < ns; ++j) {
+            double sx = (double)src[3 * s[j]] - (double)src[3 * s[i]];
+            double sy = (double)src[3 * s[j] + 1] - (double)src[3 * s[i] + 1];
+            double sz = (double)src[3 * s[j] + 2] - (double)src[3 * s[i] + 2];
+            double tx = (double)tgt[3 * s[j]] - (double)tgt[3 * s[i]];
+            double ty = (double)tgt[3 * s[j] + 1] - (double)tgt[3 * s[i] + 1];
+            double tz = (double)tgt[3 * s[j] + 2] - (double)tgt[3 * s[i] + 2];
+            double ds = sqrt((sx * sx + sy * sy) + sz * sz);
+            double dt = sqrt((tx * tx + ty * ty) + tz * tz);
+            if (ds < dt * SIM || dt < ds * SIM) return 0;
+        }
+    return 1;
+}
+
+ORC_API int orc_elc(const float *src, const float *tgt, const int32_t *sample, int ns)
+{
+    return elc_ok(src, tgt, sample, ns);
+}
+
+/* -------------------------------------------------------------- Kabsch ---- */
+
+#define JACOBI_SWEEPS 8
+
+/* Largest-eigenvalue eigenvector of a symmetric 4x4 by cyclic Jacobi (fixed sweep count). */
+static void jacobi4_maxvec(double A[4][4], double q[4])
+{
+    double V[4][4] = { {1,0,0,0}, {0,1,0,0}, {0,0,1,0}, {0,0,0,1} };
+    for (int sweep = 0; sweep < JACOBI_SWEEPS; ++sweep) {
+        for (int p = 0; p < 3; ++p)
+            for (int r = p + 1; r < 4; ++r) {
+                double apq = A[p][r];
+                if (apq == 0.0) continue;
+                double theta = (A[r][r] - A[p][p]) / (2.0 * apq);
+                double at = fabs(theta);
+                double t = 1.0 / (at + sqrt(theta * theta + 1.0));
+                if (theta < 0.0) t = -t;
+                double c = 1.0 / sqrt(t * t + 1.0);
+                double s = t * c;
+                double tau = s / (1.0 + c);
+                double h = t * apq;
+                A[p][p] = A[p][p] - h;
+                A[r][r] = A[r][r] + h;
+                A[p][r] = 0.0; A[r][p] = 0.0;
+                for (int k = 0; k < 4; ++k) {
+                    if (k == p || k == r) continue;
+                    double g = A[k][p], f = A[k][r];
+                    double gn = g - s * (f + g * tau);
+                    double fn = f + s * (g - f * tau);
+                    A[k][p] = gn; A[p][k] = gn;
+                    A[k][r] = fn; A[r][k] = fn;
+                }
+                for (int k = 0; k < 4; ++k) {
+                    double g = V[k][p], f = V[k][r];
+                    V[k][p] = g - s * (f + g * tau);
+                    V[k][r] = f + s * (g - f * tau);
+                }
+            }
+    }
+    int im = 0;
+    for (int k = 1; k < 4; ++k) if (A[k][k] > A[im][im]) im = k;
+    double w = V[0][im], x = V[1][im], y = V[2][im], z = V[3][im];
+    double nn = sqrt(((w * w + x * x) + y * y) + z * z);
+    q[0] = w / nn; q[1] = x / nn; q[2] = y / nn; q[3] = z / nn;
+}
+
+/* H = sum (p - cp)(q - cq)^T  (3x3, row = source axis, col = target axis) -> R, t with q ~ R p + t */
+static void rt_from_cov(const double H[3][3], const double cp[3], const double cq[3], double T[16])
+{
+    double Sxx = H[0][0], Sxy = H[0][1], Sxz = H[0][2];
+    double Syx = H[1][0], Syy = H[1][1], Syz = H[1][2];
+    double Szx = H[2][0], Szy = H[2][1], Szz = H[2][2];
+    double N[4][4];
+    N[0][0] = (Sxx + Syy) + Szz;  N[0][1] = Syz - Szy;           N[0][2] = Szx - Sxz;            N[0][3] = Sxy - Syx;
+    N[1][0] = N[0][1];            N[1][1] = (Sxx - Syy) - Szz;   N[1][2] = Sxy + Syx;            N[1][3] = Szx + Sxz;
+    N[2][0] = N[0][2];            N[2][1] = N[1][2];             N[2][2] = (Syy - Sxx) - Szz;    N[2][3] = Syz + Szy;
+    N[3][0] = N[0][3];            N[3][1] = N[1][3];             N[3][2] = N[2][3];              N[3][3] = (Szz - Sxx) - Syy;
+    double q[4];
+    jacobi4_maxvec(N, q);
+    double w = q[0], x = q[1], y = q[2], z = q[3];
+    double R[3][3];
+    R[0][0] = 1.0 - 2.0 * (y * y + z * z); R[0][1] = 2.0 * (x * y - w * z);       R[0][2] = 2.0 * (x * z + w * y);
+    R[1][0] = 2.0 * (x * y + w * z);       R[1][1] = 1.0 - 2.0 * (x * x + z * z); R[1][2] = 2.0 * (y * z - w * x);
+    R[2][0] = 2.0 * (x * z - w * y);       R[2][1] = 2.0 * (y * z + w * x);       R[2][2] = 1.0 - 2.0 * (x * x + y * y);
+    for (int a = 0; a < 3; ++a) {
+        double rc = (R[a][0] * cp[0] + R[a][1] * cp[1]) + R[a][2] * cp[2];
+        T[4 * a + 0] = R[a][0]; T[4 * a + 1] = R[a][1]; T[4 * a + 2] = R[a][2];
+        T[4 * a + 3] = cq[a] - rc;
+    }
+    T[12] = 0.0; T[13] = 0.0; T[14] = 0.0; T[15] = 1.0;
+}
+
+/* Kabsch on n explicit point pairs (minimal samples, goldens).  T is 4x4 row-major, column-vector
+ * convention, maps src -> tgt.  Optional weights w (NULL = 1).                                       */
+ORC_API void orc_kabsch_points(const double *P, const double *Q, const double *w, int n, double T[16])
+{
+    double cp[3] = {0, 0, 0}, cq[3] = {0, 0, 0}, W = 0.0;
+    for (int i = 0; i < n; ++i) {
+        double wi = w ? w[i] : 1.0;
+        W = W + wi;
+        for (int a = 0; a < 3; ++a) { cp[a] = cp[a] + wi * P[3 * i + a]; cq[a] = cq[a] + wi * Q[3 * i + a]; }
+    }
+    for (int a = 0; a < 3; ++a) { cp[a] = cp[a] / W; cq[a] = cq[a] / W; }
+    double H[3][3] = { {0,0,0}, {0,0,0}, {0,0,0} };
+    for (int i = 0; i < n; ++i) {
+        double wi = w ? w[i] : 1.0;
+        double pc[3], qc[3];
+        for (int a = 0; a < 3; ++a) { pc[a] = P[3 * i + a] - cp[a]; qc[a] = Q[3 * i + a] - cq[a]; }
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) H[a][b] = H[a][b] + (wi * pc[a]) * qc[b];
+    }
+    rt_from_cov(H, cp, cq, T);
+}
+
+/* Kabsch from raw moments: n, sum p, sum q, sum p q^T (what the refit kernel accumulates). */
+ORC_API void orc_kabsch_moments(double n, const double sp[3], const double sq[3], const double spq[9], double T[16])
+{
+    double cp[3], cq[3], H[3][3];
+    for (int a = 0; a < 3; ++a) { cp[a] = sp[a] / n; cq[a] = sq[a] / n; }
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) H[a][b] = spq[3 * a + b] - (n * cp[a]) * cq[b];
+    rt_from_cov(H, cp, cq, T);
+}
+
+/* -------------------------------------------------------------- RANSAC ---- */
+
+typedef struct {
+    int32_t  sample_size;     /* 3 (GC minimal solver) or 4 (FR.py:134 ransac_n)      */
+    int32_t  use_elc;         /* edge-length pre-check on the sample                  */
+    float    thr2;            /* squared inlier threshold (0.6 m)^2                   */
+    int32_t  iters;           /* hypotheses h = 0 .. iters-1                          */
+    uint64_t seed;
+} orc_ransac_params;
+
+typedef struct {
+    int64_t  best_h;          /* winning hypothesis id, -1 if none                    */
+    uint32_t best_count;      /* its inlier count                                     */
+    uint64_t best_ssq;        /* sum over inliers of (uint32)(d2 * 2^20)              */
+    int64_t  n_valid;         /* hypotheses that passed the pre-check                 */
+} orc_ransac_result;
+
+/* fp64 minimal-sample Kabsch for hypothesis h; returns 0 when the pre-check rejects it */
+static int hypothesis_T(const float *src, const float *tgt, int m, const orc_ransac_params *p,
+                        uint64_t h, double T[16], int32_t *sample_out)
+{
+    int32_t s[4];
+    draw_sample(p->seed, h, m, p->sample_size, s);
+    if (sample_out) memcpy(sample_out, s, sizeof(int32_t) * p->sample_size);
+    if (p->use_elc && !elc_ok(src, tgt, s, p->sample_size)) return 0;
+    double P[12], Q[12];
+    for (int k = 0; k < p->sample_size; ++k)
+        for (int a = 0; a < 3; ++a) { P[3 * k + a] = (double)src[3 * s[k] + a]; Q[3 * k + a] = (double)tgt[3 * s[k] + a]; }
+    orc_kabsch_points(P, Q, NULL, p->sample_size, T);
+    return 1;
+}
+
+ORC_API int orc_hypothesis(const float *src, const float *tgt, int m, const orc_ransac_params *p,
+                           uint64_t h, double T[16], int32_t sample[4])
+{
+    return hypothesis_T(src, tgt, m, p, h, T, sample);
+}
+
+/* inlier count + fixed-point squared-error sum of one fp32 model over all m correspondences */
+static void score_model(const float *src, const float *tgt, int m, const float Rt[12], float thr2,
+                        uint32_t *count, uint64_t *ssq)
+{
+    uint32_t c = 0; uint64_t q = 0;
+    for (int i = 0; i < m; ++i) {
+        float px = src[3 * i], py = src[3 * i + 1], pz = src[3 * i + 2];
+        float x = fmaf(Rt[0], px, fmaf(Rt[1], py, fmaf(Rt[2], pz, Rt[3])));
+        float y = fmaf(Rt[4], px, fmaf(Rt[5], py, fmaf(Rt[6], pz, Rt[7])));
+        float z = fmaf(Rt[8], px, fmaf(Rt[9], py, fmaf(Rt[10], pz, Rt[11])));
+        float dx = x - tgt[3 * i], dy = y - tgt[3 * i + 1], dz = z - tgt[3 * i + 2];
+        float d2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+        if (d2 < thr2) { c += 1; q += (uint64_t)(uint32_t)(d2 * 1048576.0f); }
+    }
+    *count = c; *ssq = q;
+}
+
+ORC_API void orc_score(const float *src, const float *tgt, int m, const double T[16], float thr2,
+                       uint32_t *count, uint64_t *ssq)
+{
+    float Rt[12];
+    for (int k = 0; k < 12; ++k) Rt[k] = (float)T[k];
+    score_model(src, tgt, m, Rt, thr2, count, ssq);
+}
+
+/* Hypothesise-and-verify loop with Open3D ordering: more inliers wins, then lower error, then lower h.
+ * Every hypothesis is evaluated (confidence-based early exit disabled, as the benchmark runs it).   */
+ORC_API void orc_ransac(const float *src, const float *tgt, int m, const orc_ransac_params *p,
+                        double T_best[16], orc_ransac_result *res)
+{
+    int64_t best_h = -1; uint32_t best_c = 0; uint64_t best_q = 0; int64_t n_valid = 0;
+#pragma omp parallel
+    {
+        int64_t lh = -1; uint32_t lc = 0; uint64_t lq = 0; int64_t lv = 0;
+#pragma omp for schedule(dynamic, 64)
+        for (int64_t h = 0; h < p->iters; ++h) {
+            double T[16];
+            if (!hypothesis_T(src, tgt, m, p, (uint64_t)h, T, NULL)) continue;
+            lv += 1;
+            float Rt[12];
+            for (int k = 0; k < 12; ++k) Rt[k] = (float)T[k];
+            uint32_t c; uint64_t q;
+            score_model(src, tgt, m, Rt, p->thr2, &c, &q);
+            if (c == 0) continue;
+            if (lh < 0 || c > lc || (c == lc && (q < lq || (q == lq && h < lh)))) { lh = h; lc = c; lq = q; }
+        }
+#pragma omp critical
+        {
+            n_valid += lv;
+            if (lh >= 0 && (best_h < 0 || lc > best_c ||
+                            (lc == best_c && (lq < best_q || (lq == best_q && lh < best_h))))) {
+                best_h = lh; best_c = lc; best_q = lq;
+            }
+        }
+    }
+    for (int k = 0; k < 16; ++k) T_best[k] = (k % 5 == 0) ? 1.0 : 0.0;
+    if (best_h >= 0) hypothesis_T(src, tgt, m, p, (uint64_t)best_h, T_best, NULL);
+    res->best_h = best_h; res->best_count = best_c; res->best_ssq = best_q; res->n_valid = n_valid;
+}
+
+/* --------------------------------------------------------------- refit ---- */
+
+/* FR.py:99-111: inliers of T over the ORIGINAL nn pairs (i, idx1[i]) within thr2 (fp64), then a
+ * least-squares rigid fit on them.  Returns the inlier count; T_out = T_in when fewer than 3.     */
+ORC_API int orc_refit(const float *xyz0, int n0, const float *xyz1, const int32_t *idx1,
+                      const double T_in[16], double thr2, double T_out[16])
+{
+    double n = 0.0, sp[3] = {0,0,0}, sq[3] = {0,0,0}, spq[9] = {0,0,0,0,0,0,0,0,0};
+    for (int i = 0; i < n0; ++i) {
+        double p[3] = { xyz0[3 * i], xyz0[3 * i + 1], xyz0[3 * i + 2] };
+        int j = idx1[i];
+        double q[3] = { xyz1[3 * j], xyz1[3 * j + 1], xyz1[3 * j + 2] };
+        double r[3];
+        for (int a = 0; a < 3; ++a)
+            r[a] = (((T_in[4 * a] * p[0] + T_in[4 * a + 1] * p[1]) + T_in[4 * a + 2] * p[2]) + T_in[4 * a + 3]) - q[a];
+        double d2 = (r[0] * r[0] + r[1] * r[1]) + r[2] * r[2];
+        if (d2 < thr2) {
+            n += 1.0;
+            for (int a = 0; a < 3; ++a) { sp[a] += p[a]; sq[a] += q[a]; }
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b) spq[3 * a + b] += p[a] * q[b];
+        }
+    }
+    if (n < 3.0) { memcpy(T_out, T_in, sizeof(double) * 16); return (int)n; }
+    orc_kabsch_moments(n, sp, sq, spq, T_out);
+    return (int)n;
+}
+
+ORC_API int orc_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

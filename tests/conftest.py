@@ -1,0 +1,35 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle as orc
+    orc.build()
+    return orc
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+class Args:
+    """argparse-like bag with the reference's hot-path defaults (Experiments/test.py:294-313)."""
+    def __init__(self, **kw):
+        self.mode = "MNN"; self.codebase = "open3D"; self.iters = 50000; self.prosac = False
+        self.GPF_grid_wid = 10; self.GPF_factor = 2.0; self.GPF_max_matches = 10 ** 9
+        self.spatial_coherence_weight = 0.0; self.GC_conf = 0.999; self.fast_rejection = "ELC"; self.GC_LO = True
+        self.__dict__.update(kw)

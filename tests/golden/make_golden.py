@@ -1,0 +1,190 @@
+"""Generate golden vectors by IMPORTING the reference (runs only where /root/reference exists).
+
+Nothing from the reference is copied: this script calls its functions on seeded synthetic inputs and
+stores inputs' seeds/shapes plus the outputs as small .npz files next to this script.
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
+
+Reference entry points exercised (paths relative to /root/reference):
+    Experiments/algorithms/matching.py  find_nn, find_2nn, nn_to_mutual, mark_best_buddies,
+                                        calc_distance_ratio_in_feature_space, Grid_Prioritized_Filter,
+                                        measure_inlier_ratio
+    Experiments/models/common.py        rigid_transform_3d
+    DGR/util/procrustes.py              weighted_procrustes
+    Experiments/libs/loss.py            TransformationLoss
+    balanced_sets/*/test.txt + test.coarse_motions.txt   (data rows -> recall table)
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+
+REF = os.environ.get("LIDARREG_REFERENCE", "/root/reference")
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", ".."))
+
+warnings.filterwarnings("ignore")
+
+
+def synth_feats(n0, n1, d, seed, rho=0.5, s=1.0):
+    """Unit-norm descriptors with a planted partial matching (same recipe as lidarregistration_amd.synth)."""
+    from lidarregistration_amd import synth
+    return synth.make_features(n0, n1, d, rho, s, seed)
+
+
+class Args:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+class FakeCloud:
+    """Duck-typed stand-in for the Open3D cloud that measure_inlier_ratio deep-copies and transforms."""
+    def __init__(self, xyz):
+        self.points = np.asarray(xyz, np.float64)
+
+    def transform(self, T):
+        self.points = self.points @ T[:3, :3].T + T[:3, 3]
+        return self
+
+
+def main():
+    import torch
+    torch.manual_seed(0)
+    torch.set_num_threads(4)
+    sys.path.insert(0, os.path.join(REF, "Experiments"))
+    from algorithms import matching as M
+
+    from lidarregistration_amd import synth
+
+    # ---------------- G1: find_nn / find_2nn -----------------------------------------------
+    out = {}
+    for tag, (n0, n1, d) in {"a": (2048, 2048, 32), "b": (3000, 2500, 32), "c": (251, 499, 32), "d": (250, 250, 32)}.items():
+        F0, F1 = synth_feats(n0, n1, d, seed=51 + len(tag) + n0)
+        i0, i1, i2 = M.find_nn(torch.from_numpy(F0), torch.from_numpy(F1), return_2nd=True)
+        j0, j1, none = M.find_nn(torch.from_numpy(F0), torch.from_numpy(F1), return_2nd=False)
+        assert none is None and torch.equal(i1, j1)
+        out[f"{tag}_shape"] = np.array([n0, n1, d, 51 + len(tag) + n0])
+        out[f"{tag}_idx1"] = i1.numpy().astype(np.int32)
+        out[f"{tag}_idx2"] = i2.numpy().astype(np.int32)
+    np.savez_compressed(os.path.join(HERE, "g1_find_nn.npz"), **out)
+
+    # ---------------- G2-G5: mutual / best buddies / ratio / GPF ---------------------------------
+    out = {}
+    n0, n1, d, seed = 3000, 2600, 32, 77
+    F0, F1 = synth_feats(n0, n1, d, seed)
+    xyz0, xyz1, T_gt = synth.make_clouds(n0, n1, 0.5, seed, clustered=True)
+    tF0, tF1 = torch.from_numpy(F0), torch.from_numpy(F1)
+    i0, i1, i2, _ = M.find_2nn(tF0, tF1)
+    out["shape"] = np.array([n0, n1, d, seed])
+    out["idx1"] = i1.numpy().astype(np.int32); out["idx2"] = i2.numpy().astype(np.int32)
+    m0, m1, m2 = M.nn_to_mutual(tF0, tF1, i0, i1, i2)
+    out["mnn_idx0"] = m0.numpy().astype(np.int32); out["mnn_idx1"] = m1.numpy().astype(np.int32)
+    out["mnn_idx2"] = m2.numpy().astype(np.int32)
+    r = M.nn_to_mutual(tF0, tF1, i0, i1)
+    assert len(r) == 2 and torch.equal(r[0], m0)
+    r = M.nn_to_mutual(tF0, tF1, i0, i1, None, force_return_2nd=True)
+    assert len(r) == 3 and r[2] is None
+    is_bb, num_bb = M.mark_best_buddies(tF0, tF1, i0, i1)
+    out["is_bb"] = is_bb; out["num_bb"] = np.array(num_bb)
+    out["ratio_nn"] = M.calc_distance_ratio_in_feature_space(tF0, tF1, i0, i1, i2).numpy()
+    out["ratio_mnn"] = M.calc_distance_ratio_in_feature_space(tF0, tF1, m0, m1, m2).numpy()
+    for k, (factor, wid) in enumerate([(2.0, 10), (0.5, 10), (0.1, 4), (1.0, 7)]):
+        a = Args(GPF_grid_wid=wid, GPF_factor=factor, GPF_max_matches=10 ** 9)
+        g = M.Grid_Prioritized_Filter(tF0, tF1, i0, i1, i2, torch.from_numpy(xyz0), a)
+        out[f"gpf{k}_cfg"] = np.array([factor, wid])
+        out[f"gpf{k}_idx0"] = g[0].numpy().astype(np.int32); out[f"gpf{k}_idx1"] = g[1].numpy().astype(np.int32)
+        out[f"gpf{k}_idx2"] = g[2].numpy().astype(np.int32); out[f"gpf{k}_score"] = g[6].numpy()
+        assert torch.equal(g[3], i0) and torch.equal(g[4], i1) and torch.equal(g[5], i2)
+    for k, cap in enumerate([100, 1000, 10 ** 9]):
+        a = Args(GPF_grid_wid=10, GPF_factor=2.0, GPF_max_matches=cap)
+        g = M.Grid_Prioritized_Filter(tF0, tF1, i0, i1, i2, torch.from_numpy(xyz0), a, BB_first=True)
+        out[f"gpfbb{k}_cap"] = np.array(cap)
+        out[f"gpfbb{k}_idx0"] = g[0].numpy().astype(np.int32); out[f"gpfbb{k}_idx1"] = g[1].numpy().astype(np.int32)
+        out[f"gpfbb{k}_has_score"] = np.array(g[6] is not None)
+        if g[6] is not None:
+            out[f"gpfbb{k}_score"] = g[6].numpy()
+    # G6: measure_inlier_ratio
+    out["T_gt"] = T_gt
+    out["ir_nn"] = np.array(M.measure_inlier_ratio(i0, i1, FakeCloud(xyz0), FakeCloud(xyz1), T_gt, 0.3))
+    out["ir_mnn"] = np.array(M.measure_inlier_ratio(m0, m1, FakeCloud(xyz0), FakeCloud(xyz1), T_gt, 0.3))
+    np.savez_compressed(os.path.join(HERE, "g2_filters.npz"), **out)
+
+    # ---------------- G7: Kabsch ----------------------------------------------------------------
+    # common.py does `from utils.SE3 import *`; Experiments/utils is a package on the path already.
+    from models.common import rigid_transform_3d
+    sys.path.insert(0, os.path.join(REF, "DGR"))
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_procrustes", os.path.join(REF, "DGR", "util", "procrustes.py"))
+    proc = importlib.util.module_from_spec(spec); spec.loader.exec_module(proc)
+    rng = np.random.default_rng(7)
+    out = {}
+    cases = []
+    for k, n in enumerate([3, 4, 100, 3, 5, 50]):
+        P = rng.uniform(-50, 50, (n, 3))
+        ang = rng.uniform(-np.pi, np.pi); ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+        K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+        R = np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * K @ K
+        t = rng.uniform(-30, 30, 3)
+        Q = P @ R.T + t + rng.normal(0, 0.05, (n, 3))
+        if k == 4:   # reflection-prone: nearly planar, mirrored noise
+            P[:, 2] *= 1e-3
+            Q = P @ R.T + t
+            Q += rng.normal(0, 0.3, Q.shape)
+        w = rng.uniform(0.1, 1.0, n) if k in (2, 5) else None
+        cases.append((P, Q, w))
+    for k, (P, Q, w) in enumerate(cases):
+        # common.py is float32 throughout (torch.eye(3) at :39), so feed it float32
+        tw = None if w is None else torch.from_numpy(w)[None].float().clone()
+        T = rigid_transform_3d(torch.from_numpy(P)[None].float(), torch.from_numpy(Q)[None].float(), tw)[0].numpy()
+        out[f"k{k}_P"] = P; out[f"k{k}_Q"] = Q
+        out[f"k{k}_w"] = np.zeros(0) if w is None else w
+        out[f"k{k}_T_common"] = T
+        # procrustes.py takes float32 clouds and does its SVD in float64 (:49-50)
+        ww = torch.ones(len(P), 1) if w is None else torch.from_numpy(w)[:, None].float()
+        Rr, tt = proc.weighted_procrustes(torch.from_numpy(P).float(), torch.from_numpy(Q).float(), ww)
+        Tp = np.eye(4); Tp[:3, :3] = Rr.numpy(); Tp[:3, 3] = tt.numpy()
+        out[f"k{k}_T_procrustes"] = Tp
+    np.savez_compressed(os.path.join(HERE, "g7_kabsch.npz"), **out)
+
+    # ---------------- G8: TransformationLoss ----------------------------------------------------
+    from libs.loss import TransformationLoss
+    loss = TransformationLoss(re_thre=5, te_thre=60)
+    out = {}
+    Ts, Tg, rec, RE, TE = [], [], [], [], []
+    for k in range(24):
+        ang_gt = rng.uniform(-np.pi, np.pi)
+        Rg = np.array([[np.cos(ang_gt), -np.sin(ang_gt), 0], [np.sin(ang_gt), np.cos(ang_gt), 0], [0, 0, 1]])
+        G = np.eye(4); G[:3, :3] = Rg; G[:3, 3] = rng.uniform(-30, 30, 3)
+        dang = np.radians([0.5, 1.9, 2.1, 4.9, 5.1, 20.0][k % 6])
+        dR = np.array([[1, 0, 0], [0, np.cos(dang), -np.sin(dang)], [0, np.sin(dang), np.cos(dang)]])
+        Tt = np.eye(4); Tt[:3, :3] = dR @ Rg
+        Tt[:3, 3] = G[:3, 3] + np.array([[0.1, 0.59, 0.61, 2.0][k % 4], 0, 0])
+        kp = torch.zeros(1, 4, 3)
+        _, r, re, te, _ = loss(torch.from_numpy(Tt)[None].float(), torch.from_numpy(G)[None].float(), kp, kp, torch.ones(1, 4))
+        Ts.append(Tt); Tg.append(G); rec.append(r); RE.append(float(re)); TE.append(float(te))
+    out["T"] = np.array(Ts); out["T_gt"] = np.array(Tg); out["recall"] = np.array(rec)
+    out["RE"] = np.array(RE); out["TE"] = np.array(TE)
+    np.savez_compressed(os.path.join(HERE, "g8_metric.npz"), **out)
+
+    # ---------------- G9: recall of the reference's own coarse motions (data rows only) -----------------
+    out = {}
+    for name in ["ApolloSouthbay", "NuScenes_boston", "NuScenes_singapore"]:
+        gt = np.loadtxt(os.path.join(REF, "balanced_sets", name, "test.txt"), skiprows=1)
+        cm = np.loadtxt(os.path.join(REF, "balanced_sets", name, "test.coarse_motions.txt"), skiprows=1)
+        assert np.array_equal(gt[:, :3], cm[:, :3])
+        sel = np.linspace(0, len(gt) - 1, 200).astype(int)     # small sample of rows, enough to pin the metric code
+        out[f"{name}_gt"] = gt[sel, 3:19]; out[f"{name}_cm"] = cm[sel, 3:19]
+        Tg = gt[:, 3:19].reshape(-1, 4, 4); Tc = cm[:, 3:19].reshape(-1, 4, 4)
+        tr = np.einsum("nij,nij->n", Tc[:, :3, :3], Tg[:, :3, :3])
+        re = np.degrees(np.arccos(np.clip((tr - 1) / 2, -1, 1)))
+        te = np.linalg.norm(Tc[:, :3, 3] - Tg[:, :3, 3], axis=1) * 100
+        out[f"{name}_recall5"] = np.array(np.mean((re < 5) & (te < 60)))
+        out[f"{name}_recall2"] = np.array(np.mean((re < 2) & (te < 60)))
+        out[f"{name}_n"] = np.array(len(gt))
+    np.savez_compressed(os.path.join(HERE, "g9_recall.npz"), **out)
+    print("golden vectors written to", HERE)
+
+
+if __name__ == "__main__":
+    main()
