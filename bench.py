@@ -1,0 +1,183 @@
+"""Registration-pairs/sec benchmark (BASELINE.json config #2: 30k-pt x 32-d synthetic FCGF pairs,
+mutual-NN + 50k-iteration RANSAC + LS refit) on N GPUs of one node.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one pass of the hot path over one batch of `--pairs` resident pairs per GPU.  Pairs shard
+over ranks with no data-path collective (weak scaling); one RCCL all_gather per step returns the result rows.
+Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` for the dominant kernel
+(nn_strip_kernel, fp32 MFMA) and `cpu_baseline` (the oracle port timed on the host cores, rank 0, N=1).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_F32_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--pairs", type=int, default=32, help="pairs per step per GPU")
+    ap.add_argument("--n", type=int, default=30000, help="points per cloud")
+    ap.add_argument("--iters", type=int, default=50000)
+    ap.add_argument("--mode", default="MNN")
+    ap.add_argument("--streams", type=int, default=4, help="pairs in flight per GPU")
+    ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic pairs generated per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-pairs", type=int, default=2)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from lidarregistration_amd import FR, _ext, shard, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    class A:
+        mode = args.mode; codebase = "open3D"; iters = args.iters; ransac_n = 3; GPF_factor = 2.0; GPF_grid_wid = 10
+    params = FR.pair_params(A)
+
+    # resident inputs: `distinct` synthetic pairs per GPU, cycled through the batch
+    pairs = []
+    for k in range(args.distinct):
+        p = synth.make_pair(N=args.n, seed=51 + rank * 1000 + k)
+        pairs.append(dict(xyz0=torch.from_numpy(p["xyz0"]).to(dev), xyz1=torch.from_numpy(p["xyz1"]).to(dev),
+                          f0=torch.from_numpy(p["feats0"]).to(dev), f1=torch.from_numpy(p["feats1"]).to(dev), T_gt=p["T_gt"]))
+    nstreams = max(1, args.streams)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
+    wss = [_ext.Workspace(args.n, args.n, 32, args.iters) for _ in range(nstreams)]
+    outs = torch.zeros((args.pairs, ctypes.sizeof(_ext.PairResult)), dtype=torch.uint8, device=dev)
+    rows = torch.zeros((args.pairs, shard.ROW), dtype=torch.float64, device=dev)
+    gathered = torch.zeros((world * args.pairs, shard.ROW), dtype=torch.float64, device=dev) if world > 1 else None
+
+    def step():
+        for i in range(args.pairs):
+            s = i % nstreams
+            pr = pairs[i % len(pairs)]
+            FR.register_pair_dev(pr["xyz0"], pr["xyz1"], pr["f0"], pr["f1"], params, out=outs[i], ws=wss[s],
+                                 stream=streams[s].cuda_stream)
+        for s in streams:
+            torch.cuda.current_stream().wait_stream(s)
+        if world > 1:
+            # result rows = the 16 doubles of T (+ stats columns, zero here); one collective per step
+            rows[:, 22:38] = outs[:, :128].view(torch.float64).view(args.pairs, 16)
+            dist.all_gather_into_tensor(gathered, rows)
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for s in streams:
+        s.wait_stream(torch.cuda.current_stream())
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # ---- sanity of what was timed: every pair of the last step registered correctly
+    res = [_ext.PairResult.from_buffer_copy(outs[i].cpu().numpy().tobytes()) for i in range(args.pairs)]
+    ok = 0
+    for i, r in enumerate(res):
+        T = np.array(r.T[:]).reshape(4, 4); G = pairs[i % len(pairs)]["T_gt"]
+        re = np.degrees(np.arccos(np.clip((np.trace(T[:3, :3].T @ G[:3, :3]) - 1) / 2, -1, 1)))
+        te = np.linalg.norm(T[:3, 3] - G[:3, 3])
+        ok += int(re < 5 and te < 0.6)
+    recall = ok / len(res)
+
+    # ---- roofline of the dominant kernel: HIP events around nn_strip_kernel on its launch stream
+    roof = None
+    if rank == 0:
+        L = _ext.lib()
+        ws = wss[0]
+        _ext.check(L.lr_workspace_timing(ws.handle, 1))
+        reps = 10
+        pr = pairs[0]
+        nn_ms = ctypes.c_float(); rs_ms = ctypes.c_float(); ns = ctypes.c_int()
+        for _ in range(reps):
+            FR.register_pair_dev(pr["xyz0"], pr["xyz1"], pr["f0"], pr["f1"], params, out=outs[0], ws=ws, stream=streams[0].cuda_stream)
+            streams[0].synchronize()
+            _ext.check(L.lr_workspace_timing_read(ws.handle, ctypes.byref(nn_ms), ctypes.byref(rs_ms), ctypes.byref(ns)))
+        _ext.check(L.lr_workspace_timing(ws.handle, 0))
+        t_launch = nn_ms.value / max(ns.value, 1) * 1e-3
+        flop_pass = 2.0 * 32 * args.n * args.n                  # W_NN = 2 D N0 N1 per pair
+        launches_per_pair = 1 if args.mode == "no_filter" else 2  # forward + reverse NN are separate launches today
+        flop_launch = flop_pass / launches_per_pair            # algorithmic flops one launch accounts for
+        achieved = flop_launch / t_launch / 1e12
+        roof = {"bound": "mfma", "kernel": "nn_strip_kernel", "achieved": round(achieved, 3), "peak": MFMA_F32_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                "launch_ms": round(t_launch * 1e3, 4), "launches_per_pair": launches_per_pair,
+                "executed_tflops_per_launch": round(flop_pass / t_launch / 1e12, 3),
+                "ransac_gen_score_ms": round(rs_ms.value / max(ns.value, 1), 4)}
+
+    # ---- CPU baseline: the oracle port on the host cores, bounded sample (rank 0, N=1 only)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as orc
+        orc.build()
+        # time only the registration calls (synthetic generation excluded)
+        t_reg = 0.0
+        for k in range(args.cpu_pairs):
+            p = synth.make_pair(N=args.n, seed=51 + k)
+            t1 = time.perf_counter()
+            orc.register_pair(p["xyz0"], p["xyz1"], p["feats0"], p["feats1"], mode=args.mode, iters=args.iters, sample_size=3, seed=51)
+            t_reg += time.perf_counter() - t1
+        cpu = {"value": round(args.cpu_pairs / t_reg, 4), "unit": "pairs/s", "cores": orc.lib().orc_num_threads(), "kind": "port",
+               "sample": f"{args.cpu_pairs} pairs of the same workload (N={args.n}, {args.mode}, {args.iters} iters), oracle/oracle.c with OpenMP"}
+
+    if rank == 0:
+        total_pairs = world * args.pairs * args.steps
+        value = total_pairs / dt
+        line = {
+            "metric": "registration pairs/sec (30k-pt FCGF pairs, mutual-NN + 50k RANSAC iters + refit)",
+            "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"configs[1]: {args.n}-pt x32-d synthetic FCGF pair, --mode {args.mode} --iters {args.iters}, "
+                                   f"3-pt sampling + ELC + LS refit", "pairs_per_step_per_gpu": args.pairs,
+                       "pairs_in_flight_per_gpu": nstreams, "parallelism": f"pair-sharded x{world}"},
+            "recall_5deg_0.6m": round(recall, 4),
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        if cpu:
+            line["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

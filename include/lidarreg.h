@@ -1,0 +1,150 @@
+/*
+ * lidarreg.h -- C ABI of liblidarreg.so (hand-written HIP for gfx950 / MI355X).
+ *
+ * Drop-in boundary for the registration hot path of AmnonDrory/LidarRegistration.  Each entry point
+ * names the reference interface it replaces (paths relative to the reference tree).  Conventions:
+ *
+ *   - every data pointer is a caller-owned DEVICE pointer (e.g. torch tensor .data_ptr()), contiguous,
+ *     row-major; the library allocates nothing behind the caller's back except inside an explicit
+ *     lr_workspace;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all calls are asynchronous on
+ *     it and do not synchronise with the host;
+ *   - return value 0 = LR_OK, negative = error (lr_last_error() gives the text); nothing throws;
+ *   - 4x4 transforms are row-major float64, column-vector convention, cloud 0 -> cloud 1
+ *     (the reference's pygcransac binding returns the transpose, GC_RANSAC.py:55 -- not here);
+ *   - a workspace may be used by one stream at a time; use one workspace per in-flight pair.
+ */
+#ifndef LIDARREG_H
+#define LIDARREG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LR_API __attribute__((visibility("default")))
+
+enum { LR_OK = 0, LR_EINVAL = -1, LR_ENOMEM = -2, LR_EHIP = -3, LR_ESIZE = -4 };
+
+/* filter modes of FR(): Experiments/algorithms/FR.py:48-56 ("MNN" | "GPF" | "no_filter") */
+enum { LR_MODE_NO_FILTER = 0, LR_MODE_MNN = 1, LR_MODE_GPF = 2 };
+
+typedef struct lr_workspace lr_workspace;
+
+/* RANSAC knobs.  Replaces the parameter dict of GC_RANSAC.py:12-37 and the keyword arguments of
+ * FR.py:128-137, with explicit flags instead of the reference's sentinel overloading.            */
+typedef struct lr_ransac_params {
+    int32_t  sample_size;   /* 3 = GC-RANSAC minimal solver, 4 = FR.py:134 ransac_n                  */
+    int32_t  use_elc;       /* edge-length pre-check, similarity 0.9 (preemption_edge_length.h:82)    */
+    float    thr2;          /* squared inlier threshold; (2*voxel)^2 = 0.36 (FR.py:85,95)             */
+    int32_t  iters;         /* hypotheses 0..iters-1 are all evaluated (--iters, FR.py:65-67)         */
+    uint64_t seed;          /* Philox4x32-10 key; sample of hypothesis h = philox(seed, h)            */
+} lr_ransac_params;
+
+/* Written to device memory by lr_ransac / lr_register_pair. */
+typedef struct lr_ransac_result {
+    int64_t  best_h;        /* winning hypothesis id, -1 when none had an inlier                     */
+    uint32_t best_count;    /* its inlier count over the M correspondences                            */
+    uint32_t pad0;
+    uint64_t best_ssq;      /* sum over its inliers of (uint32)(d^2 * 2^20)                           */
+    int64_t  n_valid;       /* hypotheses that passed the pre-check and were scored                   */
+} lr_ransac_result;
+
+/* Per-pair result block of lr_register_pair (device memory, 336 bytes). */
+typedef struct lr_pair_result {
+    double   T[16];         /* final transform (after the LS refit when refit != 0)                   */
+    double   T_ransac[16];  /* winning minimal-sample model before the refit                          */
+    lr_ransac_result ransac;
+    int32_t  n_corr;        /* correspondences after filtering (num_pairs_filtered, FR.py:60)         */
+    int32_t  n_refit;       /* inliers used by the refit (FR.py:104-108)                              */
+    int32_t  n_nn_fixed;    /* NN rows/cols that needed the exact sqrt tie-break path                 */
+    int32_t  status;        /* 0 ok, 1 = no valid hypothesis (T = identity, GC_RANSAC.py:51-52)       */
+    int32_t  reserved[8];
+} lr_pair_result;
+
+typedef struct lr_pair_params {
+    int32_t  mode;          /* LR_MODE_*                                                             */
+    int32_t  refit;         /* 1: LS refit on the original NN pairs within thr (FR.py:99-111)         */
+    lr_ransac_params ransac;
+    /* GPF (matching.py:100-205), only read when mode == LR_MODE_GPF */
+    int32_t  gpf_grid_wid;  /* --GPF_grid_wid, default 10                                            */
+    int32_t  pad0;
+    double   gpf_factor;    /* --GPF_factor,   default 2.0 (a Python float in the reference)         */
+    double   refit_thr2;    /* fp64 squared threshold of the refit's inlier test, (2*0.3)**2 (FR.py:105) */
+} lr_pair_params;
+
+/* ---- library ------------------------------------------------------------------------------- */
+LR_API int         lr_version(void);
+LR_API const char *lr_last_error(void);
+
+/* Scratch for clouds up to (max_n0, max_n1) points x dim and up to max_iters hypotheses. */
+LR_API int    lr_workspace_create(lr_workspace **ws, int max_n0, int max_n1, int dim, int max_iters);
+LR_API int    lr_workspace_destroy(lr_workspace *ws);
+LR_API size_t lr_workspace_bytes(const lr_workspace *ws);
+
+/* ---- a1/a2: find_nn / find_2nn  (Experiments/algorithms/matching.py:6-65) ------------------------
+ * For every row of F0 [n0,dim] the nearest and second nearest row of F1 [n1,dim] under L2, first
+ * minimal value wins.  idx2/s1/s2 may be NULL.  s = sqrt(max(d2,1e-30)) as matching.py:30.        */
+LR_API int lr_nn_top2(lr_workspace *ws, const float *F0, int n0, const float *F1, int n1, int dim,
+                      int32_t *idx1, int32_t *idx2, float *s1, float *s2, void *stream);
+
+/* ---- a3-a5: nn_to_mutual / mark_best_buddies  (matching.py:67-87, 207-239) -----------------------
+ * Runs the reverse NN (F1 -> F0) and intersects: is_bb[i] = (rev[idx1[i]] == i).  The surviving
+ * pairs are written in ascending i (torch coalesce order) to out_idx0/out_idx1[/out_idx2]; their
+ * number to *n_out (device int32).  is_bb, out_* and idx2 may be NULL.                             */
+LR_API int lr_nn_to_mutual(lr_workspace *ws, const float *F0, int n0, const float *F1, int n1, int dim,
+                           const int32_t *idx1, const int32_t *idx2,
+                           uint8_t *is_bb, int32_t *out_idx0, int32_t *out_idx1, int32_t *out_idx2,
+                           int32_t *n_out, void *stream);
+
+/* ---- a6: calc_distance_ratio_in_feature_space  (matching.py:89-98) ------------------------------- */
+LR_API int lr_feat_ratio(const float *F0, const float *F1, int dim, int m,
+                         const int32_t *i0, const int32_t *i1, const int32_t *i2, float *out, void *stream);
+
+/* ---- a7: Grid_Prioritized_Filter, BB_first=False  (matching.py:100-205) --------------------------
+ * idx1/idx2 are the NN lists of all n0 rows; xyz0 [n0,3].  Kept pairs (ascending i) go to out_*,
+ * their count to *n_out (device), their score (norm_feat_dist, matching.py:124,134) to out_score. */
+LR_API int lr_gpf(lr_workspace *ws, const float *F0, int n0, const float *F1, int n1, int dim,
+                  const int32_t *idx1, const int32_t *idx2, const float *xyz0,
+                  int grid_wid, double factor,
+                  int32_t *out_idx0, int32_t *out_idx1, int32_t *out_idx2, float *out_score,
+                  int32_t *n_out, void *stream);
+
+/* ---- a10/a12: RANSAC over M correspondences src[i] <-> tgt[i]  ([M,3] float32 each) ---------------
+ * Replaces pygcransac.findRigidTransform(x1y1z1, x2y2z2, ...) (GC_RANSAC.py:46-49; native side
+ * gcransac_python.cpp:404-416) and o3d registration_ransac_based_on_correspondence (FR.py:128-137).
+ * m_dev, if not NULL, is a device int32 holding the live M (<= m).  Writes T_out[16] and *res.    */
+LR_API int lr_ransac(lr_workspace *ws, const float *src, const float *tgt, int m, const int32_t *m_dev,
+                     const lr_ransac_params *p, double *T_out, lr_ransac_result *res, void *stream);
+
+/* ---- a11: LS refit on the original NN pairs within thr of T_in  (FR.py:99-111) -------------------- */
+LR_API int lr_refit(lr_workspace *ws, const float *xyz0, int n0, const float *xyz1, const int32_t *idx1,
+                    const double *T_in, double thr2, double *T_out, int32_t *n_inliers, void *stream);
+
+/* ---- a13: least-squares rigid fit of n point pairs  (models/common.py:7-45) -------------------------
+ * P, Q [n,3] float64, optional weights w [n]; T_out[16].                                           */
+LR_API int lr_kabsch(const double *P, const double *Q, const double *w, int n, double *T_out, void *stream);
+
+/* ---- a9: FR() end to end on device  (Experiments/algorithms/FR.py:16-119) -------------------------
+ * NN -> filter (mode) -> RANSAC -> optional refit, one call, no host synchronisation.             */
+LR_API int lr_register_pair(lr_workspace *ws, const float *xyz0, const float *xyz1,
+                            const float *F0, const float *F1, int n0, int n1, int dim,
+                            const lr_pair_params *p, lr_pair_result *out, void *stream);
+
+/* Copies the correspondence lists of the last lr_register_pair on this workspace into caller-owned
+ * device buffers (any may be NULL): the NN lists over all n0 rows (FR.py's corres_idx1_orig / idx1_2nd_orig)
+ * and the filtered lists, of which the first out->n_corr entries are live (buffers sized n0).     */
+LR_API int lr_workspace_lists(lr_workspace *ws, int n0, int32_t *nn_idx1, int32_t *nn_idx2,
+                              int32_t *corr_idx0, int32_t *corr_idx1, void *stream);
+
+/* ---- measurement hook for bench.py: duration of the last NN distance kernel(s) on this workspace,
+ * from HIP events recorded on the launch stream.  Enable, run, synchronise, then read.            */
+LR_API int lr_workspace_timing(lr_workspace *ws, int enable);
+LR_API int lr_workspace_timing_read(lr_workspace *ws, float *nn_ms, float *ransac_ms, int *n_samples);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIDARREG_H */

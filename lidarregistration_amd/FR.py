@@ -1,0 +1,116 @@
+"""Drop-in for the reference's ``Experiments/algorithms/FR.py``: ``FR(A, B, A_feat, B_feat, args, T_gt)``.
+
+Same positional signature and 8-tuple as FR.py:16,119.  The whole pair (NN -> filter -> RANSAC ->
+refit) runs as ONE call into the C ABI (``lr_register_pair``) with no host synchronisation until the
+336-byte result block is read back.
+"""
+import ctypes
+from time import time
+
+import numpy as np
+import torch
+
+from . import _ext
+from .matching import _device, _f32, _stream, measure_inlier_ratio, workspace
+from .ransac import DEFAULT_SEED
+
+VOXEL_SIZE = 0.3            # FR.py:18
+MODES = {"MNN": _ext.LR_MODE_MNN, "MMN": _ext.LR_MODE_MNN,      # README.md:55 spells it MMN
+         "GPF": _ext.LR_MODE_GPF, "no_filter": _ext.LR_MODE_NO_FILTER}
+
+
+class PointCloud:
+    """Minimal stand-in for open3d.geometry.PointCloud (the harness reads .points / calls .transform)."""
+
+    def __init__(self, xyz):
+        self.points = np.asarray(xyz, np.float64)
+
+    def transform(self, T):
+        T = np.asarray(T, np.float64)
+        self.points = self.points @ T[:3, :3].T + T[:3, 3]
+        return self
+
+
+def pair_params(args):
+    """Translate the reference's argparse namespace (Experiments/test.py:294-313) into lr_pair_params."""
+    mode = getattr(args, "mode", "MNN")
+    assert mode in MODES, "unknown mode"                               # FR.py:56
+    codebase = getattr(args, "codebase", "GC")
+    assert codebase in ("GC", "open3D"), "unknown codebase"            # FR.py:113-114
+    iters = getattr(args, "iters", None)
+    iters = 500 * 10 ** 3 if iters is None else int(iters)            # FR.py:65-67
+    thr = 2 * VOXEL_SIZE
+    if codebase == "GC":
+        sample_size = 3
+        use_elc = getattr(args, "fast_rejection", "ELC") == "ELC"
+    else:
+        sample_size = int(getattr(args, "ransac_n", 4))                # FR.py:134
+        use_elc = True                                                 # FR.py:135 edge-length checker
+    rp = _ext.RansacParams(sample_size, int(use_elc), np.float32(thr * thr), iters, int(getattr(args, "seed", DEFAULT_SEED)))
+    p = _ext.PairParams()
+    p.mode = MODES[mode]
+    p.refit = int(getattr(args, "refit", True))
+    p.ransac = rp
+    p.gpf_grid_wid = int(getattr(args, "GPF_grid_wid", 10))
+    p.gpf_factor = float(getattr(args, "GPF_factor", 2.0))
+    p.refit_thr2 = thr ** 2                                            # FR.py:105, fp64
+    return p
+
+
+def register_pair_dev(xyz0, xyz1, feats0, feats1, params, out=None, ws=None, stream=None):
+    """Enqueue one pair; returns the device result buffer (uint8[336]).  No synchronisation."""
+    n0, n1, d = feats0.shape[0], feats1.shape[0], feats0.shape[1]
+    if ws is None:
+        ws = workspace(n0, n1, params.ransac.iters, d)
+    if out is None:
+        out = torch.empty(ctypes.sizeof(_ext.PairResult), dtype=torch.uint8, device=feats0.device)
+    _ext.check(_ext.lib().lr_register_pair(ws.handle, xyz0.data_ptr(), xyz1.data_ptr(), feats0.data_ptr(), feats1.data_ptr(),
+                                            n0, n1, d, ctypes.byref(params), out.data_ptr(),
+                                            _stream() if stream is None else stream))
+    return out
+
+
+def read_result(out):
+    """Device result block -> _ext.PairResult (synchronises on the copy)."""
+    return _ext.PairResult.from_buffer_copy(out.cpu().numpy().tobytes())
+
+
+def pair_lists(ws, n0, n_corr, dev):
+    """(nn_idx1 [n0], corr_idx0 [n_corr], corr_idx1 [n_corr]) numpy arrays of the last pair on ws."""
+    nn1 = torch.empty(n0, dtype=torch.int32, device=dev)
+    c0 = torch.empty(n0, dtype=torch.int32, device=dev)
+    c1 = torch.empty(n0, dtype=torch.int32, device=dev)
+    _ext.check(_ext.lib().lr_workspace_lists(ws.handle, n0, nn1.data_ptr(), None, c0.data_ptr(), c1.data_ptr(), _stream()))
+    return nn1.cpu().numpy(), c0[:n_corr].cpu().numpy(), c1[:n_corr].cpu().numpy()
+
+
+def FR(A, B, A_feat, B_feat, args, T_gt):
+    """FR.py:16-119.  Returns (T, elapsed_time, pcd0, pcd1, num_pairs_init, inlier_ratio_init,
+    num_pairs_filtered, inlier_ratio_filtered)."""
+    xyz0_np = torch.as_tensor(A).detach().cpu().numpy().astype(np.float64)
+    xyz1_np = torch.as_tensor(B).detach().cpu().numpy().astype(np.float64)
+    pcd0, pcd1 = PointCloud(xyz0_np), PointCloud(xyz1_np)
+    dev = _device()
+    xyz0, xyz1 = _f32(A), _f32(B)
+    f0, f1 = _f32(A_feat), _f32(B_feat)
+    params = pair_params(args)
+    n0, n1 = f0.shape[0], f1.shape[0]
+    ws = workspace(n0, n1, params.ransac.iters, f0.shape[1])
+
+    torch.cuda.synchronize(dev)
+    start_time = time()
+    out = register_pair_dev(xyz0, xyz1, f0, f1, params, ws=ws)
+    r = read_result(out)                                   # the only device->host sync of the pair
+    elapsed_time = time() - start_time
+
+    T = np.array(r.T[:], np.float64).reshape(4, 4)
+    if r.status != 0:
+        T = np.eye(4)                                      # GC_RANSAC.py:51-52: failure -> identity
+
+    # statistics outside the timed region, as FR.py:43,61
+    idx1, ci0, ci1 = pair_lists(ws, n0, int(r.n_corr), dev)
+    num_pairs_init = n0
+    inlier_ratio_init = measure_inlier_ratio(np.arange(n0), idx1, pcd0, pcd1, T_gt, VOXEL_SIZE)
+    num_pairs_filtered = int(r.n_corr)
+    inlier_ratio_filtered = measure_inlier_ratio(ci0, ci1, pcd0, pcd1, T_gt, VOXEL_SIZE)
+    return T, elapsed_time, pcd0, pcd1, num_pairs_init, inlier_ratio_init, num_pairs_filtered, inlier_ratio_filtered

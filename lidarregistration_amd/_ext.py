@@ -1,0 +1,130 @@
+"""ctypes binding of liblidarreg.so (the C ABI in include/lidarreg.h).
+
+There is no fallback: if the library is missing or a call fails, an exception is raised.  PyTorch
+is only used by the callers for device memory and streams; no torch type crosses this boundary.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "liblidarreg.so")
+
+LR_MODE_NO_FILTER, LR_MODE_MNN, LR_MODE_GPF = 0, 1, 2
+
+SYMBOLS = [
+    "lr_version", "lr_last_error", "lr_workspace_create", "lr_workspace_destroy", "lr_workspace_bytes",
+    "lr_nn_top2", "lr_nn_to_mutual", "lr_feat_ratio", "lr_gpf", "lr_ransac", "lr_refit", "lr_kabsch",
+    "lr_register_pair", "lr_workspace_lists", "lr_workspace_timing", "lr_workspace_timing_read",
+]
+
+
+class LidarRegError(RuntimeError):
+    pass
+
+
+class RansacParams(ctypes.Structure):
+    _fields_ = [("sample_size", ctypes.c_int32), ("use_elc", ctypes.c_int32), ("thr2", ctypes.c_float),
+                ("iters", ctypes.c_int32), ("seed", ctypes.c_uint64)]
+
+
+class RansacResult(ctypes.Structure):
+    _fields_ = [("best_h", ctypes.c_int64), ("best_count", ctypes.c_uint32), ("pad0", ctypes.c_uint32),
+                ("best_ssq", ctypes.c_uint64), ("n_valid", ctypes.c_int64)]
+
+
+class PairResult(ctypes.Structure):
+    _fields_ = [("T", ctypes.c_double * 16), ("T_ransac", ctypes.c_double * 16), ("ransac", RansacResult),
+                ("n_corr", ctypes.c_int32), ("n_refit", ctypes.c_int32), ("n_nn_fixed", ctypes.c_int32),
+                ("status", ctypes.c_int32), ("reserved", ctypes.c_int32 * 8)]
+
+
+class PairParams(ctypes.Structure):
+    _fields_ = [("mode", ctypes.c_int32), ("refit", ctypes.c_int32), ("ransac", RansacParams),
+                ("gpf_grid_wid", ctypes.c_int32), ("pad0", ctypes.c_int32), ("gpf_factor", ctypes.c_double),
+                ("refit_thr2", ctypes.c_double)]
+
+
+assert ctypes.sizeof(PairResult) == 336, ctypes.sizeof(PairResult)
+
+_lib = None
+
+
+def build(force=False):
+    """hipcc --offload-arch=gfx950 -> csrc/liblidarreg.so (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.join(_HERE, "..", "include", "lidarreg.h"))
+    stale = not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", CSRC, "-s", "-j4", "liblidarreg.so"])
+    return LIB_PATH
+
+
+def lib():
+    """Load the HIP library; raises LidarRegError when it is not there."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LidarRegError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        try:
+            L = ctypes.CDLL(LIB_PATH)
+        except OSError as e:
+            raise LidarRegError(f"cannot load {LIB_PATH}: {e}") from e
+        L.lr_last_error.restype = ctypes.c_char_p
+        L.lr_workspace_bytes.restype = ctypes.c_size_t
+        L.lr_workspace_bytes.argtypes = [ctypes.c_void_p]
+        L.lr_workspace_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        L.lr_workspace_destroy.argtypes = [ctypes.c_void_p]
+        vp, ci = ctypes.c_void_p, ctypes.c_int
+        L.lr_nn_top2.argtypes = [vp, vp, ci, vp, ci, ci, vp, vp, vp, vp, vp]
+        L.lr_nn_to_mutual.argtypes = [vp, vp, ci, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.lr_feat_ratio.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp, vp]
+        L.lr_gpf.argtypes = [vp, vp, ci, vp, ci, ci, vp, vp, vp, ci, ctypes.c_double, vp, vp, vp, vp, vp, vp]
+        L.lr_ransac.argtypes = [vp, vp, vp, ci, vp, ctypes.POINTER(RansacParams), vp, vp, vp]
+        L.lr_refit.argtypes = [vp, vp, ci, vp, vp, vp, ctypes.c_double, vp, vp, vp]
+        L.lr_kabsch.argtypes = [vp, vp, vp, ci, vp, vp]
+        L.lr_register_pair.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ctypes.POINTER(PairParams), vp, vp]
+        L.lr_workspace_lists.argtypes = [vp, ci, vp, vp, vp, vp, vp]
+        L.lr_workspace_timing.argtypes = [vp, ci]
+        L.lr_workspace_timing_read.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ci)]
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise LidarRegError(f"liblidarreg error {rc}: {lib().lr_last_error().decode()}")
+
+
+class Workspace:
+    """Owns one lr_workspace (device scratch for one in-flight pair)."""
+
+    def __init__(self, max_n0, max_n1, dim=32, max_iters=50000):
+        self._h = ctypes.c_void_p()
+        self.max_n0, self.max_n1, self.dim, self.max_iters = int(max_n0), int(max_n1), int(dim), int(max_iters)
+        check(lib().lr_workspace_create(ctypes.byref(self._h), self.max_n0, self.max_n1, self.dim, self.max_iters))
+
+    @property
+    def handle(self):
+        return self._h
+
+    def fits(self, n0, n1, iters):
+        return n0 <= self.max_n0 and n1 <= self.max_n1 and iters <= self.max_iters
+
+    @property
+    def nbytes(self):
+        return lib().lr_workspace_bytes(self._h)
+
+    def close(self):
+        if self._h:
+            lib().lr_workspace_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,282 @@
+// C-ABI entry points of liblidarreg.so: workspace management, the per-function operators that mirror
+// the reference's matching.py / GC_RANSAC.py helpers, and the fused per-pair pipeline behind FR().
+#include "lr_internal.h"
+#include <stdarg.h>
+#include <string.h>
+#include <new>
+
+static thread_local char g_err[512] = "";
+
+void lr_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" int lr_version(void) { return 100; }
+extern "C" const char *lr_last_error(void) { return g_err; }
+
+// ------------------------------------------------------------------ workspace
+namespace {
+struct Carver {
+    size_t off = 0;
+    char *base = nullptr;
+    template <class T> T *take(size_t count)
+    {
+        off = (off + 255) & ~size_t(255);
+        T *p = base ? reinterpret_cast<T *>(base + off) : nullptr;
+        off += sizeof(T) * count;
+        return p;
+    }
+};
+
+void carve(lr_workspace *ws, Carver &c)
+{
+    const size_t n0 = ws->max_n0, n1 = ws->max_n1, n = ws->max_n, it = ws->max_iters;
+    ws->Fp0 = c.take<float>(n0 * 32); ws->Fp1 = c.take<float>(n1 * 32);
+    ws->nrm0 = c.take<float>(n0); ws->nrm1 = c.take<float>(n1);
+    ws->pb1 = c.take<float>(n * LR_NN_MAX_STRIPS); ws->pb2 = c.take<float>(n * LR_NN_MAX_STRIPS);
+    ws->pb3 = c.take<float>(n * LR_NN_MAX_STRIPS);
+    ws->pi1 = c.take<int32_t>(n * LR_NN_MAX_STRIPS); ws->pi2 = c.take<int32_t>(n * LR_NN_MAX_STRIPS);
+    ws->fix_list = c.take<int32_t>(n);
+    ws->counters = c.take<int32_t>(LR_CNT_COUNT);
+    ws->nn_idx1 = c.take<int32_t>(n0); ws->nn_idx2 = c.take<int32_t>(n0);
+    ws->nn_s1 = c.take<float>(n0); ws->nn_s2 = c.take<float>(n0);
+    ws->rev_idx1 = c.take<int32_t>(n1);
+    ws->is_bb = c.take<uint8_t>(n0);
+    ws->corr_idx0 = c.take<int32_t>(n0); ws->corr_idx1 = c.take<int32_t>(n0); ws->corr_idx2 = c.take<int32_t>(n0);
+    ws->corr_score = c.take<float>(n0);
+    ws->ratio = c.take<float>(n0);
+    ws->cell = c.take<int32_t>(n0); ws->cell_sorted = c.take<int32_t>(n0);
+    ws->gpf_quota = c.take<double>(LR_GPF_MAX_CELLS);
+    ws->gpf_cells = c.take<int32_t>(3 * (LR_GPF_MAX_CELLS + 8));
+    ws->gpf_keep = c.take<uint8_t>(n0);
+    ws->gpf_f = c.take<float>(8);
+    ws->corr8 = c.take<float>(n0 * 8);
+    ws->models = c.take<float>(it * 12);
+    ws->model_h = c.take<int32_t>(it);
+    ws->score_cnt = c.take<uint32_t>(it);
+    ws->score_ssq = c.take<unsigned long long>(it);
+    ws->refit_part = c.take<double>((n0 / 256 + 2) * 16);
+    ws->res_tmp = c.take<lr_ransac_result>(1);
+    ws->T_tmp = c.take<double>(32);
+}
+}  // namespace
+
+extern "C" int lr_workspace_create(lr_workspace **out, int max_n0, int max_n1, int dim, int max_iters)
+{
+    LR_REQUIRE(out, LR_EINVAL, "lr_workspace_create: null output");
+    LR_REQUIRE(max_n0 > 0 && max_n1 > 0 && max_iters >= 0, LR_EINVAL, "lr_workspace_create: sizes must be positive");
+    LR_REQUIRE(dim == LR_FEAT_DIM, LR_EINVAL, "lr_workspace_create: only 32-d descriptors (FCGF) are supported");
+    lr_workspace *ws = new (std::nothrow) lr_workspace();
+    LR_REQUIRE(ws, LR_ENOMEM, "lr_workspace_create: host allocation failed");
+    memset(ws, 0, sizeof(*ws));
+    ws->max_n0 = max_n0; ws->max_n1 = max_n1; ws->max_n = max_n0 > max_n1 ? max_n0 : max_n1;
+    ws->dim = dim; ws->max_iters = max_iters > 0 ? max_iters : 1;
+    Carver sizing;
+    carve(ws, sizing);
+    ws->bytes = sizing.off + 256;
+    hipError_t e = hipMalloc(&ws->base, ws->bytes);
+    if (e != hipSuccess) {
+        lr_set_error("lr_workspace_create: hipMalloc(%zu) -> %s", ws->bytes, hipGetErrorString(e));
+        delete ws;
+        return e == hipErrorOutOfMemory ? LR_ENOMEM : LR_EHIP;
+    }
+    Carver real;
+    real.base = ws->base;
+    carve(ws, real);
+    if (hipMemset(ws->base, 0, ws->bytes) != hipSuccess) { (void)hipFree(ws->base); delete ws; lr_set_error("lr_workspace_create: hipMemset failed"); return LR_EHIP; }
+    for (int k = 0; k < 4; ++k)
+        if (hipEventCreate(&ws->ev[k]) != hipSuccess) { (void)hipFree(ws->base); delete ws; lr_set_error("lr_workspace_create: hipEventCreate failed"); return LR_EHIP; }
+    *out = ws;
+    return LR_OK;
+}
+
+extern "C" int lr_workspace_destroy(lr_workspace *ws)
+{
+    if (!ws) return LR_OK;
+    for (int k = 0; k < 4; ++k) (void)hipEventDestroy(ws->ev[k]);
+    (void)hipFree(ws->base);
+    delete ws;
+    return LR_OK;
+}
+
+extern "C" size_t lr_workspace_bytes(const lr_workspace *ws) { return ws ? ws->bytes : 0; }
+
+extern "C" int lr_workspace_lists(lr_workspace *ws, int n0, int32_t *nn_idx1, int32_t *nn_idx2,
+                                  int32_t *corr_idx0, int32_t *corr_idx1, void *stream)
+{
+    LR_REQUIRE(ws, LR_EINVAL, "lr_workspace_lists: null workspace");
+    LR_REQUIRE(n0 > 0 && n0 <= ws->max_n0, LR_ESIZE, "lr_workspace_lists: n0 exceeds the workspace");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t nb = sizeof(int32_t) * (size_t)n0;
+    if (nn_idx1) LR_HIP(hipMemcpyAsync(nn_idx1, ws->nn_idx1, nb, hipMemcpyDeviceToDevice, st));
+    if (nn_idx2) LR_HIP(hipMemcpyAsync(nn_idx2, ws->nn_idx2, nb, hipMemcpyDeviceToDevice, st));
+    if (corr_idx0) LR_HIP(hipMemcpyAsync(corr_idx0, ws->corr_idx0, nb, hipMemcpyDeviceToDevice, st));
+    if (corr_idx1) LR_HIP(hipMemcpyAsync(corr_idx1, ws->corr_idx1, nb, hipMemcpyDeviceToDevice, st));
+    return LR_OK;
+}
+
+extern "C" int lr_workspace_timing(lr_workspace *ws, int enable)
+{
+    LR_REQUIRE(ws, LR_EINVAL, "lr_workspace_timing: null workspace");
+    ws->timing = enable; ws->ev_pending = 0; ws->nn_ms_acc = 0; ws->ransac_ms_acc = 0; ws->n_samples = 0;
+    return LR_OK;
+}
+
+// Reads the events of the last timed pair; the caller has synchronised the stream.
+extern "C" int lr_workspace_timing_read(lr_workspace *ws, float *nn_ms, float *ransac_ms, int *n_samples)
+{
+    LR_REQUIRE(ws, LR_EINVAL, "lr_workspace_timing_read: null workspace");
+    if (ws->ev_pending >= 1) {
+        float ms = 0;
+        LR_HIP(hipEventElapsedTime(&ms, ws->ev[0], ws->ev[1]));
+        ws->nn_ms_acc += ms;
+        if (ws->ev_pending >= 2) { LR_HIP(hipEventElapsedTime(&ms, ws->ev[2], ws->ev[3])); ws->ransac_ms_acc += ms; }
+        ws->n_samples += 1;
+        ws->ev_pending = 0;
+    }
+    if (nn_ms) *nn_ms = ws->nn_ms_acc;
+    if (ransac_ms) *ransac_ms = ws->ransac_ms_acc;
+    if (n_samples) *n_samples = ws->n_samples;
+    return LR_OK;
+}
+
+// ------------------------------------------------------------------ checks
+static int check_nn_args(const lr_workspace *ws, const void *F0, int n0, const void *F1, int n1, int dim, const char *who)
+{
+    if (!ws || !F0 || !F1) { lr_set_error("%s: null pointer", who); return LR_EINVAL; }
+    if (dim != ws->dim) { lr_set_error("%s: dim %d != workspace dim %d", who, dim, ws->dim); return LR_EINVAL; }
+    if (n0 <= 0 || n1 <= 0) { lr_set_error("%s: empty cloud (n0=%d, n1=%d)", who, n0, n1); return LR_EINVAL; }
+    if (n0 > ws->max_n0 || n1 > ws->max_n1) { lr_set_error("%s: (%d,%d) exceeds workspace (%d,%d)", who, n0, n1, ws->max_n0, ws->max_n1); return LR_ESIZE; }
+    return LR_OK;
+}
+
+#define LR_TRY(x) do { int rc_ = (x); if (rc_ != LR_OK) return rc_; } while (0)
+
+// ------------------------------------------------------------------ a1/a2
+extern "C" int lr_nn_top2(lr_workspace *ws, const float *F0, int n0, const float *F1, int n1, int dim,
+                          int32_t *idx1, int32_t *idx2, float *s1, float *s2, void *stream)
+{
+    LR_TRY(check_nn_args(ws, F0, n0, F1, n1, dim, "lr_nn_top2"));
+    LR_REQUIRE(idx1, LR_EINVAL, "lr_nn_top2: idx1 is required");
+    hipStream_t st = (hipStream_t)stream;
+    LR_TRY(lr_nn_prep(ws, F0, n0, ws->Fp0, ws->nrm0, st));
+    LR_TRY(lr_nn_prep(ws, F1, n1, ws->Fp1, ws->nrm1, st));
+    return lr_nn_run(ws, ws->Fp0, ws->nrm0, n0, ws->Fp1, ws->nrm1, n1, idx1, idx2, s1, s2, st);
+}
+
+// ------------------------------------------------------------------ a3-a5
+extern "C" int lr_nn_to_mutual(lr_workspace *ws, const float *F0, int n0, const float *F1, int n1, int dim,
+                               const int32_t *idx1, const int32_t *idx2, uint8_t *is_bb,
+                               int32_t *o0, int32_t *o1, int32_t *o2, int32_t *n_out, void *stream)
+{
+    LR_TRY(check_nn_args(ws, F0, n0, F1, n1, dim, "lr_nn_to_mutual"));
+    LR_REQUIRE(idx1, LR_EINVAL, "lr_nn_to_mutual: idx1 is required");
+    hipStream_t st = (hipStream_t)stream;
+    LR_TRY(lr_nn_prep(ws, F0, n0, ws->Fp0, ws->nrm0, st));
+    LR_TRY(lr_nn_prep(ws, F1, n1, ws->Fp1, ws->nrm1, st));
+    // reverse direction: every row of F1 against all of F0 (the reference restricts it to the unique
+    // forward targets, matching.py:224-225; rows that are nobody's target never enter the intersection)
+    LR_TRY(lr_nn_run(ws, ws->Fp1, ws->nrm1, n1, ws->Fp0, ws->nrm0, n0, ws->rev_idx1, nullptr, nullptr, nullptr, st));
+    return lr_mutual_run(ws, n0, idx1, idx2, ws->rev_idx1, is_bb, o0, o1, o2, n_out, st);
+}
+
+// ------------------------------------------------------------------ a7
+extern "C" int lr_gpf(lr_workspace *ws, const float *F0, int n0, const float *F1, int n1, int dim,
+                      const int32_t *idx1, const int32_t *idx2, const float *xyz0, int grid_wid, double factor,
+                      int32_t *o0, int32_t *o1, int32_t *o2, float *oscore, int32_t *n_out, void *stream)
+{
+    LR_TRY(check_nn_args(ws, F0, n0, F1, n1, dim, "lr_gpf"));
+    LR_REQUIRE(idx1 && idx2 && xyz0 && o0 && o1, LR_EINVAL, "lr_gpf: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    LR_TRY(lr_nn_prep(ws, F0, n0, ws->Fp0, ws->nrm0, st));
+    LR_TRY(lr_nn_prep(ws, F1, n1, ws->Fp1, ws->nrm1, st));
+    LR_TRY(lr_nn_run(ws, ws->Fp1, ws->nrm1, n1, ws->Fp0, ws->nrm0, n0, ws->rev_idx1, nullptr, nullptr, nullptr, st));
+    LR_TRY(lr_mutual_run(ws, n0, idx1, nullptr, ws->rev_idx1, ws->is_bb, nullptr, nullptr, nullptr, nullptr, st));
+    return lr_gpf_run(ws, F0, n0, F1, dim, idx1, idx2, ws->is_bb, xyz0, grid_wid, factor, o0, o1, o2, oscore, n_out, st);
+}
+
+// ------------------------------------------------------------------ a10/a12
+extern "C" int lr_ransac(lr_workspace *ws, const float *src, const float *tgt, int m, const int32_t *m_dev,
+                         const lr_ransac_params *p, double *T_out, lr_ransac_result *res, void *stream)
+{
+    LR_REQUIRE(ws && src && tgt && p && T_out && res, LR_EINVAL, "lr_ransac: null pointer");
+    LR_REQUIRE(m >= 0 && m <= ws->max_n0, LR_ESIZE, "lr_ransac: m exceeds the workspace");
+    hipStream_t st = (hipStream_t)stream;
+    LR_TRY(lr_pack_corr(src, tgt, nullptr, nullptr, m, m_dev, ws->corr8, st));
+    return lr_ransac_run(ws, ws->corr8, m, m_dev, p, T_out, res, st);
+}
+
+// ------------------------------------------------------------------ a11
+extern "C" int lr_refit(lr_workspace *ws, const float *xyz0, int n0, const float *xyz1, const int32_t *idx1,
+                        const double *T_in, double thr2, double *T_out, int32_t *n_inl, void *stream)
+{
+    LR_REQUIRE(ws && xyz0 && xyz1 && idx1 && T_in && T_out, LR_EINVAL, "lr_refit: null pointer");
+    LR_REQUIRE(n0 > 0 && n0 <= ws->max_n0, LR_ESIZE, "lr_refit: n0 exceeds the workspace");
+    return lr_refit_run(ws, xyz0, n0, xyz1, idx1, T_in, thr2, T_out, n_inl, nullptr, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------ a9: the whole pair
+__global__ void pair_result_kernel(const double *__restrict__ T_ransac, const double *__restrict__ T_final,
+                                   const lr_ransac_result *__restrict__ rr, const int32_t *__restrict__ counters,
+                                   const int32_t *__restrict__ n_refit, lr_pair_result *__restrict__ out)
+{
+    const int k = threadIdx.x;
+    if (k < 16) { out->T[k] = T_final[k]; out->T_ransac[k] = T_ransac[k]; }
+    if (k == 0) {
+        out->ransac = *rr;
+        out->n_corr = counters[LR_CNT_NCORR];
+        out->n_refit = n_refit ? *n_refit : 0;
+        out->n_nn_fixed = counters[LR_CNT_FIX_TOTAL];
+        out->status = rr->best_h < 0 ? 1 : 0;
+        for (int q = 0; q < 8; ++q) out->reserved[q] = 0;
+    }
+}
+
+extern "C" int lr_register_pair(lr_workspace *ws, const float *xyz0, const float *xyz1, const float *F0, const float *F1,
+                                int n0, int n1, int dim, const lr_pair_params *p, lr_pair_result *out, void *stream)
+{
+    LR_TRY(check_nn_args(ws, F0, n0, F1, n1, dim, "lr_register_pair"));
+    LR_REQUIRE(xyz0 && xyz1 && p && out, LR_EINVAL, "lr_register_pair: null pointer");
+    LR_REQUIRE(p->mode == LR_MODE_NO_FILTER || p->mode == LR_MODE_MNN || p->mode == LR_MODE_GPF, LR_EINVAL,
+               "lr_register_pair: unknown mode");
+    hipStream_t st = (hipStream_t)stream;
+    int32_t *m_dev = ws->counters + LR_CNT_NCORR;
+    int32_t *n_refit = ws->counters + LR_CNT_COUNT - 2;
+    LR_HIP(hipMemsetAsync(ws->counters, 0, sizeof(int32_t) * LR_CNT_COUNT, st));
+    // 1. coarse correspondences (FR.py:38): first + second NN of every cloud-0 descriptor
+    LR_TRY(lr_nn_prep(ws, F0, n0, ws->Fp0, ws->nrm0, st));
+    LR_TRY(lr_nn_prep(ws, F1, n1, ws->Fp1, ws->nrm1, st));
+    LR_TRY(lr_nn_run(ws, ws->Fp0, ws->nrm0, n0, ws->Fp1, ws->nrm1, n1, ws->nn_idx1, ws->nn_idx2, ws->nn_s1, ws->nn_s2, st));
+    // 2. filter (FR.py:48-56)
+    if (p->mode == LR_MODE_NO_FILTER) {
+        LR_TRY(lr_identity_corr(ws, n0, ws->nn_idx1, ws->nn_idx2, ws->corr_idx0, ws->corr_idx1, ws->corr_idx2, m_dev, st));
+    } else {
+        LR_TRY(lr_nn_run(ws, ws->Fp1, ws->nrm1, n1, ws->Fp0, ws->nrm0, n0, ws->rev_idx1, nullptr, nullptr, nullptr, st));
+        if (p->mode == LR_MODE_MNN) {
+            LR_TRY(lr_mutual_run(ws, n0, ws->nn_idx1, ws->nn_idx2, ws->rev_idx1, ws->is_bb, ws->corr_idx0, ws->corr_idx1,
+                                 ws->corr_idx2, m_dev, st));
+        } else {
+            LR_TRY(lr_mutual_run(ws, n0, ws->nn_idx1, nullptr, ws->rev_idx1, ws->is_bb, nullptr, nullptr, nullptr, nullptr, st));
+            LR_TRY(lr_gpf_run(ws, F0, n0, F1, dim, ws->nn_idx1, ws->nn_idx2, ws->is_bb, xyz0, p->gpf_grid_wid, p->gpf_factor,
+                              ws->corr_idx0, ws->corr_idx1, ws->corr_idx2, ws->corr_score, m_dev, st));
+        }
+    }
+    // 3. RANSAC on the surviving pairs (FR.py:70-97)
+    LR_TRY(lr_pack_corr(xyz0, xyz1, ws->corr_idx0, ws->corr_idx1, n0, m_dev, ws->corr8, st));
+    LR_TRY(lr_ransac_run(ws, ws->corr8, n0, m_dev, &p->ransac, ws->T_tmp, ws->res_tmp, st));
+    // 4. LS refit over the original NN pairs (FR.py:99-111)
+    const double *T_final = ws->T_tmp;
+    if (p->refit) {
+        LR_TRY(lr_refit_run(ws, xyz0, n0, xyz1, ws->nn_idx1, ws->T_tmp, p->refit_thr2,
+                            ws->T_tmp + 16, n_refit, ws->res_tmp, st));
+        T_final = ws->T_tmp + 16;
+    }
+    hipLaunchKernelGGL(pair_result_kernel, dim3(1), dim3(64), 0, st, ws->T_tmp, T_final, ws->res_tmp, ws->counters,
+                       p->refit ? n_refit : (const int32_t *)nullptr, out);
+    LR_LAUNCH_CHECK();
+    return LR_OK;
+}

@@ -1,0 +1,110 @@
+// Internal declarations shared by the translation units of liblidarreg.so (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/lidarreg.h"
+
+void lr_set_error(const char *fmt, ...);
+
+#define LR_HIP(call)                                                                      \
+    do {                                                                                  \
+        hipError_t e_ = (call);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            lr_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+            return LR_EHIP;                                                               \
+        }                                                                                 \
+    } while (0)
+
+#define LR_LAUNCH_CHECK() LR_HIP(hipGetLastError())
+
+#define LR_REQUIRE(cond, code, msg)                 \
+    do {                                            \
+        if (!(cond)) { lr_set_error("%s", msg); return code; } \
+    } while (0)
+
+static inline int lr_cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// Column strips of the NN distance kernel: each wave owns 32 query rows x one strip.
+#define LR_NN_MAX_STRIPS 8
+#define LR_FEAT_DIM 32
+
+// One wave per block in the scoring kernel; this many blocks are launched and map themselves onto
+// (hypothesis group, correspondence chunk) from the live counts on device.
+#define LR_SCORE_BLOCKS 8192
+#define LR_GPF_MAX_CELLS 4096
+
+struct lr_workspace {
+    int max_n0, max_n1, max_n, dim, max_iters;
+    size_t bytes;
+    char *base;                  // one hipMalloc
+    // --- NN (both directions share these) ---
+    float *Fp0, *Fp1;            // [n,32] de-interleaved copies (even k | odd k)
+    float *nrm0, *nrm1;          // row norms
+    float *pb1, *pb2, *pb3;      // partial top-3 values [strips][max_n]
+    int32_t *pi1, *pi2;          // partial top-2 indices
+    int32_t *fix_list;           // rows needing the exact tie-break path [max_n]
+    int32_t *counters;           // small int block, see LR_CNT_*
+    // --- per-pair lists ---
+    int32_t *nn_idx1, *nn_idx2;  // forward NN over n0 rows
+    float *nn_s1, *nn_s2;
+    int32_t *rev_idx1;           // reverse NN over n1 rows
+    uint8_t *is_bb;
+    int32_t *corr_idx0, *corr_idx1, *corr_idx2;   // filtered lists [max_n0]
+    float *corr_score;
+    float *ratio;                // GPF: ratio / normalised score over n0
+    int32_t *cell;               // GPF: cell id per pair
+    int32_t *cell_sorted;        // GPF: pair ids bucketed by cell
+    double *gpf_quota;           // GPF: per-cell quota [LR_GPF_MAX_CELLS]
+    int32_t *gpf_cells;          // GPF: cell_count | cell_fill | cell_off, each [LR_GPF_MAX_CELLS + 8]
+    uint8_t *gpf_keep;           // GPF: keep mask [max_n0]
+    float *gpf_f;                // GPF: min/max scratch
+    float *corr8;                // packed correspondences [max_n0][8] = px py pz qx qy qz 0 0
+    // --- RANSAC ---
+    float *models;               // [max_iters][12] fp32 R|t rows of hypotheses that passed the pre-check
+    int32_t *model_h;            // [max_iters] their hypothesis ids
+    uint32_t *score_cnt;         // [max_iters]
+    unsigned long long *score_ssq; // [max_iters]
+    double *refit_part;          // [blocks][16] moment partials
+    lr_ransac_result *res_tmp;
+    double *T_tmp;               // [32]
+    // --- timing hook ---
+    int timing;
+    hipEvent_t ev[4];
+    float nn_ms_acc, ransac_ms_acc;
+    int n_samples;
+    int ev_pending;
+};
+
+enum {
+    LR_CNT_FIX = 0,      // number of rows in fix_list
+    LR_CNT_FIX_TOTAL,    // running total over the pair (stats)
+    LR_CNT_NCORR,        // live M
+    LR_CNT_NVALID,       // hypotheses appended to models[]
+    LR_CNT_NBB,          // best buddies
+    LR_CNT_COUNT = 16
+};
+
+// lr_nn.hip
+int lr_nn_run(lr_workspace *ws, const float *Fa, const float *nrma, int na, const float *Fb, const float *nrmb, int nb,
+              int32_t *idx1, int32_t *idx2, float *s1, float *s2, hipStream_t st);
+int lr_nn_prep(lr_workspace *ws, const float *F, int n, float *Fp, float *nrm, hipStream_t st);
+
+// lr_filter.hip
+int lr_mutual_run(lr_workspace *ws, int n0, const int32_t *idx1, const int32_t *idx2, const int32_t *rev,
+                  uint8_t *is_bb, int32_t *o0, int32_t *o1, int32_t *o2, int32_t *n_out, hipStream_t st);
+int lr_identity_corr(lr_workspace *ws, int n0, const int32_t *idx1, const int32_t *idx2,
+                     int32_t *o0, int32_t *o1, int32_t *o2, int32_t *n_out, hipStream_t st);
+int lr_pack_corr(const float *xyz0, const float *xyz1, const int32_t *i0, const int32_t *i1, int m_max,
+                 const int32_t *m_dev, float *corr8, hipStream_t st);
+int lr_gpf_run(lr_workspace *ws, const float *F0, int n0, const float *F1, int dim,
+               const int32_t *idx1, const int32_t *idx2, const uint8_t *is_bb, const float *xyz0,
+               int grid_wid, double factor, int32_t *o0, int32_t *o1, int32_t *o2, float *oscore,
+               int32_t *n_out, hipStream_t st);
+
+// lr_ransac.hip
+int lr_ransac_run(lr_workspace *ws, const float *corr8, int m_max, const int32_t *m_dev, const lr_ransac_params *p,
+                  double *T_out, lr_ransac_result *res, hipStream_t st);
+int lr_refit_run(lr_workspace *ws, const float *xyz0, int n0, const float *xyz1, const int32_t *idx1,
+                 const double *T_in, double thr2, double *T_out, int32_t *n_inl, const lr_ransac_result *gate,
+                 hipStream_t st);

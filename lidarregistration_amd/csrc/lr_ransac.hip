@@ -1,0 +1,490 @@
+// RANSAC hypothesis generation + inlier scoring + Kabsch fit + LS refit on gfx950.
+//
+// Replaces the third-party loops behind Experiments/algorithms/FR.py:122-139 (Open3D
+// registration_ransac_based_on_correspondence) and GC_RANSAC.py:46-49 (pygcransac.findRigidTransform,
+// native driver GC-RANSAC/src/pygcransac/src/gcransac_python.cpp:404-624 with the authors' edge-length
+// pre-check preemption_edge_length.h:71-128), plus the LS refit FR.py:99-111.
+//
+// Structure (all counts stay on device, no host round trip):
+//   gen     one thread per hypothesis id h: Philox sample -> ELC (fp64) -> minimal-sample Kabsch (fp64, Horn
+//           quaternion + Jacobi) -> fp32 model appended to a dense list
+//   score   one LANE per surviving hypothesis; the correspondence stream is wave-uniform, so it arrives
+//           through scalar loads (s_load_dwordx8) and every VALU op is useful work: 17 ops per
+//           (hypothesis, correspondence), no cross-lane reduction, no LDS traffic
+//   select  max inlier count; ties are broken by the fixed-point squared error, computed only for the tied
+//           hypotheses, then by the lower hypothesis id -> the winner does not depend on scheduling
+//   refit   fp64 moments of the inliers over the ORIGINAL NN pairs -> Kabsch
+//
+// Arithmetic is spelled out op by op and must stay identical to oracle/oracle.c (build: -ffp-contract=off).
+#include "lr_internal.h"
+#include <math.h>
+
+// ------------------------------------------------------------------ Philox4x32-10
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+        uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+// ------------------------------------------------------------------ Kabsch (fp64, + - * / sqrt only)
+#define LR_JACOBI_SWEEPS 8
+
+__device__ __forceinline__ void jacobi4_maxvec(double A[4][4], double q[4])
+{
+    double V[4][4] = { { 1, 0, 0, 0 }, { 0, 1, 0, 0 }, { 0, 0, 1, 0 }, { 0, 0, 0, 1 } };
+    for (int sweep = 0; sweep < LR_JACOBI_SWEEPS; ++sweep) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int r = p + 1; r < 4; ++r) {
+                double apq = A[p][r];
+                if (apq != 0.0) {
+                    double theta = (A[r][r] - A[p][p]) / (2.0 * apq);
+                    double at = fabs(theta);
+                    double t = 1.0 / (at + sqrt(theta * theta + 1.0));
+                    if (theta < 0.0) t = -t;
+                    double c = 1.0 / sqrt(t * t + 1.0);
+                    double s = t * c;
+                    double tau = s / (1.0 + c);
+                    double h = t * apq;
+                    A[p][p] = A[p][p] - h;
+                    A[r][r] = A[r][r] + h;
+                    A[p][r] = 0.0; A[r][p] = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (k == p || k == r) continue;
+                        double g = A[k][p], f = A[k][r];
+                        double gn = g - s * (f + g * tau);
+                        double fn = f + s * (g - f * tau);
+                        A[k][p] = gn; A[p][k] = gn;
+                        A[k][r] = fn; A[r][k] = fn;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        double g = V[k][p], f = V[k][r];
+                        V[k][p] = g - s * (f + g * tau);
+                        V[k][r] = f + s * (g - f * tau);
+                    }
+                }
+            }
+    }
+    double w = V[0][0], x = V[1][0], y = V[2][0], z = V[3][0], best = A[0][0];
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+        if (A[k][k] > best) { best = A[k][k]; w = V[0][k]; x = V[1][k]; y = V[2][k]; z = V[3][k]; }
+    double nn = sqrt(((w * w + x * x) + y * y) + z * z);
+    q[0] = w / nn; q[1] = x / nn; q[2] = y / nn; q[3] = z / nn;
+}
+
+// H[a][b] = sum (p-cp)_a (q-cq)_b  ->  T (row-major 4x4, q ~ R p + t)
+__device__ __forceinline__ void rt_from_cov(const double H[3][3], const double cp[3], const double cq[3], double T[16])
+{
+    double Sxx = H[0][0], Sxy = H[0][1], Sxz = H[0][2];
+    double Syx = H[1][0], Syy = H[1][1], Syz = H[1][2];
+    double Szx = H[2][0], Szy = H[2][1], Szz = H[2][2];
+    double N[4][4];
+    N[0][0] = (Sxx + Syy) + Szz; N[0][1] = Syz - Szy;         N[0][2] = Szx - Sxz;         N[0][3] = Sxy - Syx;
+    N[1][0] = N[0][1];           N[1][1] = (Sxx - Syy) - Szz; N[1][2] = Sxy + Syx;         N[1][3] = Szx + Sxz;
+    N[2][0] = N[0][2];           N[2][1] = N[1][2];           N[2][2] = (Syy - Sxx) - Szz; N[2][3] = Syz + Szy;
+    N[3][0] = N[0][3];           N[3][1] = N[1][3];           N[3][2] = N[2][3];           N[3][3] = (Szz - Sxx) - Syy;
+    double q[4];
+    jacobi4_maxvec(N, q);
+    double w = q[0], x = q[1], y = q[2], z = q[3];
+    double R[3][3];
+    R[0][0] = 1.0 - 2.0 * (y * y + z * z); R[0][1] = 2.0 * (x * y - w * z);       R[0][2] = 2.0 * (x * z + w * y);
+    R[1][0] = 2.0 * (x * y + w * z);       R[1][1] = 1.0 - 2.0 * (x * x + z * z); R[1][2] = 2.0 * (y * z - w * x);
+    R[2][0] = 2.0 * (x * z - w * y);       R[2][1] = 2.0 * (y * z + w * x);       R[2][2] = 1.0 - 2.0 * (x * x + y * y);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        double rc = (R[a][0] * cp[0] + R[a][1] * cp[1]) + R[a][2] * cp[2];
+        T[4 * a + 0] = R[a][0]; T[4 * a + 1] = R[a][1]; T[4 * a + 2] = R[a][2];
+        T[4 * a + 3] = cq[a] - rc;
+    }
+    T[12] = 0.0; T[13] = 0.0; T[14] = 0.0; T[15] = 1.0;
+}
+
+// unweighted Kabsch on NS (3 or 4) sample points held in registers
+template <int NS>
+__device__ __forceinline__ void kabsch_sample(const double P[NS][3], const double Q[NS][3], double T[16])
+{
+    double cp[3] = { 0, 0, 0 }, cq[3] = { 0, 0, 0 }, W = 0.0;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        W = W + 1.0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { cp[a] = cp[a] + 1.0 * P[i][a]; cq[a] = cq[a] + 1.0 * Q[i][a]; }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { cp[a] = cp[a] / W; cq[a] = cq[a] / W; }
+    double H[3][3] = { { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 } };
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        double pc[3], qc[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { pc[a] = P[i][a] - cp[a]; qc[a] = Q[i][a] - cq[a]; }
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) H[a][b] = H[a][b] + (1.0 * pc[a]) * qc[b];
+    }
+    rt_from_cov(H, cp, cq, T);
+}
+
+// sample + ELC + Kabsch of hypothesis h; false when the pre-check rejects it
+template <int NS>
+__device__ __forceinline__ bool hypothesis_T(const float *__restrict__ corr8, int m, uint64_t seed, uint64_t h,
+                                             int use_elc, double T[16])
+{
+    uint32_t c[4] = { (uint32_t)h, (uint32_t)(h >> 32), 0u, 0u };
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    double P[NS][3], Q[NS][3];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        uint32_t s = __umulhi(c[k], (uint32_t)m);
+        const float4 lo = reinterpret_cast<const float4 *>(corr8)[2 * (size_t)s];
+        const float4 hi = reinterpret_cast<const float4 *>(corr8)[2 * (size_t)s + 1];
+        P[k][0] = (double)lo.x; P[k][1] = (double)lo.y; P[k][2] = (double)lo.z;
+        Q[k][0] = (double)lo.w; Q[k][1] = (double)hi.x; Q[k][2] = (double)hi.y;
+    }
+    if (use_elc) {
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < NS; ++i)
+#pragma unroll
+            for (int j = i + 1; j < NS; ++j) {
+                double sx = P[j][0] - P[i][0], sy = P[j][1] - P[i][1], sz = P[j][2] - P[i][2];
+                double tx = Q[j][0] - Q[i][0], ty = Q[j][1] - Q[i][1], tz = Q[j][2] - Q[i][2];
+                double ds = sqrt((sx * sx + sy * sy) + sz * sz);
+                double dt = sqrt((tx * tx + ty * ty) + tz * tz);
+                if (ds < dt * 0.9 || dt < ds * 0.9) ok = false;
+            }
+        if (!ok) return false;
+    }
+    kabsch_sample<NS>(P, Q, T);
+    return true;
+}
+
+// ------------------------------------------------------------------ gen
+template <int NS>
+__global__ void __launch_bounds__(64)
+ransac_gen_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__restrict__ m_dev, lr_ransac_params p,
+                  float *__restrict__ models, int32_t *__restrict__ model_h, uint32_t *__restrict__ score_cnt,
+                  int32_t *__restrict__ counters)
+{
+    const int m = m_dev ? min(*m_dev, m_max) : m_max;
+    const int h = blockIdx.x * 64 + threadIdx.x;
+    if (h >= p.iters || m <= 0) return;
+    double T[16];
+    if (!hypothesis_T<NS>(corr8, m, p.seed, (uint64_t)h, p.use_elc, T)) return;
+    const int slot = atomicAdd(&counters[LR_CNT_NVALID], 1);
+#pragma unroll
+    for (int k = 0; k < 12; ++k) models[(size_t)slot * 12 + k] = (float)T[k];
+    model_h[slot] = h;
+    score_cnt[slot] = 0u;
+}
+
+// ------------------------------------------------------------------ score
+// Work items = (group of 64 hypotheses) x (chunk of correspondences); blocks stride over them.
+__global__ void __launch_bounds__(64)
+ransac_score_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__restrict__ m_dev, float thr2,
+                    const float *__restrict__ models, uint32_t *__restrict__ score_cnt,
+                    const int32_t *__restrict__ counters)
+{
+    const int m = m_dev ? min(*m_dev, m_max) : m_max;
+    const int V = counters[LR_CNT_NVALID];
+    const int hb = (V + 63) >> 6;
+    if (hb == 0 || m <= 0) return;
+    int chunks = (int)gridDim.x / hb;
+    const int cmax = m / 512 > 0 ? m / 512 : 1;
+    if (chunks > cmax) chunks = cmax;
+    if (chunks < 1) chunks = 1;
+    const int per = (m + chunks - 1) / chunks;
+    const int lane = threadIdx.x;
+    for (int w = blockIdx.x; w < hb * chunks; w += gridDim.x) {
+        const int g = w % hb, c = w / hb;
+        const int slot = g * 64 + lane;
+        const bool active = slot < V;
+        const float *mp = models + (size_t)(active ? slot : 0) * 12;
+        const float r00 = mp[0], r01 = mp[1], r02 = mp[2], tx = mp[3];
+        const float r10 = mp[4], r11 = mp[5], r12 = mp[6], ty = mp[7];
+        const float r20 = mp[8], r21 = mp[9], r22 = mp[10], tz = mp[11];
+        const int begin = c * per, end = min(m, begin + per);
+        uint32_t cnt = 0;
+        const float4 *rec = reinterpret_cast<const float4 *>(corr8);
+#pragma unroll 4
+        for (int i = begin; i < end; ++i) {
+            const float4 lo = rec[2 * i], hi = rec[2 * i + 1];       // wave-uniform address -> scalar loads
+            float x = __builtin_fmaf(r00, lo.x, __builtin_fmaf(r01, lo.y, __builtin_fmaf(r02, lo.z, tx)));
+            float y = __builtin_fmaf(r10, lo.x, __builtin_fmaf(r11, lo.y, __builtin_fmaf(r12, lo.z, ty)));
+            float z = __builtin_fmaf(r20, lo.x, __builtin_fmaf(r21, lo.y, __builtin_fmaf(r22, lo.z, tz)));
+            float dx = x - lo.w, dy = y - hi.x, dz = z - hi.y;
+            float d2 = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
+            cnt += (d2 < thr2) ? 1u : 0u;
+        }
+        if (active && cnt) atomicAdd(&score_cnt[slot], cnt);
+    }
+}
+
+// ------------------------------------------------------------------ select
+// pass 1: maximum inlier count over the V scored hypotheses
+__global__ void __launch_bounds__(1024)
+ransac_max_kernel(const uint32_t *__restrict__ score_cnt, int32_t *__restrict__ counters, uint32_t *__restrict__ cmax_out)
+{
+    __shared__ uint32_t sm[16];
+    const int V = counters[LR_CNT_NVALID];
+    uint32_t best = 0;
+    for (int s = threadIdx.x; s < V; s += 1024) best = max(best, score_cnt[s]);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) best = max(best, (uint32_t)__shfl_xor((int)best, m));
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w) best = max(best, sm[w]);
+        *cmax_out = best;
+    }
+}
+
+// pass 2: fixed-point squared error of every hypothesis that reaches the maximum count (one wave each)
+__global__ void __launch_bounds__(64)
+ransac_tiebreak_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__restrict__ m_dev, float thr2,
+                       const float *__restrict__ models, const uint32_t *__restrict__ score_cnt,
+                       const int32_t *__restrict__ counters, const uint32_t *__restrict__ cmax_in,
+                       unsigned long long *__restrict__ score_ssq)
+{
+    const int m = m_dev ? min(*m_dev, m_max) : m_max;
+    const int V = counters[LR_CNT_NVALID];
+    const uint32_t cmax = *cmax_in;
+    if (cmax == 0) return;
+    const int lane = threadIdx.x;
+    for (int base = blockIdx.x * 64; base < V; base += gridDim.x * 64) {
+        const int mine = base + lane;
+        unsigned long long tied = __ballot(mine < V && score_cnt[mine] == cmax);
+        while (tied) {
+            const int l = __ffsll((long long)tied) - 1;
+            tied &= tied - 1;
+            const int slot = base + l;
+            const float *mp = models + (size_t)slot * 12;
+            const float r00 = mp[0], r01 = mp[1], r02 = mp[2], tx = mp[3];
+            const float r10 = mp[4], r11 = mp[5], r12 = mp[6], ty = mp[7];
+            const float r20 = mp[8], r21 = mp[9], r22 = mp[10], tz = mp[11];
+            unsigned long long q = 0;
+            const float4 *rec = reinterpret_cast<const float4 *>(corr8);
+            for (int i = lane; i < m; i += 64) {
+                const float4 lo = rec[2 * i], hi = rec[2 * i + 1];
+                float x = __builtin_fmaf(r00, lo.x, __builtin_fmaf(r01, lo.y, __builtin_fmaf(r02, lo.z, tx)));
+                float y = __builtin_fmaf(r10, lo.x, __builtin_fmaf(r11, lo.y, __builtin_fmaf(r12, lo.z, ty)));
+                float z = __builtin_fmaf(r20, lo.x, __builtin_fmaf(r21, lo.y, __builtin_fmaf(r22, lo.z, tz)));
+                float dx = x - lo.w, dy = y - hi.x, dz = z - hi.y;
+                float d2 = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
+                if (d2 < thr2) q += (unsigned long long)(uint32_t)(d2 * 1048576.0f);
+            }
+#pragma unroll
+            for (int mk = 32; mk >= 1; mk >>= 1) q += __shfl_xor(q, mk);
+            if (lane == 0) score_ssq[slot] = q;
+        }
+    }
+}
+
+// pass 3: among the tied hypotheses the lowest (ssq, h) wins; thread 0 rebuilds its fp64 model
+template <int NS>
+__global__ void __launch_bounds__(1024)
+ransac_final_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__restrict__ m_dev, lr_ransac_params p,
+                    const uint32_t *__restrict__ score_cnt, const unsigned long long *__restrict__ score_ssq,
+                    const int32_t *__restrict__ model_h, const int32_t *__restrict__ counters,
+                    const uint32_t *__restrict__ cmax_in, double *__restrict__ T_out, lr_ransac_result *__restrict__ res)
+{
+    __shared__ unsigned long long s_q[16];
+    __shared__ int s_h[16];
+    const int m = m_dev ? min(*m_dev, m_max) : m_max;
+    const int V = counters[LR_CNT_NVALID];
+    const uint32_t cmax = *cmax_in;
+    unsigned long long bq = ~0ull;
+    int bh = 0x7fffffff;
+    if (cmax > 0)
+        for (int s = threadIdx.x; s < V; s += 1024)
+            if (score_cnt[s] == cmax) {
+                unsigned long long q = score_ssq[s];
+                int h = model_h[s];
+                if (q < bq || (q == bq && h < bh)) { bq = q; bh = h; }
+            }
+#pragma unroll
+    for (int mk = 32; mk >= 1; mk >>= 1) {
+        unsigned long long oq = __shfl_xor(bq, mk);
+        int oh = __shfl_xor(bh, mk);
+        if (oq < bq || (oq == bq && oh < bh)) { bq = oq; bh = oh; }
+    }
+    if ((threadIdx.x & 63) == 0) { s_q[threadIdx.x >> 6] = bq; s_h[threadIdx.x >> 6] = bh; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w)
+            if (s_q[w] < bq || (s_q[w] == bq && s_h[w] < bh)) { bq = s_q[w]; bh = s_h[w]; }
+        double T[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) T[k] = (k % 5 == 0) ? 1.0 : 0.0;
+        lr_ransac_result r;
+        r.best_h = -1; r.best_count = 0; r.pad0 = 0; r.best_ssq = 0; r.n_valid = V;
+        if (cmax > 0 && bh != 0x7fffffff) {
+            hypothesis_T<NS>(corr8, m, p.seed, (uint64_t)bh, p.use_elc, T);
+            r.best_h = bh; r.best_count = cmax; r.best_ssq = bq;
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) T_out[k] = T[k];
+        *res = r;
+    }
+}
+
+int lr_ransac_run(lr_workspace *ws, const float *corr8, int m_max, const int32_t *m_dev, const lr_ransac_params *p,
+                  double *T_out, lr_ransac_result *res, hipStream_t st)
+{
+    LR_REQUIRE(p->sample_size == 3 || p->sample_size == 4, LR_EINVAL, "lr_ransac: sample_size must be 3 or 4");
+    LR_REQUIRE(p->iters >= 0 && p->iters <= ws->max_iters, LR_ESIZE, "lr_ransac: iters exceeds the workspace");
+    LR_REQUIRE(m_max >= 0 && m_max <= ws->max_n0, LR_ESIZE, "lr_ransac: m exceeds the workspace");
+    uint32_t *cmax = reinterpret_cast<uint32_t *>(ws->counters + LR_CNT_COUNT - 1);
+    LR_HIP(hipMemsetAsync(ws->counters + LR_CNT_NVALID, 0, sizeof(int32_t), st));
+    const int gb = lr_cdiv(p->iters > 0 ? p->iters : 1, 64);
+    if (ws->timing && ws->ev_pending == 1) { LR_HIP(hipEventRecord(ws->ev[2], st)); }
+    if (p->sample_size == 3)
+        hipLaunchKernelGGL(ransac_gen_kernel<3>, dim3(gb), dim3(64), 0, st, corr8, m_max, m_dev, *p, ws->models, ws->model_h,
+                           ws->score_cnt, ws->counters);
+    else
+        hipLaunchKernelGGL(ransac_gen_kernel<4>, dim3(gb), dim3(64), 0, st, corr8, m_max, m_dev, *p, ws->models, ws->model_h,
+                           ws->score_cnt, ws->counters);
+    hipLaunchKernelGGL(ransac_score_kernel, dim3(LR_SCORE_BLOCKS), dim3(64), 0, st, corr8, m_max, m_dev, p->thr2, ws->models,
+                       ws->score_cnt, ws->counters);
+    if (ws->timing && ws->ev_pending == 1) { LR_HIP(hipEventRecord(ws->ev[3], st)); ws->ev_pending = 2; }
+    hipLaunchKernelGGL(ransac_max_kernel, dim3(1), dim3(1024), 0, st, ws->score_cnt, ws->counters, cmax);
+    hipLaunchKernelGGL(ransac_tiebreak_kernel, dim3(256), dim3(64), 0, st, corr8, m_max, m_dev, p->thr2, ws->models,
+                       ws->score_cnt, ws->counters, cmax, ws->score_ssq);
+    if (p->sample_size == 3)
+        hipLaunchKernelGGL(ransac_final_kernel<3>, dim3(1), dim3(1024), 0, st, corr8, m_max, m_dev, *p, ws->score_cnt,
+                           ws->score_ssq, ws->model_h, ws->counters, cmax, T_out, res);
+    else
+        hipLaunchKernelGGL(ransac_final_kernel<4>, dim3(1), dim3(1024), 0, st, corr8, m_max, m_dev, *p, ws->score_cnt,
+                           ws->score_ssq, ws->model_h, ws->counters, cmax, T_out, res);
+    LR_LAUNCH_CHECK();
+    return LR_OK;
+}
+
+// ------------------------------------------------------------------ refit (FR.py:99-111)
+// partial[b][0] = n, [1..3] = sum p, [4..6] = sum q, [7..15] = sum p q^T over the inliers of block b
+__global__ void __launch_bounds__(256)
+refit_moments_kernel(const float *__restrict__ xyz0, int n0, const float *__restrict__ xyz1, const int32_t *__restrict__ idx1,
+                     const double *__restrict__ T_in, double thr2, double *__restrict__ partial)
+{
+    __shared__ double sm[4][16];
+    double T[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) T[k] = T_in[k];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = 0.0;
+    if (i < n0) {
+        const int j = idx1[i];
+        double p[3] = { (double)xyz0[3 * i], (double)xyz0[3 * i + 1], (double)xyz0[3 * i + 2] };
+        double q[3] = { (double)xyz1[3 * j], (double)xyz1[3 * j + 1], (double)xyz1[3 * j + 2] };
+        double r[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+            r[a] = (((T[4 * a] * p[0] + T[4 * a + 1] * p[1]) + T[4 * a + 2] * p[2]) + T[4 * a + 3]) - q[a];
+        double d2 = (r[0] * r[0] + r[1] * r[1]) + r[2] * r[2];
+        if (d2 < thr2) {
+            v[0] = 1.0;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { v[1 + a] = p[a]; v[4 + a] = q[a]; }
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) v[7 + 3 * a + b] = p[a] * q[b];
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        double s = v[k];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+        if (lane == 0) sm[wave][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 16)
+        partial[(size_t)blockIdx.x * 16 + threadIdx.x] = ((sm[0][threadIdx.x] + sm[1][threadIdx.x]) + sm[2][threadIdx.x]) + sm[3][threadIdx.x];
+}
+
+__global__ void __launch_bounds__(64)
+refit_solve_kernel(const double *__restrict__ partial, int nblocks, const double *__restrict__ T_in,
+                   const lr_ransac_result *__restrict__ gate, double *__restrict__ T_out, int32_t *__restrict__ n_inl)
+{
+    __shared__ double mom[16];
+    if (threadIdx.x < 16) {
+        double s = 0.0;
+        for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * 16 + threadIdx.x];   // fixed order: reproducible
+        mom[threadIdx.x] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const bool have_model = gate ? gate->best_h >= 0 : true;
+    const double n = mom[0];
+    if (!have_model || n < 3.0) {
+        for (int k = 0; k < 16; ++k) T_out[k] = T_in[k];
+        if (n_inl) *n_inl = have_model ? (int)n : 0;
+        return;
+    }
+    double cp[3], cq[3], H[3][3], T[16];
+    for (int a = 0; a < 3; ++a) { cp[a] = mom[1 + a] / n; cq[a] = mom[4 + a] / n; }
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) H[a][b] = mom[7 + 3 * a + b] - (n * cp[a]) * cq[b];
+    rt_from_cov(H, cp, cq, T);
+    for (int k = 0; k < 16; ++k) T_out[k] = T[k];
+    if (n_inl) *n_inl = (int)n;
+}
+
+int lr_refit_run(lr_workspace *ws, const float *xyz0, int n0, const float *xyz1, const int32_t *idx1,
+                 const double *T_in, double thr2, double *T_out, int32_t *n_inl, const lr_ransac_result *gate,
+                 hipStream_t st)
+{
+    const int nb = lr_cdiv(n0, 256);
+    hipLaunchKernelGGL(refit_moments_kernel, dim3(nb), dim3(256), 0, st, xyz0, n0, xyz1, idx1, T_in, thr2, ws->refit_part);
+    hipLaunchKernelGGL(refit_solve_kernel, dim3(1), dim3(64), 0, st, ws->refit_part, nb, T_in, gate, T_out, n_inl);
+    LR_LAUNCH_CHECK();
+    return LR_OK;
+}
+
+// ------------------------------------------------------------------ a13: explicit point pairs
+__global__ void kabsch_points_kernel(const double *__restrict__ P, const double *__restrict__ Q, const double *__restrict__ w,
+                                     int n, double *__restrict__ T_out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double cp[3] = { 0, 0, 0 }, cq[3] = { 0, 0, 0 }, W = 0.0;
+    for (int i = 0; i < n; ++i) {
+        double wi = w ? w[i] : 1.0;
+        W = W + wi;
+        for (int a = 0; a < 3; ++a) { cp[a] = cp[a] + wi * P[3 * i + a]; cq[a] = cq[a] + wi * Q[3 * i + a]; }
+    }
+    for (int a = 0; a < 3; ++a) { cp[a] = cp[a] / W; cq[a] = cq[a] / W; }
+    double H[3][3] = { { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 } };
+    for (int i = 0; i < n; ++i) {
+        double wi = w ? w[i] : 1.0;
+        double pc[3], qc[3];
+        for (int a = 0; a < 3; ++a) { pc[a] = P[3 * i + a] - cp[a]; qc[a] = Q[3 * i + a] - cq[a]; }
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) H[a][b] = H[a][b] + (wi * pc[a]) * qc[b];
+    }
+    double T[16];
+    rt_from_cov(H, cp, cq, T);
+    for (int k = 0; k < 16; ++k) T_out[k] = T[k];
+}
+
+extern "C" int lr_kabsch(const double *P, const double *Q, const double *w, int n, double *T_out, void *stream)
+{
+    LR_REQUIRE(P && Q && T_out && n >= 1, LR_EINVAL, "lr_kabsch: bad argument");
+    hipLaunchKernelGGL(kabsch_points_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, P, Q, w, n, T_out);
+    LR_LAUNCH_CHECK();
+    return LR_OK;
+}

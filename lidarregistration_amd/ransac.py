@@ -1,0 +1,84 @@
+"""RANSAC / Kabsch / refit operators on top of liblidarreg.so.
+
+``GC_RANSAC`` keeps the reference's call shape (Experiments/algorithms/GC_RANSAC.py:8-55);
+``RANSAC_registration`` keeps FR.py:122-139's.  Both run the same HIP kernels (hypothesis
+generation, lane-per-hypothesis scoring, Kabsch) -- see csrc/lr_ransac.hip.
+"""
+import ctypes
+from time import time
+
+import numpy as np
+import torch
+
+from . import _ext
+from .matching import _device, _f32, _i32, _stream, workspace
+
+DEFAULT_SEED = 51          # Experiments/test.py:357
+
+
+def ransac_params(iters, sample_size=3, use_elc=True, thr=0.6, seed=DEFAULT_SEED):
+    return _ext.RansacParams(int(sample_size), int(bool(use_elc)), np.float32(float(thr) * float(thr)), int(iters), int(seed))
+
+
+def ransac_dev(src, tgt, iters, sample_size=3, use_elc=True, thr=0.6, seed=DEFAULT_SEED):
+    """RANSAC over M correspondences src[i] <-> tgt[i] ([M,3]).  Returns (T 4x4 float64 numpy, info dict)."""
+    src, tgt = _f32(src), _f32(tgt)
+    m = src.shape[0]
+    ws = workspace(max(m, 1), 1, iters)
+    T = torch.empty(16, dtype=torch.float64, device=src.device)
+    res = torch.zeros(ctypes.sizeof(_ext.RansacResult), dtype=torch.uint8, device=src.device)
+    p = ransac_params(iters, sample_size, use_elc, thr, seed)
+    _ext.check(_ext.lib().lr_ransac(ws.handle, src.data_ptr(), tgt.data_ptr(), m, None, ctypes.byref(p),
+                                     T.data_ptr(), res.data_ptr(), _stream()))
+    r = _ext.RansacResult.from_buffer_copy(res.cpu().numpy().tobytes())
+    info = dict(best_h=r.best_h, best_count=r.best_count, best_ssq=r.best_ssq, n_valid=r.n_valid)
+    return T.cpu().numpy().reshape(4, 4), info
+
+
+def refit_dev(xyz0, xyz1, idx1, T, thr=0.6):
+    """FR.py:99-111: LS refit over the original NN pairs within thr of T.  Returns (T 4x4, n_inliers)."""
+    xyz0, xyz1, idx1 = _f32(xyz0), _f32(xyz1), _i32(idx1)
+    n0 = xyz0.shape[0]
+    ws = workspace(n0, 1)
+    Tin = torch.as_tensor(np.ascontiguousarray(T, np.float64).reshape(16)).to(xyz0.device)
+    Tout = torch.empty(16, dtype=torch.float64, device=xyz0.device)
+    n = torch.zeros(1, dtype=torch.int32, device=xyz0.device)
+    _ext.check(_ext.lib().lr_refit(ws.handle, xyz0.data_ptr(), n0, xyz1.data_ptr(), idx1.data_ptr(), Tin.data_ptr(),
+                                    float(thr) * float(thr), Tout.data_ptr(), n.data_ptr(), _stream()))
+    return Tout.cpu().numpy().reshape(4, 4), int(n.item())
+
+
+def kabsch_dev(P, Q, w=None):
+    """Least-squares rigid fit Q ~ R P + t (models/common.py:7-45).  Returns 4x4 float64 numpy."""
+    dev = _device()
+    P = torch.as_tensor(np.ascontiguousarray(P, np.float64)).to(dev)
+    Q = torch.as_tensor(np.ascontiguousarray(Q, np.float64)).to(dev)
+    wt = None if w is None else torch.as_tensor(np.ascontiguousarray(w, np.float64)).to(dev)
+    T = torch.empty(16, dtype=torch.float64, device=dev)
+    _ext.check(_ext.lib().lr_kabsch(P.data_ptr(), Q.data_ptr(), None if wt is None else wt.data_ptr(), P.shape[0],
+                                     T.data_ptr(), _stream()))
+    return T.cpu().numpy().reshape(4, 4)
+
+
+def GC_RANSAC(A, B, distance_threshold, num_iterations, args, match_quality):
+    """GC_RANSAC.py:8-55: (pose 4x4 column-vector convention, elapsed seconds).
+
+    A, B: [M,3] float32 numpy.  Flags read from args: fast_rejection ("ELC" | "NONE" | "SPRT"; SPRT has no
+    device counterpart and is treated as ELC off).  PROSAC ordering (match_quality), local optimisation and
+    the spatial-coherence term of the third-party library are not part of this path: sampling is uniform."""
+    use_elc = getattr(args, "fast_rejection", "ELC") == "ELC"
+    start_time = time()
+    T, info = ransac_dev(A, B, num_iterations, sample_size=3, use_elc=use_elc, thr=distance_threshold,
+                         seed=getattr(args, "seed", DEFAULT_SEED))
+    if info["best_h"] < 0:
+        T = np.eye(4)                                       # GC_RANSAC.py:51-52
+    return T, time() - start_time
+
+
+def RANSAC_registration(pcd0, pcd1, idx0, idx1, distance_threshold, num_iterations, args):
+    """FR.py:122-139 (Open3D registration_ransac_based_on_correspondence, ransac_n=4, edge-length checker)."""
+    p0 = np.asarray(pcd0.points, np.float32)[np.asarray(idx0)]
+    p1 = np.asarray(pcd1.points, np.float32)[np.asarray(idx1)]
+    T, info = ransac_dev(p0, p1, num_iterations, sample_size=getattr(args, "ransac_n", 4), use_elc=True,
+                         thr=distance_threshold, seed=getattr(args, "seed", DEFAULT_SEED))
+    return T if info["best_h"] >= 0 else np.eye(4)

@@ -1,0 +1,74 @@
+"""CPU-side checks of the C-ABI library: it builds for gfx950, loads, and exports every symbol the header declares.
+No compute call is made here (there is no GPU in the build container)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from lidarregistration_amd import _ext
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def libpath():
+    return _ext.build()
+
+
+def test_header_symbols_are_exported(libpath):
+    hdr = open(os.path.join(ROOT, "include", "lidarreg.h")).read()
+    declared = sorted(set(re.findall(r"LR_API\s+[\w\s\*]+?\b(lr_\w+)\s*\(", hdr)))
+    assert declared, "no LR_API declarations found"
+    assert sorted(_ext.SYMBOLS) == declared
+    L = ctypes.CDLL(libpath)
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/lidarreg.h but not exported"
+
+
+def test_version_and_error_string(libpath):
+    L = _ext.lib()
+    assert L.lr_version() >= 100
+    assert isinstance(L.lr_last_error(), bytes)
+
+
+def test_struct_layouts_match_header():
+    # sizes the C side static-asserts implicitly through its field order (include/lidarreg.h)
+    assert ctypes.sizeof(_ext.RansacParams) == 24
+    assert ctypes.sizeof(_ext.RansacResult) == 32
+    assert ctypes.sizeof(_ext.PairResult) == 336
+    assert ctypes.sizeof(_ext.PairParams) == 56
+    assert _ext.PairParams.ransac.offset == 8 and _ext.PairParams.gpf_factor.offset == 40
+
+
+def test_bad_arguments_are_reported_not_crashed(libpath):
+    L = _ext.lib()
+    h = ctypes.c_void_p()
+    # argument validation happens before any HIP call, so this is safe without a device
+    assert L.lr_workspace_create(ctypes.byref(h), 0, 10, 32, 10) == -1
+    assert b"positive" in L.lr_last_error()
+    assert L.lr_workspace_create(ctypes.byref(h), 10, 10, 16, 10) == -1
+    assert b"32-d" in L.lr_last_error()
+    assert L.lr_feat_ratio(None, None, 32, 4, None, None, None, None, None) == -1
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "lidarregistration_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, re.M), f"{f} imports the oracle"
+                assert "liboracle" not in text, f"{f} references the oracle library"
+
+
+def test_mode_aliases_and_defaults():
+    from lidarregistration_amd import FR as fr
+    from tests.conftest import Args
+    p = fr.pair_params(Args(mode="MMN", codebase="GC", iters=None))
+    assert p.mode == _ext.LR_MODE_MNN and p.ransac.iters == 500000 and p.ransac.sample_size == 3 and p.ransac.use_elc == 1
+    p = fr.pair_params(Args(mode="GPF", codebase="open3D", iters=1000, GPF_factor=0.5, GPF_grid_wid=4))
+    assert p.mode == _ext.LR_MODE_GPF and p.ransac.sample_size == 4 and p.gpf_factor == 0.5 and p.gpf_grid_wid == 4
+    assert abs(p.refit_thr2 - 0.36) < 1e-15 and abs(p.ransac.thr2 - 0.36) < 1e-7
+    with pytest.raises(AssertionError):
+        fr.pair_params(Args(mode="bogus"))

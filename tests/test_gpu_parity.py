@@ -1,0 +1,253 @@
+"""Parity of the HIP path (through the C ABI) against the oracle and the golden vectors.  Needs an MI355X."""
+import numpy as np
+import pytest
+
+from lidarregistration_amd import synth
+from tests.conftest import Args, golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lr():
+    import torch
+    assert torch.cuda.is_available(), "these tests need a GPU"
+    from lidarregistration_amd import FR, _ext, matching, ransac
+    _ext.lib()                      # fails loudly if liblidarreg.so is missing
+    class NS: pass
+    ns = NS(); ns.FR = FR; ns.matching = matching; ns.ransac = ransac; ns.torch = torch; ns.ext = _ext
+    return ns
+
+
+def _bits(a):
+    return np.asarray(a, np.float32).view(np.uint32)
+
+
+# ----------------------------------------------------------------------------- NN (a1/a2)
+@pytest.mark.parametrize("n0,n1,seed", [(2048, 2048, 1), (3000, 2500, 2), (251, 499, 3), (250, 250, 4), (33, 65, 5),
+                                       (1, 40, 6), (5000, 1029, 7), (4100, 9000, 8)])
+def test_nn_top2_bit_exact(lr, oracle, n0, n1, seed):
+    F0, F1 = synth.make_features(n0, n1, 32, 0.5, 1.0, seed)
+    i1, i2, s1, s2 = lr.matching.nn_top2_dev(F0, F1, want_2nd=True, want_dist=True)
+    o1, o2, os1, os2 = oracle.nn_top2(F0, F1)
+    assert np.array_equal(i1.cpu().numpy(), o1)
+    assert np.array_equal(i2.cpu().numpy(), o2)
+    assert np.array_equal(_bits(s1.cpu().numpy()), _bits(os1))      # distances bit for bit
+    assert np.array_equal(_bits(s2.cpu().numpy()), _bits(os2))
+
+
+def test_nn_golden_vectors(lr):
+    g = golden("g1_find_nn.npz")
+    for tag in "abcd":
+        n0, n1, d, seed = [int(v) for v in g[f"{tag}_shape"]]
+        F0, F1 = synth.make_features(n0, n1, d, 0.5, 1.0, seed)
+        c0, c1, c2 = lr.matching.find_nn(lr.torch.from_numpy(F0), lr.torch.from_numpy(F1), return_2nd=True)
+        assert c1.dtype == lr.torch.int64 and not c1.is_cuda
+        assert np.array_equal(c0.numpy(), np.arange(n0))
+        assert np.array_equal(c1.numpy(), g[f"{tag}_idx1"]) and np.array_equal(c2.numpy(), g[f"{tag}_idx2"])
+        d0, d1, none = lr.matching.find_nn(lr.torch.from_numpy(F0), lr.torch.from_numpy(F1), return_2nd=False)
+        assert none is None and np.array_equal(d1.numpy(), c1.numpy())
+
+
+def test_nn_exact_ties_and_duplicates(lr, oracle):
+    # every candidate row appears three times -> exact distance ties everywhere -> first index must win,
+    # and the 2nd/3rd candidates tie after sqrt, which drives every row through the exact fix-up kernel
+    F0, F1 = synth.make_features(700, 300, 32, 0.5, 1.0, 11)
+    F1 = np.concatenate([F1, F1, F1], 0)
+    i1, i2, s1, s2 = lr.matching.nn_top2_dev(F0, F1, want_2nd=True, want_dist=True)
+    o1, o2, os1, os2 = oracle.nn_top2(F0, F1)
+    assert np.array_equal(i1.cpu().numpy(), o1) and np.array_equal(i2.cpu().numpy(), o2)
+    assert (o1 < 300).all() and np.array_equal(o2, o1 + 300)
+    # identical clouds: distance clamps at 1e-30 -> sqrt -> 1e-15; self match first
+    i1, i2, s1, _ = lr.matching.nn_top2_dev(F0, F0, want_2nd=True, want_dist=True)
+    o1, o2, os1, _ = oracle.nn_top2(F0, F0)
+    assert np.array_equal(i1.cpu().numpy(), o1) and np.array_equal(i2.cpu().numpy(), o2)
+    assert np.array_equal(_bits(s1.cpu().numpy()), _bits(os1))
+
+
+def test_nn_near_ties_sqrt_rounding(lr, oracle):
+    # candidates that differ by one ulp-scale perturbation: d2 differs, sqrt(d2) often does not
+    rng = np.random.default_rng(5)
+    F0, F1 = synth.make_features(512, 64, 32, 0.5, 1.0, 21)
+    reps = []
+    for k in range(40):
+        P = F1.copy()
+        P[:, k % 32] = np.nextafter(P[:, k % 32], np.float32(2.0 * (k % 2) - 1.0))
+        reps.append(P)
+    F1 = np.concatenate(reps[::-1], 0).astype(np.float32)
+    i1, i2, _, _ = lr.matching.nn_top2_dev(F0, F1, want_2nd=True)
+    o1, o2, _, _ = oracle.nn_top2(F0, F1)
+    assert np.array_equal(i1.cpu().numpy(), o1) and np.array_equal(i2.cpu().numpy(), o2)
+
+
+def test_nn_full_size_30k(lr, oracle):
+    p = synth.make_pair(N=30000, seed=51)
+    i1, i2, s1, s2 = lr.matching.nn_top2_dev(p["feats0"], p["feats1"], want_2nd=True, want_dist=True)
+    o1, o2, os1, os2 = oracle.nn_top2(p["feats0"], p["feats1"])
+    assert np.array_equal(i1.cpu().numpy(), o1) and np.array_equal(i2.cpu().numpy(), o2)
+    assert np.array_equal(_bits(s1.cpu().numpy()), _bits(os1))
+
+
+# ----------------------------------------------------------------------------- mutual / ratio / GPF (a3-a7)
+@pytest.fixture(scope="module")
+def filt(oracle):
+    g = golden("g2_filters.npz")
+    n0, n1, d, seed = [int(v) for v in g["shape"]]
+    F0, F1 = synth.make_features(n0, n1, d, 0.5, 1.0, seed)
+    xyz0, xyz1, T_gt = synth.make_clouds(n0, n1, 0.5, seed, clustered=True)
+    i0, i1, i2, _ = oracle.find_2nn(F0, F1)
+    return dict(g=g, F0=F0, F1=F1, xyz0=xyz0, xyz1=xyz1, T_gt=T_gt, i0=i0, i1=i1, i2=i2)
+
+
+def test_nn_to_mutual_golden_and_arity(lr, filt):
+    t = lr.torch.from_numpy
+    g = filt["g"]
+    m0, m1, m2 = lr.matching.nn_to_mutual(t(filt["F0"]), t(filt["F1"]), t(filt["i0"]), t(filt["i1"]), t(filt["i2"]))
+    assert np.array_equal(m0.numpy(), g["mnn_idx0"]) and np.array_equal(m1.numpy(), g["mnn_idx1"])
+    assert np.array_equal(m2.numpy(), g["mnn_idx2"])
+    assert len(lr.matching.nn_to_mutual(t(filt["F0"]), t(filt["F1"]), t(filt["i0"]), t(filt["i1"]))) == 2
+    r = lr.matching.nn_to_mutual(t(filt["F0"]), t(filt["F1"]), t(filt["i0"]), t(filt["i1"]), None, force_return_2nd=True)
+    assert len(r) == 3 and r[2] is None
+    is_bb, num_bb = lr.matching.mark_best_buddies(t(filt["F0"]), t(filt["F1"]), t(filt["i0"]), t(filt["i1"]))
+    assert np.array_equal(is_bb, g["is_bb"]) and int(num_bb) == int(g["num_bb"])
+
+
+@pytest.mark.parametrize("n0,n1,seed", [(1000, 3000, 31), (3000, 1000, 32), (257, 255, 33)])
+def test_nn_to_mutual_ragged_vs_oracle(lr, oracle, n0, n1, seed):
+    F0, F1 = synth.make_features(n0, n1, 32, 0.5, 0.8, seed)
+    i0, i1, i2, _ = oracle.find_2nn(F0, F1)
+    e0, e1, e2 = oracle.nn_to_mutual(F0, F1, i0, i1, i2)
+    t = lr.torch.from_numpy
+    m0, m1, m2 = lr.matching.nn_to_mutual(t(F0), t(F1), t(i0), t(i1), t(i2))
+    assert np.array_equal(m0.numpy(), e0) and np.array_equal(m1.numpy(), e1) and np.array_equal(m2.numpy(), e2)
+
+
+def test_ratio_bit_exact(lr, oracle, filt):
+    r = lr.matching.calc_distance_ratio_in_feature_space(filt["F0"], filt["F1"], filt["i0"], filt["i1"], filt["i2"])
+    e = oracle.calc_distance_ratio_in_feature_space(filt["F0"], filt["F1"], filt["i0"], filt["i1"], filt["i2"])
+    assert np.array_equal(_bits(r.cpu().numpy()), _bits(e))
+    np.testing.assert_allclose(r.cpu().numpy(), filt["g"]["ratio_nn"], rtol=2e-6)
+
+
+@pytest.mark.parametrize("k", [0, 1, 2, 3])
+def test_gpf_golden(lr, oracle, filt, k):
+    g = filt["g"]
+    factor, wid = g[f"gpf{k}_cfg"]
+    a = Args(GPF_grid_wid=int(wid), GPF_factor=float(factor))
+    t = lr.torch.from_numpy
+    out = lr.matching.Grid_Prioritized_Filter(t(filt["F0"]), t(filt["F1"]), t(filt["i0"]), t(filt["i1"]), t(filt["i2"]),
+                                              t(filt["xyz0"]), a)
+    assert np.array_equal(out[0].numpy(), g[f"gpf{k}_idx0"])
+    assert np.array_equal(out[1].numpy(), g[f"gpf{k}_idx1"])
+    assert np.array_equal(out[2].numpy(), g[f"gpf{k}_idx2"])
+    e = oracle.Grid_Prioritized_Filter(filt["F0"], filt["F1"], filt["i0"], filt["i1"], filt["i2"], filt["xyz0"], a)
+    assert np.array_equal(_bits(out[6].cpu().numpy()), _bits(e[6]))
+
+
+@pytest.mark.parametrize("factor,wid,seed", [(0.3, 10, 41), (0.05, 3, 42), (1.5, 16, 43)])
+def test_gpf_vs_oracle(lr, oracle, factor, wid, seed):
+    n0, n1 = 4000, 3500
+    F0, F1 = synth.make_features(n0, n1, 32, 0.5, 1.0, seed)
+    xyz0, _, _ = synth.make_clouds(n0, n1, 0.5, seed, clustered=True)
+    i0, i1, i2, _ = oracle.find_2nn(F0, F1)
+    a = Args(GPF_grid_wid=wid, GPF_factor=factor)
+    e = oracle.Grid_Prioritized_Filter(F0, F1, i0, i1, i2, xyz0, a)
+    t = lr.torch.from_numpy
+    out = lr.matching.Grid_Prioritized_Filter(t(F0), t(F1), t(i0), t(i1), t(i2), t(xyz0), a)
+    assert np.array_equal(out[0].numpy(), e[0]) and np.array_equal(out[1].numpy(), e[1]) and np.array_equal(out[2].numpy(), e[2])
+    assert len(e[0]) < n0
+
+
+# ----------------------------------------------------------------------------- Kabsch / RANSAC / refit
+@pytest.mark.parametrize("k", range(6))
+def test_kabsch_golden(lr, oracle, k):
+    g = golden("g7_kabsch.npz")
+    P, Q, w = g[f"k{k}_P"], g[f"k{k}_Q"], g[f"k{k}_w"]
+    T = lr.ransac.kabsch_dev(P, Q, w if len(w) else None)
+    np.testing.assert_allclose(T, oracle.kabsch(P, Q, w if len(w) else None), rtol=0, atol=1e-12)
+    np.testing.assert_allclose(T, g[f"k{k}_T_procrustes"], rtol=0, atol=2e-5)
+
+
+def _planted(n=4000, inlier=0.3, seed=3):
+    rng = np.random.default_rng(seed)
+    src = np.concatenate([rng.uniform(-80, 80, (n, 2)), rng.uniform(-3, 5, (n, 1))], 1).astype(np.float32)
+    T = synth.random_motion(rng)
+    tgt = (src.astype(np.float64) @ T[:3, :3].T + T[:3, 3] + rng.normal(0, 0.05, (n, 3))).astype(np.float32)
+    bad = rng.random(n) > inlier
+    tgt[bad] = np.concatenate([rng.uniform(-80, 80, (bad.sum(), 2)), rng.uniform(-3, 5, (bad.sum(), 1))], 1)
+    return src, tgt, T
+
+
+@pytest.mark.parametrize("ns,elc,n,iters,seed", [(3, True, 4000, 5000, 51), (4, True, 3000, 5000, 7), (3, False, 1500, 700, 9),
+                                                 (4, False, 900, 300, 1), (3, True, 17000, 20000, 123)])
+def test_ransac_same_winner_as_oracle(lr, oracle, ns, elc, n, iters, seed):
+    src, tgt, T_gt = _planted(n=n, seed=seed)
+    T, info = lr.ransac.ransac_dev(src, tgt, iters, sample_size=ns, use_elc=elc, seed=seed)
+    Te, einfo = oracle.ransac(src, tgt, iters, sample_size=ns, use_elc=elc, seed=seed)
+    assert info == einfo                                   # same hypothesis id, inlier count, error sum, #valid
+    assert np.array_equal(T, Te)                           # fp64 minimal-sample model, bit for bit
+    assert oracle.rotation_error_deg(T, T_gt) < 1.0
+
+
+def test_ransac_degenerate_inputs(lr, oracle):
+    rng = np.random.default_rng(0)
+    src = rng.uniform(-80, 80, (300, 3)).astype(np.float32)
+    tgt = (rng.uniform(1e3, 2e3, (300, 3)) * np.array([1, 50, 1000])).astype(np.float32)
+    T, info = lr.ransac.ransac_dev(src, tgt, 200, thr=1e-4)
+    Te, einfo = oracle.ransac(src, tgt, 200, thr=1e-4)
+    assert info == einfo and np.array_equal(T, Te)
+    # all correspondences identical: every sample is degenerate, Kabsch must still return finite numbers
+    src1 = np.tile(src[:1], (50, 1)); tgt1 = np.tile(tgt[:1], (50, 1))
+    T, info = lr.ransac.ransac_dev(src1, tgt1, 64)
+    Te, einfo = oracle.ransac(src1, tgt1, 64)
+    assert info == einfo and np.array_equal(np.isfinite(T), np.isfinite(Te))
+
+
+def test_refit_vs_oracle(lr, oracle):
+    p = synth.make_pair(N=6000, rho=0.5, s=0.8, seed=17)
+    i0, i1, i2, _ = oracle.find_2nn(p["feats0"], p["feats1"])
+    Tn = p["T_gt"].copy(); Tn[:3, 3] += [0.2, -0.1, 0.05]
+    T, n = lr.ransac.refit_dev(p["xyz0"], p["xyz1"], i1, Tn)
+    Te, ne = oracle.refit(p["xyz0"], p["xyz1"], i1, Tn)
+    assert n == ne and n > 500
+    np.testing.assert_allclose(T, Te, rtol=0, atol=1e-10)
+
+
+# ----------------------------------------------------------------------------- FR end to end (a9)
+@pytest.mark.parametrize("mode,codebase,N,iters", [("MNN", "open3D", 5000, 1000), ("MMN", "GC", 5000, 1000),
+                                                   ("GPF", "GC", 4000, 2000), ("no_filter", "open3D", 3000, 3000)])
+def test_FR_matches_oracle_pipeline(lr, oracle, mode, codebase, N, iters):
+    p = synth.make_pair(N=N, rho=0.5, s=0.9, seed=51, clustered=(mode == "GPF"))
+    a = Args(mode=mode, codebase=codebase, iters=iters, GPF_factor=0.5)
+    t = lr.torch.from_numpy
+    T, elapsed, pcd0, pcd1, n_init, ir_init, n_filt, ir_filt = lr.FR.FR(t(p["xyz0"]), t(p["xyz1"]), t(p["feats0"]), t(p["feats1"]), a, p["T_gt"])
+    ns = 3 if codebase == "GC" else 4
+    e = oracle.register_pair(p["xyz0"], p["xyz1"], p["feats0"], p["feats1"], mode=mode, iters=iters, sample_size=ns,
+                             use_elc=True, seed=51, args=a)
+    assert n_init == N and n_filt == len(e["idx0"])
+    # contract: <= 1e-4 rad rotation, <= 1e-3 m translation on identical correspondence inputs
+    assert np.radians(oracle.rotation_error_deg(T, e["T"])) <= 1e-4
+    assert oracle.translation_error_cm(T, e["T"]) / 100 <= 1e-3
+    np.testing.assert_allclose(T, e["T"], rtol=0, atol=1e-9)
+    assert T.dtype == np.float64 and T.shape == (4, 4) and elapsed > 0
+    assert pcd0.points.shape == (N, 3) and pcd0.points.dtype == np.float64
+    assert ir_init == oracle.measure_inlier_ratio(np.arange(N), e["idx1_orig"], p["xyz0"], p["xyz1"], p["T_gt"], 0.3)
+    assert ir_filt == oracle.measure_inlier_ratio(e["idx0"], e["idx1"], p["xyz0"], p["xyz1"], p["T_gt"], 0.3)
+    assert oracle.rotation_error_deg(T, p["T_gt"]) < 1.0 and oracle.translation_error_cm(T, p["T_gt"]) < 30
+
+
+def test_FR_full_size_config2(lr, oracle):
+    """BASELINE config #2: 30k-pt pair, MNN, 50k iterations -- whole pipeline against the oracle."""
+    p = synth.make_pair(N=30000, seed=51)
+    a = Args(mode="MNN", codebase="open3D", iters=50000, ransac_n=3)
+    t = lr.torch.from_numpy
+    T, elapsed, *_rest = lr.FR.FR(t(p["xyz0"]), t(p["xyz1"]), t(p["feats0"]), t(p["feats1"]), a, p["T_gt"])
+    e = oracle.register_pair(p["xyz0"], p["xyz1"], p["feats0"], p["feats1"], mode="MNN", iters=50000, sample_size=3, seed=51)
+    assert _rest[4] == len(e["idx0"])
+    assert np.radians(oracle.rotation_error_deg(T, e["T"])) <= 1e-4 and oracle.translation_error_cm(T, e["T"]) / 100 <= 1e-3
+    assert oracle.rotation_error_deg(T, p["T_gt"]) < 0.5 and oracle.translation_error_cm(T, p["T_gt"]) < 20
+
+
+def test_errors_are_loud(lr):
+    with pytest.raises(lr.ext.LidarRegError):
+        lr.matching.nn_top2_dev(np.zeros((10, 16), np.float32), np.zeros((10, 16), np.float32))
