@@ -142,8 +142,8 @@ ratio_kernel(const float *__restrict__ F0, const float *__restrict__ F1, int dim
         s1 = s1 + q1;
         s2 = s2 + q2;
     }
-    float d1 = __fsqrt_rn(s1), d2 = __fsqrt_rn(s2);
-    out[c] = __fdiv_rn(d1, d2 + 1e-6f);
+    float d1 = __builtin_sqrtf(s1), d2 = __builtin_sqrtf(s2);
+    out[c] = ((d1) / (d2 + 1e-6f));
 }
 
 extern "C" int lr_feat_ratio(const float *F0, const float *F1, int dim, int m, const int32_t *i0, const int32_t *i1,
@@ -208,12 +208,12 @@ gpf_score_cell_kernel(int n0, int G, const float *__restrict__ gf, const uint8_t
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n0) return;
     const float m = gf[0], M = gf[1];
-    float nfd = __fdiv_rn(ratio_inout[i] - m, M - m);
+    float nfd = ((ratio_inout[i] - m) / (M - m));
     if (is_bb[i]) nfd = nfd - 1.0f;
     ratio_inout[i] = nfd;
     const float denx = (gf[3] - gf[2]) + 1e-3f, deny = (gf[5] - gf[4]) + 1e-3f;
-    float qx = floorf((float)G * __fdiv_rn(xyz0[3 * i] - gf[2], denx));
-    float qy = floorf((float)G * __fdiv_rn(xyz0[3 * i + 1] - gf[4], deny));
+    float qx = floorf((float)G * ((xyz0[3 * i] - gf[2]) / (denx)));
+    float qy = floorf((float)G * ((xyz0[3 * i + 1] - gf[4]) / (deny)));
     int c = (int)qx * G + (int)qy;
     cell[i] = c;
     atomicAdd(&cell_count[c], 1);

@@ -220,7 +220,7 @@ nn_finalize_kernel(int na, int nstrips, int part_stride,
         size_t o = (size_t)s * part_stride + row;
         top3_merge(b1, i1, b2, i2, b3, pb1[o], pi1[o], pb2[o], pi2[o], pb3[o]);
     }
-    float s1 = __fsqrt_rn(b1), s2 = __fsqrt_rn(b2), s3 = __fsqrt_rn(b3);
+    float s1 = __builtin_sqrtf(b1), s2 = __builtin_sqrtf(b2), s3 = __builtin_sqrtf(b3);
     if (s2 == s3) {
         // a third candidate ties with the second after sqrt rounding: resolve exactly
         int slot = atomicAdd(&counters[LR_CNT_FIX], 1);
@@ -266,7 +266,7 @@ nn_fix_kernel(const float *__restrict__ Ap, const float *__restrict__ nA,
             }
             float t = nq + nB[j];
             float d2 = __builtin_fmaf(-2.0f, acc, t);
-            float s = __fsqrt_rn(fmaxf(d2, 1e-30f));
+            float s = __builtin_sqrtf(fmaxf(d2, 1e-30f));
             if (s < b1) { b2 = b1; i2 = i1; b1 = s; i1 = j; }
             else if (s < b2) { b2 = s; i2 = j; }
         }
