@@ -46,6 +46,7 @@ void carve(lr_workspace *ws, Carver &c)
     ws->nn_s1 = c.take<float>(n0); ws->nn_s2 = c.take<float>(n0);
     ws->rev_idx1 = c.take<int32_t>(n1);
     ws->is_bb = c.take<uint8_t>(n0);
+    ws->blk_cnt = c.take<int32_t>(n0 / 256 + 2);
     ws->corr_idx0 = c.take<int32_t>(n0); ws->corr_idx1 = c.take<int32_t>(n0); ws->corr_idx2 = c.take<int32_t>(n0);
     ws->corr_score = c.take<float>(n0);
     ws->ratio = c.take<float>(n0);
@@ -56,6 +57,7 @@ void carve(lr_workspace *ws, Carver &c)
     ws->gpf_f = c.take<float>(8);
     ws->corr8 = c.take<float>(n0 * 8);
     ws->models = c.take<float>(it * 12);
+    ws->models64 = c.take<double>(it * 12);
     ws->model_h = c.take<int32_t>(it);
     ws->score_cnt = c.take<uint32_t>(it);
     ws->score_ssq = c.take<unsigned long long>(it);

@@ -11,66 +11,81 @@
 
 #define LR_INF __builtin_huge_valf()
 
-// ------------------------------------------------------------------ ordered compaction helper
-// Block b owns elements [256 b, 256 b + 256).  Its output offset is the number of kept elements
-// before it, recounted by the block itself (N <= a few 1e4, so this is cheaper than a scan pass).
-template <class Pred>
-__device__ __forceinline__ int ordered_slot(int n, Pred keep_fn, bool *kept_out, int *total_out)
+// ------------------------------------------------------------------ ordered compaction
+// Two small launches instead of a scan: (1) flags + per-block (256 elements) counts, (2) every block sums the
+// counts of the blocks before it (<= n/256 values, one coalesced read) and scatters its survivors in order.
+__device__ __forceinline__ void block_count(bool k, int32_t *__restrict__ blk_cnt)
 {
     __shared__ int s_wave[4];
-    __shared__ int s_prefix;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int start = blockIdx.x * 256;
-    // 1) kept elements in [0, start)
-    int c = 0;
-    for (int i = tid; i < start; i += 256) c += keep_fn(i) ? 1 : 0;
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) c += __shfl_xor(c, m);
-    if (lane == 0) s_wave[wave] = c;
-    __syncthreads();
-    if (tid == 0) s_prefix = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-    __syncthreads();
-    const int prefix = s_prefix;
-    __syncthreads();
-    // 2) own element
-    const int i = start + tid;
-    const bool k = i < n && keep_fn(i);
     const unsigned long long bal = __ballot(k);
-    const int within = __popcll(bal & ((1ull << lane) - 1ull));
-    if (lane == 0) s_wave[wave] = __popcll(bal);
+    if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = __popcll(bal);
     __syncthreads();
-    int woff = 0;
-    for (int w = 0; w < wave; ++w) woff += s_wave[w];
-    *kept_out = k;
-    if (total_out) *total_out = prefix + s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-    return prefix + woff + within;
+    if (threadIdx.x == 0) blk_cnt[blockIdx.x] = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
 }
 
-// ------------------------------------------------------------------ mutual NN (a3-a5)
-// keep[i] = rev[idx1[i]] == i ; survivors in ascending i == torch coalesce order (matching.py:80-85)
+// keep[i] = rev[idx1[i]] == i  (torch_intersect, matching.py:67-87, reduced to its gather-compare core)
 __global__ void __launch_bounds__(256)
-mutual_kernel(int n0, const int32_t *__restrict__ idx1, const int32_t *__restrict__ idx2,
-              const int32_t *__restrict__ rev, uint8_t *__restrict__ is_bb,
-              int32_t *__restrict__ o0, int32_t *__restrict__ o1, int32_t *__restrict__ o2, int32_t *__restrict__ n_out)
+mutual_flag_kernel(int n0, const int32_t *__restrict__ idx1, const int32_t *__restrict__ rev,
+                   uint8_t *__restrict__ is_bb, int32_t *__restrict__ blk_cnt)
 {
-    auto keep = [&](int i) { return rev[idx1[i]] == i; };
-    bool k; int total;
-    int slot = ordered_slot(n0, keep, &k, &total);
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n0 && is_bb) is_bb[i] = k ? 1 : 0;
+    const bool k = i < n0 && rev[idx1[i]] == i;
+    if (i < n0) is_bb[i] = k ? 1 : 0;
+    block_count(k, blk_cnt);
+}
+
+__global__ void __launch_bounds__(256)
+count_flags_kernel(int n0, const uint8_t *__restrict__ flags, int32_t *__restrict__ blk_cnt)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    block_count(i < n0 && flags[i] != 0, blk_cnt);
+}
+
+// survivors in ascending i == torch coalesce order (matching.py:80-85) / boolean-mask order (matching.py:197-199)
+__global__ void __launch_bounds__(256)
+compact_kernel(int n0, const uint8_t *__restrict__ flags, const int32_t *__restrict__ blk_cnt,
+               const int32_t *__restrict__ idx1, const int32_t *__restrict__ idx2, const float *__restrict__ score,
+               int32_t *__restrict__ o0, int32_t *__restrict__ o1, int32_t *__restrict__ o2, float *__restrict__ oscore,
+               int32_t *__restrict__ n_out, int32_t *__restrict__ n_out2)
+{
+    __shared__ int s_wave[4];
+    __shared__ int s_part[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int c = 0;
+    for (int b = tid; b < (int)blockIdx.x; b += 256) c += blk_cnt[b];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) c += __shfl_xor(c, m);
+    const int i = blockIdx.x * 256 + tid;
+    const bool k = i < n0 && flags[i] != 0;
+    const unsigned long long bal = __ballot(k);
+    if (lane == 0) { s_part[wave] = c; s_wave[wave] = __popcll(bal); }
+    __syncthreads();
+    const int prefix = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += s_wave[w];
+    const int slot = prefix + woff + __popcll(bal & ((1ull << lane) - 1ull));
     if (k) {
         if (o0) o0[slot] = i;
         if (o1) o1[slot] = idx1[i];
         if (o2 && idx2) o2[slot] = idx2[i];
+        if (oscore && score) oscore[slot] = score[i];
     }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0 && n_out) *n_out = total;
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) {
+        const int total = prefix + s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        if (n_out) *n_out = total;
+        if (n_out2) *n_out2 = total;
+    }
 }
 
 int lr_mutual_run(lr_workspace *ws, int n0, const int32_t *idx1, const int32_t *idx2, const int32_t *rev,
                   uint8_t *is_bb, int32_t *o0, int32_t *o1, int32_t *o2, int32_t *n_out, hipStream_t st)
 {
-    (void)ws;
-    hipLaunchKernelGGL(mutual_kernel, dim3(lr_cdiv(n0, 256)), dim3(256), 0, st, n0, idx1, idx2, rev, is_bb, o0, o1, o2, n_out);
+    const int nb = lr_cdiv(n0, 256);
+    uint8_t *flags = is_bb ? is_bb : ws->is_bb;
+    hipLaunchKernelGGL(mutual_flag_kernel, dim3(nb), dim3(256), 0, st, n0, idx1, rev, flags, ws->blk_cnt);
+    // the number of best buddies is wanted even when no list is (GPF's TOTAL_NUM, matching.py:115-116)
+    hipLaunchKernelGGL(compact_kernel, dim3(nb), dim3(256), 0, st, n0, flags, ws->blk_cnt, idx1, idx2, (const float *)nullptr,
+                       o0, o1, o2, (float *)nullptr, n_out, ws->counters + LR_CNT_NBB);
     LR_LAUNCH_CHECK();
     return LR_OK;
 }
@@ -292,31 +307,6 @@ gpf_select_kernel(int n0, const int32_t *__restrict__ cell, const int32_t *__res
     keep[i] = k ? 1 : 0;
 }
 
-__global__ void __launch_bounds__(256)
-gpf_compact_kernel(int n0, const uint8_t *__restrict__ keep, const int32_t *__restrict__ idx1, const int32_t *__restrict__ idx2,
-                   const float *__restrict__ score, int32_t *__restrict__ o0, int32_t *__restrict__ o1,
-                   int32_t *__restrict__ o2, float *__restrict__ oscore, int32_t *__restrict__ n_out)
-{
-    auto kf = [&](int i) { return keep[i] != 0; };
-    bool k; int total;
-    int slot = ordered_slot(n0, kf, &k, &total);
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (k) {
-        o0[slot] = i; o1[slot] = idx1[i];
-        if (o2) o2[slot] = idx2[i];
-        if (oscore) oscore[slot] = score[i];
-    }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0 && n_out) *n_out = total;
-}
-
-__global__ void count_bb_kernel(int n0, const uint8_t *__restrict__ is_bb, int32_t *__restrict__ counters)
-{
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    bool k = i < n0 && is_bb[i];
-    unsigned long long bal = __ballot(k);
-    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&counters[LR_CNT_NBB], __popcll(bal));
-}
-
 int lr_gpf_run(lr_workspace *ws, const float *F0, int n0, const float *F1, int dim,
                const int32_t *idx1, const int32_t *idx2, const uint8_t *is_bb, const float *xyz0,
                int G, double factor, int32_t *o0, int32_t *o1, int32_t *o2, float *oscore,
@@ -330,8 +320,6 @@ int lr_gpf_run(lr_workspace *ws, const float *F0, int n0, const float *F1, int d
     uint8_t *keep = ws->gpf_keep;
     const int nb = lr_cdiv(n0, 256);
     LR_HIP(hipMemsetAsync(cell_count, 0, sizeof(int32_t) * 2 * (LR_GPF_MAX_CELLS + 8), st));
-    LR_HIP(hipMemsetAsync(ws->counters + LR_CNT_NBB, 0, sizeof(int32_t), st));
-    hipLaunchKernelGGL(count_bb_kernel, dim3(nb), dim3(256), 0, st, n0, is_bb, ws->counters);
     // ratio over all n0 NN pairs (corres_idx0 == arange)
     hipLaunchKernelGGL(ratio_kernel, dim3(nb), dim3(256), 0, st, F0, F1, dim, n0, (const int32_t *)nullptr,
                        (const int32_t *)nullptr, idx1, idx2, ws->ratio);
@@ -342,7 +330,9 @@ int lr_gpf_run(lr_workspace *ws, const float *F0, int n0, const float *F1, int d
     hipLaunchKernelGGL(gpf_bucket_kernel, dim3(nb), dim3(256), 0, st, n0, ws->cell, cell_off, cell_fill, ws->cell_sorted);
     hipLaunchKernelGGL(gpf_select_kernel, dim3(nb), dim3(256), 0, st, n0, ws->cell, cell_off, cell_count, quota,
                        ws->cell_sorted, ws->ratio, keep);
-    hipLaunchKernelGGL(gpf_compact_kernel, dim3(nb), dim3(256), 0, st, n0, keep, idx1, idx2, ws->ratio, o0, o1, o2, oscore, n_out);
+    hipLaunchKernelGGL(count_flags_kernel, dim3(nb), dim3(256), 0, st, n0, keep, ws->blk_cnt);
+    hipLaunchKernelGGL(compact_kernel, dim3(nb), dim3(256), 0, st, n0, keep, ws->blk_cnt, idx1, idx2, ws->ratio, o0, o1, o2, oscore,
+                       n_out, (int32_t *)nullptr);
     LR_LAUNCH_CHECK();
     return LR_OK;
 }

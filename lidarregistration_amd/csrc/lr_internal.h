@@ -50,6 +50,7 @@ struct lr_workspace {
     float *nn_s1, *nn_s2;
     int32_t *rev_idx1;           // reverse NN over n1 rows
     uint8_t *is_bb;
+    int32_t *blk_cnt;            // per-256-element survivor counts of the ordered compaction
     int32_t *corr_idx0, *corr_idx1, *corr_idx2;   // filtered lists [max_n0]
     float *corr_score;
     float *ratio;                // GPF: ratio / normalised score over n0
@@ -62,6 +63,7 @@ struct lr_workspace {
     float *corr8;                // packed correspondences [max_n0][8] = px py pz qx qy qz 0 0
     // --- RANSAC ---
     float *models;               // [max_iters][12] fp32 R|t rows of hypotheses that passed the pre-check
+    double *models64;            // [max_iters][12] the same models in fp64 (the winner is returned from here)
     int32_t *model_h;            // [max_iters] their hypothesis ids
     uint32_t *score_cnt;         // [max_iters]
     unsigned long long *score_ssq; // [max_iters]

@@ -119,6 +119,14 @@ nn_strip_kernel(const float *__restrict__ Ap, const float *__restrict__ nA, int 
         float nv_ = nB[min(col_, nb - 1)];                                                                    \
         ndst = col_ < c_end ? nv_ : LR_INF;                                                                   \
     }
+#if defined(LR_NN_NO_UPDATE) || defined(LR_NN_NO_SCHED)
+#define LR_SCHED_HINT
+#else
+#define LR_SCHED_HINT __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 11, 0);
+#endif
+#ifdef LR_NN_NO_UPDATE
+#define LR_UPDATE(g, accv, colv, nbv) { b1[g] = fminf(b1[g], accv); }
+#else
 #define LR_UPDATE(g, accv, colv, nbv)                                                                         \
     {                                                                                                         \
         float t_ = nq[g] + (nbv);                                                                             \
@@ -133,6 +141,7 @@ nn_strip_kernel(const float *__restrict__ Ap, const float *__restrict__ nA, int 
         i2[g] = lt1_ ? oi1_ : k2_;                                                                            \
         i1[g] = lt1_ ? (colv) : oi1_;                                                                         \
     }
+#endif
     // one pipeline stage: multiply tile (bt) into accN while folding accC (tile at column colC) into the state
 #define LR_STAGE(accN, bt, accC, colC, nbC)                                                                   \
     {                                                                                                         \
@@ -140,8 +149,7 @@ nn_strip_kernel(const float *__restrict__ Ap, const float *__restrict__ nA, int 
         _Pragma("unroll") for (int m = 0; m < 16; ++m) {                                                      \
             accN = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bt[m], accN, 0, 0, 0);                          \
             LR_UPDATE(m, accC[m], colC, nbC)                                                                  \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                \
-            __builtin_amdgcn_sched_group_barrier(0x002, 11, 0);                                               \
+            LR_SCHED_HINT                                                                                     \
         }                                                                                                     \
     }
 

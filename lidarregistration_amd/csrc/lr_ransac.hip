@@ -9,10 +9,12 @@
 //   gen     one thread per hypothesis id h: Philox sample -> ELC (fp64) -> minimal-sample Kabsch (fp64, Horn
 //           quaternion + Jacobi) -> fp32 model appended to a dense list
 //   score   one LANE per surviving hypothesis; the correspondence stream is wave-uniform, so it arrives
-//           through scalar loads (s_load_dwordx8) and every VALU op is useful work: 17 ops per
-//           (hypothesis, correspondence), no cross-lane reduction, no LDS traffic
-//   select  max inlier count; ties are broken by the fixed-point squared error, computed only for the tied
-//           hypotheses, then by the lower hypothesis id -> the winner does not depend on scheduling
+//           through scalar loads (s_load_dwordx8) and every VALU op is useful work: ~21 ops per
+//           (hypothesis, correspondence), no cross-lane reduction, no LDS traffic.  Inlier count and the
+//           fixed-point squared error are both integers, so chunk partials combine with integer atomics
+//           and the result does not depend on scheduling
+//   select  more inliers, then lower error, then lower hypothesis id (ties on the count are the norm when
+//           the inlier noise is far below the threshold, so the error is accumulated for everyone)
 //   refit   fp64 moments of the inliers over the ORIGINAL NN pairs -> Kabsch
 //
 // Arithmetic is spelled out op by op and must stay identical to oracle/oracle.c (build: -ffp-contract=off).
@@ -174,7 +176,8 @@ __device__ __forceinline__ bool hypothesis_T(const float *__restrict__ corr8, in
 template <int NS>
 __global__ void __launch_bounds__(64)
 ransac_gen_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__restrict__ m_dev, lr_ransac_params p,
-                  float *__restrict__ models, int32_t *__restrict__ model_h, uint32_t *__restrict__ score_cnt,
+                  float *__restrict__ models, double *__restrict__ models64, int32_t *__restrict__ model_h,
+                  uint32_t *__restrict__ score_cnt, unsigned long long *__restrict__ score_ssq,
                   int32_t *__restrict__ counters)
 {
     const int m = m_dev ? min(*m_dev, m_max) : m_max;
@@ -184,9 +187,10 @@ ransac_gen_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__r
     if (!hypothesis_T<NS>(corr8, m, p.seed, (uint64_t)h, p.use_elc, T)) return;
     const int slot = atomicAdd(&counters[LR_CNT_NVALID], 1);
 #pragma unroll
-    for (int k = 0; k < 12; ++k) models[(size_t)slot * 12 + k] = (float)T[k];
+    for (int k = 0; k < 12; ++k) { models[(size_t)slot * 12 + k] = (float)T[k]; models64[(size_t)slot * 12 + k] = T[k]; }
     model_h[slot] = h;
     score_cnt[slot] = 0u;
+    score_ssq[slot] = 0ull;
 }
 
 // ------------------------------------------------------------------ score
@@ -194,7 +198,7 @@ ransac_gen_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__r
 __global__ void __launch_bounds__(64)
 ransac_score_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__restrict__ m_dev, float thr2,
                     const float *__restrict__ models, uint32_t *__restrict__ score_cnt,
-                    const int32_t *__restrict__ counters)
+                    unsigned long long *__restrict__ score_ssq, const int32_t *__restrict__ counters, int sub)
 {
     const int m = m_dev ? min(*m_dev, m_max) : m_max;
     const int V = counters[LR_CNT_NVALID];
@@ -216,126 +220,77 @@ ransac_score_kernel(const float *__restrict__ corr8, int m_max, const int32_t *_
         const float r20 = mp[8], r21 = mp[9], r22 = mp[10], tz = mp[11];
         const int begin = c * per, end = min(m, begin + per);
         uint32_t cnt = 0;
+        unsigned long long ssq = 0;
         const float4 *rec = reinterpret_cast<const float4 *>(corr8);
+        // the error sum runs in 32 bits over sub-blocks short enough not to overflow (sub * thr2 * 2^20 < 2^32)
+        for (int b0 = begin; b0 < end; b0 += sub) {
+            const int b1 = min(end, b0 + sub);
+            uint32_t q32 = 0;
 #pragma unroll 4
-        for (int i = begin; i < end; ++i) {
-            const float4 lo = rec[2 * i], hi = rec[2 * i + 1];       // wave-uniform address -> scalar loads
-            float x = __builtin_fmaf(r00, lo.x, __builtin_fmaf(r01, lo.y, __builtin_fmaf(r02, lo.z, tx)));
-            float y = __builtin_fmaf(r10, lo.x, __builtin_fmaf(r11, lo.y, __builtin_fmaf(r12, lo.z, ty)));
-            float z = __builtin_fmaf(r20, lo.x, __builtin_fmaf(r21, lo.y, __builtin_fmaf(r22, lo.z, tz)));
-            float dx = x - lo.w, dy = y - hi.x, dz = z - hi.y;
-            float d2 = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
-            cnt += (d2 < thr2) ? 1u : 0u;
-        }
-        if (active && cnt) atomicAdd(&score_cnt[slot], cnt);
-    }
-}
-
-// ------------------------------------------------------------------ select
-// pass 1: maximum inlier count over the V scored hypotheses
-__global__ void __launch_bounds__(1024)
-ransac_max_kernel(const uint32_t *__restrict__ score_cnt, int32_t *__restrict__ counters, uint32_t *__restrict__ cmax_out)
-{
-    __shared__ uint32_t sm[16];
-    const int V = counters[LR_CNT_NVALID];
-    uint32_t best = 0;
-    for (int s = threadIdx.x; s < V; s += 1024) best = max(best, score_cnt[s]);
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) best = max(best, (uint32_t)__shfl_xor((int)best, m));
-    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = best;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < 16; ++w) best = max(best, sm[w]);
-        *cmax_out = best;
-    }
-}
-
-// pass 2: fixed-point squared error of every hypothesis that reaches the maximum count (one wave each)
-__global__ void __launch_bounds__(64)
-ransac_tiebreak_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__restrict__ m_dev, float thr2,
-                       const float *__restrict__ models, const uint32_t *__restrict__ score_cnt,
-                       const int32_t *__restrict__ counters, const uint32_t *__restrict__ cmax_in,
-                       unsigned long long *__restrict__ score_ssq)
-{
-    const int m = m_dev ? min(*m_dev, m_max) : m_max;
-    const int V = counters[LR_CNT_NVALID];
-    const uint32_t cmax = *cmax_in;
-    if (cmax == 0) return;
-    const int lane = threadIdx.x;
-    for (int base = blockIdx.x * 64; base < V; base += gridDim.x * 64) {
-        const int mine = base + lane;
-        unsigned long long tied = __ballot(mine < V && score_cnt[mine] == cmax);
-        while (tied) {
-            const int l = __ffsll((long long)tied) - 1;
-            tied &= tied - 1;
-            const int slot = base + l;
-            const float *mp = models + (size_t)slot * 12;
-            const float r00 = mp[0], r01 = mp[1], r02 = mp[2], tx = mp[3];
-            const float r10 = mp[4], r11 = mp[5], r12 = mp[6], ty = mp[7];
-            const float r20 = mp[8], r21 = mp[9], r22 = mp[10], tz = mp[11];
-            unsigned long long q = 0;
-            const float4 *rec = reinterpret_cast<const float4 *>(corr8);
-            for (int i = lane; i < m; i += 64) {
-                const float4 lo = rec[2 * i], hi = rec[2 * i + 1];
+            for (int i = b0; i < b1; ++i) {
+                const float4 lo = rec[2 * i], hi = rec[2 * i + 1];       // wave-uniform address -> scalar loads
                 float x = __builtin_fmaf(r00, lo.x, __builtin_fmaf(r01, lo.y, __builtin_fmaf(r02, lo.z, tx)));
                 float y = __builtin_fmaf(r10, lo.x, __builtin_fmaf(r11, lo.y, __builtin_fmaf(r12, lo.z, ty)));
                 float z = __builtin_fmaf(r20, lo.x, __builtin_fmaf(r21, lo.y, __builtin_fmaf(r22, lo.z, tz)));
                 float dx = x - lo.w, dy = y - hi.x, dz = z - hi.y;
                 float d2 = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
-                if (d2 < thr2) q += (unsigned long long)(uint32_t)(d2 * 1048576.0f);
+                const bool in = d2 < thr2;
+                cnt += in ? 1u : 0u;
+                q32 += in ? (uint32_t)(d2 * 1048576.0f) : 0u;
             }
-#pragma unroll
-            for (int mk = 32; mk >= 1; mk >>= 1) q += __shfl_xor(q, mk);
-            if (lane == 0) score_ssq[slot] = q;
+            ssq += q32;
         }
+        if (active && cnt) { atomicAdd(&score_cnt[slot], cnt); atomicAdd(&score_ssq[slot], ssq); }
     }
 }
 
-// pass 3: among the tied hypotheses the lowest (ssq, h) wins; thread 0 rebuilds its fp64 model
-template <int NS>
+// ------------------------------------------------------------------ select
+// best = more inliers, then lower fixed-point error, then lower hypothesis id; its fp64 model was kept by gen
+__device__ __forceinline__ bool better(uint32_t c, unsigned long long q, int h, uint32_t bc, unsigned long long bq, int bh)
+{
+    return c > bc || (c == bc && (q < bq || (q == bq && h < bh)));
+}
+
 __global__ void __launch_bounds__(1024)
-ransac_final_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__restrict__ m_dev, lr_ransac_params p,
-                    const uint32_t *__restrict__ score_cnt, const unsigned long long *__restrict__ score_ssq,
-                    const int32_t *__restrict__ model_h, const int32_t *__restrict__ counters,
-                    const uint32_t *__restrict__ cmax_in, double *__restrict__ T_out, lr_ransac_result *__restrict__ res)
+ransac_final_kernel(const uint32_t *__restrict__ score_cnt, const unsigned long long *__restrict__ score_ssq,
+                    const int32_t *__restrict__ model_h, const double *__restrict__ models64,
+                    const int32_t *__restrict__ counters, double *__restrict__ T_out, lr_ransac_result *__restrict__ res)
 {
     __shared__ unsigned long long s_q[16];
-    __shared__ int s_h[16];
-    const int m = m_dev ? min(*m_dev, m_max) : m_max;
+    __shared__ uint32_t s_c[16];
+    __shared__ int s_h[16], s_s[16];
     const int V = counters[LR_CNT_NVALID];
-    const uint32_t cmax = *cmax_in;
-    unsigned long long bq = ~0ull;
-    int bh = 0x7fffffff;
-    if (cmax > 0)
-        for (int s = threadIdx.x; s < V; s += 1024)
-            if (score_cnt[s] == cmax) {
-                unsigned long long q = score_ssq[s];
-                int h = model_h[s];
-                if (q < bq || (q == bq && h < bh)) { bq = q; bh = h; }
-            }
+    uint32_t bc = 0; unsigned long long bq = ~0ull; int bh = 0x7fffffff, bs = -1;
+    for (int s = threadIdx.x; s < V; s += 1024) {
+        uint32_t c = score_cnt[s];
+        if (c == 0) continue;
+        unsigned long long q = score_ssq[s];
+        int h = model_h[s];
+        if (better(c, q, h, bc, bq, bh)) { bc = c; bq = q; bh = h; bs = s; }
+    }
 #pragma unroll
     for (int mk = 32; mk >= 1; mk >>= 1) {
+        uint32_t oc = (uint32_t)__shfl_xor((int)bc, mk);
         unsigned long long oq = __shfl_xor(bq, mk);
-        int oh = __shfl_xor(bh, mk);
-        if (oq < bq || (oq == bq && oh < bh)) { bq = oq; bh = oh; }
+        int oh = __shfl_xor(bh, mk), os = __shfl_xor(bs, mk);
+        if (better(oc, oq, oh, bc, bq, bh)) { bc = oc; bq = oq; bh = oh; bs = os; }
     }
-    if ((threadIdx.x & 63) == 0) { s_q[threadIdx.x >> 6] = bq; s_h[threadIdx.x >> 6] = bh; }
+    if ((threadIdx.x & 63) == 0) { s_c[threadIdx.x >> 6] = bc; s_q[threadIdx.x >> 6] = bq; s_h[threadIdx.x >> 6] = bh; s_s[threadIdx.x >> 6] = bs; }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < 16) {
         for (int w = 1; w < 16; ++w)
-            if (s_q[w] < bq || (s_q[w] == bq && s_h[w] < bh)) { bq = s_q[w]; bh = s_h[w]; }
-        double T[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) T[k] = (k % 5 == 0) ? 1.0 : 0.0;
-        lr_ransac_result r;
-        r.best_h = -1; r.best_count = 0; r.pad0 = 0; r.best_ssq = 0; r.n_valid = V;
-        if (cmax > 0 && bh != 0x7fffffff) {
-            hypothesis_T<NS>(corr8, m, p.seed, (uint64_t)bh, p.use_elc, T);
-            r.best_h = bh; r.best_count = cmax; r.best_ssq = bq;
+            if (better(s_c[w], s_q[w], s_h[w], bc, bq, bh)) { bc = s_c[w]; bq = s_q[w]; bh = s_h[w]; bs = s_s[w]; }
+        // every one of these 16 lanes now holds the same winner; lane k writes T[k]
+        const int k = threadIdx.x;
+        const bool have = bc > 0 && bs >= 0;
+        double v = (k % 5 == 0) ? 1.0 : 0.0;
+        if (have && k < 12) v = models64[(size_t)bs * 12 + k];
+        T_out[k] = v;
+        if (k == 0) {
+            lr_ransac_result r;
+            r.best_h = have ? bh : -1; r.best_count = have ? bc : 0; r.pad0 = 0; r.best_ssq = have ? bq : 0; r.n_valid = V;
+            *res = r;
         }
-#pragma unroll
-        for (int k = 0; k < 16; ++k) T_out[k] = T[k];
-        *res = r;
     }
 }
 
@@ -345,28 +300,24 @@ int lr_ransac_run(lr_workspace *ws, const float *corr8, int m_max, const int32_t
     LR_REQUIRE(p->sample_size == 3 || p->sample_size == 4, LR_EINVAL, "lr_ransac: sample_size must be 3 or 4");
     LR_REQUIRE(p->iters >= 0 && p->iters <= ws->max_iters, LR_ESIZE, "lr_ransac: iters exceeds the workspace");
     LR_REQUIRE(m_max >= 0 && m_max <= ws->max_n0, LR_ESIZE, "lr_ransac: m exceeds the workspace");
-    uint32_t *cmax = reinterpret_cast<uint32_t *>(ws->counters + LR_CNT_COUNT - 1);
+    LR_REQUIRE(p->thr2 > 0.0f && p->thr2 < 2048.0f, LR_EINVAL, "lr_ransac: thr2 must be in (0, 2048)");
     LR_HIP(hipMemsetAsync(ws->counters + LR_CNT_NVALID, 0, sizeof(int32_t), st));
     const int gb = lr_cdiv(p->iters > 0 ? p->iters : 1, 64);
+    int sub = (int)(4095.0 / ((double)p->thr2 * 1.0000001 + 1e-6));     // sub * thr2 * 2^20 < 2^32
+    if (sub > 4096) sub = 4096;
+    if (sub < 1) sub = 1;
     if (ws->timing && ws->ev_pending == 1) { LR_HIP(hipEventRecord(ws->ev[2], st)); }
     if (p->sample_size == 3)
-        hipLaunchKernelGGL(ransac_gen_kernel<3>, dim3(gb), dim3(64), 0, st, corr8, m_max, m_dev, *p, ws->models, ws->model_h,
-                           ws->score_cnt, ws->counters);
+        hipLaunchKernelGGL(ransac_gen_kernel<3>, dim3(gb), dim3(64), 0, st, corr8, m_max, m_dev, *p, ws->models, ws->models64,
+                           ws->model_h, ws->score_cnt, ws->score_ssq, ws->counters);
     else
-        hipLaunchKernelGGL(ransac_gen_kernel<4>, dim3(gb), dim3(64), 0, st, corr8, m_max, m_dev, *p, ws->models, ws->model_h,
-                           ws->score_cnt, ws->counters);
+        hipLaunchKernelGGL(ransac_gen_kernel<4>, dim3(gb), dim3(64), 0, st, corr8, m_max, m_dev, *p, ws->models, ws->models64,
+                           ws->model_h, ws->score_cnt, ws->score_ssq, ws->counters);
     hipLaunchKernelGGL(ransac_score_kernel, dim3(LR_SCORE_BLOCKS), dim3(64), 0, st, corr8, m_max, m_dev, p->thr2, ws->models,
-                       ws->score_cnt, ws->counters);
+                       ws->score_cnt, ws->score_ssq, ws->counters, sub);
     if (ws->timing && ws->ev_pending == 1) { LR_HIP(hipEventRecord(ws->ev[3], st)); ws->ev_pending = 2; }
-    hipLaunchKernelGGL(ransac_max_kernel, dim3(1), dim3(1024), 0, st, ws->score_cnt, ws->counters, cmax);
-    hipLaunchKernelGGL(ransac_tiebreak_kernel, dim3(256), dim3(64), 0, st, corr8, m_max, m_dev, p->thr2, ws->models,
-                       ws->score_cnt, ws->counters, cmax, ws->score_ssq);
-    if (p->sample_size == 3)
-        hipLaunchKernelGGL(ransac_final_kernel<3>, dim3(1), dim3(1024), 0, st, corr8, m_max, m_dev, *p, ws->score_cnt,
-                           ws->score_ssq, ws->model_h, ws->counters, cmax, T_out, res);
-    else
-        hipLaunchKernelGGL(ransac_final_kernel<4>, dim3(1), dim3(1024), 0, st, corr8, m_max, m_dev, *p, ws->score_cnt,
-                           ws->score_ssq, ws->model_h, ws->counters, cmax, T_out, res);
+    hipLaunchKernelGGL(ransac_final_kernel, dim3(1), dim3(1024), 0, st, ws->score_cnt, ws->score_ssq, ws->model_h, ws->models64,
+                       ws->counters, T_out, res);
     LR_LAUNCH_CHECK();
     return LR_OK;
 }
@@ -422,11 +373,19 @@ refit_solve_kernel(const double *__restrict__ partial, int nblocks, const double
                    const lr_ransac_result *__restrict__ gate, double *__restrict__ T_out, int32_t *__restrict__ n_inl)
 {
     __shared__ double mom[16];
-    if (threadIdx.x < 16) {
-        double s = 0.0;
-        for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * 16 + threadIdx.x];   // fixed order: reproducible
-        mom[threadIdx.x] = s;
+    __shared__ double stage[64 * 16];
+    // partials are summed in block order (reproducible); they are staged through LDS 64 blocks at a time so the
+    // 16 summing lanes do not walk a chain of dependent global loads
+    double acc = 0.0;
+    for (int b0 = 0; b0 < nblocks; b0 += 64) {
+        const int nb = min(64, nblocks - b0);
+        for (int t = threadIdx.x; t < nb * 16; t += 64) stage[t] = partial[(size_t)b0 * 16 + t];
+        __syncthreads();
+        if (threadIdx.x < 16)
+            for (int b = 0; b < nb; ++b) acc += stage[b * 16 + threadIdx.x];
+        __syncthreads();
     }
+    if (threadIdx.x < 16) mom[threadIdx.x] = acc;
     __syncthreads();
     if (threadIdx.x != 0) return;
     const bool have_model = gate ? gate->best_h >= 0 : true;
