@@ -3,6 +3,7 @@
 #include "lr_internal.h"
 #include <stdarg.h>
 #include <string.h>
+#include <stdlib.h>
 #include <new>
 
 static thread_local char g_err[512] = "";
@@ -37,6 +38,10 @@ void carve(lr_workspace *ws, Carver &c)
     const size_t n0 = ws->max_n0, n1 = ws->max_n1, n = ws->max_n, it = ws->max_iters;
     ws->Fp0 = c.take<float>(n0 * 32); ws->Fp1 = c.take<float>(n1 * 32);
     ws->nrm0 = c.take<float>(n0); ws->nrm1 = c.take<float>(n1);
+    ws->H0 = c.take<_Float16>(n0 * 32); ws->H1 = c.take<_Float16>(n1 * 32);
+    ws->tau = c.take<float>(n);
+    ws->cand_cnt = c.take<int32_t>(n); ws->cand = c.take<int32_t>(n * LR_NN16_CAP);
+    ws->max_norm = c.take<uint32_t>(2);
     ws->pb1 = c.take<float>(n * LR_NN_MAX_STRIPS); ws->pb2 = c.take<float>(n * LR_NN_MAX_STRIPS);
     ws->pb3 = c.take<float>(n * LR_NN_MAX_STRIPS);
     ws->pi1 = c.take<int32_t>(n * LR_NN_MAX_STRIPS); ws->pi2 = c.take<int32_t>(n * LR_NN_MAX_STRIPS);
@@ -77,6 +82,10 @@ extern "C" int lr_workspace_create(lr_workspace **out, int max_n0, int max_n1, i
     memset(ws, 0, sizeof(*ws));
     ws->max_n0 = max_n0; ws->max_n1 = max_n1; ws->max_n = max_n0 > max_n1 ? max_n0 : max_n1;
     ws->dim = dim; ws->max_iters = max_iters > 0 ? max_iters : 1;
+    {
+        const char *e = getenv("LIDARREG_NN_PATH");
+        ws->nn_path = (e && strcmp(e, "fp32") == 0) ? LR_NN_PATH_FP32_MFMA : LR_NN_PATH_F16_FILTER;
+    }
     Carver sizing;
     carve(ws, sizing);
     ws->bytes = sizing.off + 256;
@@ -158,6 +167,37 @@ static int check_nn_args(const lr_workspace *ws, const void *F0, int n0, const v
 
 #define LR_TRY(x) do { int rc_ = (x); if (rc_ != LR_OK) return rc_; } while (0)
 
+// norms + operand copies of both clouds for whichever NN path the workspace uses
+static int prep_both(lr_workspace *ws, const float *F0, int n0, const float *F1, int n1, hipStream_t st)
+{
+    if (ws->nn_path == LR_NN_PATH_FP32_MFMA) {
+        LR_TRY(lr_nn_prep(ws, F0, n0, ws->Fp0, ws->nrm0, st));
+        return lr_nn_prep(ws, F1, n1, ws->Fp1, ws->nrm1, st);
+    }
+    LR_TRY(lr_nn16_prep(ws, F0, n0, ws->Fp0, ws->H0, ws->nrm0, ws->max_norm + 0, st));
+    return lr_nn16_prep(ws, F1, n1, ws->Fp1, ws->H1, ws->nrm1, ws->max_norm + 1, st);
+}
+
+// forward: rows of cloud 0 against cloud 1 (first + second NN)
+static int nn_forward(lr_workspace *ws, const float *F0, int n0, const float *F1, int n1,
+                      int32_t *idx1, int32_t *idx2, float *s1, float *s2, hipStream_t st)
+{
+    if (ws->nn_path == LR_NN_PATH_FP32_MFMA)
+        return lr_nn_run(ws, ws->Fp0, ws->nrm0, n0, ws->Fp1, ws->nrm1, n1, idx1, idx2, s1, s2, st);
+    return lr_nn16_run(ws, F0, ws->Fp0, ws->H0, ws->nrm0, n0, F1, ws->Fp1, ws->H1, ws->nrm1, ws->max_norm + 1, n1,
+                       2, idx1, idx2, s1, s2, st);
+}
+
+// reverse: rows of cloud 1 against cloud 0 (first NN only).  The reference restricts it to the unique forward
+// targets (matching.py:224-225); rows that are nobody's target never enter the intersection, so all rows is equivalent.
+static int nn_reverse(lr_workspace *ws, const float *F0, int n0, const float *F1, int n1, int32_t *rev, hipStream_t st)
+{
+    if (ws->nn_path == LR_NN_PATH_FP32_MFMA)
+        return lr_nn_run(ws, ws->Fp1, ws->nrm1, n1, ws->Fp0, ws->nrm0, n0, rev, nullptr, nullptr, nullptr, st);
+    return lr_nn16_run(ws, F1, ws->Fp1, ws->H1, ws->nrm1, n1, F0, ws->Fp0, ws->H0, ws->nrm0, ws->max_norm + 0, n0,
+                       1, rev, nullptr, nullptr, nullptr, st);
+}
+
 // ------------------------------------------------------------------ a1/a2
 extern "C" int lr_nn_top2(lr_workspace *ws, const float *F0, int n0, const float *F1, int n1, int dim,
                           int32_t *idx1, int32_t *idx2, float *s1, float *s2, void *stream)
@@ -165,9 +205,8 @@ extern "C" int lr_nn_top2(lr_workspace *ws, const float *F0, int n0, const float
     LR_TRY(check_nn_args(ws, F0, n0, F1, n1, dim, "lr_nn_top2"));
     LR_REQUIRE(idx1, LR_EINVAL, "lr_nn_top2: idx1 is required");
     hipStream_t st = (hipStream_t)stream;
-    LR_TRY(lr_nn_prep(ws, F0, n0, ws->Fp0, ws->nrm0, st));
-    LR_TRY(lr_nn_prep(ws, F1, n1, ws->Fp1, ws->nrm1, st));
-    return lr_nn_run(ws, ws->Fp0, ws->nrm0, n0, ws->Fp1, ws->nrm1, n1, idx1, idx2, s1, s2, st);
+    LR_TRY(prep_both(ws, F0, n0, F1, n1, st));
+    return nn_forward(ws, F0, n0, F1, n1, idx1, idx2, s1, s2, st);
 }
 
 // ------------------------------------------------------------------ a3-a5
@@ -178,11 +217,8 @@ extern "C" int lr_nn_to_mutual(lr_workspace *ws, const float *F0, int n0, const 
     LR_TRY(check_nn_args(ws, F0, n0, F1, n1, dim, "lr_nn_to_mutual"));
     LR_REQUIRE(idx1, LR_EINVAL, "lr_nn_to_mutual: idx1 is required");
     hipStream_t st = (hipStream_t)stream;
-    LR_TRY(lr_nn_prep(ws, F0, n0, ws->Fp0, ws->nrm0, st));
-    LR_TRY(lr_nn_prep(ws, F1, n1, ws->Fp1, ws->nrm1, st));
-    // reverse direction: every row of F1 against all of F0 (the reference restricts it to the unique
-    // forward targets, matching.py:224-225; rows that are nobody's target never enter the intersection)
-    LR_TRY(lr_nn_run(ws, ws->Fp1, ws->nrm1, n1, ws->Fp0, ws->nrm0, n0, ws->rev_idx1, nullptr, nullptr, nullptr, st));
+    LR_TRY(prep_both(ws, F0, n0, F1, n1, st));
+    LR_TRY(nn_reverse(ws, F0, n0, F1, n1, ws->rev_idx1, st));
     return lr_mutual_run(ws, n0, idx1, idx2, ws->rev_idx1, is_bb, o0, o1, o2, n_out, st);
 }
 
@@ -194,9 +230,8 @@ extern "C" int lr_gpf(lr_workspace *ws, const float *F0, int n0, const float *F1
     LR_TRY(check_nn_args(ws, F0, n0, F1, n1, dim, "lr_gpf"));
     LR_REQUIRE(idx1 && idx2 && xyz0 && o0 && o1, LR_EINVAL, "lr_gpf: null pointer");
     hipStream_t st = (hipStream_t)stream;
-    LR_TRY(lr_nn_prep(ws, F0, n0, ws->Fp0, ws->nrm0, st));
-    LR_TRY(lr_nn_prep(ws, F1, n1, ws->Fp1, ws->nrm1, st));
-    LR_TRY(lr_nn_run(ws, ws->Fp1, ws->nrm1, n1, ws->Fp0, ws->nrm0, n0, ws->rev_idx1, nullptr, nullptr, nullptr, st));
+    LR_TRY(prep_both(ws, F0, n0, F1, n1, st));
+    LR_TRY(nn_reverse(ws, F0, n0, F1, n1, ws->rev_idx1, st));
     LR_TRY(lr_mutual_run(ws, n0, idx1, nullptr, ws->rev_idx1, ws->is_bb, nullptr, nullptr, nullptr, nullptr, st));
     return lr_gpf_run(ws, F0, n0, F1, dim, idx1, idx2, ws->is_bb, xyz0, grid_wid, factor, o0, o1, o2, oscore, n_out, st);
 }
@@ -250,14 +285,13 @@ extern "C" int lr_register_pair(lr_workspace *ws, const float *xyz0, const float
     int32_t *n_refit = ws->counters + LR_CNT_COUNT - 2;
     LR_HIP(hipMemsetAsync(ws->counters, 0, sizeof(int32_t) * LR_CNT_COUNT, st));
     // 1. coarse correspondences (FR.py:38): first + second NN of every cloud-0 descriptor
-    LR_TRY(lr_nn_prep(ws, F0, n0, ws->Fp0, ws->nrm0, st));
-    LR_TRY(lr_nn_prep(ws, F1, n1, ws->Fp1, ws->nrm1, st));
-    LR_TRY(lr_nn_run(ws, ws->Fp0, ws->nrm0, n0, ws->Fp1, ws->nrm1, n1, ws->nn_idx1, ws->nn_idx2, ws->nn_s1, ws->nn_s2, st));
+    LR_TRY(prep_both(ws, F0, n0, F1, n1, st));
+    LR_TRY(nn_forward(ws, F0, n0, F1, n1, ws->nn_idx1, ws->nn_idx2, ws->nn_s1, ws->nn_s2, st));
     // 2. filter (FR.py:48-56)
     if (p->mode == LR_MODE_NO_FILTER) {
         LR_TRY(lr_identity_corr(ws, n0, ws->nn_idx1, ws->nn_idx2, ws->corr_idx0, ws->corr_idx1, ws->corr_idx2, m_dev, st));
     } else {
-        LR_TRY(lr_nn_run(ws, ws->Fp1, ws->nrm1, n1, ws->Fp0, ws->nrm0, n0, ws->rev_idx1, nullptr, nullptr, nullptr, st));
+        LR_TRY(nn_reverse(ws, F0, n0, F1, n1, ws->rev_idx1, st));
         if (p->mode == LR_MODE_MNN) {
             LR_TRY(lr_mutual_run(ws, n0, ws->nn_idx1, ws->nn_idx2, ws->rev_idx1, ws->is_bb, ws->corr_idx0, ws->corr_idx1,
                                  ws->corr_idx2, m_dev, st));

@@ -33,6 +33,10 @@ static inline int lr_cdiv(int a, int b) { return (a + b - 1) / b; }
 // (hypothesis group, correspondence chunk) from the live counts on device.
 #define LR_SCORE_BLOCKS 8192
 #define LR_GPF_MAX_CELLS 4096
+// f16 filter path: pass A samples every LR_NN16_STRIDE-th column tile; candidate list capacity per row
+#define LR_NN16_STRIDE 4
+#define LR_NN16_CAP 64
+enum { LR_NN_PATH_F16_FILTER = 0, LR_NN_PATH_FP32_MFMA = 1 };
 
 struct lr_workspace {
     int max_n0, max_n1, max_n, dim, max_iters;
@@ -41,6 +45,11 @@ struct lr_workspace {
     // --- NN (both directions share these) ---
     float *Fp0, *Fp1;            // [n,32] de-interleaved copies (even k | odd k)
     float *nrm0, *nrm1;          // row norms
+    _Float16 *H0, *H1;           // [n,32] f16 copies for the matrix-core filter passes
+    float *tau;                  // [max_n] per-row candidate threshold
+    int32_t *cand_cnt, *cand;    // [max_n], [max_n][LR_NN16_CAP] candidate lists
+    uint32_t *max_norm;          // [2] bit patterns of max_i n0_i, max_j n1_j
+    int nn_path;                 // LR_NN_PATH_*
     float *pb1, *pb2, *pb3;      // partial top-3 values [strips][max_n]
     int32_t *pi1, *pi2;          // partial top-2 indices
     int32_t *fix_list;           // rows needing the exact tie-break path [max_n]
@@ -91,6 +100,14 @@ enum {
 int lr_nn_run(lr_workspace *ws, const float *Fa, const float *nrma, int na, const float *Fb, const float *nrmb, int nb,
               int32_t *idx1, int32_t *idx2, float *s1, float *s2, hipStream_t st);
 int lr_nn_prep(lr_workspace *ws, const float *F, int n, float *Fp, float *nrm, hipStream_t st);
+
+// lr_nn16.hip
+int lr_nn16_prep(lr_workspace *ws, const float *F, int n, float *Fp, _Float16 *H, float *nrm, uint32_t *max_bits, hipStream_t st);
+int lr_nn16_run(lr_workspace *ws, const float *Fq, const float *Fpq, const _Float16 *Hq, const float *nQ, int na,
+                const float *Fc, const float *Fpc, const _Float16 *Hc, const float *nC, const uint32_t *max_c_bits, int nb,
+                int need, int32_t *idx1, int32_t *idx2, float *s1, float *s2, hipStream_t st);
+int lr_nn_fix_rows(lr_workspace *ws, const float *Fpa, const float *nrma, const float *Fpb, const float *nrmb, int nb,
+                   int32_t *idx1, int32_t *idx2, float *s1, float *s2, hipStream_t st);
 
 // lr_filter.hip
 int lr_mutual_run(lr_workspace *ws, int n0, const int32_t *idx1, const int32_t *idx2, const int32_t *rev,

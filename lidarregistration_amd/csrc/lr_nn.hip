@@ -304,6 +304,15 @@ int lr_nn_prep(lr_workspace *ws, const float *F, int n, float *Fp, float *nrm, h
     return LR_OK;
 }
 
+int lr_nn_fix_rows(lr_workspace *ws, const float *Fpa, const float *nrma, const float *Fpb, const float *nrmb, int nb,
+                   int32_t *idx1, int32_t *idx2, float *s1, float *s2, hipStream_t st)
+{
+    hipLaunchKernelGGL(nn_fix_kernel, dim3(256), dim3(64), 0, st, Fpa, nrma, Fpb, nrmb, nb, ws->fix_list, ws->counters,
+                       idx1, idx2, s1, s2);
+    LR_LAUNCH_CHECK();
+    return LR_OK;
+}
+
 static int pick_strips(int na, int nb)
 {
     // aim for >= 2 waves per SIMD (2048 waves on 256 CUs) without making strips shorter than 1024 columns
