@@ -40,7 +40,7 @@ void carve(lr_workspace *ws, Carver &c)
     ws->nrm0 = c.take<float>(n0); ws->nrm1 = c.take<float>(n1);
     ws->H0 = c.take<_Float16>(n0 * 32); ws->H1 = c.take<_Float16>(n1 * 32);
     ws->tau = c.take<float>(n);
-    ws->cand_cnt = c.take<int32_t>(n); ws->cand = c.take<int32_t>(n * LR_NN16_CAP);
+    ws->cand_cnt = c.take<int32_t>(n * LR_NN_MAX_STRIPS); ws->cand = c.take<int32_t>(n * LR_NN_MAX_STRIPS * LR_NN16_CAPS);
     ws->max_norm = c.take<uint32_t>(2);
     ws->pb1 = c.take<float>(n * LR_NN_MAX_STRIPS); ws->pb2 = c.take<float>(n * LR_NN_MAX_STRIPS);
     ws->pb3 = c.take<float>(n * LR_NN_MAX_STRIPS);
@@ -77,6 +77,7 @@ extern "C" int lr_workspace_create(lr_workspace **out, int max_n0, int max_n1, i
     LR_REQUIRE(out, LR_EINVAL, "lr_workspace_create: null output");
     LR_REQUIRE(max_n0 > 0 && max_n1 > 0 && max_iters >= 0, LR_EINVAL, "lr_workspace_create: sizes must be positive");
     LR_REQUIRE(dim == LR_FEAT_DIM, LR_EINVAL, "lr_workspace_create: only 32-d descriptors (FCGF) are supported");
+    LR_REQUIRE(max_n0 < (1 << 24) && max_n1 < (1 << 24), LR_ESIZE, "lr_workspace_create: clouds are limited to 2^24 points");
     lr_workspace *ws = new (std::nothrow) lr_workspace();
     LR_REQUIRE(ws, LR_ENOMEM, "lr_workspace_create: host allocation failed");
     memset(ws, 0, sizeof(*ws));

@@ -35,7 +35,8 @@ static inline int lr_cdiv(int a, int b) { return (a + b - 1) / b; }
 #define LR_GPF_MAX_CELLS 4096
 // f16 filter path: pass A samples every LR_NN16_STRIDE-th column tile; candidate list capacity per row
 #define LR_NN16_STRIDE 4
-#define LR_NN16_CAP 64
+#define LR_NN16_CAPS 16      // candidate slots per (row, strip)
+#define LR_NN16_LIST 2048    // per-block LDS candidate list (256 rows x one strip); columns must be < 2^24
 enum { LR_NN_PATH_F16_FILTER = 0, LR_NN_PATH_FP32_MFMA = 1 };
 
 struct lr_workspace {
@@ -47,7 +48,7 @@ struct lr_workspace {
     float *nrm0, *nrm1;          // row norms
     _Float16 *H0, *H1;           // [n,32] f16 copies for the matrix-core filter passes
     float *tau;                  // [max_n] per-row candidate threshold
-    int32_t *cand_cnt, *cand;    // [max_n], [max_n][LR_NN16_CAP] candidate lists
+    int32_t *cand_cnt, *cand;    // [max_n][strips], [max_n][strips][LR_NN16_CAPS] candidate lists
     uint32_t *max_norm;          // [2] bit patterns of max_i n0_i, max_j n1_j
     int nn_path;                 // LR_NN_PATH_*
     float *pb1, *pb2, *pb3;      // partial top-3 values [strips][max_n]

@@ -77,24 +77,41 @@ nn16_prep_kernel(const float *__restrict__ F, int n, float *__restrict__ Fp, _Fl
 }
 
 // ------------------------------------------------------------------ pass A / pass B
-// One wave = 64 query rows (two 32-row MFMA blocks) x the column tiles of its strip.
-//   MODE 0 (pass A): running (u1, u2) per accumulator element over the sampled tiles -> partials [strip][row]
-//   MODE 1 (pass B): compare against tau[row]; passing (row, col) are appended to the row's candidate list
+// Block = 4 waves x 64 query rows = 256 rows; the block walks the column tiles of its strip in chunks of LR_CH
+// tiles that are staged once through LDS (register-staged, double-buffered, one barrier per chunk) and shared by
+// the four waves.  LDS image: one 80-byte row per column (64 B of f16 + 16 B pad): with that stride the two
+// ds_read_b128 of a fragment are bank-conflict-free for the b128 lane groups.
+//
+//   MODE 0 (pass A): running two largest g = dot16 - n1[j]/2 per accumulator element over the sampled tiles
+//                    (u' = -2 g, so the two largest g are the two smallest u') -> partials [strip][row]
+//   MODE 1 (pass B): the accumulator is started at y_i = tau_i / 2 instead of 0, so the candidate test
+//                    u' <= tau_i  <=>  dot16 + y_i >= n1[j]/2  is ONE v_cmp per element; lane masks are OR-ed on
+//                    the scalar unit and looked at once per 8 accumulator registers.  Candidates are appended to
+//                    the (row, strip) slot list; the per-row counters live in LDS (rows are private to the block
+//                    within a strip), so the hot loop issues no global atomics.
+#define LR_CH 4
+#define LR_LDS_ROW 80
 template <int MODE>
 __global__ void __launch_bounds__(256)
 nn16_pass_kernel(const _Float16 *__restrict__ Hq, int na, const _Float16 *__restrict__ Hc, const float *__restrict__ nC, int nb,
                  int tiles_per_strip, int tile_stride, int part_stride,
-                 float *__restrict__ pu1, float *__restrict__ pu2,
-                 const float *__restrict__ tau, int32_t *__restrict__ cand_cnt, int32_t *__restrict__ cand, int cap)
+                 float *__restrict__ pg1, float *__restrict__ pg2,
+                 const float *__restrict__ tau, int32_t *__restrict__ cand_cnt, int32_t *__restrict__ cand)
 {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][LR_CH * 32 * LR_LDS_ROW + LR_CH * 32 * 4];
+    __shared__ int s_cnt[256];
+    __shared__ int s_list[LR_NN16_LIST];      // block-level candidate list: (local row << 24) | chunk-relative info, see below
+    __shared__ int s_n;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r = lane & 31, h = lane >> 5;
     const int row0 = (blockIdx.x * 4 + wave) * 64;
-    if (row0 >= na) return;
-    const int strip = blockIdx.y;
+    const int strip = blockIdx.y, nstrips = gridDim.y;
     const int ntiles = (nb + 31) >> 5;
     const int t_begin = strip * tiles_per_strip;
     const int t_end = min(ntiles, t_begin + tiles_per_strip);
+    const int nsamp = t_end > t_begin ? (t_end - t_begin + tile_stride - 1) / tile_stride : 0;   // tiles this block visits
+    const int nchunks = (nsamp + LR_CH - 1) / LR_CH;
+    if (MODE == 1) { s_cnt[tid] = 0; if (tid == 0) s_n = 0; }
 
     f16x8 a[2][2];
 #pragma unroll
@@ -103,96 +120,136 @@ nn16_pass_kernel(const _Float16 *__restrict__ Hq, int na, const _Float16 *__rest
         const f16x8 *p = reinterpret_cast<const f16x8 *>(Hq + (size_t)row * 32 + 16 * h);
         a[rb][0] = p[0]; a[rb][1] = p[1];
     }
-
-    float u1[2][16], u2[2][16];      // MODE 0 state; MODE 1: u1 holds tau per element row
+    f32x16 st1[2], st2[2];      // MODE 0: running two largest g; MODE 1: st1 = y = tau/2 of the element's row
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
-            if (MODE == 0) { u1[rb][g] = LR_INF; u2[rb][g] = LR_INF; }
+            if (MODE == 0) { st1[rb][g] = -LR_INF; st2[rb][g] = -LR_INF; }
             else {
                 const int row = row0 + 32 * rb + (g & 3) + 8 * (g >> 2) + 4 * h;
-                u1[rb][g] = row < na ? tau[row] : -LR_INF;
-                u2[rb][g] = 0.0f;
+                st1[rb][g] = row < na ? 0.5f * tau[row] : -LR_INF;
+                st2[rb][g] = 0.0f;
             }
         }
 
-    // software prefetch of the next candidate fragment
-    f16x8 bn0, bn1;
-    float nbn;
-    {
-        const int col = t_begin * 32 + r;
-        const f16x8 *p = reinterpret_cast<const f16x8 *>(Hc + (size_t)min(col, nb - 1) * 32 + 16 * h);
-        bn0 = p[0]; bn1 = p[1];
-        const float nv = nC[min(col, nb - 1)];
-        nbn = col < nb ? nv : LR_INF;
-    }
-    for (int t = t_begin; t < t_end; t += tile_stride) {
-        const f16x8 b0 = bn0, b1 = bn1;
-        const float nbv = nbn;
-        const int col = t * 32 + r;
-        if (t + tile_stride < t_end) {
-            const int coln = col + 32 * tile_stride;
-            const f16x8 *p = reinterpret_cast<const f16x8 *>(Hc + (size_t)min(coln, nb - 1) * 32 + 16 * h);
-            bn0 = p[0]; bn1 = p[1];
-            const float nv = nC[min(coln, nb - 1)];
-            nbn = coln < nb ? nv : LR_INF;
+    // staging: thread t moves two 16-byte pieces per chunk (piece p -> column p/4 of the chunk, 16-byte part p%4)
+    f32x4 stage[2];
+    float stage_n = LR_INF;
+    auto chunk_col = [&](int c, int lc) {      // global column of local column lc (0..LR_CH*32) of chunk c
+        const int k = lc >> 5;
+        return (t_begin + (c * LR_CH + k) * tile_stride) * 32 + (lc & 31);
+    };
+    auto load_chunk = [&](int c) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int p = tid + 256 * q;
+            const int col = chunk_col(c, p >> 2);
+            stage[q] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const unsigned char *>(Hc) + (size_t)min(col, nb - 1) * 64 + (p & 3) * 16);
         }
-        f32x16 acc[2];
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-            acc[rb] = f32x16{ 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-            acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rb][0], b0, acc[rb], 0, 0, 0);
-            acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rb][1], b1, acc[rb], 0, 0, 0);
+        if (tid < LR_CH * 32) {
+            const int col = chunk_col(c, tid);
+            const int tile = t_begin + (c * LR_CH + (tid >> 5)) * tile_stride;
+            const float nv = nC[min(col, nb - 1)];
+            stage_n = (col < nb && tile < t_end) ? 0.5f * nv : LR_INF;     // x_j = n1[j]/2 ; +inf masks columns past the end
         }
-        if (MODE == 0) {
+    };
+    auto store_chunk = [&](int buf) {
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
+        for (int q = 0; q < 2; ++q) {
+            const int p = tid + 256 * q;
+            *reinterpret_cast<f32x4 *>(&lds[buf][(p >> 2) * LR_LDS_ROW + (p & 3) * 16]) = stage[q];
+        }
+        if (tid < LR_CH * 32) *reinterpret_cast<float *>(&lds[buf][LR_CH * 32 * LR_LDS_ROW + tid * 4]) = stage_n;
+    };
+
+    if (nchunks > 0) { load_chunk(0); store_chunk(0); }
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) load_chunk(c + 1);
+        if (row0 < na) {
+#pragma unroll 2
+            for (int k = 0; k < LR_CH; ++k) {
+                const unsigned char *bp = &lds[buf][(32 * k + r) * LR_LDS_ROW + 32 * h];
+                const f16x8 b0 = *reinterpret_cast<const f16x8 *>(bp);
+                const f16x8 b1 = *reinterpret_cast<const f16x8 *>(bp + 16);
+                const float xj = *reinterpret_cast<const float *>(&lds[buf][LR_CH * 32 * LR_LDS_ROW + (32 * k + r) * 4]);
+                f32x16 acc[2];
 #pragma unroll
-                for (int g = 0; g < 16; ++g) {
-                    const float u = __builtin_fmaf(-2.0f, acc[rb][g], nbv);
-                    u2[rb][g] = __builtin_amdgcn_fmed3f(u1[rb][g], u2[rb][g], u);
-                    u1[rb][g] = fminf(u1[rb][g], u);
+                for (int rb = 0; rb < 2; ++rb) {
+                    if (MODE == 0) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rb][0], b0, f32x16{ 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, 0, 0, 0);
+                    else acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rb][0], b0, st1[rb], 0, 0, 0);
+                    acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rb][1], b1, acc[rb], 0, 0, 0);
                 }
-        } else {
-            bool any = false;
+                if (MODE == 0) {
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
+                    for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-                for (int g = 0; g < 16; ++g) {
-                    const float u = __builtin_fmaf(-2.0f, acc[rb][g], nbv);
-                    any |= (u <= u1[rb][g]);
-                }
-            if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
-                // rare: some lane holds a candidate in this tile
-#pragma unroll
-                for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-                    for (int g = 0; g < 16; ++g) {
-                        const float u = __builtin_fmaf(-2.0f, acc[rb][g], nbv);
-                        if (u <= u1[rb][g]) {
-                            const int row = row0 + 32 * rb + (g & 3) + 8 * (g >> 2) + 4 * h;
-                            const int slot = atomicAdd(&cand_cnt[row], 1);
-                            if (slot < cap) cand[(size_t)row * cap + slot] = col;
+                        for (int g = 0; g < 16; ++g) {
+                            const float gv = acc[rb][g] - xj;
+                            st2[rb][g] = __builtin_amdgcn_fmed3f(st1[rb][g], st2[rb][g], gv);
+                            st1[rb][g] = fmaxf(st1[rb][g], gv);
                         }
-                    }
+                } else {
+#pragma unroll
+                    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                        for (int g0 = 0; g0 < 16; g0 += 8) {
+                            bool any = false;
+#pragma unroll
+                            for (int g = g0; g < g0 + 8; ++g) any |= (acc[rb][g] >= xj);
+                            if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
+                                // some lane of the wave holds a candidate among these 8 x 64 elements: park (row, column)
+                                // in the block's LDS list; it is sorted into the per-row slots after the main loop, so this
+                                // path stays light on registers (one LDS atomic + one LDS store per candidate)
+                                const int col = chunk_col(c, 32 * k + r);
+                                const int lbase = (wave * 64 + 32 * rb + 4 * h) << 24;
+#pragma unroll
+                                for (int g = g0; g < g0 + 8; ++g)
+                                    if (acc[rb][g] >= xj) {
+                                        const int slot = atomicAdd(&s_n, 1);
+                                        if (slot < LR_NN16_LIST) s_list[slot] = (lbase + (((g & 3) + 8 * (g >> 2)) << 24)) | col;
+                                    }
+                            }
+                        }
+                }
             }
         }
+        if (c + 1 < nchunks) store_chunk(buf ^ 1);
+        __syncthreads();
     }
 
-    if (MODE == 0) {
+    if (MODE == 1) {
+        // distribute the parked candidates to the (row, strip) slot lists; a block that overflowed its LDS list marks
+        // all its rows as overflowed, which sends them through the exact row kernel
+        const int n_list = s_n;
+        const bool over = n_list > LR_NN16_LIST;
+        for (int e = tid; e < min(n_list, LR_NN16_LIST); e += 256) {
+            const int v = s_list[e];
+            const int lrow = (v >> 24) & 0xff, col = v & 0xffffff;
+            const int slot = atomicAdd(&s_cnt[lrow], 1);
+            if (slot < LR_NN16_CAPS) cand[((size_t)(blockIdx.x * 256 + lrow) * nstrips + strip) * LR_NN16_CAPS + slot] = col;
+        }
+        __syncthreads();
+        const int row = blockIdx.x * 256 + tid;
+        if (row < na) cand_cnt[(size_t)row * nstrips + strip] = over ? LR_NN16_CAPS + 1 : s_cnt[tid];
+    }
+    if (MODE == 0 && row0 < na) {
         // fold the 32 lanes (columns) of each half; values only
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
+                float v1 = st1[rb][g], v2 = st2[rb][g];
 #pragma unroll
                 for (int m = 1; m < 32; m <<= 1) {
-                    const float c1 = __shfl_xor(u1[rb][g], m), c2 = __shfl_xor(u2[rb][g], m);
-                    const float lo = fminf(u1[rb][g], c1), hi = fmaxf(u1[rb][g], c1);
-                    u2[rb][g] = fminf(hi, fminf(u2[rb][g], c2));
-                    u1[rb][g] = lo;
+                    const float c1 = __shfl_xor(v1, m), c2 = __shfl_xor(v2, m);
+                    const float hi = fmaxf(v1, c1), lo = fminf(v1, c1);
+                    v2 = fmaxf(lo, fmaxf(v2, c2));
+                    v1 = hi;
                 }
+                st1[rb][g] = v1; st2[rb][g] = v2;
             }
         if (r == 0) {
             const size_t base = (size_t)strip * part_stride;
@@ -201,34 +258,34 @@ nn16_pass_kernel(const _Float16 *__restrict__ Hq, int na, const _Float16 *__rest
 #pragma unroll
                 for (int g = 0; g < 16; ++g) {
                     const int row = row0 + 32 * rb + (g & 3) + 8 * (g >> 2) + 4 * h;
-                    if (row < na) { pu1[base + row] = u1[rb][g]; pu2[base + row] = u2[rb][g]; }
+                    if (row < na) { pg1[base + row] = st1[rb][g]; pg2[base + row] = st2[rb][g]; }
                 }
         }
     }
 }
 
 // ------------------------------------------------------------------ thresholds
+// U = need-th smallest sampled u' = -2 * (need-th largest g)
 __global__ void __launch_bounds__(256)
-nn16_thresh_kernel(int na, int nstrips, int part_stride, const float *__restrict__ pu1, const float *__restrict__ pu2,
+nn16_thresh_kernel(int na, int nstrips, int part_stride, const float *__restrict__ pg1, const float *__restrict__ pg2,
                    const float *__restrict__ nQ, const uint32_t *__restrict__ max_norm_c_bits, int need,
-                   float *__restrict__ tau, int32_t *__restrict__ cand_cnt)
+                   float *__restrict__ tau, int32_t *__restrict__ counters)
 {
     const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row == 0) counters[LR_CNT_FIX] = 0;
     if (row >= na) return;
-    float a1 = pu1[row], a2 = pu2[row];
+    float a1 = pg1[row], a2 = pg2[row];
     for (int s = 1; s < nstrips; ++s) {
-        const float c1 = pu1[(size_t)s * part_stride + row], c2 = pu2[(size_t)s * part_stride + row];
-        const float lo = fminf(a1, c1), hi = fmaxf(a1, c1);
-        a2 = fminf(hi, fminf(a2, c2));
-        a1 = lo;
+        const float c1 = pg1[(size_t)s * part_stride + row], c2 = pg2[(size_t)s * part_stride + row];
+        const float hi = fmaxf(a1, c1), lo = fminf(a1, c1);
+        a2 = fmaxf(lo, fmaxf(a2, c2));
+        a1 = hi;
     }
-    const float U = need >= 2 ? a2 : a1;
+    const float U = -2.0f * (need >= 2 ? a2 : a1);
     const float scale = nQ[row] + __uint_as_float(*max_norm_c_bits);
     const float E = 1.05e-3f * scale + 4e-7f;
-    // U + 2E + sqrt band 2^-21 (n0 + U + E) + rounding slop of this very expression
-    float t = U + 2.0f * E + 3e-6f * scale + 1e-6f * fabsf(U);
-    tau[row] = t;            // +inf when fewer than `need` columns were sampled: every column becomes a candidate
-    cand_cnt[row] = 0;
+    // U + 2E + sqrt band 2^-21 (n0 + U + E) + rounding slop (this expression, y = tau/2 folded into the MFMA accumulator)
+    tau[row] = U + 2.0f * E + 6e-6f * scale + 2e-6f * fabsf(U);   // +inf when fewer than `need` columns were sampled
 }
 
 // ------------------------------------------------------------------ exact verification of the candidates
@@ -236,15 +293,20 @@ nn16_thresh_kernel(int na, int nstrips, int part_stride, const float *__restrict
 __global__ void __launch_bounds__(128)
 nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, int na,
                   const float *__restrict__ Fc, const float *__restrict__ nC, int nb,
-                  const int32_t *__restrict__ cand_cnt, const int32_t *__restrict__ cand, int cap, int need,
+                  const int32_t *__restrict__ cand_cnt, const int32_t *__restrict__ cand, int nstrips, int need,
                   int32_t *__restrict__ idx1, int32_t *__restrict__ idx2, float *__restrict__ s1o, float *__restrict__ s2o,
                   int32_t *__restrict__ fix_list, int32_t *__restrict__ counters)
 {
     const int row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= na) return;
-    const int cnt = cand_cnt[row];
-    const int want = min(need, nb);
-    if (cnt > cap || cnt < want) {
+    int total = 0;
+    bool overflow = false;
+    for (int s = 0; s < nstrips; ++s) {
+        const int c = cand_cnt[(size_t)row * nstrips + s];
+        total += c;
+        overflow |= c > LR_NN16_CAPS;
+    }
+    if (overflow || total < min(need, nb)) {
         const int slot = atomicAdd(&counters[LR_CNT_FIX], 1);
         fix_list[slot] = row;
         return;
@@ -256,26 +318,29 @@ nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, in
     const float nq = nQ[row];
     float b1 = LR_INF, b2 = LR_INF;
     int i1 = LR_IMAX, i2 = LR_IMAX;
-    for (int c = 0; c < cnt; ++c) {
-        const int j = cand[(size_t)row * cap + c];
-        const f32x4 *pb = reinterpret_cast<const f32x4 *>(Fc + (size_t)j * 32);
-        float acc = 0.0f;
+    for (int s = 0; s < nstrips; ++s) {
+        const int cnt = cand_cnt[(size_t)row * nstrips + s];
+        for (int c = 0; c < cnt; ++c) {
+            const int j = cand[((size_t)row * nstrips + s) * LR_NN16_CAPS + c];
+            const f32x4 *pb = reinterpret_cast<const f32x4 *>(Fc + (size_t)j * 32);
+            float acc = 0.0f;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const f32x4 t = pb[q];
-            acc = __builtin_fmaf(a[4 * q], t.x, acc);
-            acc = __builtin_fmaf(a[4 * q + 1], t.y, acc);
-            acc = __builtin_fmaf(a[4 * q + 2], t.z, acc);
-            acc = __builtin_fmaf(a[4 * q + 3], t.w, acc);
+            for (int q = 0; q < 8; ++q) {
+                const f32x4 t = pb[q];
+                acc = __builtin_fmaf(a[4 * q], t.x, acc);
+                acc = __builtin_fmaf(a[4 * q + 1], t.y, acc);
+                acc = __builtin_fmaf(a[4 * q + 2], t.z, acc);
+                acc = __builtin_fmaf(a[4 * q + 3], t.w, acc);
+            }
+            const float tt = nq + nC[j];
+            const float d2 = __builtin_fmaf(-2.0f, acc, tt);
+            const float sv = __builtin_sqrtf(fmaxf(d2, 1e-30f));
+            // candidates arrive in arbitrary order: order by (sqrt value, index)
+            const bool lt1 = sv < b1 || (sv == b1 && j < i1);
+            const bool lt2 = sv < b2 || (sv == b2 && j < i2);
+            if (lt1) { b2 = b1; i2 = i1; b1 = sv; i1 = j; }
+            else if (lt2) { b2 = sv; i2 = j; }
         }
-        const float tt = nq + nC[j];
-        const float d2 = __builtin_fmaf(-2.0f, acc, tt);
-        const float s = __builtin_sqrtf(fmaxf(d2, 1e-30f));
-        // candidates arrive in arbitrary order: order by (s, j)
-        const bool lt1 = s < b1 || (s == b1 && j < i1);
-        const bool lt2 = s < b2 || (s == b2 && j < i2);
-        if (lt1) { b2 = b1; i2 = i1; b1 = s; i1 = j; }
-        else if (lt2) { b2 = s; i2 = j; }
     }
     idx1[row] = i1;
     if (idx2) idx2[row] = i2;
@@ -303,25 +368,24 @@ int lr_nn16_run(lr_workspace *ws, const float *Fq, const float *Fpq, const _Floa
     int stride = ntiles / 16;
     if (stride > LR_NN16_STRIDE) stride = LR_NN16_STRIDE;
     if (stride < 1) stride = 1;
-    // strips: enough blocks to fill 256 CUs a few times over, at least 8 tiles per strip
+    // strips: enough blocks to fill 256 CUs a few times over, at least 8 sampled tiles per strip
     int strips = lr_cdiv(1024, row_blocks);
     int smax = ntiles / (8 * stride);
     if (strips > smax) strips = smax;
     if (strips > LR_NN_MAX_STRIPS) strips = LR_NN_MAX_STRIPS;
     if (strips < 1) strips = 1;
-    int tps = lr_cdiv(lr_cdiv(ntiles, strips), stride) * stride;     // tiles per strip, multiple of the stride
-    LR_HIP(hipMemsetAsync(ws->counters + LR_CNT_FIX, 0, sizeof(int32_t), st));
+    const int tps = lr_cdiv(lr_cdiv(ntiles, strips), stride) * stride;     // tiles per strip, multiple of the stride
     dim3 grid(row_blocks, strips);
     hipLaunchKernelGGL(nn16_pass_kernel<0>, grid, dim3(256), 0, st, Hq, na, Hc, nC, nb, tps, stride, ws->max_n, ws->pb1, ws->pb2,
-                       (const float *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, 0);
+                       (const float *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
     hipLaunchKernelGGL(nn16_thresh_kernel, dim3(lr_cdiv(na, 256)), dim3(256), 0, st, na, strips, ws->max_n, ws->pb1, ws->pb2, nQ,
-                       max_c_bits, need, ws->tau, ws->cand_cnt);
+                       max_c_bits, need, ws->tau, ws->counters);
     if (ws->timing && !ws->ev_pending) { LR_HIP(hipEventRecord(ws->ev[0], st)); }
     hipLaunchKernelGGL(nn16_pass_kernel<1>, grid, dim3(256), 0, st, Hq, na, Hc, nC, nb, tps, 1, ws->max_n, (float *)nullptr,
-                       (float *)nullptr, ws->tau, ws->cand_cnt, ws->cand, LR_NN16_CAP);
+                       (float *)nullptr, ws->tau, ws->cand_cnt, ws->cand);
     if (ws->timing && !ws->ev_pending) { LR_HIP(hipEventRecord(ws->ev[1], st)); ws->ev_pending = 1; }
     hipLaunchKernelGGL(nn16_exact_kernel, dim3(lr_cdiv(na, 128)), dim3(128), 0, st, Fq, nQ, na, Fc, nC, nb, ws->cand_cnt, ws->cand,
-                       LR_NN16_CAP, need, idx1, idx2, s1, s2, ws->fix_list, ws->counters);
+                       strips, need, idx1, idx2, s1, s2, ws->fix_list, ws->counters);
     LR_LAUNCH_CHECK();
     return lr_nn_fix_rows(ws, Fpq, nQ, Fpc, nC, nb, idx1, idx2, s1, s2, st);
 }

@@ -1,0 +1,51 @@
+// Timing harness for nn16_pass_kernel (development tool).  hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tools/nn16_micro.hip -o tools/bin/nn16_micro
+#include "../lidarregistration_amd/csrc/lr_nn16.hip"
+#include <vector>
+#include <random>
+void lr_set_error(const char *, ...) {}
+int lr_nn_fix_rows(lr_workspace *, const float *, const float *, const float *, const float *, int, int32_t *, int32_t *, float *, float *, hipStream_t) { return 0; }
+template <class F> float timeit(F f, int reps = 20) {
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int w = 0; w < 3; ++w) f();
+    hipDeviceSynchronize();
+    float best = 1e9;
+    for (int r = 0; r < reps; ++r) { hipEventRecord(e0, 0); f(); hipEventRecord(e1, 0); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); best = ms < best ? ms : best; }
+    return best;
+}
+int main(int argc, char **argv)
+{
+    int n = argc > 1 ? atoi(argv[1]) : 30000;
+    int strips = argc > 2 ? atoi(argv[2]) : 8;
+    std::vector<float> h((size_t)n * 32);
+    std::mt19937 rng(1); std::normal_distribution<float> nd;
+    for (size_t r = 0; r < (size_t)n; ++r) { double s = 0; for (int k = 0; k < 32; ++k) { h[r*32+k] = nd(rng); s += h[r*32+k]*h[r*32+k]; } for (int k = 0; k < 32; ++k) h[r*32+k] /= (float)sqrt(s); }
+    float *F, *Fp, *nrm, *pu1, *pu2, *tau; _Float16 *H; uint32_t *mx; int32_t *cnt, *cand;
+    hipMalloc(&F, (size_t)n*128); hipMalloc(&Fp, (size_t)n*128); hipMalloc(&H, (size_t)n*64); hipMalloc(&nrm, n*4); hipMalloc(&mx, 8);
+    hipMalloc(&pu1, (size_t)n*4*8); hipMalloc(&pu2, (size_t)n*4*8); hipMalloc(&tau, n*4); hipMalloc(&cnt, n*4*8); hipMalloc(&cand, (size_t)n*4*8*16);
+    hipMemcpy(F, h.data(), (size_t)n*128, hipMemcpyHostToDevice);
+    hipMemset(mx, 0, 8);
+    hipLaunchKernelGGL(nn16_prep_kernel, dim3((n+255)/256), dim3(256), 0, 0, F, n, Fp, H, nrm, mx);
+    int ntiles = (n + 31) / 32;
+    int row_blocks = (n + 255) / 256;
+    for (int stride : {1, 2, 4}) {
+        int tps = ((ntiles + strips - 1) / strips + stride - 1) / stride * stride;
+        dim3 grid(row_blocks, strips);
+        float ms = timeit([&] { hipLaunchKernelGGL(nn16_pass_kernel<0>, grid, dim3(256), 0, 0, H, n, H, nrm, n, tps, stride, n, pu1, pu2, (const float*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr); });
+        printf("passA stride %d strips %d: %.3f ms\n", stride, strips, ms);
+        // thresholds from this pass A, then pass B
+        hipLaunchKernelGGL(nn16_thresh_kernel, dim3((n+255)/256), dim3(256), 0, 0, n, strips, n, pu1, pu2, nrm, mx + 0, 2, tau, cnt);  // cnt doubles as the counters block here
+        int tpsb = (ntiles + strips - 1) / strips;
+        float msb = timeit([&] { hipLaunchKernelGGL(nn16_pass_kernel<1>, grid, dim3(256), 0, 0, H, n, H, nrm, n, tpsb, 1, n, (float*)nullptr, (float*)nullptr, tau, cnt, cand); });
+        std::vector<int32_t> hc((size_t)n*strips); hipMemcpy(hc.data(), cnt, (size_t)n*strips*4, hipMemcpyDeviceToHost);
+        double tot = 0; int mxc = 0; for (int v : hc) { tot += v; mxc = v > mxc ? v : mxc; }
+        printf("passB (thresholds from stride %d): %.3f ms   candidates/row avg %.2f max %d\n", stride, msb, tot / n, mxc);
+    }
+    // pass B with no candidates at all (pure fast path)
+    {
+        std::vector<float> t(n, -1e30f); hipMemcpy(tau, t.data(), n*4, hipMemcpyHostToDevice);
+        int tpsb = (ntiles + strips - 1) / strips; dim3 grid(row_blocks, strips);
+        float msb = timeit([&] { hipLaunchKernelGGL(nn16_pass_kernel<1>, grid, dim3(256), 0, 0, H, n, H, nrm, n, tpsb, 1, n, (float*)nullptr, (float*)nullptr, tau, cnt, cand); });
+        printf("passB no candidates: %.3f ms\n", msb);
+    }
+    return 0;
+}
