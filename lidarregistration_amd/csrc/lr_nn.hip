@@ -119,14 +119,7 @@ nn_strip_kernel(const float *__restrict__ Ap, const float *__restrict__ nA, int 
         float nv_ = nB[min(col_, nb - 1)];                                                                    \
         ndst = col_ < c_end ? nv_ : LR_INF;                                                                   \
     }
-#if defined(LR_NN_NO_UPDATE) || defined(LR_NN_NO_SCHED)
-#define LR_SCHED_HINT
-#else
 #define LR_SCHED_HINT __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 11, 0);
-#endif
-#ifdef LR_NN_NO_UPDATE
-#define LR_UPDATE(g, accv, colv, nbv) { b1[g] = fminf(b1[g], accv); }
-#else
 #define LR_UPDATE(g, accv, colv, nbv)                                                                         \
     {                                                                                                         \
         float t_ = nq[g] + (nbv);                                                                             \
@@ -141,7 +134,6 @@ nn_strip_kernel(const float *__restrict__ Ap, const float *__restrict__ nA, int 
         i2[g] = lt1_ ? oi1_ : k2_;                                                                            \
         i1[g] = lt1_ ? (colv) : oi1_;                                                                         \
     }
-#endif
     // one pipeline stage: multiply tile (bt) into accN while folding accC (tile at column colC) into the state
 #define LR_STAGE(accN, bt, accC, colC, nbC)                                                                   \
     {                                                                                                         \
@@ -186,6 +178,7 @@ nn_strip_kernel(const float *__restrict__ Ap, const float *__restrict__ nA, int 
         }
     }
 #undef LR_STAGE
+#undef LR_SCHED_HINT
 #undef LR_UPDATE
 #undef LR_LOAD_B
 

@@ -127,40 +127,70 @@ nn16_pass_kernel(const _Float16 *__restrict__ Hq, int na, const _Float16 *__rest
         for (int g = 0; g < 16; ++g) {
             if (MODE == 0) { st1[rb][g] = -LR_INF; st2[rb][g] = -LR_INF; }
             else {
+                // unconditional (clamped) loads: a conditional load here turns into 32 serialized round trips
                 const int row = row0 + 32 * rb + (g & 3) + 8 * (g >> 2) + 4 * h;
-                st1[rb][g] = row < na ? 0.5f * tau[row] : -LR_INF;
+                const float tv = tau[min(row, na - 1)];
+                st1[rb][g] = row < na ? 0.5f * tv : -LR_INF;
                 st2[rb][g] = 0.0f;
             }
         }
 
     // staging: thread t moves two 16-byte pieces per chunk (piece p -> column p/4 of the chunk, 16-byte part p%4)
-    f32x4 stage[2];
-    float stage_n = LR_INF;
+    f32x4 stage[LR_CH / 2];
+    float stage_n = 0.0f;        // raw norm of the staged column: NOT touched until store_chunk, so that the compiler's
+    bool stage_ok = false;       // s_waitcnt for it lands after the tile loop instead of right behind the prefetch
     auto chunk_col = [&](int c, int lc) {      // global column of local column lc (0..LR_CH*32) of chunk c
         const int k = lc >> 5;
         return (t_begin + (c * LR_CH + k) * tile_stride) * 32 + (lc & 31);
     };
     auto load_chunk = [&](int c) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < LR_CH / 2; ++q) {
             const int p = tid + 256 * q;
             const int col = chunk_col(c, p >> 2);
             stage[q] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const unsigned char *>(Hc) + (size_t)min(col, nb - 1) * 64 + (p & 3) * 16);
         }
-        if (tid < LR_CH * 32) {
-            const int col = chunk_col(c, tid);
-            const int tile = t_begin + (c * LR_CH + (tid >> 5)) * tile_stride;
-            const float nv = nC[min(col, nb - 1)];
-            stage_n = (col < nb && tile < t_end) ? 0.5f * nv : LR_INF;     // x_j = n1[j]/2 ; +inf masks columns past the end
+        {
+            const int lc = tid & (LR_CH * 32 - 1);
+            const int col = chunk_col(c, lc);
+            const int tile = t_begin + (c * LR_CH + (lc >> 5)) * tile_stride;
+            stage_n = nC[min(col, nb - 1)];
+            stage_ok = col < nb && tile < t_end;
         }
     };
     auto store_chunk = [&](int buf) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < LR_CH / 2; ++q) {
             const int p = tid + 256 * q;
             *reinterpret_cast<f32x4 *>(&lds[buf][(p >> 2) * LR_LDS_ROW + (p & 3) * 16]) = stage[q];
         }
-        if (tid < LR_CH * 32) *reinterpret_cast<float *>(&lds[buf][LR_CH * 32 * LR_LDS_ROW + tid * 4]) = stage_n;
+        // x_j = n1[j]/2 ; +inf masks columns past the end of the cloud or of the strip
+        if (tid < LR_CH * 32) *reinterpret_cast<float *>(&lds[buf][LR_CH * 32 * LR_LDS_ROW + tid * 4]) = stage_ok ? 0.5f * stage_n : LR_INF;
+    };
+
+    // one tile of work: fragment read, 2 x 2 MFMAs (accumulators start at y in MODE 1)
+    auto read_b = [&](int buf, int k, f16x8 &b0, f16x8 &b1, float &xj) {
+        const unsigned char *bp = &lds[buf][(32 * k + r) * LR_LDS_ROW + 32 * h];
+        b0 = *reinterpret_cast<const f16x8 *>(bp);
+        b1 = *reinterpret_cast<const f16x8 *>(bp + 16);
+        xj = *reinterpret_cast<const float *>(&lds[buf][LR_CH * 32 * LR_LDS_ROW + (32 * k + r) * 4]);
+    };
+    auto mma = [&](const f16x8 &b0, const f16x8 &b1, f32x16 (&acc)[2]) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            if (MODE == 0) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rb][0], b0, f32x16{ 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, 0, 0, 0);
+            else acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rb][0], b0, st1[rb], 0, 0, 0);
+            acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rb][1], b1, acc[rb], 0, 0, 0);
+        }
+    };
+    // pass A: fold the tile into the per-lane running maximum of g = dot16 - x_j (2 VALU ops per element).  The two largest
+    // of the 32 lane maxima of a row belong to two different columns, so the smaller of them is a valid (and almost always
+    // exact) lower bound of the row's 2nd largest g.
+    auto fold = [&](const f32x16 (&acc)[2], float xj) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) st1[rb][g] = fmaxf(st1[rb][g], acc[rb][g] - xj);
     };
 
     if (nchunks > 0) { load_chunk(0); store_chunk(0); }
@@ -169,29 +199,35 @@ nn16_pass_kernel(const _Float16 *__restrict__ Hq, int na, const _Float16 *__rest
         const int buf = c & 1;
         if (c + 1 < nchunks) load_chunk(c + 1);
         if (row0 < na) {
-#pragma unroll 2
-            for (int k = 0; k < LR_CH; ++k) {
-                const unsigned char *bp = &lds[buf][(32 * k + r) * LR_LDS_ROW + 32 * h];
-                const f16x8 b0 = *reinterpret_cast<const f16x8 *>(bp);
-                const f16x8 b1 = *reinterpret_cast<const f16x8 *>(bp + 16);
-                const float xj = *reinterpret_cast<const float *>(&lds[buf][LR_CH * 32 * LR_LDS_ROW + (32 * k + r) * 4]);
-                f32x16 acc[2];
+            if (MODE == 0) {
+                // software pipeline over the LR_CH tiles of the chunk: the MFMAs of tile k+1 are issued before the VALU
+                // fold of tile k, and the fragment of tile k+1 is read from LDS before the MFMAs of tile k (no branch inside)
+                f16x8 bA0, bA1, bB0, bB1;
+                float xA, xB;
+                f32x16 accA[2], accB[2];
+                read_b(buf, 0, bA0, bA1, xA);
+                read_b(buf, 1, bB0, bB1, xB);
+                mma(bA0, bA1, accA);
+                mma(bB0, bB1, accB);
 #pragma unroll
-                for (int rb = 0; rb < 2; ++rb) {
-                    if (MODE == 0) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rb][0], b0, f32x16{ 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, 0, 0, 0);
-                    else acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rb][0], b0, st1[rb], 0, 0, 0);
-                    acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rb][1], b1, acc[rb], 0, 0, 0);
+                for (int k = 0; k < LR_CH; k += 2) {
+                    const float x0 = xA, x1 = xB;
+                    if (k + 2 < LR_CH) read_b(buf, k + 2, bA0, bA1, xA);
+                    fold(accA, x0);
+                    if (k + 2 < LR_CH) mma(bA0, bA1, accA);
+                    if (k + 3 < LR_CH) read_b(buf, k + 3, bB0, bB1, xB);
+                    fold(accB, x1);
+                    if (k + 3 < LR_CH) mma(bB0, bB1, accB);
                 }
-                if (MODE == 0) {
-#pragma unroll
-                    for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-                        for (int g = 0; g < 16; ++g) {
-                            const float gv = acc[rb][g] - xj;
-                            st2[rb][g] = __builtin_amdgcn_fmed3f(st1[rb][g], st2[rb][g], gv);
-                            st1[rb][g] = fmaxf(st1[rb][g], gv);
-                        }
-                } else {
+            } else {
+                // measured: looking at the accumulators of a tile in four groups of 8 registers (one scalar test each) and
+                // parking the candidates right away beats a branch-free chunk loop that re-multiplies the flagged tiles
+#pragma unroll 2
+                for (int k = 0; k < LR_CH; ++k) {
+                    f16x8 b0, b1; float xj;
+                    f32x16 acc[2];
+                    read_b(buf, k, b0, b1, xj);
+                    mma(b0, b1, acc);
 #pragma unroll
                     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
@@ -200,9 +236,9 @@ nn16_pass_kernel(const _Float16 *__restrict__ Hq, int na, const _Float16 *__rest
 #pragma unroll
                             for (int g = g0; g < g0 + 8; ++g) any |= (acc[rb][g] >= xj);
                             if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
-                                // some lane of the wave holds a candidate among these 8 x 64 elements: park (row, column)
-                                // in the block's LDS list; it is sorted into the per-row slots after the main loop, so this
-                                // path stays light on registers (one LDS atomic + one LDS store per candidate)
+                                // some lane holds a candidate among these 8 x 64 elements: park (row, column) in the block's
+                                // LDS list (one LDS atomic + one LDS store each); it is sorted into the per-row slots after
+                                // the main loop, which keeps this path light on registers
                                 const int col = chunk_col(c, 32 * k + r);
                                 const int lbase = (wave * 64 + 32 * rb + 4 * h) << 24;
 #pragma unroll
@@ -236,12 +272,12 @@ nn16_pass_kernel(const _Float16 *__restrict__ Hq, int na, const _Float16 *__rest
         if (row < na) cand_cnt[(size_t)row * nstrips + strip] = over ? LR_NN16_CAPS + 1 : s_cnt[tid];
     }
     if (MODE == 0 && row0 < na) {
-        // fold the 32 lanes (columns) of each half; values only
+        // two largest of the 32 lane maxima of each row (lanes of one half hold the same rows, different columns)
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
-                float v1 = st1[rb][g], v2 = st2[rb][g];
+                float v1 = st1[rb][g], v2 = -LR_INF;
 #pragma unroll
                 for (int m = 1; m < 32; m <<= 1) {
                     const float c1 = __shfl_xor(v1, m), c2 = __shfl_xor(v2, m);
