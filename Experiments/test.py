@@ -1,0 +1,127 @@
+"""CLI with the reference's surface (Experiments/test.py:273-353): run from this directory as
+
+    python -m test --dataset A --algo RANSAC --mode GPF --iters 50000
+    ./test_parallel.sh --dataset B --algo RANSAC --mode MNN --iters 1000000 --GC_conf 0.9995
+
+Same flags and defaults for the RANSAC path, same `test_parallel <start_time> <tmp_base> <world> <rank|analysis>` protocol,
+same outputs (`outputs/<dataset>.Test.<time>/{raw_stats.npy,log.txt}`) plus `coarse_motions.txt` (format of
+FCGF_FAST/test.py:86-106).  Datasets and FCGF weights are not part of this repo; pairs come from, in order:
+  1. a feature cache  (env LIDARREG_FEATURE_CACHE=<dir> + LIDARREG_BALANCED_SETS=<dir with <set>/<phase>.txt>),
+  2. the list-driven synthetic surrogate (LIDARREG_BALANCED_SETS only: GT motion + overlap from the list rows),
+  3. plain synthetic pairs (--dataset synthetic --num_pairs P).
+"""
+import argparse
+import datetime
+import logging
+import os
+import sys
+import tempfile
+from glob import glob
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+logging.basicConfig(level=logging.INFO, format="%(asctime)s %(message)s", datefmt="%m/%d %H:%M:%S", stream=sys.stdout)
+
+
+def str2bool(v):
+    return str(v).lower() in ("true", "1")       # Experiments/config.py:18-19
+
+
+def get_args(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    if argv and argv[0] == "test_parallel":        # Experiments/test.py:275-285
+        start_time, tmp_file_base, world_size = argv[1], argv[2], int(argv[3])
+        do_analysis = argv[4] == "analysis"
+        rank = None if do_analysis else int(argv[4])
+        argv = argv[5:]
+    else:
+        start_time = None
+        tmp_file_base = tempfile.gettempdir() + "/test_%016d" % int(np.random.rand() * 10 ** 16)
+        world_size, rank, do_analysis = 1, 0, True
+    p = argparse.ArgumentParser()
+    p.add_argument("--dataset", type=str, default="synthetic", help="A, B, S, K, L (balanced sets) or synthetic")
+    p.add_argument("--algo", type=str, default="RANSAC", choices=["RANSAC"])
+    p.add_argument("--codebase", type=str, default="GC", choices=["open3D", "GC"])
+    p.add_argument("--mode", type=str, default="MNN", help="MNN (alias MMN), GPF or no_filter")
+    p.add_argument("--max_samples", type=int, default=None)
+    p.add_argument("--iters", type=int, default=None)
+    p.add_argument("--phase", type=str, default="test", choices=["train", "validation", "test"])
+    p.add_argument("--spatial_coherence_weight", type=float, default=0.0)
+    p.add_argument("--fast_rejection", type=str, default="ELC", choices=["SPRT", "ELC", "NONE"])
+    p.add_argument("--prosac", type=str2bool, default=True)
+    p.add_argument("--GPF_factor", type=float, default=2.0)
+    p.add_argument("--GPF_grid_wid", type=int, default=10)
+    p.add_argument("--GPF_max_matches", type=int, default=10 ** 9)
+    p.add_argument("--GC_conf", type=float, default=0.999)
+    p.add_argument("--GC_LO", type=str2bool, default=True)
+    # additions of this implementation
+    p.add_argument("--num_pairs", type=int, default=32, help="synthetic: number of pairs")
+    p.add_argument("--synthetic_n", type=int, default=30000, help="synthetic: points per cloud")
+    p.add_argument("--seed", type=int, default=51)
+    p.add_argument("--in_flight", type=int, default=4, help="pairs in flight per GPU")
+    args = p.parse_args(argv)
+    args.start_time, args.tmp_file_base, args.world_size, args.rank, args.do_analysis = start_time, tmp_file_base, world_size, rank, do_analysis
+    from lidarregistration_amd import io_lists
+    args.dataset_name = io_lists.DATASET_NAMES.get(args.dataset, args.dataset)
+    t = args.start_time or datetime.datetime.now().strftime("%Y%m%d_%H_%M_%S")
+    args.outdir = f"outputs/{args.dataset_name}.Test.{t}/"
+    os.makedirs(args.outdir, exist_ok=True)
+    return args
+
+
+def make_source(args):
+    from lidarregistration_amd import harness, io_lists
+    sets, cache = os.environ.get("LIDARREG_BALANCED_SETS"), os.environ.get("LIDARREG_FEATURE_CACHE")
+    if args.dataset in io_lists.DATASET_NAMES and sets:
+        lst = io_lists.read_pair_list(os.path.join(sets, args.dataset_name, args.phase + ".txt"))
+        if cache:
+            return harness.CacheSource(lst, os.path.join(cache, args.dataset_name, args.phase))
+        return harness.SyntheticSource(len(lst["session"]), n=args.synthetic_n, seed=args.seed, pair_list=lst)
+    return harness.SyntheticSource(args.num_pairs, n=args.synthetic_n, seed=args.seed)
+
+
+def test_subset(args):
+    import torch
+    from lidarregistration_amd import harness, shard
+    source = make_source(args)
+    P = len(source) if args.max_samples is None else min(len(source), args.max_samples)
+    idx = shard.shard_indices(P, args.world_size, args.rank)
+    print("process %d, GPU: cuda:%d, %d pairs" % (args.rank, torch.cuda.current_device(), len(idx)))
+    stats, T = harness.eval_pairs(source, idx, args, in_flight=args.in_flight, verbose=args.rank == 0)
+    np.save(f"{args.tmp_file_base}_res_{args.world_size}_{args.rank}.npy", np.concatenate([stats, T.reshape(-1, 16), np.asarray(idx, np.float64)[:, None]], 1))
+
+
+def analyze_stats(args):
+    from lidarregistration_amd import io_lists, metrics
+    parts = [np.load(f) for f in sorted(glob(args.tmp_file_base + "_res_*"))]
+    allrows = np.vstack(parts)
+    _, first = np.unique(allrows[:, -1], return_index=True)          # drop wrap-around padding, restore list order
+    allrows = allrows[first]
+    stats, T = allrows[:, :22], allrows[:, 22:38].reshape(-1, 4, 4)
+    np.save(args.outdir + "raw_stats.npy", stats)
+    s = metrics.summarize(stats, args.algo)
+    logging.info(s)
+    with open(args.outdir + "log.txt", "w") as fid:
+        for k, v in args.__dict__.items():
+            fid.write(f"{k} = {v}\n")
+        fid.write("\n" + s)
+    io_lists.write_coarse_motions(args.outdir + "coarse_motions.txt", stats[:, 19], stats[:, 20], stats[:, 21], T)
+    return stats
+
+
+def main(argv=None):
+    args = get_args(argv)
+    logging.info("Starting")
+    if args.rank is not None:
+        test_subset(args)
+    if args.do_analysis:
+        stats = analyze_stats(args)
+        for f in glob(args.tmp_file_base + "_res_*"):
+            os.remove(f)
+        return stats
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,127 @@
+"""Per-rank evaluation loop around FR(): the role of eval_KITTI_per_pair in the reference (Experiments/test.py:91-234).
+
+Pairs come from a PairSource (synthetic, list-driven synthetic surrogate, or a feature cache).  Several pairs are kept in
+flight on separate HIP streams, each with its own workspace; results stay on the device until the shard is done.
+Stats row layout = Experiments/test.py:98-100 (22 columns); the 4x4 transforms are returned next to it.
+"""
+import ctypes
+import time
+
+import numpy as np
+import torch
+
+from . import FR as fr
+from . import _ext, io_lists, metrics, synth
+
+
+class SyntheticSource:
+    """`num_pairs` synthetic pairs; when `pair_list` (io_lists.read_pair_list) is given, pair k takes its ground-truth
+    motion and overlap from row k of the list (SURVEY.md 8d "list-driven synthetic surrogate")."""
+
+    def __init__(self, num_pairs, n=30000, rho=0.5, s=1.2, seed=51, pair_list=None):
+        self.num_pairs, self.n, self.rho, self.s, self.seed, self.pair_list = num_pairs, n, rho, s, seed, pair_list
+
+    def __len__(self):
+        return self.num_pairs
+
+    def ids(self, k):
+        if self.pair_list is not None:
+            return int(self.pair_list["session"][k]), int(self.pair_list["src"][k]), int(self.pair_list["tgt"][k])
+        return 0, k, k
+
+    def get(self, k):
+        rho = self.rho
+        if self.pair_list is not None and self.pair_list["overlap"] is not None:
+            rho = float(np.clip(self.pair_list["overlap"][k], 0.05, 0.95))
+        p = synth.make_pair(N=self.n, rho=rho, s=self.s, seed=self.seed + k)
+        if self.pair_list is not None:
+            # re-plant the list's ground-truth motion: move cloud 1 from the synthetic motion to the listed one
+            T_new, T_old = self.pair_list["T_gt"][k], p["T_gt"]
+            M = T_new @ np.linalg.inv(T_old)
+            p["xyz1"] = (p["xyz1"].astype(np.float64) @ M[:3, :3].T + M[:3, 3]).astype(np.float32)
+            p["T_gt"] = T_new
+        return p
+
+
+class CacheSource:
+    """Real clouds + FCGF features from a feature cache (io_lists.save_cloud) for the pairs of a balanced list."""
+
+    def __init__(self, pair_list, cache_dir):
+        self.pair_list, self.cache_dir = pair_list, cache_dir
+
+    def __len__(self):
+        return len(self.pair_list["session"])
+
+    def ids(self, k):
+        return int(self.pair_list["session"][k]), int(self.pair_list["src"][k]), int(self.pair_list["tgt"][k])
+
+    def get(self, k):
+        s, i, j = self.ids(k)
+        xyz0, f0 = io_lists.load_cloud(self.cache_dir, s, i)
+        xyz1, f1 = io_lists.load_cloud(self.cache_dir, s, j)
+        return dict(xyz0=xyz0, xyz1=xyz1, feats0=f0, feats1=f1, T_gt=self.pair_list["T_gt"][k])
+
+
+def eval_pairs(source, indices, args, device=None, in_flight=4, verbose=False):
+    """Register source[k] for k in indices.  Returns (stats [n,22] float64, T [n,4,4] float64)."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    params = fr.pair_params(args)
+    n = len(indices)
+    stats = np.full((n, 22), np.nan)
+    Ts = np.tile(np.eye(4), (n, 1, 1))
+    streams = [torch.cuda.Stream(device=dev) for _ in range(in_flight)]
+    wss = [None] * in_flight
+    slots = [None] * in_flight          # (row, result buffer, events, host data) of the pair in flight on each stream
+
+    def retire(s):
+        row, out, ev0, ev1, p, t_data, n0 = slots[s]
+        ev1.synchronize()
+        r = fr.read_result(out)
+        T = np.array(r.T[:], np.float64).reshape(4, 4) if r.status == 0 else np.eye(4)
+        idx1, ci0, ci1 = fr.pair_lists(wss[s], n0, int(r.n_corr), dev)
+        pcd0, pcd1 = fr.PointCloud(p["xyz0"]), fr.PointCloud(p["xyz1"])
+        re, te = metrics.rotation_error_deg(T, p["T_gt"]), metrics.translation_error_cm(T, p["T_gt"])
+        sess, si, ti = source.ids(indices[row])
+        stats[row, 0] = float(re < metrics.RE_THRE_DEG and te < metrics.TE_THRE_CM)
+        stats[row, 1], stats[row, 2] = re, te
+        stats[row, 9] = ev0.elapsed_time(ev1) * 1e-3          # registration time on the device, whole path incl. NN
+        stats[row, 10], stats[row, 11] = t_data, 0.0
+        stats[row, 15] = n0
+        stats[row, 16] = fr.measure_inlier_ratio(np.arange(n0), idx1, pcd0, pcd1, p["T_gt"], fr.VOXEL_SIZE)
+        stats[row, 17] = int(r.n_corr)
+        stats[row, 18] = fr.measure_inlier_ratio(ci0, ci1, pcd0, pcd1, p["T_gt"], fr.VOXEL_SIZE)
+        stats[row, 19], stats[row, 20], stats[row, 21] = sess, si, ti
+        Ts[row] = T
+        slots[s] = None
+        if verbose:
+            print(f"{time.strftime('%m/%d %H:%M:%S')} Finished pair:{row}/{n}", flush=True)
+
+    for row, k in enumerate(indices):
+        s = row % in_flight
+        if slots[s] is not None:
+            retire(s)
+        t0 = time.time()
+        p = source.get(k)
+        t_data = time.time() - t0
+        n0, n1, d = p["feats0"].shape[0], p["feats1"].shape[0], p["feats0"].shape[1]
+        if wss[s] is None or not wss[s].fits(n0, n1, params.ransac.iters):
+            if wss[s] is not None:
+                torch.cuda.synchronize(dev)
+                wss[s].close()
+            wss[s] = _ext.Workspace(int(n0 * 1.25), int(n1 * 1.25), d, params.ransac.iters)
+        with torch.cuda.stream(streams[s]):
+            x0 = torch.from_numpy(p["xyz0"]).to(dev, non_blocking=True); x1 = torch.from_numpy(p["xyz1"]).to(dev, non_blocking=True)
+            f0 = torch.from_numpy(p["feats0"]).to(dev, non_blocking=True); f1 = torch.from_numpy(p["feats1"]).to(dev, non_blocking=True)
+            out = torch.empty(ctypes.sizeof(_ext.PairResult), dtype=torch.uint8, device=dev)
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record(streams[s])
+            fr.register_pair_dev(x0, x1, f0, f1, params, out=out, ws=wss[s], stream=streams[s].cuda_stream)
+            ev1.record(streams[s])
+        slots[s] = (row, out, ev0, ev1, dict(p, _keep=(x0, x1, f0, f1)), t_data, n0)
+    for s in range(in_flight):
+        if slots[s] is not None:
+            retire(s)
+    for w in wss:
+        if w is not None:
+            w.close()
+    return stats, Ts

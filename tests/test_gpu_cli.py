@@ -1,0 +1,72 @@
+"""The CLI surface end to end on the GPU: Experiments/test.py (single process and the test_parallel protocol), the demo,
+and shard equivalence (the merged table does not depend on the world size)."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture()
+def cli(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    sys.path.insert(0, os.path.join(ROOT, "Experiments"))
+    mod = importlib.import_module("test")
+    yield mod
+    sys.path.remove(os.path.join(ROOT, "Experiments"))
+
+
+COMMON = ["--dataset", "synthetic", "--num_pairs", "6", "--synthetic_n", "4000", "--algo", "RANSAC", "--iters", "2000"]
+
+
+def _outputs(tmp_path):
+    d = sorted((tmp_path / "outputs").iterdir())[-1]
+    from lidarregistration_amd import io_lists
+    ids, T = io_lists.read_coarse_motions(str(d / "coarse_motions.txt"))
+    return np.load(d / "raw_stats.npy"), ids, T, (d / "log.txt").read_text()
+
+
+@pytest.mark.parametrize("mode_args", [["--mode", "MMN"], ["--mode", "GPF", "--GPF_factor", "0.5"], ["--mode", "no_filter", "--codebase", "open3D"]])
+def test_single_process_run(cli, tmp_path, oracle, mode_args):
+    stats = cli.main(COMMON + mode_args)
+    raw, ids, T, log = _outputs(tmp_path)
+    assert raw.shape == (6, 22) and np.array_equal(raw, stats, equal_nan=True)
+    assert (raw[:, 0] == 1).all() and (raw[:, 1] < 1.0).all() and (raw[:, 2] < 30).all()
+    assert ids[:, 1].tolist() == list(range(6)) and "recall: 100.00%" in log and "mode = " in log
+    # pair 2 of the run against the oracle pipeline on the same synthetic pair
+    from lidarregistration_amd import synth
+    from tests.conftest import Args
+    p = synth.make_pair(N=4000, seed=51 + 2)
+    mode = mode_args[1]
+    ns = 4 if "open3D" in mode_args else 3
+    e = oracle.register_pair(p["xyz0"], p["xyz1"], p["feats0"], p["feats1"], mode=mode, iters=2000, sample_size=ns, seed=51,
+                             args=Args(GPF_factor=0.5))
+    assert np.radians(oracle.rotation_error_deg(T[2], e["T"])) <= 1e-4 and oracle.translation_error_cm(T[2], e["T"]) / 100 <= 1e-3
+    assert raw[2, 17] == len(e["idx0"])
+
+
+def test_parallel_protocol_is_shard_invariant(cli, tmp_path):
+    ref = cli.main(COMMON + ["--mode", "MNN"])
+    base = str(tmp_path / "pp")
+    for r in range(2):
+        cli.main(["test_parallel", "20260101_00_00_00", base, "2", str(r)] + COMMON + ["--mode", "MNN"])
+    merged = cli.main(["test_parallel", "20260101_00_00_00", base, "2", "analysis"] + COMMON + ["--mode", "MNN"])
+    for c in (0, 1, 2, 15, 16, 17, 18, 19, 20, 21):
+        assert np.array_equal(ref[:, c], merged[:, c]), c       # identical results whatever the world size
+    # 3 ranks over 6 pairs with --max_samples 5: wrap-around padding is dropped by the analysis pass
+    base = str(tmp_path / "qq")
+    for r in range(3):
+        cli.main(["test_parallel", "20260101_00_00_01", base, "3", str(r)] + COMMON + ["--mode", "MNN", "--max_samples", "5"])
+    merged = cli.main(["test_parallel", "20260101_00_00_01", base, "3", "analysis"] + COMMON + ["--mode", "MNN", "--max_samples", "5"])
+    assert merged.shape == (5, 22) and np.array_equal(merged[:, 1], ref[:5, 1])
+
+
+def test_demo_registration(cli, capsys):
+    demo = importlib.import_module("demo_registration")
+    T = demo.main(["--algo", "RANSAC", "--mode", "MMN", "--iters", "1000"])
+    out = capsys.readouterr().out
+    assert T.shape == (4, 4) and "RE = " in out and "filtered pairs" in out
