@@ -41,12 +41,12 @@ void carve(lr_workspace *ws, Carver &c)
     ws->H0 = c.take<_Float16>(n0 * 32); ws->H1 = c.take<_Float16>(n1 * 32);
     ws->tau = c.take<float>(n);
     ws->cand_cnt = c.take<int32_t>(n * LR_NN_MAX_STRIPS); ws->cand = c.take<int32_t>(n * LR_NN_MAX_STRIPS * LR_NN16_CAPS);
-    ws->max_norm = c.take<uint32_t>(2);
     ws->pb1 = c.take<float>(n * LR_NN_MAX_STRIPS); ws->pb2 = c.take<float>(n * LR_NN_MAX_STRIPS);
     ws->pb3 = c.take<float>(n * LR_NN_MAX_STRIPS);
     ws->pi1 = c.take<int32_t>(n * LR_NN_MAX_STRIPS); ws->pi2 = c.take<int32_t>(n * LR_NN_MAX_STRIPS);
     ws->fix_list = c.take<int32_t>(n);
     ws->counters = c.take<int32_t>(LR_CNT_COUNT);
+    ws->max_norm = reinterpret_cast<uint32_t *>(ws->counters ? ws->counters + LR_CNT_MAXN0 : nullptr);
     ws->nn_idx1 = c.take<int32_t>(n0); ws->nn_idx2 = c.take<int32_t>(n0);
     ws->nn_s1 = c.take<float>(n0); ws->nn_s2 = c.take<float>(n0);
     ws->rev_idx1 = c.take<int32_t>(n1);
@@ -169,12 +169,13 @@ static int check_nn_args(const lr_workspace *ws, const void *F0, int n0, const v
 #define LR_TRY(x) do { int rc_ = (x); if (rc_ != LR_OK) return rc_; } while (0)
 
 // norms + operand copies of both clouds for whichever NN path the workspace uses
-static int prep_both(lr_workspace *ws, const float *F0, int n0, const float *F1, int n1, hipStream_t st)
+static int prep_both(lr_workspace *ws, const float *F0, int n0, const float *F1, int n1, hipStream_t st, bool counters_zeroed = false)
 {
     if (ws->nn_path == LR_NN_PATH_FP32_MFMA) {
         LR_TRY(lr_nn_prep(ws, F0, n0, ws->Fp0, ws->nrm0, st));
         return lr_nn_prep(ws, F1, n1, ws->Fp1, ws->nrm1, st);
     }
+    if (!counters_zeroed) LR_HIP(hipMemsetAsync(ws->max_norm, 0, 2 * sizeof(uint32_t), st));
     LR_TRY(lr_nn16_prep(ws, F0, n0, ws->Fp0, ws->H0, ws->nrm0, ws->max_norm + 0, st));
     return lr_nn16_prep(ws, F1, n1, ws->Fp1, ws->H1, ws->nrm1, ws->max_norm + 1, st);
 }
@@ -244,7 +245,7 @@ extern "C" int lr_ransac(lr_workspace *ws, const float *src, const float *tgt, i
     LR_REQUIRE(ws && src && tgt && p && T_out && res, LR_EINVAL, "lr_ransac: null pointer");
     LR_REQUIRE(m >= 0 && m <= ws->max_n0, LR_ESIZE, "lr_ransac: m exceeds the workspace");
     hipStream_t st = (hipStream_t)stream;
-    LR_TRY(lr_pack_corr(src, tgt, nullptr, nullptr, m, m_dev, ws->corr8, st));
+    LR_TRY(lr_pack_corr(ws, src, tgt, nullptr, nullptr, m, m_dev, ws->corr8, st));
     return lr_ransac_run(ws, ws->corr8, m, m_dev, p, T_out, res, st);
 }
 
@@ -286,7 +287,7 @@ extern "C" int lr_register_pair(lr_workspace *ws, const float *xyz0, const float
     int32_t *n_refit = ws->counters + LR_CNT_COUNT - 2;
     LR_HIP(hipMemsetAsync(ws->counters, 0, sizeof(int32_t) * LR_CNT_COUNT, st));
     // 1. coarse correspondences (FR.py:38): first + second NN of every cloud-0 descriptor
-    LR_TRY(prep_both(ws, F0, n0, F1, n1, st));
+    LR_TRY(prep_both(ws, F0, n0, F1, n1, st, true));
     LR_TRY(nn_forward(ws, F0, n0, F1, n1, ws->nn_idx1, ws->nn_idx2, ws->nn_s1, ws->nn_s2, st));
     // 2. filter (FR.py:48-56)
     if (p->mode == LR_MODE_NO_FILTER) {
@@ -303,7 +304,7 @@ extern "C" int lr_register_pair(lr_workspace *ws, const float *xyz0, const float
         }
     }
     // 3. RANSAC on the surviving pairs (FR.py:70-97)
-    LR_TRY(lr_pack_corr(xyz0, xyz1, ws->corr_idx0, ws->corr_idx1, n0, m_dev, ws->corr8, st));
+    LR_TRY(lr_pack_corr(ws, xyz0, xyz1, ws->corr_idx0, ws->corr_idx1, n0, m_dev, ws->corr8, st));
     LR_TRY(lr_ransac_run(ws, ws->corr8, n0, m_dev, &p->ransac, ws->T_tmp, ws->res_tmp, st));
     // 4. LS refit over the original NN pairs (FR.py:99-111)
     const double *T_final = ws->T_tmp;

@@ -115,9 +115,11 @@ int lr_identity_corr(lr_workspace *ws, int n0, const int32_t *idx1, const int32_
 // corr8[c] = { p.x p.y p.z q.x q.y q.z 0 0 } (32 B): one s_load_dwordx8 per correspondence in the scoring loop
 __global__ void pack_corr_kernel(const float *__restrict__ xyz0, const float *__restrict__ xyz1,
                                  const int32_t *__restrict__ i0, const int32_t *__restrict__ i1,
-                                 int m_max, const int32_t *__restrict__ m_dev, float *__restrict__ corr8)
+                                 int m_max, const int32_t *__restrict__ m_dev, float *__restrict__ corr8,
+                                 int32_t *__restrict__ counters)
 {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0) counters[LR_CNT_NVALID] = 0;        // the hypothesis list of the RANSAC that follows starts empty
     int m = m_dev ? min(*m_dev, m_max) : m_max;
     if (c >= m) return;
     int a = i0 ? i0[c] : c, b = i1 ? i1[c] : c;
@@ -127,11 +129,11 @@ __global__ void pack_corr_kernel(const float *__restrict__ xyz0, const float *__
     reinterpret_cast<float4 *>(corr8)[2 * c + 1] = hi;
 }
 
-int lr_pack_corr(const float *xyz0, const float *xyz1, const int32_t *i0, const int32_t *i1, int m_max,
+int lr_pack_corr(lr_workspace *ws, const float *xyz0, const float *xyz1, const int32_t *i0, const int32_t *i1, int m_max,
                  const int32_t *m_dev, float *corr8, hipStream_t st)
 {
-    if (m_max <= 0) return LR_OK;
-    hipLaunchKernelGGL(pack_corr_kernel, dim3(lr_cdiv(m_max, 256)), dim3(256), 0, st, xyz0, xyz1, i0, i1, m_max, m_dev, corr8);
+    hipLaunchKernelGGL(pack_corr_kernel, dim3(lr_cdiv(m_max > 0 ? m_max : 1, 256)), dim3(256), 0, st, xyz0, xyz1, i0, i1, m_max, m_dev, corr8,
+                       ws->counters);
     LR_LAUNCH_CHECK();
     return LR_OK;
 }

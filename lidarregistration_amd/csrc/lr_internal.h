@@ -94,6 +94,8 @@ enum {
     LR_CNT_NCORR,        // live M
     LR_CNT_NVALID,       // hypotheses appended to models[]
     LR_CNT_NBB,          // best buddies
+    LR_CNT_MAXN0,        // bit pattern of max_i n0_i (f16 filter error bound)
+    LR_CNT_MAXN1,        // bit pattern of max_j n1_j
     LR_CNT_COUNT = 16
 };
 
@@ -115,7 +117,7 @@ int lr_mutual_run(lr_workspace *ws, int n0, const int32_t *idx1, const int32_t *
                   uint8_t *is_bb, int32_t *o0, int32_t *o1, int32_t *o2, int32_t *n_out, hipStream_t st);
 int lr_identity_corr(lr_workspace *ws, int n0, const int32_t *idx1, const int32_t *idx2,
                      int32_t *o0, int32_t *o1, int32_t *o2, int32_t *n_out, hipStream_t st);
-int lr_pack_corr(const float *xyz0, const float *xyz1, const int32_t *i0, const int32_t *i1, int m_max,
+int lr_pack_corr(lr_workspace *ws, const float *xyz0, const float *xyz1, const int32_t *i0, const int32_t *i1, int m_max,
                  const int32_t *m_dev, float *corr8, hipStream_t st);
 int lr_gpf_run(lr_workspace *ws, const float *F0, int n0, const float *F1, int dim,
                const int32_t *idx1, const int32_t *idx2, const uint8_t *is_bb, const float *xyz0,

@@ -325,58 +325,73 @@ nn16_thresh_kernel(int na, int nstrips, int part_stride, const float *__restrict
 }
 
 // ------------------------------------------------------------------ exact verification of the candidates
-// One thread per row.  Rows with an overflowing or too-short candidate list are queued for the full exact row kernel.
-__global__ void __launch_bounds__(128)
+// Four lanes per row: lane q takes the candidate slots of strips q, q+4, ...; the four partial (first, second) pairs are
+// merged under the (sqrt value, index) order with two shuffles.  Rows with an overflowing or too-short candidate list
+// are queued for the full exact row kernel.
+__device__ __forceinline__ bool sj_lt(float a, int ia, float b, int ib) { return a < b || (a == b && ia < ib); }
+
+__global__ void __launch_bounds__(256)
 nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, int na,
                   const float *__restrict__ Fc, const float *__restrict__ nC, int nb,
                   const int32_t *__restrict__ cand_cnt, const int32_t *__restrict__ cand, int nstrips, int need,
                   int32_t *__restrict__ idx1, int32_t *__restrict__ idx2, float *__restrict__ s1o, float *__restrict__ s2o,
                   int32_t *__restrict__ fix_list, int32_t *__restrict__ counters)
 {
-    const int row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= na) return;
-    int total = 0;
-    bool overflow = false;
-    for (int s = 0; s < nstrips; ++s) {
-        const int c = cand_cnt[(size_t)row * nstrips + s];
-        total += c;
-        overflow |= c > LR_NN16_CAPS;
-    }
-    if (overflow || total < min(need, nb)) {
-        const int slot = atomicAdd(&counters[LR_CNT_FIX], 1);
-        fix_list[slot] = row;
-        return;
-    }
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int row = gid >> 2, q = gid & 3;
+    const bool live = row < na;
+    const int rowc = live ? row : na - 1;
     float a[32];
-    const f32x4 *pa = reinterpret_cast<const f32x4 *>(Fq + (size_t)row * 32);
+    const f32x4 *pa = reinterpret_cast<const f32x4 *>(Fq + (size_t)rowc * 32);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) { f32x4 t = pa[q]; a[4 * q] = t.x; a[4 * q + 1] = t.y; a[4 * q + 2] = t.z; a[4 * q + 3] = t.w; }
-    const float nq = nQ[row];
+    for (int k = 0; k < 8; ++k) { f32x4 t = pa[k]; a[4 * k] = t.x; a[4 * k + 1] = t.y; a[4 * k + 2] = t.z; a[4 * k + 3] = t.w; }
+    const float nq = nQ[rowc];
     float b1 = LR_INF, b2 = LR_INF;
     int i1 = LR_IMAX, i2 = LR_IMAX;
-    for (int s = 0; s < nstrips; ++s) {
-        const int cnt = cand_cnt[(size_t)row * nstrips + s];
-        for (int c = 0; c < cnt; ++c) {
-            const int j = cand[((size_t)row * nstrips + s) * LR_NN16_CAPS + c];
+    int total = 0, over = 0;
+    for (int s = q; s < nstrips; s += 4) {
+        const int cnt = cand_cnt[(size_t)rowc * nstrips + s];
+        total += cnt;
+        over |= cnt > LR_NN16_CAPS ? 1 : 0;
+        const int lim = min(cnt, LR_NN16_CAPS);
+        for (int c = 0; c < lim; ++c) {
+            const int j = cand[((size_t)rowc * nstrips + s) * LR_NN16_CAPS + c];
             const f32x4 *pb = reinterpret_cast<const f32x4 *>(Fc + (size_t)j * 32);
             float acc = 0.0f;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const f32x4 t = pb[q];
-                acc = __builtin_fmaf(a[4 * q], t.x, acc);
-                acc = __builtin_fmaf(a[4 * q + 1], t.y, acc);
-                acc = __builtin_fmaf(a[4 * q + 2], t.z, acc);
-                acc = __builtin_fmaf(a[4 * q + 3], t.w, acc);
+            for (int k = 0; k < 8; ++k) {
+                const f32x4 t = pb[k];
+                acc = __builtin_fmaf(a[4 * k], t.x, acc);
+                acc = __builtin_fmaf(a[4 * k + 1], t.y, acc);
+                acc = __builtin_fmaf(a[4 * k + 2], t.z, acc);
+                acc = __builtin_fmaf(a[4 * k + 3], t.w, acc);
             }
             const float tt = nq + nC[j];
             const float d2 = __builtin_fmaf(-2.0f, acc, tt);
             const float sv = __builtin_sqrtf(fmaxf(d2, 1e-30f));
-            // candidates arrive in arbitrary order: order by (sqrt value, index)
-            const bool lt1 = sv < b1 || (sv == b1 && j < i1);
-            const bool lt2 = sv < b2 || (sv == b2 && j < i2);
-            if (lt1) { b2 = b1; i2 = i1; b1 = sv; i1 = j; }
-            else if (lt2) { b2 = sv; i2 = j; }
+            // candidates arrive in arbitrary order: order by (sqrt value, index) == torch.min's first minimal value
+            if (sj_lt(sv, j, b1, i1)) { b2 = b1; i2 = i1; b1 = sv; i1 = j; }
+            else if (sj_lt(sv, j, b2, i2)) { b2 = sv; i2 = j; }
         }
+    }
+#pragma unroll
+    for (int m = 1; m <= 2; m <<= 1) {
+        total += __shfl_xor(total, m);
+        over |= __shfl_xor(over, m);
+        const float c1 = __shfl_xor(b1, m), c2 = __shfl_xor(b2, m);
+        const int j1 = __shfl_xor(i1, m), j2 = __shfl_xor(i2, m);
+        const bool cf = sj_lt(c1, j1, b1, i1);
+        const float x1 = cf ? c1 : b1, x2 = cf ? c2 : b2, y1 = cf ? b1 : c1;
+        const int xi1 = cf ? j1 : i1, xi2 = cf ? j2 : i2, yi1 = cf ? i1 : j1;
+        const bool sy = sj_lt(y1, yi1, x2, xi2);
+        b1 = x1; i1 = xi1;
+        b2 = sy ? y1 : x2; i2 = sy ? yi1 : xi2;
+    }
+    if (!live || q != 0) return;
+    if (over || total < min(need, nb)) {
+        const int slot = atomicAdd(&counters[LR_CNT_FIX], 1);
+        fix_list[slot] = row;
+        return;
     }
     idx1[row] = i1;
     if (idx2) idx2[row] = i2;
@@ -388,7 +403,6 @@ nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, in
 int lr_nn16_prep(lr_workspace *ws, const float *F, int n, float *Fp, _Float16 *H, float *nrm, uint32_t *max_bits, hipStream_t st)
 {
     (void)ws;
-    LR_HIP(hipMemsetAsync(max_bits, 0, sizeof(uint32_t), st));
     hipLaunchKernelGGL(nn16_prep_kernel, dim3(lr_cdiv(n, 256)), dim3(256), 0, st, F, n, Fp, H, nrm, max_bits);
     LR_LAUNCH_CHECK();
     return LR_OK;
@@ -420,7 +434,7 @@ int lr_nn16_run(lr_workspace *ws, const float *Fq, const float *Fpq, const _Floa
     hipLaunchKernelGGL(nn16_pass_kernel<1>, grid, dim3(256), 0, st, Hq, na, Hc, nC, nb, tps, 1, ws->max_n, (float *)nullptr,
                        (float *)nullptr, ws->tau, ws->cand_cnt, ws->cand);
     if (ws->timing && !ws->ev_pending) { LR_HIP(hipEventRecord(ws->ev[1], st)); ws->ev_pending = 1; }
-    hipLaunchKernelGGL(nn16_exact_kernel, dim3(lr_cdiv(na, 128)), dim3(128), 0, st, Fq, nQ, na, Fc, nC, nb, ws->cand_cnt, ws->cand,
+    hipLaunchKernelGGL(nn16_exact_kernel, dim3(lr_cdiv(na, 64)), dim3(256), 0, st, Fq, nQ, na, Fc, nC, nb, ws->cand_cnt, ws->cand,
                        strips, need, idx1, idx2, s1, s2, ws->fix_list, ws->counters);
     LR_LAUNCH_CHECK();
     return lr_nn_fix_rows(ws, Fpq, nQ, Fpc, nC, nb, idx1, idx2, s1, s2, st);

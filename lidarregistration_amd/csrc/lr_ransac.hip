@@ -35,12 +35,15 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32
 }
 
 // ------------------------------------------------------------------ Kabsch (fp64, + - * / sqrt only)
-#define LR_JACOBI_SWEEPS 8
+#define LR_JACOBI_SWEEPS 10      // upper bound; sweeps stop once the off-diagonal mass is below 1e-15 of the diagonal
 
 __device__ __forceinline__ void jacobi4_maxvec(double A[4][4], double q[4])
 {
     double V[4][4] = { { 1, 0, 0, 0 }, { 0, 1, 0, 0 }, { 0, 0, 1, 0 }, { 0, 0, 0, 1 } };
     for (int sweep = 0; sweep < LR_JACOBI_SWEEPS; ++sweep) {
+        double off2 = ((((A[0][1] * A[0][1] + A[0][2] * A[0][2]) + A[0][3] * A[0][3]) + A[1][2] * A[1][2]) + A[1][3] * A[1][3]) + A[2][3] * A[2][3];
+        double dia2 = ((A[0][0] * A[0][0] + A[1][1] * A[1][1]) + A[2][2] * A[2][2]) + A[3][3] * A[3][3];
+        if (off2 <= 1e-30 * dia2) break;
 #pragma unroll
         for (int p = 0; p < 3; ++p)
 #pragma unroll
@@ -301,7 +304,6 @@ int lr_ransac_run(lr_workspace *ws, const float *corr8, int m_max, const int32_t
     LR_REQUIRE(p->iters >= 0 && p->iters <= ws->max_iters, LR_ESIZE, "lr_ransac: iters exceeds the workspace");
     LR_REQUIRE(m_max >= 0 && m_max <= ws->max_n0, LR_ESIZE, "lr_ransac: m exceeds the workspace");
     LR_REQUIRE(p->thr2 > 0.0f && p->thr2 < 2048.0f, LR_EINVAL, "lr_ransac: thr2 must be in (0, 2048)");
-    LR_HIP(hipMemsetAsync(ws->counters + LR_CNT_NVALID, 0, sizeof(int32_t), st));
     const int gb = lr_cdiv(p->iters > 0 ? p->iters : 1, 64);
     int sub = (int)(4095.0 / ((double)p->thr2 * 1.0000001 + 1e-6));     // sub * thr2 * 2^20 < 2^32
     if (sub > 4096) sub = 4096;

@@ -178,13 +178,16 @@ ORC_API int orc_elc(const float *src, const float *tgt, const int32_t *sample, i
 
 /* -------------------------------------------------------------- Kabsch ---- */
 
-#define JACOBI_SWEEPS 8
+#define JACOBI_SWEEPS 10          /* upper bound; the sweep loop stops once the off-diagonal mass is below 1e-15 of the diagonal */
 
 /* Largest-eigenvalue eigenvector of a symmetric 4x4 by cyclic Jacobi (fixed sweep count). */
 static void jacobi4_maxvec(double A[4][4], double q[4])
 {
     double V[4][4] = { {1,0,0,0}, {0,1,0,0}, {0,0,1,0}, {0,0,0,1} };
     for (int sweep = 0; sweep < JACOBI_SWEEPS; ++sweep) {
+        double off2 = ((((A[0][1] * A[0][1] + A[0][2] * A[0][2]) + A[0][3] * A[0][3]) + A[1][2] * A[1][2]) + A[1][3] * A[1][3]) + A[2][3] * A[2][3];
+        double dia2 = ((A[0][0] * A[0][0] + A[1][1] * A[1][1]) + A[2][2] * A[2][2]) + A[3][3] * A[3][3];
+        if (off2 <= 1e-30 * dia2) break;
         for (int p = 0; p < 3; ++p)
             for (int r = p + 1; r < 4; ++r) {
                 double apq = A[p][r];
