@@ -46,7 +46,7 @@ void carve(lr_workspace *ws, Carver &c)
     ws->pi1 = c.take<int32_t>(n * LR_NN_MAX_STRIPS); ws->pi2 = c.take<int32_t>(n * LR_NN_MAX_STRIPS);
     ws->fix_list = c.take<int32_t>(n);
     ws->counters = c.take<int32_t>(LR_CNT_COUNT);
-    ws->max_norm = reinterpret_cast<uint32_t *>(ws->counters ? ws->counters + LR_CNT_MAXN0 : nullptr);
+    ws->bmax0 = c.take<float>(n0 / 32 + 2); ws->bmax1 = c.take<float>(n1 / 32 + 2);
     ws->nn_idx1 = c.take<int32_t>(n0); ws->nn_idx2 = c.take<int32_t>(n0);
     ws->nn_s1 = c.take<float>(n0); ws->nn_s2 = c.take<float>(n0);
     ws->rev_idx1 = c.take<int32_t>(n1);
@@ -169,15 +169,14 @@ static int check_nn_args(const lr_workspace *ws, const void *F0, int n0, const v
 #define LR_TRY(x) do { int rc_ = (x); if (rc_ != LR_OK) return rc_; } while (0)
 
 // norms + operand copies of both clouds for whichever NN path the workspace uses
-static int prep_both(lr_workspace *ws, const float *F0, int n0, const float *F1, int n1, hipStream_t st, bool counters_zeroed = false)
+static int prep_both(lr_workspace *ws, const float *F0, int n0, const float *F1, int n1, hipStream_t st)
 {
     if (ws->nn_path == LR_NN_PATH_FP32_MFMA) {
         LR_TRY(lr_nn_prep(ws, F0, n0, ws->Fp0, ws->nrm0, st));
         return lr_nn_prep(ws, F1, n1, ws->Fp1, ws->nrm1, st);
     }
-    if (!counters_zeroed) LR_HIP(hipMemsetAsync(ws->max_norm, 0, 2 * sizeof(uint32_t), st));
-    LR_TRY(lr_nn16_prep(ws, F0, n0, ws->Fp0, ws->H0, ws->nrm0, ws->max_norm + 0, st));
-    return lr_nn16_prep(ws, F1, n1, ws->Fp1, ws->H1, ws->nrm1, ws->max_norm + 1, st);
+    LR_TRY(lr_nn16_prep(ws, F0, n0, ws->H0, ws->nrm0, ws->bmax0, st));
+    return lr_nn16_prep(ws, F1, n1, ws->H1, ws->nrm1, ws->bmax1, st);
 }
 
 // forward: rows of cloud 0 against cloud 1 (first + second NN)
@@ -186,7 +185,7 @@ static int nn_forward(lr_workspace *ws, const float *F0, int n0, const float *F1
 {
     if (ws->nn_path == LR_NN_PATH_FP32_MFMA)
         return lr_nn_run(ws, ws->Fp0, ws->nrm0, n0, ws->Fp1, ws->nrm1, n1, idx1, idx2, s1, s2, st);
-    return lr_nn16_run(ws, F0, ws->Fp0, ws->H0, ws->nrm0, n0, F1, ws->Fp1, ws->H1, ws->nrm1, ws->max_norm + 1, n1,
+    return lr_nn16_run(ws, F0, ws->H0, ws->nrm0, n0, F1, ws->H1, ws->nrm1, ws->bmax1, n1,
                        2, idx1, idx2, s1, s2, st);
 }
 
@@ -196,7 +195,7 @@ static int nn_reverse(lr_workspace *ws, const float *F0, int n0, const float *F1
 {
     if (ws->nn_path == LR_NN_PATH_FP32_MFMA)
         return lr_nn_run(ws, ws->Fp1, ws->nrm1, n1, ws->Fp0, ws->nrm0, n0, rev, nullptr, nullptr, nullptr, st);
-    return lr_nn16_run(ws, F1, ws->Fp1, ws->H1, ws->nrm1, n1, F0, ws->Fp0, ws->H0, ws->nrm0, ws->max_norm + 0, n0,
+    return lr_nn16_run(ws, F1, ws->H1, ws->nrm1, n1, F0, ws->H0, ws->nrm0, ws->bmax0, n0,
                        1, rev, nullptr, nullptr, nullptr, st);
 }
 
@@ -287,7 +286,7 @@ extern "C" int lr_register_pair(lr_workspace *ws, const float *xyz0, const float
     int32_t *n_refit = ws->counters + LR_CNT_COUNT - 2;
     LR_HIP(hipMemsetAsync(ws->counters, 0, sizeof(int32_t) * LR_CNT_COUNT, st));
     // 1. coarse correspondences (FR.py:38): first + second NN of every cloud-0 descriptor
-    LR_TRY(prep_both(ws, F0, n0, F1, n1, st, true));
+    LR_TRY(prep_both(ws, F0, n0, F1, n1, st));
     LR_TRY(nn_forward(ws, F0, n0, F1, n1, ws->nn_idx1, ws->nn_idx2, ws->nn_s1, ws->nn_s2, st));
     // 2. filter (FR.py:48-56)
     if (p->mode == LR_MODE_NO_FILTER) {

@@ -49,7 +49,7 @@ struct lr_workspace {
     _Float16 *H0, *H1;           // [n,32] f16 copies for the matrix-core filter passes
     float *tau;                  // [max_n] per-row candidate threshold
     int32_t *cand_cnt, *cand;    // [max_n][strips], [max_n][strips][LR_NN16_CAPS] candidate lists
-    uint32_t *max_norm;          // [2] bit patterns of max_i n0_i, max_j n1_j
+    float *bmax0, *bmax1;        // per-32-row maxima of the norms (f16 filter error bound)
     int nn_path;                 // LR_NN_PATH_*
     float *pb1, *pb2, *pb3;      // partial top-3 values [strips][max_n]
     int32_t *pi1, *pi2;          // partial top-2 indices
@@ -94,8 +94,6 @@ enum {
     LR_CNT_NCORR,        // live M
     LR_CNT_NVALID,       // hypotheses appended to models[]
     LR_CNT_NBB,          // best buddies
-    LR_CNT_MAXN0,        // bit pattern of max_i n0_i (f16 filter error bound)
-    LR_CNT_MAXN1,        // bit pattern of max_j n1_j
     LR_CNT_COUNT = 16
 };
 
@@ -105,11 +103,11 @@ int lr_nn_run(lr_workspace *ws, const float *Fa, const float *nrma, int na, cons
 int lr_nn_prep(lr_workspace *ws, const float *F, int n, float *Fp, float *nrm, hipStream_t st);
 
 // lr_nn16.hip
-int lr_nn16_prep(lr_workspace *ws, const float *F, int n, float *Fp, _Float16 *H, float *nrm, uint32_t *max_bits, hipStream_t st);
-int lr_nn16_run(lr_workspace *ws, const float *Fq, const float *Fpq, const _Float16 *Hq, const float *nQ, int na,
-                const float *Fc, const float *Fpc, const _Float16 *Hc, const float *nC, const uint32_t *max_c_bits, int nb,
+int lr_nn16_prep(lr_workspace *ws, const float *F, int n, _Float16 *H, float *nrm, float *block_max, hipStream_t st);
+int lr_nn16_run(lr_workspace *ws, const float *Fq, const _Float16 *Hq, const float *nQ, int na,
+                const float *Fc, const _Float16 *Hc, const float *nC, const float *block_max_c, int nb,
                 int need, int32_t *idx1, int32_t *idx2, float *s1, float *s2, hipStream_t st);
-int lr_nn_fix_rows(lr_workspace *ws, const float *Fpa, const float *nrma, const float *Fpb, const float *nrmb, int nb,
+int lr_nn_fix_rows(lr_workspace *ws, bool permuted, const float *Fa, const float *nrma, const float *Fb, const float *nrmb, int nb,
                    int32_t *idx1, int32_t *idx2, float *s1, float *s2, hipStream_t st);
 
 // lr_filter.hip

@@ -237,6 +237,8 @@ nn_finalize_kernel(int na, int nstrips, int part_stride,
 
 // ------------------------------------------------------------------ exact path for flagged rows
 // One wave per flagged row; every candidate's s = sqrt(max(d2,1e-30)) is formed and ordered by (s, j).
+// PERM: the operands are the de-interleaved copies of nn_prep_kernel (k = 2m at m, 2m+1 at 16+m); otherwise plain rows.
+template <bool PERM>
 __global__ void __launch_bounds__(64)
 nn_fix_kernel(const float *__restrict__ Ap, const float *__restrict__ nA,
               const float *__restrict__ Bp, const float *__restrict__ nB, int nb,
@@ -260,10 +262,15 @@ nn_fix_kernel(const float *__restrict__ Ap, const float *__restrict__ nA,
 #pragma unroll
             for (int q = 0; q < 8; ++q) { f32x4 t = pb[q]; b[4 * q] = t.x; b[4 * q + 1] = t.y; b[4 * q + 2] = t.z; b[4 * q + 3] = t.w; }
             float acc = 0.0f;
+            if (PERM) {
 #pragma unroll
-            for (int m = 0; m < 16; ++m) {      // natural k order: (2m) sits at m, (2m+1) at 16+m
-                acc = __builtin_fmaf(a[m], b[m], acc);
-                acc = __builtin_fmaf(a[16 + m], b[16 + m], acc);
+                for (int m = 0; m < 16; ++m) {      // natural k order: (2m) sits at m, (2m+1) at 16+m
+                    acc = __builtin_fmaf(a[m], b[m], acc);
+                    acc = __builtin_fmaf(a[16 + m], b[16 + m], acc);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 32; ++k) acc = __builtin_fmaf(a[k], b[k], acc);
             }
             float t = nq + nB[j];
             float d2 = __builtin_fmaf(-2.0f, acc, t);
@@ -297,11 +304,15 @@ int lr_nn_prep(lr_workspace *ws, const float *F, int n, float *Fp, float *nrm, h
     return LR_OK;
 }
 
-int lr_nn_fix_rows(lr_workspace *ws, const float *Fpa, const float *nrma, const float *Fpb, const float *nrmb, int nb,
+int lr_nn_fix_rows(lr_workspace *ws, bool permuted, const float *Fa, const float *nrma, const float *Fb, const float *nrmb, int nb,
                    int32_t *idx1, int32_t *idx2, float *s1, float *s2, hipStream_t st)
 {
-    hipLaunchKernelGGL(nn_fix_kernel, dim3(256), dim3(64), 0, st, Fpa, nrma, Fpb, nrmb, nb, ws->fix_list, ws->counters,
-                       idx1, idx2, s1, s2);
+    if (permuted)
+        hipLaunchKernelGGL(nn_fix_kernel<true>, dim3(256), dim3(64), 0, st, Fa, nrma, Fb, nrmb, nb, ws->fix_list, ws->counters,
+                           idx1, idx2, s1, s2);
+    else
+        hipLaunchKernelGGL(nn_fix_kernel<false>, dim3(256), dim3(64), 0, st, Fa, nrma, Fb, nrmb, nb, ws->fix_list, ws->counters,
+                           idx1, idx2, s1, s2);
     LR_LAUNCH_CHECK();
     return LR_OK;
 }
@@ -333,8 +344,6 @@ int lr_nn_run(lr_workspace *ws, const float *Fa, const float *nrma, int na, cons
     hipLaunchKernelGGL(nn_finalize_kernel, dim3(lr_cdiv(na, 256)), dim3(256), 0, st, na, nstrips, ws->max_n,
                        ws->pb1, ws->pb2, ws->pb3, ws->pi1, ws->pi2, idx1, idx2, s1, s2, ws->fix_list, ws->counters);
     LR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(nn_fix_kernel, dim3(256), dim3(64), 0, st, Fa, nrma, Fb, nrmb, nb, ws->fix_list, ws->counters,
-                       idx1, idx2, s1, s2);
     LR_LAUNCH_CHECK();
-    return LR_OK;
+    return lr_nn_fix_rows(ws, true, Fa, nrma, Fb, nrmb, nb, idx1, idx2, s1, s2, st);
 }

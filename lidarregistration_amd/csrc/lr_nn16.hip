@@ -36,44 +36,49 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define LR_INF __builtin_huge_valf()
 #define LR_IMAX 0x7fffffff
 
-// ------------------------------------------------------------------ prep: norms, fp32 de-interleaved copy, f16 copy
+// ------------------------------------------------------------------ prep: norms + f16 copy
+// Eight threads per row (coalesced 16-byte loads).  The norm is the sequential fp32 fma chain over k = 0..31 of the
+// arithmetic contract: thread t continues the chain over its four values from where thread t-1 stopped.
 // H[row] (64 B) = f16 of { k0..7, k16..23 | k8..15, k24..31 }: lane half h of an MFMA operand reads bytes [32h, 32h+32).
 __global__ void __launch_bounds__(256)
-nn16_prep_kernel(const float *__restrict__ F, int n, float *__restrict__ Fp, _Float16 *__restrict__ H,
-                 float *__restrict__ nrm, uint32_t *__restrict__ max_norm_bits)
+nn16_prep_kernel(const float *__restrict__ F, int n, _Float16 *__restrict__ H, float *__restrict__ nrm,
+                 float *__restrict__ block_max)
 {
-    int row = blockIdx.x * blockDim.x + threadIdx.x;
-    float acc = 0.0f;
-    if (row < n) {
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(F + (size_t)row * 32);
-        float v[32];
+    __shared__ float s_m[4];
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int row = gid >> 3, t = gid & 7, lane = threadIdx.x & 63;
+    const bool live = row < n;
+    f32x4 v = { 0.0f, 0.0f, 0.0f, 0.0f };
+    if (live) v = reinterpret_cast<const f32x4 *>(F + (size_t)row * 32)[t];
+    float run = 0.0f;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { f32x4 t = src[q]; v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w; }
-#pragma unroll
-        for (int k = 0; k < 32; ++k) acc = __builtin_fmaf(v[k], v[k], acc);
-        nrm[row] = acc;
-        f32x4 *dst = reinterpret_cast<f32x4 *>(Fp + (size_t)row * 32);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            f32x4 e = { v[8 * q], v[8 * q + 2], v[8 * q + 4], v[8 * q + 6] };
-            f32x4 o = { v[8 * q + 1], v[8 * q + 3], v[8 * q + 5], v[8 * q + 7] };
-            dst[q] = e; dst[4 + q] = o;
-        }
-        f16x8 *hd = reinterpret_cast<f16x8 *>(H + (size_t)row * 32);
-        const int kbase[4] = { 0, 16, 8, 24 };
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            f16x8 hv;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) hv[j] = (_Float16)v[kbase[c] + j];
-            hd[c] = hv;
-        }
+    for (int s = 0; s < 8; ++s) {
+        float in = __shfl(run, (lane & ~7) | (s > 0 ? s - 1 : 0));
+        if (s == 0) in = 0.0f;
+        float out = __builtin_fmaf(v.x, v.x, in);
+        out = __builtin_fmaf(v.y, v.y, out);
+        out = __builtin_fmaf(v.z, v.z, out);
+        out = __builtin_fmaf(v.w, v.w, out);
+        if (t == s) run = out;
     }
-    // block max of the norms -> one atomic (norms are >= 0, so their bit patterns order like unsigned ints)
-    float m = acc;
+    const float norm = __shfl(run, (lane & ~7) | 7);
+    if (live) {
+        if (t == 0) nrm[row] = norm;
+        // k = 4t..4t+3 sits in 8-element chunk c = t/2; chunks are stored in the order 0, 2, 1, 3
+        const int c = t >> 1;
+        const int pos = (c == 0 ? 0 : c == 1 ? 2 : c == 2 ? 1 : 3) * 8 + (t & 1) * 4;
+        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+        f16x4 hv = { (_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w };
+        *reinterpret_cast<f16x4 *>(H + (size_t)row * 32 + pos) = hv;
+    }
+    // largest norm of the block (32 rows) -> block_max[blockIdx.x]; the threshold kernel reduces that short array
+    // (no same-address atomics: thousands of them serialise at ~12 ns each)
+    float m = live ? norm : 0.0f;
 #pragma unroll
     for (int k = 32; k >= 1; k >>= 1) m = fmaxf(m, __shfl_xor(m, k));
-    if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(max_norm_bits, __float_as_uint(m));
+    if (lane == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) block_max[blockIdx.x] = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
 }
 
 // ------------------------------------------------------------------ pass A / pass B
@@ -304,11 +309,20 @@ nn16_pass_kernel(const _Float16 *__restrict__ Hq, int na, const _Float16 *__rest
 // U = need-th smallest sampled u' = -2 * (need-th largest g)
 __global__ void __launch_bounds__(256)
 nn16_thresh_kernel(int na, int nstrips, int part_stride, const float *__restrict__ pg1, const float *__restrict__ pg2,
-                   const float *__restrict__ nQ, const uint32_t *__restrict__ max_norm_c_bits, int need,
+                   const float *__restrict__ nQ, const float *__restrict__ block_max_c, int nblk_c, int need,
                    float *__restrict__ tau, int32_t *__restrict__ counters)
 {
+    __shared__ float s_m[4];
     const int row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row == 0) counters[LR_CNT_FIX] = 0;
+    // max_j n1_j of the column cloud from the per-block maxima of its prep kernel
+    float mx = 0.0f;
+    for (int b = threadIdx.x; b < nblk_c; b += 256) mx = fmaxf(mx, block_max_c[b]);
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) mx = fmaxf(mx, __shfl_xor(mx, k));
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    const float max_nc = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
     if (row >= na) return;
     float a1 = pg1[row], a2 = pg2[row];
     for (int s = 1; s < nstrips; ++s) {
@@ -318,7 +332,7 @@ nn16_thresh_kernel(int na, int nstrips, int part_stride, const float *__restrict
         a1 = hi;
     }
     const float U = -2.0f * (need >= 2 ? a2 : a1);
-    const float scale = nQ[row] + __uint_as_float(*max_norm_c_bits);
+    const float scale = nQ[row] + max_nc;
     const float E = 1.05e-3f * scale + 4e-7f;
     // U + 2E + sqrt band 2^-21 (n0 + U + E) + rounding slop (this expression, y = tau/2 folded into the MFMA accumulator)
     tau[row] = U + 2.0f * E + 6e-6f * scale + 2e-6f * fabsf(U);   // +inf when fewer than `need` columns were sampled
@@ -400,16 +414,16 @@ nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, in
 }
 
 // ------------------------------------------------------------------ host side
-int lr_nn16_prep(lr_workspace *ws, const float *F, int n, float *Fp, _Float16 *H, float *nrm, uint32_t *max_bits, hipStream_t st)
+int lr_nn16_prep(lr_workspace *ws, const float *F, int n, _Float16 *H, float *nrm, float *block_max, hipStream_t st)
 {
     (void)ws;
-    hipLaunchKernelGGL(nn16_prep_kernel, dim3(lr_cdiv(n, 256)), dim3(256), 0, st, F, n, Fp, H, nrm, max_bits);
+    hipLaunchKernelGGL(nn16_prep_kernel, dim3(lr_cdiv(n, 32)), dim3(256), 0, st, F, n, H, nrm, block_max);
     LR_LAUNCH_CHECK();
     return LR_OK;
 }
 
-int lr_nn16_run(lr_workspace *ws, const float *Fq, const float *Fpq, const _Float16 *Hq, const float *nQ, int na,
-                const float *Fc, const float *Fpc, const _Float16 *Hc, const float *nC, const uint32_t *max_c_bits, int nb,
+int lr_nn16_run(lr_workspace *ws, const float *Fq, const _Float16 *Hq, const float *nQ, int na,
+                const float *Fc, const _Float16 *Hc, const float *nC, const float *block_max_c, int nb,
                 int need, int32_t *idx1, int32_t *idx2, float *s1, float *s2, hipStream_t st)
 {
     const int ntiles = lr_cdiv(nb, 32);
@@ -429,7 +443,7 @@ int lr_nn16_run(lr_workspace *ws, const float *Fq, const float *Fpq, const _Floa
     hipLaunchKernelGGL(nn16_pass_kernel<0>, grid, dim3(256), 0, st, Hq, na, Hc, nC, nb, tps, stride, ws->max_n, ws->pb1, ws->pb2,
                        (const float *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
     hipLaunchKernelGGL(nn16_thresh_kernel, dim3(lr_cdiv(na, 256)), dim3(256), 0, st, na, strips, ws->max_n, ws->pb1, ws->pb2, nQ,
-                       max_c_bits, need, ws->tau, ws->counters);
+                       block_max_c, lr_cdiv(nb, 32), need, ws->tau, ws->counters);
     if (ws->timing && !ws->ev_pending) { LR_HIP(hipEventRecord(ws->ev[0], st)); }
     hipLaunchKernelGGL(nn16_pass_kernel<1>, grid, dim3(256), 0, st, Hq, na, Hc, nC, nb, tps, 1, ws->max_n, (float *)nullptr,
                        (float *)nullptr, ws->tau, ws->cand_cnt, ws->cand);
@@ -437,5 +451,5 @@ int lr_nn16_run(lr_workspace *ws, const float *Fq, const float *Fpq, const _Floa
     hipLaunchKernelGGL(nn16_exact_kernel, dim3(lr_cdiv(na, 64)), dim3(256), 0, st, Fq, nQ, na, Fc, nC, nb, ws->cand_cnt, ws->cand,
                        strips, need, idx1, idx2, s1, s2, ws->fix_list, ws->counters);
     LR_LAUNCH_CHECK();
-    return lr_nn_fix_rows(ws, Fpq, nQ, Fpc, nC, nb, idx1, idx2, s1, s2, st);
+    return lr_nn_fix_rows(ws, false, Fq, nQ, Fc, nC, nb, idx1, idx2, s1, s2, st);
 }

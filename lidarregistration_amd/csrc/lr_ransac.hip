@@ -141,14 +141,13 @@ __device__ __forceinline__ void kabsch_sample(const double P[NS][3], const doubl
     rt_from_cov(H, cp, cq, T);
 }
 
-// sample + ELC + Kabsch of hypothesis h; false when the pre-check rejects it
+// sample of hypothesis h and its edge-length pre-check; false when the pre-check rejects it
 template <int NS>
-__device__ __forceinline__ bool hypothesis_T(const float *__restrict__ corr8, int m, uint64_t seed, uint64_t h,
-                                             int use_elc, double T[16])
+__device__ __forceinline__ bool hypothesis_sample(const float *__restrict__ corr8, int m, uint64_t seed, uint64_t h,
+                                                  int use_elc, double P[NS][3], double Q[NS][3])
 {
     uint32_t c[4] = { (uint32_t)h, (uint32_t)(h >> 32), 0u, 0u };
     philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-    double P[NS][3], Q[NS][3];
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
         uint32_t s = __umulhi(c[k], (uint32_t)m);
@@ -157,41 +156,56 @@ __device__ __forceinline__ bool hypothesis_T(const float *__restrict__ corr8, in
         P[k][0] = (double)lo.x; P[k][1] = (double)lo.y; P[k][2] = (double)lo.z;
         Q[k][0] = (double)lo.w; Q[k][1] = (double)hi.x; Q[k][2] = (double)hi.y;
     }
-    if (use_elc) {
-        bool ok = true;
+    if (!use_elc) return true;
+    bool ok = true;
 #pragma unroll
-        for (int i = 0; i < NS; ++i)
+    for (int i = 0; i < NS; ++i)
 #pragma unroll
-            for (int j = i + 1; j < NS; ++j) {
-                double sx = P[j][0] - P[i][0], sy = P[j][1] - P[i][1], sz = P[j][2] - P[i][2];
-                double tx = Q[j][0] - Q[i][0], ty = Q[j][1] - Q[i][1], tz = Q[j][2] - Q[i][2];
-                double ds = sqrt((sx * sx + sy * sy) + sz * sz);
-                double dt = sqrt((tx * tx + ty * ty) + tz * tz);
-                if (ds < dt * 0.9 || dt < ds * 0.9) ok = false;
-            }
-        if (!ok) return false;
-    }
-    kabsch_sample<NS>(P, Q, T);
-    return true;
+        for (int j = i + 1; j < NS; ++j) {
+            double sx = P[j][0] - P[i][0], sy = P[j][1] - P[i][1], sz = P[j][2] - P[i][2];
+            double tx = Q[j][0] - Q[i][0], ty = Q[j][1] - Q[i][1], tz = Q[j][2] - Q[i][2];
+            double ds = sqrt((sx * sx + sy * sy) + sz * sz);
+            double dt = sqrt((tx * tx + ty * ty) + tz * tz);
+            if (ds < dt * 0.9 || dt < ds * 0.9) ok = false;
+        }
+    return ok;
 }
 
 // ------------------------------------------------------------------ gen
+// 256 hypothesis ids per block.  Phase 1: every thread draws its sample and runs the pre-check (cheap, ~93 % fail on
+// 3-point samples at a 40 % inlier ratio).  Phase 2: the survivors are compacted through LDS so that the expensive fp64
+// Kabsch runs on densely packed lanes of one wave instead of a few stragglers in every wave.
 template <int NS>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(256)
 ransac_gen_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__restrict__ m_dev, lr_ransac_params p,
                   float *__restrict__ models, double *__restrict__ models64, int32_t *__restrict__ model_h,
                   uint32_t *__restrict__ score_cnt, unsigned long long *__restrict__ score_ssq,
                   int32_t *__restrict__ counters)
 {
+    __shared__ int s_pass[256];
+    __shared__ int s_np, s_base;
     const int m = m_dev ? min(*m_dev, m_max) : m_max;
-    const int h = blockIdx.x * 64 + threadIdx.x;
-    if (h >= p.iters || m <= 0) return;
-    double T[16];
-    if (!hypothesis_T<NS>(corr8, m, p.seed, (uint64_t)h, p.use_elc, T)) return;
-    const int slot = atomicAdd(&counters[LR_CNT_NVALID], 1);
+    if (m <= 0) return;
+    if (threadIdx.x == 0) s_np = 0;
+    __syncthreads();
+    const int h = blockIdx.x * 256 + threadIdx.x;
+    {
+        double P[NS][3], Q[NS][3];
+        if (h < p.iters && hypothesis_sample<NS>(corr8, m, p.seed, (uint64_t)h, p.use_elc, P, Q)) s_pass[atomicAdd(&s_np, 1)] = h;
+    }
+    __syncthreads();
+    const int np = s_np;
+    if (threadIdx.x == 0 && np > 0) s_base = atomicAdd(&counters[LR_CNT_NVALID], np);
+    __syncthreads();
+    if ((int)threadIdx.x >= np) return;
+    const int hh = s_pass[threadIdx.x];
+    double P[NS][3], Q[NS][3], T[16];
+    hypothesis_sample<NS>(corr8, m, p.seed, (uint64_t)hh, 0, P, Q);
+    kabsch_sample<NS>(P, Q, T);
+    const int slot = s_base + threadIdx.x;
 #pragma unroll
     for (int k = 0; k < 12; ++k) { models[(size_t)slot * 12 + k] = (float)T[k]; models64[(size_t)slot * 12 + k] = T[k]; }
-    model_h[slot] = h;
+    model_h[slot] = hh;
     score_cnt[slot] = 0u;
     score_ssq[slot] = 0ull;
 }
@@ -304,16 +318,16 @@ int lr_ransac_run(lr_workspace *ws, const float *corr8, int m_max, const int32_t
     LR_REQUIRE(p->iters >= 0 && p->iters <= ws->max_iters, LR_ESIZE, "lr_ransac: iters exceeds the workspace");
     LR_REQUIRE(m_max >= 0 && m_max <= ws->max_n0, LR_ESIZE, "lr_ransac: m exceeds the workspace");
     LR_REQUIRE(p->thr2 > 0.0f && p->thr2 < 2048.0f, LR_EINVAL, "lr_ransac: thr2 must be in (0, 2048)");
-    const int gb = lr_cdiv(p->iters > 0 ? p->iters : 1, 64);
+    const int gb = lr_cdiv(p->iters > 0 ? p->iters : 1, 256);
     int sub = (int)(4095.0 / ((double)p->thr2 * 1.0000001 + 1e-6));     // sub * thr2 * 2^20 < 2^32
     if (sub > 4096) sub = 4096;
     if (sub < 1) sub = 1;
     if (ws->timing && ws->ev_pending == 1) { LR_HIP(hipEventRecord(ws->ev[2], st)); }
     if (p->sample_size == 3)
-        hipLaunchKernelGGL(ransac_gen_kernel<3>, dim3(gb), dim3(64), 0, st, corr8, m_max, m_dev, *p, ws->models, ws->models64,
+        hipLaunchKernelGGL(ransac_gen_kernel<3>, dim3(gb), dim3(256), 0, st, corr8, m_max, m_dev, *p, ws->models, ws->models64,
                            ws->model_h, ws->score_cnt, ws->score_ssq, ws->counters);
     else
-        hipLaunchKernelGGL(ransac_gen_kernel<4>, dim3(gb), dim3(64), 0, st, corr8, m_max, m_dev, *p, ws->models, ws->models64,
+        hipLaunchKernelGGL(ransac_gen_kernel<4>, dim3(gb), dim3(256), 0, st, corr8, m_max, m_dev, *p, ws->models, ws->models64,
                            ws->model_h, ws->score_cnt, ws->score_ssq, ws->counters);
     hipLaunchKernelGGL(ransac_score_kernel, dim3(LR_SCORE_BLOCKS), dim3(64), 0, st, corr8, m_max, m_dev, p->thr2, ws->models,
                        ws->score_cnt, ws->score_ssq, ws->counters, sub);

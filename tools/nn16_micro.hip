@@ -33,7 +33,7 @@ int main(int argc, char **argv)
         float ms = timeit([&] { hipLaunchKernelGGL(nn16_pass_kernel<0>, grid, dim3(256), 0, 0, H, n, H, nrm, n, tps, stride, n, pu1, pu2, (const float*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr); });
         printf("passA stride %d strips %d: %.3f ms\n", stride, strips, ms);
         // thresholds from this pass A, then pass B
-        hipLaunchKernelGGL(nn16_thresh_kernel, dim3((n+255)/256), dim3(256), 0, 0, n, strips, n, pu1, pu2, nrm, mx + 0, 2, tau, cnt);  // cnt doubles as the counters block here
+        hipLaunchKernelGGL(nn16_thresh_kernel, dim3((n+255)/256), dim3(256), 0, 0, n, strips, n, pu1, pu2, nrm, (const float*)mxf, 1, 2, tau, cnt);
         int tpsb = (ntiles + strips - 1) / strips;
         float msb = timeit([&] { hipLaunchKernelGGL(nn16_pass_kernel<1>, grid, dim3(256), 0, 0, H, n, H, nrm, n, tpsb, 1, n, (float*)nullptr, (float*)nullptr, tau, cnt, cand); });
         std::vector<int32_t> hc((size_t)n*strips); hipMemcpy(hc.data(), cnt, (size_t)n*strips*4, hipMemcpyDeviceToHost);
