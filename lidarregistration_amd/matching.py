@@ -30,12 +30,13 @@ def workspace(n0, n1, iters=0, dim=32):
     """Cached per-device workspace large enough for (n0, n1, iters)."""
     dev = torch.cuda.current_device()
     ws = _WS.get(dev)
-    if ws is None or not ws.fits(n0, n1, iters) or ws.dim != dim:
+    if ws is None or not ws.handle or not ws.fits(n0, n1, iters) or ws.dim != dim:
+        grow = (ws.max_n0, ws.max_n1, ws.max_iters) if ws is not None else (0, 0, 0)
         if ws is not None:
+            _WS.pop(dev, None)
             torch.cuda.synchronize()
             ws.close()
-        ws = _ext.Workspace(max(n0, ws.max_n0 if ws else 0), max(n1, ws.max_n1 if ws else 0), dim,
-                            max(iters, ws.max_iters if ws else 0, 1))
+        ws = _ext.Workspace(max(n0, grow[0]), max(n1, grow[1]), dim, max(iters, grow[2], 1))
         _WS[dev] = ws
     return ws
 

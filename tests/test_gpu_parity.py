@@ -251,3 +251,88 @@ def test_FR_full_size_config2(lr, oracle):
 def test_errors_are_loud(lr):
     with pytest.raises(lr.ext.LidarRegError):
         lr.matching.nn_top2_dev(np.zeros((10, 16), np.float32), np.zeros((10, 16), np.float32))
+
+
+# ----------------------------------------------------------------------------- f16 filter robustness (error bound, fallbacks)
+@pytest.mark.parametrize("scale0,scale1", [(1.0, 1.0), (37.0, 37.0), (1e-3, 1e-3), (3.0, 0.2), (300.0, 300.0), (1e-6, 1e-6)])
+def test_nn_scaled_features_still_bit_exact(lr, oracle, scale0, scale1):
+    # non-unit-norm descriptors: the filter's error bound scales with the norms; 300 overflows f16 dot products only
+    # mildly, 1e-6 underflows f16 entirely -> every row goes through the exact fallback; results must not change
+    F0, F1 = synth.make_features(1500, 1300, 32, 0.5, 1.0, 61)
+    F0 = (F0 * np.float32(scale0)).astype(np.float32); F1 = (F1 * np.float32(scale1)).astype(np.float32)
+    i1, i2, s1, s2 = lr.matching.nn_top2_dev(F0, F1, want_2nd=True, want_dist=True)
+    o1, o2, os1, os2 = oracle.nn_top2(F0, F1)
+    assert np.array_equal(i1.cpu().numpy(), o1) and np.array_equal(i2.cpu().numpy(), o2)
+    assert np.array_equal(_bits(s1.cpu().numpy()), _bits(os1)) and np.array_equal(_bits(s2.cpu().numpy()), _bits(os2))
+
+
+def test_nn_f16_overflow_and_mixed_norms(lr, oracle):
+    rng = np.random.default_rng(3)
+    F0, F1 = synth.make_features(900, 1100, 32, 0.5, 1.0, 62)
+    F0 = (F0 * rng.uniform(0.05, 20.0, (900, 1))).astype(np.float32)          # per-row norms over 2.5 decades
+    F1 = (F1 * rng.uniform(0.05, 20.0, (1100, 1))).astype(np.float32)
+    F1[::97] *= np.float32(1e5)                                                # some rows beyond the f16 range (inf in H)
+    i1, i2, _, _ = lr.matching.nn_top2_dev(F0, F1, want_2nd=True)
+    o1, o2, _, _ = oracle.nn_top2(F0, F1)
+    assert np.array_equal(i1.cpu().numpy(), o1) and np.array_equal(i2.cpu().numpy(), o2)
+
+
+def test_nn_lattice_many_near_equal_distances(lr, oracle):
+    # descriptors on a coarse lattice: huge numbers of equal and nearly equal distances -> candidate lists overflow for
+    # many rows, which must route them through the exact row kernel without changing a single index
+    rng = np.random.default_rng(9)
+    F0 = rng.integers(-1, 2, (800, 32)).astype(np.float32) * 0.25
+    F1 = rng.integers(-1, 2, (2000, 32)).astype(np.float32) * 0.25
+    F1[:500] = F1[500:1000]                                                    # exact duplicates
+    i1, i2, s1, _ = lr.matching.nn_top2_dev(F0, F1, want_2nd=True, want_dist=True)
+    o1, o2, os1, _ = oracle.nn_top2(F0, F1)
+    assert np.array_equal(i1.cpu().numpy(), o1) and np.array_equal(i2.cpu().numpy(), o2)
+    assert np.array_equal(_bits(s1.cpu().numpy()), _bits(os1))
+
+
+@pytest.mark.parametrize("n0,n1", [(1, 1), (2, 1), (1, 2), (3, 3), (31, 33), (64, 2), (257, 31)])
+def test_nn_tiny_clouds(lr, oracle, n0, n1):
+    F0, F1 = synth.make_features(n0, n1, 32, 0.5, 1.0, 70 + n0 + n1)
+    i1, i2, s1, _ = lr.matching.nn_top2_dev(F0, F1, want_2nd=True, want_dist=True)
+    o1, o2, os1, _ = oracle.nn_top2(F0, F1)
+    assert np.array_equal(i1.cpu().numpy(), o1)
+    if n1 >= 2:
+        assert np.array_equal(i2.cpu().numpy(), o2)
+    assert np.array_equal(_bits(s1.cpu().numpy()), _bits(os1))
+
+
+def test_fp32_mfma_path_agrees(lr, oracle, monkeypatch):
+    # the exact fp32-MFMA kernel (LIDARREG_NN_PATH=fp32) stays available and must give the same answers
+    import ctypes
+    from lidarregistration_amd import _ext
+    monkeypatch.setenv("LIDARREG_NN_PATH", "fp32")
+    F0, F1 = synth.make_features(3000, 2500, 32, 0.5, 1.0, 2)
+    ws = _ext.Workspace(3000, 2500, 32, 1)
+    t = lr.torch
+    f0, f1 = t.from_numpy(F0).cuda(), t.from_numpy(F1).cuda()
+    i1 = t.empty(3000, dtype=t.int32, device="cuda"); i2 = t.empty_like(i1)
+    _ext.check(_ext.lib().lr_nn_top2(ws.handle, f0.data_ptr(), 3000, f1.data_ptr(), 2500, 32, i1.data_ptr(), i2.data_ptr(), None, None,
+                                      t.cuda.current_stream().cuda_stream))
+    o1, o2, _, _ = oracle.nn_top2(F0, F1)
+    assert np.array_equal(i1.cpu().numpy(), o1) and np.array_equal(i2.cpu().numpy(), o2)
+    ws.close()
+
+
+def test_FR_gpf_full_size(lr, oracle):
+    """30k-point pair through --mode GPF (factor 0.5 so that the filter really selects) against the oracle pipeline."""
+    p = synth.make_pair(N=30000, seed=52, clustered=True)
+    a = Args(mode="GPF", codebase="GC", iters=20000, GPF_factor=0.5)
+    t = lr.torch.from_numpy
+    T, elapsed, _, _, n_init, _, n_filt, _ = lr.FR.FR(t(p["xyz0"]), t(p["xyz1"]), t(p["feats0"]), t(p["feats1"]), a, p["T_gt"])
+    e = oracle.register_pair(p["xyz0"], p["xyz1"], p["feats0"], p["feats1"], mode="GPF", iters=20000, sample_size=3, seed=51, args=a)
+    assert n_filt == len(e["idx0"]) and n_filt < n_init
+    assert np.radians(oracle.rotation_error_deg(T, e["T"])) <= 1e-4 and oracle.translation_error_cm(T, e["T"]) / 100 <= 1e-3
+
+
+def test_ransac_iteration_property_more_iters_never_worse(lr):
+    src, tgt, _ = _planted(n=5000, inlier=0.25, seed=77)
+    best = 0
+    for iters in (200, 2000, 20000):
+        _, info = lr.ransac.ransac_dev(src, tgt, iters, seed=5)
+        assert info["best_count"] >= best          # hypotheses 0..iters-1 are a prefix of the longer run
+        best = info["best_count"]
