@@ -191,12 +191,13 @@ static int nn_forward(lr_workspace *ws, const float *F0, int n0, const float *F1
 
 // reverse: rows of cloud 1 against cloud 0 (first NN only).  The reference restricts it to the unique forward
 // targets (matching.py:224-225); rows that are nobody's target never enter the intersection, so all rows is equivalent.
-static int nn_reverse(lr_workspace *ws, const float *F0, int n0, const float *F1, int n1, int32_t *rev, hipStream_t st)
+static int nn_reverse(lr_workspace *ws, const float *F0, int n0, const float *F1, int n1, const int32_t *fwd_idx1,
+                      int32_t *rev, hipStream_t st)
 {
     if (ws->nn_path == LR_NN_PATH_FP32_MFMA)
         return lr_nn_run(ws, ws->Fp1, ws->nrm1, n1, ws->Fp0, ws->nrm0, n0, rev, nullptr, nullptr, nullptr, st);
-    return lr_nn16_run(ws, F1, ws->H1, ws->nrm1, n1, F0, ws->H0, ws->nrm0, ws->bmax0, n0,
-                       1, rev, nullptr, nullptr, nullptr, st);
+    // seeded by the forward pairs: only columns some query points at are resolved (others get -1)
+    return lr_nn16_reverse(ws, F0, ws->H0, ws->nrm0, ws->bmax0, n0, F1, ws->H1, ws->nrm1, n1, fwd_idx1, rev, st);
 }
 
 // ------------------------------------------------------------------ a1/a2
@@ -219,7 +220,7 @@ extern "C" int lr_nn_to_mutual(lr_workspace *ws, const float *F0, int n0, const 
     LR_REQUIRE(idx1, LR_EINVAL, "lr_nn_to_mutual: idx1 is required");
     hipStream_t st = (hipStream_t)stream;
     LR_TRY(prep_both(ws, F0, n0, F1, n1, st));
-    LR_TRY(nn_reverse(ws, F0, n0, F1, n1, ws->rev_idx1, st));
+    LR_TRY(nn_reverse(ws, F0, n0, F1, n1, idx1, ws->rev_idx1, st));
     return lr_mutual_run(ws, n0, idx1, idx2, ws->rev_idx1, is_bb, o0, o1, o2, n_out, st);
 }
 
@@ -232,7 +233,7 @@ extern "C" int lr_gpf(lr_workspace *ws, const float *F0, int n0, const float *F1
     LR_REQUIRE(idx1 && idx2 && xyz0 && o0 && o1, LR_EINVAL, "lr_gpf: null pointer");
     hipStream_t st = (hipStream_t)stream;
     LR_TRY(prep_both(ws, F0, n0, F1, n1, st));
-    LR_TRY(nn_reverse(ws, F0, n0, F1, n1, ws->rev_idx1, st));
+    LR_TRY(nn_reverse(ws, F0, n0, F1, n1, idx1, ws->rev_idx1, st));
     LR_TRY(lr_mutual_run(ws, n0, idx1, nullptr, ws->rev_idx1, ws->is_bb, nullptr, nullptr, nullptr, nullptr, st));
     return lr_gpf_run(ws, F0, n0, F1, dim, idx1, idx2, ws->is_bb, xyz0, grid_wid, factor, o0, o1, o2, oscore, n_out, st);
 }
@@ -292,7 +293,7 @@ extern "C" int lr_register_pair(lr_workspace *ws, const float *xyz0, const float
     if (p->mode == LR_MODE_NO_FILTER) {
         LR_TRY(lr_identity_corr(ws, n0, ws->nn_idx1, ws->nn_idx2, ws->corr_idx0, ws->corr_idx1, ws->corr_idx2, m_dev, st));
     } else {
-        LR_TRY(nn_reverse(ws, F0, n0, F1, n1, ws->rev_idx1, st));
+        LR_TRY(nn_reverse(ws, F0, n0, F1, n1, ws->nn_idx1, ws->rev_idx1, st));
         if (p->mode == LR_MODE_MNN) {
             LR_TRY(lr_mutual_run(ws, n0, ws->nn_idx1, ws->nn_idx2, ws->rev_idx1, ws->is_bb, ws->corr_idx0, ws->corr_idx1,
                                  ws->corr_idx2, m_dev, st));

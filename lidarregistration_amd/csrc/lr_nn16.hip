@@ -348,6 +348,7 @@ __global__ void __launch_bounds__(256)
 nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, int na,
                   const float *__restrict__ Fc, const float *__restrict__ nC, int nb,
                   const int32_t *__restrict__ cand_cnt, const int32_t *__restrict__ cand, int nstrips, int need,
+                  const float *__restrict__ skip_tau,
                   int32_t *__restrict__ idx1, int32_t *__restrict__ idx2, float *__restrict__ s1o, float *__restrict__ s2o,
                   int32_t *__restrict__ fix_list, int32_t *__restrict__ counters)
 {
@@ -402,6 +403,10 @@ nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, in
         b2 = sy ? y1 : x2; i2 = sy ? yi1 : xi2;
     }
     if (!live || q != 0) return;
+    if (skip_tau && skip_tau[row] == -LR_INF) {      // nobody asked for this row (reverse NN of a column no query points at)
+        idx1[row] = -1;
+        return;
+    }
     if (over || total < min(need, nb)) {
         const int slot = atomicAdd(&counters[LR_CNT_FIX], 1);
         fix_list[slot] = row;
@@ -449,7 +454,87 @@ int lr_nn16_run(lr_workspace *ws, const float *Fq, const _Float16 *Hq, const flo
                        (float *)nullptr, ws->tau, ws->cand_cnt, ws->cand);
     if (ws->timing && !ws->ev_pending) { LR_HIP(hipEventRecord(ws->ev[1], st)); ws->ev_pending = 1; }
     hipLaunchKernelGGL(nn16_exact_kernel, dim3(lr_cdiv(na, 64)), dim3(256), 0, st, Fq, nQ, na, Fc, nC, nb, ws->cand_cnt, ws->cand,
-                       strips, need, idx1, idx2, s1, s2, ws->fix_list, ws->counters);
+                       strips, need, (const float *)nullptr, idx1, idx2, s1, s2, ws->fix_list, ws->counters);
     LR_LAUNCH_CHECK();
     return lr_nn_fix_rows(ws, false, Fq, nQ, Fc, nC, nb, idx1, idx2, s1, s2, st);
+}
+
+// ------------------------------------------------------------------ reverse NN seeded by the forward result
+// The mutual test only asks, for a column j that some query i points at, whether any other row beats that pair.  So the
+// reverse direction needs no sampling pass: the exact distance of the best forward pair (i*, j) IS an upper bound of the
+// column's minimum, and pass B looks for rows with u' <= s*^2 (1 + 4e-7) - n_j + E.  Columns nobody points at are
+// skipped (their reverse NN is reported as -1; the reference does not compute it either, matching.py:224-225).
+__global__ void __launch_bounds__(256)
+nn16_rev_seed_kernel(const float *__restrict__ F0, const float *__restrict__ n0v, int n0, const float *__restrict__ F1,
+                     const float *__restrict__ n1v, const int32_t *__restrict__ idx1, uint32_t *__restrict__ seed_bits)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n0) return;
+    const int j = idx1[i];
+    const f32x4 *pa = reinterpret_cast<const f32x4 *>(F0 + (size_t)i * 32);
+    const f32x4 *pb = reinterpret_cast<const f32x4 *>(F1 + (size_t)j * 32);
+    float acc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const f32x4 a = pa[k], b = pb[k];
+        acc = __builtin_fmaf(a.x, b.x, acc);
+        acc = __builtin_fmaf(a.y, b.y, acc);
+        acc = __builtin_fmaf(a.z, b.z, acc);
+        acc = __builtin_fmaf(a.w, b.w, acc);
+    }
+    // same value the reverse direction forms for (j, i): the sum n1 + n0 and the products commute bit for bit
+    const float d2 = __builtin_fmaf(-2.0f, acc, n0v[i] + n1v[j]);
+    const float sv = __builtin_sqrtf(fmaxf(d2, 1e-30f));
+    atomicMin(&seed_bits[j], __float_as_uint(sv));      // sv > 0: bit patterns order like the values
+}
+
+__global__ void __launch_bounds__(256)
+nn16_thresh_seed_kernel(int na, const uint32_t *__restrict__ seed_bits, const float *__restrict__ nQ,
+                        const float *__restrict__ block_max_c, int nblk_c, float *__restrict__ tau, int32_t *__restrict__ counters)
+{
+    __shared__ float s_m[4];
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row == 0) counters[LR_CNT_FIX] = 0;
+    float mx = 0.0f;
+    for (int b = threadIdx.x; b < nblk_c; b += 256) mx = fmaxf(mx, block_max_c[b]);
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) mx = fmaxf(mx, __shfl_xor(mx, k));
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    const float max_nc = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+    if (row >= na) return;
+    const float sv = __uint_as_float(seed_bits[row]);
+    if (!(sv < 3.0e38f)) { tau[row] = -LR_INF; return; }      // still the 0x7f7f7f7f fill: no query points at this row
+    const float scale = nQ[row] + max_nc;
+    const float E = 1.05e-3f * scale + 4e-7f;
+    const float d2hi = sv * sv * (1.0f + 6e-7f);               // every d2 whose sqrt rounds to <= sv lies below this
+    tau[row] = (d2hi - nQ[row]) + E + 6e-6f * scale + 2e-6f * d2hi;
+}
+
+int lr_nn16_reverse(lr_workspace *ws, const float *F0, const _Float16 *H0, const float *nrm0, const float *bmax0, int n0,
+                    const float *F1, const _Float16 *H1, const float *nrm1, int n1, const int32_t *fwd_idx1,
+                    int32_t *rev, hipStream_t st)
+{
+    // rows = cloud 1 (the columns of the forward direction), columns = cloud 0
+    const int na = n1, nb = n0;
+    const int ntiles = lr_cdiv(nb, 32);
+    const int row_blocks = lr_cdiv(na, 256);
+    int strips = lr_cdiv(1024, row_blocks);
+    int smax = ntiles / 8;
+    if (strips > smax) strips = smax;
+    if (strips > LR_NN_MAX_STRIPS) strips = LR_NN_MAX_STRIPS;
+    if (strips < 1) strips = 1;
+    const int tps = lr_cdiv(ntiles, strips);
+    uint32_t *seed = reinterpret_cast<uint32_t *>(ws->pb1);
+    LR_HIP(hipMemsetAsync(seed, 0x7f, sizeof(uint32_t) * (size_t)na, st));
+    hipLaunchKernelGGL(nn16_rev_seed_kernel, dim3(lr_cdiv(n0, 256)), dim3(256), 0, st, F0, nrm0, n0, F1, nrm1, fwd_idx1, seed);
+    hipLaunchKernelGGL(nn16_thresh_seed_kernel, dim3(lr_cdiv(na, 256)), dim3(256), 0, st, na, seed, nrm1, bmax0, lr_cdiv(nb, 32),
+                       ws->tau, ws->counters);
+    dim3 grid(row_blocks, strips);
+    hipLaunchKernelGGL(nn16_pass_kernel<1>, grid, dim3(256), 0, st, H1, na, H0, nrm0, nb, tps, 1, ws->max_n, (float *)nullptr,
+                       (float *)nullptr, ws->tau, ws->cand_cnt, ws->cand);
+    hipLaunchKernelGGL(nn16_exact_kernel, dim3(lr_cdiv(na, 64)), dim3(256), 0, st, F1, nrm1, na, F0, nrm0, nb, ws->cand_cnt, ws->cand,
+                       strips, 1, ws->tau, rev, (int32_t *)nullptr, (float *)nullptr, (float *)nullptr, ws->fix_list, ws->counters);
+    LR_LAUNCH_CHECK();
+    return lr_nn_fix_rows(ws, false, F1, nrm1, F0, nrm0, nb, rev, nullptr, nullptr, nullptr, st);
 }
