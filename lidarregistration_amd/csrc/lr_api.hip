@@ -47,6 +47,7 @@ void carve(lr_workspace *ws, Carver &c)
     ws->fix_list = c.take<int32_t>(n);
     ws->counters = c.take<int32_t>(LR_CNT_COUNT);
     ws->bmax0 = c.take<float>(n0 / 32 + 2); ws->bmax1 = c.take<float>(n1 / 32 + 2);
+    ws->rev_seed = c.take<uint32_t>(n1);
     ws->nn_idx1 = c.take<int32_t>(n0); ws->nn_idx2 = c.take<int32_t>(n0);
     ws->nn_s1 = c.take<float>(n0); ws->nn_s2 = c.take<float>(n0);
     ws->rev_idx1 = c.take<int32_t>(n1);
@@ -175,8 +176,7 @@ static int prep_both(lr_workspace *ws, const float *F0, int n0, const float *F1,
         LR_TRY(lr_nn_prep(ws, F0, n0, ws->Fp0, ws->nrm0, st));
         return lr_nn_prep(ws, F1, n1, ws->Fp1, ws->nrm1, st);
     }
-    LR_TRY(lr_nn16_prep(ws, F0, n0, ws->H0, ws->nrm0, ws->bmax0, st));
-    return lr_nn16_prep(ws, F1, n1, ws->H1, ws->nrm1, ws->bmax1, st);
+    return lr_nn16_prep(ws, F0, n0, F1, n1, st);
 }
 
 // forward: rows of cloud 0 against cloud 1 (first + second NN)
@@ -296,22 +296,22 @@ extern "C" int lr_register_pair(lr_workspace *ws, const float *xyz0, const float
         LR_TRY(nn_reverse(ws, F0, n0, F1, n1, ws->nn_idx1, ws->rev_idx1, st));
         if (p->mode == LR_MODE_MNN) {
             LR_TRY(lr_mutual_run(ws, n0, ws->nn_idx1, ws->nn_idx2, ws->rev_idx1, ws->is_bb, ws->corr_idx0, ws->corr_idx1,
-                                 ws->corr_idx2, m_dev, st));
+                                 ws->corr_idx2, m_dev, st, xyz0, xyz1, ws->corr8));
         } else {
             LR_TRY(lr_mutual_run(ws, n0, ws->nn_idx1, nullptr, ws->rev_idx1, ws->is_bb, nullptr, nullptr, nullptr, nullptr, st));
             LR_TRY(lr_gpf_run(ws, F0, n0, F1, dim, ws->nn_idx1, ws->nn_idx2, ws->is_bb, xyz0, p->gpf_grid_wid, p->gpf_factor,
-                              ws->corr_idx0, ws->corr_idx1, ws->corr_idx2, ws->corr_score, m_dev, st));
+                              ws->corr_idx0, ws->corr_idx1, ws->corr_idx2, ws->corr_score, m_dev, st, xyz1, ws->corr8));
         }
     }
-    // 3. RANSAC on the surviving pairs (FR.py:70-97)
-    LR_TRY(lr_pack_corr(ws, xyz0, xyz1, ws->corr_idx0, ws->corr_idx1, n0, m_dev, ws->corr8, st));
+    // 3. RANSAC on the surviving pairs (FR.py:70-97); MNN / GPF pack the point pairs inside their compaction kernel
+    if (p->mode == LR_MODE_NO_FILTER) LR_TRY(lr_pack_corr(ws, xyz0, xyz1, ws->corr_idx0, ws->corr_idx1, n0, m_dev, ws->corr8, st));
     LR_TRY(lr_ransac_run(ws, ws->corr8, n0, m_dev, &p->ransac, ws->T_tmp, ws->res_tmp, st));
     // 4. LS refit over the original NN pairs (FR.py:99-111)
     const double *T_final = ws->T_tmp;
     if (p->refit) {
         LR_TRY(lr_refit_run(ws, xyz0, n0, xyz1, ws->nn_idx1, ws->T_tmp, p->refit_thr2,
-                            ws->T_tmp + 16, n_refit, ws->res_tmp, st));
-        T_final = ws->T_tmp + 16;
+                            ws->T_tmp + 16, n_refit, ws->res_tmp, st, out));
+        return LR_OK;
     }
     hipLaunchKernelGGL(pair_result_kernel, dim3(1), dim3(64), 0, st, ws->T_tmp, T_final, ws->res_tmp, ws->counters,
                        p->refit ? n_refit : (const int32_t *)nullptr, out);

@@ -46,7 +46,8 @@ __global__ void __launch_bounds__(256)
 compact_kernel(int n0, const uint8_t *__restrict__ flags, const int32_t *__restrict__ blk_cnt,
                const int32_t *__restrict__ idx1, const int32_t *__restrict__ idx2, const float *__restrict__ score,
                int32_t *__restrict__ o0, int32_t *__restrict__ o1, int32_t *__restrict__ o2, float *__restrict__ oscore,
-               int32_t *__restrict__ n_out, int32_t *__restrict__ n_out2)
+               int32_t *__restrict__ n_out, int32_t *__restrict__ n_out2,
+               const float *__restrict__ xyz0, const float *__restrict__ xyz1, float *__restrict__ corr8, int32_t *__restrict__ counters)
 {
     __shared__ int s_wave[4];
     __shared__ int s_part[4];
@@ -69,7 +70,15 @@ compact_kernel(int n0, const uint8_t *__restrict__ flags, const int32_t *__restr
         if (o1) o1[slot] = idx1[i];
         if (o2 && idx2) o2[slot] = idx2[i];
         if (oscore && score) oscore[slot] = score[i];
+        if (corr8) {        // fused pack_corr_kernel: the survivor's point pair as one 32-byte record for the RANSAC kernels
+            const int b = idx1[i];
+            float4 lo = { xyz0[3 * i], xyz0[3 * i + 1], xyz0[3 * i + 2], xyz1[3 * b] };
+            float4 hi = { xyz1[3 * b + 1], xyz1[3 * b + 2], 0.0f, 0.0f };
+            reinterpret_cast<float4 *>(corr8)[2 * slot] = lo;
+            reinterpret_cast<float4 *>(corr8)[2 * slot + 1] = hi;
+        }
     }
+    if (corr8 && blockIdx.x == 0 && tid == 0) counters[LR_CNT_NVALID] = 0;
     if (blockIdx.x == gridDim.x - 1 && tid == 0) {
         const int total = prefix + s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
         if (n_out) *n_out = total;
@@ -78,14 +87,15 @@ compact_kernel(int n0, const uint8_t *__restrict__ flags, const int32_t *__restr
 }
 
 int lr_mutual_run(lr_workspace *ws, int n0, const int32_t *idx1, const int32_t *idx2, const int32_t *rev,
-                  uint8_t *is_bb, int32_t *o0, int32_t *o1, int32_t *o2, int32_t *n_out, hipStream_t st)
+                  uint8_t *is_bb, int32_t *o0, int32_t *o1, int32_t *o2, int32_t *n_out, hipStream_t st,
+                  const float *xyz0, const float *xyz1, float *corr8)
 {
     const int nb = lr_cdiv(n0, 256);
     uint8_t *flags = is_bb ? is_bb : ws->is_bb;
     hipLaunchKernelGGL(mutual_flag_kernel, dim3(nb), dim3(256), 0, st, n0, idx1, rev, flags, ws->blk_cnt);
     // the number of best buddies is wanted even when no list is (GPF's TOTAL_NUM, matching.py:115-116)
     hipLaunchKernelGGL(compact_kernel, dim3(nb), dim3(256), 0, st, n0, flags, ws->blk_cnt, idx1, idx2, (const float *)nullptr,
-                       o0, o1, o2, (float *)nullptr, n_out, ws->counters + LR_CNT_NBB);
+                       o0, o1, o2, (float *)nullptr, n_out, ws->counters + LR_CNT_NBB, xyz0, xyz1, corr8, ws->counters);
     LR_LAUNCH_CHECK();
     return LR_OK;
 }
@@ -312,7 +322,7 @@ gpf_select_kernel(int n0, const int32_t *__restrict__ cell, const int32_t *__res
 int lr_gpf_run(lr_workspace *ws, const float *F0, int n0, const float *F1, int dim,
                const int32_t *idx1, const int32_t *idx2, const uint8_t *is_bb, const float *xyz0,
                int G, double factor, int32_t *o0, int32_t *o1, int32_t *o2, float *oscore,
-               int32_t *n_out, hipStream_t st)
+               int32_t *n_out, hipStream_t st, const float *xyz1, float *corr8)
 {
     LR_REQUIRE(G >= 1 && G <= 64, LR_EINVAL, "lr_gpf: grid width must be in [1,64]");
     int32_t *cell_count = ws->gpf_cells;
@@ -334,7 +344,7 @@ int lr_gpf_run(lr_workspace *ws, const float *F0, int n0, const float *F1, int d
                        ws->cell_sorted, ws->ratio, keep);
     hipLaunchKernelGGL(count_flags_kernel, dim3(nb), dim3(256), 0, st, n0, keep, ws->blk_cnt);
     hipLaunchKernelGGL(compact_kernel, dim3(nb), dim3(256), 0, st, n0, keep, ws->blk_cnt, idx1, idx2, ws->ratio, o0, o1, o2, oscore,
-                       n_out, (int32_t *)nullptr);
+                       n_out, (int32_t *)nullptr, xyz0, xyz1, corr8, ws->counters);
     LR_LAUNCH_CHECK();
     return LR_OK;
 }

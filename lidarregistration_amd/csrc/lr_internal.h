@@ -50,6 +50,7 @@ struct lr_workspace {
     float *tau;                  // [max_n] per-row candidate threshold
     int32_t *cand_cnt, *cand;    // [max_n][strips], [max_n][strips][LR_NN16_CAPS] candidate lists
     float *bmax0, *bmax1;        // per-32-row maxima of the norms (f16 filter error bound)
+    uint32_t *rev_seed;          // [max_n1] best forward distance pointing at each cloud-1 row (bit pattern)
     int nn_path;                 // LR_NN_PATH_*
     float *pb1, *pb2, *pb3;      // partial top-3 values [strips][max_n]
     int32_t *pi1, *pi2;          // partial top-2 indices
@@ -103,7 +104,7 @@ int lr_nn_run(lr_workspace *ws, const float *Fa, const float *nrma, int na, cons
 int lr_nn_prep(lr_workspace *ws, const float *F, int n, float *Fp, float *nrm, hipStream_t st);
 
 // lr_nn16.hip
-int lr_nn16_prep(lr_workspace *ws, const float *F, int n, _Float16 *H, float *nrm, float *block_max, hipStream_t st);
+int lr_nn16_prep(lr_workspace *ws, const float *F0, int n0, const float *F1, int n1, hipStream_t st);
 int lr_nn16_run(lr_workspace *ws, const float *Fq, const _Float16 *Hq, const float *nQ, int na,
                 const float *Fc, const _Float16 *Hc, const float *nC, const float *block_max_c, int nb,
                 int need, int32_t *idx1, int32_t *idx2, float *s1, float *s2, hipStream_t st);
@@ -115,7 +116,8 @@ int lr_nn_fix_rows(lr_workspace *ws, bool permuted, const float *Fa, const float
 
 // lr_filter.hip
 int lr_mutual_run(lr_workspace *ws, int n0, const int32_t *idx1, const int32_t *idx2, const int32_t *rev,
-                  uint8_t *is_bb, int32_t *o0, int32_t *o1, int32_t *o2, int32_t *n_out, hipStream_t st);
+                  uint8_t *is_bb, int32_t *o0, int32_t *o1, int32_t *o2, int32_t *n_out, hipStream_t st,
+                  const float *xyz0 = nullptr, const float *xyz1 = nullptr, float *corr8 = nullptr);
 int lr_identity_corr(lr_workspace *ws, int n0, const int32_t *idx1, const int32_t *idx2,
                      int32_t *o0, int32_t *o1, int32_t *o2, int32_t *n_out, hipStream_t st);
 int lr_pack_corr(lr_workspace *ws, const float *xyz0, const float *xyz1, const int32_t *i0, const int32_t *i1, int m_max,
@@ -123,11 +125,11 @@ int lr_pack_corr(lr_workspace *ws, const float *xyz0, const float *xyz1, const i
 int lr_gpf_run(lr_workspace *ws, const float *F0, int n0, const float *F1, int dim,
                const int32_t *idx1, const int32_t *idx2, const uint8_t *is_bb, const float *xyz0,
                int grid_wid, double factor, int32_t *o0, int32_t *o1, int32_t *o2, float *oscore,
-               int32_t *n_out, hipStream_t st);
+               int32_t *n_out, hipStream_t st, const float *xyz1 = nullptr, float *corr8 = nullptr);
 
 // lr_ransac.hip
 int lr_ransac_run(lr_workspace *ws, const float *corr8, int m_max, const int32_t *m_dev, const lr_ransac_params *p,
                   double *T_out, lr_ransac_result *res, hipStream_t st);
 int lr_refit_run(lr_workspace *ws, const float *xyz0, int n0, const float *xyz1, const int32_t *idx1,
                  const double *T_in, double thr2, double *T_out, int32_t *n_inl, const lr_ransac_result *gate,
-                 hipStream_t st);
+                 hipStream_t st, lr_pair_result *pair_out = nullptr);

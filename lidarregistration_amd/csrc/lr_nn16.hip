@@ -13,7 +13,7 @@
 //   exact   per row, the fp32 fma-chain distance of its few candidates, ordered by (sqrt value, index) --
 //           this is exactly torch.min's "first minimal value" order, so no separate tie-break path is needed;
 //           rows whose candidate list overflowed (duplicate-heavy inputs) or could not be filled (non-finite
-//           f16 conversions) go through the full exact row kernel nn_fix_kernel of lr_nn.hip.
+//           f16 conversions) are re-done in place by an exact scan of all columns.
 //
 // Why the candidate set is a superset of what the exact order needs: let S be the sampled columns and j1, j2 in S the
 // two with the smallest u'.  Their exact distances are <= n0_i + U_i + E_i, hence so is the exact 2nd smallest x2 of
@@ -41,11 +41,21 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // arithmetic contract: thread t continues the chain over its four values from where thread t-1 stopped.
 // H[row] (64 B) = f16 of { k0..7, k16..23 | k8..15, k24..31 }: lane half h of an MFMA operand reads bytes [32h, 32h+32).
 __global__ void __launch_bounds__(256)
-nn16_prep_kernel(const float *__restrict__ F, int n, _Float16 *__restrict__ H, float *__restrict__ nrm,
-                 float *__restrict__ block_max)
+nn16_prep_kernel(const float *__restrict__ Fa, int na, _Float16 *__restrict__ Ha, float *__restrict__ nrma, float *__restrict__ bmaxa,
+                 const float *__restrict__ Fb, int nb, _Float16 *__restrict__ Hb, float *__restrict__ nrmb, float *__restrict__ bmaxb,
+                 uint32_t *__restrict__ seed_b)
 {
     __shared__ float s_m[4];
-    const int gid = blockIdx.x * 256 + threadIdx.x;
+    // blocks [0, ceil(na/32)) prepare cloud a, the rest cloud b (one launch for the pair)
+    const int nblk_a = (na + 31) >> 5;
+    const bool second = (int)blockIdx.x >= nblk_a;
+    const float *__restrict__ F = second ? Fb : Fa;
+    _Float16 *__restrict__ H = second ? Hb : Ha;
+    float *__restrict__ nrm = second ? nrmb : nrma;
+    float *__restrict__ block_max = second ? bmaxb : bmaxa;
+    const int n = second ? nb : na;
+    const int blk = second ? blockIdx.x - nblk_a : blockIdx.x;
+    const int gid = blk * 256 + threadIdx.x;
     const int row = gid >> 3, t = gid & 7, lane = threadIdx.x & 63;
     const bool live = row < n;
     f32x4 v = { 0.0f, 0.0f, 0.0f, 0.0f };
@@ -63,7 +73,10 @@ nn16_prep_kernel(const float *__restrict__ F, int n, _Float16 *__restrict__ H, f
     }
     const float norm = __shfl(run, (lane & ~7) | 7);
     if (live) {
-        if (t == 0) nrm[row] = norm;
+        if (t == 0) {
+            nrm[row] = norm;
+            if (second && seed_b) seed_b[row] = 0x7f7f7f7fu;      // "no query points at this row yet" (lr_nn16_reverse)
+        }
         // k = 4t..4t+3 sits in 8-element chunk c = t/2; chunks are stored in the order 0, 2, 1, 3
         const int c = t >> 1;
         const int pos = (c == 0 ? 0 : c == 1 ? 2 : c == 2 ? 1 : 3) * 8 + (t & 1) * 4;
@@ -78,7 +91,7 @@ nn16_prep_kernel(const float *__restrict__ F, int n, _Float16 *__restrict__ H, f
     for (int k = 32; k >= 1; k >>= 1) m = fmaxf(m, __shfl_xor(m, k));
     if (lane == 0) s_m[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) block_max[blockIdx.x] = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+    if (threadIdx.x == 0) block_max[blk] = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
 }
 
 // ------------------------------------------------------------------ pass A / pass B
@@ -314,7 +327,7 @@ nn16_thresh_kernel(int na, int nstrips, int part_stride, const float *__restrict
 {
     __shared__ float s_m[4];
     const int row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row == 0) counters[LR_CNT_FIX] = 0;
+    (void)counters;
     // max_j n1_j of the column cloud from the per-block maxima of its prep kernel
     float mx = 0.0f;
     for (int b = threadIdx.x; b < nblk_c; b += 256) mx = fmaxf(mx, block_max_c[b]);
@@ -341,16 +354,16 @@ nn16_thresh_kernel(int na, int nstrips, int part_stride, const float *__restrict
 // ------------------------------------------------------------------ exact verification of the candidates
 // Four lanes per row: lane q takes the candidate slots of strips q, q+4, ...; the four partial (first, second) pairs are
 // merged under the (sqrt value, index) order with two shuffles.  Rows with an overflowing or too-short candidate list
-// are queued for the full exact row kernel.
+// are re-done by a full exact scan of all columns, in place.
 __device__ __forceinline__ bool sj_lt(float a, int ia, float b, int ib) { return a < b || (a == b && ia < ib); }
 
 __global__ void __launch_bounds__(256)
 nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, int na,
                   const float *__restrict__ Fc, const float *__restrict__ nC, int nb,
                   const int32_t *__restrict__ cand_cnt, const int32_t *__restrict__ cand, int nstrips, int need,
-                  const float *__restrict__ skip_tau,
+                  const uint32_t *__restrict__ skip_seed,
                   int32_t *__restrict__ idx1, int32_t *__restrict__ idx2, float *__restrict__ s1o, float *__restrict__ s2o,
-                  int32_t *__restrict__ fix_list, int32_t *__restrict__ counters)
+                  int32_t *__restrict__ counters)
 {
     const int gid = blockIdx.x * 256 + threadIdx.x;
     const int row = gid >> 2, q = gid & 3;
@@ -393,6 +406,33 @@ nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, in
     for (int m = 1; m <= 2; m <<= 1) {
         total += __shfl_xor(total, m);
         over |= __shfl_xor(over, m);
+    }
+    const bool skip = skip_seed && !(__uint_as_float(skip_seed[rowc]) < 3.0e38f);   // reverse NN nobody asked for
+    if (!skip && (over || total < min(need, nb))) {
+        // candidate list overflowed (duplicate-heavy input) or could not be filled (non-finite f16 values): the four
+        // lanes of the row scan every column exactly -- slow, rare, and by construction the reference answer
+        b1 = LR_INF; b2 = LR_INF; i1 = LR_IMAX; i2 = LR_IMAX;
+        for (int j = q; j < nb; j += 4) {
+            const f32x4 *pb = reinterpret_cast<const f32x4 *>(Fc + (size_t)j * 32);
+            float acc = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const f32x4 t = pb[k];
+                acc = __builtin_fmaf(a[4 * k], t.x, acc);
+                acc = __builtin_fmaf(a[4 * k + 1], t.y, acc);
+                acc = __builtin_fmaf(a[4 * k + 2], t.z, acc);
+                acc = __builtin_fmaf(a[4 * k + 3], t.w, acc);
+            }
+            const float tt = nq + nC[j];
+            const float d2 = __builtin_fmaf(-2.0f, acc, tt);
+            const float sv = __builtin_sqrtf(fmaxf(d2, 1e-30f));
+            if (sj_lt(sv, j, b1, i1)) { b2 = b1; i2 = i1; b1 = sv; i1 = j; }
+            else if (sj_lt(sv, j, b2, i2)) { b2 = sv; i2 = j; }
+        }
+        if (q == 0 && live) atomicAdd(&counters[LR_CNT_FIX_TOTAL], 1);
+    }
+#pragma unroll
+    for (int m = 1; m <= 2; m <<= 1) {
         const float c1 = __shfl_xor(b1, m), c2 = __shfl_xor(b2, m);
         const int j1 = __shfl_xor(i1, m), j2 = __shfl_xor(i2, m);
         const bool cf = sj_lt(c1, j1, b1, i1);
@@ -403,15 +443,7 @@ nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, in
         b2 = sy ? y1 : x2; i2 = sy ? yi1 : xi2;
     }
     if (!live || q != 0) return;
-    if (skip_tau && skip_tau[row] == -LR_INF) {      // nobody asked for this row (reverse NN of a column no query points at)
-        idx1[row] = -1;
-        return;
-    }
-    if (over || total < min(need, nb)) {
-        const int slot = atomicAdd(&counters[LR_CNT_FIX], 1);
-        fix_list[slot] = row;
-        return;
-    }
+    if (skip) { idx1[row] = -1; return; }
     idx1[row] = i1;
     if (idx2) idx2[row] = i2;
     if (s1o) s1o[row] = b1;
@@ -419,10 +451,10 @@ nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, in
 }
 
 // ------------------------------------------------------------------ host side
-int lr_nn16_prep(lr_workspace *ws, const float *F, int n, _Float16 *H, float *nrm, float *block_max, hipStream_t st)
+int lr_nn16_prep(lr_workspace *ws, const float *F0, int n0, const float *F1, int n1, hipStream_t st)
 {
-    (void)ws;
-    hipLaunchKernelGGL(nn16_prep_kernel, dim3(lr_cdiv(n, 32)), dim3(256), 0, st, F, n, H, nrm, block_max);
+    hipLaunchKernelGGL(nn16_prep_kernel, dim3(lr_cdiv(n0, 32) + lr_cdiv(n1, 32)), dim3(256), 0, st, F0, n0, ws->H0, ws->nrm0, ws->bmax0,
+                       F1, n1, ws->H1, ws->nrm1, ws->bmax1, ws->rev_seed);
     LR_LAUNCH_CHECK();
     return LR_OK;
 }
@@ -454,9 +486,9 @@ int lr_nn16_run(lr_workspace *ws, const float *Fq, const _Float16 *Hq, const flo
                        (float *)nullptr, ws->tau, ws->cand_cnt, ws->cand);
     if (ws->timing && !ws->ev_pending) { LR_HIP(hipEventRecord(ws->ev[1], st)); ws->ev_pending = 1; }
     hipLaunchKernelGGL(nn16_exact_kernel, dim3(lr_cdiv(na, 64)), dim3(256), 0, st, Fq, nQ, na, Fc, nC, nb, ws->cand_cnt, ws->cand,
-                       strips, need, (const float *)nullptr, idx1, idx2, s1, s2, ws->fix_list, ws->counters);
+                       strips, need, (const uint32_t *)nullptr, idx1, idx2, s1, s2, ws->counters);
     LR_LAUNCH_CHECK();
-    return lr_nn_fix_rows(ws, false, Fq, nQ, Fc, nC, nb, idx1, idx2, s1, s2, st);
+    return LR_OK;
 }
 
 // ------------------------------------------------------------------ reverse NN seeded by the forward result
@@ -494,7 +526,7 @@ nn16_thresh_seed_kernel(int na, const uint32_t *__restrict__ seed_bits, const fl
 {
     __shared__ float s_m[4];
     const int row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row == 0) counters[LR_CNT_FIX] = 0;
+    (void)counters;
     float mx = 0.0f;
     for (int b = threadIdx.x; b < nblk_c; b += 256) mx = fmaxf(mx, block_max_c[b]);
 #pragma unroll
@@ -525,8 +557,7 @@ int lr_nn16_reverse(lr_workspace *ws, const float *F0, const _Float16 *H0, const
     if (strips > LR_NN_MAX_STRIPS) strips = LR_NN_MAX_STRIPS;
     if (strips < 1) strips = 1;
     const int tps = lr_cdiv(ntiles, strips);
-    uint32_t *seed = reinterpret_cast<uint32_t *>(ws->pb1);
-    LR_HIP(hipMemsetAsync(seed, 0x7f, sizeof(uint32_t) * (size_t)na, st));
+    uint32_t *seed = ws->rev_seed;          // filled with 0x7f7f7f7f by the prep kernel of this pair
     hipLaunchKernelGGL(nn16_rev_seed_kernel, dim3(lr_cdiv(n0, 256)), dim3(256), 0, st, F0, nrm0, n0, F1, nrm1, fwd_idx1, seed);
     hipLaunchKernelGGL(nn16_thresh_seed_kernel, dim3(lr_cdiv(na, 256)), dim3(256), 0, st, na, seed, nrm1, bmax0, lr_cdiv(nb, 32),
                        ws->tau, ws->counters);
@@ -534,7 +565,7 @@ int lr_nn16_reverse(lr_workspace *ws, const float *F0, const _Float16 *H0, const
     hipLaunchKernelGGL(nn16_pass_kernel<1>, grid, dim3(256), 0, st, H1, na, H0, nrm0, nb, tps, 1, ws->max_n, (float *)nullptr,
                        (float *)nullptr, ws->tau, ws->cand_cnt, ws->cand);
     hipLaunchKernelGGL(nn16_exact_kernel, dim3(lr_cdiv(na, 64)), dim3(256), 0, st, F1, nrm1, na, F0, nrm0, nb, ws->cand_cnt, ws->cand,
-                       strips, 1, ws->tau, rev, (int32_t *)nullptr, (float *)nullptr, (float *)nullptr, ws->fix_list, ws->counters);
+                       strips, 1, seed, rev, (int32_t *)nullptr, (float *)nullptr, (float *)nullptr, ws->counters);
     LR_LAUNCH_CHECK();
-    return lr_nn_fix_rows(ws, false, F1, nrm1, F0, nrm0, nb, rev, nullptr, nullptr, nullptr, st);
+    return LR_OK;
 }

@@ -386,7 +386,8 @@ refit_moments_kernel(const float *__restrict__ xyz0, int n0, const float *__rest
 
 __global__ void __launch_bounds__(64)
 refit_solve_kernel(const double *__restrict__ partial, int nblocks, const double *__restrict__ T_in,
-                   const lr_ransac_result *__restrict__ gate, double *__restrict__ T_out, int32_t *__restrict__ n_inl)
+                   const lr_ransac_result *__restrict__ gate, double *__restrict__ T_out, int32_t *__restrict__ n_inl,
+                   lr_pair_result *__restrict__ pair_out, const int32_t *__restrict__ counters)
 {
     __shared__ double mom[16];
     __shared__ double stage[64 * 16];
@@ -406,27 +407,39 @@ refit_solve_kernel(const double *__restrict__ partial, int nblocks, const double
     if (threadIdx.x != 0) return;
     const bool have_model = gate ? gate->best_h >= 0 : true;
     const double n = mom[0];
+    double T[16];
+    int n_used;
     if (!have_model || n < 3.0) {
-        for (int k = 0; k < 16; ++k) T_out[k] = T_in[k];
-        if (n_inl) *n_inl = have_model ? (int)n : 0;
-        return;
+        for (int k = 0; k < 16; ++k) T[k] = T_in[k];
+        n_used = have_model ? (int)n : 0;
+    } else {
+        double cp[3], cq[3], H[3][3];
+        for (int a = 0; a < 3; ++a) { cp[a] = mom[1 + a] / n; cq[a] = mom[4 + a] / n; }
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) H[a][b] = mom[7 + 3 * a + b] - (n * cp[a]) * cq[b];
+        rt_from_cov(H, cp, cq, T);
+        n_used = (int)n;
     }
-    double cp[3], cq[3], H[3][3], T[16];
-    for (int a = 0; a < 3; ++a) { cp[a] = mom[1 + a] / n; cq[a] = mom[4 + a] / n; }
-    for (int a = 0; a < 3; ++a)
-        for (int b = 0; b < 3; ++b) H[a][b] = mom[7 + 3 * a + b] - (n * cp[a]) * cq[b];
-    rt_from_cov(H, cp, cq, T);
     for (int k = 0; k < 16; ++k) T_out[k] = T[k];
-    if (n_inl) *n_inl = (int)n;
+    if (n_inl) *n_inl = n_used;
+    if (pair_out) {          // result block of lr_register_pair (fused: saves a launch)
+        for (int k = 0; k < 16; ++k) { pair_out->T[k] = T[k]; pair_out->T_ransac[k] = T_in[k]; }
+        pair_out->ransac = *gate;
+        pair_out->n_corr = counters[LR_CNT_NCORR];
+        pair_out->n_refit = n_used;
+        pair_out->n_nn_fixed = counters[LR_CNT_FIX_TOTAL];
+        pair_out->status = gate->best_h < 0 ? 1 : 0;
+        for (int q = 0; q < 8; ++q) pair_out->reserved[q] = 0;
+    }
 }
 
 int lr_refit_run(lr_workspace *ws, const float *xyz0, int n0, const float *xyz1, const int32_t *idx1,
                  const double *T_in, double thr2, double *T_out, int32_t *n_inl, const lr_ransac_result *gate,
-                 hipStream_t st)
+                 hipStream_t st, lr_pair_result *pair_out)
 {
     const int nb = lr_cdiv(n0, 256);
     hipLaunchKernelGGL(refit_moments_kernel, dim3(nb), dim3(256), 0, st, xyz0, n0, xyz1, idx1, T_in, thr2, ws->refit_part);
-    hipLaunchKernelGGL(refit_solve_kernel, dim3(1), dim3(64), 0, st, ws->refit_part, nb, T_in, gate, T_out, n_inl);
+    hipLaunchKernelGGL(refit_solve_kernel, dim3(1), dim3(64), 0, st, ws->refit_part, nb, T_in, gate, T_out, n_inl, pair_out, ws->counters);
     LR_LAUNCH_CHECK();
     return LR_OK;
 }
