@@ -78,7 +78,7 @@ extern "C" int lr_workspace_create(lr_workspace **out, int max_n0, int max_n1, i
     LR_REQUIRE(out, LR_EINVAL, "lr_workspace_create: null output");
     LR_REQUIRE(max_n0 > 0 && max_n1 > 0 && max_iters >= 0, LR_EINVAL, "lr_workspace_create: sizes must be positive");
     LR_REQUIRE(dim == LR_FEAT_DIM, LR_EINVAL, "lr_workspace_create: only 32-d descriptors (FCGF) are supported");
-    LR_REQUIRE(max_n0 < (1 << 24) && max_n1 < (1 << 24), LR_ESIZE, "lr_workspace_create: clouds are limited to 2^24 points");
+    LR_REQUIRE(max_n0 < (1 << 22) && max_n1 < (1 << 22), LR_ESIZE, "lr_workspace_create: clouds are limited to 2^22 points");
     lr_workspace *ws = new (std::nothrow) lr_workspace();
     LR_REQUIRE(ws, LR_ENOMEM, "lr_workspace_create: host allocation failed");
     memset(ws, 0, sizeof(*ws));

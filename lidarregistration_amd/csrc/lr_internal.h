@@ -36,7 +36,7 @@ static inline int lr_cdiv(int a, int b) { return (a + b - 1) / b; }
 // f16 filter path: pass A samples every LR_NN16_STRIDE-th column tile; candidate list capacity per row
 #define LR_NN16_STRIDE 4
 #define LR_NN16_CAPS 16      // candidate slots per (row, strip)
-#define LR_NN16_LIST 2048    // per-block LDS candidate list (256 rows x one strip); columns must be < 2^24
+#define LR_NN16_LIST 2048    // per-block LDS candidate list (256 rows x one strip); columns must be < 2^22
 enum { LR_NN_PATH_F16_FILTER = 0, LR_NN_PATH_FP32_MFMA = 1 };
 
 struct lr_workspace {

@@ -109,6 +109,10 @@ nn16_prep_kernel(const float *__restrict__ Fa, int na, _Float16 *__restrict__ Ha
 //                    within a strip), so the hot loop issues no global atomics.
 #define LR_CH 4
 #define LR_LDS_ROW 80
+#ifndef LR_RB
+#define LR_RB 2                  // 32-row MFMA blocks per wave (rows per wave = 32 LR_RB, rows per block = 128 LR_RB)
+#endif
+#define LR_BLOCK_ROWS (128 * LR_RB)
 template <int MODE>
 __global__ void __launch_bounds__(256)
 nn16_pass_kernel(const _Float16 *__restrict__ Hq, int na, const _Float16 *__restrict__ Hc, const float *__restrict__ nC, int nb,
@@ -117,43 +121,45 @@ nn16_pass_kernel(const _Float16 *__restrict__ Hq, int na, const _Float16 *__rest
                  const float *__restrict__ tau, int32_t *__restrict__ cand_cnt, int32_t *__restrict__ cand)
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][LR_CH * 32 * LR_LDS_ROW + LR_CH * 32 * 4];
-    __shared__ int s_cnt[256];
-    __shared__ int s_list[LR_NN16_LIST];      // block-level candidate list: (local row << 24) | chunk-relative info, see below
+    __shared__ int s_cnt[LR_BLOCK_ROWS];
+    __shared__ int s_list[LR_NN16_LIST];      // block-level candidate list: (local row << 22) | column
     __shared__ int s_n;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r = lane & 31, h = lane >> 5;
-    const int row0 = (blockIdx.x * 4 + wave) * 64;
+    const int row0 = blockIdx.x * LR_BLOCK_ROWS + wave * 32 * LR_RB;
     const int strip = blockIdx.y, nstrips = gridDim.y;
     const int ntiles = (nb + 31) >> 5;
     const int t_begin = strip * tiles_per_strip;
     const int t_end = min(ntiles, t_begin + tiles_per_strip);
     const int nsamp = t_end > t_begin ? (t_end - t_begin + tile_stride - 1) / tile_stride : 0;   // tiles this block visits
     const int nchunks = (nsamp + LR_CH - 1) / LR_CH;
-    if (MODE == 1) { s_cnt[tid] = 0; if (tid == 0) s_n = 0; }
+    if (MODE == 1) {
+        for (int t = tid; t < LR_BLOCK_ROWS; t += 256) s_cnt[t] = 0;
+        if (tid == 0) s_n = 0;
+    }
 
-    f16x8 a[2][2];
+    f16x8 a[LR_RB][2];
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
+    for (int rb = 0; rb < LR_RB; ++rb) {
         const int row = min(row0 + 32 * rb + r, na - 1);
         const f16x8 *p = reinterpret_cast<const f16x8 *>(Hq + (size_t)row * 32 + 16 * h);
         a[rb][0] = p[0]; a[rb][1] = p[1];
     }
-    f32x16 st1[2], st2[2];      // MODE 0: running two largest g; MODE 1: st1 = y = tau/2 of the element's row
+    f32x16 st1[LR_RB];      // MODE 0: per-lane running maximum of g; MODE 1: y = tau/2 of the element's row
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
+    for (int rb = 0; rb < LR_RB; ++rb)
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
-            if (MODE == 0) { st1[rb][g] = -LR_INF; st2[rb][g] = -LR_INF; }
+            if (MODE == 0) st1[rb][g] = -LR_INF;
             else {
-                // unconditional (clamped) loads: a conditional load here turns into 32 serialized round trips
+                // unconditional (clamped) loads: a conditional load here turns into serialized round trips
                 const int row = row0 + 32 * rb + (g & 3) + 8 * (g >> 2) + 4 * h;
                 const float tv = tau[min(row, na - 1)];
                 st1[rb][g] = row < na ? 0.5f * tv : -LR_INF;
-                st2[rb][g] = 0.0f;
             }
         }
 
-    // staging: thread t moves two 16-byte pieces per chunk (piece p -> column p/4 of the chunk, 16-byte part p%4)
+    // staging: thread t moves LR_CH/2 16-byte pieces per chunk (piece p -> column p/4 of the chunk, 16-byte part p%4)
     f32x4 stage[LR_CH / 2];
     float stage_n = 0.0f;        // raw norm of the staged column: NOT touched until store_chunk, so that the compiler's
     bool stage_ok = false;       // s_waitcnt for it lands after the tile loop instead of right behind the prefetch
@@ -185,30 +191,20 @@ nn16_pass_kernel(const _Float16 *__restrict__ Hq, int na, const _Float16 *__rest
         // x_j = n1[j]/2 ; +inf masks columns past the end of the cloud or of the strip
         if (tid < LR_CH * 32) *reinterpret_cast<float *>(&lds[buf][LR_CH * 32 * LR_LDS_ROW + tid * 4]) = stage_ok ? 0.5f * stage_n : LR_INF;
     };
-
-    // one tile of work: fragment read, 2 x 2 MFMAs (accumulators start at y in MODE 1)
     auto read_b = [&](int buf, int k, f16x8 &b0, f16x8 &b1, float &xj) {
         const unsigned char *bp = &lds[buf][(32 * k + r) * LR_LDS_ROW + 32 * h];
         b0 = *reinterpret_cast<const f16x8 *>(bp);
         b1 = *reinterpret_cast<const f16x8 *>(bp + 16);
         xj = *reinterpret_cast<const float *>(&lds[buf][LR_CH * 32 * LR_LDS_ROW + (32 * k + r) * 4]);
     };
-    auto mma = [&](const f16x8 &b0, const f16x8 &b1, f32x16 (&acc)[2]) {
+    // two 32-row blocks (rb0, rb0+1) against one column fragment; accumulators start at y in MODE 1
+    auto mma2 = [&](int rb0, const f16x8 &b0, const f16x8 &b1, f32x16 (&acc)[2]) {
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-            if (MODE == 0) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rb][0], b0, f32x16{ 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, 0, 0, 0);
-            else acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rb][0], b0, st1[rb], 0, 0, 0);
-            acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rb][1], b1, acc[rb], 0, 0, 0);
+        for (int q = 0; q < 2; ++q) {
+            if (MODE == 0) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rb0 + q][0], b0, f32x16{ 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, 0, 0, 0);
+            else acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rb0 + q][0], b0, st1[rb0 + q], 0, 0, 0);
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rb0 + q][1], b1, acc[q], 0, 0, 0);
         }
-    };
-    // pass A: fold the tile into the per-lane running maximum of g = dot16 - x_j (2 VALU ops per element).  The two largest
-    // of the 32 lane maxima of a row belong to two different columns, so the smaller of them is a valid (and almost always
-    // exact) lower bound of the row's 2nd largest g.
-    auto fold = [&](const f32x16 (&acc)[2], float xj) {
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-            for (int g = 0; g < 16; ++g) st1[rb][g] = fmaxf(st1[rb][g], acc[rb][g] - xj);
     };
 
     if (nchunks > 0) { load_chunk(0); store_chunk(0); }
@@ -217,56 +213,45 @@ nn16_pass_kernel(const _Float16 *__restrict__ Hq, int na, const _Float16 *__rest
         const int buf = c & 1;
         if (c + 1 < nchunks) load_chunk(c + 1);
         if (row0 < na) {
-            if (MODE == 0) {
-                // software pipeline over the LR_CH tiles of the chunk: the MFMAs of tile k+1 are issued before the VALU
-                // fold of tile k, and the fragment of tile k+1 is read from LDS before the MFMAs of tile k (no branch inside)
-                f16x8 bA0, bA1, bB0, bB1;
-                float xA, xB;
-                f32x16 accA[2], accB[2];
-                read_b(buf, 0, bA0, bA1, xA);
-                read_b(buf, 1, bB0, bB1, xB);
-                mma(bA0, bA1, accA);
-                mma(bB0, bB1, accB);
-#pragma unroll
-                for (int k = 0; k < LR_CH; k += 2) {
-                    const float x0 = xA, x1 = xB;
-                    if (k + 2 < LR_CH) read_b(buf, k + 2, bA0, bA1, xA);
-                    fold(accA, x0);
-                    if (k + 2 < LR_CH) mma(bA0, bA1, accA);
-                    if (k + 3 < LR_CH) read_b(buf, k + 3, bB0, bB1, xB);
-                    fold(accB, x1);
-                    if (k + 3 < LR_CH) mma(bB0, bB1, accB);
-                }
-            } else {
-                // measured: looking at the accumulators of a tile in four groups of 8 registers (one scalar test each) and
-                // parking the candidates right away beats a branch-free chunk loop that re-multiplies the flagged tiles
 #pragma unroll 2
-                for (int k = 0; k < LR_CH; ++k) {
-                    f16x8 b0, b1; float xj;
+            for (int k = 0; k < LR_CH; ++k) {
+                f16x8 b0, b1; float xj;
+                read_b(buf, k, b0, b1, xj);
+#pragma unroll
+                for (int rb0 = 0; rb0 < LR_RB; rb0 += 2) {
                     f32x16 acc[2];
-                    read_b(buf, k, b0, b1, xj);
-                    mma(b0, b1, acc);
+                    mma2(rb0, b0, b1, acc);
+                    if (MODE == 0) {
+                        // pass A: per-lane running maximum of g = dot16 - x_j (2 VALU ops per element).  The two largest of
+                        // the 32 lane maxima of a row belong to two different columns, so the smaller of them is a valid
+                        // (and almost always exact) lower bound of the row's 2nd largest g.
 #pragma unroll
-                    for (int rb = 0; rb < 2; ++rb)
+                        for (int q = 0; q < 2; ++q)
 #pragma unroll
-                        for (int g0 = 0; g0 < 16; g0 += 8) {
-                            bool any = false;
+                            for (int g = 0; g < 16; ++g) st1[rb0 + q][g] = fmaxf(st1[rb0 + q][g], acc[q][g] - xj);
+                    } else {
+                        // pass B: look at the accumulators in groups of 8 registers (one scalar test each); candidates are
+                        // parked right away in the block's LDS list (one LDS atomic + one LDS store each) and sorted into
+                        // the per-row slots after the main loop, which keeps this path light on registers
 #pragma unroll
-                            for (int g = g0; g < g0 + 8; ++g) any |= (acc[rb][g] >= xj);
-                            if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
-                                // some lane holds a candidate among these 8 x 64 elements: park (row, column) in the block's
-                                // LDS list (one LDS atomic + one LDS store each); it is sorted into the per-row slots after
-                                // the main loop, which keeps this path light on registers
-                                const int col = chunk_col(c, 32 * k + r);
-                                const int lbase = (wave * 64 + 32 * rb + 4 * h) << 24;
+                        for (int q = 0; q < 2; ++q)
 #pragma unroll
-                                for (int g = g0; g < g0 + 8; ++g)
-                                    if (acc[rb][g] >= xj) {
-                                        const int slot = atomicAdd(&s_n, 1);
-                                        if (slot < LR_NN16_LIST) s_list[slot] = (lbase + (((g & 3) + 8 * (g >> 2)) << 24)) | col;
-                                    }
+                            for (int g0 = 0; g0 < 16; g0 += 8) {
+                                bool any = false;
+#pragma unroll
+                                for (int g = g0; g < g0 + 8; ++g) any |= (acc[q][g] >= xj);
+                                if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
+                                    const int col = chunk_col(c, 32 * k + r);
+                                    const int lbase = (wave * 32 * LR_RB + 32 * (rb0 + q) + 4 * h) << 22;
+#pragma unroll
+                                    for (int g = g0; g < g0 + 8; ++g)
+                                        if (acc[q][g] >= xj) {
+                                            const int slot = atomicAdd(&s_n, 1);
+                                            if (slot < LR_NN16_LIST) s_list[slot] = (lbase + (((g & 3) + 8 * (g >> 2)) << 22)) | col;
+                                        }
+                                }
                             }
-                        }
+                    }
                 }
             }
         }
@@ -276,23 +261,26 @@ nn16_pass_kernel(const _Float16 *__restrict__ Hq, int na, const _Float16 *__rest
 
     if (MODE == 1) {
         // distribute the parked candidates to the (row, strip) slot lists; a block that overflowed its LDS list marks
-        // all its rows as overflowed, which sends them through the exact row kernel
+        // all its rows as overflowed, which sends them through the exact full-row scan
         const int n_list = s_n;
         const bool over = n_list > LR_NN16_LIST;
         for (int e = tid; e < min(n_list, LR_NN16_LIST); e += 256) {
             const int v = s_list[e];
-            const int lrow = (v >> 24) & 0xff, col = v & 0xffffff;
+            const int lrow = (v >> 22) & 0x3ff, col = v & 0x3fffff;
             const int slot = atomicAdd(&s_cnt[lrow], 1);
-            if (slot < LR_NN16_CAPS) cand[((size_t)(blockIdx.x * 256 + lrow) * nstrips + strip) * LR_NN16_CAPS + slot] = col;
+            if (slot < LR_NN16_CAPS) cand[((size_t)(blockIdx.x * LR_BLOCK_ROWS + lrow) * nstrips + strip) * LR_NN16_CAPS + slot] = col;
         }
         __syncthreads();
-        const int row = blockIdx.x * 256 + tid;
-        if (row < na) cand_cnt[(size_t)row * nstrips + strip] = over ? LR_NN16_CAPS + 1 : s_cnt[tid];
+        for (int t = tid; t < LR_BLOCK_ROWS; t += 256) {
+            const int row = blockIdx.x * LR_BLOCK_ROWS + t;
+            if (row < na) cand_cnt[(size_t)row * nstrips + strip] = over ? LR_NN16_CAPS + 1 : s_cnt[t];
+        }
     }
     if (MODE == 0 && row0 < na) {
         // two largest of the 32 lane maxima of each row (lanes of one half hold the same rows, different columns)
+        const size_t base = (size_t)strip * part_stride;
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
+        for (int rb = 0; rb < LR_RB; ++rb)
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
                 float v1 = st1[rb][g], v2 = -LR_INF;
@@ -303,18 +291,9 @@ nn16_pass_kernel(const _Float16 *__restrict__ Hq, int na, const _Float16 *__rest
                     v2 = fmaxf(lo, fmaxf(v2, c2));
                     v1 = hi;
                 }
-                st1[rb][g] = v1; st2[rb][g] = v2;
+                const int row = row0 + 32 * rb + (g & 3) + 8 * (g >> 2) + 4 * h;
+                if (r == 0 && row < na) { pg1[base + row] = v1; pg2[base + row] = v2; }
             }
-        if (r == 0) {
-            const size_t base = (size_t)strip * part_stride;
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-                for (int g = 0; g < 16; ++g) {
-                    const int row = row0 + 32 * rb + (g & 3) + 8 * (g >> 2) + 4 * h;
-                    if (row < na) { pg1[base + row] = st1[rb][g]; pg2[base + row] = st2[rb][g]; }
-                }
-        }
     }
 }
 
@@ -464,7 +443,7 @@ int lr_nn16_run(lr_workspace *ws, const float *Fq, const _Float16 *Hq, const flo
                 int need, int32_t *idx1, int32_t *idx2, float *s1, float *s2, hipStream_t st)
 {
     const int ntiles = lr_cdiv(nb, 32);
-    const int row_blocks = lr_cdiv(na, 256);
+    const int row_blocks = lr_cdiv(na, LR_BLOCK_ROWS);
     // pass A samples every `stride`-th tile (any subset gives a valid, if looser, threshold)
     int stride = ntiles / 16;
     if (stride > LR_NN16_STRIDE) stride = LR_NN16_STRIDE;
@@ -550,7 +529,7 @@ int lr_nn16_reverse(lr_workspace *ws, const float *F0, const _Float16 *H0, const
     // rows = cloud 1 (the columns of the forward direction), columns = cloud 0
     const int na = n1, nb = n0;
     const int ntiles = lr_cdiv(nb, 32);
-    const int row_blocks = lr_cdiv(na, 256);
+    const int row_blocks = lr_cdiv(na, LR_BLOCK_ROWS);
     int strips = lr_cdiv(1024, row_blocks);
     int smax = ntiles / 8;
     if (strips > smax) strips = smax;

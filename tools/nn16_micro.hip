@@ -24,16 +24,17 @@ int main(int argc, char **argv)
     hipMalloc(&pu1, (size_t)n*4*8); hipMalloc(&pu2, (size_t)n*4*8); hipMalloc(&tau, n*4); hipMalloc(&cnt, n*4*8); hipMalloc(&cand, (size_t)n*4*8*16);
     hipMemcpy(F, h.data(), (size_t)n*128, hipMemcpyHostToDevice);
     hipMemset(mx, 0, 8);
-    hipLaunchKernelGGL(nn16_prep_kernel, dim3((n+255)/256), dim3(256), 0, 0, F, n, Fp, H, nrm, mx);
+    float *bmax; hipMalloc(&bmax, (n/32+2)*4);
+    hipLaunchKernelGGL(nn16_prep_kernel, dim3((n+31)/32), dim3(256), 0, 0, F, n, H, nrm, bmax, F, 0, H, nrm, bmax, (uint32_t*)nullptr);
     int ntiles = (n + 31) / 32;
-    int row_blocks = (n + 255) / 256;
+    int row_blocks = (n + LR_BLOCK_ROWS - 1) / LR_BLOCK_ROWS;
     for (int stride : {1, 2, 4}) {
         int tps = ((ntiles + strips - 1) / strips + stride - 1) / stride * stride;
         dim3 grid(row_blocks, strips);
         float ms = timeit([&] { hipLaunchKernelGGL(nn16_pass_kernel<0>, grid, dim3(256), 0, 0, H, n, H, nrm, n, tps, stride, n, pu1, pu2, (const float*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr); });
         printf("passA stride %d strips %d: %.3f ms\n", stride, strips, ms);
         // thresholds from this pass A, then pass B
-        hipLaunchKernelGGL(nn16_thresh_kernel, dim3((n+255)/256), dim3(256), 0, 0, n, strips, n, pu1, pu2, nrm, (const float*)mxf, 1, 2, tau, cnt);
+        hipLaunchKernelGGL(nn16_thresh_kernel, dim3((n+255)/256), dim3(256), 0, 0, n, strips, n, pu1, pu2, nrm, (const float*)bmax, (n+31)/32, 2, tau, cnt);
         int tpsb = (ntiles + strips - 1) / strips;
         float msb = timeit([&] { hipLaunchKernelGGL(nn16_pass_kernel<1>, grid, dim3(256), 0, 0, H, n, H, nrm, n, tpsb, 1, n, (float*)nullptr, (float*)nullptr, tau, cnt, cand); });
         std::vector<int32_t> hc((size_t)n*strips); hipMemcpy(hc.data(), cnt, (size_t)n*strips*4, hipMemcpyDeviceToHost);
