@@ -40,7 +40,7 @@ void carve(lr_workspace *ws, Carver &c)
     ws->nrm0 = c.take<float>(n0); ws->nrm1 = c.take<float>(n1);
     ws->H0 = c.take<_Float16>(n0 * 32); ws->H1 = c.take<_Float16>(n1 * 32);
     ws->tau = c.take<float>(n);
-    ws->cand_cnt = c.take<int32_t>(n * LR_NN_MAX_STRIPS); ws->cand = c.take<int32_t>(n * LR_NN_MAX_STRIPS * LR_NN16_CAPS);
+    ws->cand_cnt = c.take<int32_t>(n); ws->cand = c.take<int32_t>(n * LR_NN16_CAP);
     ws->pb1 = c.take<float>(n * LR_NN_MAX_STRIPS); ws->pb2 = c.take<float>(n * LR_NN_MAX_STRIPS);
     ws->pb3 = c.take<float>(n * LR_NN_MAX_STRIPS);
     ws->pi1 = c.take<int32_t>(n * LR_NN_MAX_STRIPS); ws->pi2 = c.take<int32_t>(n * LR_NN_MAX_STRIPS);
@@ -87,6 +87,9 @@ extern "C" int lr_workspace_create(lr_workspace **out, int max_n0, int max_n1, i
     {
         const char *e = getenv("LIDARREG_NN_PATH");
         ws->nn_path = (e && strcmp(e, "fp32") == 0) ? LR_NN_PATH_FP32_MFMA : LR_NN_PATH_F16_FILTER;
+        const char *b = getenv("LIDARREG_NN_BLOCKS");      // tuning knob: blocks per filter pass (default 512 = 2 per CU; measured best with many pairs in flight)
+        ws->nn_blocks_target = b ? atoi(b) : 512;
+        if (ws->nn_blocks_target < 1) ws->nn_blocks_target = 1;
     }
     Carver sizing;
     carve(ws, sizing);

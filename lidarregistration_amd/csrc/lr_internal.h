@@ -35,7 +35,7 @@ static inline int lr_cdiv(int a, int b) { return (a + b - 1) / b; }
 #define LR_GPF_MAX_CELLS 4096
 // f16 filter path: pass A samples every LR_NN16_STRIDE-th column tile; candidate list capacity per row
 #define LR_NN16_STRIDE 4
-#define LR_NN16_CAPS 16      // candidate slots per (row, strip)
+#define LR_NN16_CAP 128      // candidate slots per row (shared by all strips)
 #define LR_NN16_LIST 2048    // per-block LDS candidate list (256 rows x one strip); columns must be < 2^22
 enum { LR_NN_PATH_F16_FILTER = 0, LR_NN_PATH_FP32_MFMA = 1 };
 
@@ -48,10 +48,11 @@ struct lr_workspace {
     float *nrm0, *nrm1;          // row norms
     _Float16 *H0, *H1;           // [n,32] f16 copies for the matrix-core filter passes
     float *tau;                  // [max_n] per-row candidate threshold
-    int32_t *cand_cnt, *cand;    // [max_n][strips], [max_n][strips][LR_NN16_CAPS] candidate lists
+    int32_t *cand_cnt, *cand;    // [max_n], [max_n][LR_NN16_CAP] candidate lists
     float *bmax0, *bmax1;        // per-32-row maxima of the norms (f16 filter error bound)
     uint32_t *rev_seed;          // [max_n1] best forward distance pointing at each cloud-1 row (bit pattern)
     int nn_path;                 // LR_NN_PATH_*
+    int nn_blocks_target;        // column strips are chosen so that a pass launches about this many blocks
     float *pb1, *pb2, *pb3;      // partial top-3 values [strips][max_n]
     int32_t *pi1, *pi2;          // partial top-2 indices
     int32_t *fix_list;           // rows needing the exact tie-break path [max_n]

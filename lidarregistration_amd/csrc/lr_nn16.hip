@@ -121,20 +121,18 @@ nn16_pass_kernel(const _Float16 *__restrict__ Hq, int na, const _Float16 *__rest
                  const float *__restrict__ tau, int32_t *__restrict__ cand_cnt, int32_t *__restrict__ cand)
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][LR_CH * 32 * LR_LDS_ROW + LR_CH * 32 * 4];
-    __shared__ int s_cnt[LR_BLOCK_ROWS];
     __shared__ int s_list[LR_NN16_LIST];      // block-level candidate list: (local row << 22) | column
     __shared__ int s_n;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r = lane & 31, h = lane >> 5;
     const int row0 = blockIdx.x * LR_BLOCK_ROWS + wave * 32 * LR_RB;
-    const int strip = blockIdx.y, nstrips = gridDim.y;
+    const int strip = blockIdx.y;
     const int ntiles = (nb + 31) >> 5;
     const int t_begin = strip * tiles_per_strip;
     const int t_end = min(ntiles, t_begin + tiles_per_strip);
     const int nsamp = t_end > t_begin ? (t_end - t_begin + tile_stride - 1) / tile_stride : 0;   // tiles this block visits
     const int nchunks = (nsamp + LR_CH - 1) / LR_CH;
     if (MODE == 1) {
-        for (int t = tid; t < LR_BLOCK_ROWS; t += 256) s_cnt[t] = 0;
         if (tid == 0) s_n = 0;
     }
 
@@ -260,20 +258,23 @@ nn16_pass_kernel(const _Float16 *__restrict__ Hq, int na, const _Float16 *__rest
     }
 
     if (MODE == 1) {
-        // distribute the parked candidates to the (row, strip) slot lists; a block that overflowed its LDS list marks
-        // all its rows as overflowed, which sends them through the exact full-row scan
+        // distribute the parked candidates to the per-row slot lists (shared by all strips; global atomics, but outside the
+        // hot loop and spread over 256 threads).  A block that overflowed its LDS list marks all its rows as overflowed,
+        // which sends them through the exact full-row scan.
         const int n_list = s_n;
-        const bool over = n_list > LR_NN16_LIST;
-        for (int e = tid; e < min(n_list, LR_NN16_LIST); e += 256) {
-            const int v = s_list[e];
-            const int lrow = (v >> 22) & 0x3ff, col = v & 0x3fffff;
-            const int slot = atomicAdd(&s_cnt[lrow], 1);
-            if (slot < LR_NN16_CAPS) cand[((size_t)(blockIdx.x * LR_BLOCK_ROWS + lrow) * nstrips + strip) * LR_NN16_CAPS + slot] = col;
-        }
-        __syncthreads();
-        for (int t = tid; t < LR_BLOCK_ROWS; t += 256) {
-            const int row = blockIdx.x * LR_BLOCK_ROWS + t;
-            if (row < na) cand_cnt[(size_t)row * nstrips + strip] = over ? LR_NN16_CAPS + 1 : s_cnt[t];
+        if (n_list > LR_NN16_LIST) {
+            for (int t = tid; t < LR_BLOCK_ROWS; t += 256) {
+                const int row = blockIdx.x * LR_BLOCK_ROWS + t;
+                if (row < na) atomicAdd(&cand_cnt[row], LR_NN16_CAP + 1);
+            }
+        } else {
+            for (int e = tid; e < n_list; e += 256) {
+                const int v = s_list[e];
+                const int row = blockIdx.x * LR_BLOCK_ROWS + ((v >> 22) & 0x3ff), col = v & 0x3fffff;
+                if (col >= nb) continue;      // padding columns pass the test only when tau is +inf (fewer than `need` samples)
+                const int slot = atomicAdd(&cand_cnt[row], 1);
+                if (slot < LR_NN16_CAP) cand[(size_t)row * LR_NN16_CAP + slot] = col;
+            }
         }
     }
     if (MODE == 0 && row0 < na) {
@@ -302,11 +303,10 @@ nn16_pass_kernel(const _Float16 *__restrict__ Hq, int na, const _Float16 *__rest
 __global__ void __launch_bounds__(256)
 nn16_thresh_kernel(int na, int nstrips, int part_stride, const float *__restrict__ pg1, const float *__restrict__ pg2,
                    const float *__restrict__ nQ, const float *__restrict__ block_max_c, int nblk_c, int need,
-                   float *__restrict__ tau, int32_t *__restrict__ counters)
+                   float *__restrict__ tau, int32_t *__restrict__ cand_cnt)
 {
     __shared__ float s_m[4];
     const int row = blockIdx.x * blockDim.x + threadIdx.x;
-    (void)counters;
     // max_j n1_j of the column cloud from the per-block maxima of its prep kernel
     float mx = 0.0f;
     for (int b = threadIdx.x; b < nblk_c; b += 256) mx = fmaxf(mx, block_max_c[b]);
@@ -328,10 +328,11 @@ nn16_thresh_kernel(int na, int nstrips, int part_stride, const float *__restrict
     const float E = 1.05e-3f * scale + 4e-7f;
     // U + 2E + sqrt band 2^-21 (n0 + U + E) + rounding slop (this expression, y = tau/2 folded into the MFMA accumulator)
     tau[row] = U + 2.0f * E + 6e-6f * scale + 2e-6f * fabsf(U);   // +inf when fewer than `need` columns were sampled
+    cand_cnt[row] = 0;
 }
 
 // ------------------------------------------------------------------ exact verification of the candidates
-// Four lanes per row: lane q takes the candidate slots of strips q, q+4, ...; the four partial (first, second) pairs are
+// Four lanes per row: lane q takes the candidate slots q, q+4, ...; the four partial (first, second) pairs are
 // merged under the (sqrt value, index) order with two shuffles.  Rows with an overflowing or too-short candidate list
 // are re-done by a full exact scan of all columns, in place.
 __device__ __forceinline__ bool sj_lt(float a, int ia, float b, int ib) { return a < b || (a == b && ia < ib); }
@@ -339,7 +340,7 @@ __device__ __forceinline__ bool sj_lt(float a, int ia, float b, int ib) { return
 __global__ void __launch_bounds__(256)
 nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, int na,
                   const float *__restrict__ Fc, const float *__restrict__ nC, int nb,
-                  const int32_t *__restrict__ cand_cnt, const int32_t *__restrict__ cand, int nstrips, int need,
+                  const int32_t *__restrict__ cand_cnt, const int32_t *__restrict__ cand, int need,
                   const uint32_t *__restrict__ skip_seed,
                   int32_t *__restrict__ idx1, int32_t *__restrict__ idx2, float *__restrict__ s1o, float *__restrict__ s2o,
                   int32_t *__restrict__ counters)
@@ -355,36 +356,26 @@ nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, in
     const float nq = nQ[rowc];
     float b1 = LR_INF, b2 = LR_INF;
     int i1 = LR_IMAX, i2 = LR_IMAX;
-    int total = 0, over = 0;
-    for (int s = q; s < nstrips; s += 4) {
-        const int cnt = cand_cnt[(size_t)rowc * nstrips + s];
-        total += cnt;
-        over |= cnt > LR_NN16_CAPS ? 1 : 0;
-        const int lim = min(cnt, LR_NN16_CAPS);
-        for (int c = 0; c < lim; ++c) {
-            const int j = cand[((size_t)rowc * nstrips + s) * LR_NN16_CAPS + c];
-            const f32x4 *pb = reinterpret_cast<const f32x4 *>(Fc + (size_t)j * 32);
-            float acc = 0.0f;
+    const int total = cand_cnt[rowc];
+    const int over = total > LR_NN16_CAP ? 1 : 0;
+    for (int c = q; c < min(total, LR_NN16_CAP); c += 4) {
+        const int j = cand[(size_t)rowc * LR_NN16_CAP + c];
+        const f32x4 *pb = reinterpret_cast<const f32x4 *>(Fc + (size_t)j * 32);
+        float acc = 0.0f;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const f32x4 t = pb[k];
-                acc = __builtin_fmaf(a[4 * k], t.x, acc);
-                acc = __builtin_fmaf(a[4 * k + 1], t.y, acc);
-                acc = __builtin_fmaf(a[4 * k + 2], t.z, acc);
-                acc = __builtin_fmaf(a[4 * k + 3], t.w, acc);
-            }
-            const float tt = nq + nC[j];
-            const float d2 = __builtin_fmaf(-2.0f, acc, tt);
-            const float sv = __builtin_sqrtf(fmaxf(d2, 1e-30f));
-            // candidates arrive in arbitrary order: order by (sqrt value, index) == torch.min's first minimal value
-            if (sj_lt(sv, j, b1, i1)) { b2 = b1; i2 = i1; b1 = sv; i1 = j; }
-            else if (sj_lt(sv, j, b2, i2)) { b2 = sv; i2 = j; }
+        for (int k = 0; k < 8; ++k) {
+            const f32x4 t = pb[k];
+            acc = __builtin_fmaf(a[4 * k], t.x, acc);
+            acc = __builtin_fmaf(a[4 * k + 1], t.y, acc);
+            acc = __builtin_fmaf(a[4 * k + 2], t.z, acc);
+            acc = __builtin_fmaf(a[4 * k + 3], t.w, acc);
         }
-    }
-#pragma unroll
-    for (int m = 1; m <= 2; m <<= 1) {
-        total += __shfl_xor(total, m);
-        over |= __shfl_xor(over, m);
+        const float tt = nq + nC[j];
+        const float d2 = __builtin_fmaf(-2.0f, acc, tt);
+        const float sv = __builtin_sqrtf(fmaxf(d2, 1e-30f));
+        // candidates arrive in arbitrary order: order by (sqrt value, index) == torch.min's first minimal value
+        if (sj_lt(sv, j, b1, i1)) { b2 = b1; i2 = i1; b1 = sv; i1 = j; }
+        else if (sj_lt(sv, j, b2, i2)) { b2 = sv; i2 = j; }
     }
     const bool skip = skip_seed && !(__uint_as_float(skip_seed[rowc]) < 3.0e38f);   // reverse NN nobody asked for
     if (!skip && (over || total < min(need, nb))) {
@@ -449,7 +440,7 @@ int lr_nn16_run(lr_workspace *ws, const float *Fq, const _Float16 *Hq, const flo
     if (stride > LR_NN16_STRIDE) stride = LR_NN16_STRIDE;
     if (stride < 1) stride = 1;
     // strips: enough blocks to fill 256 CUs a few times over, at least 8 sampled tiles per strip
-    int strips = lr_cdiv(1024, row_blocks);
+    int strips = lr_cdiv(ws->nn_blocks_target, row_blocks);
     int smax = ntiles / (8 * stride);
     if (strips > smax) strips = smax;
     if (strips > LR_NN_MAX_STRIPS) strips = LR_NN_MAX_STRIPS;
@@ -459,13 +450,13 @@ int lr_nn16_run(lr_workspace *ws, const float *Fq, const _Float16 *Hq, const flo
     hipLaunchKernelGGL(nn16_pass_kernel<0>, grid, dim3(256), 0, st, Hq, na, Hc, nC, nb, tps, stride, ws->max_n, ws->pb1, ws->pb2,
                        (const float *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
     hipLaunchKernelGGL(nn16_thresh_kernel, dim3(lr_cdiv(na, 256)), dim3(256), 0, st, na, strips, ws->max_n, ws->pb1, ws->pb2, nQ,
-                       block_max_c, lr_cdiv(nb, 32), need, ws->tau, ws->counters);
+                       block_max_c, lr_cdiv(nb, 32), need, ws->tau, ws->cand_cnt);
     if (ws->timing && !ws->ev_pending) { LR_HIP(hipEventRecord(ws->ev[0], st)); }
     hipLaunchKernelGGL(nn16_pass_kernel<1>, grid, dim3(256), 0, st, Hq, na, Hc, nC, nb, tps, 1, ws->max_n, (float *)nullptr,
                        (float *)nullptr, ws->tau, ws->cand_cnt, ws->cand);
     if (ws->timing && !ws->ev_pending) { LR_HIP(hipEventRecord(ws->ev[1], st)); ws->ev_pending = 1; }
     hipLaunchKernelGGL(nn16_exact_kernel, dim3(lr_cdiv(na, 64)), dim3(256), 0, st, Fq, nQ, na, Fc, nC, nb, ws->cand_cnt, ws->cand,
-                       strips, need, (const uint32_t *)nullptr, idx1, idx2, s1, s2, ws->counters);
+                       need, (const uint32_t *)nullptr, idx1, idx2, s1, s2, ws->counters);
     LR_LAUNCH_CHECK();
     return LR_OK;
 }
@@ -501,11 +492,10 @@ nn16_rev_seed_kernel(const float *__restrict__ F0, const float *__restrict__ n0v
 
 __global__ void __launch_bounds__(256)
 nn16_thresh_seed_kernel(int na, const uint32_t *__restrict__ seed_bits, const float *__restrict__ nQ,
-                        const float *__restrict__ block_max_c, int nblk_c, float *__restrict__ tau, int32_t *__restrict__ counters)
+                        const float *__restrict__ block_max_c, int nblk_c, float *__restrict__ tau, int32_t *__restrict__ cand_cnt)
 {
     __shared__ float s_m[4];
     const int row = blockIdx.x * blockDim.x + threadIdx.x;
-    (void)counters;
     float mx = 0.0f;
     for (int b = threadIdx.x; b < nblk_c; b += 256) mx = fmaxf(mx, block_max_c[b]);
 #pragma unroll
@@ -514,6 +504,7 @@ nn16_thresh_seed_kernel(int na, const uint32_t *__restrict__ seed_bits, const fl
     __syncthreads();
     const float max_nc = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
     if (row >= na) return;
+    cand_cnt[row] = 0;
     const float sv = __uint_as_float(seed_bits[row]);
     if (!(sv < 3.0e38f)) { tau[row] = -LR_INF; return; }      // still the 0x7f7f7f7f fill: no query points at this row
     const float scale = nQ[row] + max_nc;
@@ -530,7 +521,7 @@ int lr_nn16_reverse(lr_workspace *ws, const float *F0, const _Float16 *H0, const
     const int na = n1, nb = n0;
     const int ntiles = lr_cdiv(nb, 32);
     const int row_blocks = lr_cdiv(na, LR_BLOCK_ROWS);
-    int strips = lr_cdiv(1024, row_blocks);
+    int strips = lr_cdiv(ws->nn_blocks_target, row_blocks);
     int smax = ntiles / 8;
     if (strips > smax) strips = smax;
     if (strips > LR_NN_MAX_STRIPS) strips = LR_NN_MAX_STRIPS;
@@ -539,12 +530,12 @@ int lr_nn16_reverse(lr_workspace *ws, const float *F0, const _Float16 *H0, const
     uint32_t *seed = ws->rev_seed;          // filled with 0x7f7f7f7f by the prep kernel of this pair
     hipLaunchKernelGGL(nn16_rev_seed_kernel, dim3(lr_cdiv(n0, 256)), dim3(256), 0, st, F0, nrm0, n0, F1, nrm1, fwd_idx1, seed);
     hipLaunchKernelGGL(nn16_thresh_seed_kernel, dim3(lr_cdiv(na, 256)), dim3(256), 0, st, na, seed, nrm1, bmax0, lr_cdiv(nb, 32),
-                       ws->tau, ws->counters);
+                       ws->tau, ws->cand_cnt);
     dim3 grid(row_blocks, strips);
     hipLaunchKernelGGL(nn16_pass_kernel<1>, grid, dim3(256), 0, st, H1, na, H0, nrm0, nb, tps, 1, ws->max_n, (float *)nullptr,
                        (float *)nullptr, ws->tau, ws->cand_cnt, ws->cand);
     hipLaunchKernelGGL(nn16_exact_kernel, dim3(lr_cdiv(na, 64)), dim3(256), 0, st, F1, nrm1, na, F0, nrm0, nb, ws->cand_cnt, ws->cand,
-                       strips, 1, seed, rev, (int32_t *)nullptr, (float *)nullptr, (float *)nullptr, ws->counters);
+                       1, seed, rev, (int32_t *)nullptr, (float *)nullptr, (float *)nullptr, ws->counters);
     LR_LAUNCH_CHECK();
     return LR_OK;
 }
