@@ -60,6 +60,7 @@ def main():
 
     class A:
         mode = args.mode; codebase = "open3D"; iters = args.iters; ransac_n = 3; GPF_factor = 2.0; GPF_grid_wid = 10
+        o3d_conf = 1.0          # every one of the --iters hypotheses is evaluated (no confidence-based early exit)
     params = FR.pair_params(A)
 
     # resident inputs: `distinct` synthetic pairs per GPU, cycled through the batch

@@ -39,8 +39,12 @@ typedef struct lr_ransac_params {
     int32_t  sample_size;   /* 3 = GC-RANSAC minimal solver, 4 = FR.py:134 ransac_n                  */
     int32_t  use_elc;       /* edge-length pre-check, similarity 0.9 (preemption_edge_length.h:82)    */
     float    thr2;          /* squared inlier threshold; (2*voxel)^2 = 0.36 (FR.py:85,95)             */
-    int32_t  iters;         /* hypotheses 0..iters-1 are all evaluated (--iters, FR.py:65-67)         */
+    int32_t  iters;         /* hypothesis ids 0..iters-1 (--iters, FR.py:65-67)                       */
     uint64_t seed;          /* Philox4x32-10 key; sample of hypothesis h = philox(seed, h)            */
+    float    confidence;    /* early exit (--GC_conf / FR.py:136): ids are evaluated in batches of `batch`; after a
+                               batch ending at id e the run stops when e >= log(1-confidence) / log(1 - (inl/M)^sample_size)
+                               for the best model so far.  >= 1 (or <= 0): every id is evaluated.             */
+    int32_t  batch;         /* batch length of the early-exit test (0 -> 8192)                        */
 } lr_ransac_params;
 
 /* Written to device memory by lr_ransac / lr_register_pair. */
@@ -50,9 +54,10 @@ typedef struct lr_ransac_result {
     uint32_t pad0;
     uint64_t best_ssq;      /* sum over its inliers of (uint32)(d^2 * 2^20)                           */
     int64_t  n_valid;       /* hypotheses that passed the pre-check and were scored                   */
+    int64_t  n_ids;         /* hypothesis ids examined before the run stopped (== iters without early exit) */
 } lr_ransac_result;
 
-/* Per-pair result block of lr_register_pair (device memory, 336 bytes). */
+/* Per-pair result block of lr_register_pair (device memory, 344 bytes). */
 typedef struct lr_pair_result {
     double   T[16];         /* final transform (after the LS refit when refit != 0)                   */
     double   T_ransac[16];  /* winning minimal-sample model before the refit                          */

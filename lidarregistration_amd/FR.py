@@ -2,7 +2,7 @@
 
 Same positional signature and 8-tuple as FR.py:16,119.  The whole pair (NN -> filter -> RANSAC ->
 refit) runs as ONE call into the C ABI (``lr_register_pair``) with no host synchronisation until the
-336-byte result block is read back.
+344-byte result block is read back.
 """
 import ctypes
 from time import time
@@ -43,10 +43,13 @@ def pair_params(args):
     if codebase == "GC":
         sample_size = 3
         use_elc = getattr(args, "fast_rejection", "ELC") == "ELC"
+        conf = float(getattr(args, "GC_conf", 0.999))                  # GC_RANSAC.py:26, test.py:312
     else:
         sample_size = int(getattr(args, "ransac_n", 4))                # FR.py:134
         use_elc = True                                                 # FR.py:135 edge-length checker
-    rp = _ext.RansacParams(sample_size, int(use_elc), np.float32(thr * thr), iters, int(getattr(args, "seed", DEFAULT_SEED)))
+        conf = float(getattr(args, "o3d_conf", 0.9995))                # FR.py:136
+    rp = _ext.RansacParams(sample_size, int(use_elc), np.float32(thr * thr), iters, int(getattr(args, "seed", DEFAULT_SEED)),
+                           conf, int(getattr(args, "ransac_batch", 0)))
     p = _ext.PairParams()
     p.mode = MODES[mode]
     p.refit = int(getattr(args, "refit", True))
@@ -58,7 +61,7 @@ def pair_params(args):
 
 
 def register_pair_dev(xyz0, xyz1, feats0, feats1, params, out=None, ws=None, stream=None):
-    """Enqueue one pair; returns the device result buffer (uint8[336]).  No synchronisation."""
+    """Enqueue one pair; returns the device result buffer (uint8[344]).  No synchronisation."""
     n0, n1, d = feats0.shape[0], feats1.shape[0], feats0.shape[1]
     if ws is None:
         ws = workspace(n0, n1, params.ransac.iters, d)

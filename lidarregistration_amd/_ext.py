@@ -26,12 +26,12 @@ class LidarRegError(RuntimeError):
 
 class RansacParams(ctypes.Structure):
     _fields_ = [("sample_size", ctypes.c_int32), ("use_elc", ctypes.c_int32), ("thr2", ctypes.c_float),
-                ("iters", ctypes.c_int32), ("seed", ctypes.c_uint64)]
+                ("iters", ctypes.c_int32), ("seed", ctypes.c_uint64), ("confidence", ctypes.c_float), ("batch", ctypes.c_int32)]
 
 
 class RansacResult(ctypes.Structure):
     _fields_ = [("best_h", ctypes.c_int64), ("best_count", ctypes.c_uint32), ("pad0", ctypes.c_uint32),
-                ("best_ssq", ctypes.c_uint64), ("n_valid", ctypes.c_int64)]
+                ("best_ssq", ctypes.c_uint64), ("n_valid", ctypes.c_int64), ("n_ids", ctypes.c_int64)]
 
 
 class PairResult(ctypes.Structure):
@@ -46,7 +46,7 @@ class PairParams(ctypes.Structure):
                 ("refit_thr2", ctypes.c_double)]
 
 
-assert ctypes.sizeof(PairResult) == 336, ctypes.sizeof(PairResult)
+assert ctypes.sizeof(PairResult) == 344, ctypes.sizeof(PairResult)
 
 _lib = None
 

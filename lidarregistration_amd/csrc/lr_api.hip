@@ -45,7 +45,7 @@ void carve(lr_workspace *ws, Carver &c)
     ws->pb3 = c.take<float>(n * LR_NN_MAX_STRIPS);
     ws->pi1 = c.take<int32_t>(n * LR_NN_MAX_STRIPS); ws->pi2 = c.take<int32_t>(n * LR_NN_MAX_STRIPS);
     ws->fix_list = c.take<int32_t>(n);
-    ws->counters = c.take<int32_t>(LR_CNT_COUNT);
+    ws->counters = c.take<int32_t>(LR_CNT_TOTAL);
     ws->bmax0 = c.take<float>(n0 / 32 + 2); ws->bmax1 = c.take<float>(n1 / 32 + 2);
     ws->rev_seed = c.take<uint32_t>(n1);
     ws->nn_idx1 = c.take<int32_t>(n0); ws->nn_idx2 = c.take<int32_t>(n0);
@@ -288,7 +288,7 @@ extern "C" int lr_register_pair(lr_workspace *ws, const float *xyz0, const float
     hipStream_t st = (hipStream_t)stream;
     int32_t *m_dev = ws->counters + LR_CNT_NCORR;
     int32_t *n_refit = ws->counters + LR_CNT_COUNT - 2;
-    LR_HIP(hipMemsetAsync(ws->counters, 0, sizeof(int32_t) * LR_CNT_COUNT, st));
+    LR_HIP(hipMemsetAsync(ws->counters, 0, sizeof(int32_t) * LR_CNT_TOTAL, st));
     // 1. coarse correspondences (FR.py:38): first + second NN of every cloud-0 descriptor
     LR_TRY(prep_both(ws, F0, n0, F1, n1, st));
     LR_TRY(nn_forward(ws, F0, n0, F1, n1, ws->nn_idx1, ws->nn_idx2, ws->nn_s1, ws->nn_s2, st));

@@ -78,7 +78,10 @@ compact_kernel(int n0, const uint8_t *__restrict__ flags, const int32_t *__restr
             reinterpret_cast<float4 *>(corr8)[2 * slot + 1] = hi;
         }
     }
-    if (corr8 && blockIdx.x == 0 && tid == 0) counters[LR_CNT_NVALID] = 0;
+    if (corr8 && blockIdx.x == 0 && tid < LR_CNT_TOTAL - LR_CNT_COUNT) {     // the RANSAC that follows starts from scratch
+        counters[LR_CNT_COUNT + tid] = 0;
+        if (tid == 0) counters[LR_CNT_NVALID] = 0;
+    }
     if (blockIdx.x == gridDim.x - 1 && tid == 0) {
         const int total = prefix + s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
         if (n_out) *n_out = total;
@@ -129,7 +132,8 @@ __global__ void pack_corr_kernel(const float *__restrict__ xyz0, const float *__
                                  int32_t *__restrict__ counters)
 {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0) counters[LR_CNT_NVALID] = 0;        // the hypothesis list of the RANSAC that follows starts empty
+    if (c < LR_CNT_TOTAL - LR_CNT_COUNT) counters[LR_CNT_COUNT + c] = 0;     // the RANSAC that follows starts from scratch
+    if (c == 0) counters[LR_CNT_NVALID] = 0;
     int m = m_dev ? min(*m_dev, m_max) : m_max;
     if (c >= m) return;
     int a = i0 ? i0[c] : c, b = i1 ? i1[c] : c;

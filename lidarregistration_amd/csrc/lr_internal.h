@@ -96,8 +96,21 @@ enum {
     LR_CNT_NCORR,        // live M
     LR_CNT_NVALID,       // hypotheses appended to models[]
     LR_CNT_NBB,          // best buddies
-    LR_CNT_COUNT = 16
+    LR_CNT_COUNT = 16,
+    LR_CNT_TOTAL = 64        // counters[16..63] hold lr_ransac_state
 };
+
+// running state of a RANSAC call across its early-exit batches (lives in counters[LR_CNT_COUNT..], zeroed with NVALID)
+struct lr_ransac_state {
+    double T[12];                 // fp64 model of the best hypothesis so far
+    unsigned long long ssq;
+    long long n_valid, n_ids;
+    uint32_t cnt;
+    int32_t h;                    // its id (valid when cnt > 0)
+    int32_t done;                 // set when the confidence test says stop: later batches return immediately
+    int32_t pad;
+};
+static_assert(sizeof(lr_ransac_state) <= (LR_CNT_TOTAL - LR_CNT_COUNT) * sizeof(int32_t), "lr_ransac_state does not fit");
 
 // lr_nn.hip
 int lr_nn_run(lr_workspace *ws, const float *Fa, const float *nrma, int na, const float *Fb, const float *nrmb, int nb,

@@ -178,20 +178,20 @@ __device__ __forceinline__ bool hypothesis_sample(const float *__restrict__ corr
 template <int NS>
 __global__ void __launch_bounds__(256)
 ransac_gen_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__restrict__ m_dev, lr_ransac_params p,
-                  float *__restrict__ models, double *__restrict__ models64, int32_t *__restrict__ model_h,
+                  int h_begin, int h_end, float *__restrict__ models, double *__restrict__ models64, int32_t *__restrict__ model_h,
                   uint32_t *__restrict__ score_cnt, unsigned long long *__restrict__ score_ssq,
                   int32_t *__restrict__ counters)
 {
     __shared__ int s_pass[256];
     __shared__ int s_np, s_base;
     const int m = m_dev ? min(*m_dev, m_max) : m_max;
-    if (m <= 0) return;
+    if (m <= 0 || reinterpret_cast<const lr_ransac_state *>(counters + LR_CNT_COUNT)->done) return;
     if (threadIdx.x == 0) s_np = 0;
     __syncthreads();
-    const int h = blockIdx.x * 256 + threadIdx.x;
+    const int h = h_begin + blockIdx.x * 256 + threadIdx.x;
     {
         double P[NS][3], Q[NS][3];
-        if (h < p.iters && hypothesis_sample<NS>(corr8, m, p.seed, (uint64_t)h, p.use_elc, P, Q)) s_pass[atomicAdd(&s_np, 1)] = h;
+        if (h < h_end && hypothesis_sample<NS>(corr8, m, p.seed, (uint64_t)h, p.use_elc, P, Q)) s_pass[atomicAdd(&s_np, 1)] = h;
     }
     __syncthreads();
     const int np = s_np;
@@ -220,7 +220,7 @@ ransac_score_kernel(const float *__restrict__ corr8, int m_max, const int32_t *_
     const int m = m_dev ? min(*m_dev, m_max) : m_max;
     const int V = counters[LR_CNT_NVALID];
     const int hb = (V + 63) >> 6;
-    if (hb == 0 || m <= 0) return;
+    if (hb == 0 || m <= 0 || reinterpret_cast<const lr_ransac_state *>(counters + LR_CNT_COUNT)->done) return;
     int chunks = (int)gridDim.x / hb;
     const int cmax = m / 512 > 0 ? m / 512 : 1;
     if (chunks > cmax) chunks = cmax;
@@ -268,14 +268,18 @@ __device__ __forceinline__ bool better(uint32_t c, unsigned long long q, int h, 
     return c > bc || (c == bc && (q < bq || (q == bq && h < bh)));
 }
 
+// best of this batch -> merged into the running state; confidence test; outputs rewritten from the state every batch
 __global__ void __launch_bounds__(1024)
 ransac_final_kernel(const uint32_t *__restrict__ score_cnt, const unsigned long long *__restrict__ score_ssq,
                     const int32_t *__restrict__ model_h, const double *__restrict__ models64,
-                    const int32_t *__restrict__ counters, double *__restrict__ T_out, lr_ransac_result *__restrict__ res)
+                    int32_t *__restrict__ counters, int m_max, const int32_t *__restrict__ m_dev, lr_ransac_params p, int h_end,
+                    double *__restrict__ T_out, lr_ransac_result *__restrict__ res)
 {
     __shared__ unsigned long long s_q[16];
     __shared__ uint32_t s_c[16];
     __shared__ int s_h[16], s_s[16];
+    lr_ransac_state *state = reinterpret_cast<lr_ransac_state *>(counters + LR_CNT_COUNT);
+    if (state->done) return;
     const int V = counters[LR_CNT_NVALID];
     uint32_t bc = 0; unsigned long long bq = ~0ull; int bh = 0x7fffffff, bs = -1;
     for (int s = threadIdx.x; s < V; s += 1024) {
@@ -294,20 +298,37 @@ ransac_final_kernel(const uint32_t *__restrict__ score_cnt, const unsigned long 
     }
     if ((threadIdx.x & 63) == 0) { s_c[threadIdx.x >> 6] = bc; s_q[threadIdx.x >> 6] = bq; s_h[threadIdx.x >> 6] = bh; s_s[threadIdx.x >> 6] = bs; }
     __syncthreads();
-    if (threadIdx.x < 16) {
-        for (int w = 1; w < 16; ++w)
-            if (better(s_c[w], s_q[w], s_h[w], bc, bq, bh)) { bc = s_c[w]; bq = s_q[w]; bh = s_h[w]; bs = s_s[w]; }
-        // every one of these 16 lanes now holds the same winner; lane k writes T[k]
-        const int k = threadIdx.x;
-        const bool have = bc > 0 && bs >= 0;
-        double v = (k % 5 == 0) ? 1.0 : 0.0;
-        if (have && k < 12) v = models64[(size_t)bs * 12 + k];
-        T_out[k] = v;
-        if (k == 0) {
-            lr_ransac_result r;
-            r.best_h = have ? bh : -1; r.best_count = have ? bc : 0; r.pad0 = 0; r.best_ssq = have ? bq : 0; r.n_valid = V;
-            *res = r;
+    if (threadIdx.x >= 16) return;
+    for (int w = 1; w < 16; ++w)
+        if (better(s_c[w], s_q[w], s_h[w], bc, bq, bh)) { bc = s_c[w]; bq = s_q[w]; bh = s_h[w]; bs = s_s[w]; }
+    // all 16 lanes hold the batch winner; merge it into the state (lane k moves T[k])
+    const int k = threadIdx.x;
+    const uint32_t oc = state->cnt; const unsigned long long oq = state->ssq; const int oh = state->h;
+    const bool take = bc > 0 && bs >= 0 && (oc == 0 || better(bc, bq, bh, oc, oq, oh));
+    double v = (k % 5 == 0) ? 1.0 : 0.0;
+    if (k < 12) {
+        if (take) { v = models64[(size_t)bs * 12 + k]; state->T[k] = v; }
+        else if (oc > 0) v = state->T[k];
+    }
+    T_out[k] = v;
+    if (k == 0) {
+        const uint32_t nc = take ? bc : oc; const unsigned long long nq = take ? bq : oq; const int nh = take ? bh : oh;
+        state->cnt = nc; state->ssq = nq; state->h = nh;
+        state->n_valid += V; state->n_ids = h_end;
+        counters[LR_CNT_NVALID] = 0;                       // the next batch appends from slot 0
+        if (p.confidence > 0.0f && p.confidence < 1.0f && nc > 0) {
+            // exit rule of Open3D's RANSAC / GC-RANSAC at batch granularity: stop once h_end >= log(1-conf)/log(1-(inl/M)^n)
+            const int m = m_dev ? min(*m_dev, m_max) : m_max;
+            const double f = (double)nc / (double)m;
+            double fn = f;
+            for (int q = 1; q < p.sample_size; ++q) fn = fn * f;
+            const double kk = log(1.0 - (double)p.confidence) / log(1.0 - fn);
+            if ((double)h_end >= kk) state->done = 1;
         }
+        lr_ransac_result r;
+        r.best_h = nc > 0 ? nh : -1; r.best_count = nc; r.pad0 = 0; r.best_ssq = nc > 0 ? nq : 0;
+        r.n_valid = state->n_valid; r.n_ids = h_end;
+        *res = r;
     }
 }
 
@@ -318,22 +339,27 @@ int lr_ransac_run(lr_workspace *ws, const float *corr8, int m_max, const int32_t
     LR_REQUIRE(p->iters >= 0 && p->iters <= ws->max_iters, LR_ESIZE, "lr_ransac: iters exceeds the workspace");
     LR_REQUIRE(m_max >= 0 && m_max <= ws->max_n0, LR_ESIZE, "lr_ransac: m exceeds the workspace");
     LR_REQUIRE(p->thr2 > 0.0f && p->thr2 < 2048.0f, LR_EINVAL, "lr_ransac: thr2 must be in (0, 2048)");
-    const int gb = lr_cdiv(p->iters > 0 ? p->iters : 1, 256);
     int sub = (int)(4095.0 / ((double)p->thr2 * 1.0000001 + 1e-6));     // sub * thr2 * 2^20 < 2^32
     if (sub > 4096) sub = 4096;
     if (sub < 1) sub = 1;
+    const bool use_exit = p->confidence > 0.0f && p->confidence < 1.0f;
+    const int B = use_exit ? (p->batch > 0 ? p->batch : 8192) : (p->iters > 0 ? p->iters : 1);
     if (ws->timing && ws->ev_pending == 1) { LR_HIP(hipEventRecord(ws->ev[2], st)); }
-    if (p->sample_size == 3)
-        hipLaunchKernelGGL(ransac_gen_kernel<3>, dim3(gb), dim3(256), 0, st, corr8, m_max, m_dev, *p, ws->models, ws->models64,
-                           ws->model_h, ws->score_cnt, ws->score_ssq, ws->counters);
-    else
-        hipLaunchKernelGGL(ransac_gen_kernel<4>, dim3(gb), dim3(256), 0, st, corr8, m_max, m_dev, *p, ws->models, ws->models64,
-                           ws->model_h, ws->score_cnt, ws->score_ssq, ws->counters);
-    hipLaunchKernelGGL(ransac_score_kernel, dim3(LR_SCORE_BLOCKS), dim3(64), 0, st, corr8, m_max, m_dev, p->thr2, ws->models,
-                       ws->score_cnt, ws->score_ssq, ws->counters, sub);
-    if (ws->timing && ws->ev_pending == 1) { LR_HIP(hipEventRecord(ws->ev[3], st)); ws->ev_pending = 2; }
-    hipLaunchKernelGGL(ransac_final_kernel, dim3(1), dim3(1024), 0, st, ws->score_cnt, ws->score_ssq, ws->model_h, ws->models64,
-                       ws->counters, T_out, res);
+    for (int h0 = 0; h0 < (p->iters > 0 ? p->iters : 1); h0 += B) {
+        const int h1 = h0 + B < p->iters ? h0 + B : p->iters;
+        const int gb = lr_cdiv(h1 - h0 > 0 ? h1 - h0 : 1, 256);
+        if (p->sample_size == 3)
+            hipLaunchKernelGGL(ransac_gen_kernel<3>, dim3(gb), dim3(256), 0, st, corr8, m_max, m_dev, *p, h0, h1, ws->models, ws->models64,
+                               ws->model_h, ws->score_cnt, ws->score_ssq, ws->counters);
+        else
+            hipLaunchKernelGGL(ransac_gen_kernel<4>, dim3(gb), dim3(256), 0, st, corr8, m_max, m_dev, *p, h0, h1, ws->models, ws->models64,
+                               ws->model_h, ws->score_cnt, ws->score_ssq, ws->counters);
+        hipLaunchKernelGGL(ransac_score_kernel, dim3(LR_SCORE_BLOCKS), dim3(64), 0, st, corr8, m_max, m_dev, p->thr2, ws->models,
+                           ws->score_cnt, ws->score_ssq, ws->counters, sub);
+        if (h0 == 0 && ws->timing && ws->ev_pending == 1) { LR_HIP(hipEventRecord(ws->ev[3], st)); ws->ev_pending = 2; }
+        hipLaunchKernelGGL(ransac_final_kernel, dim3(1), dim3(1024), 0, st, ws->score_cnt, ws->score_ssq, ws->model_h, ws->models64,
+                           ws->counters, m_max, m_dev, *p, h1, T_out, res);
+    }
     LR_LAUNCH_CHECK();
     return LR_OK;
 }

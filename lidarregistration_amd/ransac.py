@@ -16,22 +16,24 @@ from .matching import _device, _f32, _i32, _stream, workspace
 DEFAULT_SEED = 51          # Experiments/test.py:357
 
 
-def ransac_params(iters, sample_size=3, use_elc=True, thr=0.6, seed=DEFAULT_SEED):
-    return _ext.RansacParams(int(sample_size), int(bool(use_elc)), np.float32(float(thr) * float(thr)), int(iters), int(seed))
+def ransac_params(iters, sample_size=3, use_elc=True, thr=0.6, seed=DEFAULT_SEED, confidence=1.0, batch=0):
+    """confidence < 1 enables the early exit between batches of `batch` hypothesis ids (0 -> 8192)."""
+    return _ext.RansacParams(int(sample_size), int(bool(use_elc)), np.float32(float(thr) * float(thr)), int(iters), int(seed),
+                             float(confidence), int(batch))
 
 
-def ransac_dev(src, tgt, iters, sample_size=3, use_elc=True, thr=0.6, seed=DEFAULT_SEED):
+def ransac_dev(src, tgt, iters, sample_size=3, use_elc=True, thr=0.6, seed=DEFAULT_SEED, confidence=1.0, batch=0):
     """RANSAC over M correspondences src[i] <-> tgt[i] ([M,3]).  Returns (T 4x4 float64 numpy, info dict)."""
     src, tgt = _f32(src), _f32(tgt)
     m = src.shape[0]
     ws = workspace(max(m, 1), 1, iters)
     T = torch.empty(16, dtype=torch.float64, device=src.device)
     res = torch.zeros(ctypes.sizeof(_ext.RansacResult), dtype=torch.uint8, device=src.device)
-    p = ransac_params(iters, sample_size, use_elc, thr, seed)
+    p = ransac_params(iters, sample_size, use_elc, thr, seed, confidence, batch)
     _ext.check(_ext.lib().lr_ransac(ws.handle, src.data_ptr(), tgt.data_ptr(), m, None, ctypes.byref(p),
                                      T.data_ptr(), res.data_ptr(), _stream()))
     r = _ext.RansacResult.from_buffer_copy(res.cpu().numpy().tobytes())
-    info = dict(best_h=r.best_h, best_count=r.best_count, best_ssq=r.best_ssq, n_valid=r.n_valid)
+    info = dict(best_h=r.best_h, best_count=r.best_count, best_ssq=r.best_ssq, n_valid=r.n_valid, n_ids=r.n_ids)
     return T.cpu().numpy().reshape(4, 4), info
 
 
@@ -69,7 +71,7 @@ def GC_RANSAC(A, B, distance_threshold, num_iterations, args, match_quality):
     use_elc = getattr(args, "fast_rejection", "ELC") == "ELC"
     start_time = time()
     T, info = ransac_dev(A, B, num_iterations, sample_size=3, use_elc=use_elc, thr=distance_threshold,
-                         seed=getattr(args, "seed", DEFAULT_SEED))
+                         seed=getattr(args, "seed", DEFAULT_SEED), confidence=getattr(args, "GC_conf", 0.999))      # GC_RANSAC.py:26
     if info["best_h"] < 0:
         T = np.eye(4)                                       # GC_RANSAC.py:51-52
     return T, time() - start_time
@@ -80,5 +82,6 @@ def RANSAC_registration(pcd0, pcd1, idx0, idx1, distance_threshold, num_iteratio
     p0 = np.asarray(pcd0.points, np.float32)[np.asarray(idx0)]
     p1 = np.asarray(pcd1.points, np.float32)[np.asarray(idx1)]
     T, info = ransac_dev(p0, p1, num_iterations, sample_size=getattr(args, "ransac_n", 4), use_elc=True,
-                         thr=distance_threshold, seed=getattr(args, "seed", DEFAULT_SEED))
+                         thr=distance_threshold, seed=getattr(args, "seed", DEFAULT_SEED),
+                         confidence=getattr(args, "o3d_conf", 0.9995))                                               # FR.py:136
     return T if info["best_h"] >= 0 else np.eye(4)

@@ -291,6 +291,8 @@ typedef struct {
     float    thr2;            /* squared inlier threshold (0.6 m)^2                   */
     int32_t  iters;           /* hypotheses h = 0 .. iters-1                          */
     uint64_t seed;
+    float    confidence;      /* early exit between batches (FR.py:136, GC_RANSAC.py:26); >= 1 or <= 0: none */
+    int32_t  batch;           /* batch length (0 -> 8192)                             */
 } orc_ransac_params;
 
 typedef struct {
@@ -298,6 +300,7 @@ typedef struct {
     uint32_t best_count;      /* its inlier count                                     */
     uint64_t best_ssq;        /* sum over inliers of (uint32)(d2 * 2^20)              */
     int64_t  n_valid;         /* hypotheses that passed the pre-check                 */
+    int64_t  n_ids;           /* hypothesis ids examined before the run stopped       */
 } orc_ransac_result;
 
 /* fp64 minimal-sample Kabsch for hypothesis h; returns 0 when the pre-check rejects it */
@@ -347,38 +350,54 @@ ORC_API void orc_score(const float *src, const float *tgt, int m, const double T
 }
 
 /* Hypothesise-and-verify loop with Open3D ordering: more inliers wins, then lower error, then lower h.
- * Every hypothesis is evaluated (confidence-based early exit disabled, as the benchmark runs it).   */
+ * Ids are processed in batches; after the batch ending at id e the loop stops when
+ * e >= log(1-conf)/log(1-(inl/M)^n) for the best model so far (the exit rule of Open3D's
+ * RegistrationRANSACBasedOnCorrespondence / GC-RANSAC, applied at batch granularity so that a parallel
+ * evaluation is deterministic).  confidence >= 1 disables it: every id is evaluated.              */
 ORC_API void orc_ransac(const float *src, const float *tgt, int m, const orc_ransac_params *p,
                         double T_best[16], orc_ransac_result *res)
 {
-    int64_t best_h = -1; uint32_t best_c = 0; uint64_t best_q = 0; int64_t n_valid = 0;
+    int64_t best_h = -1; uint32_t best_c = 0; uint64_t best_q = 0; int64_t n_valid = 0, n_ids = 0;
+    const int use_exit = p->confidence > 0.0f && p->confidence < 1.0f;
+    const int64_t B = use_exit ? (p->batch > 0 ? p->batch : 8192) : (p->iters > 0 ? p->iters : 1);
+    for (int64_t h0 = 0; h0 < p->iters; h0 += B) {
+        const int64_t h1 = h0 + B < p->iters ? h0 + B : p->iters;
 #pragma omp parallel
-    {
-        int64_t lh = -1; uint32_t lc = 0; uint64_t lq = 0; int64_t lv = 0;
-#pragma omp for schedule(dynamic, 64)
-        for (int64_t h = 0; h < p->iters; ++h) {
-            double T[16];
-            if (!hypothesis_T(src, tgt, m, p, (uint64_t)h, T, NULL)) continue;
-            lv += 1;
-            float Rt[12];
-            for (int k = 0; k < 12; ++k) Rt[k] = (float)T[k];
-            uint32_t c; uint64_t q;
-            score_model(src, tgt, m, Rt, p->thr2, &c, &q);
-            if (c == 0) continue;
-            if (lh < 0 || c > lc || (c == lc && (q < lq || (q == lq && h < lh)))) { lh = h; lc = c; lq = q; }
-        }
-#pragma omp critical
         {
-            n_valid += lv;
-            if (lh >= 0 && (best_h < 0 || lc > best_c ||
-                            (lc == best_c && (lq < best_q || (lq == best_q && lh < best_h))))) {
-                best_h = lh; best_c = lc; best_q = lq;
+            int64_t lh = -1; uint32_t lc = 0; uint64_t lq = 0; int64_t lv = 0;
+#pragma omp for schedule(dynamic, 64)
+            for (int64_t h = h0; h < h1; ++h) {
+                double T[16];
+                if (!hypothesis_T(src, tgt, m, p, (uint64_t)h, T, NULL)) continue;
+                lv += 1;
+                float Rt[12];
+                for (int k = 0; k < 12; ++k) Rt[k] = (float)T[k];
+                uint32_t c; uint64_t q;
+                score_model(src, tgt, m, Rt, p->thr2, &c, &q);
+                if (c == 0) continue;
+                if (lh < 0 || c > lc || (c == lc && (q < lq || (q == lq && h < lh)))) { lh = h; lc = c; lq = q; }
             }
+#pragma omp critical
+            {
+                n_valid += lv;
+                if (lh >= 0 && (best_h < 0 || lc > best_c ||
+                                (lc == best_c && (lq < best_q || (lq == best_q && lh < best_h))))) {
+                    best_h = lh; best_c = lc; best_q = lq;
+                }
+            }
+        }
+        n_ids = h1;
+        if (use_exit && best_c > 0) {
+            double f = (double)best_c / (double)m;
+            double fn = f;
+            for (int k = 1; k < p->sample_size; ++k) fn = fn * f;
+            double kk = log(1.0 - (double)p->confidence) / log(1.0 - fn);
+            if ((double)h1 >= kk) break;
         }
     }
     for (int k = 0; k < 16; ++k) T_best[k] = (k % 5 == 0) ? 1.0 : 0.0;
     if (best_h >= 0) hypothesis_T(src, tgt, m, p, (uint64_t)best_h, T_best, NULL);
-    res->best_h = best_h; res->best_count = best_c; res->best_ssq = best_q; res->n_valid = n_valid;
+    res->best_h = best_h; res->best_count = best_c; res->best_ssq = best_q; res->n_valid = n_valid; res->n_ids = n_ids;
 }
 
 /* --------------------------------------------------------------- refit ---- */

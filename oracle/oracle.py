@@ -33,12 +33,13 @@ c_i32p = ctypes.POINTER(ctypes.c_int32)
 
 class RansacParams(ctypes.Structure):
     _fields_ = [("sample_size", ctypes.c_int32), ("use_elc", ctypes.c_int32),
-                ("thr2", ctypes.c_float), ("iters", ctypes.c_int32), ("seed", ctypes.c_uint64)]
+                ("thr2", ctypes.c_float), ("iters", ctypes.c_int32), ("seed", ctypes.c_uint64),
+                ("confidence", ctypes.c_float), ("batch", ctypes.c_int32)]
 
 
 class RansacResult(ctypes.Structure):
     _fields_ = [("best_h", ctypes.c_int64), ("best_count", ctypes.c_uint32),
-                ("best_ssq", ctypes.c_uint64), ("n_valid", ctypes.c_int64)]
+                ("best_ssq", ctypes.c_uint64), ("n_valid", ctypes.c_int64), ("n_ids", ctypes.c_int64)]
 
 
 def build(force=False):
@@ -281,8 +282,8 @@ def philox(seed, h):
 
 # ----------------------------------------------------------------------------- RANSAC (a10) + refit (a11)
 
-def _params(sample_size, use_elc, thr, iters, seed):
-    return RansacParams(sample_size, int(use_elc), np.float32(float(thr) * float(thr)), iters, seed)
+def _params(sample_size, use_elc, thr, iters, seed, confidence=1.0, batch=0):
+    return RansacParams(sample_size, int(use_elc), np.float32(float(thr) * float(thr)), iters, seed, confidence, batch)
 
 
 def hypothesis(src, tgt, h, sample_size=3, use_elc=True, thr=0.6, seed=51):
@@ -303,14 +304,14 @@ def score(src, tgt, T, thr=0.6):
     return c.value, q.value
 
 
-def ransac(src, tgt, iters, sample_size=3, use_elc=True, thr=0.6, seed=51):
+def ransac(src, tgt, iters, sample_size=3, use_elc=True, thr=0.6, seed=51, confidence=1.0, batch=0):
     """RANSAC over M correspondences src[i] <-> tgt[i].  Returns (T 4x4 float64, info dict)."""
     src, tgt = _f32(src), _f32(tgt)
     T = np.empty(16, np.float64)
-    p = _params(sample_size, use_elc, thr, iters, seed)
+    p = _params(sample_size, use_elc, thr, iters, seed, confidence, batch)
     r = RansacResult()
     lib().orc_ransac(_p(src, c_f32p), _p(tgt, c_f32p), src.shape[0], ctypes.byref(p), _p(T, c_f64p), ctypes.byref(r))
-    return T.reshape(4, 4), dict(best_h=r.best_h, best_count=r.best_count, best_ssq=r.best_ssq, n_valid=r.n_valid)
+    return T.reshape(4, 4), dict(best_h=r.best_h, best_count=r.best_count, best_ssq=r.best_ssq, n_valid=r.n_valid, n_ids=r.n_ids)
 
 
 def refit(xyz0, xyz1, idx1, T, thr=0.6):
@@ -340,7 +341,7 @@ def translation_error_cm(T, T_gt):
 # ----------------------------------------------------------------------------- whole pair (a9)
 
 def register_pair(xyz0, xyz1, feats0, feats1, mode="MNN", iters=50000, sample_size=3, use_elc=True,
-                  thr=0.6, seed=51, args=None, refit_on_orig=True):
+                  thr=0.6, seed=51, args=None, refit_on_orig=True, confidence=1.0, batch=0):
     """FR.py:16-119 with the open3D-codebase ordering: NN -> filter -> RANSAC -> LS refit on the
     original NN pairs.  Returns dict(T, idx0, idx1, idx1_orig, ransac=info)."""
     idx0, idx1, idx2, _ = find_2nn(feats0, feats1)
@@ -354,7 +355,7 @@ def register_pair(xyz0, xyz1, feats0, feats1, mode="MNN", iters=50000, sample_si
     else:
         raise AssertionError("unknown mode")
     src = _f32(xyz0)[f0]; tgt = _f32(xyz1)[f1]
-    T, info = ransac(src, tgt, iters, sample_size, use_elc, thr, seed)
+    T, info = ransac(src, tgt, iters, sample_size, use_elc, thr, seed, confidence, batch)
     n_ref = 0
     if refit_on_orig and info["best_h"] >= 0:
         T, n_ref = refit(xyz0, xyz1, idx1_orig, T, thr)

@@ -31,5 +31,5 @@ class Args:
     def __init__(self, **kw):
         self.mode = "MNN"; self.codebase = "open3D"; self.iters = 50000; self.prosac = False
         self.GPF_grid_wid = 10; self.GPF_factor = 2.0; self.GPF_max_matches = 10 ** 9
-        self.spatial_coherence_weight = 0.0; self.GC_conf = 0.999; self.fast_rejection = "ELC"; self.GC_LO = True
+        self.spatial_coherence_weight = 0.0; self.GC_conf = 0.999; self.o3d_conf = 0.9995; self.fast_rejection = "ELC"; self.GC_LO = True
         self.__dict__.update(kw)

@@ -34,11 +34,11 @@ def test_version_and_error_string(libpath):
 
 def test_struct_layouts_match_header():
     # sizes the C side static-asserts implicitly through its field order (include/lidarreg.h)
-    assert ctypes.sizeof(_ext.RansacParams) == 24
-    assert ctypes.sizeof(_ext.RansacResult) == 32
-    assert ctypes.sizeof(_ext.PairResult) == 336
-    assert ctypes.sizeof(_ext.PairParams) == 56
-    assert _ext.PairParams.ransac.offset == 8 and _ext.PairParams.gpf_factor.offset == 40
+    assert ctypes.sizeof(_ext.RansacParams) == 32
+    assert ctypes.sizeof(_ext.RansacResult) == 40
+    assert ctypes.sizeof(_ext.PairResult) == 344
+    assert ctypes.sizeof(_ext.PairParams) == 64
+    assert _ext.PairParams.ransac.offset == 8 and _ext.PairParams.gpf_factor.offset == 48
 
 
 def test_bad_arguments_are_reported_not_crashed(libpath):
@@ -67,6 +67,7 @@ def test_mode_aliases_and_defaults():
     from tests.conftest import Args
     p = fr.pair_params(Args(mode="MMN", codebase="GC", iters=None))
     assert p.mode == _ext.LR_MODE_MNN and p.ransac.iters == 500000 and p.ransac.sample_size == 3 and p.ransac.use_elc == 1
+    assert abs(p.ransac.confidence - 0.999) < 1e-6
     p = fr.pair_params(Args(mode="GPF", codebase="open3D", iters=1000, GPF_factor=0.5, GPF_grid_wid=4))
     assert p.mode == _ext.LR_MODE_GPF and p.ransac.sample_size == 4 and p.gpf_factor == 0.5 and p.gpf_grid_wid == 4
     assert abs(p.refit_thr2 - 0.36) < 1e-15 and abs(p.ransac.thr2 - 0.36) < 1e-7

@@ -223,7 +223,7 @@ def test_FR_matches_oracle_pipeline(lr, oracle, mode, codebase, N, iters):
     T, elapsed, pcd0, pcd1, n_init, ir_init, n_filt, ir_filt = lr.FR.FR(t(p["xyz0"]), t(p["xyz1"]), t(p["feats0"]), t(p["feats1"]), a, p["T_gt"])
     ns = 3 if codebase == "GC" else 4
     e = oracle.register_pair(p["xyz0"], p["xyz1"], p["feats0"], p["feats1"], mode=mode, iters=iters, sample_size=ns,
-                             use_elc=True, seed=51, args=a)
+                             use_elc=True, seed=51, args=a, confidence=a.GC_conf if codebase == "GC" else a.o3d_conf)
     assert n_init == N and n_filt == len(e["idx0"])
     # contract: <= 1e-4 rad rotation, <= 1e-3 m translation on identical correspondence inputs
     assert np.radians(oracle.rotation_error_deg(T, e["T"])) <= 1e-4
@@ -239,7 +239,7 @@ def test_FR_matches_oracle_pipeline(lr, oracle, mode, codebase, N, iters):
 def test_FR_full_size_config2(lr, oracle):
     """BASELINE config #2: 30k-pt pair, MNN, 50k iterations -- whole pipeline against the oracle."""
     p = synth.make_pair(N=30000, seed=51)
-    a = Args(mode="MNN", codebase="open3D", iters=50000, ransac_n=3)
+    a = Args(mode="MNN", codebase="open3D", iters=50000, ransac_n=3, o3d_conf=1.0)      # all 50k hypotheses, as bench.py
     t = lr.torch.from_numpy
     T, elapsed, *_rest = lr.FR.FR(t(p["xyz0"]), t(p["xyz1"]), t(p["feats0"]), t(p["feats1"]), a, p["T_gt"])
     e = oracle.register_pair(p["xyz0"], p["xyz1"], p["feats0"], p["feats1"], mode="MNN", iters=50000, sample_size=3, seed=51)
@@ -324,9 +324,20 @@ def test_FR_gpf_full_size(lr, oracle):
     a = Args(mode="GPF", codebase="GC", iters=20000, GPF_factor=0.5)
     t = lr.torch.from_numpy
     T, elapsed, _, _, n_init, _, n_filt, _ = lr.FR.FR(t(p["xyz0"]), t(p["xyz1"]), t(p["feats0"]), t(p["feats1"]), a, p["T_gt"])
-    e = oracle.register_pair(p["xyz0"], p["xyz1"], p["feats0"], p["feats1"], mode="GPF", iters=20000, sample_size=3, seed=51, args=a)
+    e = oracle.register_pair(p["xyz0"], p["xyz1"], p["feats0"], p["feats1"], mode="GPF", iters=20000, sample_size=3, seed=51, args=a,
+                             confidence=a.GC_conf)
     assert n_filt == len(e["idx0"]) and n_filt < n_init
     assert np.radians(oracle.rotation_error_deg(T, e["T"])) <= 1e-4 and oracle.translation_error_cm(T, e["T"]) / 100 <= 1e-3
+
+
+@pytest.mark.parametrize("conf,batch", [(0.999, 0), (0.999, 1024), (0.9, 512), (0.999999, 2048)])
+def test_ransac_confidence_early_exit_matches_oracle(lr, oracle, conf, batch):
+    src, tgt, T_gt = _planted(n=6000, inlier=0.3, seed=31)
+    T, info = lr.ransac.ransac_dev(src, tgt, 50000, seed=3, confidence=conf, batch=batch)
+    Te, einfo = oracle.ransac(src, tgt, 50000, seed=3, confidence=conf, batch=batch)
+    assert info == einfo and np.array_equal(T, Te)
+    assert info["n_ids"] < 50000 and info["n_ids"] % (batch or 8192) == 0           # stopped at a batch boundary
+    assert oracle.rotation_error_deg(T, T_gt) < 1.0
 
 
 def test_ransac_iteration_property_more_iters_never_worse(lr):
