@@ -117,6 +117,15 @@ LR_API int lr_gpf(lr_workspace *ws, const float *F0, int n0, const float *F1, in
                   int32_t *out_idx0, int32_t *out_idx1, int32_t *out_idx2, float *out_score,
                   int32_t *n_out, void *stream);
 
+/* ---- a7, BB_first=True  (matching.py:109-113,126; the reference's TEASER wrapper, TEASER_plus_plus.py:109-110) ----
+ * Mutual pairs first, then the grid filter over them with TOTAL_NUM = max_matches and no best-buddy shift.
+ * *has_score (device int32) is 0 when the mutual set was already <= max_matches (the reference returns None). */
+LR_API int lr_gpf_bb_first(lr_workspace *ws, const float *F0, int n0, const float *F1, int n1, int dim,
+                           const int32_t *idx1, const int32_t *idx2, const float *xyz0,
+                           int grid_wid, double max_matches,
+                           int32_t *out_idx0, int32_t *out_idx1, int32_t *out_idx2, float *out_score,
+                           int32_t *n_out, int32_t *has_score, void *stream);
+
 /* ---- a10/a12: RANSAC over M correspondences src[i] <-> tgt[i]  ([M,3] float32 each) ---------------
  * Replaces pygcransac.findRigidTransform(x1y1z1, x2y2z2, ...) (GC_RANSAC.py:46-49; native side
  * gcransac_python.cpp:404-416) and o3d registration_ransac_based_on_correspondence (FR.py:128-137).

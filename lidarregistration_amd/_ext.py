@@ -15,7 +15,7 @@ LR_MODE_NO_FILTER, LR_MODE_MNN, LR_MODE_GPF = 0, 1, 2
 
 SYMBOLS = [
     "lr_version", "lr_last_error", "lr_workspace_create", "lr_workspace_destroy", "lr_workspace_bytes",
-    "lr_nn_top2", "lr_nn_to_mutual", "lr_feat_ratio", "lr_gpf", "lr_ransac", "lr_refit", "lr_kabsch",
+    "lr_nn_top2", "lr_nn_to_mutual", "lr_feat_ratio", "lr_gpf", "lr_gpf_bb_first", "lr_ransac", "lr_refit", "lr_kabsch",
     "lr_register_pair", "lr_workspace_lists", "lr_workspace_timing", "lr_workspace_timing_read",
 ]
 
@@ -83,6 +83,7 @@ def lib():
         L.lr_nn_to_mutual.argtypes = [vp, vp, ci, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp]
         L.lr_feat_ratio.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp, vp]
         L.lr_gpf.argtypes = [vp, vp, ci, vp, ci, ci, vp, vp, vp, ci, ctypes.c_double, vp, vp, vp, vp, vp, vp]
+        L.lr_gpf_bb_first.argtypes = [vp, vp, ci, vp, ci, ci, vp, vp, vp, ci, ctypes.c_double, vp, vp, vp, vp, vp, vp, vp]
         L.lr_ransac.argtypes = [vp, vp, vp, ci, vp, ctypes.POINTER(RansacParams), vp, vp, vp]
         L.lr_refit.argtypes = [vp, vp, ci, vp, vp, vp, ctypes.c_double, vp, vp, vp]
         L.lr_kabsch.argtypes = [vp, vp, vp, ci, vp, vp]

@@ -241,6 +241,23 @@ extern "C" int lr_gpf(lr_workspace *ws, const float *F0, int n0, const float *F1
     return lr_gpf_run(ws, F0, n0, F1, dim, idx1, idx2, ws->is_bb, xyz0, grid_wid, factor, o0, o1, o2, oscore, n_out, st);
 }
 
+// a7, BB_first=True: mutual pairs first, then the grid filter over them with TOTAL_NUM = max_matches
+extern "C" int lr_gpf_bb_first(lr_workspace *ws, const float *F0, int n0, const float *F1, int n1, int dim,
+                               const int32_t *idx1, const int32_t *idx2, const float *xyz0, int grid_wid, double max_matches,
+                               int32_t *o0, int32_t *o1, int32_t *o2, float *oscore, int32_t *n_out, int32_t *has_score,
+                               void *stream)
+{
+    LR_TRY(check_nn_args(ws, F0, n0, F1, n1, dim, "lr_gpf_bb_first"));
+    LR_REQUIRE(idx1 && idx2 && xyz0 && o0 && o1 && o2 && n_out && has_score, LR_EINVAL, "lr_gpf_bb_first: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    int32_t *mb_dev = ws->counters + LR_CNT_NCORR;
+    LR_TRY(prep_both(ws, F0, n0, F1, n1, st));
+    LR_TRY(nn_reverse(ws, F0, n0, F1, n1, idx1, ws->rev_idx1, st));
+    LR_TRY(lr_mutual_run(ws, n0, idx1, idx2, ws->rev_idx1, ws->is_bb, ws->corr_idx0, ws->corr_idx1, ws->corr_idx2, mb_dev, st));
+    return lr_gpf_bb_run(ws, F0, n0, F1, dim, ws->corr_idx0, ws->corr_idx1, ws->corr_idx2, mb_dev, xyz0, grid_wid, max_matches,
+                         o0, o1, o2, oscore, n_out, has_score, st);
+}
+
 // ------------------------------------------------------------------ a10/a12
 extern "C" int lr_ransac(lr_workspace *ws, const float *src, const float *tgt, int m, const int32_t *m_dev,
                          const lr_ransac_params *p, double *T_out, lr_ransac_result *res, void *stream)

@@ -35,8 +35,9 @@ mutual_flag_kernel(int n0, const int32_t *__restrict__ idx1, const int32_t *__re
 }
 
 __global__ void __launch_bounds__(256)
-count_flags_kernel(int n0, const uint8_t *__restrict__ flags, int32_t *__restrict__ blk_cnt)
+count_flags_kernel(int n0, const int32_t *__restrict__ m_dev, const uint8_t *__restrict__ flags, int32_t *__restrict__ blk_cnt)
 {
+    if (m_dev) n0 = min(n0, *m_dev);
     const int i = blockIdx.x * 256 + threadIdx.x;
     block_count(i < n0 && flags[i] != 0, blk_cnt);
 }
@@ -47,10 +48,12 @@ compact_kernel(int n0, const uint8_t *__restrict__ flags, const int32_t *__restr
                const int32_t *__restrict__ idx1, const int32_t *__restrict__ idx2, const float *__restrict__ score,
                int32_t *__restrict__ o0, int32_t *__restrict__ o1, int32_t *__restrict__ o2, float *__restrict__ oscore,
                int32_t *__restrict__ n_out, int32_t *__restrict__ n_out2,
-               const float *__restrict__ xyz0, const float *__restrict__ xyz1, float *__restrict__ corr8, int32_t *__restrict__ counters)
+               const float *__restrict__ xyz0, const float *__restrict__ xyz1, float *__restrict__ corr8, int32_t *__restrict__ counters,
+               const int32_t *__restrict__ m_dev = nullptr, const int32_t *__restrict__ src0 = nullptr)
 {
     __shared__ int s_wave[4];
     __shared__ int s_part[4];
+    if (m_dev) n0 = min(n0, *m_dev);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int c = 0;
     for (int b = tid; b < (int)blockIdx.x; b += 256) c += blk_cnt[b];
@@ -66,7 +69,7 @@ compact_kernel(int n0, const uint8_t *__restrict__ flags, const int32_t *__restr
     for (int w = 0; w < wave; ++w) woff += s_wave[w];
     const int slot = prefix + woff + __popcll(bal & ((1ull << lane) - 1ull));
     if (k) {
-        if (o0) o0[slot] = i;
+        if (o0) o0[slot] = src0 ? src0[i] : i;
         if (o1) o1[slot] = idx1[i];
         if (o2 && idx2) o2[slot] = idx2[i];
         if (oscore && score) oscore[slot] = score[i];
@@ -207,12 +210,15 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // min/max of the ratio and of x,y over the n0 pairs (one block; n0 is a few 1e4)
 __global__ void __launch_bounds__(1024)
-gpf_minmax_kernel(int n0, const float *__restrict__ ratio, const float *__restrict__ xyz0, float *__restrict__ gf)
+gpf_minmax_kernel(int n0, const float *__restrict__ ratio, const float *__restrict__ xyz0, float *__restrict__ gf,
+                  const int32_t *__restrict__ m_dev = nullptr, const int32_t *__restrict__ pidx = nullptr)
 {
     __shared__ float sm[6][16];
+    if (m_dev) n0 = min(n0, *m_dev);
     float lo[3] = { LR_INF, LR_INF, LR_INF }, hi[3] = { -LR_INF, -LR_INF, -LR_INF };
     for (int i = threadIdx.x; i < n0; i += 1024) {
-        float v[3] = { ratio[i], xyz0[3 * i], xyz0[3 * i + 1] };
+        const int pi = pidx ? pidx[i] : i;
+        float v[3] = { ratio[i], xyz0[3 * pi], xyz0[3 * pi + 1] };
 #pragma unroll
         for (int k = 0; k < 3; ++k) { lo[k] = fminf(lo[k], v[k]); hi[k] = fmaxf(hi[k], v[k]); }
     }
@@ -234,30 +240,46 @@ gpf_minmax_kernel(int n0, const float *__restrict__ ratio, const float *__restri
 __global__ void __launch_bounds__(256)
 gpf_score_cell_kernel(int n0, int G, const float *__restrict__ gf, const uint8_t *__restrict__ is_bb,
                       const float *__restrict__ xyz0, float *__restrict__ ratio_inout, int32_t *__restrict__ cell,
-                      int32_t *__restrict__ cell_count)
+                      int32_t *__restrict__ cell_count, const int32_t *__restrict__ m_dev = nullptr,
+                      const int32_t *__restrict__ pidx = nullptr)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m_dev) n0 = min(n0, *m_dev);
     if (i >= n0) return;
+    const int pi = pidx ? pidx[i] : i;
     const float m = gf[0], M = gf[1];
     float nfd = ((ratio_inout[i] - m) / (M - m));
-    if (is_bb[i]) nfd = nfd - 1.0f;
+    if (is_bb && is_bb[i]) nfd = nfd - 1.0f;          // BB_first=True has no best-buddy shift (matching.py:126)
     ratio_inout[i] = nfd;
     const float denx = (gf[3] - gf[2]) + 1e-3f, deny = (gf[5] - gf[4]) + 1e-3f;
-    float qx = floorf((float)G * ((xyz0[3 * i] - gf[2]) / (denx)));
-    float qy = floorf((float)G * ((xyz0[3 * i + 1] - gf[4]) / (deny)));
+    float qx = floorf((float)G * ((xyz0[3 * pi] - gf[2]) / (denx)));
+    float qy = floorf((float)G * ((xyz0[3 * pi + 1] - gf[4]) / (deny)));
     int c = (int)qx * G + (int)qy;
     cell[i] = c;
     atomicAdd(&cell_count[c], 1);
 }
 
 // water-filling bisection in fp64 exactly as matching.py:154-179, then exclusive cell offsets; one thread
+// total_fixed >= 0 selects the BB_first=True form: TOTAL = GPF_max_matches, and nothing is filtered (has_score = 0) when
+// the mutual set is already that small (matching.py:109-113)
 __global__ void gpf_waterfill_kernel(int G, double factor, const int32_t *__restrict__ counters,
                                      const int32_t *__restrict__ cell_count, double *__restrict__ quota,
-                                     int32_t *__restrict__ cell_off)
+                                     int32_t *__restrict__ cell_off, double total_fixed = -1.0,
+                                     const int32_t *__restrict__ m_dev = nullptr, int32_t *__restrict__ has_score = nullptr)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const int C = G * G;
-    const double TOTAL = factor * (double)counters[LR_CNT_NBB];
+    const double TOTAL = total_fixed >= 0.0 ? total_fixed : factor * (double)counters[LR_CNT_NBB];
+    if (total_fixed >= 0.0) {
+        const bool keep_all = TOTAL >= (double)*m_dev;
+        if (has_score) *has_score = keep_all ? 0 : 1;
+        if (keep_all) {
+            int off = 0;
+            for (int c = 0; c < C; ++c) { quota[c] = (double)cell_count[c]; cell_off[c] = off; off += cell_count[c]; }
+            cell_off[C] = off;
+            return;
+        }
+    }
     auto total_at = [&](double h) {
         double s = 0.0;
         for (int c = 0; c < C; ++c) { double m = (double)cell_count[c]; s += (m < h) ? m : h; }
@@ -285,9 +307,10 @@ __global__ void gpf_waterfill_kernel(int G, double factor, const int32_t *__rest
 // bucket pair ids by cell (order inside a bucket is irrelevant: ranks below use (score, id))
 __global__ void __launch_bounds__(256)
 gpf_bucket_kernel(int n0, const int32_t *__restrict__ cell, const int32_t *__restrict__ cell_off,
-                  int32_t *__restrict__ cell_fill, int32_t *__restrict__ bucket)
+                  int32_t *__restrict__ cell_fill, int32_t *__restrict__ bucket, const int32_t *__restrict__ m_dev = nullptr)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m_dev) n0 = min(n0, *m_dev);
     if (i >= n0) return;
     int c = cell[i];
     int pos = atomicAdd(&cell_fill[c], 1);
@@ -299,9 +322,11 @@ gpf_bucket_kernel(int n0, const int32_t *__restrict__ cell, const int32_t *__res
 __global__ void __launch_bounds__(256)
 gpf_select_kernel(int n0, const int32_t *__restrict__ cell, const int32_t *__restrict__ cell_off,
                   const int32_t *__restrict__ cell_count, const double *__restrict__ quota,
-                  const int32_t *__restrict__ bucket, const float *__restrict__ score, uint8_t *__restrict__ keep)
+                  const int32_t *__restrict__ bucket, const float *__restrict__ score, uint8_t *__restrict__ keep,
+                  const int32_t *__restrict__ m_dev = nullptr)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m_dev) n0 = min(n0, *m_dev);
     if (i >= n0) return;
     const int c = cell[i];
     const int q = (int)quota[c];
@@ -346,9 +371,41 @@ int lr_gpf_run(lr_workspace *ws, const float *F0, int n0, const float *F1, int d
     hipLaunchKernelGGL(gpf_bucket_kernel, dim3(nb), dim3(256), 0, st, n0, ws->cell, cell_off, cell_fill, ws->cell_sorted);
     hipLaunchKernelGGL(gpf_select_kernel, dim3(nb), dim3(256), 0, st, n0, ws->cell, cell_off, cell_count, quota,
                        ws->cell_sorted, ws->ratio, keep);
-    hipLaunchKernelGGL(count_flags_kernel, dim3(nb), dim3(256), 0, st, n0, keep, ws->blk_cnt);
+    hipLaunchKernelGGL(count_flags_kernel, dim3(nb), dim3(256), 0, st, n0, (const int32_t *)nullptr, keep, ws->blk_cnt);
     hipLaunchKernelGGL(compact_kernel, dim3(nb), dim3(256), 0, st, n0, keep, ws->blk_cnt, idx1, idx2, ws->ratio, o0, o1, o2, oscore,
                        n_out, (int32_t *)nullptr, xyz0, xyz1, corr8, ws->counters);
+    LR_LAUNCH_CHECK();
+    return LR_OK;
+}
+
+// Grid_Prioritized_Filter(BB_first=True) (matching.py:100-205 with :109-113,126): the filter runs over the MUTUAL pairs
+// (b0,b1,b2 of live length *mb_dev), TOTAL_NUM = GPF_max_matches, no best-buddy shift.  Used by the reference's TEASER
+// wrapper only (TEASER_plus_plus.py:109-110).
+int lr_gpf_bb_run(lr_workspace *ws, const float *F0, int n0, const float *F1, int dim,
+                  const int32_t *b0, const int32_t *b1, const int32_t *b2, const int32_t *mb_dev, const float *xyz0,
+                  int G, double max_matches, int32_t *o0, int32_t *o1, int32_t *o2, float *oscore,
+                  int32_t *n_out, int32_t *has_score, hipStream_t st)
+{
+    LR_REQUIRE(G >= 1 && G <= 64, LR_EINVAL, "lr_gpf: grid width must be in [1,64]");
+    int32_t *cell_count = ws->gpf_cells;
+    int32_t *cell_fill = cell_count + LR_GPF_MAX_CELLS + 8;
+    int32_t *cell_off = cell_fill + LR_GPF_MAX_CELLS + 8;
+    double *quota = ws->gpf_quota;
+    uint8_t *keep = ws->gpf_keep;
+    const int nb = lr_cdiv(n0, 256);
+    LR_HIP(hipMemsetAsync(cell_count, 0, sizeof(int32_t) * 2 * (LR_GPF_MAX_CELLS + 8), st));
+    hipLaunchKernelGGL(ratio_kernel, dim3(nb), dim3(256), 0, st, F0, F1, dim, n0, mb_dev, b0, b1, b2, ws->ratio);
+    hipLaunchKernelGGL(gpf_minmax_kernel, dim3(1), dim3(1024), 0, st, n0, ws->ratio, xyz0, ws->gpf_f, mb_dev, b0);
+    hipLaunchKernelGGL(gpf_score_cell_kernel, dim3(nb), dim3(256), 0, st, n0, G, ws->gpf_f, (const uint8_t *)nullptr, xyz0, ws->ratio,
+                       ws->cell, cell_count, mb_dev, b0);
+    hipLaunchKernelGGL(gpf_waterfill_kernel, dim3(1), dim3(64), 0, st, G, 0.0, ws->counters, cell_count, quota, cell_off, max_matches,
+                       mb_dev, has_score);
+    hipLaunchKernelGGL(gpf_bucket_kernel, dim3(nb), dim3(256), 0, st, n0, ws->cell, cell_off, cell_fill, ws->cell_sorted, mb_dev);
+    hipLaunchKernelGGL(gpf_select_kernel, dim3(nb), dim3(256), 0, st, n0, ws->cell, cell_off, cell_count, quota,
+                       ws->cell_sorted, ws->ratio, keep, mb_dev);
+    hipLaunchKernelGGL(count_flags_kernel, dim3(nb), dim3(256), 0, st, n0, mb_dev, keep, ws->blk_cnt);
+    hipLaunchKernelGGL(compact_kernel, dim3(nb), dim3(256), 0, st, n0, keep, ws->blk_cnt, b1, b2, ws->ratio, o0, o1, o2, oscore,
+                       n_out, (int32_t *)nullptr, (const float *)nullptr, (const float *)nullptr, (float *)nullptr, ws->counters, mb_dev, b0);
     LR_LAUNCH_CHECK();
     return LR_OK;
 }

@@ -141,6 +141,11 @@ int lr_gpf_run(lr_workspace *ws, const float *F0, int n0, const float *F1, int d
                int grid_wid, double factor, int32_t *o0, int32_t *o1, int32_t *o2, float *oscore,
                int32_t *n_out, hipStream_t st, const float *xyz1 = nullptr, float *corr8 = nullptr);
 
+int lr_gpf_bb_run(lr_workspace *ws, const float *F0, int n0, const float *F1, int dim,
+                  const int32_t *b0, const int32_t *b1, const int32_t *b2, const int32_t *mb_dev, const float *xyz0,
+                  int G, double max_matches, int32_t *o0, int32_t *o1, int32_t *o2, float *oscore,
+                  int32_t *n_out, int32_t *has_score, hipStream_t st);
+
 // lr_ransac.hip
 int lr_ransac_run(lr_workspace *ws, const float *corr8, int m_max, const int32_t *m_dev, const lr_ransac_params *p,
                   double *T_out, lr_ransac_result *res, hipStream_t st);

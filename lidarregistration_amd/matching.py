@@ -137,10 +137,7 @@ def calc_distance_ratio_in_feature_space(fcgf_feats0, fcgf_feats1, corres_idx0, 
 
 
 def Grid_Prioritized_Filter(fcgf_feats0, fcgf_feats1, corres_idx0, corres_idx1, idx1_2nd, xyz0, args, BB_first=False):
-    """matching.py:100-205.  ``BB_first=True`` (used only by the reference's TEASER wrapper) is not on the
-    RANSAC path and is not implemented on device."""
-    if BB_first:
-        raise NotImplementedError("Grid_Prioritized_Filter(BB_first=True) is outside the RANSAC hot path")
+    """matching.py:100-205, both forms (``BB_first=True`` is what the reference's TEASER wrapper calls)."""
     F0, F1 = _f32(fcgf_feats0), _f32(fcgf_feats1)
     i1, i2 = _i32(corres_idx1), _i32(idx1_2nd)
     xyz = _f32(xyz0)
@@ -149,11 +146,19 @@ def Grid_Prioritized_Filter(fcgf_feats0, fcgf_feats1, corres_idx0, corres_idx1, 
     dev = F0.device
     o0 = torch.empty(n0, dtype=torch.int32, device=dev); o1 = torch.empty_like(o0); o2 = torch.empty_like(o0)
     sc = torch.empty(n0, dtype=torch.float32, device=dev)
-    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    cnt = torch.zeros(2, dtype=torch.int32, device=dev)
+    if BB_first:
+        _ext.check(_ext.lib().lr_gpf_bb_first(ws.handle, F0.data_ptr(), n0, F1.data_ptr(), n1, d, i1.data_ptr(), i2.data_ptr(),
+                                               xyz.data_ptr(), int(args.GPF_grid_wid), float(args.GPF_max_matches),
+                                               o0.data_ptr(), o1.data_ptr(), o2.data_ptr(), sc.data_ptr(), cnt.data_ptr(),
+                                               cnt[1:].data_ptr(), _stream()))
+        m, has_score = [int(v) for v in cnt.cpu()]
+        return (o0[:m].long().cpu(), o1[:m].long().cpu(), o2[:m].long().cpu(),
+                corres_idx0, corres_idx1, idx1_2nd, sc[:m] if has_score else None)
     _ext.check(_ext.lib().lr_gpf(ws.handle, F0.data_ptr(), n0, F1.data_ptr(), n1, d, i1.data_ptr(), i2.data_ptr(),
                                   xyz.data_ptr(), int(args.GPF_grid_wid), float(args.GPF_factor),
                                   o0.data_ptr(), o1.data_ptr(), o2.data_ptr(), sc.data_ptr(), cnt.data_ptr(), _stream()))
-    m = int(cnt.item())
+    m = int(cnt[0].item())
     return (o0[:m].long().cpu(), o1[:m].long().cpu(), o2[:m].long().cpu(),
             corres_idx0, corres_idx1, idx1_2nd, sc[:m])
 

@@ -144,6 +144,19 @@ def test_gpf_golden(lr, oracle, filt, k):
     assert np.array_equal(_bits(out[6].cpu().numpy()), _bits(e[6]))
 
 
+@pytest.mark.parametrize("k", [0, 1, 2])
+def test_gpf_bb_first_golden(lr, filt, k):
+    g = filt["g"]
+    a = Args(GPF_max_matches=int(g[f"gpfbb{k}_cap"]))
+    t = lr.torch.from_numpy
+    out = lr.matching.Grid_Prioritized_Filter(t(filt["F0"]), t(filt["F1"]), t(filt["i0"]), t(filt["i1"]), t(filt["i2"]),
+                                              t(filt["xyz0"]), a, BB_first=True)
+    assert np.array_equal(out[0].numpy(), g[f"gpfbb{k}_idx0"]) and np.array_equal(out[1].numpy(), g[f"gpfbb{k}_idx1"])
+    assert (out[6] is not None) == bool(g[f"gpfbb{k}_has_score"])
+    if out[6] is not None:
+        np.testing.assert_allclose(out[6].cpu().numpy(), g[f"gpfbb{k}_score"], rtol=0, atol=3e-6)
+
+
 @pytest.mark.parametrize("factor,wid,seed", [(0.3, 10, 41), (0.05, 3, 42), (1.5, 16, 43)])
 def test_gpf_vs_oracle(lr, oracle, factor, wid, seed):
     n0, n1 = 4000, 3500
