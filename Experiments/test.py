@@ -61,6 +61,7 @@ def get_args(argv=None):
     p.add_argument("--synthetic_n", type=int, default=30000, help="synthetic: points per cloud")
     p.add_argument("--seed", type=int, default=51)
     p.add_argument("--in_flight", type=int, default=4, help="pairs in flight per GPU")
+    p.add_argument("--icp", type=str2bool, default=True, help="refine by point-to-point ICP and fill stats columns 11-14 (test.py:183-193)")
     p.add_argument("--o3d_conf", type=float, default=0.9995, help="confidence of the open3D codebase (FR.py:136)")
     args = p.parse_args(argv)
     args.start_time, args.tmp_file_base, args.world_size, args.rank, args.do_analysis = start_time, tmp_file_base, world_size, rank, do_analysis

@@ -57,7 +57,15 @@ typedef struct lr_ransac_result {
     int64_t  n_ids;         /* hypothesis ids examined before the run stopped (== iters without early exit) */
 } lr_ransac_result;
 
-/* Per-pair result block of lr_register_pair (device memory, 344 bytes). */
+/* Written by lr_icp / lr_register_pair(icp != 0). */
+typedef struct lr_icp_result {
+    double   fitness;       /* correspondences within max_dist / source points, last evaluation       */
+    double   inlier_rmse;   /* sqrt(mean squared distance) over those correspondences                  */
+    int32_t  n_corr;
+    int32_t  iterations;    /* transform updates applied                                               */
+} lr_icp_result;
+
+/* Per-pair result block of lr_register_pair (device memory, 496 bytes). */
 typedef struct lr_pair_result {
     double   T[16];         /* final transform (after the LS refit when refit != 0)                   */
     double   T_ransac[16];  /* winning minimal-sample model before the refit                          */
@@ -67,6 +75,8 @@ typedef struct lr_pair_result {
     int32_t  n_nn_fixed;    /* NN rows/cols that needed the exact sqrt tie-break path                 */
     int32_t  status;        /* 0 ok, 1 = no valid hypothesis (T = identity, GC_RANSAC.py:51-52)       */
     int32_t  reserved[8];
+    double   T_icp[16];     /* T refined by point-to-point ICP (test.py:183-189) when icp != 0, else = T */
+    lr_icp_result icp;
 } lr_pair_result;
 
 typedef struct lr_pair_params {
@@ -75,7 +85,7 @@ typedef struct lr_pair_params {
     lr_ransac_params ransac;
     /* GPF (matching.py:100-205), only read when mode == LR_MODE_GPF */
     int32_t  gpf_grid_wid;  /* --GPF_grid_wid, default 10                                            */
-    int32_t  pad0;
+    int32_t  icp;           /* 1: refine T by ICP (max distance 0.6 m, 30 updates, 1e-6 criteria; test.py:183-189) */
     double   gpf_factor;    /* --GPF_factor,   default 2.0 (a Python float in the reference)         */
     double   refit_thr2;    /* fp64 squared threshold of the refit's inlier test, (2*0.3)**2 (FR.py:105) */
 } lr_pair_params;
@@ -136,6 +146,13 @@ LR_API int lr_ransac(lr_workspace *ws, const float *src, const float *tgt, int m
 /* ---- a11: LS refit on the original NN pairs within thr of T_in  (FR.py:99-111) -------------------- */
 LR_API int lr_refit(lr_workspace *ws, const float *xyz0, int n0, const float *xyz1, const int32_t *idx1,
                     const double *T_in, double thr2, double *T_out, int32_t *n_inliers, void *stream);
+
+/* ---- f1: point-to-point ICP refinement (Experiments/test.py:183-189; Open3D registration_icp) ---------------
+ * src = xyz0 [n0,3], tgt = xyz1 [n1,3] float32, T_init[16] device float64.  Open3D defaults: max_iter 30,
+ * rel_fitness = rel_rmse = 1e-6.                                                                   */
+LR_API int lr_icp(lr_workspace *ws, const float *xyz0, int n0, const float *xyz1, int n1, const double *T_init,
+                  double max_dist, int max_iter, double rel_fitness, double rel_rmse,
+                  double *T_out, lr_icp_result *res, void *stream);
 
 /* ---- a13: least-squares rigid fit of n point pairs  (models/common.py:7-45) -------------------------
  * P, Q [n,3] float64, optional weights w [n]; T_out[16].                                           */

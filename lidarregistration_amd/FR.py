@@ -2,7 +2,7 @@
 
 Same positional signature and 8-tuple as FR.py:16,119.  The whole pair (NN -> filter -> RANSAC ->
 refit) runs as ONE call into the C ABI (``lr_register_pair``) with no host synchronisation until the
-344-byte result block is read back.
+496-byte result block is read back.
 """
 import ctypes
 from time import time
@@ -57,11 +57,12 @@ def pair_params(args):
     p.gpf_grid_wid = int(getattr(args, "GPF_grid_wid", 10))
     p.gpf_factor = float(getattr(args, "GPF_factor", 2.0))
     p.refit_thr2 = thr ** 2                                            # FR.py:105, fp64
+    p.icp = int(getattr(args, "icp", False))                           # the harness' ICP stage (test.py:183-189), off inside FR()
     return p
 
 
 def register_pair_dev(xyz0, xyz1, feats0, feats1, params, out=None, ws=None, stream=None):
-    """Enqueue one pair; returns the device result buffer (uint8[344]).  No synchronisation."""
+    """Enqueue one pair; returns the device result buffer (uint8[496]).  No synchronisation."""
     n0, n1, d = feats0.shape[0], feats1.shape[0], feats0.shape[1]
     if ws is None:
         ws = workspace(n0, n1, params.ransac.iters, d)

@@ -15,7 +15,7 @@ LR_MODE_NO_FILTER, LR_MODE_MNN, LR_MODE_GPF = 0, 1, 2
 
 SYMBOLS = [
     "lr_version", "lr_last_error", "lr_workspace_create", "lr_workspace_destroy", "lr_workspace_bytes",
-    "lr_nn_top2", "lr_nn_to_mutual", "lr_feat_ratio", "lr_gpf", "lr_gpf_bb_first", "lr_ransac", "lr_refit", "lr_kabsch",
+    "lr_nn_top2", "lr_nn_to_mutual", "lr_feat_ratio", "lr_gpf", "lr_gpf_bb_first", "lr_ransac", "lr_refit", "lr_icp", "lr_kabsch",
     "lr_register_pair", "lr_workspace_lists", "lr_workspace_timing", "lr_workspace_timing_read",
 ]
 
@@ -34,19 +34,24 @@ class RansacResult(ctypes.Structure):
                 ("best_ssq", ctypes.c_uint64), ("n_valid", ctypes.c_int64), ("n_ids", ctypes.c_int64)]
 
 
+class IcpResult(ctypes.Structure):
+    _fields_ = [("fitness", ctypes.c_double), ("inlier_rmse", ctypes.c_double), ("n_corr", ctypes.c_int32),
+                ("iterations", ctypes.c_int32)]
+
+
 class PairResult(ctypes.Structure):
     _fields_ = [("T", ctypes.c_double * 16), ("T_ransac", ctypes.c_double * 16), ("ransac", RansacResult),
                 ("n_corr", ctypes.c_int32), ("n_refit", ctypes.c_int32), ("n_nn_fixed", ctypes.c_int32),
-                ("status", ctypes.c_int32), ("reserved", ctypes.c_int32 * 8)]
+                ("status", ctypes.c_int32), ("reserved", ctypes.c_int32 * 8), ("T_icp", ctypes.c_double * 16), ("icp", IcpResult)]
 
 
 class PairParams(ctypes.Structure):
     _fields_ = [("mode", ctypes.c_int32), ("refit", ctypes.c_int32), ("ransac", RansacParams),
-                ("gpf_grid_wid", ctypes.c_int32), ("pad0", ctypes.c_int32), ("gpf_factor", ctypes.c_double),
+                ("gpf_grid_wid", ctypes.c_int32), ("icp", ctypes.c_int32), ("gpf_factor", ctypes.c_double),
                 ("refit_thr2", ctypes.c_double)]
 
 
-assert ctypes.sizeof(PairResult) == 344, ctypes.sizeof(PairResult)
+assert ctypes.sizeof(PairResult) == 496, ctypes.sizeof(PairResult)
 
 _lib = None
 
@@ -86,6 +91,7 @@ def lib():
         L.lr_gpf_bb_first.argtypes = [vp, vp, ci, vp, ci, ci, vp, vp, vp, ci, ctypes.c_double, vp, vp, vp, vp, vp, vp, vp]
         L.lr_ransac.argtypes = [vp, vp, vp, ci, vp, ctypes.POINTER(RansacParams), vp, vp, vp]
         L.lr_refit.argtypes = [vp, vp, ci, vp, vp, vp, ctypes.c_double, vp, vp, vp]
+        L.lr_icp.argtypes = [vp, vp, ci, vp, ci, vp, ctypes.c_double, ci, ctypes.c_double, ctypes.c_double, vp, vp, vp]
         L.lr_kabsch.argtypes = [vp, vp, vp, ci, vp, vp]
         L.lr_register_pair.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ctypes.POINTER(PairParams), vp, vp]
         L.lr_workspace_lists.argtypes = [vp, ci, vp, vp, vp, vp, vp]

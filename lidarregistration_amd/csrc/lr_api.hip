@@ -68,6 +68,9 @@ void carve(lr_workspace *ws, Carver &c)
     ws->score_cnt = c.take<uint32_t>(it);
     ws->score_ssq = c.take<unsigned long long>(it);
     ws->refit_part = c.take<double>((n0 / 256 + 2) * 16);
+    ws->icp_ints = c.take<int32_t>(3 * (32768 + 8));
+    ws->icp_bucket = c.take<int32_t>(n1); ws->icp_sorted = c.take<int32_t>(n1);
+    ws->icp_state = c.take<double>(32); ws->icp_part = c.take<double>((n0 / 256 + 2) * 18);
     ws->res_tmp = c.take<lr_ransac_result>(1);
     ws->T_tmp = c.take<double>(32);
 }
@@ -278,6 +281,25 @@ extern "C" int lr_refit(lr_workspace *ws, const float *xyz0, int n0, const float
     return lr_refit_run(ws, xyz0, n0, xyz1, idx1, T_in, thr2, T_out, n_inl, nullptr, (hipStream_t)stream);
 }
 
+// ------------------------------------------------------------------ f1: ICP
+extern "C" int lr_icp(lr_workspace *ws, const float *xyz0, int n0, const float *xyz1, int n1, const double *T_init,
+                      double max_dist, int max_iter, double rel_fitness, double rel_rmse, double *T_out, lr_icp_result *res, void *stream)
+{
+    LR_REQUIRE(ws && xyz0 && xyz1 && T_init && T_out, LR_EINVAL, "lr_icp: null pointer");
+    LR_REQUIRE(n0 > 0 && n0 <= ws->max_n0 && n1 > 0 && n1 <= ws->max_n1, LR_ESIZE, "lr_icp: cloud exceeds the workspace");
+    return lr_icp_run(ws, xyz0, n0, xyz1, n1, T_init, nullptr, max_dist, max_iter, rel_fitness, rel_rmse, T_out, res, (hipStream_t)stream);
+}
+
+__global__ void pair_icp_kernel(const double *__restrict__ T_icp, const lr_icp_result *__restrict__ r, lr_pair_result *__restrict__ out, int have)
+{
+    const int k = threadIdx.x;
+    if (k < 16) out->T_icp[k] = have ? T_icp[k] : out->T[k];
+    if (k == 0) {
+        if (have) out->icp = *r;
+        else { out->icp.fitness = 0.0; out->icp.inlier_rmse = 0.0; out->icp.n_corr = 0; out->icp.iterations = 0; }
+    }
+}
+
 // ------------------------------------------------------------------ a9: the whole pair
 __global__ void pair_result_kernel(const double *__restrict__ T_ransac, const double *__restrict__ T_final,
                                    const lr_ransac_result *__restrict__ rr, const int32_t *__restrict__ counters,
@@ -331,10 +353,15 @@ extern "C" int lr_register_pair(lr_workspace *ws, const float *xyz0, const float
     if (p->refit) {
         LR_TRY(lr_refit_run(ws, xyz0, n0, xyz1, ws->nn_idx1, ws->T_tmp, p->refit_thr2,
                             ws->T_tmp + 16, n_refit, ws->res_tmp, st, out));
-        return LR_OK;
-    }
+        T_final = ws->T_tmp + 16;
+    } else
     hipLaunchKernelGGL(pair_result_kernel, dim3(1), dim3(64), 0, st, ws->T_tmp, T_final, ws->res_tmp, ws->counters,
                        p->refit ? n_refit : (const int32_t *)nullptr, out);
+    // 5. ICP refinement (test.py:183-189): max distance 2*voxel, Open3D's default criteria
+    lr_icp_result *icp_res = reinterpret_cast<lr_icp_result *>(ws->icp_state + 24);
+    if (p->icp)
+        LR_TRY(lr_icp_run(ws, xyz0, n0, xyz1, n1, T_final, ws->res_tmp, 0.6, 30, 1e-6, 1e-6, ws->T_tmp, icp_res, st));
+    hipLaunchKernelGGL(pair_icp_kernel, dim3(1), dim3(64), 0, st, ws->T_tmp, icp_res, out, p->icp ? 1 : 0);
     LR_LAUNCH_CHECK();
     return LR_OK;
 }

@@ -82,6 +82,10 @@ struct lr_workspace {
     double *refit_part;          // [blocks][16] moment partials
     lr_ransac_result *res_tmp;
     double *T_tmp;               // [32]
+    // --- ICP ---
+    int32_t *icp_ints;           // hist | fill | start of the hashed target grid
+    int32_t *icp_bucket, *icp_sorted;   // [max_n1]
+    double *icp_state, *icp_part;
     // --- timing hook ---
     int timing;
     hipEvent_t ev[4];
@@ -145,6 +149,11 @@ int lr_gpf_bb_run(lr_workspace *ws, const float *F0, int n0, const float *F1, in
                   const int32_t *b0, const int32_t *b1, const int32_t *b2, const int32_t *mb_dev, const float *xyz0,
                   int G, double max_matches, int32_t *o0, int32_t *o1, int32_t *o2, float *oscore,
                   int32_t *n_out, int32_t *has_score, hipStream_t st);
+
+// lr_icp.hip
+int lr_icp_run(lr_workspace *ws, const float *xyz0, int n0, const float *xyz1, int n1, const double *T_init,
+               const lr_ransac_result *gate, double max_dist, int max_iter, double rel_fit, double rel_rmse,
+               double *T_out, lr_icp_result *res, hipStream_t st);
 
 // lr_ransac.hip
 int lr_ransac_run(lr_workspace *ws, const float *corr8, int m_max, const int32_t *m_dev, const lr_ransac_params *p,

@@ -34,85 +34,7 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32
     }
 }
 
-// ------------------------------------------------------------------ Kabsch (fp64, + - * / sqrt only)
-#define LR_JACOBI_SWEEPS 10      // upper bound; sweeps stop once the off-diagonal mass is below 1e-15 of the diagonal
-
-__device__ __forceinline__ void jacobi4_maxvec(double A[4][4], double q[4])
-{
-    double V[4][4] = { { 1, 0, 0, 0 }, { 0, 1, 0, 0 }, { 0, 0, 1, 0 }, { 0, 0, 0, 1 } };
-    for (int sweep = 0; sweep < LR_JACOBI_SWEEPS; ++sweep) {
-        double off2 = ((((A[0][1] * A[0][1] + A[0][2] * A[0][2]) + A[0][3] * A[0][3]) + A[1][2] * A[1][2]) + A[1][3] * A[1][3]) + A[2][3] * A[2][3];
-        double dia2 = ((A[0][0] * A[0][0] + A[1][1] * A[1][1]) + A[2][2] * A[2][2]) + A[3][3] * A[3][3];
-        if (off2 <= 1e-30 * dia2) break;
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-            for (int r = p + 1; r < 4; ++r) {
-                double apq = A[p][r];
-                if (apq != 0.0) {
-                    double theta = (A[r][r] - A[p][p]) / (2.0 * apq);
-                    double at = fabs(theta);
-                    double t = 1.0 / (at + sqrt(theta * theta + 1.0));
-                    if (theta < 0.0) t = -t;
-                    double c = 1.0 / sqrt(t * t + 1.0);
-                    double s = t * c;
-                    double tau = s / (1.0 + c);
-                    double h = t * apq;
-                    A[p][p] = A[p][p] - h;
-                    A[r][r] = A[r][r] + h;
-                    A[p][r] = 0.0; A[r][p] = 0.0;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        if (k == p || k == r) continue;
-                        double g = A[k][p], f = A[k][r];
-                        double gn = g - s * (f + g * tau);
-                        double fn = f + s * (g - f * tau);
-                        A[k][p] = gn; A[p][k] = gn;
-                        A[k][r] = fn; A[r][k] = fn;
-                    }
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        double g = V[k][p], f = V[k][r];
-                        V[k][p] = g - s * (f + g * tau);
-                        V[k][r] = f + s * (g - f * tau);
-                    }
-                }
-            }
-    }
-    double w = V[0][0], x = V[1][0], y = V[2][0], z = V[3][0], best = A[0][0];
-#pragma unroll
-    for (int k = 1; k < 4; ++k)
-        if (A[k][k] > best) { best = A[k][k]; w = V[0][k]; x = V[1][k]; y = V[2][k]; z = V[3][k]; }
-    double nn = sqrt(((w * w + x * x) + y * y) + z * z);
-    q[0] = w / nn; q[1] = x / nn; q[2] = y / nn; q[3] = z / nn;
-}
-
-// H[a][b] = sum (p-cp)_a (q-cq)_b  ->  T (row-major 4x4, q ~ R p + t)
-__device__ __forceinline__ void rt_from_cov(const double H[3][3], const double cp[3], const double cq[3], double T[16])
-{
-    double Sxx = H[0][0], Sxy = H[0][1], Sxz = H[0][2];
-    double Syx = H[1][0], Syy = H[1][1], Syz = H[1][2];
-    double Szx = H[2][0], Szy = H[2][1], Szz = H[2][2];
-    double N[4][4];
-    N[0][0] = (Sxx + Syy) + Szz; N[0][1] = Syz - Szy;         N[0][2] = Szx - Sxz;         N[0][3] = Sxy - Syx;
-    N[1][0] = N[0][1];           N[1][1] = (Sxx - Syy) - Szz; N[1][2] = Sxy + Syx;         N[1][3] = Szx + Sxz;
-    N[2][0] = N[0][2];           N[2][1] = N[1][2];           N[2][2] = (Syy - Sxx) - Szz; N[2][3] = Syz + Szy;
-    N[3][0] = N[0][3];           N[3][1] = N[1][3];           N[3][2] = N[2][3];           N[3][3] = (Szz - Sxx) - Syy;
-    double q[4];
-    jacobi4_maxvec(N, q);
-    double w = q[0], x = q[1], y = q[2], z = q[3];
-    double R[3][3];
-    R[0][0] = 1.0 - 2.0 * (y * y + z * z); R[0][1] = 2.0 * (x * y - w * z);       R[0][2] = 2.0 * (x * z + w * y);
-    R[1][0] = 2.0 * (x * y + w * z);       R[1][1] = 1.0 - 2.0 * (x * x + z * z); R[1][2] = 2.0 * (y * z - w * x);
-    R[2][0] = 2.0 * (x * z - w * y);       R[2][1] = 2.0 * (y * z + w * x);       R[2][2] = 1.0 - 2.0 * (x * x + y * y);
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        double rc = (R[a][0] * cp[0] + R[a][1] * cp[1]) + R[a][2] * cp[2];
-        T[4 * a + 0] = R[a][0]; T[4 * a + 1] = R[a][1]; T[4 * a + 2] = R[a][2];
-        T[4 * a + 3] = cq[a] - rc;
-    }
-    T[12] = 0.0; T[13] = 0.0; T[14] = 0.0; T[15] = 1.0;
-}
+#include "lr_kabsch.h"
 
 // unweighted Kabsch on NS (3 or 4) sample points held in registers
 template <int NS>
@@ -138,7 +60,7 @@ __device__ __forceinline__ void kabsch_sample(const double P[NS][3], const doubl
 #pragma unroll
             for (int b = 0; b < 3; ++b) H[a][b] = H[a][b] + (1.0 * pc[a]) * qc[b];
     }
-    rt_from_cov(H, cp, cq, T);
+    lr_rt_from_cov(H, cp, cq, T);
 }
 
 // sample of hypothesis h and its edge-length pre-check; false when the pre-check rejects it
@@ -443,7 +365,7 @@ refit_solve_kernel(const double *__restrict__ partial, int nblocks, const double
         for (int a = 0; a < 3; ++a) { cp[a] = mom[1 + a] / n; cq[a] = mom[4 + a] / n; }
         for (int a = 0; a < 3; ++a)
             for (int b = 0; b < 3; ++b) H[a][b] = mom[7 + 3 * a + b] - (n * cp[a]) * cq[b];
-        rt_from_cov(H, cp, cq, T);
+        lr_rt_from_cov(H, cp, cq, T);
         n_used = (int)n;
     }
     for (int k = 0; k < 16; ++k) T_out[k] = T[k];
@@ -491,7 +413,7 @@ __global__ void kabsch_points_kernel(const double *__restrict__ P, const double 
             for (int b = 0; b < 3; ++b) H[a][b] = H[a][b] + (wi * pc[a]) * qc[b];
     }
     double T[16];
-    rt_from_cov(H, cp, cq, T);
+    lr_rt_from_cov(H, cp, cq, T);
     for (int k = 0; k < 16; ++k) T_out[k] = T[k];
 }
 

@@ -74,8 +74,8 @@ def eval_pairs(source, indices, args, device=None, in_flight=4, verbose=False):
     slots = [None] * in_flight          # (row, result buffer, events, host data) of the pair in flight on each stream
 
     def retire(s):
-        row, out, ev0, ev1, p, t_data, n0 = slots[s]
-        ev1.synchronize()
+        row, out, ev0, ev1, p, t_data, n0, icp_buf, ev2 = slots[s]
+        (ev2 or ev1).synchronize()
         r = fr.read_result(out)
         T = np.array(r.T[:], np.float64).reshape(4, 4) if r.status == 0 else np.eye(4)
         idx1, ci0, ci1 = fr.pair_lists(wss[s], n0, int(r.n_corr), dev)
@@ -86,6 +86,12 @@ def eval_pairs(source, indices, args, device=None, in_flight=4, verbose=False):
         stats[row, 1], stats[row, 2] = re, te
         stats[row, 9] = ev0.elapsed_time(ev1) * 1e-3          # registration time on the device, whole path incl. NN
         stats[row, 10], stats[row, 11] = t_data, 0.0
+        if icp_buf is not None:                                # stats columns 11-14 = the harness' ICP stage (test.py:183-193)
+            T_icp = icp_buf[0].cpu().numpy().reshape(4, 4) if r.status == 0 else np.eye(4)
+            re_i, te_i = metrics.rotation_error_deg(T_icp, p["T_gt"]), metrics.translation_error_cm(T_icp, p["T_gt"])
+            stats[row, 11] = ev1.elapsed_time(ev2) * 1e-3
+            stats[row, 12] = float(re_i < metrics.RE_THRE_DEG and te_i < metrics.TE_THRE_CM)
+            stats[row, 13], stats[row, 14] = re_i, te_i
         stats[row, 15] = n0
         stats[row, 16] = fr.measure_inlier_ratio(np.arange(n0), idx1, pcd0, pcd1, p["T_gt"], fr.VOXEL_SIZE)
         stats[row, 17] = int(r.n_corr)
@@ -117,7 +123,17 @@ def eval_pairs(source, indices, args, device=None, in_flight=4, verbose=False):
             ev0.record(streams[s])
             fr.register_pair_dev(x0, x1, f0, f1, params, out=out, ws=wss[s], stream=streams[s].cuda_stream)
             ev1.record(streams[s])
-        slots[s] = (row, out, ev0, ev1, dict(p, _keep=(x0, x1, f0, f1)), t_data, n0)
+            icp_buf, ev2 = None, None
+            if getattr(args, "icp", False):
+                # ICP refinement of the registration result, timed on its own like the reference's icp_timer
+                T_icp = torch.empty(16, dtype=torch.float64, device=dev)
+                res_icp = torch.empty(ctypes.sizeof(_ext.IcpResult), dtype=torch.uint8, device=dev)
+                _ext.check(_ext.lib().lr_icp(wss[s].handle, x0.data_ptr(), n0, x1.data_ptr(), n1, out.data_ptr(), 2 * fr.VOXEL_SIZE, 30,
+                                              1e-6, 1e-6, T_icp.data_ptr(), res_icp.data_ptr(), streams[s].cuda_stream))
+                ev2 = torch.cuda.Event(enable_timing=True)
+                ev2.record(streams[s])
+                icp_buf = (T_icp, res_icp)
+        slots[s] = (row, out, ev0, ev1, dict(p, _keep=(x0, x1, f0, f1)), t_data, n0, icp_buf, ev2)
     for s in range(in_flight):
         if slots[s] is not None:
             retire(s)

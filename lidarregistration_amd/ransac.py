@@ -50,6 +50,20 @@ def refit_dev(xyz0, xyz1, idx1, T, thr=0.6):
     return Tout.cpu().numpy().reshape(4, 4), int(n.item())
 
 
+def icp_dev(xyz0, xyz1, T_init, max_dist=0.6, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6):
+    """Point-to-point ICP refinement (Experiments/test.py:183-189).  Returns (T 4x4 float64 numpy, info dict)."""
+    xyz0, xyz1 = _f32(xyz0), _f32(xyz1)
+    ws = workspace(xyz0.shape[0], xyz1.shape[0])
+    Tin = torch.as_tensor(np.ascontiguousarray(T_init, np.float64).reshape(16)).to(xyz0.device)
+    Tout = torch.empty(16, dtype=torch.float64, device=xyz0.device)
+    res = torch.zeros(ctypes.sizeof(_ext.IcpResult), dtype=torch.uint8, device=xyz0.device)
+    _ext.check(_ext.lib().lr_icp(ws.handle, xyz0.data_ptr(), xyz0.shape[0], xyz1.data_ptr(), xyz1.shape[0], Tin.data_ptr(),
+                                  float(max_dist), int(max_iter), float(rel_fitness), float(rel_rmse), Tout.data_ptr(), res.data_ptr(),
+                                  _stream()))
+    r = _ext.IcpResult.from_buffer_copy(res.cpu().numpy().tobytes())
+    return Tout.cpu().numpy().reshape(4, 4), dict(fitness=r.fitness, inlier_rmse=r.inlier_rmse, n_corr=r.n_corr, iterations=r.iterations)
+
+
 def kabsch_dev(P, Q, w=None):
     """Least-squares rigid fit Q ~ R P + t (models/common.py:7-45).  Returns 4x4 float64 numpy."""
     dev = _device()

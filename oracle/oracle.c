@@ -428,6 +428,69 @@ ORC_API int orc_refit(const float *xyz0, int n0, const float *xyz1, const int32_
     return (int)n;
 }
 
+/* ----------------------------------------------------------------- ICP ---- */
+
+/* Point-to-point ICP as Open3D 0.13.0's RegistrationICP runs it for Experiments/test.py:183-189 (third-party, not
+ * vendored: parity unpinned): nearest target within max_dist (strict) of every transformed source point, Umeyama update,
+ * at most max_iter updates, stop when fitness and inlier RMSE both move by less than the relative criteria.
+ * Brute-force neighbour search (test sizes only).  out[0]=fitness, out[1]=rmse, out[2]=n_corr, out[3]=updates.     */
+ORC_API void orc_icp(const float *src, int n0, const float *tgt, int n1, const double T_init[16], double max_dist,
+                     int max_iter, double rel_fit, double rel_rmse, double T_out[16], double out[4])
+{
+    double T[16];
+    memcpy(T, T_init, sizeof(T));
+    double prev_fit = 0.0, prev_rmse = 0.0;
+    const double max_d2 = max_dist * max_dist;
+    int k = 0;
+    for (;; ++k) {
+        double n = 0.0, sp[3] = {0,0,0}, sq[3] = {0,0,0}, spq[9] = {0,0,0,0,0,0,0,0,0}, err2 = 0.0;
+#pragma omp parallel
+        {
+            double ln = 0.0, lsp[3] = {0,0,0}, lsq[3] = {0,0,0}, lspq[9] = {0,0,0,0,0,0,0,0,0}, lerr = 0.0;
+#pragma omp for schedule(static)
+            for (int i = 0; i < n0; ++i) {
+                double px = src[3 * i], py = src[3 * i + 1], pz = src[3 * i + 2], p[3];
+                for (int a = 0; a < 3; ++a) p[a] = ((T[4 * a] * px + T[4 * a + 1] * py) + T[4 * a + 2] * pz) + T[4 * a + 3];
+                double best = max_d2; int bj = -1;
+                for (int j = 0; j < n1; ++j) {
+                    double qx = (double)tgt[3 * j] - p[0], qy = (double)tgt[3 * j + 1] - p[1], qz = (double)tgt[3 * j + 2] - p[2];
+                    double d2 = (qx * qx + qy * qy) + qz * qz;
+                    if (d2 < best) { best = d2; bj = j; }
+                }
+                if (bj >= 0) {
+                    double q[3] = { tgt[3 * bj], tgt[3 * bj + 1], tgt[3 * bj + 2] };
+                    ln += 1.0; lerr += best;
+                    for (int a = 0; a < 3; ++a) { lsp[a] += p[a]; lsq[a] += q[a]; }
+                    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) lspq[3 * a + b] += p[a] * q[b];
+                }
+            }
+#pragma omp critical
+            {
+                n += ln; err2 += lerr;
+                for (int a = 0; a < 3; ++a) { sp[a] += lsp[a]; sq[a] += lsq[a]; }
+                for (int a = 0; a < 9; ++a) spq[a] += lspq[a];
+            }
+        }
+        double fit = n / (double)n0, rmse = n > 0.0 ? sqrt(err2 / n) : 0.0;
+        out[0] = fit; out[1] = rmse; out[2] = n;
+        int done = 0;
+        if (k > 0 && fabs(prev_fit - fit) < rel_fit && fabs(prev_rmse - rmse) < rel_rmse) done = 1;
+        if (k >= max_iter || n < 3.0) done = 1;
+        if (done) break;
+        double U[16], Tn[16];
+        orc_kabsch_moments(n, sp, sq, spq, U);
+        for (int a = 0; a < 3; ++a) {
+            for (int b = 0; b < 3; ++b) Tn[4 * a + b] = (U[4 * a] * T[b] + U[4 * a + 1] * T[4 + b]) + U[4 * a + 2] * T[8 + b];
+            Tn[4 * a + 3] = ((U[4 * a] * T[3] + U[4 * a + 1] * T[7]) + U[4 * a + 2] * T[11]) + U[4 * a + 3];
+        }
+        for (int q = 0; q < 12; ++q) T[q] = Tn[q];
+        prev_fit = fit; prev_rmse = rmse;
+    }
+    memcpy(T_out, T, sizeof(T));
+    T_out[12] = 0; T_out[13] = 0; T_out[14] = 0; T_out[15] = 1;
+    out[3] = (double)k;
+}
+
 ORC_API int orc_num_threads(void)
 {
 #ifdef _OPENMP

@@ -324,6 +324,18 @@ def refit(xyz0, xyz1, idx1, T, thr=0.6):
     return Tout.reshape(4, 4), n
 
 
+# ----------------------------------------------------------------------------- ICP (f1)
+
+def icp(src, tgt, T_init, max_dist=0.6, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6):
+    """Point-to-point ICP as Experiments/test.py:183-189 calls Open3D's registration_icp.  Returns (T, info)."""
+    src, tgt = _f32(src), _f32(tgt)
+    Tin = np.ascontiguousarray(T_init, np.float64).reshape(16)
+    Tout = np.empty(16, np.float64); out = np.zeros(4, np.float64)
+    lib().orc_icp(_p(src, c_f32p), src.shape[0], _p(tgt, c_f32p), tgt.shape[0], _p(Tin, c_f64p), ctypes.c_double(max_dist),
+                  int(max_iter), ctypes.c_double(rel_fitness), ctypes.c_double(rel_rmse), _p(Tout, c_f64p), _p(out, c_f64p))
+    return Tout.reshape(4, 4), dict(fitness=out[0], inlier_rmse=out[1], n_corr=int(out[2]), iterations=int(out[3]))
+
+
 # ----------------------------------------------------------------------------- metric (a15)
 
 def rotation_error_deg(T, T_gt):

@@ -36,7 +36,7 @@ def test_struct_layouts_match_header():
     # sizes the C side static-asserts implicitly through its field order (include/lidarreg.h)
     assert ctypes.sizeof(_ext.RansacParams) == 32
     assert ctypes.sizeof(_ext.RansacResult) == 40
-    assert ctypes.sizeof(_ext.PairResult) == 344
+    assert ctypes.sizeof(_ext.PairResult) == 496
     assert ctypes.sizeof(_ext.PairParams) == 64
     assert _ext.PairParams.ransac.offset == 8 and _ext.PairParams.gpf_factor.offset == 48
 

@@ -36,6 +36,7 @@ def test_single_process_run(cli, tmp_path, oracle, mode_args):
     raw, ids, T, log = _outputs(tmp_path)
     assert raw.shape == (6, 22) and np.array_equal(raw, stats, equal_nan=True)
     assert (raw[:, 0] == 1).all() and (raw[:, 1] < 1.0).all() and (raw[:, 2] < 30).all()
+    assert (raw[:, 12] == 1).all() and (raw[:, 13] < 1.0).all() and (raw[:, 14] < 30).all() and (raw[:, 11] > 0).all()    # ICP columns
     assert ids[:, 1].tolist() == list(range(6)) and "recall: 100.00%" in log and "mode = " in log
     # pair 2 of the run against the oracle pipeline on the same synthetic pair
     from lidarregistration_amd import synth

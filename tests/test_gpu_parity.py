@@ -360,3 +360,47 @@ def test_ransac_iteration_property_more_iters_never_worse(lr):
         _, info = lr.ransac.ransac_dev(src, tgt, iters, seed=5)
         assert info["best_count"] >= best          # hypotheses 0..iters-1 are a prefix of the longer run
         best = info["best_count"]
+
+
+# ----------------------------------------------------------------------------- ICP (next row f1)
+@pytest.mark.parametrize("n,rho,seed,offset", [(3000, 0.6, 5, 0.25), (4000, 0.4, 6, 0.4), (1500, 0.8, 7, 0.1)])
+def test_icp_matches_oracle(lr, oracle, n, rho, seed, offset):
+    xyz0, xyz1, T_gt = synth.make_clouds(n, n, rho, seed)
+    T0 = T_gt.copy(); T0[:3, 3] += [offset, -0.5 * offset, 0.1]
+    ang = np.radians(1.0); c, s = np.cos(ang), np.sin(ang)
+    T0[:3, :3] = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]]) @ T0[:3, :3]
+    T, info = lr.ransac.icp_dev(xyz0, xyz1, T0)
+    Te, einfo = oracle.icp(xyz0, xyz1, T0)
+    assert info["n_corr"] == einfo["n_corr"] and info["iterations"] == einfo["iterations"]
+    np.testing.assert_allclose(T, Te, rtol=0, atol=1e-9)
+    assert abs(info["fitness"] - einfo["fitness"]) < 1e-12 and abs(info["inlier_rmse"] - einfo["inlier_rmse"]) < 1e-9
+    # ICP pulls the perturbed start back onto the planted motion
+    assert oracle.translation_error_cm(T, T_gt) < oracle.translation_error_cm(T0, T_gt)
+    assert oracle.rotation_error_deg(T, T_gt) < 0.2 and oracle.translation_error_cm(T, T_gt) < 5
+
+
+def test_icp_edge_cases(lr, oracle):
+    xyz0, xyz1, T_gt = synth.make_clouds(800, 700, 0.5, 3)
+    # max_iter 0: the start transform is returned, evaluated once
+    T, info = lr.ransac.icp_dev(xyz0, xyz1, T_gt, max_iter=0)
+    assert np.array_equal(T, T_gt) and info["iterations"] == 0 and info["n_corr"] == oracle.icp(xyz0, xyz1, T_gt, max_iter=0)[1]["n_corr"]
+    # no point within reach: nothing to fit, start transform comes back
+    far = np.eye(4); far[:3, 3] = [1e4, 1e4, 1e4]
+    T, info = lr.ransac.icp_dev(xyz0, xyz1, far)
+    assert np.array_equal(T, far) and info["n_corr"] == 0
+
+
+def test_register_pair_with_icp_block(lr, oracle):
+    import ctypes
+    p = synth.make_pair(N=5000, rho=0.5, s=0.9, seed=51)
+    a = Args(mode="MNN", codebase="GC", iters=2000, icp=True)
+    t = lr.torch.from_numpy
+    params = lr.FR.pair_params(a)
+    assert params.icp == 1
+    dev = lr.torch.device("cuda")
+    out = lr.FR.register_pair_dev(t(p["xyz0"]).to(dev), t(p["xyz1"]).to(dev), t(p["feats0"]).to(dev), t(p["feats1"]).to(dev), params)
+    r = lr.FR.read_result(out)
+    T = np.array(r.T[:]).reshape(4, 4); T_icp = np.array(r.T_icp[:]).reshape(4, 4)
+    Te, einfo = oracle.icp(p["xyz0"], p["xyz1"], T)
+    np.testing.assert_allclose(T_icp, Te, rtol=0, atol=1e-9)
+    assert r.icp.n_corr == einfo["n_corr"] and r.icp.iterations == einfo["iterations"]
