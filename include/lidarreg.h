@@ -81,7 +81,8 @@ typedef struct lr_pair_result {
 
 typedef struct lr_pair_params {
     int32_t  mode;          /* LR_MODE_*                                                             */
-    int32_t  refit;         /* 1: LS refit on the original NN pairs within thr (FR.py:99-111)         */
+    int32_t  refit;         /* 0 none; 1: LS refit on the ORIGINAL NN pairs within thr (FR.py:99-111, codebase open3D);
+                               2: on the FILTERED pairs RANSAC ran on (GC-RANSAC's final least squares over its inliers) */
     lr_ransac_params ransac;
     /* GPF (matching.py:100-205), only read when mode == LR_MODE_GPF */
     int32_t  gpf_grid_wid;  /* --GPF_grid_wid, default 10                                            */

@@ -52,7 +52,9 @@ def pair_params(args):
                            conf, int(getattr(args, "ransac_batch", 0)))
     p = _ext.PairParams()
     p.mode = MODES[mode]
-    p.refit = int(getattr(args, "refit", True))
+    # open3D codebase: FR.py:99-111 refits over the original NN pairs; the GC codebase returns pygcransac's own final
+    # least squares over its inliers, i.e. over the filtered pairs it was given (GC_RANSAC.py:46-55)
+    p.refit = int(getattr(args, "refit", 2 if codebase == "GC" else 1))
     p.ransac = rp
     p.gpf_grid_wid = int(getattr(args, "GPF_grid_wid", 10))
     p.gpf_factor = float(getattr(args, "GPF_factor", 2.0))

@@ -351,8 +351,12 @@ extern "C" int lr_register_pair(lr_workspace *ws, const float *xyz0, const float
     // 4. LS refit over the original NN pairs (FR.py:99-111)
     const double *T_final = ws->T_tmp;
     if (p->refit) {
-        LR_TRY(lr_refit_run(ws, xyz0, n0, xyz1, ws->nn_idx1, ws->T_tmp, p->refit_thr2,
-                            ws->T_tmp + 16, n_refit, ws->res_tmp, st, out));
+        if (p->refit == 2)      // GC codebase: final least squares over the inliers among the FILTERED pairs RANSAC worked on
+            LR_TRY(lr_refit_run(ws, xyz0, n0, xyz1, ws->corr_idx1, ws->T_tmp, p->refit_thr2, ws->T_tmp + 16, n_refit, ws->res_tmp, st, out,
+                                ws->corr_idx0, m_dev));
+        else                    // open3D codebase: inliers over the ORIGINAL NN pairs (FR.py:99-111)
+            LR_TRY(lr_refit_run(ws, xyz0, n0, xyz1, ws->nn_idx1, ws->T_tmp, p->refit_thr2,
+                                ws->T_tmp + 16, n_refit, ws->res_tmp, st, out));
         T_final = ws->T_tmp + 16;
     } else
     hipLaunchKernelGGL(pair_result_kernel, dim3(1), dim3(64), 0, st, ws->T_tmp, T_final, ws->res_tmp, ws->counters,

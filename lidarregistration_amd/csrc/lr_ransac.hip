@@ -290,7 +290,8 @@ int lr_ransac_run(lr_workspace *ws, const float *corr8, int m_max, const int32_t
 // partial[b][0] = n, [1..3] = sum p, [4..6] = sum q, [7..15] = sum p q^T over the inliers of block b
 __global__ void __launch_bounds__(256)
 refit_moments_kernel(const float *__restrict__ xyz0, int n0, const float *__restrict__ xyz1, const int32_t *__restrict__ idx1,
-                     const double *__restrict__ T_in, double thr2, double *__restrict__ partial)
+                     const double *__restrict__ T_in, double thr2, double *__restrict__ partial,
+                     const int32_t *__restrict__ idx0, const int32_t *__restrict__ m_dev)
 {
     __shared__ double sm[4][16];
     double T[12];
@@ -300,9 +301,12 @@ refit_moments_kernel(const float *__restrict__ xyz0, int n0, const float *__rest
     double v[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) v[k] = 0.0;
+    // pairs (i, idx1[i]) over all n0 rows, or -- with idx0 -- the listed pairs (idx0[c], idx1[c]), c < *m_dev
+    if (m_dev) n0 = min(n0, *m_dev);
     if (i < n0) {
         const int j = idx1[i];
-        double p[3] = { (double)xyz0[3 * i], (double)xyz0[3 * i + 1], (double)xyz0[3 * i + 2] };
+        const int pi = idx0 ? idx0[i] : i;
+        double p[3] = { (double)xyz0[3 * pi], (double)xyz0[3 * pi + 1], (double)xyz0[3 * pi + 2] };
         double q[3] = { (double)xyz1[3 * j], (double)xyz1[3 * j + 1], (double)xyz1[3 * j + 2] };
         double r[3];
 #pragma unroll
@@ -383,10 +387,10 @@ refit_solve_kernel(const double *__restrict__ partial, int nblocks, const double
 
 int lr_refit_run(lr_workspace *ws, const float *xyz0, int n0, const float *xyz1, const int32_t *idx1,
                  const double *T_in, double thr2, double *T_out, int32_t *n_inl, const lr_ransac_result *gate,
-                 hipStream_t st, lr_pair_result *pair_out)
+                 hipStream_t st, lr_pair_result *pair_out, const int32_t *idx0, const int32_t *m_dev)
 {
     const int nb = lr_cdiv(n0, 256);
-    hipLaunchKernelGGL(refit_moments_kernel, dim3(nb), dim3(256), 0, st, xyz0, n0, xyz1, idx1, T_in, thr2, ws->refit_part);
+    hipLaunchKernelGGL(refit_moments_kernel, dim3(nb), dim3(256), 0, st, xyz0, n0, xyz1, idx1, T_in, thr2, ws->refit_part, idx0, m_dev);
     hipLaunchKernelGGL(refit_solve_kernel, dim3(1), dim3(64), 0, st, ws->refit_part, nb, T_in, gate, T_out, n_inl, pair_out, ws->counters);
     LR_LAUNCH_CHECK();
     return LR_OK;

@@ -369,6 +369,10 @@ def register_pair(xyz0, xyz1, feats0, feats1, mode="MNN", iters=50000, sample_si
     src = _f32(xyz0)[f0]; tgt = _f32(xyz1)[f1]
     T, info = ransac(src, tgt, iters, sample_size, use_elc, thr, seed, confidence, batch)
     n_ref = 0
-    if refit_on_orig and info["best_h"] >= 0:
+    if refit_on_orig == 2 and info["best_h"] >= 0:
+        # GC codebase: final least squares over the inliers among the filtered pairs
+        Tr, n_ref = refit(src, tgt, np.arange(len(src)), T, thr)
+        T = Tr
+    elif refit_on_orig and info["best_h"] >= 0:
         T, n_ref = refit(xyz0, xyz1, idx1_orig, T, thr)
     return dict(T=T, idx0=f0, idx1=f1, idx1_orig=idx1_orig, ransac=info, n_refit=n_ref)

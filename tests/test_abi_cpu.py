@@ -67,9 +67,9 @@ def test_mode_aliases_and_defaults():
     from tests.conftest import Args
     p = fr.pair_params(Args(mode="MMN", codebase="GC", iters=None))
     assert p.mode == _ext.LR_MODE_MNN and p.ransac.iters == 500000 and p.ransac.sample_size == 3 and p.ransac.use_elc == 1
-    assert abs(p.ransac.confidence - 0.999) < 1e-6
+    assert abs(p.ransac.confidence - 0.999) < 1e-6 and p.refit == 2
     p = fr.pair_params(Args(mode="GPF", codebase="open3D", iters=1000, GPF_factor=0.5, GPF_grid_wid=4))
-    assert p.mode == _ext.LR_MODE_GPF and p.ransac.sample_size == 4 and p.gpf_factor == 0.5 and p.gpf_grid_wid == 4
+    assert p.mode == _ext.LR_MODE_GPF and p.ransac.sample_size == 4 and p.gpf_factor == 0.5 and p.gpf_grid_wid == 4 and p.refit == 1
     assert abs(p.refit_thr2 - 0.36) < 1e-15 and abs(p.ransac.thr2 - 0.36) < 1e-7
     with pytest.raises(AssertionError):
         fr.pair_params(Args(mode="bogus"))

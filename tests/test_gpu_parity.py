@@ -236,7 +236,8 @@ def test_FR_matches_oracle_pipeline(lr, oracle, mode, codebase, N, iters):
     T, elapsed, pcd0, pcd1, n_init, ir_init, n_filt, ir_filt = lr.FR.FR(t(p["xyz0"]), t(p["xyz1"]), t(p["feats0"]), t(p["feats1"]), a, p["T_gt"])
     ns = 3 if codebase == "GC" else 4
     e = oracle.register_pair(p["xyz0"], p["xyz1"], p["feats0"], p["feats1"], mode=mode, iters=iters, sample_size=ns,
-                             use_elc=True, seed=51, args=a, confidence=a.GC_conf if codebase == "GC" else a.o3d_conf)
+                             use_elc=True, seed=51, args=a, confidence=a.GC_conf if codebase == "GC" else a.o3d_conf,
+                             refit_on_orig=2 if codebase == "GC" else 1)
     assert n_init == N and n_filt == len(e["idx0"])
     # contract: <= 1e-4 rad rotation, <= 1e-3 m translation on identical correspondence inputs
     assert np.radians(oracle.rotation_error_deg(T, e["T"])) <= 1e-4
@@ -338,7 +339,7 @@ def test_FR_gpf_full_size(lr, oracle):
     t = lr.torch.from_numpy
     T, elapsed, _, _, n_init, _, n_filt, _ = lr.FR.FR(t(p["xyz0"]), t(p["xyz1"]), t(p["feats0"]), t(p["feats1"]), a, p["T_gt"])
     e = oracle.register_pair(p["xyz0"], p["xyz1"], p["feats0"], p["feats1"], mode="GPF", iters=20000, sample_size=3, seed=51, args=a,
-                             confidence=a.GC_conf)
+                             confidence=a.GC_conf, refit_on_orig=2)
     assert n_filt == len(e["idx0"]) and n_filt < n_init
     assert np.radians(oracle.rotation_error_deg(T, e["T"])) <= 1e-4 and oracle.translation_error_cm(T, e["T"]) / 100 <= 1e-3
 
