@@ -183,6 +183,17 @@ def main():
         out[f"{name}_recall2"] = np.array(np.mean((re < 2) & (te < 60)))
         out[f"{name}_n"] = np.array(len(gt))
     np.savez_compressed(os.path.join(HERE, "g9_recall.npz"), **out)
+
+    # ---------------- G10: 64-row excerpts of two pair lists (data rows only) for the list-driven surrogate runs -------
+    for name in ["ApolloSouthbay", "NuScenes_boston"]:
+        src = os.path.join(REF, "balanced_sets", name, "test.txt")
+        lines = open(src).read().splitlines()
+        rows = lines[1:]
+        pick = [rows[i] for i in np.linspace(0, len(rows) - 1, 64).astype(int)]
+        d = os.path.join(HERE, "balanced_sets_excerpt", name)
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "test.txt"), "w") as f:
+            f.write(lines[0] + "\n" + "\n".join(pick) + "\n")
     print("golden vectors written to", HERE)
 
 

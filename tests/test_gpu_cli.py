@@ -71,3 +71,19 @@ def test_demo_registration(cli, capsys):
     T = demo.main(["--algo", "RANSAC", "--mode", "MMN", "--iters", "1000"])
     out = capsys.readouterr().out
     assert T.shape == (4, 4) and "RE = " in out and "filtered pairs" in out
+
+
+@pytest.mark.parametrize("dataset,extra", [("A", ["--mode", "GPF", "--iters", "50000"]),
+                                           ("B", ["--mode", "MNN", "--iters", "1000000", "--GC_conf", "0.9995"])])
+def test_list_driven_surrogate_configs(cli, tmp_path, monkeypatch, dataset, extra):
+    """BASELINE configs 3 and 4 with the list-driven synthetic surrogate: ground-truth motion and overlap of every pair come from
+    rows of the reference's balanced lists (64-row excerpts under tests/golden/), clouds and descriptors are synthetic."""
+    monkeypatch.setenv("LIDARREG_BALANCED_SETS", os.path.join(ROOT, "tests", "golden", "balanced_sets_excerpt"))
+    stats = cli.main(["--dataset", dataset, "--algo", "RANSAC", "--synthetic_n", "6000", "--max_samples", "12"] + extra)
+    raw, ids, T, log = _outputs(tmp_path)
+    assert raw.shape == (12, 22)
+    from lidarregistration_amd import io_lists
+    lst = io_lists.read_pair_list(os.path.join(ROOT, "tests", "golden", "balanced_sets_excerpt", io_lists.DATASET_NAMES[dataset], "test.txt"))
+    # session / source / target ids of the list rows are carried through to the output files
+    assert sorted(map(tuple, ids.tolist())) == sorted(zip(lst["session"][:12].tolist(), lst["src"][:12].tolist(), lst["tgt"][:12].tolist()))
+    assert raw[:, 0].mean() >= 0.9 and np.nanmean(raw[:, 12]) >= 0.9            # recall of RANSAC and of RANSAC+ICP on the surrogate
