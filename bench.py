@@ -182,11 +182,11 @@ def main():
         total_pairs = world * args.pairs * args.steps
         value = total_pairs / dt
         line = {
-            "metric": "registration pairs/sec (30k-pt FCGF pairs, mutual-NN + 50k RANSAC iters + refit)",
+            "metric": f"registration pairs/sec ({args.n // 1000}k-pt FCGF pairs, {'mutual-NN' if args.mode in ('MNN', 'MMN') else args.mode} + {args.iters // 1000}k RANSAC iters + refit)",
             "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic" + (" (inputs copied from pinned host memory inside the timed region)" if args.include_h2d else ""),
-            "config": {"workload": f"configs[1]: {args.n}-pt x32-d synthetic FCGF pair, --mode {args.mode} --iters {args.iters}, "
+            "config": {"workload": f"{'configs[1]' if args.n == 30000 else 'configs[4]-like dense'}: {args.n}-pt x32-d synthetic FCGF pair, --mode {args.mode} --iters {args.iters}, "
                                    f"3-pt sampling + ELC + LS refit", "pairs_per_step_per_gpu": args.pairs,
                        "pairs_in_flight_per_gpu": nstreams, "parallelism": f"pair-sharded x{world}"},
             "recall_5deg_0.6m": round(recall, 4),

@@ -82,7 +82,9 @@ typedef struct lr_pair_result {
 typedef struct lr_pair_params {
     int32_t  mode;          /* LR_MODE_*                                                             */
     int32_t  refit;         /* 0 none; 1: LS refit on the ORIGINAL NN pairs within thr (FR.py:99-111, codebase open3D);
-                               2: on the FILTERED pairs RANSAC ran on (GC-RANSAC's final least squares over its inliers) */
+                               2: on the FILTERED pairs RANSAC ran on (GC-RANSAC's final least squares over its inliers);
+                               3: as 1 but weighted by the inverse feature distance of each pair (DGR register_FCGF,
+                                  DGR/core/deep_global_registration.py:531-537)                                  */
     lr_ransac_params ransac;
     /* GPF (matching.py:100-205), only read when mode == LR_MODE_GPF */
     int32_t  gpf_grid_wid;  /* --GPF_grid_wid, default 10                                            */

@@ -354,6 +354,9 @@ extern "C" int lr_register_pair(lr_workspace *ws, const float *xyz0, const float
         if (p->refit == 2)      // GC codebase: final least squares over the inliers among the FILTERED pairs RANSAC worked on
             LR_TRY(lr_refit_run(ws, xyz0, n0, xyz1, ws->corr_idx1, ws->T_tmp, p->refit_thr2, ws->T_tmp + 16, n_refit, ws->res_tmp, st, out,
                                 ws->corr_idx0, m_dev));
+        else if (p->refit == 3) // DGR register_FCGF: inverse-feature-distance weighted Procrustes over the original NN pairs
+            LR_TRY(lr_refit_run(ws, xyz0, n0, xyz1, ws->nn_idx1, ws->T_tmp, p->refit_thr2, ws->T_tmp + 16, n_refit, ws->res_tmp, st, out,
+                                nullptr, nullptr, F0, F1));
         else                    // open3D codebase: inliers over the ORIGINAL NN pairs (FR.py:99-111)
             LR_TRY(lr_refit_run(ws, xyz0, n0, xyz1, ws->nn_idx1, ws->T_tmp, p->refit_thr2,
                                 ws->T_tmp + 16, n_refit, ws->res_tmp, st, out));

@@ -160,4 +160,5 @@ int lr_ransac_run(lr_workspace *ws, const float *corr8, int m_max, const int32_t
                   double *T_out, lr_ransac_result *res, hipStream_t st);
 int lr_refit_run(lr_workspace *ws, const float *xyz0, int n0, const float *xyz1, const int32_t *idx1,
                  const double *T_in, double thr2, double *T_out, int32_t *n_inl, const lr_ransac_result *gate,
-                 hipStream_t st, lr_pair_result *pair_out = nullptr, const int32_t *idx0 = nullptr, const int32_t *m_dev = nullptr);
+                 hipStream_t st, lr_pair_result *pair_out = nullptr, const int32_t *idx0 = nullptr, const int32_t *m_dev = nullptr,
+                 const float *F0 = nullptr, const float *F1 = nullptr);

@@ -291,7 +291,8 @@ int lr_ransac_run(lr_workspace *ws, const float *corr8, int m_max, const int32_t
 __global__ void __launch_bounds__(256)
 refit_moments_kernel(const float *__restrict__ xyz0, int n0, const float *__restrict__ xyz1, const int32_t *__restrict__ idx1,
                      const double *__restrict__ T_in, double thr2, double *__restrict__ partial,
-                     const int32_t *__restrict__ idx0, const int32_t *__restrict__ m_dev)
+                     const int32_t *__restrict__ idx0, const int32_t *__restrict__ m_dev,
+                     const float *__restrict__ F0, const float *__restrict__ F1)
 {
     __shared__ double sm[4][16];
     double T[12];
@@ -314,13 +315,22 @@ refit_moments_kernel(const float *__restrict__ xyz0, int n0, const float *__rest
             r[a] = (((T[4 * a] * p[0] + T[4 * a + 1] * p[1]) + T[4 * a + 2] * p[2]) + T[4 * a + 3]) - q[a];
         double d2 = (r[0] * r[0] + r[1] * r[1]) + r[2] * r[2];
         if (d2 < thr2) {
-            v[0] = 1.0;
+            // weight 1 (Umeyama, FR.py:110-111) or the inverse feature distance of the pair (DGR's weighted
+            // Procrustes refit, DGR/core/deep_global_registration.py:531-537)
+            double w = 1.0;
+            if (F0) {
+                const float *fa = F0 + (size_t)pi * 32, *fb = F1 + (size_t)j * 32;
+                float acc = 0.0f;
+                for (int k = 0; k < 32; ++k) { const float e = fa[k] - fb[k]; const float q2 = e * e; acc = acc + q2; }
+                w = 1.0 / (double)fmaxf(__builtin_sqrtf(acc), 1e-12f);
+            }
+            v[0] = w;
 #pragma unroll
-            for (int a = 0; a < 3; ++a) { v[1 + a] = p[a]; v[4 + a] = q[a]; }
+            for (int a = 0; a < 3; ++a) { v[1 + a] = w * p[a]; v[4 + a] = w * q[a]; }
 #pragma unroll
             for (int a = 0; a < 3; ++a)
 #pragma unroll
-                for (int b = 0; b < 3; ++b) v[7 + 3 * a + b] = p[a] * q[b];
+                for (int b = 0; b < 3; ++b) v[7 + 3 * a + b] = (w * p[a]) * q[b];
         }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -339,7 +349,7 @@ refit_moments_kernel(const float *__restrict__ xyz0, int n0, const float *__rest
 __global__ void __launch_bounds__(64)
 refit_solve_kernel(const double *__restrict__ partial, int nblocks, const double *__restrict__ T_in,
                    const lr_ransac_result *__restrict__ gate, double *__restrict__ T_out, int32_t *__restrict__ n_inl,
-                   lr_pair_result *__restrict__ pair_out, const int32_t *__restrict__ counters)
+                   lr_pair_result *__restrict__ pair_out, const int32_t *__restrict__ counters, int weighted)
 {
     __shared__ double mom[16];
     __shared__ double stage[64 * 16];
@@ -361,7 +371,7 @@ refit_solve_kernel(const double *__restrict__ partial, int nblocks, const double
     const double n = mom[0];
     double T[16];
     int n_used;
-    if (!have_model || n < 3.0) {
+    if (!have_model || !(n > 0.0) || (!weighted && n < 3.0)) {
         for (int k = 0; k < 16; ++k) T[k] = T_in[k];
         n_used = have_model ? (int)n : 0;
     } else {
@@ -387,11 +397,14 @@ refit_solve_kernel(const double *__restrict__ partial, int nblocks, const double
 
 int lr_refit_run(lr_workspace *ws, const float *xyz0, int n0, const float *xyz1, const int32_t *idx1,
                  const double *T_in, double thr2, double *T_out, int32_t *n_inl, const lr_ransac_result *gate,
-                 hipStream_t st, lr_pair_result *pair_out, const int32_t *idx0, const int32_t *m_dev)
+                 hipStream_t st, lr_pair_result *pair_out, const int32_t *idx0, const int32_t *m_dev,
+                 const float *F0, const float *F1)
 {
     const int nb = lr_cdiv(n0, 256);
-    hipLaunchKernelGGL(refit_moments_kernel, dim3(nb), dim3(256), 0, st, xyz0, n0, xyz1, idx1, T_in, thr2, ws->refit_part, idx0, m_dev);
-    hipLaunchKernelGGL(refit_solve_kernel, dim3(1), dim3(64), 0, st, ws->refit_part, nb, T_in, gate, T_out, n_inl, pair_out, ws->counters);
+    hipLaunchKernelGGL(refit_moments_kernel, dim3(nb), dim3(256), 0, st, xyz0, n0, xyz1, idx1, T_in, thr2, ws->refit_part, idx0, m_dev,
+                       F0, F1);
+    hipLaunchKernelGGL(refit_solve_kernel, dim3(1), dim3(64), 0, st, ws->refit_part, nb, T_in, gate, T_out, n_inl, pair_out, ws->counters,
+                       F0 ? 1 : 0);
     LR_LAUNCH_CHECK();
     return LR_OK;
 }

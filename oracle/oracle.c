@@ -404,10 +404,27 @@ ORC_API void orc_ransac(const float *src, const float *tgt, int m, const orc_ran
 
 /* FR.py:99-111: inliers of T over the ORIGINAL nn pairs (i, idx1[i]) within thr2 (fp64), then a
  * least-squares rigid fit on them.  Returns the inlier count; T_out = T_in when fewer than 3.     */
+static int refit_impl(const float *xyz0, int n0, const float *xyz1, const int32_t *idx1,
+                      const double T_in[16], double thr2, double T_out[16], const float *F0, const float *F1);
+
 ORC_API int orc_refit(const float *xyz0, int n0, const float *xyz1, const int32_t *idx1,
                       const double T_in[16], double thr2, double T_out[16])
 {
+    return refit_impl(xyz0, n0, xyz1, idx1, T_in, thr2, T_out, NULL, NULL);
+}
+
+/* DGR/core/deep_global_registration.py:519-537: the same inlier set, weighted by 1 / ||F0[i] - F1[idx1[i]]|| */
+ORC_API int orc_refit_weighted(const float *xyz0, int n0, const float *xyz1, const int32_t *idx1, const double T_in[16],
+                               double thr2, double T_out[16], const float *F0, const float *F1)
+{
+    return refit_impl(xyz0, n0, xyz1, idx1, T_in, thr2, T_out, F0, F1);
+}
+
+static int refit_impl(const float *xyz0, int n0, const float *xyz1, const int32_t *idx1,
+                      const double T_in[16], double thr2, double T_out[16], const float *F0, const float *F1)
+{
     double n = 0.0, sp[3] = {0,0,0}, sq[3] = {0,0,0}, spq[9] = {0,0,0,0,0,0,0,0,0};
+    int cnt = 0;
     for (int i = 0; i < n0; ++i) {
         double p[3] = { xyz0[3 * i], xyz0[3 * i + 1], xyz0[3 * i + 2] };
         int j = idx1[i];
@@ -417,15 +434,22 @@ ORC_API int orc_refit(const float *xyz0, int n0, const float *xyz1, const int32_
             r[a] = (((T_in[4 * a] * p[0] + T_in[4 * a + 1] * p[1]) + T_in[4 * a + 2] * p[2]) + T_in[4 * a + 3]) - q[a];
         double d2 = (r[0] * r[0] + r[1] * r[1]) + r[2] * r[2];
         if (d2 < thr2) {
-            n += 1.0;
-            for (int a = 0; a < 3; ++a) { sp[a] += p[a]; sq[a] += q[a]; }
+            double w = 1.0;
+            if (F0) {
+                const float *fa = F0 + (size_t)i * 32, *fb = F1 + (size_t)j * 32;
+                float acc = 0.0f;
+                for (int k = 0; k < 32; ++k) { float e = fa[k] - fb[k]; float q2 = e * e; acc = acc + q2; }
+                w = 1.0 / (double)fmaxf(sqrtf(acc), 1e-12f);
+            }
+            n += w; cnt += 1;
+            for (int a = 0; a < 3; ++a) { sp[a] += w * p[a]; sq[a] += w * q[a]; }
             for (int a = 0; a < 3; ++a)
-                for (int b = 0; b < 3; ++b) spq[3 * a + b] += p[a] * q[b];
+                for (int b = 0; b < 3; ++b) spq[3 * a + b] += (w * p[a]) * q[b];
         }
     }
-    if (n < 3.0) { memcpy(T_out, T_in, sizeof(double) * 16); return (int)n; }
+    if (!(n > 0.0) || (!F0 && n < 3.0)) { memcpy(T_out, T_in, sizeof(double) * 16); return cnt; }
     orc_kabsch_moments(n, sp, sq, spq, T_out);
-    return (int)n;
+    return cnt;
 }
 
 /* ----------------------------------------------------------------- ICP ---- */

@@ -314,11 +314,16 @@ def ransac(src, tgt, iters, sample_size=3, use_elc=True, thr=0.6, seed=51, confi
     return T.reshape(4, 4), dict(best_h=r.best_h, best_count=r.best_count, best_ssq=r.best_ssq, n_valid=r.n_valid, n_ids=r.n_ids)
 
 
-def refit(xyz0, xyz1, idx1, T, thr=0.6):
-    """FR.py:99-111.  Returns (T 4x4 float64, inlier count)."""
+def refit(xyz0, xyz1, idx1, T, thr=0.6, feats0=None, feats1=None):
+    """FR.py:99-111 (with feats: DGR's inverse-feature-distance weighted form).  Returns (T 4x4 float64, inlier count)."""
     xyz0, xyz1, idx1 = _f32(xyz0), _f32(xyz1), _i32(idx1)
     Tin = np.ascontiguousarray(T, np.float64).reshape(16)
     Tout = np.empty(16, np.float64)
+    if feats0 is not None:
+        F0, F1 = _f32(feats0), _f32(feats1)
+        n = lib().orc_refit_weighted(_p(xyz0, c_f32p), xyz0.shape[0], _p(xyz1, c_f32p), _p(idx1, c_i32p), _p(Tin, c_f64p),
+                                     ctypes.c_double(float(thr) * float(thr)), _p(Tout, c_f64p), _p(F0, c_f32p), _p(F1, c_f32p))
+        return Tout.reshape(4, 4), n
     n = lib().orc_refit(_p(xyz0, c_f32p), xyz0.shape[0], _p(xyz1, c_f32p), _p(idx1, c_i32p),
                         _p(Tin, c_f64p), ctypes.c_double(float(thr) * float(thr)), _p(Tout, c_f64p))
     return Tout.reshape(4, 4), n
@@ -373,6 +378,8 @@ def register_pair(xyz0, xyz1, feats0, feats1, mode="MNN", iters=50000, sample_si
         # GC codebase: final least squares over the inliers among the filtered pairs
         Tr, n_ref = refit(src, tgt, np.arange(len(src)), T, thr)
         T = Tr
+    elif refit_on_orig == 3 and info["best_h"] >= 0:
+        T, n_ref = refit(xyz0, xyz1, idx1_orig, T, thr, feats0, feats1)
     elif refit_on_orig and info["best_h"] >= 0:
         T, n_ref = refit(xyz0, xyz1, idx1_orig, T, thr)
     return dict(T=T, idx0=f0, idx1=f1, idx1_orig=idx1_orig, ransac=info, n_refit=n_ref)

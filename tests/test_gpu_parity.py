@@ -405,3 +405,24 @@ def test_register_pair_with_icp_block(lr, oracle):
     Te, einfo = oracle.icp(p["xyz0"], p["xyz1"], T)
     np.testing.assert_allclose(T_icp, Te, rtol=0, atol=1e-9)
     assert r.icp.n_corr == einfo["n_corr"] and r.icp.iterations == einfo["iterations"]
+
+
+# ----------------------------------------------------------------------------- sibling callers (next row f4)
+def test_fcgf_fast_and_dgr_callers(lr, oracle):
+    from lidarregistration_amd import callers
+    p = synth.make_pair(N=4000, rho=0.5, s=0.8, seed=23)
+    t = lr.torch.from_numpy
+    T, elapsed, pcd0, pcd1, ir = callers.FCGF_FAST_RANSAC(t(p["xyz0"]), t(p["xyz1"]), t(p["feats0"]), t(p["feats1"]), p["T_gt"], iters=20000)
+    e = oracle.register_pair(p["xyz0"], p["xyz1"], p["feats0"], p["feats1"], mode="MNN", iters=20000, sample_size=4, seed=51,
+                             confidence=0.9999, refit_on_orig=1)
+    np.testing.assert_allclose(T, e["T"], rtol=0, atol=1e-9)
+    assert 0 < ir < 1 and pcd0.points.shape == (4000, 3)
+    r = callers.DGR_register_FCGF(t(p["xyz0"]), t(p["xyz1"]), t(p["feats0"]), t(p["feats1"]), iters=20000, T_gt=p["T_gt"])
+    e = oracle.register_pair(p["xyz0"], p["xyz1"], p["feats0"], p["feats1"], mode="no_filter", iters=20000, sample_size=4, seed=51,
+                             confidence=0.9999, refit_on_orig=3)
+    np.testing.assert_allclose(r["base"], e["T"], rtol=0, atol=1e-9)
+    assert oracle.rotation_error_deg(r["base"], p["T_gt"]) < 0.5
+    # the weighted refit is really different from the unweighted one
+    e1 = oracle.register_pair(p["xyz0"], p["xyz1"], p["feats0"], p["feats1"], mode="no_filter", iters=20000, sample_size=4, seed=51,
+                              confidence=0.9999, refit_on_orig=1)
+    assert np.abs(e1["T"] - e["T"]).max() > 1e-7
