@@ -298,6 +298,201 @@ nn16_pass_kernel(const _Float16 *__restrict__ Hq, int na, const _Float16 *__rest
     }
 }
 
+// ------------------------------------------------------------------ pass B, software-pipelined
+// Same candidate sets as nn16_pass_kernel<1>, different instruction order.  A 32x32x16 MFMA occupies the matrix pipe for
+// 32 cycles but holds the SIMD's vector issue for only 8 of them, so the candidate test of tile t-1 (3 v_max3 + 1 v_max +
+// 1 v_cmp + 1 scalar branch per 8 accumulator registers) is placed in the shadow of the MFMAs of tile t: every test
+// group follows one MFMA in program order and its branch ends the basic block, so the compiler cannot pull the pieces
+// apart again.  The column fragments of tile t+1 are read from LDS one step ahead, which moves the chunk barrier one
+// step forward.  Hits are parked in a wave-private LDS list whose fill count lives in a scalar register: no atomics and
+// no LDS round trip in the loop; the wave empties its own list into the per-row slots whenever it is half full.
+#ifndef LR_PB_CH
+#define LR_PB_CH 4
+#endif
+#ifndef LR_PB_PIPE
+#define LR_PB_PIPE 1
+#endif
+#ifndef LR_PB_EXP
+#define LR_PB_EXP 0     // development switches (tools/nn16_micro.hip): 1 no staging, 2 no tests
+#endif
+#define LR_PB_WLIST 512          // entries per wave (8 bytes each)
+
+__global__ void __launch_bounds__(256)
+nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na, const _Float16 *__restrict__ Hc, const float *__restrict__ nC, int nb,
+                  int tiles_per_strip, const float *__restrict__ tau, int32_t *__restrict__ cand_cnt, int32_t *__restrict__ cand)
+{
+    constexpr int CH = LR_PB_CH;
+    constexpr int XOFF = CH * 32 * LR_LDS_ROW;
+    constexpr int BUF = XOFF + CH * 32 * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
+    __shared__ uint2 wlist[4][LR_PB_WLIST];   // per wave: { column, (code << 8) | register mask }, code = rb*4 + (g0/8)*2 + h
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int r = lane & 31, h = lane >> 5;
+    const int row0 = blockIdx.x * LR_BLOCK_ROWS + wave * 64;
+    const int ntiles = (nb + 31) >> 5;
+    const int t_begin = blockIdx.y * tiles_per_strip;
+    const int t_end = min(ntiles, t_begin + tiles_per_strip);
+    const int nchunks = t_end > t_begin ? (t_end - t_begin + CH - 1) / CH : 0;
+
+    f16x8 a[2][2];
+    f32x16 y[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        const int row = min(row0 + 32 * rb + r, na - 1);
+        const f16x8 *p = reinterpret_cast<const f16x8 *>(Hq + (size_t)row * 32 + 16 * h);
+        a[rb][0] = p[0]; a[rb][1] = p[1];
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const int rw = row0 + 32 * rb + (g & 3) + 8 * (g >> 2) + 4 * h;
+            const float tv = tau[min(rw, na - 1)];
+            y[rb][g] = rw < na ? 0.5f * tv : -LR_INF;        // rows past the end never pass the test
+        }
+    }
+
+    f32x4 stage[CH / 2];
+    float stage_n = 0.0f;
+    bool stage_ok = false;
+    auto load_chunk = [&](int c) {
+#pragma unroll
+        for (int q = 0; q < CH / 2; ++q) {
+            const int p = tid + 256 * q;
+            const int col = (t_begin + c * CH) * 32 + (p >> 2);
+            stage[q] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const unsigned char *>(Hc) + (size_t)min(col, nb - 1) * 64 + (p & 3) * 16);
+        }
+        const int col = (t_begin + c * CH) * 32 + (tid & (CH * 32 - 1));
+        stage_n = nC[min(col, nb - 1)];
+        stage_ok = col < nb && (col >> 5) < t_end;
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < CH / 2; ++q) {
+            const int p = tid + 256 * q;
+            *reinterpret_cast<f32x4 *>(&lds[buf * BUF + (p >> 2) * LR_LDS_ROW + (p & 3) * 16]) = stage[q];
+        }
+        // x_j = n1[j]/2 ; +inf masks columns past the end of the cloud or of the strip
+        if (tid < CH * 32) *reinterpret_cast<float *>(&lds[buf * BUF + XOFF + tid * 4]) = stage_ok ? 0.5f * stage_n : LR_INF;
+    };
+    // per-lane byte offsets of the fragment / x_j of tile 0 of the current and the other buffer; tile k adds a constant
+    const int frag_lane = r * LR_LDS_ROW + 32 * h, x_lane = XOFF + r * 4;
+    int fo_cur = frag_lane, fo_oth = frag_lane + BUF, xo_cur = x_lane, xo_oth = x_lane + BUF;
+    auto read_b = [&](int fo, int xo, int k, f16x8 &b0, f16x8 &b1, float &xj) {
+        b0 = *reinterpret_cast<const f16x8 *>(&lds[fo + k * 32 * LR_LDS_ROW]);
+        b1 = *reinterpret_cast<const f16x8 *>(&lds[fo + k * 32 * LR_LDS_ROW + 16]);
+        xj = *reinterpret_cast<const float *>(&lds[xo + k * 32 * 4]);
+    };
+
+    int wcnt = 0;            // entries in this wave's list (wave-uniform: lives in a scalar register)
+    // empty the wave's list into the per-row slots shared by all strips (global atomics, off the hot path)
+    auto flush = [&]() {
+        if (wcnt > LR_PB_WLIST) {
+            // more hits than the list holds (duplicate-heavy input): the wave's rows go through the exact full-row scan
+            if (row0 + lane < na) atomicAdd(&cand_cnt[row0 + lane], LR_NN16_CAP + 1);
+        } else {
+            for (int e = lane; e < wcnt; e += 64) {
+                const uint2 v = wlist[wave][e];
+                const int col = (int)v.x, code = (int)(v.y >> 8);
+                if (col >= nb || (col >> 5) >= t_end) continue;      // padding columns pass the test only when tau is +inf
+                const int rbase = row0 + 32 * (code >> 2) + 4 * (code & 1);
+                unsigned m = v.y & 0xffu;
+                while (m) {
+                    const int g = 8 * ((code >> 1) & 1) + __builtin_ctz(m);
+                    m &= m - 1;
+                    const int row = rbase + (g & 3) + 8 * (g >> 2);
+                    const int slot = atomicAdd(&cand_cnt[row], 1);
+                    if (slot < LR_NN16_CAP) cand[(size_t)row * LR_NN16_CAP + slot] = col;
+                }
+            }
+        }
+        wcnt = 0;
+    };
+    // candidate test of 8 accumulator registers (16 rows x 32 columns of the wave's tile)
+    auto check = [&](const f32x16 &acc, int g0, float x, int tile, int rb) {
+#if LR_PB_EXP & 2
+        if (g0 == 0) asm volatile("" :: "v"(acc));
+        return;
+#endif
+        float m;
+        asm("v_max3_f32 %0, %1, %2, %3\n\tv_max3_f32 %0, %0, %4, %5\n\tv_max3_f32 %0, %0, %6, %7\n\tv_max_f32 %0, %0, %8"
+            : "=&v"(m)
+            : "v"(acc[g0]), "v"(acc[g0 + 1]), "v"(acc[g0 + 2]), "v"(acc[g0 + 3]), "v"(acc[g0 + 4]), "v"(acc[g0 + 5]), "v"(acc[g0 + 6]),
+              "v"(acc[g0 + 7]));
+        const unsigned long long hit = __builtin_amdgcn_ballot_w64(m >= x);
+        if (__builtin_expect(hit != 0ull, 0)) {       // rare: keeps the common path a fall-through
+            if (m >= x) {
+                unsigned mask = 0;
+#pragma unroll
+                for (int g = 0; g < 8; ++g) mask |= acc[g0 + g] >= x ? 1u << g : 0u;
+                const int pos = wcnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(hit >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hit, 0u));
+                if (pos < LR_PB_WLIST) wlist[wave][pos] = make_uint2((unsigned)(tile * 32 + r), mask | (unsigned)((rb * 4 + (g0 >> 3) * 2 + h) << 8));
+            }
+            wcnt += __builtin_popcountll(hit);
+        }
+    };
+
+    f16x8 b0, b1;
+    float xN = LR_INF, xC = LR_INF;
+    f32x16 accA[2], accB[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) { accA[q][g] = -LR_INF; accB[q][g] = -LR_INF; }
+
+    // one pipeline step: MFMAs of tile (c, k) into accN, tests of the previous tile in accC, LDS read of the next tile
+    auto step = [&](int c, int k, f32x16 (&accN)[2], const f32x16 (&accC)[2]) {
+        f16x8 n0, n1; float nx;
+        if (k + 1 < CH) read_b(fo_cur, xo_cur, k + 1, n0, n1, nx);
+        else read_b(fo_oth, xo_oth, 0, n0, n1, nx);
+        const int tileC = t_begin + c * CH + k - 1;
+        accN[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][0], b0, y[0], 0, 0, 0);
+        check(accC[0], 0, xC, tileC, 0);
+        accN[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][0], b0, y[1], 0, 0, 0);
+        check(accC[0], 8, xC, tileC, 0);
+        accN[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][1], b1, accN[0], 0, 0, 0);
+        check(accC[1], 0, xC, tileC, 1);
+        accN[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][1], b1, accN[1], 0, 0, 0);
+        check(accC[1], 8, xC, tileC, 1);
+        b0 = n0; b1 = n1; xC = xN; xN = nx;
+    };
+
+    if (nchunks > 0) {
+        load_chunk(0); store_chunk(0);
+        __syncthreads();
+        // everything older than the prefetch below (row fragments, thresholds) is complete from here on: the loop's
+        // counted waits then only ever refer to the prefetch itself
+        __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
+        if (nchunks > 1) load_chunk(1);
+        read_b(fo_cur, xo_cur, 0, b0, b1, xN);
+        for (int c = 0; c < nchunks; ++c) {
+#pragma unroll
+            for (int k = 0; k < CH; k += 2) {
+                step(c, k, accA, accB);
+                if (k == CH - 2) {
+                    // the last step of a chunk reads the first fragment of the next one: make that chunk visible now.  All
+                    // reads of the buffer it goes to were issued before the previous barrier (the step above read this
+                    // chunk's own last tile), so one barrier per chunk still orders everything.
+#if !(LR_PB_EXP & 1)
+                    if (c + 1 < nchunks) store_chunk((c & 1) ^ 1);
+                    __syncthreads();
+                    if (c + 2 < nchunks) load_chunk(c + 2);
+#endif
+                }
+                step(c, k + 1, accB, accA);
+            }
+            { const int t0 = fo_cur; fo_cur = fo_oth; fo_oth = t0; const int t1 = xo_cur; xo_cur = xo_oth; xo_oth = t1; }
+            if (wcnt >= LR_PB_WLIST / 2) flush();
+        }
+        // drain: the last tile of the last chunk sits in accB
+        {
+            const int tileC = t_begin + nchunks * CH - 1;
+            check(accB[0], 0, xC, tileC, 0);
+            check(accB[0], 8, xC, tileC, 0);
+            check(accB[1], 0, xC, tileC, 1);
+            check(accB[1], 8, xC, tileC, 1);
+        }
+        flush();
+    }
+}
+
 // ------------------------------------------------------------------ thresholds
 // U = need-th smallest sampled u' = -2 * (need-th largest g)
 __global__ void __launch_bounds__(256)
@@ -452,8 +647,12 @@ int lr_nn16_run(lr_workspace *ws, const float *Fq, const _Float16 *Hq, const flo
     hipLaunchKernelGGL(nn16_thresh_kernel, dim3(lr_cdiv(na, 256)), dim3(256), 0, st, na, strips, ws->max_n, ws->pb1, ws->pb2, nQ,
                        block_max_c, lr_cdiv(nb, 32), need, ws->tau, ws->cand_cnt);
     if (ws->timing && !ws->ev_pending) { LR_HIP(hipEventRecord(ws->ev[0], st)); }
+#if LR_PB_PIPE
+    hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), 0, st, Hq, na, Hc, nC, nb, tps, ws->tau, ws->cand_cnt, ws->cand);
+#else
     hipLaunchKernelGGL(nn16_pass_kernel<1>, grid, dim3(256), 0, st, Hq, na, Hc, nC, nb, tps, 1, ws->max_n, (float *)nullptr,
                        (float *)nullptr, ws->tau, ws->cand_cnt, ws->cand);
+#endif
     if (ws->timing && !ws->ev_pending) { LR_HIP(hipEventRecord(ws->ev[1], st)); ws->ev_pending = 1; }
     hipLaunchKernelGGL(nn16_exact_kernel, dim3(lr_cdiv(na, 64)), dim3(256), 0, st, Fq, nQ, na, Fc, nC, nb, ws->cand_cnt, ws->cand,
                        need, (const uint32_t *)nullptr, idx1, idx2, s1, s2, ws->counters);
@@ -532,8 +731,12 @@ int lr_nn16_reverse(lr_workspace *ws, const float *F0, const _Float16 *H0, const
     hipLaunchKernelGGL(nn16_thresh_seed_kernel, dim3(lr_cdiv(na, 256)), dim3(256), 0, st, na, seed, nrm1, bmax0, lr_cdiv(nb, 32),
                        ws->tau, ws->cand_cnt);
     dim3 grid(row_blocks, strips);
+#if LR_PB_PIPE
+    hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), 0, st, H1, na, H0, nrm0, nb, tps, ws->tau, ws->cand_cnt, ws->cand);
+#else
     hipLaunchKernelGGL(nn16_pass_kernel<1>, grid, dim3(256), 0, st, H1, na, H0, nrm0, nb, tps, 1, ws->max_n, (float *)nullptr,
                        (float *)nullptr, ws->tau, ws->cand_cnt, ws->cand);
+#endif
     hipLaunchKernelGGL(nn16_exact_kernel, dim3(lr_cdiv(na, 64)), dim3(256), 0, st, F1, nrm1, na, F0, nrm0, nb, ws->cand_cnt, ws->cand,
                        1, seed, rev, (int32_t *)nullptr, (float *)nullptr, (float *)nullptr, ws->counters);
     LR_LAUNCH_CHECK();

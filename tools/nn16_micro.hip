@@ -2,6 +2,7 @@
 #include "../lidarregistration_amd/csrc/lr_nn16.hip"
 #include <vector>
 #include <random>
+#include <algorithm>
 void lr_set_error(const char *, ...) {}
 int lr_nn_fix_rows(lr_workspace *, const float *, const float *, const float *, const float *, int, int32_t *, int32_t *, float *, float *, hipStream_t) { return 0; }
 template <class F> float timeit(F f, int reps = 20) {
@@ -37,16 +38,33 @@ int main(int argc, char **argv)
         hipLaunchKernelGGL(nn16_thresh_kernel, dim3((n+255)/256), dim3(256), 0, 0, n, strips, n, pu1, pu2, nrm, (const float*)bmax, (n+31)/32, 2, tau, cnt);
         int tpsb = (ntiles + strips - 1) / strips;
         float msb = timeit([&] { hipLaunchKernelGGL(nn16_pass_kernel<1>, grid, dim3(256), 0, 0, H, n, H, nrm, n, tpsb, 1, n, (float*)nullptr, (float*)nullptr, tau, cnt, cand); });
-        std::vector<int32_t> hc((size_t)n*strips); hipMemcpy(hc.data(), cnt, (size_t)n*strips*4, hipMemcpyDeviceToHost);
-        double tot = 0; int mxc = 0; for (int v : hc) { tot += v; mxc = v > mxc ? v : mxc; }
-        printf("passB (thresholds from stride %d): %.3f ms   candidates/row avg %.2f max %d\n", stride, msb, tot / n, mxc);
+        float msp = timeit([&] { hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), 0, 0, H, n, H, nrm, n, tpsb, tau, cnt, cand); });
+        // one counted launch of each, candidate sets compared per row
+        std::vector<int32_t> c0(n), c1(n), l0((size_t)n*LR_NN16_CAP), l1((size_t)n*LR_NN16_CAP);
+        hipMemset(cnt, 0, n*4);
+        hipLaunchKernelGGL(nn16_pass_kernel<1>, grid, dim3(256), 0, 0, H, n, H, nrm, n, tpsb, 1, n, (float*)nullptr, (float*)nullptr, tau, cnt, cand);
+        hipMemcpy(c0.data(), cnt, n*4, hipMemcpyDeviceToHost); hipMemcpy(l0.data(), cand, (size_t)n*LR_NN16_CAP*4, hipMemcpyDeviceToHost);
+        hipMemset(cnt, 0, n*4);
+        hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), 0, 0, H, n, H, nrm, n, tpsb, tau, cnt, cand);
+        hipMemcpy(c1.data(), cnt, n*4, hipMemcpyDeviceToHost); hipMemcpy(l1.data(), cand, (size_t)n*LR_NN16_CAP*4, hipMemcpyDeviceToHost);
+        double tot = 0; int mxc = 0, bad = 0;
+        for (int i = 0; i < n; ++i) {
+            tot += c0[i]; mxc = c0[i] > mxc ? c0[i] : mxc;
+            if (c0[i] != c1[i]) { ++bad; continue; }
+            if (c0[i] > LR_NN16_CAP) continue;
+            std::vector<int32_t> x(l0.begin() + (size_t)i*LR_NN16_CAP, l0.begin() + (size_t)i*LR_NN16_CAP + c0[i]), y(l1.begin() + (size_t)i*LR_NN16_CAP, l1.begin() + (size_t)i*LR_NN16_CAP + c1[i]);
+            std::sort(x.begin(), x.end()); std::sort(y.begin(), y.end());
+            if (x != y) ++bad;
+        }
+        printf("passB (thresholds from stride %d): old %.3f ms  pipelined %.3f ms   candidates/row avg %.2f max %d   rows differing %d\n", stride, msb, msp, tot / n, mxc, bad);
     }
     // pass B with no candidates at all (pure fast path)
     {
         std::vector<float> t(n, -1e30f); hipMemcpy(tau, t.data(), n*4, hipMemcpyHostToDevice);
         int tpsb = (ntiles + strips - 1) / strips; dim3 grid(row_blocks, strips);
         float msb = timeit([&] { hipLaunchKernelGGL(nn16_pass_kernel<1>, grid, dim3(256), 0, 0, H, n, H, nrm, n, tpsb, 1, n, (float*)nullptr, (float*)nullptr, tau, cnt, cand); });
-        printf("passB no candidates: %.3f ms\n", msb);
+        float msp = timeit([&] { hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), 0, 0, H, n, H, nrm, n, tpsb, tau, cnt, cand); });
+        printf("passB no candidates: old %.3f ms  pipelined %.3f ms\n", msb, msp);
     }
     return 0;
 }
