@@ -81,7 +81,10 @@ def main():
         host = [{k: v.cpu().pin_memory() for k, v in pr.items() if k != "T_gt"} for pr in pairs]
         staged = [{k: torch.empty_like(pairs[0][k]) for k in ("xyz0", "xyz1", "f0", "f1")} for _ in range(nstreams)]
 
+    enq = [0.0]
+
     def step():
+        t_enq = time.perf_counter()
         for i in range(args.pairs):
             s = i % nstreams
             pr = pairs[i % len(pairs)]
@@ -92,6 +95,7 @@ def main():
                 pr = staged[s]
             FR.register_pair_dev(pr["xyz0"], pr["xyz1"], pr["f0"], pr["f1"], params, out=outs[i], ws=wss[s],
                                  stream=streams[s].cuda_stream)
+        enq[0] += time.perf_counter() - t_enq
         for s in streams:
             torch.cuda.current_stream().wait_stream(s)
         if world > 1:
@@ -110,6 +114,7 @@ def main():
     for _ in range(args.warmup):
         step()
     sync_all()
+    enq[0] = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -189,7 +194,7 @@ def main():
             "config": {"workload": f"{'configs[1]' if args.n == 30000 else 'configs[4]-like dense'}: {args.n}-pt x32-d synthetic FCGF pair, --mode {args.mode} --iters {args.iters}, "
                                    f"3-pt sampling + ELC + LS refit", "pairs_per_step_per_gpu": args.pairs,
                        "pairs_in_flight_per_gpu": nstreams, "parallelism": f"pair-sharded x{world}"},
-            "recall_5deg_0.6m": round(recall, 4),
+            "recall_5deg_0.6m": round(recall, 4), "host_enqueue_ms_per_step": round(enq[0] / args.steps * 1e3, 3),
             "roofline": roof, "cpu_baseline": cpu,
         }
         if cpu:

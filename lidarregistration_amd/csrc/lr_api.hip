@@ -47,7 +47,7 @@ void carve(lr_workspace *ws, Carver &c)
     ws->fix_list = c.take<int32_t>(n);
     ws->counters = c.take<int32_t>(LR_CNT_TOTAL);
     ws->bmax0 = c.take<float>(n0 / 32 + 2); ws->bmax1 = c.take<float>(n1 / 32 + 2);
-    ws->rev_seed = c.take<uint32_t>(n1);
+    ws->rev_seed = c.take<uint32_t>(n1); ws->rev_rows = c.take<int32_t>(n1);
     ws->nn_idx1 = c.take<int32_t>(n0); ws->nn_idx2 = c.take<int32_t>(n0);
     ws->nn_s1 = c.take<float>(n0); ws->nn_s2 = c.take<float>(n0);
     ws->rev_idx1 = c.take<int32_t>(n1);

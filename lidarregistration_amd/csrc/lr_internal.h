@@ -51,6 +51,7 @@ struct lr_workspace {
     int32_t *cand_cnt, *cand;    // [max_n], [max_n][LR_NN16_CAP] candidate lists
     float *bmax0, *bmax1;        // per-32-row maxima of the norms (f16 filter error bound)
     uint32_t *rev_seed;          // [max_n1] best forward distance pointing at each cloud-1 row (bit pattern)
+    int32_t *rev_rows;           // [max_n1] compacted list of the cloud-1 rows that have one
     int nn_path;                 // LR_NN_PATH_*
     int nn_blocks_target;        // column strips are chosen so that a pass launches about this many blocks
     float *pb1, *pb2, *pb3;      // partial top-3 values [strips][max_n]
@@ -100,6 +101,7 @@ enum {
     LR_CNT_NCORR,        // live M
     LR_CNT_NVALID,       // hypotheses appended to models[]
     LR_CNT_NBB,          // best buddies
+    LR_CNT_NREV,         // rows of the reverse NN pass (cloud-1 points some query points at)
     LR_CNT_COUNT = 16,
     LR_CNT_TOTAL = 64        // counters[16..63] hold lr_ransac_state
 };

@@ -43,9 +43,10 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 __global__ void __launch_bounds__(256)
 nn16_prep_kernel(const float *__restrict__ Fa, int na, _Float16 *__restrict__ Ha, float *__restrict__ nrma, float *__restrict__ bmaxa,
                  const float *__restrict__ Fb, int nb, _Float16 *__restrict__ Hb, float *__restrict__ nrmb, float *__restrict__ bmaxb,
-                 uint32_t *__restrict__ seed_b)
+                 uint32_t *__restrict__ seed_b, int32_t *__restrict__ rev_rows_count)
 {
     __shared__ float s_m[4];
+    if (rev_rows_count && blockIdx.x == 0 && threadIdx.x == 0) *rev_rows_count = 0;      // lr_nn16_reverse compacts into it
     // blocks [0, ceil(na/32)) prepare cloud a, the rest cloud b (one launch for the pair)
     const int nblk_a = (na + 31) >> 5;
     const bool second = (int)blockIdx.x >= nblk_a;
@@ -94,35 +95,22 @@ nn16_prep_kernel(const float *__restrict__ Fa, int na, _Float16 *__restrict__ Ha
     if (threadIdx.x == 0) block_max[blk] = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
 }
 
-// ------------------------------------------------------------------ pass A / pass B
-// Block = 4 waves x 64 query rows = 256 rows; the block walks the column tiles of its strip in chunks of LR_CH
-// tiles that are staged once through LDS (register-staged, double-buffered, one barrier per chunk) and shared by
-// the four waves.  LDS image: one 80-byte row per column (64 B of f16 + 16 B pad): with that stride the two
+// ------------------------------------------------------------------ pass A
+// Block = 4 waves x 64 query rows = 256 rows; the block walks every `tile_stride`-th column tile of its strip in chunks
+// of LR_CH tiles that are staged once through LDS (register-staged, double-buffered, one barrier per chunk) and shared
+// by the four waves.  LDS image: one 80-byte row per column (64 B of f16 + 16 B pad): with that stride the two
 // ds_read_b128 of a fragment are bank-conflict-free for the b128 lane groups.
-//
-//   MODE 0 (pass A): running two largest g = dot16 - n1[j]/2 per accumulator element over the sampled tiles
-//                    (u' = -2 g, so the two largest g are the two smallest u') -> partials [strip][row]
-//   MODE 1 (pass B): the accumulator is started at y_i = tau_i / 2 instead of 0, so the candidate test
-//                    u' <= tau_i  <=>  dot16 + y_i >= n1[j]/2  is ONE v_cmp per element; lane masks are OR-ed on
-//                    the scalar unit and looked at once per 8 accumulator registers.  Candidates are appended to
-//                    the (row, strip) slot list; the per-row counters live in LDS (rows are private to the block
-//                    within a strip), so the hot loop issues no global atomics.
+// Output: the two largest g = dot16 - n1[j]/2 per query row over the sampled tiles (u' = -2 g, so the two largest g
+// are the two smallest u') -> partials [strip][row].
 #define LR_CH 4
 #define LR_LDS_ROW 80
-#ifndef LR_RB
-#define LR_RB 2                  // 32-row MFMA blocks per wave (rows per wave = 32 LR_RB, rows per block = 128 LR_RB)
-#endif
+#define LR_RB 2                  // 32-row MFMA blocks per wave (rows per wave = 64, rows per block = 256)
 #define LR_BLOCK_ROWS (128 * LR_RB)
-template <int MODE>
 __global__ void __launch_bounds__(256)
-nn16_pass_kernel(const _Float16 *__restrict__ Hq, int na, const _Float16 *__restrict__ Hc, const float *__restrict__ nC, int nb,
-                 int tiles_per_strip, int tile_stride, int part_stride,
-                 float *__restrict__ pg1, float *__restrict__ pg2,
-                 const float *__restrict__ tau, int32_t *__restrict__ cand_cnt, int32_t *__restrict__ cand)
+nn16_passa_kernel(const _Float16 *__restrict__ Hq, int na, const _Float16 *__restrict__ Hc, const float *__restrict__ nC, int nb,
+                  int tiles_per_strip, int tile_stride, int part_stride, float *__restrict__ pg1, float *__restrict__ pg2)
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][LR_CH * 32 * LR_LDS_ROW + LR_CH * 32 * 4];
-    __shared__ int s_list[LR_NN16_LIST];      // block-level candidate list: (local row << 22) | column
-    __shared__ int s_n;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r = lane & 31, h = lane >> 5;
     const int row0 = blockIdx.x * LR_BLOCK_ROWS + wave * 32 * LR_RB;
@@ -132,9 +120,6 @@ nn16_pass_kernel(const _Float16 *__restrict__ Hq, int na, const _Float16 *__rest
     const int t_end = min(ntiles, t_begin + tiles_per_strip);
     const int nsamp = t_end > t_begin ? (t_end - t_begin + tile_stride - 1) / tile_stride : 0;   // tiles this block visits
     const int nchunks = (nsamp + LR_CH - 1) / LR_CH;
-    if (MODE == 1) {
-        if (tid == 0) s_n = 0;
-    }
 
     f16x8 a[LR_RB][2];
 #pragma unroll
@@ -143,19 +128,11 @@ nn16_pass_kernel(const _Float16 *__restrict__ Hq, int na, const _Float16 *__rest
         const f16x8 *p = reinterpret_cast<const f16x8 *>(Hq + (size_t)row * 32 + 16 * h);
         a[rb][0] = p[0]; a[rb][1] = p[1];
     }
-    f32x16 st1[LR_RB];      // MODE 0: per-lane running maximum of g; MODE 1: y = tau/2 of the element's row
+    f32x16 st1[LR_RB];      // per-lane running maximum of g
 #pragma unroll
     for (int rb = 0; rb < LR_RB; ++rb)
 #pragma unroll
-        for (int g = 0; g < 16; ++g) {
-            if (MODE == 0) st1[rb][g] = -LR_INF;
-            else {
-                // unconditional (clamped) loads: a conditional load here turns into serialized round trips
-                const int row = row0 + 32 * rb + (g & 3) + 8 * (g >> 2) + 4 * h;
-                const float tv = tau[min(row, na - 1)];
-                st1[rb][g] = row < na ? 0.5f * tv : -LR_INF;
-            }
-        }
+        for (int g = 0; g < 16; ++g) st1[rb][g] = -LR_INF;
 
     // staging: thread t moves LR_CH/2 16-byte pieces per chunk (piece p -> column p/4 of the chunk, 16-byte part p%4)
     f32x4 stage[LR_CH / 2];
@@ -195,15 +172,6 @@ nn16_pass_kernel(const _Float16 *__restrict__ Hq, int na, const _Float16 *__rest
         b1 = *reinterpret_cast<const f16x8 *>(bp + 16);
         xj = *reinterpret_cast<const float *>(&lds[buf][LR_CH * 32 * LR_LDS_ROW + (32 * k + r) * 4]);
     };
-    // two 32-row blocks (rb0, rb0+1) against one column fragment; accumulators start at y in MODE 1
-    auto mma2 = [&](int rb0, const f16x8 &b0, const f16x8 &b1, f32x16 (&acc)[2]) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            if (MODE == 0) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rb0 + q][0], b0, f32x16{ 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, 0, 0, 0);
-            else acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rb0 + q][0], b0, st1[rb0 + q], 0, 0, 0);
-            acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rb0 + q][1], b1, acc[q], 0, 0, 0);
-        }
-    };
 
     if (nchunks > 0) { load_chunk(0); store_chunk(0); }
     __syncthreads();
@@ -215,69 +183,26 @@ nn16_pass_kernel(const _Float16 *__restrict__ Hq, int na, const _Float16 *__rest
             for (int k = 0; k < LR_CH; ++k) {
                 f16x8 b0, b1; float xj;
                 read_b(buf, k, b0, b1, xj);
+                f32x16 acc[2];
 #pragma unroll
-                for (int rb0 = 0; rb0 < LR_RB; rb0 += 2) {
-                    f32x16 acc[2];
-                    mma2(rb0, b0, b1, acc);
-                    if (MODE == 0) {
-                        // pass A: per-lane running maximum of g = dot16 - x_j (2 VALU ops per element).  The two largest of
-                        // the 32 lane maxima of a row belong to two different columns, so the smaller of them is a valid
-                        // (and almost always exact) lower bound of the row's 2nd largest g.
-#pragma unroll
-                        for (int q = 0; q < 2; ++q)
-#pragma unroll
-                            for (int g = 0; g < 16; ++g) st1[rb0 + q][g] = fmaxf(st1[rb0 + q][g], acc[q][g] - xj);
-                    } else {
-                        // pass B: look at the accumulators in groups of 8 registers (one scalar test each); candidates are
-                        // parked right away in the block's LDS list (one LDS atomic + one LDS store each) and sorted into
-                        // the per-row slots after the main loop, which keeps this path light on registers
-#pragma unroll
-                        for (int q = 0; q < 2; ++q)
-#pragma unroll
-                            for (int g0 = 0; g0 < 16; g0 += 8) {
-                                bool any = false;
-#pragma unroll
-                                for (int g = g0; g < g0 + 8; ++g) any |= (acc[q][g] >= xj);
-                                if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
-                                    const int col = chunk_col(c, 32 * k + r);
-                                    const int lbase = (wave * 32 * LR_RB + 32 * (rb0 + q) + 4 * h) << 22;
-#pragma unroll
-                                    for (int g = g0; g < g0 + 8; ++g)
-                                        if (acc[q][g] >= xj) {
-                                            const int slot = atomicAdd(&s_n, 1);
-                                            if (slot < LR_NN16_LIST) s_list[slot] = (lbase + (((g & 3) + 8 * (g >> 2)) << 22)) | col;
-                                        }
-                                }
-                            }
-                    }
+                for (int q = 0; q < 2; ++q) {
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[q][0], b0, f32x16{ 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, 0, 0, 0);
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[q][1], b1, acc[q], 0, 0, 0);
                 }
+                // per-lane running maximum of g = dot16 - x_j (2 VALU ops per element).  The two largest of the 32 lane
+                // maxima of a row belong to two different columns, so the smaller of them is a valid (and almost always
+                // exact) lower bound of the row's 2nd largest g.
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) st1[q][g] = fmaxf(st1[q][g], acc[q][g] - xj);
             }
         }
         if (c + 1 < nchunks) store_chunk(buf ^ 1);
         __syncthreads();
     }
 
-    if (MODE == 1) {
-        // distribute the parked candidates to the per-row slot lists (shared by all strips; global atomics, but outside the
-        // hot loop and spread over 256 threads).  A block that overflowed its LDS list marks all its rows as overflowed,
-        // which sends them through the exact full-row scan.
-        const int n_list = s_n;
-        if (n_list > LR_NN16_LIST) {
-            for (int t = tid; t < LR_BLOCK_ROWS; t += 256) {
-                const int row = blockIdx.x * LR_BLOCK_ROWS + t;
-                if (row < na) atomicAdd(&cand_cnt[row], LR_NN16_CAP + 1);
-            }
-        } else {
-            for (int e = tid; e < n_list; e += 256) {
-                const int v = s_list[e];
-                const int row = blockIdx.x * LR_BLOCK_ROWS + ((v >> 22) & 0x3ff), col = v & 0x3fffff;
-                if (col >= nb) continue;      // padding columns pass the test only when tau is +inf (fewer than `need` samples)
-                const int slot = atomicAdd(&cand_cnt[row], 1);
-                if (slot < LR_NN16_CAP) cand[(size_t)row * LR_NN16_CAP + slot] = col;
-            }
-        }
-    }
-    if (MODE == 0 && row0 < na) {
+    if (row0 < na) {
         // two largest of the 32 lane maxima of each row (lanes of one half hold the same rows, different columns)
         const size_t base = (size_t)strip * part_stride;
 #pragma unroll
@@ -299,7 +224,9 @@ nn16_pass_kernel(const _Float16 *__restrict__ Hq, int na, const _Float16 *__rest
 }
 
 // ------------------------------------------------------------------ pass B, software-pipelined
-// Same candidate sets as nn16_pass_kernel<1>, different instruction order.  A 32x32x16 MFMA occupies the matrix pipe for
+// The accumulator is started at y_i = tau_i / 2 instead of 0, so the candidate test u' <= tau_i  <=>  dot16 + y_i >= n1[j]/2
+// needs no per-element arithmetic: the lane's largest of 8 accumulator registers is compared with x_j = n1[j]/2 once.
+// A 32x32x16 MFMA occupies the matrix pipe for
 // 32 cycles but holds the SIMD's vector issue for only 8 of them, so the candidate test of tile t-1 (3 v_max3 + 1 v_max +
 // 1 v_cmp + 1 scalar branch per 8 accumulator registers) is placed in the shadow of the MFMAs of tile t: every test
 // group follows one MFMA in program order and its branch ends the basic block, so the compiler cannot pull the pieces
@@ -309,18 +236,20 @@ nn16_pass_kernel(const _Float16 *__restrict__ Hq, int na, const _Float16 *__rest
 #ifndef LR_PB_CH
 #define LR_PB_CH 4
 #endif
-#ifndef LR_PB_PIPE
-#define LR_PB_PIPE 1
-#endif
 #ifndef LR_PB_EXP
 #define LR_PB_EXP 0     // development switches (tools/nn16_micro.hip): 1 no staging, 2 no tests
 #endif
 #define LR_PB_WLIST 512          // entries per wave (8 bytes each)
 
 __global__ void __launch_bounds__(256)
-nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na, const _Float16 *__restrict__ Hc, const float *__restrict__ nC, int nb,
+nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *__restrict__ rowmap, const int32_t *__restrict__ na_dev,
+                  const _Float16 *__restrict__ Hc, const float *__restrict__ nC, int nb,
                   int tiles_per_strip, const float *__restrict__ tau, int32_t *__restrict__ cand_cnt, int32_t *__restrict__ cand)
 {
+    // rows: either 0..na_host-1, or (reverse direction) the compacted list rowmap[0..*na_dev-1]; tau, cand_cnt and cand
+    // are indexed by the position in that list
+    const int na = na_dev ? *na_dev : na_host;
+    if ((int)blockIdx.x * LR_BLOCK_ROWS >= na) return;
     constexpr int CH = LR_PB_CH;
     constexpr int XOFF = CH * 32 * LR_LDS_ROW;
     constexpr int BUF = XOFF + CH * 32 * 4;
@@ -338,7 +267,8 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na, const _Float16 *__res
     f32x16 y[2];
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
-        const int row = min(row0 + 32 * rb + r, na - 1);
+        int row = min(row0 + 32 * rb + r, na - 1);
+        if (rowmap) row = rowmap[row];
         const f16x8 *p = reinterpret_cast<const f16x8 *>(Hq + (size_t)row * 32 + 16 * h);
         a[rb][0] = p[0]; a[rb][1] = p[1];
 #pragma unroll
@@ -536,19 +466,22 @@ __global__ void __launch_bounds__(256)
 nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, int na,
                   const float *__restrict__ Fc, const float *__restrict__ nC, int nb,
                   const int32_t *__restrict__ cand_cnt, const int32_t *__restrict__ cand, int need,
-                  const uint32_t *__restrict__ skip_seed,
+                  const int32_t *__restrict__ rowmap, const int32_t *__restrict__ na_dev,
                   int32_t *__restrict__ idx1, int32_t *__restrict__ idx2, float *__restrict__ s1o, float *__restrict__ s2o,
                   int32_t *__restrict__ counters)
 {
     const int gid = blockIdx.x * 256 + threadIdx.x;
     const int row = gid >> 2, q = gid & 3;
+    if (na_dev) na = *na_dev;                  // compacted row list (reverse direction): lists by position, data by rowmap[]
+    if ((int)blockIdx.x * 64 >= na) return;
     const bool live = row < na;
     const int rowc = live ? row : na - 1;
+    const int rowd = rowmap ? rowmap[rowc] : rowc;
     float a[32];
-    const f32x4 *pa = reinterpret_cast<const f32x4 *>(Fq + (size_t)rowc * 32);
+    const f32x4 *pa = reinterpret_cast<const f32x4 *>(Fq + (size_t)rowd * 32);
 #pragma unroll
     for (int k = 0; k < 8; ++k) { f32x4 t = pa[k]; a[4 * k] = t.x; a[4 * k + 1] = t.y; a[4 * k + 2] = t.z; a[4 * k + 3] = t.w; }
-    const float nq = nQ[rowc];
+    const float nq = nQ[rowd];
     float b1 = LR_INF, b2 = LR_INF;
     int i1 = LR_IMAX, i2 = LR_IMAX;
     const int total = cand_cnt[rowc];
@@ -572,8 +505,7 @@ nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, in
         if (sj_lt(sv, j, b1, i1)) { b2 = b1; i2 = i1; b1 = sv; i1 = j; }
         else if (sj_lt(sv, j, b2, i2)) { b2 = sv; i2 = j; }
     }
-    const bool skip = skip_seed && !(__uint_as_float(skip_seed[rowc]) < 3.0e38f);   // reverse NN nobody asked for
-    if (!skip && (over || total < min(need, nb))) {
+    if (over || total < min(need, nb)) {
         // candidate list overflowed (duplicate-heavy input) or could not be filled (non-finite f16 values): the four
         // lanes of the row scan every column exactly -- slow, rare, and by construction the reference answer
         b1 = LR_INF; b2 = LR_INF; i1 = LR_IMAX; i2 = LR_IMAX;
@@ -608,18 +540,17 @@ nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, in
         b2 = sy ? y1 : x2; i2 = sy ? yi1 : xi2;
     }
     if (!live || q != 0) return;
-    if (skip) { idx1[row] = -1; return; }
-    idx1[row] = i1;
-    if (idx2) idx2[row] = i2;
-    if (s1o) s1o[row] = b1;
-    if (s2o) s2o[row] = b2;
+    idx1[rowd] = i1;
+    if (idx2) idx2[rowd] = i2;
+    if (s1o) s1o[rowd] = b1;
+    if (s2o) s2o[rowd] = b2;
 }
 
 // ------------------------------------------------------------------ host side
 int lr_nn16_prep(lr_workspace *ws, const float *F0, int n0, const float *F1, int n1, hipStream_t st)
 {
     hipLaunchKernelGGL(nn16_prep_kernel, dim3(lr_cdiv(n0, 32) + lr_cdiv(n1, 32)), dim3(256), 0, st, F0, n0, ws->H0, ws->nrm0, ws->bmax0,
-                       F1, n1, ws->H1, ws->nrm1, ws->bmax1, ws->rev_seed);
+                       F1, n1, ws->H1, ws->nrm1, ws->bmax1, ws->rev_seed, ws->counters + LR_CNT_NREV);
     LR_LAUNCH_CHECK();
     return LR_OK;
 }
@@ -642,20 +573,15 @@ int lr_nn16_run(lr_workspace *ws, const float *Fq, const _Float16 *Hq, const flo
     if (strips < 1) strips = 1;
     const int tps = lr_cdiv(lr_cdiv(ntiles, strips), stride) * stride;     // tiles per strip, multiple of the stride
     dim3 grid(row_blocks, strips);
-    hipLaunchKernelGGL(nn16_pass_kernel<0>, grid, dim3(256), 0, st, Hq, na, Hc, nC, nb, tps, stride, ws->max_n, ws->pb1, ws->pb2,
-                       (const float *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
+    hipLaunchKernelGGL(nn16_passa_kernel, grid, dim3(256), 0, st, Hq, na, Hc, nC, nb, tps, stride, ws->max_n, ws->pb1, ws->pb2);
     hipLaunchKernelGGL(nn16_thresh_kernel, dim3(lr_cdiv(na, 256)), dim3(256), 0, st, na, strips, ws->max_n, ws->pb1, ws->pb2, nQ,
                        block_max_c, lr_cdiv(nb, 32), need, ws->tau, ws->cand_cnt);
     if (ws->timing && !ws->ev_pending) { LR_HIP(hipEventRecord(ws->ev[0], st)); }
-#if LR_PB_PIPE
-    hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), 0, st, Hq, na, Hc, nC, nb, tps, ws->tau, ws->cand_cnt, ws->cand);
-#else
-    hipLaunchKernelGGL(nn16_pass_kernel<1>, grid, dim3(256), 0, st, Hq, na, Hc, nC, nb, tps, 1, ws->max_n, (float *)nullptr,
-                       (float *)nullptr, ws->tau, ws->cand_cnt, ws->cand);
-#endif
+    hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), 0, st, Hq, na, (const int32_t *)nullptr, (const int32_t *)nullptr, Hc, nC, nb,
+                       tps, ws->tau, ws->cand_cnt, ws->cand);
     if (ws->timing && !ws->ev_pending) { LR_HIP(hipEventRecord(ws->ev[1], st)); ws->ev_pending = 1; }
     hipLaunchKernelGGL(nn16_exact_kernel, dim3(lr_cdiv(na, 64)), dim3(256), 0, st, Fq, nQ, na, Fc, nC, nb, ws->cand_cnt, ws->cand,
-                       need, (const uint32_t *)nullptr, idx1, idx2, s1, s2, ws->counters);
+                       need, (const int32_t *)nullptr, (const int32_t *)nullptr, idx1, idx2, s1, s2, ws->counters);
     LR_LAUNCH_CHECK();
     return LR_OK;
 }
@@ -664,7 +590,8 @@ int lr_nn16_run(lr_workspace *ws, const float *Fq, const _Float16 *Hq, const flo
 // The mutual test only asks, for a column j that some query i points at, whether any other row beats that pair.  So the
 // reverse direction needs no sampling pass: the exact distance of the best forward pair (i*, j) IS an upper bound of the
 // column's minimum, and pass B looks for rows with u' <= s*^2 (1 + 4e-7) - n_j + E.  Columns nobody points at are
-// skipped (their reverse NN is reported as -1; the reference does not compute it either, matching.py:224-225).
+// left out altogether (their reverse NN is reported as -1; the reference does not compute it either,
+// matching.py:224-225): the rows of the reverse pass are the compacted list of the pointed-at columns.
 __global__ void __launch_bounds__(256)
 nn16_rev_seed_kernel(const float *__restrict__ F0, const float *__restrict__ n0v, int n0, const float *__restrict__ F1,
                      const float *__restrict__ n1v, const int32_t *__restrict__ idx1, uint32_t *__restrict__ seed_bits)
@@ -689,27 +616,40 @@ nn16_rev_seed_kernel(const float *__restrict__ F0, const float *__restrict__ n0v
     atomicMin(&seed_bits[j], __float_as_uint(sv));      // sv > 0: bit patterns order like the values
 }
 
+// thresholds of the seeded rows + their compaction: rowmap[pos] = row, tau[pos], cand_cnt[pos] = 0, *n_rows = count.
+// One global atomic per block (the order of the list does not matter: every result is written back by row id).
 __global__ void __launch_bounds__(256)
 nn16_thresh_seed_kernel(int na, const uint32_t *__restrict__ seed_bits, const float *__restrict__ nQ,
-                        const float *__restrict__ block_max_c, int nblk_c, float *__restrict__ tau, int32_t *__restrict__ cand_cnt)
+                        const float *__restrict__ block_max_c, int nblk_c, float *__restrict__ tau, int32_t *__restrict__ cand_cnt,
+                        int32_t *__restrict__ rowmap, int32_t *__restrict__ n_rows, int32_t *__restrict__ rev_out)
 {
     __shared__ float s_m[4];
+    __shared__ int s_cnt[4], s_base;
     const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    const int wave = threadIdx.x >> 6;
     float mx = 0.0f;
     for (int b = threadIdx.x; b < nblk_c; b += 256) mx = fmaxf(mx, block_max_c[b]);
 #pragma unroll
     for (int k = 32; k >= 1; k >>= 1) mx = fmaxf(mx, __shfl_xor(mx, k));
-    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = mx;
+    if ((threadIdx.x & 63) == 0) s_m[wave] = mx;
+    const float sv = row < na ? __uint_as_float(seed_bits[row]) : LR_INF;
+    const bool seeded = sv < 3.0e38f;                      // else still the 0x7f7f7f7f fill: no query points at this row
+    const unsigned long long bal = __builtin_amdgcn_ballot_w64(seeded);
+    if ((threadIdx.x & 63) == 0) s_cnt[wave] = __builtin_popcountll(bal);
     __syncthreads();
-    const float max_nc = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+    if (threadIdx.x == 0) s_base = atomicAdd(n_rows, s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3]);
+    __syncthreads();
     if (row >= na) return;
-    cand_cnt[row] = 0;
-    const float sv = __uint_as_float(seed_bits[row]);
-    if (!(sv < 3.0e38f)) { tau[row] = -LR_INF; return; }      // still the 0x7f7f7f7f fill: no query points at this row
+    if (!seeded) { rev_out[row] = -1; return; }
+    int pos = s_base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+    for (int w = 0; w < wave; ++w) pos += s_cnt[w];
+    const float max_nc = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
     const float scale = nQ[row] + max_nc;
     const float E = 1.05e-3f * scale + 4e-7f;
     const float d2hi = sv * sv * (1.0f + 6e-7f);               // every d2 whose sqrt rounds to <= sv lies below this
-    tau[row] = (d2hi - nQ[row]) + E + 6e-6f * scale + 2e-6f * d2hi;
+    rowmap[pos] = row;
+    tau[pos] = (d2hi - nQ[row]) + E + 6e-6f * scale + 2e-6f * d2hi;
+    cand_cnt[pos] = 0;
 }
 
 int lr_nn16_reverse(lr_workspace *ws, const float *F0, const _Float16 *H0, const float *nrm0, const float *bmax0, int n0,
@@ -726,19 +666,18 @@ int lr_nn16_reverse(lr_workspace *ws, const float *F0, const _Float16 *H0, const
     if (strips > LR_NN_MAX_STRIPS) strips = LR_NN_MAX_STRIPS;
     if (strips < 1) strips = 1;
     const int tps = lr_cdiv(ntiles, strips);
-    uint32_t *seed = ws->rev_seed;          // filled with 0x7f7f7f7f by the prep kernel of this pair
+    uint32_t *seed = ws->rev_seed;          // filled with 0x7f7f7f7f, and the row counter zeroed, by the prep kernel of this pair
+    int32_t *n_rows = ws->counters + LR_CNT_NREV;
     hipLaunchKernelGGL(nn16_rev_seed_kernel, dim3(lr_cdiv(n0, 256)), dim3(256), 0, st, F0, nrm0, n0, F1, nrm1, fwd_idx1, seed);
     hipLaunchKernelGGL(nn16_thresh_seed_kernel, dim3(lr_cdiv(na, 256)), dim3(256), 0, st, na, seed, nrm1, bmax0, lr_cdiv(nb, 32),
-                       ws->tau, ws->cand_cnt);
+                       ws->tau, ws->cand_cnt, ws->rev_rows, n_rows, rev);
+    // grids are sized for all rows; blocks past the compacted count leave at once
     dim3 grid(row_blocks, strips);
-#if LR_PB_PIPE
-    hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), 0, st, H1, na, H0, nrm0, nb, tps, ws->tau, ws->cand_cnt, ws->cand);
-#else
-    hipLaunchKernelGGL(nn16_pass_kernel<1>, grid, dim3(256), 0, st, H1, na, H0, nrm0, nb, tps, 1, ws->max_n, (float *)nullptr,
-                       (float *)nullptr, ws->tau, ws->cand_cnt, ws->cand);
-#endif
+    hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), 0, st, H1, na, (const int32_t *)ws->rev_rows, (const int32_t *)n_rows, H0, nrm0,
+                       nb, tps, ws->tau, ws->cand_cnt, ws->cand);
     hipLaunchKernelGGL(nn16_exact_kernel, dim3(lr_cdiv(na, 64)), dim3(256), 0, st, F1, nrm1, na, F0, nrm0, nb, ws->cand_cnt, ws->cand,
-                       1, seed, rev, (int32_t *)nullptr, (float *)nullptr, (float *)nullptr, ws->counters);
+                       1, (const int32_t *)ws->rev_rows, (const int32_t *)n_rows, rev, (int32_t *)nullptr, (float *)nullptr, (float *)nullptr,
+                       ws->counters);
     LR_LAUNCH_CHECK();
     return LR_OK;
 }

@@ -1,4 +1,4 @@
-// Timing harness for nn16_pass_kernel (development tool).  hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tools/nn16_micro.hip -o tools/bin/nn16_micro
+// Timing harness for the nn16 pass A / pass B kernels (development tool).  hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tools/nn16_micro.hip -o tools/bin/nn16_micro
 #include "../lidarregistration_amd/csrc/lr_nn16.hip"
 #include <vector>
 #include <random>
@@ -26,45 +26,32 @@ int main(int argc, char **argv)
     hipMemcpy(F, h.data(), (size_t)n*128, hipMemcpyHostToDevice);
     hipMemset(mx, 0, 8);
     float *bmax; hipMalloc(&bmax, (n/32+2)*4);
-    hipLaunchKernelGGL(nn16_prep_kernel, dim3((n+31)/32), dim3(256), 0, 0, F, n, H, nrm, bmax, F, 0, H, nrm, bmax, (uint32_t*)nullptr);
+    hipLaunchKernelGGL(nn16_prep_kernel, dim3((n+31)/32), dim3(256), 0, 0, F, n, H, nrm, bmax, F, 0, H, nrm, bmax, (uint32_t*)nullptr, (int32_t*)nullptr);
     int ntiles = (n + 31) / 32;
     int row_blocks = (n + LR_BLOCK_ROWS - 1) / LR_BLOCK_ROWS;
     for (int stride : {1, 2, 4}) {
         int tps = ((ntiles + strips - 1) / strips + stride - 1) / stride * stride;
         dim3 grid(row_blocks, strips);
-        float ms = timeit([&] { hipLaunchKernelGGL(nn16_pass_kernel<0>, grid, dim3(256), 0, 0, H, n, H, nrm, n, tps, stride, n, pu1, pu2, (const float*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr); });
+        float ms = timeit([&] { hipLaunchKernelGGL(nn16_passa_kernel, grid, dim3(256), 0, 0, H, n, H, nrm, n, tps, stride, n, pu1, pu2); });
         printf("passA stride %d strips %d: %.3f ms\n", stride, strips, ms);
         // thresholds from this pass A, then pass B
         hipLaunchKernelGGL(nn16_thresh_kernel, dim3((n+255)/256), dim3(256), 0, 0, n, strips, n, pu1, pu2, nrm, (const float*)bmax, (n+31)/32, 2, tau, cnt);
         int tpsb = (ntiles + strips - 1) / strips;
-        float msb = timeit([&] { hipLaunchKernelGGL(nn16_pass_kernel<1>, grid, dim3(256), 0, 0, H, n, H, nrm, n, tpsb, 1, n, (float*)nullptr, (float*)nullptr, tau, cnt, cand); });
-        float msp = timeit([&] { hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), 0, 0, H, n, H, nrm, n, tpsb, tau, cnt, cand); });
-        // one counted launch of each, candidate sets compared per row
-        std::vector<int32_t> c0(n), c1(n), l0((size_t)n*LR_NN16_CAP), l1((size_t)n*LR_NN16_CAP);
+        float msp = timeit([&] { hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), 0, 0, H, n, (const int32_t*)nullptr, (const int32_t*)nullptr, H, nrm, n, tpsb, tau, cnt, cand); });
+        std::vector<int32_t> c1(n);
         hipMemset(cnt, 0, n*4);
-        hipLaunchKernelGGL(nn16_pass_kernel<1>, grid, dim3(256), 0, 0, H, n, H, nrm, n, tpsb, 1, n, (float*)nullptr, (float*)nullptr, tau, cnt, cand);
-        hipMemcpy(c0.data(), cnt, n*4, hipMemcpyDeviceToHost); hipMemcpy(l0.data(), cand, (size_t)n*LR_NN16_CAP*4, hipMemcpyDeviceToHost);
-        hipMemset(cnt, 0, n*4);
-        hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), 0, 0, H, n, H, nrm, n, tpsb, tau, cnt, cand);
-        hipMemcpy(c1.data(), cnt, n*4, hipMemcpyDeviceToHost); hipMemcpy(l1.data(), cand, (size_t)n*LR_NN16_CAP*4, hipMemcpyDeviceToHost);
-        double tot = 0; int mxc = 0, bad = 0;
-        for (int i = 0; i < n; ++i) {
-            tot += c0[i]; mxc = c0[i] > mxc ? c0[i] : mxc;
-            if (c0[i] != c1[i]) { ++bad; continue; }
-            if (c0[i] > LR_NN16_CAP) continue;
-            std::vector<int32_t> x(l0.begin() + (size_t)i*LR_NN16_CAP, l0.begin() + (size_t)i*LR_NN16_CAP + c0[i]), y(l1.begin() + (size_t)i*LR_NN16_CAP, l1.begin() + (size_t)i*LR_NN16_CAP + c1[i]);
-            std::sort(x.begin(), x.end()); std::sort(y.begin(), y.end());
-            if (x != y) ++bad;
-        }
-        printf("passB (thresholds from stride %d): old %.3f ms  pipelined %.3f ms   candidates/row avg %.2f max %d   rows differing %d\n", stride, msb, msp, tot / n, mxc, bad);
+        hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), 0, 0, H, n, (const int32_t*)nullptr, (const int32_t*)nullptr, H, nrm, n, tpsb, tau, cnt, cand);
+        hipMemcpy(c1.data(), cnt, n*4, hipMemcpyDeviceToHost);
+        double tot = 0; int mxc = 0;
+        for (int i = 0; i < n; ++i) { tot += c1[i]; mxc = c1[i] > mxc ? c1[i] : mxc; }
+        printf("passB (thresholds from stride %d): %.3f ms   candidates/row avg %.2f max %d\n", stride, msp, tot / n, mxc);
     }
     // pass B with no candidates at all (pure fast path)
     {
         std::vector<float> t(n, -1e30f); hipMemcpy(tau, t.data(), n*4, hipMemcpyHostToDevice);
         int tpsb = (ntiles + strips - 1) / strips; dim3 grid(row_blocks, strips);
-        float msb = timeit([&] { hipLaunchKernelGGL(nn16_pass_kernel<1>, grid, dim3(256), 0, 0, H, n, H, nrm, n, tpsb, 1, n, (float*)nullptr, (float*)nullptr, tau, cnt, cand); });
-        float msp = timeit([&] { hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), 0, 0, H, n, H, nrm, n, tpsb, tau, cnt, cand); });
-        printf("passB no candidates: old %.3f ms  pipelined %.3f ms\n", msb, msp);
+        float msp = timeit([&] { hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), 0, 0, H, n, (const int32_t*)nullptr, (const int32_t*)nullptr, H, nrm, n, tpsb, tau, cnt, cand); });
+        printf("passB no candidates: %.3f ms\n", msp);
     }
     return 0;
 }
