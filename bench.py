@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--n", type=int, default=30000, help="points per cloud")
     ap.add_argument("--iters", type=int, default=50000)
     ap.add_argument("--mode", default="MNN")
-    ap.add_argument("--streams", type=int, default=16, help="pairs in flight per GPU")
+    ap.add_argument("--streams", type=int, default=32, help="pairs in flight per GPU")
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic pairs generated per GPU")
     ap.add_argument("--include-h2d", action="store_true", help="copy each pair from pinned host memory inside the timed region (PCIe-inclusive rate; not the headline value)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

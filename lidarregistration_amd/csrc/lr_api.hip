@@ -61,7 +61,7 @@ void carve(lr_workspace *ws, Carver &c)
     ws->gpf_cells = c.take<int32_t>(3 * (LR_GPF_MAX_CELLS + 8));
     ws->gpf_keep = c.take<uint8_t>(n0);
     ws->gpf_f = c.take<float>(8);
-    ws->corr8 = c.take<float>(n0 * 8);
+    ws->corr8 = c.take<float>((n0 + 2) * 8);
     ws->models = c.take<float>(it * 12);
     ws->models64 = c.take<double>(it * 12);
     ws->model_h = c.take<int32_t>(it);

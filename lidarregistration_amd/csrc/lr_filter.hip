@@ -73,12 +73,13 @@ compact_kernel(int n0, const uint8_t *__restrict__ flags, const int32_t *__restr
         if (o1) o1[slot] = idx1[i];
         if (o2 && idx2) o2[slot] = idx2[i];
         if (oscore && score) oscore[slot] = score[i];
-        if (corr8) {        // fused pack_corr_kernel: the survivor's point pair as one 32-byte record for the RANSAC kernels
+        if (corr8) {        // fused pack_corr_kernel: the survivor's point pair in the RANSAC kernels' record layout
             const int b = idx1[i];
-            float4 lo = { xyz0[3 * i], xyz0[3 * i + 1], xyz0[3 * i + 2], xyz1[3 * b] };
-            float4 hi = { xyz1[3 * b + 1], xyz1[3 * b + 2], 0.0f, 0.0f };
-            reinterpret_cast<float4 *>(corr8)[2 * slot] = lo;
-            reinterpret_cast<float4 *>(corr8)[2 * slot + 1] = hi;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                corr8[lr_corr_at(slot, k)] = xyz0[3 * i + k];
+                corr8[lr_corr_at(slot, 3 + k)] = xyz1[3 * b + k];
+            }
         }
     }
     if (corr8 && blockIdx.x == 0 && tid < LR_CNT_TOTAL - LR_CNT_COUNT) {     // the RANSAC that follows starts from scratch
@@ -128,7 +129,8 @@ int lr_identity_corr(lr_workspace *ws, int n0, const int32_t *idx1, const int32_
 }
 
 // ------------------------------------------------------------------ pack survivors for RANSAC
-// corr8[c] = { p.x p.y p.z q.x q.y q.z 0 0 } (32 B): one s_load_dwordx8 per correspondence in the scoring loop
+// corr8: point pairs in the pair-interleaved record layout of lr_corr_at (one 64-byte scalar load per two
+// correspondences in the scoring loop)
 __global__ void pack_corr_kernel(const float *__restrict__ xyz0, const float *__restrict__ xyz1,
                                  const int32_t *__restrict__ i0, const int32_t *__restrict__ i1,
                                  int m_max, const int32_t *__restrict__ m_dev, float *__restrict__ corr8,
@@ -140,10 +142,11 @@ __global__ void pack_corr_kernel(const float *__restrict__ xyz0, const float *__
     int m = m_dev ? min(*m_dev, m_max) : m_max;
     if (c >= m) return;
     int a = i0 ? i0[c] : c, b = i1 ? i1[c] : c;
-    float4 lo = { xyz0[3 * a], xyz0[3 * a + 1], xyz0[3 * a + 2], xyz1[3 * b] };
-    float4 hi = { xyz1[3 * b + 1], xyz1[3 * b + 2], 0.0f, 0.0f };
-    reinterpret_cast<float4 *>(corr8)[2 * c] = lo;
-    reinterpret_cast<float4 *>(corr8)[2 * c + 1] = hi;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        corr8[lr_corr_at(c, k)] = xyz0[3 * a + k];
+        corr8[lr_corr_at(c, 3 + k)] = xyz1[3 * b + k];
+    }
 }
 
 int lr_pack_corr(lr_workspace *ws, const float *xyz0, const float *xyz1, const int32_t *i0, const int32_t *i1, int m_max,

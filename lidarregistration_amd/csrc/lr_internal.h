@@ -73,7 +73,7 @@ struct lr_workspace {
     int32_t *gpf_cells;          // GPF: cell_count | cell_fill | cell_off, each [LR_GPF_MAX_CELLS + 8]
     uint8_t *gpf_keep;           // GPF: keep mask [max_n0]
     float *gpf_f;                // GPF: min/max scratch
-    float *corr8;                // packed correspondences [max_n0][8] = px py pz qx qy qz 0 0
+    float *corr8;                // packed correspondences, 8 floats each, interleaved in pairs (lr_corr_at)
     // --- RANSAC ---
     float *models;               // [max_iters][12] fp32 R|t rows of hypotheses that passed the pre-check
     double *models64;            // [max_iters][12] the same models in fp64 (the winner is returned from here)
@@ -105,6 +105,11 @@ enum {
     LR_CNT_COUNT = 16,
     LR_CNT_TOTAL = 64        // counters[16..63] hold lr_ransac_state
 };
+
+// corr8 layout: two correspondences share one 64-byte record { px_a px_b py_a py_b pz_a pz_b qx_a qx_b qy_a qy_b qz_a qz_b 0 0 0 0 },
+// so the scoring loop reads a pair with one scalar load and feeds the halves to packed fp32 instructions as they lie.
+// Float index of component k (0..5 = px py pz qx qy qz) of correspondence c:
+__host__ __device__ inline size_t lr_corr_at(int c, int k) { return (size_t)(c >> 1) * 16 + 2 * k + (c & 1); }
 
 // running state of a RANSAC call across its early-exit batches (lives in counters[LR_CNT_COUNT..], zeroed with NVALID)
 struct lr_ransac_state {

@@ -36,6 +36,8 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32
 
 #include "lr_kabsch.h"
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 // unweighted Kabsch on NS (3 or 4) sample points held in registers
 template <int NS>
 __device__ __forceinline__ void kabsch_sample(const double P[NS][3], const double Q[NS][3], double T[16])
@@ -73,10 +75,11 @@ __device__ __forceinline__ bool hypothesis_sample(const float *__restrict__ corr
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
         uint32_t s = __umulhi(c[k], (uint32_t)m);
-        const float4 lo = reinterpret_cast<const float4 *>(corr8)[2 * (size_t)s];
-        const float4 hi = reinterpret_cast<const float4 *>(corr8)[2 * (size_t)s + 1];
-        P[k][0] = (double)lo.x; P[k][1] = (double)lo.y; P[k][2] = (double)lo.z;
-        Q[k][0] = (double)lo.w; Q[k][1] = (double)hi.x; Q[k][2] = (double)hi.y;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            P[k][a] = (double)corr8[lr_corr_at((int)s, a)];
+            Q[k][a] = (double)corr8[lr_corr_at((int)s, 3 + a)];
+        }
     }
     if (!use_elc) return true;
     bool ok = true;
@@ -147,7 +150,7 @@ ransac_score_kernel(const float *__restrict__ corr8, int m_max, const int32_t *_
     const int cmax = m / 512 > 0 ? m / 512 : 1;
     if (chunks > cmax) chunks = cmax;
     if (chunks < 1) chunks = 1;
-    const int per = (m + chunks - 1) / chunks;
+    const int per = ((m + chunks - 1) / chunks + 1) & ~1;      // even: chunks start on a pair boundary
     const int lane = threadIdx.x;
     for (int w = blockIdx.x; w < hb * chunks; w += gridDim.x) {
         const int g = w % hb, c = w / hb;
@@ -160,24 +163,43 @@ ransac_score_kernel(const float *__restrict__ corr8, int m_max, const int32_t *_
         const int begin = c * per, end = min(m, begin + per);
         uint32_t cnt = 0;
         unsigned long long ssq = 0;
-        const float4 *rec = reinterpret_cast<const float4 *>(corr8);
-        // the error sum runs in 32 bits over sub-blocks short enough not to overflow (sub * thr2 * 2^20 < 2^32)
-        for (int b0 = begin; b0 < end; b0 += sub) {
-            const int b1 = min(end, b0 + sub);
+        // two correspondences per iteration: the record of a pair is wave-uniform (scalar load) and its halves feed
+        // packed fp32 instructions directly; every component keeps the fma order of the arithmetic contract.
+        // The error sum runs in 32 bits over sub-blocks short enough not to overflow (sub * thr2 * 2^20 < 2^32).
+        const f32x2 *rec = reinterpret_cast<const f32x2 *>(corr8);
+        const f32x2 R00 = { r00, r00 }, R01 = { r01, r01 }, R02 = { r02, r02 }, TX = { tx, tx };
+        const f32x2 R10 = { r10, r10 }, R11 = { r11, r11 }, R12 = { r12, r12 }, TY = { ty, ty };
+        const f32x2 R20 = { r20, r20 }, R21 = { r21, r21 }, R22 = { r22, r22 }, TZ = { tz, tz };
+        const f32x2 SC = { 1048576.0f, 1048576.0f };
+        const int pend = end & ~1;                       // `begin` is even; a trailing odd correspondence is done alone below
+        for (int b0 = begin; b0 < pend; b0 += sub) {
+            const int b1 = min(pend, b0 + sub);
             uint32_t q32 = 0;
-#pragma unroll 4
-            for (int i = b0; i < b1; ++i) {
-                const float4 lo = rec[2 * i], hi = rec[2 * i + 1];       // wave-uniform address -> scalar loads
-                float x = __builtin_fmaf(r00, lo.x, __builtin_fmaf(r01, lo.y, __builtin_fmaf(r02, lo.z, tx)));
-                float y = __builtin_fmaf(r10, lo.x, __builtin_fmaf(r11, lo.y, __builtin_fmaf(r12, lo.z, ty)));
-                float z = __builtin_fmaf(r20, lo.x, __builtin_fmaf(r21, lo.y, __builtin_fmaf(r22, lo.z, tz)));
-                float dx = x - lo.w, dy = y - hi.x, dz = z - hi.y;
-                float d2 = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
-                const bool in = d2 < thr2;
-                cnt += in ? 1u : 0u;
-                q32 += in ? (uint32_t)(d2 * 1048576.0f) : 0u;
+#pragma unroll 2
+            for (int i = b0; i < b1; i += 2) {
+                const f32x2 *q = rec + (size_t)(i >> 1) * 8;
+                const f32x2 px = q[0], py = q[1], pz = q[2], qx = q[3], qy = q[4], qz = q[5];
+                const f32x2 x = __builtin_elementwise_fma(R00, px, __builtin_elementwise_fma(R01, py, __builtin_elementwise_fma(R02, pz, TX)));
+                const f32x2 y = __builtin_elementwise_fma(R10, px, __builtin_elementwise_fma(R11, py, __builtin_elementwise_fma(R12, pz, TY)));
+                const f32x2 z = __builtin_elementwise_fma(R20, px, __builtin_elementwise_fma(R21, py, __builtin_elementwise_fma(R22, pz, TZ)));
+                const f32x2 dx = x - qx, dy = y - qy, dz = z - qz;
+                const f32x2 d2 = __builtin_elementwise_fma(dx, dx, __builtin_elementwise_fma(dy, dy, dz * dz));
+                const f32x2 fx = d2 * SC;
+                const bool in0 = d2.x < thr2, in1 = d2.y < thr2;
+                cnt += (in0 ? 1u : 0u) + (in1 ? 1u : 0u);
+                q32 += (in0 ? (uint32_t)fx.x : 0u) + (in1 ? (uint32_t)fx.y : 0u);
             }
             ssq += q32;
+        }
+        if (pend < end) {
+            const int i = pend;
+            const float px = corr8[lr_corr_at(i, 0)], py = corr8[lr_corr_at(i, 1)], pz = corr8[lr_corr_at(i, 2)];
+            float x = __builtin_fmaf(r00, px, __builtin_fmaf(r01, py, __builtin_fmaf(r02, pz, tx)));
+            float y = __builtin_fmaf(r10, px, __builtin_fmaf(r11, py, __builtin_fmaf(r12, pz, ty)));
+            float z = __builtin_fmaf(r20, px, __builtin_fmaf(r21, py, __builtin_fmaf(r22, pz, tz)));
+            float dx = x - corr8[lr_corr_at(i, 3)], dy = y - corr8[lr_corr_at(i, 4)], dz = z - corr8[lr_corr_at(i, 5)];
+            float d2 = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
+            if (d2 < thr2) { cnt += 1u; ssq += (uint32_t)(d2 * 1048576.0f); }
         }
         if (active && cnt) { atomicAdd(&score_cnt[slot], cnt); atomicAdd(&score_ssq[slot], ssq); }
     }
@@ -263,7 +285,8 @@ int lr_ransac_run(lr_workspace *ws, const float *corr8, int m_max, const int32_t
     LR_REQUIRE(p->thr2 > 0.0f && p->thr2 < 2048.0f, LR_EINVAL, "lr_ransac: thr2 must be in (0, 2048)");
     int sub = (int)(4095.0 / ((double)p->thr2 * 1.0000001 + 1e-6));     // sub * thr2 * 2^20 < 2^32
     if (sub > 4096) sub = 4096;
-    if (sub < 1) sub = 1;
+    sub &= ~1;                  // the scoring loop takes correspondences two at a time
+    if (sub < 2) sub = 2;       // 2 * thr2 * 2^20 < 2^32 for every admissible thr2 (< 2048)
     const bool use_exit = p->confidence > 0.0f && p->confidence < 1.0f;
     const int B = use_exit ? (p->batch > 0 ? p->batch : 8192) : (p->iters > 0 ? p->iters : 1);
     if (ws->timing && ws->ev_pending == 1) { LR_HIP(hipEventRecord(ws->ev[2], st)); }
