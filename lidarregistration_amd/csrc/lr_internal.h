@@ -51,7 +51,12 @@ struct lr_workspace {
     int32_t *cand_cnt, *cand;    // [max_n], [max_n][LR_NN16_CAP] candidate lists
     float *bmax0, *bmax1;        // per-32-row maxima of the norms (f16 filter error bound)
     uint32_t *rev_seed;          // [max_n1] best forward distance pointing at each cloud-1 row (bit pattern)
-    int32_t *rev_rows;           // [max_n1] compacted list of the cloud-1 rows that have one
+    int32_t *rev_rows;           // [max_n1] the cloud-1 rows that have one, by descending seed
+    int32_t *rev_cols;           // [max_n0] cloud-0 points by ascending NN distance (columns of the reverse pass)
+    float *rev_s1;               // [max_n0] forward NN distance per cloud-0 point
+    float *rev_tmin;             // [max_n0/32+1] smallest rev_s1s of each column tile
+    int32_t *rev_hist;           // [2][4096] counting-sort offsets
+    _Float16 *Hs; float *nrms;   // [max_n0] f16 rows and norms of cloud 0 in rev_cols order
     int nn_path;                 // LR_NN_PATH_*
     int nn_blocks_target;        // column strips are chosen so that a pass launches about this many blocks
     float *pb1, *pb2, *pb3;      // partial top-3 values [strips][max_n]
@@ -102,6 +107,8 @@ enum {
     LR_CNT_NVALID,       // hypotheses appended to models[]
     LR_CNT_NBB,          // best buddies
     LR_CNT_NREV,         // rows of the reverse NN pass (cloud-1 points some query points at)
+    LR_CNT_RLO,          // smallest / largest forward NN distance of the pair (float bit patterns)
+    LR_CNT_RHI,
     LR_CNT_COUNT = 16,
     LR_CNT_TOTAL = 64        // counters[16..63] hold lr_ransac_state
 };

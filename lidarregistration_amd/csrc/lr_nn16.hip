@@ -43,10 +43,10 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 __global__ void __launch_bounds__(256)
 nn16_prep_kernel(const float *__restrict__ Fa, int na, _Float16 *__restrict__ Ha, float *__restrict__ nrma, float *__restrict__ bmaxa,
                  const float *__restrict__ Fb, int nb, _Float16 *__restrict__ Hb, float *__restrict__ nrmb, float *__restrict__ bmaxb,
-                 uint32_t *__restrict__ seed_b, int32_t *__restrict__ rev_rows_count)
+                 uint32_t *__restrict__ seed_b, uint32_t *__restrict__ rev_range)
 {
     __shared__ float s_m[4];
-    if (rev_rows_count && blockIdx.x == 0 && threadIdx.x == 0) *rev_rows_count = 0;      // lr_nn16_reverse compacts into it
+    if (rev_range && blockIdx.x == 0 && threadIdx.x == 0) { rev_range[0] = 0x7f7f7f7fu; rev_range[1] = 0u; }   // lr_nn16_reverse
     // blocks [0, ceil(na/32)) prepare cloud a, the rest cloud b (one launch for the pair)
     const int nblk_a = (na + 31) >> 5;
     const bool second = (int)blockIdx.x >= nblk_a;
@@ -244,12 +244,15 @@ nn16_passa_kernel(const _Float16 *__restrict__ Hq, int na, const _Float16 *__res
 __global__ void __launch_bounds__(256)
 nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *__restrict__ rowmap, const int32_t *__restrict__ na_dev,
                   const _Float16 *__restrict__ Hc, const float *__restrict__ nC, int nb,
-                  int tiles_per_strip, const float *__restrict__ tau, int32_t *__restrict__ cand_cnt, int32_t *__restrict__ cand)
+                  int tiles_per_strip, const float *__restrict__ tau, int32_t *__restrict__ cand_cnt, int32_t *__restrict__ cand,
+                  const int32_t *__restrict__ colmap, const float *__restrict__ tile_min, const uint32_t *__restrict__ row_bound)
 {
-    // rows: either 0..na_host-1, or (reverse direction) the compacted list rowmap[0..*na_dev-1]; tau, cand_cnt and cand
-    // are indexed by the position in that list
+    // rows: either 0..na_host-1, or (reverse direction) the ordered list rowmap[0..*na_dev-1]; tau, cand_cnt and cand
+    // are indexed by the position in that list.  Columns: Hc/nC as they lie; with colmap they are a permuted copy and
+    // a candidate's column id is colmap[position].
     const int na = na_dev ? *na_dev : na_host;
     if ((int)blockIdx.x * LR_BLOCK_ROWS >= na) return;
+    __shared__ int s_limit[4];
     constexpr int CH = LR_PB_CH;
     constexpr int XOFF = CH * 32 * LR_LDS_ROW;
     constexpr int BUF = XOFF + CH * 32 * 4;
@@ -258,7 +261,34 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r = lane & 31, h = lane >> 5;
     const int row0 = blockIdx.x * LR_BLOCK_ROWS + wave * 64;
-    const int ntiles = (nb + 31) >> 5;
+    int ntiles = (nb + 31) >> 5;
+    if (tile_min) {
+        // Ordered reverse pass (lr_nn16_reverse): a column can only win a row if its own NN distance is <= the row's
+        // bound, so this row block needs the column tiles up to the last one whose smallest NN distance is <= the
+        // block's largest bound -- all exact fp32 values, no margin.  The strips then split that prefix.
+        float bmax = 0.0f;
+        {
+            const int rw = (int)blockIdx.x * LR_BLOCK_ROWS + tid;
+            if (rw < na) bmax = __uint_as_float(row_bound[rowmap[rw]]);
+        }
+#pragma unroll
+        for (int k = 32; k >= 1; k >>= 1) bmax = fmaxf(bmax, __shfl_xor(bmax, k));
+        __shared__ float s_b[4];
+        if (lane == 0) s_b[wave] = bmax;
+        __syncthreads();
+        bmax = fmaxf(fmaxf(s_b[0], s_b[1]), fmaxf(s_b[2], s_b[3]));
+        int last = -1;
+        for (int t = tid; t < ntiles; t += 256) if (tile_min[t] <= bmax) last = t;
+#pragma unroll
+        for (int k = 32; k >= 1; k >>= 1) last = max(last, __shfl_xor(last, k));
+        if (lane == 0) s_limit[wave] = last;
+        __syncthreads();
+        ntiles = max(max(s_limit[0], s_limit[1]), max(s_limit[2], s_limit[3])) + 1;
+        // as many of the offered strips as the prefix is worth (a full-length row block uses all of them)
+        const int my_strips = min((int)gridDim.y, (ntiles + tiles_per_strip - 1) / tiles_per_strip);
+        if ((int)blockIdx.y >= my_strips) return;
+        tiles_per_strip = (ntiles + my_strips - 1) / my_strips;
+    }
     const int t_begin = blockIdx.y * tiles_per_strip;
     const int t_end = min(ntiles, t_begin + tiles_per_strip);
     const int nchunks = t_end > t_begin ? (t_end - t_begin + CH - 1) / CH : 0;
@@ -320,8 +350,10 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         } else {
             for (int e = lane; e < wcnt; e += 64) {
                 const uint2 v = wlist[wave][e];
-                const int col = (int)v.x, code = (int)(v.y >> 8);
+                int col = (int)v.x;
+                const int code = (int)(v.y >> 8);
                 if (col >= nb || (col >> 5) >= t_end) continue;      // padding columns pass the test only when tau is +inf
+                if (colmap) col = colmap[col];
                 const int rbase = row0 + 32 * (code >> 2) + 4 * (code & 1);
                 unsigned m = v.y & 0xffu;
                 while (m) {
@@ -550,7 +582,7 @@ nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, in
 int lr_nn16_prep(lr_workspace *ws, const float *F0, int n0, const float *F1, int n1, hipStream_t st)
 {
     hipLaunchKernelGGL(nn16_prep_kernel, dim3(lr_cdiv(n0, 32) + lr_cdiv(n1, 32)), dim3(256), 0, st, F0, n0, ws->H0, ws->nrm0, ws->bmax0,
-                       F1, n1, ws->H1, ws->nrm1, ws->bmax1, ws->rev_seed, ws->counters + LR_CNT_NREV);
+                       F1, n1, ws->H1, ws->nrm1, ws->bmax1, ws->rev_seed, reinterpret_cast<uint32_t *>(ws->counters + LR_CNT_RLO));
     LR_LAUNCH_CHECK();
     return LR_OK;
 }
@@ -578,7 +610,7 @@ int lr_nn16_run(lr_workspace *ws, const float *Fq, const _Float16 *Hq, const flo
                        block_max_c, lr_cdiv(nb, 32), need, ws->tau, ws->cand_cnt);
     if (ws->timing && !ws->ev_pending) { LR_HIP(hipEventRecord(ws->ev[0], st)); }
     hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), 0, st, Hq, na, (const int32_t *)nullptr, (const int32_t *)nullptr, Hc, nC, nb,
-                       tps, ws->tau, ws->cand_cnt, ws->cand);
+                       tps, ws->tau, ws->cand_cnt, ws->cand, (const int32_t *)nullptr, (const float *)nullptr, (const uint32_t *)nullptr);
     if (ws->timing && !ws->ev_pending) { LR_HIP(hipEventRecord(ws->ev[1], st)); ws->ev_pending = 1; }
     hipLaunchKernelGGL(nn16_exact_kernel, dim3(lr_cdiv(na, 64)), dim3(256), 0, st, Fq, nQ, na, Fc, nC, nb, ws->cand_cnt, ws->cand,
                        need, (const int32_t *)nullptr, (const int32_t *)nullptr, idx1, idx2, s1, s2, ws->counters);
@@ -587,17 +619,37 @@ int lr_nn16_run(lr_workspace *ws, const float *Fq, const _Float16 *Hq, const flo
 }
 
 // ------------------------------------------------------------------ reverse NN seeded by the forward result
-// The mutual test only asks, for a column j that some query i points at, whether any other row beats that pair.  So the
-// reverse direction needs no sampling pass: the exact distance of the best forward pair (i*, j) IS an upper bound of the
-// column's minimum, and pass B looks for rows with u' <= s*^2 (1 + 4e-7) - n_j + E.  Columns nobody points at are
-// left out altogether (their reverse NN is reported as -1; the reference does not compute it either,
-// matching.py:224-225): the rows of the reverse pass are the compacted list of the pointed-at columns.
+// The mutual test only asks, for a cloud-1 point j that some query i points at, whether any other cloud-0 point beats
+// that pair.  So the reverse direction needs no sampling pass: the exact distance s*_j of the best forward pair (i*, j)
+// IS an upper bound of j's minimum, and pass B looks for points with u' <= s*^2 (1 + 4e-7) - n_j + E.
+//   - points j nobody points at are left out (their reverse NN is reported as -1; the reference does not compute it
+//     either, matching.py:224-225);
+//   - a cloud-0 point i' can only win j if its own NN distance s1(i') -- a by-product of the seeding kernel -- is
+//     <= s*_j: d(i', j) >= s1(i') holds exactly in fp32 because both directions form bit-identical distances.  The rows
+//     (pointed-at j) are therefore ordered by descending s*, the columns (all i') by ascending s1 (a counting sort on
+//     LR_RS_BUCKETS linear buckets; any order is valid, a better one only prunes more), and each 256-row block walks
+//     only the prefix of column tiles that can matter to it (nn16_passb_kernel, tile_min / row_bound).
+#define LR_RS_BUCKETS 4096
+
+// monotone map distance -> bucket: linear over the pair's range of forward NN distances [lo, hi] (well spread keys keep
+// the sort's atomics apart); any monotone map is valid, a coarser one only prunes less
+__device__ __forceinline__ int rs_bucket(float v, float lo, float scale)
+{
+    const int b = (int)((v - lo) * scale);
+    return min(max(b, 0), LR_RS_BUCKETS - 1);
+}
+__device__ __forceinline__ float rs_scale(float lo, float hi) { return hi > lo ? (float)LR_RS_BUCKETS / (hi - lo) : 0.0f; }
+
+// seeds: seed_bits[j] = min over i with idx1[i] == j of the exact distance; s1[i] = that distance; range = their min / max
 __global__ void __launch_bounds__(256)
 nn16_rev_seed_kernel(const float *__restrict__ F0, const float *__restrict__ n0v, int n0, const float *__restrict__ F1,
-                     const float *__restrict__ n1v, const int32_t *__restrict__ idx1, uint32_t *__restrict__ seed_bits)
+                     const float *__restrict__ n1v, const int32_t *__restrict__ idx1, uint32_t *__restrict__ seed_bits,
+                     float *__restrict__ s1, uint32_t *__restrict__ range)
 {
+    __shared__ float s_lo[4], s_hi[4];
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n0) return;
+    float sv = 0.0f;
+    if (i < n0) {
     const int j = idx1[i];
     const f32x4 *pa = reinterpret_cast<const f32x4 *>(F0 + (size_t)i * 32);
     const f32x4 *pb = reinterpret_cast<const f32x4 *>(F1 + (size_t)j * 32);
@@ -612,44 +664,107 @@ nn16_rev_seed_kernel(const float *__restrict__ F0, const float *__restrict__ n0v
     }
     // same value the reverse direction forms for (j, i): the sum n1 + n0 and the products commute bit for bit
     const float d2 = __builtin_fmaf(-2.0f, acc, n0v[i] + n1v[j]);
-    const float sv = __builtin_sqrtf(fmaxf(d2, 1e-30f));
+    sv = __builtin_sqrtf(fmaxf(d2, 1e-30f));
+    if (!(sv < 3.0e38f)) sv = 3.0e38f;                  // non-finite features: keep the bit pattern below the "empty" fill
     atomicMin(&seed_bits[j], __float_as_uint(sv));      // sv > 0: bit patterns order like the values
+    s1[i] = sv;
+    }
+    float lo = i < n0 ? sv : 3.0e38f, hi = i < n0 ? sv : 0.0f;
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) { lo = fminf(lo, __shfl_xor(lo, k)); hi = fmaxf(hi, __shfl_xor(hi, k)); }
+    if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicMin(&range[0], __float_as_uint(fminf(fminf(s_lo[0], s_lo[1]), fminf(s_lo[2], s_lo[3]))));
+        atomicMax(&range[1], __float_as_uint(fmaxf(fmaxf(s_hi[0], s_hi[1]), fmaxf(s_hi[2], s_hi[3]))));
+    }
 }
 
-// thresholds of the seeded rows + their compaction: rowmap[pos] = row, tau[pos], cand_cnt[pos] = 0, *n_rows = count.
-// One global atomic per block (the order of the list does not matter: every result is written back by row id).
+// counting sort, passes 1 + 2 in one block: bucket histograms in LDS (cloud-0 points keyed by s1, ascending; cloud-1
+// points with a seed keyed by s*, descending), exclusive prefix sums -> offs[2][LR_RS_BUCKETS]; the row total is the
+// length of the reverse pass; tile_min is reset for the scatter kernel's atomicMin
+__global__ void __launch_bounds__(1024)
+nn16_rev_scan_kernel(int n0, int n1, const float *__restrict__ s1, const uint32_t *__restrict__ seed_bits,
+                     const uint32_t *__restrict__ range, int32_t *__restrict__ offs, int32_t *__restrict__ n_rows,
+                     uint32_t *__restrict__ tile_min_bits)
+{
+    __shared__ int s_h[2 * LR_RS_BUCKETS];
+    __shared__ int s_w[16];
+    const float lo = __uint_as_float(range[0]), scale = rs_scale(lo, __uint_as_float(range[1]));
+    for (int k = threadIdx.x; k < 2 * LR_RS_BUCKETS; k += 1024) s_h[k] = 0;
+    for (int t = threadIdx.x; t < (n0 + 31) / 32; t += 1024) tile_min_bits[t] = 0x7f800000u;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n0; i += 1024) atomicAdd(&s_h[rs_bucket(s1[i], lo, scale)], 1);
+    for (int j = threadIdx.x; j < n1; j += 1024) {
+        const float sv = __uint_as_float(seed_bits[j]);
+        if (sv <= 3.0e38f) atomicAdd(&s_h[LR_RS_BUCKETS + (LR_RS_BUCKETS - 1 - rs_bucket(sv, lo, scale))], 1);
+    }
+    __syncthreads();
+    for (int side = 0; side < 2; ++side) {
+        int *hp = s_h + side * LR_RS_BUCKETS;
+        int v[LR_RS_BUCKETS / 1024], sum = 0;
+#pragma unroll
+        for (int k = 0; k < LR_RS_BUCKETS / 1024; ++k) { v[k] = hp[threadIdx.x * (LR_RS_BUCKETS / 1024) + k]; sum += v[k]; }
+        int inc = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if ((int)(threadIdx.x & 63) >= d) inc += o; }
+        if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += s_w[w];
+        int run = base + inc - sum;
+#pragma unroll
+        for (int k = 0; k < LR_RS_BUCKETS / 1024; ++k) { offs[side * LR_RS_BUCKETS + threadIdx.x * (LR_RS_BUCKETS / 1024) + k] = run; run += v[k]; }
+        if (side == 1 && threadIdx.x == 1023) *n_rows = run;
+        __syncthreads();
+    }
+}
+
+// pass 3: scatter.  Four lanes per point.  Cloud-0 points: position in ascending-s1 order -> colmap, and the f16 row /
+// norm copied there (pass B streams the permuted copy, no indirection in its loop); tile_min = smallest s1 of every
+// column tile of that copy.  Cloud-1 points with a seed: position in descending-s* order -> rowmap, threshold and empty
+// candidate list at that position; the others get rev = -1.
 __global__ void __launch_bounds__(256)
-nn16_thresh_seed_kernel(int na, const uint32_t *__restrict__ seed_bits, const float *__restrict__ nQ,
-                        const float *__restrict__ block_max_c, int nblk_c, float *__restrict__ tau, int32_t *__restrict__ cand_cnt,
-                        int32_t *__restrict__ rowmap, int32_t *__restrict__ n_rows, int32_t *__restrict__ rev_out)
+nn16_rev_scatter_kernel(int n0, int n1, const float *__restrict__ s1, const uint32_t *__restrict__ seed_bits,
+                        const uint32_t *__restrict__ range, int32_t *__restrict__ offs,
+                        const _Float16 *__restrict__ H0, const float *__restrict__ nrm0, const float *__restrict__ block_max_c, int nblk_c,
+                        const float *__restrict__ nrm1,
+                        int32_t *__restrict__ colmap, _Float16 *__restrict__ H0s, float *__restrict__ nrm0s, uint32_t *__restrict__ tile_min_bits,
+                        int32_t *__restrict__ rowmap, float *__restrict__ tau, int32_t *__restrict__ cand_cnt, int32_t *__restrict__ rev_out)
 {
     __shared__ float s_m[4];
-    __shared__ int s_cnt[4], s_base;
-    const int row = blockIdx.x * blockDim.x + threadIdx.x;
-    const int wave = threadIdx.x >> 6;
+    const int t = (blockIdx.x * 256 + threadIdx.x) >> 2, q = threadIdx.x & 3, lane = threadIdx.x & 63;
     float mx = 0.0f;
     for (int b = threadIdx.x; b < nblk_c; b += 256) mx = fmaxf(mx, block_max_c[b]);
 #pragma unroll
     for (int k = 32; k >= 1; k >>= 1) mx = fmaxf(mx, __shfl_xor(mx, k));
-    if ((threadIdx.x & 63) == 0) s_m[wave] = mx;
-    const float sv = row < na ? __uint_as_float(seed_bits[row]) : LR_INF;
-    const bool seeded = sv < 3.0e38f;                      // else still the 0x7f7f7f7f fill: no query points at this row
-    const unsigned long long bal = __builtin_amdgcn_ballot_w64(seeded);
-    if ((threadIdx.x & 63) == 0) s_cnt[wave] = __builtin_popcountll(bal);
+    if (lane == 0) s_m[threadIdx.x >> 6] = mx;
     __syncthreads();
-    if (threadIdx.x == 0) s_base = atomicAdd(n_rows, s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3]);
-    __syncthreads();
-    if (row >= na) return;
-    if (!seeded) { rev_out[row] = -1; return; }
-    int pos = s_base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-    for (int w = 0; w < wave; ++w) pos += s_cnt[w];
-    const float max_nc = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
-    const float scale = nQ[row] + max_nc;
-    const float E = 1.05e-3f * scale + 4e-7f;
-    const float d2hi = sv * sv * (1.0f + 6e-7f);               // every d2 whose sqrt rounds to <= sv lies below this
-    rowmap[pos] = row;
-    tau[pos] = (d2hi - nQ[row]) + E + 6e-6f * scale + 2e-6f * d2hi;
-    cand_cnt[pos] = 0;
+    const float max_nc = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));      // largest norm of cloud 0 (the columns)
+    const float lo = __uint_as_float(range[0]), scale = rs_scale(lo, __uint_as_float(range[1]));
+    if (t < n0) {
+        const float sv = s1[t];
+        int pos = 0;
+        if (q == 0) pos = atomicAdd(&offs[rs_bucket(sv, lo, scale)], 1);
+        pos = __shfl(pos, lane & ~3);
+        reinterpret_cast<f32x4 *>(H0s + (size_t)pos * 32)[q] = reinterpret_cast<const f32x4 *>(H0 + (size_t)t * 32)[q];
+        if (q == 0) {
+            colmap[pos] = t;
+            nrm0s[pos] = nrm0[t];
+            atomicMin(&tile_min_bits[pos >> 5], __float_as_uint(sv));
+        }
+    } else if (t < n0 + n1 && q == 0) {
+        const int row = t - n0;
+        const float sv = __uint_as_float(seed_bits[row]);
+        if (!(sv <= 3.0e38f)) { rev_out[row] = -1; return; }      // still the 0x7f7f7f7f fill: no query points at this row
+        const int pos = atomicAdd(&offs[LR_RS_BUCKETS + (LR_RS_BUCKETS - 1 - rs_bucket(sv, lo, scale))], 1);
+        const float scl = nrm1[row] + max_nc;
+        const float E = 1.05e-3f * scl + 4e-7f;
+        const float d2hi = sv * sv * (1.0f + 6e-7f);               // every d2 whose sqrt rounds to <= sv lies below this
+        rowmap[pos] = row;
+        tau[pos] = (d2hi - nrm1[row]) + E + 6e-6f * scl + 2e-6f * d2hi;
+        cand_cnt[pos] = 0;
+    }
 }
 
 int lr_nn16_reverse(lr_workspace *ws, const float *F0, const _Float16 *H0, const float *nrm0, const float *bmax0, int n0,
@@ -660,21 +775,27 @@ int lr_nn16_reverse(lr_workspace *ws, const float *F0, const _Float16 *H0, const
     const int na = n1, nb = n0;
     const int ntiles = lr_cdiv(nb, 32);
     const int row_blocks = lr_cdiv(na, LR_BLOCK_ROWS);
-    int strips = lr_cdiv(ws->nn_blocks_target, row_blocks);
+    // the grid offers every row block the maximum number of strips; a block uses as many as its column prefix is worth
+    int strips = LR_NN_MAX_STRIPS;
     int smax = ntiles / 8;
     if (strips > smax) strips = smax;
-    if (strips > LR_NN_MAX_STRIPS) strips = LR_NN_MAX_STRIPS;
     if (strips < 1) strips = 1;
     const int tps = lr_cdiv(ntiles, strips);
-    uint32_t *seed = ws->rev_seed;          // filled with 0x7f7f7f7f, and the row counter zeroed, by the prep kernel of this pair
+    uint32_t *seed = ws->rev_seed;          // filled with 0x7f7f7f7f, and range reset to { 0x7f7f7f7f, 0 }, by the prep kernel of this pair
+    uint32_t *range = reinterpret_cast<uint32_t *>(ws->counters + LR_CNT_RLO);
     int32_t *n_rows = ws->counters + LR_CNT_NREV;
-    hipLaunchKernelGGL(nn16_rev_seed_kernel, dim3(lr_cdiv(n0, 256)), dim3(256), 0, st, F0, nrm0, n0, F1, nrm1, fwd_idx1, seed);
-    hipLaunchKernelGGL(nn16_thresh_seed_kernel, dim3(lr_cdiv(na, 256)), dim3(256), 0, st, na, seed, nrm1, bmax0, lr_cdiv(nb, 32),
-                       ws->tau, ws->cand_cnt, ws->rev_rows, n_rows, rev);
-    // grids are sized for all rows; blocks past the compacted count leave at once
+    uint32_t *tmin = reinterpret_cast<uint32_t *>(ws->rev_tmin);
+    hipLaunchKernelGGL(nn16_rev_seed_kernel, dim3(lr_cdiv(n0, 256)), dim3(256), 0, st, F0, nrm0, n0, F1, nrm1, fwd_idx1, seed, ws->rev_s1, range);
+    hipLaunchKernelGGL(nn16_rev_scan_kernel, dim3(1), dim3(1024), 0, st, n0, n1, (const float *)ws->rev_s1, (const uint32_t *)seed,
+                       (const uint32_t *)range, ws->rev_hist, n_rows, tmin);
+    hipLaunchKernelGGL(nn16_rev_scatter_kernel, dim3(lr_cdiv(4 * (n0 + n1), 256)), dim3(256), 0, st, n0, n1, (const float *)ws->rev_s1,
+                       (const uint32_t *)seed, (const uint32_t *)range, ws->rev_hist, H0, nrm0, bmax0, lr_cdiv(nb, 32), nrm1,
+                       ws->rev_cols, ws->Hs, ws->nrms, tmin, ws->rev_rows, ws->tau, ws->cand_cnt, rev);
+    // grids are sized for all rows; blocks past the compacted count (or past their row block's strips) leave at once
     dim3 grid(row_blocks, strips);
-    hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), 0, st, H1, na, (const int32_t *)ws->rev_rows, (const int32_t *)n_rows, H0, nrm0,
-                       nb, tps, ws->tau, ws->cand_cnt, ws->cand);
+    hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), 0, st, H1, na, (const int32_t *)ws->rev_rows, (const int32_t *)n_rows,
+                       (const _Float16 *)ws->Hs, (const float *)ws->nrms, nb, tps, ws->tau, ws->cand_cnt, ws->cand,
+                       (const int32_t *)ws->rev_cols, (const float *)ws->rev_tmin, (const uint32_t *)seed);
     hipLaunchKernelGGL(nn16_exact_kernel, dim3(lr_cdiv(na, 64)), dim3(256), 0, st, F1, nrm1, na, F0, nrm0, nb, ws->cand_cnt, ws->cand,
                        1, (const int32_t *)ws->rev_rows, (const int32_t *)n_rows, rev, (int32_t *)nullptr, (float *)nullptr, (float *)nullptr,
                        ws->counters);

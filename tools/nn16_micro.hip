@@ -26,7 +26,7 @@ int main(int argc, char **argv)
     hipMemcpy(F, h.data(), (size_t)n*128, hipMemcpyHostToDevice);
     hipMemset(mx, 0, 8);
     float *bmax; hipMalloc(&bmax, (n/32+2)*4);
-    hipLaunchKernelGGL(nn16_prep_kernel, dim3((n+31)/32), dim3(256), 0, 0, F, n, H, nrm, bmax, F, 0, H, nrm, bmax, (uint32_t*)nullptr, (int32_t*)nullptr);
+    hipLaunchKernelGGL(nn16_prep_kernel, dim3((n+31)/32), dim3(256), 0, 0, F, n, H, nrm, bmax, F, 0, H, nrm, bmax, (uint32_t*)nullptr, (uint32_t*)nullptr);
     int ntiles = (n + 31) / 32;
     int row_blocks = (n + LR_BLOCK_ROWS - 1) / LR_BLOCK_ROWS;
     for (int stride : {1, 2, 4}) {
@@ -37,10 +37,10 @@ int main(int argc, char **argv)
         // thresholds from this pass A, then pass B
         hipLaunchKernelGGL(nn16_thresh_kernel, dim3((n+255)/256), dim3(256), 0, 0, n, strips, n, pu1, pu2, nrm, (const float*)bmax, (n+31)/32, 2, tau, cnt);
         int tpsb = (ntiles + strips - 1) / strips;
-        float msp = timeit([&] { hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), 0, 0, H, n, (const int32_t*)nullptr, (const int32_t*)nullptr, H, nrm, n, tpsb, tau, cnt, cand); });
+        float msp = timeit([&] { hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), 0, 0, H, n, (const int32_t*)nullptr, (const int32_t*)nullptr, H, nrm, n, tpsb, tau, cnt, cand, (const int32_t*)nullptr, (const float*)nullptr, (const uint32_t*)nullptr); });
         std::vector<int32_t> c1(n);
         hipMemset(cnt, 0, n*4);
-        hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), 0, 0, H, n, (const int32_t*)nullptr, (const int32_t*)nullptr, H, nrm, n, tpsb, tau, cnt, cand);
+        hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), 0, 0, H, n, (const int32_t*)nullptr, (const int32_t*)nullptr, H, nrm, n, tpsb, tau, cnt, cand, (const int32_t*)nullptr, (const float*)nullptr, (const uint32_t*)nullptr);
         hipMemcpy(c1.data(), cnt, n*4, hipMemcpyDeviceToHost);
         double tot = 0; int mxc = 0;
         for (int i = 0; i < n; ++i) { tot += c1[i]; mxc = c1[i] > mxc ? c1[i] : mxc; }
@@ -50,7 +50,7 @@ int main(int argc, char **argv)
     {
         std::vector<float> t(n, -1e30f); hipMemcpy(tau, t.data(), n*4, hipMemcpyHostToDevice);
         int tpsb = (ntiles + strips - 1) / strips; dim3 grid(row_blocks, strips);
-        float msp = timeit([&] { hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), 0, 0, H, n, (const int32_t*)nullptr, (const int32_t*)nullptr, H, nrm, n, tpsb, tau, cnt, cand); });
+        float msp = timeit([&] { hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), 0, 0, H, n, (const int32_t*)nullptr, (const int32_t*)nullptr, H, nrm, n, tpsb, tau, cnt, cand, (const int32_t*)nullptr, (const float*)nullptr, (const uint32_t*)nullptr); });
         printf("passB no candidates: %.3f ms\n", msp);
     }
     return 0;
