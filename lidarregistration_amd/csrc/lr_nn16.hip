@@ -100,126 +100,138 @@ nn16_prep_kernel(const float *__restrict__ Fa, int na, _Float16 *__restrict__ Ha
 // of LR_CH tiles that are staged once through LDS (register-staged, double-buffered, one barrier per chunk) and shared
 // by the four waves.  LDS image: one 80-byte row per column (64 B of f16 + 16 B pad): with that stride the two
 // ds_read_b128 of a fragment are bank-conflict-free for the b128 lane groups.
-// Output: the two largest g = dot16 - n1[j]/2 per query row over the sampled tiles (u' = -2 g, so the two largest g
-// are the two smallest u') -> partials [strip][row].
+//
+// Operand roles are swapped with respect to pass B: the column fragment is the MFMA's first operand, the query rows
+// the second, so a LANE holds one query row and its 16 accumulator registers are 16 different columns.  The
+// accumulator starts at -x_j = -n1[j]/2 (read from LDS as the C operand, no VALU), so after the two MFMAs it holds
+// g = dot16 - n1[j]/2 and the row's best column of the tile is an in-lane maximum tree (7 v_max3 + 1 v_max per 16
+// values); three more ops merge it into the running two largest tile maxima of the row.  Tile maxima belong to
+// different columns, so their second largest is a valid (and almost always exact) lower bound of the row's 2nd
+// largest g (u' = -2 g: the 2nd smallest u').  Output: partials pg1 / pg2 [strip][row].
 #define LR_CH 4
 #define LR_LDS_ROW 80
 #define LR_RB 2                  // 32-row MFMA blocks per wave (rows per wave = 64, rows per block = 256)
 #define LR_BLOCK_ROWS (128 * LR_RB)
+
+
 __global__ void __launch_bounds__(256)
 nn16_passa_kernel(const _Float16 *__restrict__ Hq, int na, const _Float16 *__restrict__ Hc, const float *__restrict__ nC, int nb,
                   int tiles_per_strip, int tile_stride, int part_stride, float *__restrict__ pg1, float *__restrict__ pg2)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2][LR_CH * 32 * LR_LDS_ROW + LR_CH * 32 * 4];
+    constexpr int CH = LR_CH;
+    constexpr int XOFF = CH * 32 * LR_LDS_ROW;
+    constexpr int BUF = XOFF + CH * 32 * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r = lane & 31, h = lane >> 5;
-    const int row0 = blockIdx.x * LR_BLOCK_ROWS + wave * 32 * LR_RB;
+    const int row0 = blockIdx.x * LR_BLOCK_ROWS + wave * 64;
     const int strip = blockIdx.y;
     const int ntiles = (nb + 31) >> 5;
     const int t_begin = strip * tiles_per_strip;
     const int t_end = min(ntiles, t_begin + tiles_per_strip);
     const int nsamp = t_end > t_begin ? (t_end - t_begin + tile_stride - 1) / tile_stride : 0;   // tiles this block visits
-    const int nchunks = (nsamp + LR_CH - 1) / LR_CH;
+    const int nchunks = (nsamp + CH - 1) / CH;
 
-    f16x8 a[LR_RB][2];
+    f16x8 a[2][2];
 #pragma unroll
-    for (int rb = 0; rb < LR_RB; ++rb) {
+    for (int rb = 0; rb < 2; ++rb) {
         const int row = min(row0 + 32 * rb + r, na - 1);
         const f16x8 *p = reinterpret_cast<const f16x8 *>(Hq + (size_t)row * 32 + 16 * h);
         a[rb][0] = p[0]; a[rb][1] = p[1];
     }
-    f32x16 st1[LR_RB];      // per-lane running maximum of g
-#pragma unroll
-    for (int rb = 0; rb < LR_RB; ++rb)
-#pragma unroll
-        for (int g = 0; g < 16; ++g) st1[rb][g] = -LR_INF;
 
-    // staging: thread t moves LR_CH/2 16-byte pieces per chunk (piece p -> column p/4 of the chunk, 16-byte part p%4)
-    f32x4 stage[LR_CH / 2];
+    // staging: thread t moves CH/2 16-byte pieces per chunk (piece p -> column p/4 of the chunk, 16-byte part p%4)
+    f32x4 stage[CH / 2];
     float stage_n = 0.0f;        // raw norm of the staged column: NOT touched until store_chunk, so that the compiler's
     bool stage_ok = false;       // s_waitcnt for it lands after the tile loop instead of right behind the prefetch
-    auto chunk_col = [&](int c, int lc) {      // global column of local column lc (0..LR_CH*32) of chunk c
-        const int k = lc >> 5;
-        return (t_begin + (c * LR_CH + k) * tile_stride) * 32 + (lc & 31);
+    auto chunk_col = [&](int c, int lc) {      // global column of local column lc (0..CH*32) of chunk c
+        return (t_begin + (c * CH + (lc >> 5)) * tile_stride) * 32 + (lc & 31);
     };
     auto load_chunk = [&](int c) {
 #pragma unroll
-        for (int q = 0; q < LR_CH / 2; ++q) {
+        for (int q = 0; q < CH / 2; ++q) {
             const int p = tid + 256 * q;
             const int col = chunk_col(c, p >> 2);
             stage[q] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const unsigned char *>(Hc) + (size_t)min(col, nb - 1) * 64 + (p & 3) * 16);
         }
-        {
-            const int lc = tid & (LR_CH * 32 - 1);
-            const int col = chunk_col(c, lc);
-            const int tile = t_begin + (c * LR_CH + (lc >> 5)) * tile_stride;
-            stage_n = nC[min(col, nb - 1)];
-            stage_ok = col < nb && tile < t_end;
-        }
+        const int lc = tid & (CH * 32 - 1);
+        const int col = chunk_col(c, lc);
+        stage_n = nC[min(col, nb - 1)];
+        stage_ok = col < nb && (col >> 5) < t_end;
     };
     auto store_chunk = [&](int buf) {
 #pragma unroll
-        for (int q = 0; q < LR_CH / 2; ++q) {
+        for (int q = 0; q < CH / 2; ++q) {
             const int p = tid + 256 * q;
-            *reinterpret_cast<f32x4 *>(&lds[buf][(p >> 2) * LR_LDS_ROW + (p & 3) * 16]) = stage[q];
+            *reinterpret_cast<f32x4 *>(&lds[buf * BUF + (p >> 2) * LR_LDS_ROW + (p & 3) * 16]) = stage[q];
         }
-        // x_j = n1[j]/2 ; +inf masks columns past the end of the cloud or of the strip
-        if (tid < LR_CH * 32) *reinterpret_cast<float *>(&lds[buf][LR_CH * 32 * LR_LDS_ROW + tid * 4]) = stage_ok ? 0.5f * stage_n : LR_INF;
+        // -x_j = -n1[j]/2 ; -inf masks columns past the end of the cloud or of the strip
+        if (tid < CH * 32) *reinterpret_cast<float *>(&lds[buf * BUF + XOFF + tid * 4]) = stage_ok ? -0.5f * stage_n : -LR_INF;
     };
-    auto read_b = [&](int buf, int k, f16x8 &b0, f16x8 &b1, float &xj) {
-        const unsigned char *bp = &lds[buf][(32 * k + r) * LR_LDS_ROW + 32 * h];
+    // fragment of tile k (lane = column r, K half h) and the C operand: register g <-> column (g&3) + 8 (g>>2) + 4 h
+    const int frag_lane = r * LR_LDS_ROW + 32 * h, x_lane = XOFF + 16 * h;
+    auto read_tile = [&](int buf, int k, f16x8 &b0, f16x8 &b1, f32x16 &cx) {
+        const unsigned char *bp = &lds[buf * BUF + frag_lane + k * 32 * LR_LDS_ROW];
         b0 = *reinterpret_cast<const f16x8 *>(bp);
         b1 = *reinterpret_cast<const f16x8 *>(bp + 16);
-        xj = *reinterpret_cast<const float *>(&lds[buf][LR_CH * 32 * LR_LDS_ROW + (32 * k + r) * 4]);
+        const unsigned char *xp = &lds[buf * BUF + x_lane + k * 32 * 4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(xp + 32 * q);
+            cx[4 * q] = v.x; cx[4 * q + 1] = v.y; cx[4 * q + 2] = v.z; cx[4 * q + 3] = v.w;
+        }
     };
 
-    if (nchunks > 0) { load_chunk(0); store_chunk(0); }
-    __syncthreads();
-    for (int c = 0; c < nchunks; ++c) {
-        const int buf = c & 1;
-        if (c + 1 < nchunks) load_chunk(c + 1);
-        if (row0 < na) {
-#pragma unroll 2
-            for (int k = 0; k < LR_CH; ++k) {
-                f16x8 b0, b1; float xj;
-                read_b(buf, k, b0, b1, xj);
-                f32x16 acc[2];
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[q][0], b0, f32x16{ 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, 0, 0, 0);
-                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[q][1], b1, acc[q], 0, 0, 0);
-                }
-                // per-lane running maximum of g = dot16 - x_j (2 VALU ops per element).  The two largest of the 32 lane
-                // maxima of a row belong to two different columns, so the smaller of them is a valid (and almost always
-                // exact) lower bound of the row's 2nd largest g.
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-#pragma unroll
-                    for (int g = 0; g < 16; ++g) st1[q][g] = fmaxf(st1[q][g], acc[q][g] - xj);
-            }
-        }
-        if (c + 1 < nchunks) store_chunk(buf ^ 1);
+    float m1[2] = { -LR_INF, -LR_INF }, m2[2] = { -LR_INF, -LR_INF };     // running two largest tile maxima of the lane's row
+    // plain fmaxf (not inline asm): the compiler must see these reads of the MFMA results to place the wait states
+    // the hardware requires between an MFMA and a VALU read of its destination
+    auto fold = [&](const f32x16 &acc, int rb) {
+        float t = fmaxf(fmaxf(acc[0], acc[1]), acc[2]);
+        float u = fmaxf(fmaxf(acc[3], acc[4]), acc[5]);
+        float v = fmaxf(fmaxf(acc[6], acc[7]), acc[8]);
+        float w = fmaxf(fmaxf(acc[9], acc[10]), acc[11]);
+        float z = fmaxf(fmaxf(acc[12], acc[13]), acc[14]);
+        t = fmaxf(fmaxf(t, u), acc[15]);
+        v = fmaxf(fmaxf(v, w), z);
+        t = fmaxf(t, v);
+        const float lo = fminf(m1[rb], t);
+        m1[rb] = fmaxf(m1[rb], t);
+        m2[rb] = fmaxf(m2[rb], lo);
+    };
+
+    // (An explicit software pipeline -- fold tile t-1 under the MFMAs of tile t -- measured no faster: at 47-59 sampled
+    // tiles per block the kernel is bound by its per-block prologue, not by this loop; the plain loop needs 92 VGPRs.)
+    if (nchunks > 0) {
+        load_chunk(0); store_chunk(0);
         __syncthreads();
+        for (int c = 0; c < nchunks; ++c) {
+            const int buf = c & 1;
+            if (c + 1 < nchunks) load_chunk(c + 1);
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                f16x8 b0, b1; f32x16 cx;
+                read_tile(buf, k, b0, b1, cx);
+                f32x16 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0, a[0][0], cx, 0, 0, 0);
+                f32x16 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0, a[1][0], cx, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b1, a[0][1], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b1, a[1][1], acc1, 0, 0, 0);
+                fold(acc0, 0);
+                fold(acc1, 1);
+            }
+            if (c + 1 < nchunks) store_chunk(buf ^ 1);
+            __syncthreads();
+        }
     }
 
-    if (row0 < na) {
-        // two largest of the 32 lane maxima of each row (lanes of one half hold the same rows, different columns)
-        const size_t base = (size_t)strip * part_stride;
+    // the two lanes of a row (h = 0, 1: different columns) merge their pairs; lane h = 0 writes
+    const size_t base = (size_t)strip * part_stride;
 #pragma unroll
-        for (int rb = 0; rb < LR_RB; ++rb)
-#pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                float v1 = st1[rb][g], v2 = -LR_INF;
-#pragma unroll
-                for (int m = 1; m < 32; m <<= 1) {
-                    const float c1 = __shfl_xor(v1, m), c2 = __shfl_xor(v2, m);
-                    const float hi = fmaxf(v1, c1), lo = fminf(v1, c1);
-                    v2 = fmaxf(lo, fmaxf(v2, c2));
-                    v1 = hi;
-                }
-                const int row = row0 + 32 * rb + (g & 3) + 8 * (g >> 2) + 4 * h;
-                if (r == 0 && row < na) { pg1[base + row] = v1; pg2[base + row] = v2; }
-            }
+    for (int rb = 0; rb < 2; ++rb) {
+        const float c1 = __shfl_xor(m1[rb], 32), c2 = __shfl_xor(m2[rb], 32);
+        const float hi = fmaxf(m1[rb], c1), lo = fminf(m1[rb], c1);
+        const float second = fmaxf(lo, fmaxf(m2[rb], c2));
+        const int row = row0 + 32 * rb + r;
+        if (h == 0 && row < na) { pg1[base + row] = hi; pg2[base + row] = second; }
     }
 }
 

@@ -34,6 +34,23 @@ int main(int argc, char **argv)
         dim3 grid(row_blocks, strips);
         float ms = timeit([&] { hipLaunchKernelGGL(nn16_passa_kernel, grid, dim3(256), 0, 0, H, n, H, nrm, n, tps, stride, n, pu1, pu2); });
         printf("passA stride %d strips %d: %.3f ms\n", stride, strips, ms);
+        {   // check: 2nd largest g of a few rows against a host computation over the same sampled columns
+            std::vector<float> h1((size_t)n * strips), h2((size_t)n * strips);
+            hipMemcpy(h1.data(), pu1, h1.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(h2.data(), pu2, h2.size() * 4, hipMemcpyDeviceToHost);
+            for (int row : {0, 1, 77, 12345}) {
+                float a1 = -1e30f, a2 = -1e30f;
+                for (int s2 = 0; s2 < strips; ++s2) { float c1 = h1[(size_t)s2 * n + row], c2 = h2[(size_t)s2 * n + row]; float hi = fmaxf(a1, c1), lo = fminf(a1, c1); a2 = fmaxf(lo, fmaxf(a2, c2)); a1 = hi; }
+                float r1 = -1e30f, r2 = -1e30f;
+                for (int sp = 0; sp < strips; ++sp)
+                    for (int t = sp * tps; t < (sp + 1) * tps && t < ntiles; t += stride)
+                        for (int j = t * 32; j < t * 32 + 32 && j < n; ++j) {
+                            double d = 0, nn = 0; for (int k = 0; k < 32; ++k) { d += (double)h[(size_t)row*32+k] * h[(size_t)j*32+k]; nn += (double)h[(size_t)j*32+k] * h[(size_t)j*32+k]; }
+                            float g = (float)(d - 0.5 * nn);
+                            if (g > r1) { r2 = r1; r1 = g; } else if (g > r2) r2 = g;
+                        }
+                printf("   row %5d  device (%.5f, %.5f)  host (%.5f, %.5f)\n", row, a1, a2, r1, r2);
+            }
+        }
         // thresholds from this pass A, then pass B
         hipLaunchKernelGGL(nn16_thresh_kernel, dim3((n+255)/256), dim3(256), 0, 0, n, strips, n, pu1, pu2, nrm, (const float*)bmax, (n+31)/32, 2, tau, cnt);
         int tpsb = (ntiles + strips - 1) / strips;
