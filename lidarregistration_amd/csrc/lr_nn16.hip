@@ -706,10 +706,23 @@ nn16_rev_scan_kernel(int n0, int n1, const float *__restrict__ s1, const uint32_
     for (int k = threadIdx.x; k < 2 * LR_RS_BUCKETS; k += 1024) s_h[k] = 0;
     for (int t = threadIdx.x; t < (n0 + 31) / 32; t += 1024) tile_min_bits[t] = 0x7f800000u;
     __syncthreads();
-    for (int i = threadIdx.x; i < n0; i += 1024) atomicAdd(&s_h[rs_bucket(s1[i], lo, scale)], 1);
-    for (int j = threadIdx.x; j < n1; j += 1024) {
-        const float sv = __uint_as_float(seed_bits[j]);
-        if (sv <= 3.0e38f) atomicAdd(&s_h[LR_RS_BUCKETS + (LR_RS_BUCKETS - 1 - rs_bucket(sv, lo, scale))], 1);
+    // eight independent loads in flight per thread (a single block: the loop is bound by load latency, not by the atomics)
+    for (int i0 = threadIdx.x; i0 < n0; i0 += 8 * 1024) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const int i = i0 + 1024 * k; v[k] = s1[min(i, n0 - 1)]; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (i0 + 1024 * k < n0) atomicAdd(&s_h[rs_bucket(v[k], lo, scale)], 1);
+    }
+    for (int j0 = threadIdx.x; j0 < n1; j0 += 8 * 1024) {
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const int j = j0 + 1024 * k; v[k] = seed_bits[min(j, n1 - 1)]; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float sv = __uint_as_float(v[k]);
+            if (j0 + 1024 * k < n1 && sv <= 3.0e38f) atomicAdd(&s_h[LR_RS_BUCKETS + (LR_RS_BUCKETS - 1 - rs_bucket(sv, lo, scale))], 1);
+        }
     }
     __syncthreads();
     for (int side = 0; side < 2; ++side) {
@@ -732,7 +745,7 @@ nn16_rev_scan_kernel(int n0, int n1, const float *__restrict__ s1, const uint32_
     }
 }
 
-// pass 3: scatter.  Four lanes per point.  Cloud-0 points: position in ascending-s1 order -> colmap, and the f16 row /
+// pass 3: scatter.  Cloud-0 points: position in ascending-s1 order -> colmap, and the f16 row /
 // norm copied there (pass B streams the permuted copy, no indirection in its loop); tile_min = smallest s1 of every
 // column tile of that copy.  Cloud-1 points with a seed: position in descending-s* order -> rowmap, threshold and empty
 // candidate list at that position; the others get rev = -1.
@@ -745,7 +758,7 @@ nn16_rev_scatter_kernel(int n0, int n1, const float *__restrict__ s1, const uint
                         int32_t *__restrict__ rowmap, float *__restrict__ tau, int32_t *__restrict__ cand_cnt, int32_t *__restrict__ rev_out)
 {
     __shared__ float s_m[4];
-    const int t = (blockIdx.x * 256 + threadIdx.x) >> 2, q = threadIdx.x & 3, lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
     float mx = 0.0f;
     for (int b = threadIdx.x; b < nblk_c; b += 256) mx = fmaxf(mx, block_max_c[b]);
 #pragma unroll
@@ -756,16 +769,16 @@ nn16_rev_scatter_kernel(int n0, int n1, const float *__restrict__ s1, const uint
     const float lo = __uint_as_float(range[0]), scale = rs_scale(lo, __uint_as_float(range[1]));
     if (t < n0) {
         const float sv = s1[t];
-        int pos = 0;
-        if (q == 0) pos = atomicAdd(&offs[rs_bucket(sv, lo, scale)], 1);
-        pos = __shfl(pos, lane & ~3);
-        reinterpret_cast<f32x4 *>(H0s + (size_t)pos * 32)[q] = reinterpret_cast<const f32x4 *>(H0 + (size_t)t * 32)[q];
-        if (q == 0) {
-            colmap[pos] = t;
-            nrm0s[pos] = nrm0[t];
-            atomicMin(&tile_min_bits[pos >> 5], __float_as_uint(sv));
-        }
-    } else if (t < n0 + n1 && q == 0) {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(H0 + (size_t)t * 32);
+        const f32x4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
+        const float nt = nrm0[t];
+        const int pos = atomicAdd(&offs[rs_bucket(sv, lo, scale)], 1);
+        f32x4 *dst = reinterpret_cast<f32x4 *>(H0s + (size_t)pos * 32);
+        dst[0] = v0; dst[1] = v1; dst[2] = v2; dst[3] = v3;
+        colmap[pos] = t;
+        nrm0s[pos] = nt;
+        atomicMin(&tile_min_bits[pos >> 5], __float_as_uint(sv));
+    } else if (t < n0 + n1) {
         const int row = t - n0;
         const float sv = __uint_as_float(seed_bits[row]);
         if (!(sv <= 3.0e38f)) { rev_out[row] = -1; return; }      // still the 0x7f7f7f7f fill: no query points at this row
@@ -800,7 +813,7 @@ int lr_nn16_reverse(lr_workspace *ws, const float *F0, const _Float16 *H0, const
     hipLaunchKernelGGL(nn16_rev_seed_kernel, dim3(lr_cdiv(n0, 256)), dim3(256), 0, st, F0, nrm0, n0, F1, nrm1, fwd_idx1, seed, ws->rev_s1, range);
     hipLaunchKernelGGL(nn16_rev_scan_kernel, dim3(1), dim3(1024), 0, st, n0, n1, (const float *)ws->rev_s1, (const uint32_t *)seed,
                        (const uint32_t *)range, ws->rev_hist, n_rows, tmin);
-    hipLaunchKernelGGL(nn16_rev_scatter_kernel, dim3(lr_cdiv(4 * (n0 + n1), 256)), dim3(256), 0, st, n0, n1, (const float *)ws->rev_s1,
+    hipLaunchKernelGGL(nn16_rev_scatter_kernel, dim3(lr_cdiv(n0 + n1, 256)), dim3(256), 0, st, n0, n1, (const float *)ws->rev_s1,
                        (const uint32_t *)seed, (const uint32_t *)range, ws->rev_hist, H0, nrm0, bmax0, lr_cdiv(nb, 32), nrm1,
                        ws->rev_cols, ws->Hs, ws->nrms, tmin, ws->rev_rows, ws->tau, ws->cand_cnt, rev);
     // grids are sized for all rows; blocks past the compacted count (or past their row block's strips) leave at once
