@@ -1,0 +1,50 @@
+"""Per-kernel HBM bytes per launch from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) -> profiles/pmc_traffic.json.
+
+    python tools/pmc_to_json.py gpurun_out/round/pmc_fetch.csv gpurun_out/round/pmc_write.csv profiles/pmc_traffic.json
+
+hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: both counters are KiB, and on gfx950 FETCH_SIZE reports half of a wide
+coalesced read (/opt/skills/guides/MI355X_MICROARCH.md, HBM / rocprofv3 section).
+"""
+import csv
+import json
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    m = re.match(r"^_Z(\d+)", name)          # rocprofv3 leaves some names mangled: _Z<len><name>...
+    if m:
+        return name[m.end():m.end() + int(m.group(1))]
+    name = re.sub(r"^void ", "", name)
+    name = name.split("(")[0]
+    return re.sub(r"<.*$", "", name) if name.startswith("at::") else name
+
+
+def per_kernel(path, counter):
+    acc = defaultdict(lambda: [0.0, 0])
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        a = acc[short(r["Kernel_Name"])]
+        a[0] += float(r["Counter_Value"]); a[1] += 1
+    return {k: v[0] / v[1] for k, v in acc.items()}
+
+
+def main(fetch_csv, write_csv, out):
+    f = per_kernel(fetch_csv, "FETCH_SIZE"); w = per_kernel(write_csv, "WRITE_SIZE")
+    res = {"_how": "rocprofv3 --pmc FETCH_SIZE (and, in a separate run, --pmc WRITE_SIZE) --output-format csv -- python3 bench.py "
+                   "--steps 2 --warmup 1 --streams 1 --pairs 8 --no-cpu-baseline ; per-launch averages over all launches of the run; "
+                   "FETCH_SIZE/WRITE_SIZE are KiB; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE reports half of a "
+                   "wide coalesced read, MI355X_MICROARCH.md section HBM); tools/prof_round.sh + tools/pmc_to_json.py"}
+    for k in sorted(set(f) | set(w)):
+        fk, wk = f.get(k, 0.0), w.get(k, 0.0)
+        res[k] = {"FETCH_SIZE_KiB": round(fk, 1), "WRITE_SIZE_KiB": round(wk, 1), "hbm_bytes_per_launch": int((2 * fk + wk) * 1024)}
+    json.dump(res, open(out, "w"), indent=1)
+    for k, v in res.items():
+        if k != "_how":
+            print(f"{k:36s} {v['hbm_bytes_per_launch'] / 1e6:9.2f} MB")
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:4])
