@@ -122,6 +122,40 @@ def test_nn_to_mutual_ragged_vs_oracle(lr, oracle, n0, n1, seed):
     assert np.array_equal(m0.numpy(), e0) and np.array_equal(m1.numpy(), e1) and np.array_equal(m2.numpy(), e2)
 
 
+def _mutual_vs_oracle(lr, oracle, F0, F1):
+    i0, i1, i2, _ = oracle.find_2nn(F0, F1)
+    e0, e1, e2 = oracle.nn_to_mutual(F0, F1, i0, i1, i2)
+    t = lr.torch.from_numpy
+    m0, m1, m2 = lr.matching.nn_to_mutual(t(F0), t(F1), t(i0), t(i1), t(i2))
+    assert np.array_equal(m0.numpy(), e0) and np.array_equal(m1.numpy(), e1) and np.array_equal(m2.numpy(), e2)
+    return len(e0)
+
+
+def test_nn_to_mutual_reverse_ordering_edge_cases(lr, oracle):
+    """The reverse pass orders rows / columns by forward NN distance and prunes column tiles: inputs that stress it."""
+    rng = np.random.default_rng(77)
+    # (a) every query points at the same target: one row in the reverse pass, 1999 cloud-1 points left out
+    F1 = rng.standard_normal((2000, 32)).astype(np.float32); F1 /= np.linalg.norm(F1, axis=1, keepdims=True)
+    F0 = np.tile(F1[123], (700, 1)) + 1e-3 * rng.standard_normal((700, 32)).astype(np.float32)
+    assert _mutual_vs_oracle(lr, oracle, F0.astype(np.float32), F1) == 1
+    # (b) all forward distances identical (a permuted copy): the distance range is a single point, one sort bucket
+    F0 = rng.standard_normal((1500, 32)).astype(np.float32)
+    perm = rng.permutation(1500)
+    assert _mutual_vs_oracle(lr, oracle, F0, F0[perm].copy()) == 1500
+    # (c) exact duplicates on both sides: ties everywhere, resolved by index order in both directions
+    base = rng.standard_normal((300, 32)).astype(np.float32)
+    F0 = np.concatenate([base, base, base[:100]]); F1 = np.concatenate([base[::-1], base[:50]])
+    _mutual_vs_oracle(lr, oracle, F0, F1)
+    # (d) widely spread distances (clusters at very different scales) and a far outlier
+    F0 = np.concatenate([1e-3 * rng.standard_normal((400, 32)), rng.standard_normal((400, 32)), 40.0 * rng.standard_normal((400, 32))]).astype(np.float32)
+    F1 = (F0[rng.permutation(1200)[:900]] * (1 + 0.05 * rng.standard_normal((900, 1)))).astype(np.float32)
+    F1[0] = 3000.0
+    _mutual_vs_oracle(lr, oracle, F0, F1)
+    # (e) more rows than one block on the reverse side, few columns
+    F0, F1 = synth.make_features(40, 2600, 32, 0.5, 0.8, 91)
+    _mutual_vs_oracle(lr, oracle, F0, F1)
+
+
 def test_ratio_bit_exact(lr, oracle, filt):
     r = lr.matching.calc_distance_ratio_in_feature_space(filt["F0"], filt["F1"], filt["i0"], filt["i1"], filt["i2"])
     e = oracle.calc_distance_ratio_in_feature_space(filt["F0"], filt["F1"], filt["i0"], filt["i1"], filt["i2"])
