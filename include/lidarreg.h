@@ -45,6 +45,12 @@ typedef struct lr_ransac_params {
                                batch ending at id e the run stops when e >= log(1-confidence) / log(1 - (inl/M)^sample_size)
                                for the best model so far.  >= 1 (or <= 0): every id is evaluated.             */
     int32_t  batch;         /* batch length of the early-exit test (0 -> 8192)                        */
+    int32_t  sampler;       /* 0: uniform (GC_RANSAC.py:19 'sampler': 0); 1: PROSAC (--prosac, GC_RANSAC.py:24,39-43):
+                               the correspondences must come best quality first; hypothesis id h = PROSAC draw h+1:
+                               sample_size-1 indices uniformly from the first n-1 correspondences plus the n-th, n from
+                               the growth function of Chum & Matas 2005 (as in USAC / GC-RANSAC's prosac_sampler.h);
+                               ids past prosac_growth fall back to uniform sampling over all correspondences        */
+    int32_t  prosac_growth; /* T_N of the growth function (0 -> 100000, GC-RANSAC's default)          */
 } lr_ransac_params;
 
 /* Written to device memory by lr_ransac / lr_register_pair. */

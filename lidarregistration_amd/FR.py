@@ -44,12 +44,14 @@ def pair_params(args):
         sample_size = 3
         use_elc = getattr(args, "fast_rejection", "ELC") == "ELC"
         conf = float(getattr(args, "GC_conf", 0.999))                  # GC_RANSAC.py:26, test.py:312
+        sampler = 1 if getattr(args, "prosac", True) else 0            # test.py:308 (default True), GC_RANSAC.py:24
     else:
+        sampler = 0
         sample_size = int(getattr(args, "ransac_n", 4))                # FR.py:134
         use_elc = True                                                 # FR.py:135 edge-length checker
         conf = float(getattr(args, "o3d_conf", 0.9995))                # FR.py:136
     rp = _ext.RansacParams(sample_size, int(use_elc), np.float32(thr * thr), iters, int(getattr(args, "seed", DEFAULT_SEED)),
-                           conf, int(getattr(args, "ransac_batch", 0)))
+                           conf, int(getattr(args, "ransac_batch", 0)), sampler, int(getattr(args, "prosac_growth", 0)))
     p = _ext.PairParams()
     p.mode = MODES[mode]
     # open3D codebase: FR.py:99-111 refits over the original NN pairs; the GC codebase returns pygcransac's own final

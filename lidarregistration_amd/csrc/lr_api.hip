@@ -16,6 +16,9 @@ void lr_set_error(const char *fmt, ...)
     va_end(ap);
 }
 
+static_assert(sizeof(lr_ransac_params) == 40 && sizeof(lr_pair_params) == 72 && sizeof(lr_pair_result) == 496,
+              "ABI structs changed: update include/lidarreg.h, _ext.py, INTEGRATION.md and tests/test_abi_cpu.py together");
+
 extern "C" int lr_version(void) { return 100; }
 extern "C" const char *lr_last_error(void) { return g_err; }
 
@@ -65,6 +68,7 @@ void carve(lr_workspace *ws, Carver &c)
     ws->gpf_keep = c.take<uint8_t>(n0);
     ws->gpf_f = c.take<float>(8);
     ws->corr8 = c.take<float>((n0 + 2) * 8);
+    ws->prosac_G = c.take<int32_t>(n0 + 2); ws->prosac_rank = c.take<int32_t>(n0);
     ws->models = c.take<float>(it * 12);
     ws->models64 = c.take<double>(it * 12);
     ws->model_h = c.take<int32_t>(it);
@@ -349,7 +353,12 @@ extern "C" int lr_register_pair(lr_workspace *ws, const float *xyz0, const float
         }
     }
     // 3. RANSAC on the surviving pairs (FR.py:70-97); MNN / GPF pack the point pairs inside their compaction kernel
-    if (p->mode == LR_MODE_NO_FILTER) LR_TRY(lr_pack_corr(ws, xyz0, xyz1, ws->corr_idx0, ws->corr_idx1, n0, m_dev, ws->corr8, st));
+    if (p->ransac.sampler == 1) {
+        // PROSAC (FR.py:73-80, GC_RANSAC.py:39-43): records re-packed best match quality first; quality = -feature-distance
+        // ratio of the pair, or GPF's normalised feature distance
+        LR_TRY(lr_prosac_order(ws, F0, F1, dim, p->mode == LR_MODE_GPF ? ws->corr_score : nullptr, n0, m_dev, st));
+        LR_TRY(lr_pack_corr(ws, xyz0, xyz1, ws->corr_idx0, ws->corr_idx1, n0, m_dev, ws->corr8, st, ws->prosac_rank));
+    } else if (p->mode == LR_MODE_NO_FILTER) LR_TRY(lr_pack_corr(ws, xyz0, xyz1, ws->corr_idx0, ws->corr_idx1, n0, m_dev, ws->corr8, st));
     LR_TRY(lr_ransac_run(ws, ws->corr8, n0, m_dev, &p->ransac, ws->T_tmp, ws->res_tmp, st));
     // 4. LS refit over the original NN pairs (FR.py:99-111)
     const double *T_final = ws->T_tmp;

@@ -134,7 +134,7 @@ int lr_identity_corr(lr_workspace *ws, int n0, const int32_t *idx1, const int32_
 __global__ void pack_corr_kernel(const float *__restrict__ xyz0, const float *__restrict__ xyz1,
                                  const int32_t *__restrict__ i0, const int32_t *__restrict__ i1,
                                  int m_max, const int32_t *__restrict__ m_dev, float *__restrict__ corr8,
-                                 int32_t *__restrict__ counters)
+                                 int32_t *__restrict__ counters, const int32_t *__restrict__ rank)
 {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < LR_CNT_TOTAL - LR_CNT_COUNT) counters[LR_CNT_COUNT + c] = 0;     // the RANSAC that follows starts from scratch
@@ -142,18 +142,60 @@ __global__ void pack_corr_kernel(const float *__restrict__ xyz0, const float *__
     int m = m_dev ? min(*m_dev, m_max) : m_max;
     if (c >= m) return;
     int a = i0 ? i0[c] : c, b = i1 ? i1[c] : c;
+    const int dst = rank ? rank[c] : c;          // PROSAC: records in quality order
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        corr8[lr_corr_at(c, k)] = xyz0[3 * a + k];
-        corr8[lr_corr_at(c, 3 + k)] = xyz1[3 * b + k];
+        corr8[lr_corr_at(dst, k)] = xyz0[3 * a + k];
+        corr8[lr_corr_at(dst, 3 + k)] = xyz1[3 * b + k];
     }
 }
 
 int lr_pack_corr(lr_workspace *ws, const float *xyz0, const float *xyz1, const int32_t *i0, const int32_t *i1, int m_max,
-                 const int32_t *m_dev, float *corr8, hipStream_t st)
+                 const int32_t *m_dev, float *corr8, hipStream_t st, const int32_t *rank)
 {
     hipLaunchKernelGGL(pack_corr_kernel, dim3(lr_cdiv(m_max > 0 ? m_max : 1, 256)), dim3(256), 0, st, xyz0, xyz1, i0, i1, m_max, m_dev, corr8,
-                       ws->counters);
+                       ws->counters, rank);
+    LR_LAUNCH_CHECK();
+    return LR_OK;
+}
+
+// ------------------------------------------------------------------ PROSAC order (GC_RANSAC.py:39-43)
+// rank[c] = position of pair c when the pairs are sorted by ascending feature distance (= descending match quality,
+// FR.py:74-80), ties by c (numpy's argsort leaves ties unspecified; a stable order keeps the result reproducible), NaN
+// last.  Counting rank, O(M^2) compares on wave-uniform loads: M is a few 1e4 and the kernel is tens of microseconds.
+__global__ void __launch_bounds__(256)
+prosac_rank_kernel(const float *__restrict__ q, int m_max, const int32_t *__restrict__ m_dev, int32_t *__restrict__ rank)
+{
+    const int m = m_dev ? min(*m_dev, m_max) : m_max;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if ((int)blockIdx.x * 256 >= m) return;
+    float v = c < m ? q[c] : 0.0f;
+    if (!(v == v)) v = __builtin_huge_valf();
+    int r = 0;
+    for (int j = 0; j < m; ++j) {
+        float w = q[j];                          // wave-uniform address: scalar load
+        if (!(w == w)) w = __builtin_huge_valf();
+        r += (w < v || (w == v && j < c)) ? 1 : 0;
+    }
+    if (c < m) rank[c] = r;
+}
+
+__global__ void ratio_kernel(const float *__restrict__ F0, const float *__restrict__ F1, int dim, int m, const int32_t *__restrict__ m_dev,
+                             const int32_t *__restrict__ i0, const int32_t *__restrict__ i1, const int32_t *__restrict__ i2,
+                             float *__restrict__ out);
+
+// quality = feature-distance ratio of the listed pairs (FR.py:77) unless the caller has one already (GPF's
+// norm_feat_dist, FR.py:75); then the ranks
+int lr_prosac_order(lr_workspace *ws, const float *F0, const float *F1, int dim, const float *quality, int m_max, const int32_t *m_dev,
+                    hipStream_t st)
+{
+    const int nb = lr_cdiv(m_max > 0 ? m_max : 1, 256);
+    if (!quality) {
+        hipLaunchKernelGGL(ratio_kernel, dim3(nb), dim3(256), 0, st, F0, F1, dim, m_max, m_dev, (const int32_t *)ws->corr_idx0,
+                           (const int32_t *)ws->corr_idx1, (const int32_t *)ws->corr_idx2, ws->ratio);
+        quality = ws->ratio;
+    }
+    hipLaunchKernelGGL(prosac_rank_kernel, dim3(nb), dim3(256), 0, st, quality, m_max, m_dev, ws->prosac_rank);
     LR_LAUNCH_CHECK();
     return LR_OK;
 }

@@ -78,6 +78,8 @@ struct lr_workspace {
     int32_t *gpf_cells;          // GPF: cell_count | cell_fill | cell_off, each [LR_GPF_MAX_CELLS + 8]
     uint8_t *gpf_keep;           // GPF: keep mask [max_n0]
     float *gpf_f;                // GPF: min/max scratch
+    int32_t *prosac_G;           // [max_n0+2] PROSAC growth function G[n], n = sample_size..M
+    int32_t *prosac_rank;        // [max_n0] position of each filtered pair in quality order
     float *corr8;                // packed correspondences, 8 floats each, interleaved in pairs (lr_corr_at)
     // --- RANSAC ---
     float *models;               // [max_iters][12] fp32 R|t rows of hypotheses that passed the pre-check
@@ -153,7 +155,9 @@ int lr_mutual_run(lr_workspace *ws, int n0, const int32_t *idx1, const int32_t *
 int lr_identity_corr(lr_workspace *ws, int n0, const int32_t *idx1, const int32_t *idx2,
                      int32_t *o0, int32_t *o1, int32_t *o2, int32_t *n_out, hipStream_t st);
 int lr_pack_corr(lr_workspace *ws, const float *xyz0, const float *xyz1, const int32_t *i0, const int32_t *i1, int m_max,
-                 const int32_t *m_dev, float *corr8, hipStream_t st);
+                 const int32_t *m_dev, float *corr8, hipStream_t st, const int32_t *rank = nullptr);
+int lr_prosac_order(lr_workspace *ws, const float *F0, const float *F1, int dim, const float *quality, int m_max, const int32_t *m_dev,
+                    hipStream_t st);
 int lr_gpf_run(lr_workspace *ws, const float *F0, int n0, const float *F1, int dim,
                const int32_t *idx1, const int32_t *idx2, const uint8_t *is_bb, const float *xyz0,
                int grid_wid, double factor, int32_t *o0, int32_t *o1, int32_t *o2, float *oscore,

@@ -530,7 +530,9 @@ nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, in
     int i1 = LR_IMAX, i2 = LR_IMAX;
     const int total = cand_cnt[rowc];
     const int over = total > LR_NN16_CAP ? 1 : 0;
-    for (int c = q; c < min(total, LR_NN16_CAP); c += 4) {
+    // an overflowed list is not read at all: its slots are only partly written (the rest is stale from earlier pairs)
+    const int ncand = over ? 0 : total;
+    for (int c = q; c < ncand; c += 4) {
         const int j = cand[(size_t)rowc * LR_NN16_CAP + c];
         const f32x4 *pb = reinterpret_cast<const f32x4 *>(Fc + (size_t)j * 32);
         float acc = 0.0f;

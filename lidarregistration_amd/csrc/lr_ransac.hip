@@ -66,15 +66,71 @@ __device__ __forceinline__ void kabsch_sample(const double P[NS][3], const doubl
 }
 
 // sample of hypothesis h and its edge-length pre-check; false when the pre-check rejects it
+// PROSAC growth function (Chum & Matas 2005, as tabulated by USAC / GC-RANSAC's prosac_sampler.h):
+//   T_n = T_N prod_{i<ns} (n-i)/(M-i),  G[ns] = 1,  G[n+1] = G[n] + ceil(T_{n+1} - T_n)
+// Draw k uses the first n_k = min(M, ns + #{n in [ns, M) : G[n] <= k}) correspondences.  T_n is evaluated in closed
+// form (same operation order as oracle/oracle.c) so that the table is a parallel prefix sum: one block.
+__device__ __forceinline__ double prosac_Tn(int n, int M, int ns, double TN)
+{
+    double t = TN;
+    for (int i = 0; i < ns; ++i) t = t * (double)(n - i) / (double)(M - i);
+    return t;
+}
+
+__global__ void __launch_bounds__(1024)
+prosac_growth_kernel(int m_max, const int32_t *__restrict__ m_dev, int ns, int TN, int32_t *__restrict__ G)
+{
+    __shared__ long long s_w[16];
+    __shared__ long long s_carry;
+    const int M = m_dev ? min(*m_dev, m_max) : m_max;
+    if (threadIdx.x == 0) s_carry = 1;       // G[ns] = 1
+    __syncthreads();
+    // elements n = ns .. M-1 carry d_n = ceil(T_{n+1} - T_n) >= 1; G[n] = 1 + sum_{j<n} d_j, written for n = ns .. M
+    for (int base = ns; base < M; base += 1024) {
+        const int n = base + threadIdx.x;
+        long long d = 0;
+        if (n < M) {
+            const double a = prosac_Tn(n, M, ns, (double)TN), b = prosac_Tn(n + 1, M, ns, (double)TN);
+            d = (long long)ceil(b - a);
+            if (d < 1) d = 1;
+        }
+        long long inc = d;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const long long v = __shfl_up(inc, o); if ((int)(threadIdx.x & 63) >= o) inc += v; }
+        if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        long long pre = s_carry;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) pre += s_w[w];
+        if (n < M) {
+            const long long g = pre + inc - d;                    // G[n]
+            G[n] = (int32_t)(g < 0x3fffffffLL ? g : 0x3fffffffLL);
+            if (n == M - 1) { const long long g1 = g + d; G[M] = (int32_t)(g1 < 0x3fffffffLL ? g1 : 0x3fffffffLL); }
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = pre + inc;
+        __syncthreads();
+    }
+}
+
 template <int NS>
 __device__ __forceinline__ bool hypothesis_sample(const float *__restrict__ corr8, int m, uint64_t seed, uint64_t h,
-                                                  int use_elc, double P[NS][3], double Q[NS][3])
+                                                  int use_elc, double P[NS][3], double Q[NS][3],
+                                                  const int32_t *__restrict__ G, int TN)
 {
     uint32_t c[4] = { (uint32_t)h, (uint32_t)(h >> 32), 0u, 0u };
     philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    // PROSAC: draw k = h + 1 takes NS-1 indices from the first n-1 correspondences and the n-th one
+    int n_top = 0;
+    if (G && h < (uint64_t)TN && m > NS) {
+        const int k = (int)h + 1;
+        int lo = NS, hi = m;                       // first n in [NS, m) with G[n] > k
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (G[mid] <= k) lo = mid + 1; else hi = mid; }
+        n_top = min(m, lo);                        // = NS + #{n : G[n] <= k}
+    }
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
         uint32_t s = __umulhi(c[k], (uint32_t)m);
+        if (n_top) s = k < NS - 1 ? __umulhi(c[k], (uint32_t)(n_top - 1)) : (uint32_t)(n_top - 1);
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             P[k][a] = (double)corr8[lr_corr_at((int)s, a)];
@@ -105,7 +161,7 @@ __global__ void __launch_bounds__(256)
 ransac_gen_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__restrict__ m_dev, lr_ransac_params p,
                   int h_begin, int h_end, float *__restrict__ models, double *__restrict__ models64, int32_t *__restrict__ model_h,
                   uint32_t *__restrict__ score_cnt, unsigned long long *__restrict__ score_ssq,
-                  int32_t *__restrict__ counters)
+                  int32_t *__restrict__ counters, const int32_t *__restrict__ G, int TN)
 {
     __shared__ int s_pass[256];
     __shared__ int s_np, s_base;
@@ -116,7 +172,7 @@ ransac_gen_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__r
     const int h = h_begin + blockIdx.x * 256 + threadIdx.x;
     {
         double P[NS][3], Q[NS][3];
-        if (h < h_end && hypothesis_sample<NS>(corr8, m, p.seed, (uint64_t)h, p.use_elc, P, Q)) s_pass[atomicAdd(&s_np, 1)] = h;
+        if (h < h_end && hypothesis_sample<NS>(corr8, m, p.seed, (uint64_t)h, p.use_elc, P, Q, G, TN)) s_pass[atomicAdd(&s_np, 1)] = h;
     }
     __syncthreads();
     const int np = s_np;
@@ -125,7 +181,7 @@ ransac_gen_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__r
     if ((int)threadIdx.x >= np) return;
     const int hh = s_pass[threadIdx.x];
     double P[NS][3], Q[NS][3], T[16];
-    hypothesis_sample<NS>(corr8, m, p.seed, (uint64_t)hh, 0, P, Q);
+    hypothesis_sample<NS>(corr8, m, p.seed, (uint64_t)hh, 0, P, Q, G, TN);
     kabsch_sample<NS>(P, Q, T);
     const int slot = s_base + threadIdx.x;
 #pragma unroll
@@ -289,16 +345,24 @@ int lr_ransac_run(lr_workspace *ws, const float *corr8, int m_max, const int32_t
     if (sub < 2) sub = 2;       // 2 * thr2 * 2^20 < 2^32 for every admissible thr2 (< 2048)
     const bool use_exit = p->confidence > 0.0f && p->confidence < 1.0f;
     const int B = use_exit ? (p->batch > 0 ? p->batch : 8192) : (p->iters > 0 ? p->iters : 1);
+    LR_REQUIRE(p->sampler == 0 || p->sampler == 1, LR_EINVAL, "lr_ransac: sampler must be 0 (uniform) or 1 (PROSAC)");
+    LR_REQUIRE(p->prosac_growth >= 0, LR_EINVAL, "lr_ransac: prosac_growth must be >= 0");
+    const int TN = p->prosac_growth > 0 ? p->prosac_growth : 100000;
+    const int32_t *G = nullptr;
     if (ws->timing && ws->ev_pending == 1) { LR_HIP(hipEventRecord(ws->ev[2], st)); }
+    if (p->sampler == 1) {
+        hipLaunchKernelGGL(prosac_growth_kernel, dim3(1), dim3(1024), 0, st, m_max, m_dev, p->sample_size, TN, ws->prosac_G);
+        G = ws->prosac_G;
+    }
     for (int h0 = 0; h0 < (p->iters > 0 ? p->iters : 1); h0 += B) {
         const int h1 = h0 + B < p->iters ? h0 + B : p->iters;
         const int gb = lr_cdiv(h1 - h0 > 0 ? h1 - h0 : 1, 256);
         if (p->sample_size == 3)
             hipLaunchKernelGGL(ransac_gen_kernel<3>, dim3(gb), dim3(256), 0, st, corr8, m_max, m_dev, *p, h0, h1, ws->models, ws->models64,
-                               ws->model_h, ws->score_cnt, ws->score_ssq, ws->counters);
+                               ws->model_h, ws->score_cnt, ws->score_ssq, ws->counters, G, TN);
         else
             hipLaunchKernelGGL(ransac_gen_kernel<4>, dim3(gb), dim3(256), 0, st, corr8, m_max, m_dev, *p, h0, h1, ws->models, ws->models64,
-                               ws->model_h, ws->score_cnt, ws->score_ssq, ws->counters);
+                               ws->model_h, ws->score_cnt, ws->score_ssq, ws->counters, G, TN);
         hipLaunchKernelGGL(ransac_score_kernel, dim3(LR_SCORE_BLOCKS), dim3(64), 0, st, corr8, m_max, m_dev, p->thr2, ws->models,
                            ws->score_cnt, ws->score_ssq, ws->counters, sub);
         if (h0 == 0 && ws->timing && ws->ev_pending == 1) { LR_HIP(hipEventRecord(ws->ev[3], st)); ws->ev_pending = 2; }

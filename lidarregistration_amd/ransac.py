@@ -16,20 +16,22 @@ from .matching import _device, _f32, _i32, _stream, workspace
 DEFAULT_SEED = 51          # Experiments/test.py:357
 
 
-def ransac_params(iters, sample_size=3, use_elc=True, thr=0.6, seed=DEFAULT_SEED, confidence=1.0, batch=0):
-    """confidence < 1 enables the early exit between batches of `batch` hypothesis ids (0 -> 8192)."""
+def ransac_params(iters, sample_size=3, use_elc=True, thr=0.6, seed=DEFAULT_SEED, confidence=1.0, batch=0, sampler=0, prosac_growth=0):
+    """confidence < 1 enables the early exit between batches of `batch` hypothesis ids (0 -> 8192); sampler 1 = PROSAC
+    (correspondences best quality first, growth parameter T_N = prosac_growth, 0 -> 100000)."""
     return _ext.RansacParams(int(sample_size), int(bool(use_elc)), np.float32(float(thr) * float(thr)), int(iters), int(seed),
-                             float(confidence), int(batch))
+                             float(confidence), int(batch), int(sampler), int(prosac_growth))
 
 
-def ransac_dev(src, tgt, iters, sample_size=3, use_elc=True, thr=0.6, seed=DEFAULT_SEED, confidence=1.0, batch=0):
+def ransac_dev(src, tgt, iters, sample_size=3, use_elc=True, thr=0.6, seed=DEFAULT_SEED, confidence=1.0, batch=0, sampler=0,
+               prosac_growth=0):
     """RANSAC over M correspondences src[i] <-> tgt[i] ([M,3]).  Returns (T 4x4 float64 numpy, info dict)."""
     src, tgt = _f32(src), _f32(tgt)
     m = src.shape[0]
     ws = workspace(max(m, 1), 1, iters)
     T = torch.empty(16, dtype=torch.float64, device=src.device)
     res = torch.zeros(ctypes.sizeof(_ext.RansacResult), dtype=torch.uint8, device=src.device)
-    p = ransac_params(iters, sample_size, use_elc, thr, seed, confidence, batch)
+    p = ransac_params(iters, sample_size, use_elc, thr, seed, confidence, batch, sampler, prosac_growth)
     _ext.check(_ext.lib().lr_ransac(ws.handle, src.data_ptr(), tgt.data_ptr(), m, None, ctypes.byref(p),
                                      T.data_ptr(), res.data_ptr(), _stream()))
     r = _ext.RansacResult.from_buffer_copy(res.cpu().numpy().tobytes())
@@ -80,12 +82,21 @@ def GC_RANSAC(A, B, distance_threshold, num_iterations, args, match_quality):
     """GC_RANSAC.py:8-55: (pose 4x4 column-vector convention, elapsed seconds).
 
     A, B: [M,3] float32 numpy.  Flags read from args: fast_rejection ("ELC" | "NONE" | "SPRT"; SPRT has no
-    device counterpart and is treated as ELC off).  PROSAC ordering (match_quality), local optimisation and
-    the spatial-coherence term of the third-party library are not part of this path: sampling is uniform."""
+    device counterpart and is treated as ELC off), prosac (GC_RANSAC.py:24,39-43: pairs sorted by -match_quality,
+    ties by index, PROSAC sampler).  Local optimisation and the spatial-coherence term of the third-party
+    library are not part of this path."""
     use_elc = getattr(args, "fast_rejection", "ELC") == "ELC"
+    A = np.ascontiguousarray(A, np.float32); B = np.ascontiguousarray(B, np.float32)
+    prosac = bool(getattr(args, "prosac", False)) and match_quality is not None
+    if prosac:
+        fd = -np.asarray(match_quality, np.float32)
+        fd[np.isnan(fd)] = np.inf
+        order = np.argsort(fd, kind="stable")                # sort from best quality to worst (GC_RANSAC.py:40-43)
+        A, B = A[order], B[order]
     start_time = time()
     T, info = ransac_dev(A, B, num_iterations, sample_size=3, use_elc=use_elc, thr=distance_threshold,
-                         seed=getattr(args, "seed", DEFAULT_SEED), confidence=getattr(args, "GC_conf", 0.999))      # GC_RANSAC.py:26
+                         seed=getattr(args, "seed", DEFAULT_SEED), confidence=getattr(args, "GC_conf", 0.999),      # GC_RANSAC.py:26
+                         sampler=1 if prosac else 0)
     if info["best_h"] < 0:
         T = np.eye(4)                                       # GC_RANSAC.py:51-52
     return T, time() - start_time

@@ -150,6 +150,48 @@ static inline void draw_sample(uint64_t seed, uint64_t h, int m, int ns, int32_t
     for (int k = 0; k < ns; ++k) s[k] = (int32_t)(((uint64_t)w[k] * (uint64_t)(uint32_t)m) >> 32);
 }
 
+/* PROSAC (Chum & Matas, CVPR 2005; tabulated as in USAC's / GC-RANSAC's prosac_sampler.h, a third-party dependency that
+ * is not vendored -- GC_RANSAC.py:19,24,39-43 only select it and sort the pairs by quality).  Growth function
+ *   T_n = T_N prod_{i<ns} (n-i)/(M-i),  G[ns] = 1,  G[n+1] = G[n] + ceil(T_{n+1} - T_n)
+ * and draw k (= hypothesis id + 1, k <= T_N) takes ns-1 indices uniformly (with replacement, like the uniform sampler
+ * above) from the first n_k - 1 correspondences plus the n_k-th, n_k = min(M, ns + #{n in [ns, M) : G[n] <= k}).
+ * T_n is evaluated in closed form, in this operation order (the HIP kernel does the same).                         */
+static double prosac_Tn(int n, int M, int ns, double TN)
+{
+    double t = TN;
+    for (int i = 0; i < ns; ++i) t = t * (double)(n - i) / (double)(M - i);
+    return t;
+}
+
+/* G[ns..M], entries below ns unused; caller frees */
+static int32_t *prosac_table(int M, int ns, int TN)
+{
+    int32_t *G = (int32_t *)malloc(sizeof(int32_t) * (size_t)(M + 2));
+    long long g = 1;
+    for (int n = ns; n <= M; ++n) {
+        G[n] = (int32_t)(g < 0x3fffffffLL ? g : 0x3fffffffLL);
+        if (n < M) {
+            long long d = (long long)ceil(prosac_Tn(n + 1, M, ns, (double)TN) - prosac_Tn(n, M, ns, (double)TN));
+            if (d < 1) d = 1;
+            g += d;
+        }
+    }
+    return G;
+}
+
+static inline void draw_sample_prosac(uint64_t seed, uint64_t h, int m, int ns, const int32_t *G, int TN, int32_t *s)
+{
+    if (!G || h >= (uint64_t)TN || m <= ns) { draw_sample(seed, h, m, ns, s); return; }
+    const int k = (int)h + 1;
+    int lo = ns, hi = m;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (G[mid] <= k) lo = mid + 1; else hi = mid; }
+    const int n = lo < m ? lo : m;
+    uint32_t w[4];
+    orc_philox(seed, h, w);
+    for (int j = 0; j < ns - 1; ++j) s[j] = (int32_t)(((uint64_t)w[j] * (uint64_t)(uint32_t)(n - 1)) >> 32);
+    s[ns - 1] = n - 1;
+}
+
 /* ----------------------------------------------------------------- ELC ---- */
 
 /* preemption_edge_length.h:71-128: reject when any pair of sample edges differs by more than 0.9 */
@@ -293,6 +335,8 @@ typedef struct {
     uint64_t seed;
     float    confidence;      /* early exit between batches (FR.py:136, GC_RANSAC.py:26); >= 1 or <= 0: none */
     int32_t  batch;           /* batch length (0 -> 8192)                             */
+    int32_t  sampler;         /* 0 uniform; 1 PROSAC (GC_RANSAC.py:24,39-43): correspondences best first */
+    int32_t  prosac_growth;   /* T_N of the PROSAC growth function (0 -> 100000)       */
 } orc_ransac_params;
 
 typedef struct {
@@ -305,10 +349,10 @@ typedef struct {
 
 /* fp64 minimal-sample Kabsch for hypothesis h; returns 0 when the pre-check rejects it */
 static int hypothesis_T(const float *src, const float *tgt, int m, const orc_ransac_params *p,
-                        uint64_t h, double T[16], int32_t *sample_out)
+                        uint64_t h, double T[16], int32_t *sample_out, const int32_t *G)
 {
     int32_t s[4];
-    draw_sample(p->seed, h, m, p->sample_size, s);
+    draw_sample_prosac(p->seed, h, m, p->sample_size, G, p->prosac_growth > 0 ? p->prosac_growth : 100000, s);
     if (sample_out) memcpy(sample_out, s, sizeof(int32_t) * p->sample_size);
     if (p->use_elc && !elc_ok(src, tgt, s, p->sample_size)) return 0;
     double P[12], Q[12];
@@ -321,7 +365,10 @@ static int hypothesis_T(const float *src, const float *tgt, int m, const orc_ran
 ORC_API int orc_hypothesis(const float *src, const float *tgt, int m, const orc_ransac_params *p,
                            uint64_t h, double T[16], int32_t sample[4])
 {
-    return hypothesis_T(src, tgt, m, p, h, T, sample);
+    int32_t *G = p->sampler == 1 ? prosac_table(m, p->sample_size, p->prosac_growth > 0 ? p->prosac_growth : 100000) : NULL;
+    const int ok = hypothesis_T(src, tgt, m, p, h, T, sample, G);
+    free(G);
+    return ok;
 }
 
 /* inlier count + fixed-point squared-error sum of one fp32 model over all m correspondences */
@@ -360,6 +407,7 @@ ORC_API void orc_ransac(const float *src, const float *tgt, int m, const orc_ran
     int64_t best_h = -1; uint32_t best_c = 0; uint64_t best_q = 0; int64_t n_valid = 0, n_ids = 0;
     const int use_exit = p->confidence > 0.0f && p->confidence < 1.0f;
     const int64_t B = use_exit ? (p->batch > 0 ? p->batch : 8192) : (p->iters > 0 ? p->iters : 1);
+    int32_t *G = p->sampler == 1 ? prosac_table(m, p->sample_size, p->prosac_growth > 0 ? p->prosac_growth : 100000) : NULL;
     for (int64_t h0 = 0; h0 < p->iters; h0 += B) {
         const int64_t h1 = h0 + B < p->iters ? h0 + B : p->iters;
 #pragma omp parallel
@@ -368,7 +416,7 @@ ORC_API void orc_ransac(const float *src, const float *tgt, int m, const orc_ran
 #pragma omp for schedule(dynamic, 64)
             for (int64_t h = h0; h < h1; ++h) {
                 double T[16];
-                if (!hypothesis_T(src, tgt, m, p, (uint64_t)h, T, NULL)) continue;
+                if (!hypothesis_T(src, tgt, m, p, (uint64_t)h, T, NULL, G)) continue;
                 lv += 1;
                 float Rt[12];
                 for (int k = 0; k < 12; ++k) Rt[k] = (float)T[k];
@@ -396,7 +444,8 @@ ORC_API void orc_ransac(const float *src, const float *tgt, int m, const orc_ran
         }
     }
     for (int k = 0; k < 16; ++k) T_best[k] = (k % 5 == 0) ? 1.0 : 0.0;
-    if (best_h >= 0) hypothesis_T(src, tgt, m, p, (uint64_t)best_h, T_best, NULL);
+    if (best_h >= 0) hypothesis_T(src, tgt, m, p, (uint64_t)best_h, T_best, NULL, G);
+    free(G);
     res->best_h = best_h; res->best_count = best_c; res->best_ssq = best_q; res->n_valid = n_valid; res->n_ids = n_ids;
 }
 

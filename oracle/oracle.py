@@ -34,7 +34,8 @@ c_i32p = ctypes.POINTER(ctypes.c_int32)
 class RansacParams(ctypes.Structure):
     _fields_ = [("sample_size", ctypes.c_int32), ("use_elc", ctypes.c_int32),
                 ("thr2", ctypes.c_float), ("iters", ctypes.c_int32), ("seed", ctypes.c_uint64),
-                ("confidence", ctypes.c_float), ("batch", ctypes.c_int32)]
+                ("confidence", ctypes.c_float), ("batch", ctypes.c_int32),
+                ("sampler", ctypes.c_int32), ("prosac_growth", ctypes.c_int32)]
 
 
 class RansacResult(ctypes.Structure):
@@ -282,14 +283,22 @@ def philox(seed, h):
 
 # ----------------------------------------------------------------------------- RANSAC (a10) + refit (a11)
 
-def _params(sample_size, use_elc, thr, iters, seed, confidence=1.0, batch=0):
-    return RansacParams(sample_size, int(use_elc), np.float32(float(thr) * float(thr)), iters, seed, confidence, batch)
+def _params(sample_size, use_elc, thr, iters, seed, confidence=1.0, batch=0, sampler=0, prosac_growth=0):
+    return RansacParams(sample_size, int(use_elc), np.float32(float(thr) * float(thr)), iters, seed, confidence, batch,
+                        int(sampler), int(prosac_growth))
 
 
-def hypothesis(src, tgt, h, sample_size=3, use_elc=True, thr=0.6, seed=51):
+def prosac_order(feat_dist):
+    """GC_RANSAC.py:39-43: ord = argsort(-match_quality) with match_quality = -feat_dist (FR.py:80); ties by index, NaN last."""
+    fd = np.asarray(feat_dist, np.float32).copy()
+    fd[np.isnan(fd)] = np.inf
+    return np.argsort(fd, kind="stable")
+
+
+def hypothesis(src, tgt, h, sample_size=3, use_elc=True, thr=0.6, seed=51, sampler=0, prosac_growth=0):
     src, tgt = _f32(src), _f32(tgt)
     T = np.empty(16, np.float64); s = np.zeros(4, np.int32)
-    p = _params(sample_size, use_elc, thr, 0, seed)
+    p = _params(sample_size, use_elc, thr, 0, seed, sampler=sampler, prosac_growth=prosac_growth)
     ok = lib().orc_hypothesis(_p(src, c_f32p), _p(tgt, c_f32p), src.shape[0], ctypes.byref(p),
                               ctypes.c_uint64(h), _p(T, c_f64p), _p(s, c_i32p))
     return bool(ok), T.reshape(4, 4), s[:sample_size]
@@ -304,11 +313,12 @@ def score(src, tgt, T, thr=0.6):
     return c.value, q.value
 
 
-def ransac(src, tgt, iters, sample_size=3, use_elc=True, thr=0.6, seed=51, confidence=1.0, batch=0):
-    """RANSAC over M correspondences src[i] <-> tgt[i].  Returns (T 4x4 float64, info dict)."""
+def ransac(src, tgt, iters, sample_size=3, use_elc=True, thr=0.6, seed=51, confidence=1.0, batch=0, sampler=0, prosac_growth=0):
+    """RANSAC over M correspondences src[i] <-> tgt[i] (sampler=1: PROSAC, pairs best quality first).
+    Returns (T 4x4 float64, info dict)."""
     src, tgt = _f32(src), _f32(tgt)
     T = np.empty(16, np.float64)
-    p = _params(sample_size, use_elc, thr, iters, seed, confidence, batch)
+    p = _params(sample_size, use_elc, thr, iters, seed, confidence, batch, sampler, prosac_growth)
     r = RansacResult()
     lib().orc_ransac(_p(src, c_f32p), _p(tgt, c_f32p), src.shape[0], ctypes.byref(p), _p(T, c_f64p), ctypes.byref(r))
     return T.reshape(4, 4), dict(best_h=r.best_h, best_count=r.best_count, best_ssq=r.best_ssq, n_valid=r.n_valid, n_ids=r.n_ids)
@@ -358,21 +368,29 @@ def translation_error_cm(T, T_gt):
 # ----------------------------------------------------------------------------- whole pair (a9)
 
 def register_pair(xyz0, xyz1, feats0, feats1, mode="MNN", iters=50000, sample_size=3, use_elc=True,
-                  thr=0.6, seed=51, args=None, refit_on_orig=True, confidence=1.0, batch=0):
+                  thr=0.6, seed=51, args=None, refit_on_orig=True, confidence=1.0, batch=0, prosac=False):
     """FR.py:16-119 with the open3D-codebase ordering: NN -> filter -> RANSAC -> LS refit on the
     original NN pairs.  Returns dict(T, idx0, idx1, idx1_orig, ransac=info)."""
     idx0, idx1, idx2, _ = find_2nn(feats0, feats1)
     idx1_orig = idx1
+    feat_dist = None
     if mode in ("MNN", "MMN"):
-        f0, f1, _ = nn_to_mutual(feats0, feats1, idx0, idx1, idx2, force_return_2nd=True)
+        f0, f1, f2 = nn_to_mutual(feats0, feats1, idx0, idx1, idx2, force_return_2nd=True)
     elif mode == "GPF":
-        f0, f1, _, _, _, _, _ = Grid_Prioritized_Filter(feats0, feats1, idx0, idx1, idx2, xyz0, args)
+        f0, f1, f2, _, _, _, feat_dist = Grid_Prioritized_Filter(feats0, feats1, idx0, idx1, idx2, xyz0, args)
     elif mode == "no_filter":
-        f0, f1 = idx0, idx1
+        f0, f1, f2 = idx0, idx1, idx2
     else:
         raise AssertionError("unknown mode")
     src = _f32(xyz0)[f0]; tgt = _f32(xyz1)[f1]
-    T, info = ransac(src, tgt, iters, sample_size, use_elc, thr, seed, confidence, batch)
+    if prosac:
+        # FR.py:73-80 + GC_RANSAC.py:39-43: pairs sorted best match quality first, PROSAC sampler
+        if feat_dist is None:
+            feat_dist = calc_distance_ratio_in_feature_space(feats0, feats1, f0, f1, f2)
+        order = prosac_order(feat_dist)
+        T, info = ransac(src[order], tgt[order], iters, sample_size, use_elc, thr, seed, confidence, batch, sampler=1)
+    else:
+        T, info = ransac(src, tgt, iters, sample_size, use_elc, thr, seed, confidence, batch)
     n_ref = 0
     if refit_on_orig == 2 and info["best_h"] >= 0:
         # GC codebase: final least squares over the inliers among the filtered pairs

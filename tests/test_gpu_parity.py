@@ -296,6 +296,42 @@ def test_FR_full_size_config2(lr, oracle):
     assert oracle.rotation_error_deg(T, p["T_gt"]) < 0.5 and oracle.translation_error_cm(T, p["T_gt"]) < 20
 
 
+# ----------------------------------------------------------------------------- PROSAC (row f3)
+@pytest.mark.parametrize("ns,n,iters,growth,seed", [(3, 4000, 3000, 0, 51), (4, 2500, 2000, 0, 7), (3, 900, 5000, 2000, 9), (3, 5, 64, 0, 1)])
+def test_prosac_sampler_same_winner_as_oracle(lr, oracle, ns, n, iters, growth, seed):
+    src, tgt, T_gt = _planted(n=n, seed=seed)
+    T, info = lr.ransac.ransac_dev(src, tgt, iters, sample_size=ns, seed=seed, sampler=1, prosac_growth=growth)
+    Te, einfo = oracle.ransac(src, tgt, iters, sample_size=ns, seed=seed, sampler=1, prosac_growth=growth)
+    assert info == einfo and np.array_equal(T, Te)
+    # a different run than the uniform sampler's
+    _, uinfo = lr.ransac.ransac_dev(src, tgt, iters, sample_size=ns, seed=seed)
+    assert n < 10 or uinfo["n_valid"] != info["n_valid"] or uinfo["best_h"] != info["best_h"]
+
+
+@pytest.mark.parametrize("mode,N,iters", [("MNN", 5000, 1500), ("GPF", 4000, 2000), ("no_filter", 2500, 2500)])
+def test_FR_prosac_matches_oracle_pipeline(lr, oracle, mode, N, iters):
+    """--codebase GC --prosac True (the reference's default, test.py:308): device-side quality order + PROSAC sampler."""
+    p = synth.make_pair(N=N, rho=0.5, s=0.9, seed=52, clustered=(mode == "GPF"))
+    a = Args(mode=mode, codebase="GC", iters=iters, GPF_factor=0.5, prosac=True)
+    t = lr.torch.from_numpy
+    T, _, _, _, n_init, _, n_filt, _ = lr.FR.FR(t(p["xyz0"]), t(p["xyz1"]), t(p["feats0"]), t(p["feats1"]), a, p["T_gt"])
+    e = oracle.register_pair(p["xyz0"], p["xyz1"], p["feats0"], p["feats1"], mode=mode, iters=iters, sample_size=3,
+                             use_elc=True, seed=51, args=a, confidence=a.GC_conf, refit_on_orig=2, prosac=True)
+    assert n_filt == len(e["idx0"])
+    assert np.radians(oracle.rotation_error_deg(T, e["T"])) <= 1e-4 and oracle.translation_error_cm(T, e["T"]) / 100 <= 1e-3
+    np.testing.assert_allclose(T, e["T"], rtol=0, atol=1e-9)
+    assert oracle.rotation_error_deg(T, p["T_gt"]) < 1.0 and oracle.translation_error_cm(T, p["T_gt"]) < 30
+    # the host-level mirror of GC_RANSAC.py sorts by -match_quality itself and must agree with the oracle too
+    fd = oracle.calc_distance_ratio_in_feature_space(p["feats0"], p["feats1"], e["idx0"], e["idx1"],
+                                                     oracle.find_2nn(p["feats0"], p["feats1"])[2][e["idx0"]]) if mode != "GPF" else None
+    if fd is not None:
+        A = p["xyz0"][e["idx0"]].astype(np.float32); B = p["xyz1"][e["idx1"]].astype(np.float32)
+        Tg, _ = lr.ransac.GC_RANSAC(A, B, 0.6, iters, a, -fd)
+        order = oracle.prosac_order(fd)
+        Te, _ = oracle.ransac(A[order], B[order], iters, 3, True, 0.6, 51, a.GC_conf, 0, sampler=1)
+        assert np.array_equal(Tg, Te)
+
+
 def test_errors_are_loud(lr):
     with pytest.raises(lr.ext.LidarRegError):
         lr.matching.nn_top2_dev(np.zeros((10, 16), np.float32), np.zeros((10, 16), np.float32))

@@ -117,3 +117,68 @@ def test_kabsch_moments_equals_points(oracle):
     R = Vt.T @ D @ U.T
     np.testing.assert_allclose(T[:3, :3], R, atol=1e-10)
     np.testing.assert_allclose(T[:3, 3], cq - R @ cp, atol=1e-9)
+
+
+# ----------------------------------------------------------------------------- PROSAC (row f3)
+def _prosac_growth_reference(M, ns, TN):
+    """USAC / OpenCV ProsacSampler growth function, the sequential recurrence of the published algorithm."""
+    T_n = float(TN)
+    for i in range(ns):
+        T_n *= (ns - i) / (M - i)
+    G = np.ones(M, np.int64)                      # growth_function[i], i = subset size - 1
+    T_n_prime = 1
+    for i in range(M):
+        if i + 1 <= ns:
+            G[i] = T_n_prime
+            continue
+        Tn_plus1 = (i + 1) * T_n / (i + 1 - ns)
+        G[i] = T_n_prime + int(np.ceil(Tn_plus1 - T_n))
+        T_n = Tn_plus1
+        T_n_prime = G[i]
+    return G
+
+
+def test_prosac_samples_follow_the_published_growth_function(oracle):
+    """Draw k uses ns-1 indices below n_k-1 plus index n_k-1, n_k from the growth function of Chum & Matas as tabulated
+    by USAC (sequential recurrence); the oracle evaluates T_n in closed form, so allow the table to differ by rounding
+    only: the subset size may be off by one where ceil() sits on an integer boundary."""
+    rng = np.random.default_rng(5)
+    M, ns, TN = 700, 3, 100000
+    src = rng.uniform(-50, 50, (M, 3)).astype(np.float32); tgt = src.copy()
+    G = _prosac_growth_reference(M, ns, TN)
+    n_seq = ns
+    last_n = ns
+    for k in range(1, 3000):
+        if k >= G[n_seq - 1] and n_seq < M:          # one increment per draw (ProsacSampler::generateSample)
+            n_seq += 1
+        ok, T, s = oracle.hypothesis(src, tgt, k - 1, sample_size=ns, use_elc=False, sampler=1, prosac_growth=TN)
+        n_k = int(s[ns - 1]) + 1
+        assert abs(n_k - n_seq) <= 1, (k, n_k, n_seq)
+        assert n_k >= last_n and all(0 <= int(v) < n_k - 1 for v in s[:ns - 1])
+        last_n = n_k
+    assert last_n > 100                              # the subset has grown well past the minimal sample
+    # past T_N draws the sampler is uniform over all correspondences
+    seen = [oracle.hypothesis(src, tgt, TN + j, sample_size=ns, use_elc=False, sampler=1, prosac_growth=TN)[2] for j in range(200)]
+    assert max(int(s.max()) for s in seen) > 0.9 * M and any(int(s[ns - 1]) < M - 1 for s in seen)
+
+
+def test_prosac_finds_the_model_sooner_when_quality_is_informative(oracle):
+    src, tgt, T_gt, inl = _planted(n=3000, inlier=0.15, seed=21)
+    rng = np.random.default_rng(1)
+    feat_dist = np.where(inl, rng.uniform(0.2, 0.8, len(inl)), rng.uniform(0.5, 1.0, len(inl))).astype(np.float32)
+    order = oracle.prosac_order(feat_dist)
+    assert np.all(np.diff(feat_dist[order]) >= 0)
+    Tp, ip = oracle.ransac(src[order], tgt[order], iters=300, seed=51, sampler=1)
+    Tu, iu = oracle.ransac(src, tgt, iters=300, seed=51)
+    assert ip["best_count"] > 0.8 * inl.sum() and oracle.rotation_error_deg(Tp, T_gt) < 0.5
+    assert ip["best_count"] >= iu["best_count"]
+    # deterministic, and the winner re-derives from its id
+    Tp2, ip2 = oracle.ransac(src[order], tgt[order], iters=300, seed=51, sampler=1)
+    assert ip == ip2 and np.array_equal(Tp, Tp2)
+    ok, Th, _ = oracle.hypothesis(src[order], tgt[order], ip["best_h"], seed=51, sampler=1)
+    assert ok and np.array_equal(Th, Tp)
+
+
+def test_prosac_order_is_stable_and_puts_nan_last(oracle):
+    fd = np.array([0.5, np.nan, 0.1, 0.5, -0.3, 0.1], np.float32)
+    assert list(oracle.prosac_order(fd)) == [4, 2, 5, 0, 3, 1]

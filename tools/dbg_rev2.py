@@ -1,0 +1,30 @@
+import sys, numpy as np, torch
+sys.path.insert(0, '.')
+from lidarregistration_amd import matching, synth
+from oracle import oracle
+big = int(sys.argv[1]) if len(sys.argv) > 1 else 30000
+t = torch.from_numpy
+p = synth.make_pair(N=big, seed=51)
+matching.find_2nn(t(p['feats0']), t(p['feats1']))
+torch.cuda.synchronize(); print('big done', flush=True)
+def cases():
+    rng = np.random.default_rng(77)
+    F1 = rng.standard_normal((2000, 32)).astype(np.float32); F1 /= np.linalg.norm(F1, axis=1, keepdims=True)
+    F0 = (np.tile(F1[123], (700, 1)) + 1e-3 * rng.standard_normal((700, 32)).astype(np.float32)).astype(np.float32)
+    yield 'a', F0, F1
+    F0 = rng.standard_normal((1500, 32)).astype(np.float32); perm = rng.permutation(1500)
+    yield 'b', F0, F0[perm].copy()
+    base = rng.standard_normal((300, 32)).astype(np.float32)
+    yield 'c', np.concatenate([base, base, base[:100]]), np.concatenate([base[::-1], base[:50]])
+    F0 = np.concatenate([1e-3 * rng.standard_normal((400, 32)), rng.standard_normal((400, 32)), 40.0 * rng.standard_normal((400, 32))]).astype(np.float32)
+    F1 = (F0[rng.permutation(1200)[:900]] * (1 + 0.05 * rng.standard_normal((900, 1)))).astype(np.float32); F1[0] = 3000.0
+    yield 'd', F0, F1
+    F0, F1 = synth.make_features(40, 2600, 32, 0.5, 0.8, 91)
+    yield 'e', F0, F1
+for name, F0, F1 in cases():
+    i0, i1, i2, _ = oracle.find_2nn(F0, F1)
+    e0, e1, e2 = oracle.nn_to_mutual(F0, F1, i0, i1, i2)
+    print(name, 'start', flush=True)
+    m0, m1, m2 = matching.nn_to_mutual(t(F0), t(F1), t(i0), t(i1), t(i2))
+    torch.cuda.synchronize()
+    print(name, 'ok', np.array_equal(m0.numpy(), e0), len(e0), flush=True)
