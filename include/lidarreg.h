@@ -107,6 +107,8 @@ LR_API const char *lr_last_error(void);
 LR_API int    lr_workspace_create(lr_workspace **ws, int max_n0, int max_n1, int dim, int max_iters);
 LR_API int    lr_workspace_destroy(lr_workspace *ws);
 LR_API size_t lr_workspace_bytes(const lr_workspace *ws);
+/* Test hook (no reference counterpart): fill the scratch arena with one byte value; results must not depend on it. */
+LR_API int    lr_workspace_poison(lr_workspace *ws, int byte, void *stream);
 
 /* ---- a1/a2: find_nn / find_2nn  (Experiments/algorithms/matching.py:6-65) ------------------------
  * For every row of F0 [n0,dim] the nearest and second nearest row of F1 [n1,dim] under L2, first

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(CSRC, "liblidarreg.so")
 LR_MODE_NO_FILTER, LR_MODE_MNN, LR_MODE_GPF = 0, 1, 2
 
 SYMBOLS = [
-    "lr_version", "lr_last_error", "lr_workspace_create", "lr_workspace_destroy", "lr_workspace_bytes",
+    "lr_version", "lr_last_error", "lr_workspace_create", "lr_workspace_destroy", "lr_workspace_bytes", "lr_workspace_poison",
     "lr_nn_top2", "lr_nn_to_mutual", "lr_feat_ratio", "lr_gpf", "lr_gpf_bb_first", "lr_ransac", "lr_refit", "lr_icp", "lr_kabsch",
     "lr_register_pair", "lr_workspace_lists", "lr_workspace_timing", "lr_workspace_timing_read",
 ]
@@ -82,6 +82,7 @@ def lib():
         L.lr_last_error.restype = ctypes.c_char_p
         L.lr_workspace_bytes.restype = ctypes.c_size_t
         L.lr_workspace_bytes.argtypes = [ctypes.c_void_p]
+        L.lr_workspace_poison.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         L.lr_workspace_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         L.lr_workspace_destroy.argtypes = [ctypes.c_void_p]
         vp, ci = ctypes.c_void_p, ctypes.c_int
@@ -125,6 +126,10 @@ class Workspace:
     @property
     def nbytes(self):
         return lib().lr_workspace_bytes(self._h)
+
+    def poison(self, byte, stream=None):
+        """Test hook: fill the scratch arena with one byte value (results must not depend on it)."""
+        check(lib().lr_workspace_poison(self._h, int(byte), stream))
 
     def close(self):
         if self._h:

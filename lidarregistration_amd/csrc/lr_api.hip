@@ -131,6 +131,15 @@ extern "C" int lr_workspace_destroy(lr_workspace *ws)
 
 extern "C" size_t lr_workspace_bytes(const lr_workspace *ws) { return ws ? ws->bytes : 0; }
 
+// test hook: overwrite the whole scratch arena with one byte value.  No entry point may depend on what an earlier call
+// (or hipMalloc) left in the scratch; the parity tests poison it with different patterns and expect identical results.
+extern "C" int lr_workspace_poison(lr_workspace *ws, int byte, void *stream)
+{
+    LR_REQUIRE(ws, LR_EINVAL, "lr_workspace_poison: null workspace");
+    LR_HIP(hipMemsetAsync(ws->base, byte & 0xff, ws->bytes, (hipStream_t)stream));
+    return LR_OK;
+}
+
 extern "C" int lr_workspace_lists(lr_workspace *ws, int n0, int32_t *nn_idx1, int32_t *nn_idx2,
                                   int32_t *corr_idx0, int32_t *corr_idx1, void *stream)
 {
