@@ -182,7 +182,7 @@ prosac_rank_kernel(const float *__restrict__ q, int m_max, const int32_t *__rest
 
 __global__ void ratio_kernel(const float *__restrict__ F0, const float *__restrict__ F1, int dim, int m, const int32_t *__restrict__ m_dev,
                              const int32_t *__restrict__ i0, const int32_t *__restrict__ i1, const int32_t *__restrict__ i2,
-                             float *__restrict__ out);
+                             float *__restrict__ out, uint32_t *__restrict__ mm, const float *__restrict__ xyz0);
 
 // quality = feature-distance ratio of the listed pairs (FR.py:77) unless the caller has one already (GPF's
 // norm_feat_dist, FR.py:75); then the ranks
@@ -192,7 +192,7 @@ int lr_prosac_order(lr_workspace *ws, const float *F0, const float *F1, int dim,
     const int nb = lr_cdiv(m_max > 0 ? m_max : 1, 256);
     if (!quality) {
         hipLaunchKernelGGL(ratio_kernel, dim3(nb), dim3(256), 0, st, F0, F1, dim, m_max, m_dev, (const int32_t *)ws->corr_idx0,
-                           (const int32_t *)ws->corr_idx1, (const int32_t *)ws->corr_idx2, ws->ratio);
+                           (const int32_t *)ws->corr_idx1, (const int32_t *)ws->corr_idx2, ws->ratio, (uint32_t *)nullptr, (const float *)nullptr);
         quality = ws->ratio;
     }
     hipLaunchKernelGGL(prosac_rank_kernel, dim3(nb), dim3(256), 0, st, quality, m_max, m_dev, ws->prosac_rank);
@@ -201,28 +201,75 @@ int lr_prosac_order(lr_workspace *ws, const float *F0, const float *F1, int dim,
 }
 
 // ------------------------------------------------------------------ ratio (a6)
-// ||A - B1|| / (||A - B2|| + 1e-6): direct differences, sequential k, no contraction (== oracle)
+// order-preserving map float -> uint32 (and back): lets min / max run as integer atomicMax on a zero-initialised slot
+__device__ __forceinline__ uint32_t lr_enc(float f) { const uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float lr_dec(uint32_t e) { return __uint_as_float((e & 0x80000000u) ? (e ^ 0x80000000u) : ~e); }
+
+// ||A - B1|| / (||A - B2|| + 1e-6): direct differences, sequential k, no contraction (== oracle).
+// mm (optional, 6 zero-initialised slots): min/max of the ratio and of x, y of the pairs' cloud-0 points, kept as
+// atomicMax of enc(-v) / enc(v) (matching.py:118-122,136-141 need them; NaN values are ignored like fminf/fmaxf do).
 __global__ void __launch_bounds__(256)
 ratio_kernel(const float *__restrict__ F0, const float *__restrict__ F1, int dim, int m, const int32_t *__restrict__ m_dev,
              const int32_t *__restrict__ i0, const int32_t *__restrict__ i1, const int32_t *__restrict__ i2,
-             float *__restrict__ out)
+             float *__restrict__ out, uint32_t *__restrict__ mm, const float *__restrict__ xyz0)
 {
+    __shared__ float s_r[6][4];
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (m_dev) m = min(m, *m_dev);
-    if (c >= m) return;
-    const float *a = F0 + (size_t)(i0 ? i0[c] : c) * dim;
-    const float *b1 = F1 + (size_t)i1[c] * dim;
-    const float *b2 = F1 + (size_t)i2[c] * dim;
-    float s1 = 0.0f, s2 = 0.0f;
-    for (int k = 0; k < dim; ++k) {
-        float av = a[k];
-        float e1 = av - b1[k], e2 = av - b2[k];
-        float q1 = e1 * e1, q2 = e2 * e2;
-        s1 = s1 + q1;
-        s2 = s2 + q2;
+    float v[3] = { 0.0f, 0.0f, 0.0f };
+    const bool live = c < m;
+    if (live) {
+        const int pa = i0 ? i0[c] : c;
+        const float *a = F0 + (size_t)pa * dim;
+        const float *b1 = F1 + (size_t)i1[c] * dim;
+        const float *b2 = F1 + (size_t)i2[c] * dim;
+        float s1 = 0.0f, s2 = 0.0f;
+        if ((dim & 3) == 0) {
+            // 16-byte loads; the sums still run over k = 0, 1, 2, ... in order (rows of a [n, dim] float array with
+            // dim % 4 == 0 are 16-byte aligned whenever the array is, and torch / hipMalloc allocations are)
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            const f32x4 *a4 = reinterpret_cast<const f32x4 *>(a), *p4 = reinterpret_cast<const f32x4 *>(b1), *q4 = reinterpret_cast<const f32x4 *>(b2);
+            for (int k = 0; k < dim / 4; ++k) {
+                const f32x4 av = a4[k], pv = p4[k], qv = q4[k];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    float e1 = av[t] - pv[t], e2 = av[t] - qv[t];
+                    float q1 = e1 * e1, q2 = e2 * e2;
+                    s1 = s1 + q1;
+                    s2 = s2 + q2;
+                }
+            }
+        } else {
+            for (int k = 0; k < dim; ++k) {
+                float av = a[k];
+                float e1 = av - b1[k], e2 = av - b2[k];
+                float q1 = e1 * e1, q2 = e2 * e2;
+                s1 = s1 + q1;
+                s2 = s2 + q2;
+            }
+        }
+        float d1 = __builtin_sqrtf(s1), d2 = __builtin_sqrtf(s2);
+        v[0] = ((d1) / (d2 + 1e-6f));
+        out[c] = v[0];
+        if (mm) { v[1] = xyz0[3 * pa]; v[2] = xyz0[3 * pa + 1]; }
     }
-    float d1 = __builtin_sqrtf(s1), d2 = __builtin_sqrtf(s2);
-    out[c] = ((d1) / (d2 + 1e-6f));
+    if (!mm) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float lo = live ? v[k] : __builtin_huge_valf(), hi = live ? v[k] : -__builtin_huge_valf();
+        if (!(lo == lo)) { lo = __builtin_huge_valf(); hi = -__builtin_huge_valf(); }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o)); hi = fmaxf(hi, __shfl_xor(hi, o)); }
+        if (lane == 0) { s_r[2 * k][wave] = lo; s_r[2 * k + 1][wave] = hi; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int k = threadIdx.x;
+        float r = s_r[k][0];
+        for (int w = 1; w < 4; ++w) r = (k & 1) ? fmaxf(r, s_r[k][w]) : fminf(r, s_r[k][w]);
+        atomicMax(&mm[k], lr_enc((k & 1) ? r : -r));
+    }
 }
 
 extern "C" int lr_feat_ratio(const float *F0, const float *F1, int dim, int m, const int32_t *i0, const int32_t *i1,
@@ -231,7 +278,7 @@ extern "C" int lr_feat_ratio(const float *F0, const float *F1, int dim, int m, c
     LR_REQUIRE(F0 && F1 && i1 && i2 && out && dim > 0 && m >= 0, LR_EINVAL, "lr_feat_ratio: bad argument");
     if (m == 0) return LR_OK;
     hipLaunchKernelGGL(ratio_kernel, dim3(lr_cdiv(m, 256)), dim3(256), 0, (hipStream_t)stream, F0, F1, dim, m,
-                       (const int32_t *)nullptr, i0, i1, i2, out);
+                       (const int32_t *)nullptr, i0, i1, i2, out, (uint32_t *)nullptr, (const float *)nullptr);
     LR_LAUNCH_CHECK();
     return LR_OK;
 }
@@ -239,7 +286,7 @@ extern "C" int lr_feat_ratio(const float *F0, const float *F1, int dim, int m, c
 // ------------------------------------------------------------------ GPF (a7, BB_first=False)
 // Step numbers follow matching.py:100-205.
 //
-// gpf_f layout: [0] min ratio [1] max ratio [2] min x [3] max x [4] min y [5] max y
+// mm (six uint32 behind cell_fill): encoded extrema [0] -min ratio [1] max ratio [2] -min x [3] max x [4] -min y [5] max y
 // gpf_d layout: [0 .. G*G) cell counts (max_per_quad), [G*G .. 2 G*G) per_quad quota, then cell offsets as int
 
 __device__ __forceinline__ float wave_min(float v) {
@@ -253,81 +300,78 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// min/max of the ratio and of x,y over the n0 pairs (one block; n0 is a few 1e4)
-__global__ void __launch_bounds__(1024)
-gpf_minmax_kernel(int n0, const float *__restrict__ ratio, const float *__restrict__ xyz0, float *__restrict__ gf,
-                  const int32_t *__restrict__ m_dev = nullptr, const int32_t *__restrict__ pidx = nullptr)
-{
-    __shared__ float sm[6][16];
-    if (m_dev) n0 = min(n0, *m_dev);
-    float lo[3] = { LR_INF, LR_INF, LR_INF }, hi[3] = { -LR_INF, -LR_INF, -LR_INF };
-    for (int i = threadIdx.x; i < n0; i += 1024) {
-        const int pi = pidx ? pidx[i] : i;
-        float v[3] = { ratio[i], xyz0[3 * pi], xyz0[3 * pi + 1] };
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { lo[k] = fminf(lo[k], v[k]); hi[k] = fmaxf(hi[k], v[k]); }
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        float a = wave_min(lo[k]), b = wave_max(hi[k]);
-        if (lane == 0) { sm[2 * k][wave] = a; sm[2 * k + 1][wave] = b; }
-    }
-    __syncthreads();
-    if (threadIdx.x < 6) {
-        float r = sm[threadIdx.x][0];
-        for (int w = 1; w < 16; ++w) r = (threadIdx.x & 1) ? fmaxf(r, sm[threadIdx.x][w]) : fminf(r, sm[threadIdx.x][w]);
-        gf[threadIdx.x] = r;
-    }
-}
-
-// normalised score (matching.py:118-134) and grid cell (matching.py:136-146), all in fp32 as torch does
+// normalised score (matching.py:118-134) and grid cell (matching.py:136-146), all in fp32 as torch does; the cell
+// histogram is built per block in LDS and added to the global one with one atomic per (block, occupied cell)
 __global__ void __launch_bounds__(256)
-gpf_score_cell_kernel(int n0, int G, const float *__restrict__ gf, const uint8_t *__restrict__ is_bb,
+gpf_score_cell_kernel(int n0, int G, const uint32_t *__restrict__ mm, const uint8_t *__restrict__ is_bb,
                       const float *__restrict__ xyz0, float *__restrict__ ratio_inout, int32_t *__restrict__ cell,
                       int32_t *__restrict__ cell_count, const int32_t *__restrict__ m_dev = nullptr,
                       const int32_t *__restrict__ pidx = nullptr)
 {
+    __shared__ int s_cnt[LR_GPF_MAX_CELLS];
+    const int C = G * G;
+    for (int k = threadIdx.x; k < C; k += 256) s_cnt[k] = 0;
+    __syncthreads();
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (m_dev) n0 = min(n0, *m_dev);
-    if (i >= n0) return;
-    const int pi = pidx ? pidx[i] : i;
-    const float m = gf[0], M = gf[1];
-    float nfd = ((ratio_inout[i] - m) / (M - m));
-    if (is_bb && is_bb[i]) nfd = nfd - 1.0f;          // BB_first=True has no best-buddy shift (matching.py:126)
-    ratio_inout[i] = nfd;
-    const float denx = (gf[3] - gf[2]) + 1e-3f, deny = (gf[5] - gf[4]) + 1e-3f;
-    float qx = floorf((float)G * ((xyz0[3 * pi] - gf[2]) / (denx)));
-    float qy = floorf((float)G * ((xyz0[3 * pi + 1] - gf[4]) / (deny)));
-    int c = (int)qx * G + (int)qy;
-    cell[i] = c;
-    atomicAdd(&cell_count[c], 1);
+    if (i < n0) {
+        const int pi = pidx ? pidx[i] : i;
+        const float m = -lr_dec(mm[0]), M = lr_dec(mm[1]);
+        const float x0 = -lr_dec(mm[2]), x1 = lr_dec(mm[3]), y0 = -lr_dec(mm[4]), y1 = lr_dec(mm[5]);
+        float nfd = ((ratio_inout[i] - m) / (M - m));
+        if (is_bb && is_bb[i]) nfd = nfd - 1.0f;          // BB_first=True has no best-buddy shift (matching.py:126)
+        ratio_inout[i] = nfd;
+        const float denx = (x1 - x0) + 1e-3f, deny = (y1 - y0) + 1e-3f;
+        float qx = floorf((float)G * ((xyz0[3 * pi] - x0) / (denx)));
+        float qy = floorf((float)G * ((xyz0[3 * pi + 1] - y0) / (deny)));
+        int c = (int)qx * G + (int)qy;
+        cell[i] = c;
+        if (c >= 0 && c < C) atomicAdd(&s_cnt[c], 1);
+        else atomicAdd(&cell_count[min(max(c, 0), LR_GPF_MAX_CELLS - 1)], 1);    // non-finite coordinates: keep the old behaviour
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < C; k += 256) if (s_cnt[k]) atomicAdd(&cell_count[k], s_cnt[k]);
 }
 
-// water-filling bisection in fp64 exactly as matching.py:154-179, then exclusive cell offsets; one thread
+// water-filling bisection in fp64 exactly as matching.py:154-179, then exclusive cell offsets.  One thread does the
+// arithmetic (the sums run in cell order, which fixes their rounding), on a copy of the counts in LDS.
 // total_fixed >= 0 selects the BB_first=True form: TOTAL = GPF_max_matches, and nothing is filtered (has_score = 0) when
 // the mutual set is already that small (matching.py:109-113)
-__global__ void gpf_waterfill_kernel(int G, double factor, const int32_t *__restrict__ counters,
-                                     const int32_t *__restrict__ cell_count, double *__restrict__ quota,
-                                     int32_t *__restrict__ cell_off, double total_fixed = -1.0,
-                                     const int32_t *__restrict__ m_dev = nullptr, int32_t *__restrict__ has_score = nullptr)
+__global__ void __launch_bounds__(64)
+gpf_waterfill_kernel(int G, double factor, const int32_t *__restrict__ counters,
+                     const int32_t *__restrict__ cell_count, double *__restrict__ quota,
+                     int32_t *__restrict__ cell_off, double total_fixed = -1.0,
+                     const int32_t *__restrict__ m_dev = nullptr, int32_t *__restrict__ has_score = nullptr)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    __shared__ double s_m[LR_GPF_MAX_CELLS];
     const int C = G * G;
+    for (int c = threadIdx.x; c < C; c += 64) s_m[c] = (double)cell_count[c];
+    __syncthreads();
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const double TOTAL = total_fixed >= 0.0 ? total_fixed : factor * (double)counters[LR_CNT_NBB];
     if (total_fixed >= 0.0) {
         const bool keep_all = TOTAL >= (double)*m_dev;
         if (has_score) *has_score = keep_all ? 0 : 1;
         if (keep_all) {
             int off = 0;
-            for (int c = 0; c < C; ++c) { quota[c] = (double)cell_count[c]; cell_off[c] = off; off += cell_count[c]; }
+            for (int c = 0; c < C; ++c) { quota[c] = s_m[c]; cell_off[c] = off; off += (int)s_m[c]; }
             cell_off[C] = off;
             return;
         }
     }
+    // the adds stay in cell order (their rounding is part of the result); the LDS reads of eight cells are issued
+    // together so that the chain only waits for the adds
     auto total_at = [&](double h) {
         double s = 0.0;
-        for (int c = 0; c < C; ++c) { double m = (double)cell_count[c]; s += (m < h) ? m : h; }
+        int c = 0;
+        for (; c + 8 <= C; c += 8) {
+            double m[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) m[k] = s_m[c + k];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += (m[k] < h) ? m[k] : h;
+        }
+        for (; c < C; ++c) { double m = s_m[c]; s += (m < h) ? m : h; }
         return s;
     };
     double max_h = TOTAL, min_h = 0.0, cur = (max_h + min_h) / 2;
@@ -341,25 +385,36 @@ __global__ void gpf_waterfill_kernel(int G, double factor, const int32_t *__rest
     const double hr = rint(cur);                      // np.round: half to even
     int off = 0;
     for (int c = 0; c < C; ++c) {
-        double m = (double)cell_count[c];
+        double m = s_m[c];
         quota[c] = (m < hr) ? m : hr;
         cell_off[c] = off;
-        off += cell_count[c];
+        off += (int)m;
     }
     cell_off[C] = off;
 }
 
-// bucket pair ids by cell (order inside a bucket is irrelevant: ranks below use (score, id))
+// bucket pair ids by cell (order inside a bucket is irrelevant: ranks below use (score, id)): ranks inside the block
+// from LDS atomics, one global atomic per (block, occupied cell) reserves the block's range
 __global__ void __launch_bounds__(256)
-gpf_bucket_kernel(int n0, const int32_t *__restrict__ cell, const int32_t *__restrict__ cell_off,
+gpf_bucket_kernel(int n0, int G, const int32_t *__restrict__ cell, const int32_t *__restrict__ cell_off,
                   int32_t *__restrict__ cell_fill, int32_t *__restrict__ bucket, const int32_t *__restrict__ m_dev = nullptr)
 {
+    __shared__ int s_cnt[LR_GPF_MAX_CELLS];
+    const int C = G * G;
+    for (int k = threadIdx.x; k < C; k += 256) s_cnt[k] = 0;
+    __syncthreads();
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (m_dev) n0 = min(n0, *m_dev);
-    if (i >= n0) return;
-    int c = cell[i];
-    int pos = atomicAdd(&cell_fill[c], 1);
-    bucket[cell_off[c] + pos] = i;
+    int c = -1, local = 0;
+    if (i < n0) {
+        c = cell[i];
+        if (c >= 0 && c < C) local = atomicAdd(&s_cnt[c], 1);
+        else { const int cc = min(max(c, 0), LR_GPF_MAX_CELLS - 1); bucket[cell_off[cc] + atomicAdd(&cell_fill[cc], 1)] = i; c = -1; }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < C; k += 256) if (s_cnt[k]) s_cnt[k] = atomicAdd(&cell_fill[k], s_cnt[k]);     // count -> base
+    __syncthreads();
+    if (c >= 0) bucket[cell_off[c] + s_cnt[c] + local] = i;
 }
 
 // keep[i] = all of the cell if quota == count, else rank of (score, i) inside the cell < quota
@@ -405,15 +460,16 @@ int lr_gpf_run(lr_workspace *ws, const float *F0, int n0, const float *F1, int d
     double *quota = ws->gpf_quota;
     uint8_t *keep = ws->gpf_keep;
     const int nb = lr_cdiv(n0, 256);
+    // one memset clears the cell counters and the six min/max slots behind them (atomicMax on encoded values, 0 = identity)
+    uint32_t *mm = reinterpret_cast<uint32_t *>(cell_fill + LR_GPF_MAX_CELLS);
     LR_HIP(hipMemsetAsync(cell_count, 0, sizeof(int32_t) * 2 * (LR_GPF_MAX_CELLS + 8), st));
-    // ratio over all n0 NN pairs (corres_idx0 == arange)
+    // ratio over all n0 NN pairs (corres_idx0 == arange), and the extrema of ratio / x / y
     hipLaunchKernelGGL(ratio_kernel, dim3(nb), dim3(256), 0, st, F0, F1, dim, n0, (const int32_t *)nullptr,
-                       (const int32_t *)nullptr, idx1, idx2, ws->ratio);
-    hipLaunchKernelGGL(gpf_minmax_kernel, dim3(1), dim3(1024), 0, st, n0, ws->ratio, xyz0, ws->gpf_f);
-    hipLaunchKernelGGL(gpf_score_cell_kernel, dim3(nb), dim3(256), 0, st, n0, G, ws->gpf_f, is_bb, xyz0, ws->ratio,
+                       (const int32_t *)nullptr, idx1, idx2, ws->ratio, mm, xyz0);
+    hipLaunchKernelGGL(gpf_score_cell_kernel, dim3(nb), dim3(256), 0, st, n0, G, (const uint32_t *)mm, is_bb, xyz0, ws->ratio,
                        ws->cell, cell_count);
     hipLaunchKernelGGL(gpf_waterfill_kernel, dim3(1), dim3(64), 0, st, G, factor, ws->counters, cell_count, quota, cell_off);
-    hipLaunchKernelGGL(gpf_bucket_kernel, dim3(nb), dim3(256), 0, st, n0, ws->cell, cell_off, cell_fill, ws->cell_sorted);
+    hipLaunchKernelGGL(gpf_bucket_kernel, dim3(nb), dim3(256), 0, st, n0, G, ws->cell, cell_off, cell_fill, ws->cell_sorted);
     hipLaunchKernelGGL(gpf_select_kernel, dim3(nb), dim3(256), 0, st, n0, ws->cell, cell_off, cell_count, quota,
                        ws->cell_sorted, ws->ratio, keep);
     hipLaunchKernelGGL(count_flags_kernel, dim3(nb), dim3(256), 0, st, n0, (const int32_t *)nullptr, keep, ws->blk_cnt);
@@ -438,14 +494,14 @@ int lr_gpf_bb_run(lr_workspace *ws, const float *F0, int n0, const float *F1, in
     double *quota = ws->gpf_quota;
     uint8_t *keep = ws->gpf_keep;
     const int nb = lr_cdiv(n0, 256);
+    uint32_t *mm = reinterpret_cast<uint32_t *>(cell_fill + LR_GPF_MAX_CELLS);
     LR_HIP(hipMemsetAsync(cell_count, 0, sizeof(int32_t) * 2 * (LR_GPF_MAX_CELLS + 8), st));
-    hipLaunchKernelGGL(ratio_kernel, dim3(nb), dim3(256), 0, st, F0, F1, dim, n0, mb_dev, b0, b1, b2, ws->ratio);
-    hipLaunchKernelGGL(gpf_minmax_kernel, dim3(1), dim3(1024), 0, st, n0, ws->ratio, xyz0, ws->gpf_f, mb_dev, b0);
-    hipLaunchKernelGGL(gpf_score_cell_kernel, dim3(nb), dim3(256), 0, st, n0, G, ws->gpf_f, (const uint8_t *)nullptr, xyz0, ws->ratio,
+    hipLaunchKernelGGL(ratio_kernel, dim3(nb), dim3(256), 0, st, F0, F1, dim, n0, mb_dev, b0, b1, b2, ws->ratio, mm, xyz0);
+    hipLaunchKernelGGL(gpf_score_cell_kernel, dim3(nb), dim3(256), 0, st, n0, G, (const uint32_t *)mm, (const uint8_t *)nullptr, xyz0, ws->ratio,
                        ws->cell, cell_count, mb_dev, b0);
     hipLaunchKernelGGL(gpf_waterfill_kernel, dim3(1), dim3(64), 0, st, G, 0.0, ws->counters, cell_count, quota, cell_off, max_matches,
                        mb_dev, has_score);
-    hipLaunchKernelGGL(gpf_bucket_kernel, dim3(nb), dim3(256), 0, st, n0, ws->cell, cell_off, cell_fill, ws->cell_sorted, mb_dev);
+    hipLaunchKernelGGL(gpf_bucket_kernel, dim3(nb), dim3(256), 0, st, n0, G, ws->cell, cell_off, cell_fill, ws->cell_sorted, mb_dev);
     hipLaunchKernelGGL(gpf_select_kernel, dim3(nb), dim3(256), 0, st, n0, ws->cell, cell_off, cell_count, quota,
                        ws->cell_sorted, ws->ratio, keep, mb_dev);
     hipLaunchKernelGGL(count_flags_kernel, dim3(nb), dim3(256), 0, st, n0, mb_dev, keep, ws->blk_cnt);
