@@ -162,22 +162,90 @@ int lr_pack_corr(lr_workspace *ws, const float *xyz0, const float *xyz1, const i
 // ------------------------------------------------------------------ PROSAC order (GC_RANSAC.py:39-43)
 // rank[c] = position of pair c when the pairs are sorted by ascending feature distance (= descending match quality,
 // FR.py:74-80), ties by c (numpy's argsort leaves ties unspecified; a stable order keeps the result reproducible), NaN
-// last.  Counting rank, O(M^2) compares on wave-uniform loads: M is a few 1e4 and the kernel is tens of microseconds.
+// last.  Bucket sort: 4096 linear buckets over the value range, then the exact rank inside the bucket by comparing with
+// its members -- O(M x bucket size) instead of the O(M^2) of a plain counting rank (M can be all N pairs under GPF).
+#define LR_PR_BUCKETS 4096
+__device__ __forceinline__ float pr_key(float v) { return v == v ? v : __builtin_huge_valf(); }
+__device__ __forceinline__ int pr_bucket(float v, float lo, float scale)
+{
+    if (!(v < __builtin_huge_valf())) return LR_PR_BUCKETS - 1;
+    const int b = (int)((v - lo) * scale);
+    return min(max(b, 0), LR_PR_BUCKETS - 1);
+}
+
+// one block: range of the finite values, bucket histogram in LDS, exclusive offsets -> offs[0..B], fill = copy of offs
+__global__ void __launch_bounds__(1024)
+prosac_scan_kernel(const float *__restrict__ q, int m_max, const int32_t *__restrict__ m_dev, int32_t *__restrict__ offs,
+                   int32_t *__restrict__ fill, float *__restrict__ range)
+{
+    __shared__ int s_h[LR_PR_BUCKETS];
+    __shared__ float s_lo[16], s_hi[16];
+    __shared__ int s_w[16];
+    const int m = m_dev ? min(*m_dev, m_max) : m_max;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float lo = __builtin_huge_valf(), hi = -__builtin_huge_valf();
+    for (int i = threadIdx.x; i < m; i += 1024) { const float v = pr_key(q[i]); if (v < __builtin_huge_valf()) { lo = fminf(lo, v); hi = fmaxf(hi, v); } }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o)); hi = fmaxf(hi, __shfl_xor(hi, o)); }
+    if (lane == 0) { s_lo[wave] = lo; s_hi[wave] = hi; }
+    for (int k = threadIdx.x; k < LR_PR_BUCKETS; k += 1024) s_h[k] = 0;
+    __syncthreads();
+    for (int w = 0; w < 16; ++w) { lo = fminf(lo, s_lo[w]); hi = fmaxf(hi, s_hi[w]); }
+    const float scale = hi > lo ? (float)LR_PR_BUCKETS / (hi - lo) : 0.0f;
+    if (threadIdx.x == 0) { range[0] = lo; range[1] = scale; }
+    for (int i0 = threadIdx.x; i0 < m; i0 += 8 * 1024) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = q[min(i0 + 1024 * k, m - 1)];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (i0 + 1024 * k < m) atomicAdd(&s_h[pr_bucket(pr_key(v[k]), lo, scale)], 1);
+    }
+    __syncthreads();
+    int v[LR_PR_BUCKETS / 1024], sum = 0;
+#pragma unroll
+    for (int k = 0; k < LR_PR_BUCKETS / 1024; ++k) { v[k] = s_h[threadIdx.x * (LR_PR_BUCKETS / 1024) + k]; sum += v[k]; }
+    int inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    int run = inc - sum;
+    for (int w = 0; w < wave; ++w) run += s_w[w];
+#pragma unroll
+    for (int k = 0; k < LR_PR_BUCKETS / 1024; ++k) {
+        const int b = threadIdx.x * (LR_PR_BUCKETS / 1024) + k;
+        offs[b] = run; fill[b] = run; run += v[k];
+    }
+    if (threadIdx.x == 1023) offs[LR_PR_BUCKETS] = run;
+}
+
 __global__ void __launch_bounds__(256)
-prosac_rank_kernel(const float *__restrict__ q, int m_max, const int32_t *__restrict__ m_dev, int32_t *__restrict__ rank)
+prosac_scatter_kernel(const float *__restrict__ q, int m_max, const int32_t *__restrict__ m_dev, const float *__restrict__ range,
+                      int32_t *__restrict__ fill, int32_t *__restrict__ members)
 {
     const int m = m_dev ? min(*m_dev, m_max) : m_max;
     const int c = blockIdx.x * 256 + threadIdx.x;
-    if ((int)blockIdx.x * 256 >= m) return;
-    float v = c < m ? q[c] : 0.0f;
-    if (!(v == v)) v = __builtin_huge_valf();
-    int r = 0;
-    for (int j = 0; j < m; ++j) {
-        float w = q[j];                          // wave-uniform address: scalar load
-        if (!(w == w)) w = __builtin_huge_valf();
+    if (c >= m) return;
+    members[atomicAdd(&fill[pr_bucket(pr_key(q[c]), range[0], range[1])], 1)] = c;
+}
+
+__global__ void __launch_bounds__(256)
+prosac_rank_kernel(const float *__restrict__ q, int m_max, const int32_t *__restrict__ m_dev, const float *__restrict__ range,
+                   const int32_t *__restrict__ offs, const int32_t *__restrict__ members, int32_t *__restrict__ rank)
+{
+    const int m = m_dev ? min(*m_dev, m_max) : m_max;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= m) return;
+    const float v = pr_key(q[c]);
+    const int b = pr_bucket(v, range[0], range[1]);
+    const int e = offs[b + 1];
+    int r = offs[b];
+    for (int t = offs[b]; t < e; ++t) {
+        const int j = members[t];
+        const float w = pr_key(q[j]);
         r += (w < v || (w == v && j < c)) ? 1 : 0;
     }
-    if (c < m) rank[c] = r;
+    rank[c] = r;
 }
 
 __global__ void ratio_kernel(const float *__restrict__ F0, const float *__restrict__ F1, int dim, int m, const int32_t *__restrict__ m_dev,
@@ -195,7 +263,13 @@ int lr_prosac_order(lr_workspace *ws, const float *F0, const float *F1, int dim,
                            (const int32_t *)ws->corr_idx1, (const int32_t *)ws->corr_idx2, ws->ratio, (uint32_t *)nullptr, (const float *)nullptr);
         quality = ws->ratio;
     }
-    hipLaunchKernelGGL(prosac_rank_kernel, dim3(nb), dim3(256), 0, st, quality, m_max, m_dev, ws->prosac_rank);
+    // GPF's scratch is free by now: offsets | fill | range in its cell arrays, bucket members in its sort buffer
+    int32_t *offs = ws->gpf_cells, *fill = offs + LR_GPF_MAX_CELLS + 8;
+    float *range = reinterpret_cast<float *>(fill + LR_GPF_MAX_CELLS + 8);
+    hipLaunchKernelGGL(prosac_scan_kernel, dim3(1), dim3(1024), 0, st, quality, m_max, m_dev, offs, fill, range);
+    hipLaunchKernelGGL(prosac_scatter_kernel, dim3(nb), dim3(256), 0, st, quality, m_max, m_dev, (const float *)range, fill, ws->cell_sorted);
+    hipLaunchKernelGGL(prosac_rank_kernel, dim3(nb), dim3(256), 0, st, quality, m_max, m_dev, (const float *)range, (const int32_t *)offs,
+                       (const int32_t *)ws->cell_sorted, ws->prosac_rank);
     LR_LAUNCH_CHECK();
     return LR_OK;
 }

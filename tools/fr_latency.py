@@ -1,0 +1,14 @@
+"""Single-pair latency of FR() (what the reference's harness logs as elapsed_time)."""
+import sys, numpy as np, torch
+sys.path.insert(0, '.')
+from lidarregistration_amd import FR, synth
+from tests.conftest import Args
+p = synth.make_pair(N=30000, seed=51)
+t = torch.from_numpy
+A, B, FA, FB = (t(p[k]).cuda() for k in ("xyz0", "xyz1", "feats0", "feats1"))
+for mode, cb in (("MNN", "open3D"), ("GPF", "GC")):
+    a = Args(mode=mode, codebase=cb, iters=50000, ransac_n=3, o3d_conf=1.0, GC_conf=1.0, prosac=(cb == "GC"))
+    ts = []
+    for _ in range(30):
+        ts.append(FR.FR(A, B, FA, FB, a, p["T_gt"])[1])
+    print(mode, cb, "FR elapsed us: median %.0f min %.0f" % (1e6 * np.median(ts[5:]), 1e6 * min(ts)))
