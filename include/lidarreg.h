@@ -44,7 +44,8 @@ typedef struct lr_ransac_params {
     float    confidence;    /* early exit (--GC_conf / FR.py:136): ids are evaluated in batches of `batch`; after a
                                batch ending at id e the run stops when e >= log(1-confidence) / log(1 - (inl/M)^sample_size)
                                for the best model so far.  >= 1 (or <= 0): every id is evaluated.             */
-    int32_t  batch;         /* batch length of the early-exit test (0 -> 8192)                        */
+    int32_t  batch;         /* batch length of the early-exit test (0 -> 8192, or iters/8 rounded up to a multiple of
+                               8192 when iters > 65536)                                                */
     int32_t  sampler;       /* 0: uniform (GC_RANSAC.py:19 'sampler': 0); 1: PROSAC (--prosac, GC_RANSAC.py:24,39-43):
                                the correspondences must come best quality first; hypothesis id h = PROSAC draw h+1:
                                sample_size-1 indices uniformly from the first n-1 correspondences plus the n-th, n from

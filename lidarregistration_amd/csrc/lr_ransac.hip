@@ -344,7 +344,8 @@ int lr_ransac_run(lr_workspace *ws, const float *corr8, int m_max, const int32_t
     sub &= ~1;                  // the scoring loop takes correspondences two at a time
     if (sub < 2) sub = 2;       // 2 * thr2 * 2^20 < 2^32 for every admissible thr2 (< 2048)
     const bool use_exit = p->confidence > 0.0f && p->confidence < 1.0f;
-    const int B = use_exit ? (p->batch > 0 ? p->batch : 8192) : (p->iters > 0 ? p->iters : 1);
+    // default batch: 8192 ids, or an eighth of a long run (the launches of the batches after the exit still cost a few us each)
+    const int B = use_exit ? (p->batch > 0 ? p->batch : (p->iters > 65536 ? ((p->iters / 8 + 8191) / 8192) * 8192 : 8192)) : (p->iters > 0 ? p->iters : 1);
     LR_REQUIRE(p->sampler == 0 || p->sampler == 1, LR_EINVAL, "lr_ransac: sampler must be 0 (uniform) or 1 (PROSAC)");
     LR_REQUIRE(p->prosac_growth >= 0, LR_EINVAL, "lr_ransac: prosac_growth must be >= 0");
     const int TN = p->prosac_growth > 0 ? p->prosac_growth : 100000;

@@ -17,7 +17,7 @@ DEFAULT_SEED = 51          # Experiments/test.py:357
 
 
 def ransac_params(iters, sample_size=3, use_elc=True, thr=0.6, seed=DEFAULT_SEED, confidence=1.0, batch=0, sampler=0, prosac_growth=0):
-    """confidence < 1 enables the early exit between batches of `batch` hypothesis ids (0 -> 8192); sampler 1 = PROSAC
+    """confidence < 1 enables the early exit between batches of `batch` hypothesis ids (0 -> 8192, an eighth of the run when iters > 65536); sampler 1 = PROSAC
     (correspondences best quality first, growth parameter T_N = prosac_growth, 0 -> 100000)."""
     return _ext.RansacParams(int(sample_size), int(bool(use_elc)), np.float32(float(thr) * float(thr)), int(iters), int(seed),
                              float(confidence), int(batch), int(sampler), int(prosac_growth))

@@ -334,7 +334,7 @@ typedef struct {
     int32_t  iters;           /* hypotheses h = 0 .. iters-1                          */
     uint64_t seed;
     float    confidence;      /* early exit between batches (FR.py:136, GC_RANSAC.py:26); >= 1 or <= 0: none */
-    int32_t  batch;           /* batch length (0 -> 8192)                             */
+    int32_t  batch;           /* batch length (0 -> 8192; iters > 65536: iters/8 rounded up to a multiple of 8192) */
     int32_t  sampler;         /* 0 uniform; 1 PROSAC (GC_RANSAC.py:24,39-43): correspondences best first */
     int32_t  prosac_growth;   /* T_N of the PROSAC growth function (0 -> 100000)       */
 } orc_ransac_params;
@@ -406,7 +406,7 @@ ORC_API void orc_ransac(const float *src, const float *tgt, int m, const orc_ran
 {
     int64_t best_h = -1; uint32_t best_c = 0; uint64_t best_q = 0; int64_t n_valid = 0, n_ids = 0;
     const int use_exit = p->confidence > 0.0f && p->confidence < 1.0f;
-    const int64_t B = use_exit ? (p->batch > 0 ? p->batch : 8192) : (p->iters > 0 ? p->iters : 1);
+    const int64_t B = use_exit ? (p->batch > 0 ? p->batch : (p->iters > 65536 ? ((p->iters / 8 + 8191) / 8192) * 8192 : 8192)) : (p->iters > 0 ? p->iters : 1);
     int32_t *G = p->sampler == 1 ? prosac_table(m, p->sample_size, p->prosac_growth > 0 ? p->prosac_growth : 100000) : NULL;
     for (int64_t h0 = 0; h0 < p->iters; h0 += B) {
         const int64_t h1 = h0 + B < p->iters ? h0 + B : p->iters;

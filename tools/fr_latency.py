@@ -12,3 +12,10 @@ for mode, cb in (("MNN", "open3D"), ("GPF", "GC")):
     for _ in range(30):
         ts.append(FR.FR(A, B, FA, FB, a, p["T_gt"])[1])
     print(mode, cb, "FR elapsed us: median %.0f min %.0f" % (1e6 * np.median(ts[5:]), 1e6 * min(ts)))
+# the reference CLI's defaults: --codebase GC --prosac True --GC_conf 0.999, iters = 500k (FR.py:65-67)
+for mode in ("MNN", "GPF"):
+    a = Args(mode=mode, codebase="GC", iters=None, prosac=True)
+    ts = []
+    for _ in range(20):
+        ts.append(FR.FR(A, B, FA, FB, a, p["T_gt"])[1])
+    print(mode, "GC defaults (500k iters, conf 0.999): FR elapsed us: median %.0f min %.0f" % (1e6 * np.median(ts[5:]), 1e6 * min(ts)))
