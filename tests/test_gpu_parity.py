@@ -433,6 +433,18 @@ def test_ransac_iteration_property_more_iters_never_worse(lr):
         best = info["best_count"]
 
 
+def test_ransac_one_million_iterations_config4(lr, oracle):
+    """BASELINE config #4 runs --iters 1000000: hypothesis ids, model storage and the batched exit at that length."""
+    src, tgt, T_gt = _planted(n=1500, inlier=0.2, seed=31)
+    T, info = lr.ransac.ransac_dev(src, tgt, 1_000_000, seed=51)                       # every id evaluated
+    Te, einfo = oracle.ransac(src, tgt, 1_000_000, seed=51)
+    assert info == einfo and np.array_equal(T, Te) and info["n_ids"] == 1_000_000
+    T2, info2 = lr.ransac.ransac_dev(src, tgt, 1_000_000, seed=51, confidence=0.999)   # default batch = an eighth of the run
+    Te2, einfo2 = oracle.ransac(src, tgt, 1_000_000, seed=51, confidence=0.999)
+    assert info2 == einfo2 and np.array_equal(T2, Te2) and info2["n_ids"] == 131072
+    assert oracle.rotation_error_deg(T2, T_gt) < 1.0
+
+
 # ----------------------------------------------------------------------------- ICP (next row f1)
 @pytest.mark.parametrize("n,rho,seed,offset", [(3000, 0.6, 5, 0.25), (4000, 0.4, 6, 0.4), (1500, 0.8, 7, 0.1)])
 def test_icp_matches_oracle(lr, oracle, n, rho, seed, offset):
