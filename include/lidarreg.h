@@ -52,6 +52,10 @@ typedef struct lr_ransac_params {
                                the growth function of Chum & Matas 2005 (as in USAC / GC-RANSAC's prosac_sampler.h);
                                ids past prosac_growth fall back to uniform sampling over all correspondences        */
     int32_t  prosac_growth; /* T_N of the growth function (0 -> 100000, GC-RANSAC's default)          */
+    int32_t  scoring;       /* which model wins: 0 = more inliers, then lower squared-error sum (Open3D: fitness, then
+                               inlier RMSE); 1 = MSAC, the truncated quadratic cost GC-RANSAC scores with: larger
+                               sum over inliers of (thr2 - d^2), evaluated as count * (uint32)(thr2 * 2^20) - best_ssq */
+    int32_t  reserved0;
 } lr_ransac_params;
 
 /* Written to device memory by lr_ransac / lr_register_pair. */

@@ -45,13 +45,16 @@ def pair_params(args):
         use_elc = getattr(args, "fast_rejection", "ELC") == "ELC"
         conf = float(getattr(args, "GC_conf", 0.999))                  # GC_RANSAC.py:26, test.py:312
         sampler = 1 if getattr(args, "prosac", True) else 0            # test.py:308 (default True), GC_RANSAC.py:24
+        scoring = 1                                                    # MSAC, the cost pygcransac ranks models by
     else:
         sampler = 0
+        scoring = 0                                                    # Open3D: fitness, then inlier RMSE
         sample_size = int(getattr(args, "ransac_n", 4))                # FR.py:134
         use_elc = True                                                 # FR.py:135 edge-length checker
         conf = float(getattr(args, "o3d_conf", 0.9995))                # FR.py:136
     rp = _ext.RansacParams(sample_size, int(use_elc), np.float32(thr * thr), iters, int(getattr(args, "seed", DEFAULT_SEED)),
-                           conf, int(getattr(args, "ransac_batch", 0)), sampler, int(getattr(args, "prosac_growth", 0)))
+                           conf, int(getattr(args, "ransac_batch", 0)), sampler, int(getattr(args, "prosac_growth", 0)),
+                           int(getattr(args, "ransac_scoring", scoring)), 0)
     p = _ext.PairParams()
     p.mode = MODES[mode]
     # open3D codebase: FR.py:99-111 refits over the original NN pairs; the GC codebase returns pygcransac's own final

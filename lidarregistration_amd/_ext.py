@@ -27,7 +27,7 @@ class LidarRegError(RuntimeError):
 class RansacParams(ctypes.Structure):
     _fields_ = [("sample_size", ctypes.c_int32), ("use_elc", ctypes.c_int32), ("thr2", ctypes.c_float),
                 ("iters", ctypes.c_int32), ("seed", ctypes.c_uint64), ("confidence", ctypes.c_float), ("batch", ctypes.c_int32),
-                ("sampler", ctypes.c_int32), ("prosac_growth", ctypes.c_int32)]
+                ("sampler", ctypes.c_int32), ("prosac_growth", ctypes.c_int32), ("scoring", ctypes.c_int32), ("reserved0", ctypes.c_int32)]
 
 
 class RansacResult(ctypes.Structure):

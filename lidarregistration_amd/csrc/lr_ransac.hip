@@ -263,9 +263,15 @@ ransac_score_kernel(const float *__restrict__ corr8, int m_max, const int32_t *_
 
 // ------------------------------------------------------------------ select
 // best = more inliers, then lower fixed-point error, then lower hypothesis id; its fp64 model was kept by gen
-__device__ __forceinline__ bool better(uint32_t c, unsigned long long q, int h, uint32_t bc, unsigned long long bq, int bh)
+__device__ __forceinline__ bool better(uint32_t c, unsigned long long q, int h, uint32_t bc, unsigned long long bq, int bh,
+                                       uint32_t msac_T)
 {
-    return c > bc || (c == bc && (q < bq || (q == bq && h < bh)));
+    if (msac_T == 0u) return c > bc || (c == bc && (q < bq || (q == bq && h < bh)));
+    // MSAC: larger sum over inliers of (thr2 - d^2) in the fixed point of the error sum; a model without inliers never wins
+    if (c == 0u) return false;
+    if (bc == 0u) return true;
+    const long long k = (long long)c * (long long)msac_T - (long long)q, bk = (long long)bc * (long long)msac_T - (long long)bq;
+    return k > bk || (k == bk && h < bh);
 }
 
 // best of this batch -> merged into the running state; confidence test; outputs rewritten from the state every batch
@@ -280,6 +286,7 @@ ransac_final_kernel(const uint32_t *__restrict__ score_cnt, const unsigned long 
     __shared__ int s_h[16], s_s[16];
     lr_ransac_state *state = reinterpret_cast<lr_ransac_state *>(counters + LR_CNT_COUNT);
     if (state->done) return;
+    const uint32_t msac_T = p.scoring == 1 ? (uint32_t)(p.thr2 * 1048576.0f) : 0u;
     const int V = counters[LR_CNT_NVALID];
     uint32_t bc = 0; unsigned long long bq = ~0ull; int bh = 0x7fffffff, bs = -1;
     for (int s = threadIdx.x; s < V; s += 1024) {
@@ -287,24 +294,24 @@ ransac_final_kernel(const uint32_t *__restrict__ score_cnt, const unsigned long 
         if (c == 0) continue;
         unsigned long long q = score_ssq[s];
         int h = model_h[s];
-        if (better(c, q, h, bc, bq, bh)) { bc = c; bq = q; bh = h; bs = s; }
+        if (better(c, q, h, bc, bq, bh, msac_T)) { bc = c; bq = q; bh = h; bs = s; }
     }
 #pragma unroll
     for (int mk = 32; mk >= 1; mk >>= 1) {
         uint32_t oc = (uint32_t)__shfl_xor((int)bc, mk);
         unsigned long long oq = __shfl_xor(bq, mk);
         int oh = __shfl_xor(bh, mk), os = __shfl_xor(bs, mk);
-        if (better(oc, oq, oh, bc, bq, bh)) { bc = oc; bq = oq; bh = oh; bs = os; }
+        if (better(oc, oq, oh, bc, bq, bh, msac_T)) { bc = oc; bq = oq; bh = oh; bs = os; }
     }
     if ((threadIdx.x & 63) == 0) { s_c[threadIdx.x >> 6] = bc; s_q[threadIdx.x >> 6] = bq; s_h[threadIdx.x >> 6] = bh; s_s[threadIdx.x >> 6] = bs; }
     __syncthreads();
     if (threadIdx.x >= 16) return;
     for (int w = 1; w < 16; ++w)
-        if (better(s_c[w], s_q[w], s_h[w], bc, bq, bh)) { bc = s_c[w]; bq = s_q[w]; bh = s_h[w]; bs = s_s[w]; }
+        if (better(s_c[w], s_q[w], s_h[w], bc, bq, bh, msac_T)) { bc = s_c[w]; bq = s_q[w]; bh = s_h[w]; bs = s_s[w]; }
     // all 16 lanes hold the batch winner; merge it into the state (lane k moves T[k])
     const int k = threadIdx.x;
     const uint32_t oc = state->cnt; const unsigned long long oq = state->ssq; const int oh = state->h;
-    const bool take = bc > 0 && bs >= 0 && (oc == 0 || better(bc, bq, bh, oc, oq, oh));
+    const bool take = bc > 0 && bs >= 0 && (oc == 0 || better(bc, bq, bh, oc, oq, oh, msac_T));
     double v = (k % 5 == 0) ? 1.0 : 0.0;
     if (k < 12) {
         if (take) { v = models64[(size_t)bs * 12 + k]; state->T[k] = v; }
@@ -348,6 +355,7 @@ int lr_ransac_run(lr_workspace *ws, const float *corr8, int m_max, const int32_t
     const int B = use_exit ? (p->batch > 0 ? p->batch : (p->iters > 65536 ? ((p->iters / 8 + 8191) / 8192) * 8192 : 8192)) : (p->iters > 0 ? p->iters : 1);
     LR_REQUIRE(p->sampler == 0 || p->sampler == 1, LR_EINVAL, "lr_ransac: sampler must be 0 (uniform) or 1 (PROSAC)");
     LR_REQUIRE(p->prosac_growth >= 0, LR_EINVAL, "lr_ransac: prosac_growth must be >= 0");
+    LR_REQUIRE(p->scoring == 0 || p->scoring == 1, LR_EINVAL, "lr_ransac: scoring must be 0 (count, then error) or 1 (MSAC)");
     const int TN = p->prosac_growth > 0 ? p->prosac_growth : 100000;
     const int32_t *G = nullptr;
     if (ws->timing && ws->ev_pending == 1) { LR_HIP(hipEventRecord(ws->ev[2], st)); }

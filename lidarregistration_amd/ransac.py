@@ -16,22 +16,23 @@ from .matching import _device, _f32, _i32, _stream, workspace
 DEFAULT_SEED = 51          # Experiments/test.py:357
 
 
-def ransac_params(iters, sample_size=3, use_elc=True, thr=0.6, seed=DEFAULT_SEED, confidence=1.0, batch=0, sampler=0, prosac_growth=0):
+def ransac_params(iters, sample_size=3, use_elc=True, thr=0.6, seed=DEFAULT_SEED, confidence=1.0, batch=0, sampler=0, prosac_growth=0,
+                  scoring=0):
     """confidence < 1 enables the early exit between batches of `batch` hypothesis ids (0 -> 8192, an eighth of the run when iters > 65536); sampler 1 = PROSAC
-    (correspondences best quality first, growth parameter T_N = prosac_growth, 0 -> 100000)."""
+    (correspondences best quality first, growth parameter T_N = prosac_growth, 0 -> 100000); scoring 1 = MSAC."""
     return _ext.RansacParams(int(sample_size), int(bool(use_elc)), np.float32(float(thr) * float(thr)), int(iters), int(seed),
-                             float(confidence), int(batch), int(sampler), int(prosac_growth))
+                             float(confidence), int(batch), int(sampler), int(prosac_growth), int(scoring), 0)
 
 
 def ransac_dev(src, tgt, iters, sample_size=3, use_elc=True, thr=0.6, seed=DEFAULT_SEED, confidence=1.0, batch=0, sampler=0,
-               prosac_growth=0):
+               prosac_growth=0, scoring=0):
     """RANSAC over M correspondences src[i] <-> tgt[i] ([M,3]).  Returns (T 4x4 float64 numpy, info dict)."""
     src, tgt = _f32(src), _f32(tgt)
     m = src.shape[0]
     ws = workspace(max(m, 1), 1, iters)
     T = torch.empty(16, dtype=torch.float64, device=src.device)
     res = torch.zeros(ctypes.sizeof(_ext.RansacResult), dtype=torch.uint8, device=src.device)
-    p = ransac_params(iters, sample_size, use_elc, thr, seed, confidence, batch, sampler, prosac_growth)
+    p = ransac_params(iters, sample_size, use_elc, thr, seed, confidence, batch, sampler, prosac_growth, scoring)
     _ext.check(_ext.lib().lr_ransac(ws.handle, src.data_ptr(), tgt.data_ptr(), m, None, ctypes.byref(p),
                                      T.data_ptr(), res.data_ptr(), _stream()))
     r = _ext.RansacResult.from_buffer_copy(res.cpu().numpy().tobytes())
@@ -96,7 +97,7 @@ def GC_RANSAC(A, B, distance_threshold, num_iterations, args, match_quality):
     start_time = time()
     T, info = ransac_dev(A, B, num_iterations, sample_size=3, use_elc=use_elc, thr=distance_threshold,
                          seed=getattr(args, "seed", DEFAULT_SEED), confidence=getattr(args, "GC_conf", 0.999),      # GC_RANSAC.py:26
-                         sampler=1 if prosac else 0)
+                         sampler=1 if prosac else 0, scoring=1)                 # MSAC, as pygcransac scores models
     if info["best_h"] < 0:
         T = np.eye(4)                                       # GC_RANSAC.py:51-52
     return T, time() - start_time

@@ -337,7 +337,19 @@ typedef struct {
     int32_t  batch;           /* batch length (0 -> 8192; iters > 65536: iters/8 rounded up to a multiple of 8192) */
     int32_t  sampler;         /* 0 uniform; 1 PROSAC (GC_RANSAC.py:24,39-43): correspondences best first */
     int32_t  prosac_growth;   /* T_N of the PROSAC growth function (0 -> 100000)       */
+    int32_t  scoring;         /* 0: inlier count, then error sum (Open3D); 1: MSAC (GC-RANSAC's truncated quadratic cost) */
+    int32_t  reserved0;
 } orc_ransac_params;
+
+/* is model (c, q, h) better than (bc, bq, bh)?  msac_T = (uint32)(thr2 * 2^20) for MSAC scoring, else 0 */
+static int model_better(uint32_t c, uint64_t q, int64_t h, uint32_t bc, uint64_t bq, int64_t bh, uint32_t msac_T)
+{
+    if (msac_T == 0u) return c > bc || (c == bc && (q < bq || (q == bq && h < bh)));
+    if (c == 0u) return 0;
+    if (bc == 0u) return 1;
+    const long long k = (long long)c * (long long)msac_T - (long long)q, bk = (long long)bc * (long long)msac_T - (long long)bq;
+    return k > bk || (k == bk && h < bh);
+}
 
 typedef struct {
     int64_t  best_h;          /* winning hypothesis id, -1 if none                    */
@@ -408,6 +420,7 @@ ORC_API void orc_ransac(const float *src, const float *tgt, int m, const orc_ran
     const int use_exit = p->confidence > 0.0f && p->confidence < 1.0f;
     const int64_t B = use_exit ? (p->batch > 0 ? p->batch : (p->iters > 65536 ? ((p->iters / 8 + 8191) / 8192) * 8192 : 8192)) : (p->iters > 0 ? p->iters : 1);
     int32_t *G = p->sampler == 1 ? prosac_table(m, p->sample_size, p->prosac_growth > 0 ? p->prosac_growth : 100000) : NULL;
+    const uint32_t msac_T = p->scoring == 1 ? (uint32_t)(p->thr2 * 1048576.0f) : 0u;
     for (int64_t h0 = 0; h0 < p->iters; h0 += B) {
         const int64_t h1 = h0 + B < p->iters ? h0 + B : p->iters;
 #pragma omp parallel
@@ -423,13 +436,12 @@ ORC_API void orc_ransac(const float *src, const float *tgt, int m, const orc_ran
                 uint32_t c; uint64_t q;
                 score_model(src, tgt, m, Rt, p->thr2, &c, &q);
                 if (c == 0) continue;
-                if (lh < 0 || c > lc || (c == lc && (q < lq || (q == lq && h < lh)))) { lh = h; lc = c; lq = q; }
+                if (lh < 0 || model_better(c, q, h, lc, lq, lh, msac_T)) { lh = h; lc = c; lq = q; }
             }
 #pragma omp critical
             {
                 n_valid += lv;
-                if (lh >= 0 && (best_h < 0 || lc > best_c ||
-                                (lc == best_c && (lq < best_q || (lq == best_q && lh < best_h))))) {
+                if (lh >= 0 && (best_h < 0 || model_better(lc, lq, lh, best_c, best_q, best_h, msac_T))) {
                     best_h = lh; best_c = lc; best_q = lq;
                 }
             }

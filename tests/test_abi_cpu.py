@@ -34,11 +34,11 @@ def test_version_and_error_string(libpath):
 
 def test_struct_layouts_match_header():
     # sizes the C side static-asserts implicitly through its field order (include/lidarreg.h)
-    assert ctypes.sizeof(_ext.RansacParams) == 40 and _ext.RansacParams.sampler.offset == 32
+    assert ctypes.sizeof(_ext.RansacParams) == 48 and _ext.RansacParams.sampler.offset == 32 and _ext.RansacParams.scoring.offset == 40
     assert ctypes.sizeof(_ext.RansacResult) == 40
     assert ctypes.sizeof(_ext.PairResult) == 496
-    assert ctypes.sizeof(_ext.PairParams) == 72
-    assert _ext.PairParams.ransac.offset == 8 and _ext.PairParams.gpf_factor.offset == 56
+    assert ctypes.sizeof(_ext.PairParams) == 80
+    assert _ext.PairParams.ransac.offset == 8 and _ext.PairParams.gpf_factor.offset == 64
 
 
 def test_bad_arguments_are_reported_not_crashed(libpath):

@@ -71,7 +71,7 @@ def test_FR_with_poisoned_scratch(lr, oracle, seed, mode, codebase, prosac):
     ns = 3 if codebase == "GC" else 4
     e = oracle.register_pair(p["xyz0"], p["xyz1"], p["feats0"], p["feats1"], mode=mode, iters=1500, sample_size=ns, use_elc=True,
                              seed=51, args=a, confidence=a.GC_conf if codebase == "GC" else a.o3d_conf,
-                             refit_on_orig=2 if codebase == "GC" else 1, prosac=prosac)
+                             refit_on_orig=2 if codebase == "GC" else 1, prosac=prosac, scoring=1 if codebase == "GC" else 0)
     t = lr.torch.from_numpy
     outs = []
     for byte in (0x00, 0xFF, 0x7F):

@@ -271,7 +271,7 @@ def test_FR_matches_oracle_pipeline(lr, oracle, mode, codebase, N, iters):
     ns = 3 if codebase == "GC" else 4
     e = oracle.register_pair(p["xyz0"], p["xyz1"], p["feats0"], p["feats1"], mode=mode, iters=iters, sample_size=ns,
                              use_elc=True, seed=51, args=a, confidence=a.GC_conf if codebase == "GC" else a.o3d_conf,
-                             refit_on_orig=2 if codebase == "GC" else 1)
+                             refit_on_orig=2 if codebase == "GC" else 1, scoring=1 if codebase == "GC" else 0)
     assert n_init == N and n_filt == len(e["idx0"])
     # contract: <= 1e-4 rad rotation, <= 1e-3 m translation on identical correspondence inputs
     assert np.radians(oracle.rotation_error_deg(T, e["T"])) <= 1e-4
@@ -316,7 +316,7 @@ def test_FR_prosac_matches_oracle_pipeline(lr, oracle, mode, N, iters):
     t = lr.torch.from_numpy
     T, _, _, _, n_init, _, n_filt, _ = lr.FR.FR(t(p["xyz0"]), t(p["xyz1"]), t(p["feats0"]), t(p["feats1"]), a, p["T_gt"])
     e = oracle.register_pair(p["xyz0"], p["xyz1"], p["feats0"], p["feats1"], mode=mode, iters=iters, sample_size=3,
-                             use_elc=True, seed=51, args=a, confidence=a.GC_conf, refit_on_orig=2, prosac=True)
+                             use_elc=True, seed=51, args=a, confidence=a.GC_conf, refit_on_orig=2, prosac=True, scoring=1)
     assert n_filt == len(e["idx0"])
     assert np.radians(oracle.rotation_error_deg(T, e["T"])) <= 1e-4 and oracle.translation_error_cm(T, e["T"]) / 100 <= 1e-3
     np.testing.assert_allclose(T, e["T"], rtol=0, atol=1e-9)
@@ -328,7 +328,7 @@ def test_FR_prosac_matches_oracle_pipeline(lr, oracle, mode, N, iters):
         A = p["xyz0"][e["idx0"]].astype(np.float32); B = p["xyz1"][e["idx1"]].astype(np.float32)
         Tg, _ = lr.ransac.GC_RANSAC(A, B, 0.6, iters, a, -fd)
         order = oracle.prosac_order(fd)
-        Te, _ = oracle.ransac(A[order], B[order], iters, 3, True, 0.6, 51, a.GC_conf, 0, sampler=1)
+        Te, _ = oracle.ransac(A[order], B[order], iters, 3, True, 0.6, 51, a.GC_conf, 0, sampler=1, scoring=1)
         assert np.array_equal(Tg, Te)
 
 
@@ -409,7 +409,7 @@ def test_FR_gpf_full_size(lr, oracle):
     t = lr.torch.from_numpy
     T, elapsed, _, _, n_init, _, n_filt, _ = lr.FR.FR(t(p["xyz0"]), t(p["xyz1"]), t(p["feats0"]), t(p["feats1"]), a, p["T_gt"])
     e = oracle.register_pair(p["xyz0"], p["xyz1"], p["feats0"], p["feats1"], mode="GPF", iters=20000, sample_size=3, seed=51, args=a,
-                             confidence=a.GC_conf, refit_on_orig=2)
+                             confidence=a.GC_conf, refit_on_orig=2, scoring=1)
     assert n_filt == len(e["idx0"]) and n_filt < n_init
     assert np.radians(oracle.rotation_error_deg(T, e["T"])) <= 1e-4 and oracle.translation_error_cm(T, e["T"]) / 100 <= 1e-3
 
@@ -431,6 +431,27 @@ def test_ransac_iteration_property_more_iters_never_worse(lr):
         _, info = lr.ransac.ransac_dev(src, tgt, iters, seed=5)
         assert info["best_count"] >= best          # hypotheses 0..iters-1 are a prefix of the longer run
         best = info["best_count"]
+
+
+@pytest.mark.parametrize("ns,n,iters,seed", [(3, 3000, 4000, 11), (4, 2000, 3000, 12)])
+def test_msac_scoring_same_winner_as_oracle(lr, oracle, ns, n, iters, seed):
+    """scoring = 1: the model with the largest sum over inliers of (thr^2 - d^2) wins (GC-RANSAC's MSAC cost)."""
+    src, tgt, T_gt = _planted(n=n, inlier=0.25, seed=seed)
+    T, info = lr.ransac.ransac_dev(src, tgt, iters, sample_size=ns, seed=seed, scoring=1)
+    Te, einfo = oracle.ransac(src, tgt, iters, sample_size=ns, seed=seed, scoring=1)
+    assert info == einfo and np.array_equal(T, Te)
+    # brute force over the hypothesis ids: nobody has a larger cost (ties towards the lower id)
+    Tq = int(np.float32(0.36) * np.float32(1048576.0))
+    best = None
+    for h in range(iters):
+        ok, Th, _ = oracle.hypothesis(src, tgt, h, sample_size=ns, seed=seed)
+        if not ok:
+            continue
+        c, q = oracle.score(src, tgt, Th)
+        if c and (best is None or c * Tq - q > best[0]):
+            best = (c * Tq - q, h)
+    assert best[1] == info["best_h"]
+    assert oracle.rotation_error_deg(T, T_gt) < 1.0
 
 
 def test_ransac_one_million_iterations_config4(lr, oracle):
