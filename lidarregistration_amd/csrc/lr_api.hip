@@ -114,7 +114,7 @@ extern "C" int lr_workspace_create(lr_workspace **out, int max_n0, int max_n1, i
     real.base = ws->base;
     carve(ws, real);
     if (hipMemset(ws->base, 0, ws->bytes) != hipSuccess) { (void)hipFree(ws->base); delete ws; lr_set_error("lr_workspace_create: hipMemset failed"); return LR_EHIP; }
-    for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < 6; ++k)
         if (hipEventCreate(&ws->ev[k]) != hipSuccess) { (void)hipFree(ws->base); delete ws; lr_set_error("lr_workspace_create: hipEventCreate failed"); return LR_EHIP; }
     *out = ws;
     return LR_OK;
@@ -123,7 +123,7 @@ extern "C" int lr_workspace_create(lr_workspace **out, int max_n0, int max_n1, i
 extern "C" int lr_workspace_destroy(lr_workspace *ws)
 {
     if (!ws) return LR_OK;
-    for (int k = 0; k < 4; ++k) (void)hipEventDestroy(ws->ev[k]);
+    for (int k = 0; k < 6; ++k) (void)hipEventDestroy(ws->ev[k]);
     (void)hipFree(ws->base);
     delete ws;
     return LR_OK;
@@ -157,7 +157,7 @@ extern "C" int lr_workspace_lists(lr_workspace *ws, int n0, int32_t *nn_idx1, in
 extern "C" int lr_workspace_timing(lr_workspace *ws, int enable)
 {
     LR_REQUIRE(ws, LR_EINVAL, "lr_workspace_timing: null workspace");
-    ws->timing = enable; ws->ev_pending = 0; ws->nn_ms_acc = 0; ws->ransac_ms_acc = 0; ws->n_samples = 0;
+    ws->timing = enable; ws->ev_pending = 0; ws->rev_recorded = 0; ws->nn_ms_acc = 0; ws->ransac_ms_acc = 0; ws->n_samples = 0;
     return LR_OK;
 }
 
@@ -169,6 +169,7 @@ extern "C" int lr_workspace_timing_read(lr_workspace *ws, float *nn_ms, float *r
         float ms = 0;
         LR_HIP(hipEventElapsedTime(&ms, ws->ev[0], ws->ev[1]));
         ws->nn_ms_acc += ms;
+        if (ws->rev_recorded) { LR_HIP(hipEventElapsedTime(&ms, ws->ev[4], ws->ev[5])); ws->nn_ms_acc += ms; ws->rev_recorded = 0; }
         if (ws->ev_pending >= 2) { LR_HIP(hipEventElapsedTime(&ms, ws->ev[2], ws->ev[3])); ws->ransac_ms_acc += ms; }
         ws->n_samples += 1;
         ws->ev_pending = 0;

@@ -96,10 +96,11 @@ struct lr_workspace {
     double *icp_state, *icp_part;
     // --- timing hook ---
     int timing;
-    hipEvent_t ev[4];
+    hipEvent_t ev[6];            // [0,1] forward pass B, [2,3] RANSAC gen+score, [4,5] reverse pass B
     float nn_ms_acc, ransac_ms_acc;
     int n_samples;
     int ev_pending;
+    int rev_recorded;
 };
 
 enum {

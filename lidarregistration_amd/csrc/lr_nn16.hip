@@ -820,9 +820,12 @@ int lr_nn16_reverse(lr_workspace *ws, const float *F0, const _Float16 *H0, const
                        ws->rev_cols, ws->Hs, ws->nrms, tmin, ws->rev_rows, ws->tau, ws->cand_cnt, rev);
     // grids are sized for all rows; blocks past the compacted count (or past their row block's strips) leave at once
     dim3 grid(row_blocks, strips);
+    const bool timed = ws->timing && ws->ev_pending == 1 && !ws->rev_recorded;
+    if (timed) { LR_HIP(hipEventRecord(ws->ev[4], st)); }
     hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), 0, st, H1, na, (const int32_t *)ws->rev_rows, (const int32_t *)n_rows,
                        (const _Float16 *)ws->Hs, (const float *)ws->nrms, nb, tps, ws->tau, ws->cand_cnt, ws->cand,
                        (const int32_t *)ws->rev_cols, (const float *)ws->rev_tmin, (const uint32_t *)seed);
+    if (timed) { LR_HIP(hipEventRecord(ws->ev[5], st)); ws->rev_recorded = 1; }
     hipLaunchKernelGGL(nn16_exact_kernel, dim3(lr_cdiv(na, 64)), dim3(256), 0, st, F1, nrm1, na, F0, nrm0, nb, ws->cand_cnt, ws->cand,
                        1, (const int32_t *)ws->rev_rows, (const int32_t *)n_rows, rev, (int32_t *)nullptr, (float *)nullptr, (float *)nullptr,
                        ws->counters);
