@@ -532,19 +532,39 @@ nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, in
     const int over = total > LR_NN16_CAP ? 1 : 0;
     // an overflowed list is not read at all: its slots are only partly written (the rest is stale from earlier pairs)
     const int ncand = over ? 0 : total;
+    // the candidate loop is a chain index -> gather -> 32 dependent fmas: the next candidate's row is fetched while the
+    // current chain runs
+    int jn = q < ncand ? cand[(size_t)rowc * LR_NN16_CAP + q] : 0;
+    f32x4 tn[8];
+    float nn = 0.0f;
+    if (q < ncand) {
+        const f32x4 *pb = reinterpret_cast<const f32x4 *>(Fc + (size_t)jn * 32);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tn[k] = pb[k];
+        nn = nC[jn];
+    }
     for (int c = q; c < ncand; c += 4) {
-        const int j = cand[(size_t)rowc * LR_NN16_CAP + c];
-        const f32x4 *pb = reinterpret_cast<const f32x4 *>(Fc + (size_t)j * 32);
+        const int j = jn;
+        f32x4 t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = tn[k];
+        const float ncj = nn;
+        if (c + 4 < ncand) {
+            jn = cand[(size_t)rowc * LR_NN16_CAP + c + 4];
+            const f32x4 *pb = reinterpret_cast<const f32x4 *>(Fc + (size_t)jn * 32);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) tn[k] = pb[k];
+            nn = nC[jn];
+        }
         float acc = 0.0f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const f32x4 t = pb[k];
-            acc = __builtin_fmaf(a[4 * k], t.x, acc);
-            acc = __builtin_fmaf(a[4 * k + 1], t.y, acc);
-            acc = __builtin_fmaf(a[4 * k + 2], t.z, acc);
-            acc = __builtin_fmaf(a[4 * k + 3], t.w, acc);
+            acc = __builtin_fmaf(a[4 * k], t[k].x, acc);
+            acc = __builtin_fmaf(a[4 * k + 1], t[k].y, acc);
+            acc = __builtin_fmaf(a[4 * k + 2], t[k].z, acc);
+            acc = __builtin_fmaf(a[4 * k + 3], t[k].w, acc);
         }
-        const float tt = nq + nC[j];
+        const float tt = nq + ncj;
         const float d2 = __builtin_fmaf(-2.0f, acc, tt);
         const float sv = __builtin_sqrtf(fmaxf(d2, 1e-30f));
         // candidates arrive in arbitrary order: order by (sqrt value, index) == torch.min's first minimal value
