@@ -193,6 +193,9 @@ ransac_gen_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__r
 
 // ------------------------------------------------------------------ score
 // Work items = (group of 64 hypotheses) x (chunk of correspondences); blocks stride over them.
+#ifndef LR_SCORE_CHUNK
+#define LR_SCORE_CHUNK 128
+#endif
 __global__ void __launch_bounds__(64)
 ransac_score_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__restrict__ m_dev, float thr2,
                     const float *__restrict__ models, uint32_t *__restrict__ score_cnt,
@@ -203,7 +206,7 @@ ransac_score_kernel(const float *__restrict__ corr8, int m_max, const int32_t *_
     const int hb = (V + 63) >> 6;
     if (hb == 0 || m <= 0 || reinterpret_cast<const lr_ransac_state *>(counters + LR_CNT_COUNT)->done) return;
     int chunks = (int)gridDim.x / hb;
-    const int cmax = m / 512 > 0 ? m / 512 : 1;
+    const int cmax = m / LR_SCORE_CHUNK > 0 ? m / LR_SCORE_CHUNK : 1;   // at least LR_SCORE_CHUNK correspondences per work item
     if (chunks > cmax) chunks = cmax;
     if (chunks < 1) chunks = 1;
     const int per = ((m + chunks - 1) / chunks + 1) & ~1;      // even: chunks start on a pair boundary
