@@ -455,8 +455,11 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
             { const int t0 = fo_cur; fo_cur = fo_oth; fo_oth = t0; const int t1 = xo_cur; xo_cur = xo_oth; xo_oth = t1; }
             if (wcnt >= LR_PB_WLIST / 2) flush();
         }
-        // drain: the last tile of the last chunk sits in accB
+        // drain: the last tile of the last chunk sits in accB.  The inline-asm maxima below read MFMA results the
+        // compiler cannot see them read (no automatic wait states): inside the loop every such read is at least two
+        // MFMAs behind its producer; here an explicit wait covers the 8-pass MFMA write latency.
         {
+            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
             const int tileC = t_begin + nchunks * CH - 1;
             check(accB[0], 0, xC, tileC, 0);
             check(accB[0], 8, xC, tileC, 0);
