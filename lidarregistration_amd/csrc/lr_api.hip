@@ -76,7 +76,7 @@ void carve(lr_workspace *ws, Carver &c)
     ws->score_ssq = c.take<unsigned long long>(it);
     ws->refit_part = c.take<double>((n0 / 256 + 2) * 16);
     ws->icp_ints = c.take<int32_t>(3 * (32768 + 8));
-    ws->icp_bucket = c.take<int32_t>(n1); ws->icp_sorted = c.take<int32_t>(n1);
+    ws->icp_bucket = c.take<int32_t>(n1); ws->icp_pts = c.take<float>(4 * n1);
     ws->icp_state = c.take<double>(32); ws->icp_part = c.take<double>((n0 / 256 + 2) * 18);
     ws->res_tmp = c.take<lr_ransac_result>(1);
     ws->T_tmp = c.take<double>(32);

@@ -63,12 +63,14 @@ icp_scan_kernel(const int32_t *__restrict__ hist, int32_t *__restrict__ start)
 
 __global__ void __launch_bounds__(256)
 icp_scatter_kernel(int n, const int32_t *__restrict__ bucket_of, const int32_t *__restrict__ start, int32_t *__restrict__ fill,
-                   int32_t *__restrict__ sorted)
+                   const float *__restrict__ tgt, float4 *__restrict__ pts)
 {
+    // the bucket holds the points themselves, { x, y, z, index bits }: the search loop then reads one contiguous 16-byte
+    // record per candidate instead of chasing index -> coordinates
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
     const int b = bucket_of[j];
-    sorted[start[b] + atomicAdd(&fill[b], 1)] = j;
+    pts[start[b] + atomicAdd(&fill[b], 1)] = make_float4(tgt[3 * j], tgt[3 * j + 1], tgt[3 * j + 2], __int_as_float(j));
 }
 
 // state block (doubles): [0..15] current T, [16] previous fitness, [17] previous rmse, [18] iteration index k,
@@ -85,7 +87,7 @@ __global__ void icp_init_kernel(const double *__restrict__ T_init, const lr_rans
 
 __global__ void __launch_bounds__(256)
 icp_iter_kernel(const float *__restrict__ src, int n0, const float *__restrict__ tgt, const int32_t *__restrict__ start,
-                const int32_t *__restrict__ sorted, double inv_cell, double max_d2, int max_iter, double rel_fit, double rel_rmse,
+                const float4 *__restrict__ pts, double inv_cell, double max_d2, int max_iter, double rel_fit, double rel_rmse,
                 double *__restrict__ state, double *__restrict__ partial)
 {
     __shared__ double sm[4][18];
@@ -107,20 +109,24 @@ icp_iter_kernel(const float *__restrict__ src, int n0, const float *__restrict__
         const int cx = (int)floor(p[0] * inv_cell), cy = (int)floor(p[1] * inv_cell), cz = (int)floor(p[2] * inv_cell);
         double best = max_d2;
         int bj = -1;
-        for (int dz = -1; dz <= 1; ++dz)
-            for (int dy = -1; dy <= 1; ++dy)
-                for (int dx = -1; dx <= 1; ++dx) {
-                    const int b = (int)icp_hash(cx + dx, cy + dy, cz + dz);
-                    const int e = start[b + 1];
-                    for (int t = start[b]; t < e; ++t) {
-                        const int j = sorted[t];
-                        const double qx = (double)tgt[3 * j] - p[0], qy = (double)tgt[3 * j + 1] - p[1], qz = (double)tgt[3 * j + 2] - p[2];
-                        const double d2 = (qx * qx + qy * qy) + qz * qz;
-                        // strictly inside the radius; nearest wins, ties to the lower target index (hash collisions
-                        // can visit a point twice, which changes nothing)
-                        if (d2 < best || (d2 == best && bj >= 0 && j < bj)) { best = d2; bj = j; }
-                    }
-                }
+        // bucket ranges of the 27 cells first (independent loads), then the buckets' records
+        int cs[27], ce[27];
+#pragma unroll
+        for (int c = 0; c < 27; ++c) {
+            const int b = (int)icp_hash(cx + (c % 3) - 1, cy + ((c / 3) % 3) - 1, cz + (c / 9) - 1);
+            cs[c] = start[b]; ce[c] = start[b + 1];
+        }
+#pragma unroll
+        for (int c = 0; c < 27; ++c)
+            for (int t = cs[c]; t < ce[c]; ++t) {
+                const float4 r = pts[t];
+                const int j = __float_as_int(r.w);
+                const double qx = (double)r.x - p[0], qy = (double)r.y - p[1], qz = (double)r.z - p[2];
+                const double d2 = (qx * qx + qy * qy) + qz * qz;
+                // strictly inside the radius; nearest wins, ties to the lower target index (hash collisions
+                // can visit a point twice, which changes nothing)
+                if (d2 < best || (d2 == best && bj >= 0 && j < bj)) { best = d2; bj = j; }
+            }
         if (bj >= 0) {
             const double q[3] = { (double)tgt[3 * bj], (double)tgt[3 * bj + 1], (double)tgt[3 * bj + 2] };
             v[0] = 1.0;
@@ -161,10 +167,20 @@ icp_iter_kernel(const float *__restrict__ src, int n0, const float *__restrict__
     }
     __syncthreads();
     if (!s_last) return;
-    if (threadIdx.x < 17) {
-        double s = 0.0;
-        for (unsigned b = 0; b < gridDim.x; ++b) s += partial[(size_t)b * 18 + threadIdx.x];      // fixed order: reproducible
-        mom[threadIdx.x] = s;
+    {
+        // block partials summed in block order (reproducible); staged through LDS 64 blocks at a time so that the 17 summing
+        // lanes do not walk a chain of dependent global loads
+        __shared__ double stage[64 * 18];
+        double acc = 0.0;
+        for (unsigned b0 = 0; b0 < gridDim.x; b0 += 64) {
+            const int nbk = min(64u, gridDim.x - b0);
+            for (int t = threadIdx.x; t < nbk * 18; t += 256) stage[t] = partial[(size_t)b0 * 18 + t];
+            __syncthreads();
+            if (threadIdx.x < 17)
+                for (int b = 0; b < nbk; ++b) acc += stage[b * 18 + threadIdx.x];
+            __syncthreads();
+        }
+        if (threadIdx.x < 17) mom[threadIdx.x] = acc;
     }
     __syncthreads();
     if (threadIdx.x != 0) return;
@@ -215,11 +231,11 @@ int lr_icp_run(lr_workspace *ws, const float *xyz0, int n0, const float *xyz1, i
     LR_HIP(hipMemsetAsync(hist, 0, sizeof(int32_t) * 2 * (LR_ICP_NB + 8), st));
     hipLaunchKernelGGL(icp_hist_kernel, dim3(lr_cdiv(n1, 256)), dim3(256), 0, st, xyz1, n1, inv_cell, ws->icp_bucket, hist);
     hipLaunchKernelGGL(icp_scan_kernel, dim3(1), dim3(1024), 0, st, hist, start);
-    hipLaunchKernelGGL(icp_scatter_kernel, dim3(lr_cdiv(n1, 256)), dim3(256), 0, st, n1, ws->icp_bucket, start, fill, ws->icp_sorted);
+    hipLaunchKernelGGL(icp_scatter_kernel, dim3(lr_cdiv(n1, 256)), dim3(256), 0, st, n1, ws->icp_bucket, start, fill, xyz1, reinterpret_cast<float4 *>(ws->icp_pts));
     hipLaunchKernelGGL(icp_init_kernel, dim3(1), dim3(64), 0, st, T_init, gate, ws->icp_state);
     const int nb = lr_cdiv(n0, 256);
     for (int k = 0; k <= max_iter; ++k)
-        hipLaunchKernelGGL(icp_iter_kernel, dim3(nb), dim3(256), 0, st, xyz0, n0, xyz1, start, ws->icp_sorted, inv_cell,
+        hipLaunchKernelGGL(icp_iter_kernel, dim3(nb), dim3(256), 0, st, xyz0, n0, xyz1, start, reinterpret_cast<const float4 *>(ws->icp_pts), inv_cell,
                            max_dist * max_dist, max_iter, rel_fit, rel_rmse, ws->icp_state, ws->icp_part);
     hipLaunchKernelGGL(icp_result_kernel, dim3(1), dim3(64), 0, st, ws->icp_state, T_out, res);
     LR_LAUNCH_CHECK();

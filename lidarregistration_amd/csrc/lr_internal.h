@@ -92,7 +92,8 @@ struct lr_workspace {
     double *T_tmp;               // [32]
     // --- ICP ---
     int32_t *icp_ints;           // hist | fill | start of the hashed target grid
-    int32_t *icp_bucket, *icp_sorted;   // [max_n1]
+    int32_t *icp_bucket;         // [max_n1] bucket of every target point
+    float *icp_pts;              // [max_n1][4] target points in bucket order: x y z index-bits
     double *icp_state, *icp_part;
     // --- timing hook ---
     int timing;

@@ -1,5 +1,5 @@
 import sys, numpy as np, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lidarregistration_amd import matching, synth
 from oracle import oracle
 big = int(sys.argv[1]) if len(sys.argv) > 1 else 30000

@@ -1,6 +1,6 @@
 """One-off soak: many random NN / mutual / FR cases against the oracle on a poisoned workspace (not part of the suite)."""
 import sys, time, numpy as np, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lidarregistration_amd import matching, synth, FR
 from oracle import oracle
 from tests.conftest import Args
