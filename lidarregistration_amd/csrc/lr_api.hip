@@ -204,23 +204,23 @@ static int prep_both(lr_workspace *ws, const float *F0, int n0, const float *F1,
 
 // forward: rows of cloud 0 against cloud 1 (first + second NN)
 static int nn_forward(lr_workspace *ws, const float *F0, int n0, const float *F1, int n1,
-                      int32_t *idx1, int32_t *idx2, float *s1, float *s2, hipStream_t st)
+                      int32_t *idx1, int32_t *idx2, float *s1, float *s2, hipStream_t st, bool seed_reverse = false)
 {
     if (ws->nn_path == LR_NN_PATH_FP32_MFMA)
         return lr_nn_run(ws, ws->Fp0, ws->nrm0, n0, ws->Fp1, ws->nrm1, n1, idx1, idx2, s1, s2, st);
     return lr_nn16_run(ws, F0, ws->H0, ws->nrm0, n0, F1, ws->H1, ws->nrm1, ws->bmax1, n1,
-                       2, idx1, idx2, s1, s2, st);
+                       2, idx1, idx2, s1, s2, st, seed_reverse);
 }
 
 // reverse: rows of cloud 1 against cloud 0 (first NN only).  The reference restricts it to the unique forward
 // targets (matching.py:224-225); rows that are nobody's target never enter the intersection, so all rows is equivalent.
 static int nn_reverse(lr_workspace *ws, const float *F0, int n0, const float *F1, int n1, const int32_t *fwd_idx1,
-                      int32_t *rev, hipStream_t st)
+                      int32_t *rev, hipStream_t st, bool seeded = false)
 {
     if (ws->nn_path == LR_NN_PATH_FP32_MFMA)
         return lr_nn_run(ws, ws->Fp1, ws->nrm1, n1, ws->Fp0, ws->nrm0, n0, rev, nullptr, nullptr, nullptr, st);
     // seeded by the forward pairs: only columns some query points at are resolved (others get -1)
-    return lr_nn16_reverse(ws, F0, ws->H0, ws->nrm0, ws->bmax0, n0, F1, ws->H1, ws->nrm1, n1, fwd_idx1, rev, st);
+    return lr_nn16_reverse(ws, F0, ws->H0, ws->nrm0, ws->bmax0, n0, F1, ws->H1, ws->nrm1, n1, fwd_idx1, rev, st, seeded);
 }
 
 // ------------------------------------------------------------------ a1/a2
@@ -347,12 +347,13 @@ extern "C" int lr_register_pair(lr_workspace *ws, const float *xyz0, const float
     LR_HIP(hipMemsetAsync(ws->counters, 0, sizeof(int32_t) * LR_CNT_TOTAL, st));
     // 1. coarse correspondences (FR.py:38): first + second NN of every cloud-0 descriptor
     LR_TRY(prep_both(ws, F0, n0, F1, n1, st));
-    LR_TRY(nn_forward(ws, F0, n0, F1, n1, ws->nn_idx1, ws->nn_idx2, ws->nn_s1, ws->nn_s2, st));
+    const bool fuse_seed = p->mode != LR_MODE_NO_FILTER && ws->nn_path != LR_NN_PATH_FP32_MFMA;   // the forward exact kernel seeds the reverse pass
+    LR_TRY(nn_forward(ws, F0, n0, F1, n1, ws->nn_idx1, ws->nn_idx2, ws->nn_s1, ws->nn_s2, st, fuse_seed));
     // 2. filter (FR.py:48-56)
     if (p->mode == LR_MODE_NO_FILTER) {
         LR_TRY(lr_identity_corr(ws, n0, ws->nn_idx1, ws->nn_idx2, ws->corr_idx0, ws->corr_idx1, ws->corr_idx2, m_dev, st));
     } else {
-        LR_TRY(nn_reverse(ws, F0, n0, F1, n1, ws->nn_idx1, ws->rev_idx1, st));
+        LR_TRY(nn_reverse(ws, F0, n0, F1, n1, ws->nn_idx1, ws->rev_idx1, st, fuse_seed));
         if (p->mode == LR_MODE_MNN) {
             LR_TRY(lr_mutual_run(ws, n0, ws->nn_idx1, ws->nn_idx2, ws->rev_idx1, ws->is_bb, ws->corr_idx0, ws->corr_idx1,
                                  ws->corr_idx2, m_dev, st, xyz0, xyz1, ws->corr8));

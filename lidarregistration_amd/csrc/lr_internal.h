@@ -143,10 +143,10 @@ int lr_nn_prep(lr_workspace *ws, const float *F, int n, float *Fp, float *nrm, h
 int lr_nn16_prep(lr_workspace *ws, const float *F0, int n0, const float *F1, int n1, hipStream_t st);
 int lr_nn16_run(lr_workspace *ws, const float *Fq, const _Float16 *Hq, const float *nQ, int na,
                 const float *Fc, const _Float16 *Hc, const float *nC, const float *block_max_c, int nb,
-                int need, int32_t *idx1, int32_t *idx2, float *s1, float *s2, hipStream_t st);
+                int need, int32_t *idx1, int32_t *idx2, float *s1, float *s2, hipStream_t st, bool seed_reverse = false);
 int lr_nn16_reverse(lr_workspace *ws, const float *F0, const _Float16 *H0, const float *nrm0, const float *bmax0, int n0,
                     const float *F1, const _Float16 *H1, const float *nrm1, int n1, const int32_t *fwd_idx1,
-                    int32_t *rev, hipStream_t st);
+                    int32_t *rev, hipStream_t st, bool seeded = false);
 int lr_nn_fix_rows(lr_workspace *ws, bool permuted, const float *Fa, const float *nrma, const float *Fb, const float *nrmb, int nb,
                    int32_t *idx1, int32_t *idx2, float *s1, float *s2, hipStream_t st);
 

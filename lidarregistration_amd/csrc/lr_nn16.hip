@@ -515,8 +515,10 @@ nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, in
                   const int32_t *__restrict__ cand_cnt, const int32_t *__restrict__ cand, int need,
                   const int32_t *__restrict__ rowmap, const int32_t *__restrict__ na_dev,
                   int32_t *__restrict__ idx1, int32_t *__restrict__ idx2, float *__restrict__ s1o, float *__restrict__ s2o,
-                  int32_t *__restrict__ counters)
+                  int32_t *__restrict__ counters,
+                  uint32_t *__restrict__ seed_out, float *__restrict__ seed_s1, uint32_t *__restrict__ seed_range)
 {
+    __shared__ float s_lo[4], s_hi[4];
     const int gid = blockIdx.x * 256 + threadIdx.x;
     const int row = gid >> 2, q = gid & 3;
     if (na_dev) na = *na_dev;                  // compacted row list (reverse direction): lists by position, data by rowmap[]
@@ -608,11 +610,31 @@ nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, in
         b1 = x1; i1 = xi1;
         b2 = sy ? y1 : x2; i2 = sy ? yi1 : xi2;
     }
-    if (!live || q != 0) return;
-    idx1[rowd] = i1;
-    if (idx2) idx2[rowd] = i2;
-    if (s1o) s1o[rowd] = b1;
-    if (s2o) s2o[rowd] = b2;
+    const bool writer = live && q == 0;
+    if (writer) {
+        idx1[rowd] = i1;
+        if (idx2) idx2[rowd] = i2;
+        if (s1o) s1o[rowd] = b1;
+        if (s2o) s2o[rowd] = b2;
+    }
+    if (!seed_out) return;
+    // forward direction of a pair: seed the reverse pass here (what nn16_rev_seed_kernel would recompute bit for bit):
+    // best forward distance per target, the row's own NN distance, and the range of all of them
+    float sv = b1;
+    if (!(sv < 3.0e38f)) sv = 3.0e38f;
+    if (writer) {
+        if (i1 >= 0 && i1 < nb) atomicMin(&seed_out[i1], __float_as_uint(sv));
+        seed_s1[rowd] = sv;
+    }
+    float lo = writer ? sv : 3.0e38f, hi = writer ? sv : 0.0f;
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) { lo = fminf(lo, __shfl_xor(lo, k)); hi = fmaxf(hi, __shfl_xor(hi, k)); }
+    if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicMin(&seed_range[0], __float_as_uint(fminf(fminf(s_lo[0], s_lo[1]), fminf(s_lo[2], s_lo[3]))));
+        atomicMax(&seed_range[1], __float_as_uint(fmaxf(fmaxf(s_hi[0], s_hi[1]), fmaxf(s_hi[2], s_hi[3]))));
+    }
 }
 
 // ------------------------------------------------------------------ host side
@@ -626,7 +648,7 @@ int lr_nn16_prep(lr_workspace *ws, const float *F0, int n0, const float *F1, int
 
 int lr_nn16_run(lr_workspace *ws, const float *Fq, const _Float16 *Hq, const float *nQ, int na,
                 const float *Fc, const _Float16 *Hc, const float *nC, const float *block_max_c, int nb,
-                int need, int32_t *idx1, int32_t *idx2, float *s1, float *s2, hipStream_t st)
+                int need, int32_t *idx1, int32_t *idx2, float *s1, float *s2, hipStream_t st, bool seed_reverse)
 {
     const int ntiles = lr_cdiv(nb, 32);
     const int row_blocks = lr_cdiv(na, LR_BLOCK_ROWS);
@@ -650,7 +672,8 @@ int lr_nn16_run(lr_workspace *ws, const float *Fq, const _Float16 *Hq, const flo
                        tps, ws->tau, ws->cand_cnt, ws->cand, (const int32_t *)nullptr, (const float *)nullptr, (const uint32_t *)nullptr);
     if (ws->timing && !ws->ev_pending) { LR_HIP(hipEventRecord(ws->ev[1], st)); ws->ev_pending = 1; }
     hipLaunchKernelGGL(nn16_exact_kernel, dim3(lr_cdiv(na, 64)), dim3(256), 0, st, Fq, nQ, na, Fc, nC, nb, ws->cand_cnt, ws->cand,
-                       need, (const int32_t *)nullptr, (const int32_t *)nullptr, idx1, idx2, s1, s2, ws->counters);
+                       need, (const int32_t *)nullptr, (const int32_t *)nullptr, idx1, idx2, s1, s2, ws->counters,
+                       seed_reverse ? ws->rev_seed : (uint32_t *)nullptr, ws->rev_s1, reinterpret_cast<uint32_t *>(ws->counters + LR_CNT_RLO));
     LR_LAUNCH_CHECK();
     return LR_OK;
 }
@@ -819,7 +842,7 @@ nn16_rev_scatter_kernel(int n0, int n1, const float *__restrict__ s1, const uint
 
 int lr_nn16_reverse(lr_workspace *ws, const float *F0, const _Float16 *H0, const float *nrm0, const float *bmax0, int n0,
                     const float *F1, const _Float16 *H1, const float *nrm1, int n1, const int32_t *fwd_idx1,
-                    int32_t *rev, hipStream_t st)
+                    int32_t *rev, hipStream_t st, bool seeded)
 {
     // rows = cloud 1 (the columns of the forward direction), columns = cloud 0
     const int na = n1, nb = n0;
@@ -835,7 +858,8 @@ int lr_nn16_reverse(lr_workspace *ws, const float *F0, const _Float16 *H0, const
     uint32_t *range = reinterpret_cast<uint32_t *>(ws->counters + LR_CNT_RLO);
     int32_t *n_rows = ws->counters + LR_CNT_NREV;
     uint32_t *tmin = reinterpret_cast<uint32_t *>(ws->rev_tmin);
-    hipLaunchKernelGGL(nn16_rev_seed_kernel, dim3(lr_cdiv(n0, 256)), dim3(256), 0, st, F0, nrm0, n0, F1, nrm1, fwd_idx1, seed, ws->rev_s1, range);
+    if (!seeded)     // (the forward pass of lr_register_pair seeds from its exact kernel: same values, one launch less)
+        hipLaunchKernelGGL(nn16_rev_seed_kernel, dim3(lr_cdiv(n0, 256)), dim3(256), 0, st, F0, nrm0, n0, F1, nrm1, fwd_idx1, seed, ws->rev_s1, range);
     hipLaunchKernelGGL(nn16_rev_scan_kernel, dim3(1), dim3(1024), 0, st, n0, n1, (const float *)ws->rev_s1, (const uint32_t *)seed,
                        (const uint32_t *)range, ws->rev_hist, n_rows, tmin);
     hipLaunchKernelGGL(nn16_rev_scatter_kernel, dim3(lr_cdiv(n0 + n1, 256)), dim3(256), 0, st, n0, n1, (const float *)ws->rev_s1,
@@ -851,7 +875,7 @@ int lr_nn16_reverse(lr_workspace *ws, const float *F0, const _Float16 *H0, const
     if (timed) { LR_HIP(hipEventRecord(ws->ev[5], st)); ws->rev_recorded = 1; }
     hipLaunchKernelGGL(nn16_exact_kernel, dim3(lr_cdiv(na, 64)), dim3(256), 0, st, F1, nrm1, na, F0, nrm0, nb, ws->cand_cnt, ws->cand,
                        1, (const int32_t *)ws->rev_rows, (const int32_t *)n_rows, rev, (int32_t *)nullptr, (float *)nullptr, (float *)nullptr,
-                       ws->counters);
+                       ws->counters, (uint32_t *)nullptr, (float *)nullptr, (uint32_t *)nullptr);
     LR_LAUNCH_CHECK();
     return LR_OK;
 }
