@@ -193,13 +193,14 @@ static int check_nn_args(const lr_workspace *ws, const void *F0, int n0, const v
 #define LR_TRY(x) do { int rc_ = (x); if (rc_ != LR_OK) return rc_; } while (0)
 
 // norms + operand copies of both clouds for whichever NN path the workspace uses
-static int prep_both(lr_workspace *ws, const float *F0, int n0, const float *F1, int n1, hipStream_t st)
+static int prep_both(lr_workspace *ws, const float *F0, int n0, const float *F1, int n1, hipStream_t st, bool zero_counters = false)
 {
     if (ws->nn_path == LR_NN_PATH_FP32_MFMA) {
+        if (zero_counters) LR_HIP(hipMemsetAsync(ws->counters, 0, sizeof(int32_t) * LR_CNT_TOTAL, st));
         LR_TRY(lr_nn_prep(ws, F0, n0, ws->Fp0, ws->nrm0, st));
         return lr_nn_prep(ws, F1, n1, ws->Fp1, ws->nrm1, st);
     }
-    return lr_nn16_prep(ws, F0, n0, F1, n1, st);
+    return lr_nn16_prep(ws, F0, n0, F1, n1, st, zero_counters);      // the prep kernel clears the counter block itself
 }
 
 // forward: rows of cloud 0 against cloud 1 (first + second NN)
@@ -331,7 +332,9 @@ __global__ void pair_result_kernel(const double *__restrict__ T_ransac, const do
         out->n_nn_fixed = counters[LR_CNT_FIX_TOTAL];
         out->status = rr->best_h < 0 ? 1 : 0;
         for (int q = 0; q < 8; ++q) out->reserved[q] = 0;
+        out->icp.fitness = 0.0; out->icp.inlier_rmse = 0.0; out->icp.n_corr = 0; out->icp.iterations = 0;
     }
+    if (k < 16) out->T_icp[k] = T_final[k];      // overwritten by pair_icp_kernel when the ICP stage runs
 }
 
 extern "C" int lr_register_pair(lr_workspace *ws, const float *xyz0, const float *xyz1, const float *F0, const float *F1,
@@ -344,9 +347,8 @@ extern "C" int lr_register_pair(lr_workspace *ws, const float *xyz0, const float
     hipStream_t st = (hipStream_t)stream;
     int32_t *m_dev = ws->counters + LR_CNT_NCORR;
     int32_t *n_refit = ws->counters + LR_CNT_COUNT - 2;
-    LR_HIP(hipMemsetAsync(ws->counters, 0, sizeof(int32_t) * LR_CNT_TOTAL, st));
     // 1. coarse correspondences (FR.py:38): first + second NN of every cloud-0 descriptor
-    LR_TRY(prep_both(ws, F0, n0, F1, n1, st));
+    LR_TRY(prep_both(ws, F0, n0, F1, n1, st, true));
     const bool fuse_seed = p->mode != LR_MODE_NO_FILTER && ws->nn_path != LR_NN_PATH_FP32_MFMA;   // the forward exact kernel seeds the reverse pass
     LR_TRY(nn_forward(ws, F0, n0, F1, n1, ws->nn_idx1, ws->nn_idx2, ws->nn_s1, ws->nn_s2, st, fuse_seed));
     // 2. filter (FR.py:48-56)
@@ -391,7 +393,7 @@ extern "C" int lr_register_pair(lr_workspace *ws, const float *xyz0, const float
     lr_icp_result *icp_res = reinterpret_cast<lr_icp_result *>(ws->icp_state + 24);
     if (p->icp)
         LR_TRY(lr_icp_run(ws, xyz0, n0, xyz1, n1, T_final, ws->res_tmp, 0.6, 30, 1e-6, 1e-6, ws->T_tmp, icp_res, st));
-    hipLaunchKernelGGL(pair_icp_kernel, dim3(1), dim3(64), 0, st, ws->T_tmp, icp_res, out, p->icp ? 1 : 0);
+    if (p->icp) hipLaunchKernelGGL(pair_icp_kernel, dim3(1), dim3(64), 0, st, ws->T_tmp, icp_res, out, 1);
     LR_LAUNCH_CHECK();
     return LR_OK;
 }

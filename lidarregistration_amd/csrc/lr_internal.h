@@ -140,7 +140,7 @@ int lr_nn_run(lr_workspace *ws, const float *Fa, const float *nrma, int na, cons
 int lr_nn_prep(lr_workspace *ws, const float *F, int n, float *Fp, float *nrm, hipStream_t st);
 
 // lr_nn16.hip
-int lr_nn16_prep(lr_workspace *ws, const float *F0, int n0, const float *F1, int n1, hipStream_t st);
+int lr_nn16_prep(lr_workspace *ws, const float *F0, int n0, const float *F1, int n1, hipStream_t st, bool zero_counters = false);
 int lr_nn16_run(lr_workspace *ws, const float *Fq, const _Float16 *Hq, const float *nQ, int na,
                 const float *Fc, const _Float16 *Hc, const float *nC, const float *block_max_c, int nb,
                 int need, int32_t *idx1, int32_t *idx2, float *s1, float *s2, hipStream_t st, bool seed_reverse = false);

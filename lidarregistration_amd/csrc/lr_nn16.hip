@@ -43,10 +43,16 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 __global__ void __launch_bounds__(256)
 nn16_prep_kernel(const float *__restrict__ Fa, int na, _Float16 *__restrict__ Ha, float *__restrict__ nrma, float *__restrict__ bmaxa,
                  const float *__restrict__ Fb, int nb, _Float16 *__restrict__ Hb, float *__restrict__ nrmb, float *__restrict__ bmaxb,
-                 uint32_t *__restrict__ seed_b, uint32_t *__restrict__ rev_range)
+                 uint32_t *__restrict__ seed_b, int32_t *__restrict__ counters, int zero_counters)
 {
     __shared__ float s_m[4];
-    if (rev_range && blockIdx.x == 0 && threadIdx.x == 0) { rev_range[0] = 0x7f7f7f7fu; rev_range[1] = 0u; }   // lr_nn16_reverse
+    // first kernel of a pair: the counter block starts from zero (lr_register_pair) and the distance range of
+    // lr_nn16_reverse from { 0x7f7f7f7f, 0 }
+    if (counters && blockIdx.x == 0 && (int)threadIdx.x < LR_CNT_TOTAL) {
+        const int k = threadIdx.x;
+        if (k == LR_CNT_RLO) counters[k] = 0x7f7f7f7f;
+        else if (k == LR_CNT_RHI || zero_counters) counters[k] = 0;
+    }
     // blocks [0, ceil(na/32)) prepare cloud a, the rest cloud b (one launch for the pair)
     const int nblk_a = (na + 31) >> 5;
     const bool second = (int)blockIdx.x >= nblk_a;
@@ -638,10 +644,10 @@ nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, in
 }
 
 // ------------------------------------------------------------------ host side
-int lr_nn16_prep(lr_workspace *ws, const float *F0, int n0, const float *F1, int n1, hipStream_t st)
+int lr_nn16_prep(lr_workspace *ws, const float *F0, int n0, const float *F1, int n1, hipStream_t st, bool zero_counters)
 {
     hipLaunchKernelGGL(nn16_prep_kernel, dim3(lr_cdiv(n0, 32) + lr_cdiv(n1, 32)), dim3(256), 0, st, F0, n0, ws->H0, ws->nrm0, ws->bmax0,
-                       F1, n1, ws->H1, ws->nrm1, ws->bmax1, ws->rev_seed, reinterpret_cast<uint32_t *>(ws->counters + LR_CNT_RLO));
+                       F1, n1, ws->H1, ws->nrm1, ws->bmax1, ws->rev_seed, ws->counters, zero_counters ? 1 : 0);
     LR_LAUNCH_CHECK();
     return LR_OK;
 }

@@ -491,6 +491,8 @@ refit_solve_kernel(const double *__restrict__ partial, int nblocks, const double
         pair_out->n_nn_fixed = counters[LR_CNT_FIX_TOTAL];
         pair_out->status = gate->best_h < 0 ? 1 : 0;
         for (int q = 0; q < 8; ++q) pair_out->reserved[q] = 0;
+        for (int k = 0; k < 16; ++k) pair_out->T_icp[k] = T[k];      // overwritten by pair_icp_kernel when the ICP stage runs
+        pair_out->icp.fitness = 0.0; pair_out->icp.inlier_rmse = 0.0; pair_out->icp.n_corr = 0; pair_out->icp.iterations = 0;
     }
 }
 

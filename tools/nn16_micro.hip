@@ -26,7 +26,7 @@ int main(int argc, char **argv)
     hipMemcpy(F, h.data(), (size_t)n*128, hipMemcpyHostToDevice);
     hipMemset(mx, 0, 8);
     float *bmax; hipMalloc(&bmax, (n/32+2)*4);
-    hipLaunchKernelGGL(nn16_prep_kernel, dim3((n+31)/32), dim3(256), 0, 0, F, n, H, nrm, bmax, F, 0, H, nrm, bmax, (uint32_t*)nullptr, (uint32_t*)nullptr);
+    hipLaunchKernelGGL(nn16_prep_kernel, dim3((n+31)/32), dim3(256), 0, 0, F, n, H, nrm, bmax, F, 0, H, nrm, bmax, (uint32_t*)nullptr, (int32_t*)nullptr, 0);
     int ntiles = (n + 31) / 32;
     int row_blocks = (n + LR_BLOCK_ROWS - 1) / LR_BLOCK_ROWS;
     for (int stride : {1, 2, 4}) {
