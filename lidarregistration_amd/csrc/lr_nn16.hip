@@ -122,7 +122,8 @@ nn16_prep_kernel(const float *__restrict__ Fa, int na, _Float16 *__restrict__ Ha
 
 __global__ void __launch_bounds__(256)
 nn16_passa_kernel(const _Float16 *__restrict__ Hq, int na, const _Float16 *__restrict__ Hc, const float *__restrict__ nC, int nb,
-                  int tiles_per_strip, int tile_stride, int part_stride, float *__restrict__ pg1, float *__restrict__ pg2)
+                  int tiles_per_strip, int tile_stride, int part_stride, float *__restrict__ pg1, float *__restrict__ pg2,
+                  int32_t *__restrict__ cand_cnt)
 {
     constexpr int CH = LR_CH;
     constexpr int XOFF = CH * 32 * LR_LDS_ROW;
@@ -137,6 +138,8 @@ nn16_passa_kernel(const _Float16 *__restrict__ Hq, int na, const _Float16 *__res
     const int t_end = min(ntiles, t_begin + tiles_per_strip);
     const int nsamp = t_end > t_begin ? (t_end - t_begin + tile_stride - 1) / tile_stride : 0;   // tiles this block visits
     const int nchunks = (nsamp + CH - 1) / CH;
+    // the candidate lists of pass B (which follows on the stream) start empty
+    if (strip == 0 && (int)blockIdx.x * LR_BLOCK_ROWS + tid < na) cand_cnt[blockIdx.x * LR_BLOCK_ROWS + tid] = 0;
 
     f16x8 a[2][2];
 #pragma unroll
@@ -259,11 +262,20 @@ nn16_passa_kernel(const _Float16 *__restrict__ Hq, int na, const _Float16 *__res
 #endif
 #define LR_PB_WLIST 512          // entries per wave (8 bytes each)
 
-__global__ void __launch_bounds__(256)
+// what the thresholds of the forward direction are made of (pass A partials); the reverse direction passes tau instead
+struct lr_thr_in {
+    const float *pg1, *pg2;      // [strips][part_stride] two largest sampled g per row and strip
+    const float *nQ;             // squared norms of the query rows
+    const float *block_max_c;    // per-32-row maxima of the column cloud's squared norms
+    int nstrips, part_stride, nblk_c, need;
+};
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *__restrict__ rowmap, const int32_t *__restrict__ na_dev,
                   const _Float16 *__restrict__ Hc, const float *__restrict__ nC, int nb,
                   int tiles_per_strip, const float *__restrict__ tau, int32_t *__restrict__ cand_cnt, int32_t *__restrict__ cand,
-                  const int32_t *__restrict__ colmap, const float *__restrict__ tile_min, const uint32_t *__restrict__ row_bound)
+                  const int32_t *__restrict__ colmap, const float *__restrict__ tile_min, const uint32_t *__restrict__ row_bound,
+                  lr_thr_in thr)
 {
     // rows: either 0..na_host-1, or (reverse direction) the ordered list rowmap[0..*na_dev-1]; tau, cand_cnt and cand
     // are indexed by the position in that list.  Columns: Hc/nC as they lie; with colmap they are a permuted copy and
@@ -311,6 +323,41 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     const int t_end = min(ntiles, t_begin + tiles_per_strip);
     const int nchunks = t_end > t_begin ? (t_end - t_begin + CH - 1) / CH : 0;
 
+    // thresholds of the block's 256 rows -> LDS: given (reverse direction), or made here from the pass-A partials:
+    // U = need-th smallest sampled u' = -2 * (need-th largest g); tau = U + 2E + sqrt band 2^-21 (n0 + U + E) + rounding
+    // slop (y = tau/2 is folded into the MFMA accumulator); +inf when fewer than `need` columns were sampled
+    __shared__ float s_tau[LR_BLOCK_ROWS];
+    {
+        const int rw = (int)blockIdx.x * LR_BLOCK_ROWS + tid;
+        float tv = 0.0f;
+        if (tau) { if (rw < na) tv = tau[rw]; }
+        else {
+            __shared__ float s_m[4];
+            float mx = 0.0f;       // max_j n1_j of the column cloud from the per-block maxima of its prep kernel
+            for (int b = tid; b < thr.nblk_c; b += 256) mx = fmaxf(mx, thr.block_max_c[b]);
+#pragma unroll
+            for (int k = 32; k >= 1; k >>= 1) mx = fmaxf(mx, __shfl_xor(mx, k));
+            if (lane == 0) s_m[wave] = mx;
+            __syncthreads();
+            const float max_nc = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+            if (rw < na) {
+                float a1 = thr.pg1[rw], a2 = thr.pg2[rw];
+                for (int sidx = 1; sidx < thr.nstrips; ++sidx) {
+                    const float c1 = thr.pg1[(size_t)sidx * thr.part_stride + rw], c2 = thr.pg2[(size_t)sidx * thr.part_stride + rw];
+                    const float hi = fmaxf(a1, c1), lo = fminf(a1, c1);
+                    a2 = fmaxf(lo, fmaxf(a2, c2));
+                    a1 = hi;
+                }
+                const float U = -2.0f * (thr.need >= 2 ? a2 : a1);
+                const float scale = thr.nQ[rw] + max_nc;
+                const float E = 1.05e-3f * scale + 4e-7f;
+                tv = U + 2.0f * E + 6e-6f * scale + 2e-6f * fabsf(U);
+            }
+        }
+        s_tau[tid] = tv;
+        __syncthreads();
+    }
+
     f16x8 a[2][2];
     f32x16 y[2];
 #pragma unroll
@@ -321,9 +368,8 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         a[rb][0] = p[0]; a[rb][1] = p[1];
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
-            const int rw = row0 + 32 * rb + (g & 3) + 8 * (g >> 2) + 4 * h;
-            const float tv = tau[min(rw, na - 1)];
-            y[rb][g] = rw < na ? 0.5f * tv : -LR_INF;        // rows past the end never pass the test
+            const int lr = wave * 64 + 32 * rb + (g & 3) + 8 * (g >> 2) + 4 * h;
+            y[rb][g] = (int)blockIdx.x * LR_BLOCK_ROWS + lr < na ? 0.5f * s_tau[lr] : -LR_INF;        // rows past the end never pass the test
         }
     }
 
@@ -474,39 +520,6 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         }
         flush();
     }
-}
-
-// ------------------------------------------------------------------ thresholds
-// U = need-th smallest sampled u' = -2 * (need-th largest g)
-__global__ void __launch_bounds__(256)
-nn16_thresh_kernel(int na, int nstrips, int part_stride, const float *__restrict__ pg1, const float *__restrict__ pg2,
-                   const float *__restrict__ nQ, const float *__restrict__ block_max_c, int nblk_c, int need,
-                   float *__restrict__ tau, int32_t *__restrict__ cand_cnt)
-{
-    __shared__ float s_m[4];
-    const int row = blockIdx.x * blockDim.x + threadIdx.x;
-    // max_j n1_j of the column cloud from the per-block maxima of its prep kernel
-    float mx = 0.0f;
-    for (int b = threadIdx.x; b < nblk_c; b += 256) mx = fmaxf(mx, block_max_c[b]);
-#pragma unroll
-    for (int k = 32; k >= 1; k >>= 1) mx = fmaxf(mx, __shfl_xor(mx, k));
-    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = mx;
-    __syncthreads();
-    const float max_nc = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
-    if (row >= na) return;
-    float a1 = pg1[row], a2 = pg2[row];
-    for (int s = 1; s < nstrips; ++s) {
-        const float c1 = pg1[(size_t)s * part_stride + row], c2 = pg2[(size_t)s * part_stride + row];
-        const float hi = fmaxf(a1, c1), lo = fminf(a1, c1);
-        a2 = fmaxf(lo, fmaxf(a2, c2));
-        a1 = hi;
-    }
-    const float U = -2.0f * (need >= 2 ? a2 : a1);
-    const float scale = nQ[row] + max_nc;
-    const float E = 1.05e-3f * scale + 4e-7f;
-    // U + 2E + sqrt band 2^-21 (n0 + U + E) + rounding slop (this expression, y = tau/2 folded into the MFMA accumulator)
-    tau[row] = U + 2.0f * E + 6e-6f * scale + 2e-6f * fabsf(U);   // +inf when fewer than `need` columns were sampled
-    cand_cnt[row] = 0;
 }
 
 // ------------------------------------------------------------------ exact verification of the candidates
@@ -670,12 +683,12 @@ int lr_nn16_run(lr_workspace *ws, const float *Fq, const _Float16 *Hq, const flo
     if (strips < 1) strips = 1;
     const int tps = lr_cdiv(lr_cdiv(ntiles, strips), stride) * stride;     // tiles per strip, multiple of the stride
     dim3 grid(row_blocks, strips);
-    hipLaunchKernelGGL(nn16_passa_kernel, grid, dim3(256), 0, st, Hq, na, Hc, nC, nb, tps, stride, ws->max_n, ws->pb1, ws->pb2);
-    hipLaunchKernelGGL(nn16_thresh_kernel, dim3(lr_cdiv(na, 256)), dim3(256), 0, st, na, strips, ws->max_n, ws->pb1, ws->pb2, nQ,
-                       block_max_c, lr_cdiv(nb, 32), need, ws->tau, ws->cand_cnt);
+    hipLaunchKernelGGL(nn16_passa_kernel, grid, dim3(256), 0, st, Hq, na, Hc, nC, nb, tps, stride, ws->max_n, ws->pb1, ws->pb2, ws->cand_cnt);
     if (ws->timing && !ws->ev_pending) { LR_HIP(hipEventRecord(ws->ev[0], st)); }
+    lr_thr_in thr = { ws->pb1, ws->pb2, nQ, block_max_c, strips, ws->max_n, lr_cdiv(nb, 32), need };
     hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), 0, st, Hq, na, (const int32_t *)nullptr, (const int32_t *)nullptr, Hc, nC, nb,
-                       tps, ws->tau, ws->cand_cnt, ws->cand, (const int32_t *)nullptr, (const float *)nullptr, (const uint32_t *)nullptr);
+                       tps, (const float *)nullptr, ws->cand_cnt, ws->cand, (const int32_t *)nullptr, (const float *)nullptr,
+                       (const uint32_t *)nullptr, thr);
     if (ws->timing && !ws->ev_pending) { LR_HIP(hipEventRecord(ws->ev[1], st)); ws->ev_pending = 1; }
     hipLaunchKernelGGL(nn16_exact_kernel, dim3(lr_cdiv(na, 64)), dim3(256), 0, st, Fq, nQ, na, Fc, nC, nb, ws->cand_cnt, ws->cand,
                        need, (const int32_t *)nullptr, (const int32_t *)nullptr, idx1, idx2, s1, s2, ws->counters,
@@ -877,7 +890,7 @@ int lr_nn16_reverse(lr_workspace *ws, const float *F0, const _Float16 *H0, const
     if (timed) { LR_HIP(hipEventRecord(ws->ev[4], st)); }
     hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), 0, st, H1, na, (const int32_t *)ws->rev_rows, (const int32_t *)n_rows,
                        (const _Float16 *)ws->Hs, (const float *)ws->nrms, nb, tps, ws->tau, ws->cand_cnt, ws->cand,
-                       (const int32_t *)ws->rev_cols, (const float *)ws->rev_tmin, (const uint32_t *)seed);
+                       (const int32_t *)ws->rev_cols, (const float *)ws->rev_tmin, (const uint32_t *)seed, lr_thr_in{});
     if (timed) { LR_HIP(hipEventRecord(ws->ev[5], st)); ws->rev_recorded = 1; }
     hipLaunchKernelGGL(nn16_exact_kernel, dim3(lr_cdiv(na, 64)), dim3(256), 0, st, F1, nrm1, na, F0, nrm0, nb, ws->cand_cnt, ws->cand,
                        1, (const int32_t *)ws->rev_rows, (const int32_t *)n_rows, rev, (int32_t *)nullptr, (float *)nullptr, (float *)nullptr,

@@ -32,7 +32,7 @@ int main(int argc, char **argv)
     for (int stride : {1, 2, 4}) {
         int tps = ((ntiles + strips - 1) / strips + stride - 1) / stride * stride;
         dim3 grid(row_blocks, strips);
-        float ms = timeit([&] { hipLaunchKernelGGL(nn16_passa_kernel, grid, dim3(256), 0, 0, H, n, H, nrm, n, tps, stride, n, pu1, pu2); });
+        float ms = timeit([&] { hipLaunchKernelGGL(nn16_passa_kernel, grid, dim3(256), 0, 0, H, n, H, nrm, n, tps, stride, n, pu1, pu2, cnt); });
         printf("passA stride %d strips %d: %.3f ms\n", stride, strips, ms);
         {   // check: 2nd largest g of a few rows against a host computation over the same sampled columns
             std::vector<float> h1((size_t)n * strips), h2((size_t)n * strips);
@@ -52,12 +52,12 @@ int main(int argc, char **argv)
             }
         }
         // thresholds from this pass A, then pass B
-        hipLaunchKernelGGL(nn16_thresh_kernel, dim3((n+255)/256), dim3(256), 0, 0, n, strips, n, pu1, pu2, nrm, (const float*)bmax, (n+31)/32, 2, tau, cnt);
+        lr_thr_in thr = { pu1, pu2, nrm, bmax, strips, n, (n+31)/32, 2 };
         int tpsb = (ntiles + strips - 1) / strips;
-        float msp = timeit([&] { hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), 0, 0, H, n, (const int32_t*)nullptr, (const int32_t*)nullptr, H, nrm, n, tpsb, tau, cnt, cand, (const int32_t*)nullptr, (const float*)nullptr, (const uint32_t*)nullptr); });
+        float msp = timeit([&] { hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), 0, 0, H, n, (const int32_t*)nullptr, (const int32_t*)nullptr, H, nrm, n, tpsb, (const float*)nullptr, cnt, cand, (const int32_t*)nullptr, (const float*)nullptr, (const uint32_t*)nullptr, thr); });
         std::vector<int32_t> c1(n);
         hipMemset(cnt, 0, n*4);
-        hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), 0, 0, H, n, (const int32_t*)nullptr, (const int32_t*)nullptr, H, nrm, n, tpsb, tau, cnt, cand, (const int32_t*)nullptr, (const float*)nullptr, (const uint32_t*)nullptr);
+        hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), 0, 0, H, n, (const int32_t*)nullptr, (const int32_t*)nullptr, H, nrm, n, tpsb, (const float*)nullptr, cnt, cand, (const int32_t*)nullptr, (const float*)nullptr, (const uint32_t*)nullptr, thr);
         hipMemcpy(c1.data(), cnt, n*4, hipMemcpyDeviceToHost);
         double tot = 0; int mxc = 0;
         for (int i = 0; i < n; ++i) { tot += c1[i]; mxc = c1[i] > mxc ? c1[i] : mxc; }
@@ -67,7 +67,7 @@ int main(int argc, char **argv)
     {
         std::vector<float> t(n, -1e30f); hipMemcpy(tau, t.data(), n*4, hipMemcpyHostToDevice);
         int tpsb = (ntiles + strips - 1) / strips; dim3 grid(row_blocks, strips);
-        float msp = timeit([&] { hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), 0, 0, H, n, (const int32_t*)nullptr, (const int32_t*)nullptr, H, nrm, n, tpsb, tau, cnt, cand, (const int32_t*)nullptr, (const float*)nullptr, (const uint32_t*)nullptr); });
+        float msp = timeit([&] { hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), 0, 0, H, n, (const int32_t*)nullptr, (const int32_t*)nullptr, H, nrm, n, tpsb, (const float*)tau, cnt, cand, (const int32_t*)nullptr, (const float*)nullptr, (const uint32_t*)nullptr, lr_thr_in{}); });
         printf("passB no candidates: %.3f ms\n", msp);
     }
     return 0;
