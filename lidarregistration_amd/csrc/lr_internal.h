@@ -113,6 +113,7 @@ enum {
     LR_CNT_NREV,         // rows of the reverse NN pass (cloud-1 points some query points at)
     LR_CNT_RLO,          // smallest / largest forward NN distance of the pair (float bit patterns)
     LR_CNT_RHI,
+    LR_CNT_REFIT_TICKET, // blocks of the refit kernel that have finished (last-block-done; reset by the last block)
     LR_CNT_COUNT = 16,
     LR_CNT_TOTAL = 64        // counters[16..63] hold lr_ransac_state
 };

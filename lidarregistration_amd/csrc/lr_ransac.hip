@@ -385,15 +385,69 @@ int lr_ransac_run(lr_workspace *ws, const float *corr8, int m_max, const int32_t
     return LR_OK;
 }
 
+// sum of the block partials (fixed order) + Kabsch + result block; run by the block that finishes last
+__device__ void refit_solve_body(const double *__restrict__ partial, int nblocks, const double *__restrict__ T_in,
+                   const lr_ransac_result *__restrict__ gate, double *__restrict__ T_out, int32_t *__restrict__ n_inl,
+                   lr_pair_result *__restrict__ pair_out, const int32_t *__restrict__ counters, int weighted)
+{
+    __shared__ double mom[16];
+    __shared__ double stage[64 * 16];
+    // partials are summed in block order (reproducible); they are staged through LDS 64 blocks at a time so the
+    // 16 summing lanes do not walk a chain of dependent global loads
+    double acc = 0.0;
+    for (int b0 = 0; b0 < nblocks; b0 += 64) {
+        const int nb = min(64, nblocks - b0);
+        for (int t = threadIdx.x; t < nb * 16; t += blockDim.x) stage[t] = partial[(size_t)b0 * 16 + t];
+        __syncthreads();
+        if (threadIdx.x < 16)
+            for (int b = 0; b < nb; ++b) acc += stage[b * 16 + threadIdx.x];
+        __syncthreads();
+    }
+    if (threadIdx.x < 16) mom[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const bool have_model = gate ? gate->best_h >= 0 : true;
+    const double n = mom[0];
+    double T[16];
+    int n_used;
+    if (!have_model || !(n > 0.0) || (!weighted && n < 3.0)) {
+        for (int k = 0; k < 16; ++k) T[k] = T_in[k];
+        n_used = have_model ? (int)n : 0;
+    } else {
+        double cp[3], cq[3], H[3][3];
+        for (int a = 0; a < 3; ++a) { cp[a] = mom[1 + a] / n; cq[a] = mom[4 + a] / n; }
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) H[a][b] = mom[7 + 3 * a + b] - (n * cp[a]) * cq[b];
+        lr_rt_from_cov(H, cp, cq, T);
+        n_used = (int)n;
+    }
+    for (int k = 0; k < 16; ++k) T_out[k] = T[k];
+    if (n_inl) *n_inl = n_used;
+    if (pair_out) {          // result block of lr_register_pair (fused: saves a launch)
+        for (int k = 0; k < 16; ++k) { pair_out->T[k] = T[k]; pair_out->T_ransac[k] = T_in[k]; }
+        pair_out->ransac = *gate;
+        pair_out->n_corr = counters[LR_CNT_NCORR];
+        pair_out->n_refit = n_used;
+        pair_out->n_nn_fixed = counters[LR_CNT_FIX_TOTAL];
+        pair_out->status = gate->best_h < 0 ? 1 : 0;
+        for (int q = 0; q < 8; ++q) pair_out->reserved[q] = 0;
+        for (int k = 0; k < 16; ++k) pair_out->T_icp[k] = T[k];      // overwritten by pair_icp_kernel when the ICP stage runs
+        pair_out->icp.fitness = 0.0; pair_out->icp.inlier_rmse = 0.0; pair_out->icp.n_corr = 0; pair_out->icp.iterations = 0;
+    }
+}
+
 // ------------------------------------------------------------------ refit (FR.py:99-111)
 // partial[b][0] = n, [1..3] = sum p, [4..6] = sum q, [7..15] = sum p q^T over the inliers of block b
 __global__ void __launch_bounds__(256)
 refit_moments_kernel(const float *__restrict__ xyz0, int n0, const float *__restrict__ xyz1, const int32_t *__restrict__ idx1,
                      const double *__restrict__ T_in, double thr2, double *__restrict__ partial,
                      const int32_t *__restrict__ idx0, const int32_t *__restrict__ m_dev,
-                     const float *__restrict__ F0, const float *__restrict__ F1)
+                     const float *__restrict__ F0, const float *__restrict__ F1,
+                     int32_t *__restrict__ ticket, const lr_ransac_result *__restrict__ gate, double *__restrict__ T_out,
+                     int32_t *__restrict__ n_inl, lr_pair_result *__restrict__ pair_out, const int32_t *__restrict__ counters)
 {
     __shared__ double sm[4][16];
+    __shared__ int s_last;
     double T[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) T[k] = T_in[k];
@@ -443,57 +497,23 @@ refit_moments_kernel(const float *__restrict__ xyz0, int n0, const float *__rest
     __syncthreads();
     if (threadIdx.x < 16)
         partial[(size_t)blockIdx.x * 16 + threadIdx.x] = ((sm[0][threadIdx.x] + sm[1][threadIdx.x]) + sm[2][threadIdx.x]) + sm[3][threadIdx.x];
-}
-
-__global__ void __launch_bounds__(64)
-refit_solve_kernel(const double *__restrict__ partial, int nblocks, const double *__restrict__ T_in,
-                   const lr_ransac_result *__restrict__ gate, double *__restrict__ T_out, int32_t *__restrict__ n_inl,
-                   lr_pair_result *__restrict__ pair_out, const int32_t *__restrict__ counters, int weighted)
-{
-    __shared__ double mom[16];
-    __shared__ double stage[64 * 16];
-    // partials are summed in block order (reproducible); they are staged through LDS 64 blocks at a time so the
-    // 16 summing lanes do not walk a chain of dependent global loads
-    double acc = 0.0;
-    for (int b0 = 0; b0 < nblocks; b0 += 64) {
-        const int nb = min(64, nblocks - b0);
-        for (int t = threadIdx.x; t < nb * 16; t += 64) stage[t] = partial[(size_t)b0 * 16 + t];
-        __syncthreads();
-        if (threadIdx.x < 16)
-            for (int b = 0; b < nb; ++b) acc += stage[b * 16 + threadIdx.x];
-        __syncthreads();
-    }
-    if (threadIdx.x < 16) mom[threadIdx.x] = acc;
+    // ---- last block done: agent-scope release of the partials, ticket, acquire, then the solve (saves a launch)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x != 0) return;
-    const bool have_model = gate ? gate->best_h >= 0 : true;
-    const double n = mom[0];
-    double T[16];
-    int n_used;
-    if (!have_model || !(n > 0.0) || (!weighted && n < 3.0)) {
-        for (int k = 0; k < 16; ++k) T[k] = T_in[k];
-        n_used = have_model ? (int)n : 0;
-    } else {
-        double cp[3], cq[3], H[3][3];
-        for (int a = 0; a < 3; ++a) { cp[a] = mom[1 + a] / n; cq[a] = mom[4 + a] / n; }
-        for (int a = 0; a < 3; ++a)
-            for (int b = 0; b < 3; ++b) H[a][b] = mom[7 + 3 * a + b] - (n * cp[a]) * cq[b];
-        lr_rt_from_cov(H, cp, cq, T);
-        n_used = (int)n;
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == (int)gridDim.x - 1);
+        if (s_last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next call
+        }
     }
-    for (int k = 0; k < 16; ++k) T_out[k] = T[k];
-    if (n_inl) *n_inl = n_used;
-    if (pair_out) {          // result block of lr_register_pair (fused: saves a launch)
-        for (int k = 0; k < 16; ++k) { pair_out->T[k] = T[k]; pair_out->T_ransac[k] = T_in[k]; }
-        pair_out->ransac = *gate;
-        pair_out->n_corr = counters[LR_CNT_NCORR];
-        pair_out->n_refit = n_used;
-        pair_out->n_nn_fixed = counters[LR_CNT_FIX_TOTAL];
-        pair_out->status = gate->best_h < 0 ? 1 : 0;
-        for (int q = 0; q < 8; ++q) pair_out->reserved[q] = 0;
-        for (int k = 0; k < 16; ++k) pair_out->T_icp[k] = T[k];      // overwritten by pair_icp_kernel when the ICP stage runs
-        pair_out->icp.fitness = 0.0; pair_out->icp.inlier_rmse = 0.0; pair_out->icp.n_corr = 0; pair_out->icp.iterations = 0;
-    }
+    __syncthreads();
+    if (!s_last) return;
+    refit_solve_body(partial, (int)gridDim.x, T_in, gate, T_out, n_inl, pair_out, counters, F0 ? 1 : 0);
 }
 
 int lr_refit_run(lr_workspace *ws, const float *xyz0, int n0, const float *xyz1, const int32_t *idx1,
@@ -502,10 +522,10 @@ int lr_refit_run(lr_workspace *ws, const float *xyz0, int n0, const float *xyz1,
                  const float *F0, const float *F1)
 {
     const int nb = lr_cdiv(n0, 256);
+    int32_t *ticket = ws->counters + LR_CNT_REFIT_TICKET;
+    if (!pair_out) LR_HIP(hipMemsetAsync(ticket, 0, sizeof(int32_t), st));      // lr_register_pair starts from cleared counters
     hipLaunchKernelGGL(refit_moments_kernel, dim3(nb), dim3(256), 0, st, xyz0, n0, xyz1, idx1, T_in, thr2, ws->refit_part, idx0, m_dev,
-                       F0, F1);
-    hipLaunchKernelGGL(refit_solve_kernel, dim3(1), dim3(64), 0, st, ws->refit_part, nb, T_in, gate, T_out, n_inl, pair_out, ws->counters,
-                       F0 ? 1 : 0);
+                       F0, F1, ticket, gate, T_out, n_inl, pair_out, (const int32_t *)ws->counters);
     LR_LAUNCH_CHECK();
     return LR_OK;
 }
