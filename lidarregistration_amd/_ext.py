@@ -75,6 +75,9 @@ def lib():
             raise LidarRegError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        # torch ships its own libamdhip64; it must be in the process before this library is, so that both use the same
+        # HIP runtime (loaded the other way round, the library binds to a second runtime that sees no device)
+        import torch  # noqa: F401
         try:
             L = ctypes.CDLL(LIB_PATH)
         except OSError as e:
