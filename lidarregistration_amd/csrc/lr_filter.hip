@@ -407,6 +407,42 @@ gpf_score_cell_kernel(int n0, int G, const uint32_t *__restrict__ mm, const uint
     for (int k = threadIdx.x; k < C; k += 256) if (s_cnt[k]) atomicAdd(&cell_count[k], s_cnt[k]);
 }
 
+// numpy's pairwise_sum (umath loops, float64, contiguous) over v[i] = m[i] < h ? m[i] : h.  The leaf (n <= 128, i.e.
+// every grid up to 11 x 11) is inlined into the bisection loop; larger grids take the recursive split through a call.
+__device__ __forceinline__ double gpf_pairwise_leaf(const double *m, int n, double h)
+{
+    if (n < 8) {
+        double res = 0.0;
+        for (int i = 0; i < n; ++i) res += (m[i] < h) ? m[i] : h;
+        return res;
+    }
+    double r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (m[j] < h) ? m[j] : h;
+    int i = 8;
+    for (; i < n - (n % 8); i += 8) {
+        double v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = m[i + j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] += (v[j] < h) ? v[j] : h;
+    }
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += (m[i] < h) ? m[i] : h;
+    return res;
+}
+__device__ __noinline__ double gpf_pairwise_split(const double *m, int n, double h)
+{
+    if (n <= 128) return gpf_pairwise_leaf(m, n, h);
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return gpf_pairwise_split(m, n2, h) + gpf_pairwise_split(m + n2, n - n2, h);
+}
+__device__ __forceinline__ double gpf_pairwise_sum(const double *m, int n, double h)
+{
+    return n <= 128 ? gpf_pairwise_leaf(m, n, h) : gpf_pairwise_split(m, n, h);
+}
+
 // water-filling bisection in fp64 exactly as matching.py:154-179, then exclusive cell offsets.  One thread does the
 // arithmetic (the sums run in cell order, which fixes their rounding), on a copy of the counts in LDS.
 // total_fixed >= 0 selects the BB_first=True form: TOTAL = GPF_max_matches, and nothing is filtered (has_score = 0) when
@@ -418,53 +454,70 @@ gpf_waterfill_kernel(int G, double factor, const int32_t *__restrict__ counters,
                      const int32_t *__restrict__ m_dev = nullptr, int32_t *__restrict__ has_score = nullptr)
 {
     __shared__ double s_m[LR_GPF_MAX_CELLS];
+    __shared__ double s_hr;
     const int C = G * G;
     for (int c = threadIdx.x; c < C; c += 64) s_m[c] = (double)cell_count[c];
     __syncthreads();
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const double TOTAL = total_fixed >= 0.0 ? total_fixed : factor * (double)counters[LR_CNT_NBB];
-    if (total_fixed >= 0.0) {
-        const bool keep_all = TOTAL >= (double)*m_dev;
-        if (has_score) *has_score = keep_all ? 0 : 1;
-        if (keep_all) {
-            int off = 0;
-            for (int c = 0; c < C; ++c) { quota[c] = s_m[c]; cell_off[c] = off; off += (int)s_m[c]; }
-            cell_off[C] = off;
-            return;
+    // the bisection: every lane runs the same loop.  per_quad.sum() of matching.py:169 is numpy's pairwise summation over
+    // the flattened [G, G] float64 array; its order (eight running sums, fixed combination tree, blocks of at most 128
+    // elements split recursively) is part of the result whenever the sum rounds, and it is reproduced exactly: for up to
+    // 128 cells lanes 0..7 own the eight running sums and the tree is three shuffles; larger grids fall back to one lane.
+    const int lane = threadIdx.x;
+    auto total_at = [&](double h) -> double {
+        if (C < 8 || C > 128) {
+            double t = 0.0;
+            if (lane == 0) t = gpf_pairwise_sum(s_m, C, h);
+            return __shfl(t, 0);
         }
-    }
-    // the adds stay in cell order (their rounding is part of the result); the LDS reads of eight cells are issued
-    // together so that the chain only waits for the adds
-    auto total_at = [&](double h) {
-        double s = 0.0;
-        int c = 0;
-        for (; c + 8 <= C; c += 8) {
-            double m[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) m[k] = s_m[c + k];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) s += (m[k] < h) ? m[k] : h;
+        const int full = C - (C % 8);
+        double r = 0.0;
+        if (lane < 8) {
+            const double m0 = s_m[lane];
+            r = (m0 < h) ? m0 : h;
+            for (int i = 8 + lane; i < full; i += 8) { const double m = s_m[i]; r += (m < h) ? m : h; }
         }
-        for (; c < C; ++c) { double m = s_m[c]; s += (m < h) ? m : h; }
-        return s;
+        r = r + __shfl_down(r, 1);      // (r0+r1) (r2+r3) (r4+r5) (r6+r7) in lanes 0 2 4 6
+        r = r + __shfl_down(r, 2);      // ((r0+r1)+(r2+r3)) in lane 0, ((r4+r5)+(r6+r7)) in lane 4
+        r = r + __shfl_down(r, 4);
+        if (lane == 0) for (int i = full; i < C; ++i) { const double m = s_m[i]; r += (m < h) ? m : h; }
+        return __shfl(r, 0);
     };
-    double max_h = TOTAL, min_h = 0.0, cur = (max_h + min_h) / 2;
-    while (fabs(max_h - min_h) > 2) {
-        double t = total_at(cur);
-        if (t == TOTAL) break;
-        else if (t < TOTAL) min_h = cur;
-        else if (t > TOTAL) max_h = cur;
-        cur = (max_h + min_h) / 2;
+    {
+        const double TOTAL = total_fixed >= 0.0 ? total_fixed : factor * (double)counters[LR_CNT_NBB];
+        bool keep_all = false;
+        if (total_fixed >= 0.0) {
+            keep_all = TOTAL >= (double)*m_dev;
+            if (has_score && lane == 0) *has_score = keep_all ? 0 : 1;
+        }
+        double hr_v = __builtin_huge_val();      // +inf = keep every pair
+        if (!keep_all) {
+            double max_h = TOTAL, min_h = 0.0, cur = (max_h + min_h) / 2;
+            while (fabs(max_h - min_h) > 2) {
+                double t = total_at(cur);
+                if (t == TOTAL) break;
+                else if (t < TOTAL) min_h = cur;
+                else if (t > TOTAL) max_h = cur;
+                cur = (max_h + min_h) / 2;
+            }
+            hr_v = rint(cur);                          // np.round: half to even
+        }
+        if (lane == 0) s_hr = hr_v;
     }
-    const double hr = rint(cur);                      // np.round: half to even
-    int off = 0;
-    for (int c = 0; c < C; ++c) {
-        double m = s_m[c];
-        quota[c] = (m < hr) ? m : hr;
-        cell_off[c] = off;
-        off += (int)m;
+    __syncthreads();
+    // all lanes: quotas and the exclusive cell offsets (a wave-wide scan, 64 cells at a time)
+    const double hr = s_hr;
+    int carry = 0;
+    for (int c0 = 0; c0 < C; c0 += 64) {
+        const int c = c0 + threadIdx.x;
+        const double m = c < C ? s_m[c] : 0.0;
+        if (c < C) quota[c] = (m < hr) ? m : hr;
+        int inc = (int)m;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if ((int)threadIdx.x >= d) inc += o; }
+        if (c < C) cell_off[c] = carry + inc - (int)m;
+        carry += __shfl(inc, 63);
     }
-    cell_off[C] = off;
+    if (threadIdx.x == 0) cell_off[C] = carry;
 }
 
 // bucket pair ids by cell (order inside a bucket is irrelevant: ranks below use (score, id)): ranks inside the block

@@ -191,7 +191,7 @@ def test_gpf_bb_first_golden(lr, filt, k):
         np.testing.assert_allclose(out[6].cpu().numpy(), g[f"gpfbb{k}_score"], rtol=0, atol=3e-6)
 
 
-@pytest.mark.parametrize("factor,wid,seed", [(0.3, 10, 41), (0.05, 3, 42), (1.5, 16, 43)])
+@pytest.mark.parametrize("factor,wid,seed", [(0.3, 10, 41), (0.05, 3, 42), (1.5, 16, 43), (0.37, 64, 44), (1.0 / 3.0, 23, 45), (0.7, 2, 46)])
 def test_gpf_vs_oracle(lr, oracle, factor, wid, seed):
     n0, n1 = 4000, 3500
     F0, F1 = synth.make_features(n0, n1, 32, 0.5, 1.0, seed)
