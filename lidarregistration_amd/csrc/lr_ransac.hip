@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(256)
 ransac_gen_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__restrict__ m_dev, lr_ransac_params p,
                   int h_begin, int h_end, float *__restrict__ models, double *__restrict__ models64, int32_t *__restrict__ model_h,
                   uint32_t *__restrict__ score_cnt, unsigned long long *__restrict__ score_ssq,
-                  int32_t *__restrict__ counters, const int32_t *__restrict__ G, int TN)
+                  int32_t *__restrict__ counters, const int32_t *__restrict__ G, int TN, int model_stride)
 {
     __shared__ int s_pass[256];
     __shared__ int s_np, s_base;
@@ -185,7 +185,9 @@ ransac_gen_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__r
     kabsch_sample<NS>(P, Q, T);
     const int slot = s_base + threadIdx.x;
 #pragma unroll
-    for (int k = 0; k < 12; ++k) { models[(size_t)slot * 12 + k] = (float)T[k]; models64[(size_t)slot * 12 + k] = T[k]; }
+    // fp32 models component-major ([12][model_stride]: the scoring kernel's 64 lanes read 64 consecutive floats per
+    // component), fp64 models row-major (only the winner is ever read back)
+    for (int k = 0; k < 12; ++k) { models[(size_t)k * model_stride + slot] = (float)T[k]; models64[(size_t)slot * 12 + k] = T[k]; }
     model_h[slot] = hh;
     score_cnt[slot] = 0u;
     score_ssq[slot] = 0ull;
@@ -199,7 +201,7 @@ ransac_gen_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__r
 __global__ void __launch_bounds__(64)
 ransac_score_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__restrict__ m_dev, float thr2,
                     const float *__restrict__ models, uint32_t *__restrict__ score_cnt,
-                    unsigned long long *__restrict__ score_ssq, const int32_t *__restrict__ counters, int sub)
+                    unsigned long long *__restrict__ score_ssq, const int32_t *__restrict__ counters, int sub, int model_stride)
 {
     const int m = m_dev ? min(*m_dev, m_max) : m_max;
     const int V = counters[LR_CNT_NVALID];
@@ -215,10 +217,11 @@ ransac_score_kernel(const float *__restrict__ corr8, int m_max, const int32_t *_
         const int g = w % hb, c = w / hb;
         const int slot = g * 64 + lane;
         const bool active = slot < V;
-        const float *mp = models + (size_t)(active ? slot : 0) * 12;
-        const float r00 = mp[0], r01 = mp[1], r02 = mp[2], tx = mp[3];
-        const float r10 = mp[4], r11 = mp[5], r12 = mp[6], ty = mp[7];
-        const float r20 = mp[8], r21 = mp[9], r22 = mp[10], tz = mp[11];
+        const float *mp = models + (active ? slot : 0);
+        const size_t ms = (size_t)model_stride;
+        const float r00 = mp[0], r01 = mp[ms], r02 = mp[2 * ms], tx = mp[3 * ms];
+        const float r10 = mp[4 * ms], r11 = mp[5 * ms], r12 = mp[6 * ms], ty = mp[7 * ms];
+        const float r20 = mp[8 * ms], r21 = mp[9 * ms], r22 = mp[10 * ms], tz = mp[11 * ms];
         const int begin = c * per, end = min(m, begin + per);
         uint32_t cnt = 0;
         unsigned long long ssq = 0;
@@ -234,7 +237,7 @@ ransac_score_kernel(const float *__restrict__ corr8, int m_max, const int32_t *_
         for (int b0 = begin; b0 < pend; b0 += sub) {
             const int b1 = min(pend, b0 + sub);
             uint32_t q32 = 0;
-#pragma unroll 2
+#pragma unroll 4
             for (int i = b0; i < b1; i += 2) {
                 const f32x2 *q = rec + (size_t)(i >> 1) * 8;
                 const f32x2 px = q[0], py = q[1], pz = q[2], qx = q[3], qy = q[4], qz = q[5];
@@ -371,12 +374,12 @@ int lr_ransac_run(lr_workspace *ws, const float *corr8, int m_max, const int32_t
         const int gb = lr_cdiv(h1 - h0 > 0 ? h1 - h0 : 1, 256);
         if (p->sample_size == 3)
             hipLaunchKernelGGL(ransac_gen_kernel<3>, dim3(gb), dim3(256), 0, st, corr8, m_max, m_dev, *p, h0, h1, ws->models, ws->models64,
-                               ws->model_h, ws->score_cnt, ws->score_ssq, ws->counters, G, TN);
+                               ws->model_h, ws->score_cnt, ws->score_ssq, ws->counters, G, TN, ws->max_iters);
         else
             hipLaunchKernelGGL(ransac_gen_kernel<4>, dim3(gb), dim3(256), 0, st, corr8, m_max, m_dev, *p, h0, h1, ws->models, ws->models64,
-                               ws->model_h, ws->score_cnt, ws->score_ssq, ws->counters, G, TN);
+                               ws->model_h, ws->score_cnt, ws->score_ssq, ws->counters, G, TN, ws->max_iters);
         hipLaunchKernelGGL(ransac_score_kernel, dim3(LR_SCORE_BLOCKS), dim3(64), 0, st, corr8, m_max, m_dev, p->thr2, ws->models,
-                           ws->score_cnt, ws->score_ssq, ws->counters, sub);
+                           ws->score_cnt, ws->score_ssq, ws->counters, sub, ws->max_iters);
         if (h0 == 0 && ws->timing && ws->ev_pending == 1) { LR_HIP(hipEventRecord(ws->ev[3], st)); ws->ev_pending = 2; }
         hipLaunchKernelGGL(ransac_final_kernel, dim3(1), dim3(1024), 0, st, ws->score_cnt, ws->score_ssq, ws->model_h, ws->models64,
                            ws->counters, m_max, m_dev, *p, h1, T_out, res);
