@@ -100,6 +100,8 @@ extern "C" int lr_workspace_create(lr_workspace **out, int max_n0, int max_n1, i
         const char *b = getenv("LIDARREG_NN_BLOCKS");      // tuning knob: blocks per filter pass (default 512 = 2 per CU; measured best with many pairs in flight)
         ws->nn_blocks_target = b ? atoi(b) : 512;
         if (ws->nn_blocks_target < 1) ws->nn_blocks_target = 1;
+        const char *sa = getenv("LIDARREG_NN_SECOND");
+        ws->nn_second_auto = (sa && strcmp(sa, "auto") == 0) ? 1 : 0;
     }
     Carver sizing;
     carve(ws, sizing);
@@ -210,7 +212,7 @@ static int nn_forward(lr_workspace *ws, const float *F0, int n0, const float *F1
     if (ws->nn_path == LR_NN_PATH_FP32_MFMA)
         return lr_nn_run(ws, ws->Fp0, ws->nrm0, n0, ws->Fp1, ws->nrm1, n1, idx1, idx2, s1, s2, st);
     return lr_nn16_run(ws, F0, ws->H0, ws->nrm0, n0, F1, ws->H1, ws->nrm1, ws->bmax1, n1,
-                       2, idx1, idx2, s1, s2, st, seed_reverse);
+                       idx2 ? 2 : 1, idx1, idx2, s1, idx2 ? s2 : nullptr, st, seed_reverse);
 }
 
 // reverse: rows of cloud 1 against cloud 0 (first NN only).  The reference restricts it to the unique forward
@@ -350,15 +352,21 @@ extern "C" int lr_register_pair(lr_workspace *ws, const float *xyz0, const float
     // 1. coarse correspondences (FR.py:38): first + second NN of every cloud-0 descriptor
     LR_TRY(prep_both(ws, F0, n0, F1, n1, st, true));
     const bool fuse_seed = p->mode != LR_MODE_NO_FILTER && ws->nn_path != LR_NN_PATH_FP32_MFMA;   // the forward exact kernel seeds the reverse pass
-    LR_TRY(nn_forward(ws, F0, n0, F1, n1, ws->nn_idx1, ws->nn_idx2, ws->nn_s1, ws->nn_s2, st, fuse_seed));
+    // The second neighbour (find_2nn, FR.py:38) feeds the feature-distance ratio only: GPF (matching.py:116) and the PROSAC
+    // quality (FR.py:77).  By default it is computed as the reference does; with LIDARREG_NN_SECOND=auto it is left out when
+    // no stage of this call reads it (plain mutual-NN / no filter with uniform sampling): the outputs are the same, the
+    // candidate lists of the forward pass are half as long.
+    const bool want2 = !(ws->nn_second_auto && ws->nn_path != LR_NN_PATH_FP32_MFMA && p->mode != LR_MODE_GPF && p->ransac.sampler == 0);
+    int32_t *idx2 = want2 ? ws->nn_idx2 : nullptr;
+    LR_TRY(nn_forward(ws, F0, n0, F1, n1, ws->nn_idx1, idx2, ws->nn_s1, ws->nn_s2, st, fuse_seed));
     // 2. filter (FR.py:48-56)
     if (p->mode == LR_MODE_NO_FILTER) {
-        LR_TRY(lr_identity_corr(ws, n0, ws->nn_idx1, ws->nn_idx2, ws->corr_idx0, ws->corr_idx1, ws->corr_idx2, m_dev, st));
+        LR_TRY(lr_identity_corr(ws, n0, ws->nn_idx1, idx2, ws->corr_idx0, ws->corr_idx1, idx2 ? ws->corr_idx2 : nullptr, m_dev, st));
     } else {
         LR_TRY(nn_reverse(ws, F0, n0, F1, n1, ws->nn_idx1, ws->rev_idx1, st, fuse_seed));
         if (p->mode == LR_MODE_MNN) {
-            LR_TRY(lr_mutual_run(ws, n0, ws->nn_idx1, ws->nn_idx2, ws->rev_idx1, ws->is_bb, ws->corr_idx0, ws->corr_idx1,
-                                 ws->corr_idx2, m_dev, st, xyz0, xyz1, ws->corr8));
+            LR_TRY(lr_mutual_run(ws, n0, ws->nn_idx1, idx2, ws->rev_idx1, ws->is_bb, ws->corr_idx0, ws->corr_idx1,
+                                 idx2 ? ws->corr_idx2 : nullptr, m_dev, st, xyz0, xyz1, ws->corr8));
         } else {
             LR_TRY(lr_mutual_run(ws, n0, ws->nn_idx1, nullptr, ws->rev_idx1, ws->is_bb, nullptr, nullptr, nullptr, nullptr, st));
             LR_TRY(lr_gpf_run(ws, F0, n0, F1, dim, ws->nn_idx1, ws->nn_idx2, ws->is_bb, xyz0, p->gpf_grid_wid, p->gpf_factor,
