@@ -385,6 +385,28 @@ def test_nn_tiny_clouds(lr, oracle, n0, n1):
     assert np.array_equal(_bits(s1.cpu().numpy()), _bits(os1))
 
 
+@pytest.mark.parametrize("mode", ["MNN", "no_filter", "GPF"])
+def test_second_neighbour_auto_mode_gives_the_same_pair_result(lr, oracle, monkeypatch, mode):
+    """LIDARREG_NN_SECOND=auto drops the second neighbour where no stage reads it; the result block must not change."""
+    from lidarregistration_amd import _ext
+    p = synth.make_pair(N=4000, rho=0.5, s=0.9, seed=71, clustered=(mode == "GPF"))
+    a = Args(mode=mode, codebase="open3D", iters=1500, GPF_factor=0.5)
+    params = lr.FR.pair_params(a)
+    t = lr.torch.from_numpy
+    dev = [t(p[k]).cuda() for k in ("xyz0", "xyz1", "feats0", "feats1")]
+    blocks = []
+    for env in (None, "auto"):
+        if env:
+            monkeypatch.setenv("LIDARREG_NN_SECOND", env)
+        ws = _ext.Workspace(4000, 4000, 32, 1500)
+        ws.poison(0xA5)
+        out = lr.FR.register_pair_dev(*dev, params, ws=ws)
+        r = lr.FR.read_result(out)
+        blocks.append((np.array(r.T[:]), r.n_corr, r.ransac.best_h, r.ransac.best_count, r.n_refit))
+        ws.close()
+    assert np.array_equal(blocks[0][0], blocks[1][0]) and blocks[0][1:] == blocks[1][1:]
+
+
 def test_fp32_mfma_path_agrees(lr, oracle, monkeypatch):
     # the exact fp32-MFMA kernel (LIDARREG_NN_PATH=fp32) stays available and must give the same answers
     import ctypes
