@@ -8,8 +8,12 @@
 //   pass A  f16 MFMA (32x32x16, the real matrix pipe) over every `stride`-th column tile; per query row the
 //           2nd smallest (1st for top-1) approximate value u' = n1[j] - 2 dot16(i,j) of that subset: U_i
 //   thresh  tau_i = U_i + 2 E_i (+ a sqrt-rounding band), E_i a rigorous bound on |d2_exact - (n0_i + u')|
-//   pass B  f16 MFMA over ALL column tiles; a column is a candidate of row i iff u' <= tau_i
-//           (2 VALU ops per element: one fma, one compare; candidates are ~1e-4 of the elements)
+//           (computed in pass B's prologue for the block's own rows)
+//   pass B  f16 MFMA over ALL column tiles; a column is a candidate of row i iff u' <= tau_i.  The accumulator starts
+//           at tau_i/2, so the test is "largest of 8 accumulator registers >= n1[j]/2": 5 VALU ops per 512 elements,
+//           placed in the shadow of the next tile's MFMAs; candidates are ~3e-4 of the elements
+//   reverse (mutual filter) thresholds from the forward result, rows / columns ordered by forward NN distance so that
+//           each row block walks only a prefix of the column tiles (lr_nn16_reverse)
 //   exact   per row, the fp32 fma-chain distance of its few candidates, ordered by (sqrt value, index) --
 //           this is exactly torch.min's "first minimal value" order, so no separate tie-break path is needed;
 //           rows whose candidate list overflowed (duplicate-heavy inputs) or could not be filled (non-finite
