@@ -527,9 +527,10 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
 }
 
 // ------------------------------------------------------------------ exact verification of the candidates
-// Four lanes per row: lane q takes the candidate slots q, q+4, ...; the four partial (first, second) pairs are
-// merged under the (sqrt value, index) order with two shuffles.  Rows with an overflowing or too-short candidate list
+// LR_EX_LANES (4; 8 measured slower: every lane reloads the query row) lanes per row: lane q takes the candidate slots q, q+4, ...; the partial (first, second) pairs are
+// merged under the (sqrt value, index) order with log2(lanes) shuffles.  Rows with an overflowing or too-short candidate list
 // are re-done by a full exact scan of all columns, in place.
+#define LR_EX_LANES 4
 __device__ __forceinline__ bool sj_lt(float a, int ia, float b, int ib) { return a < b || (a == b && ia < ib); }
 
 __global__ void __launch_bounds__(256)
@@ -543,9 +544,9 @@ nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, in
 {
     __shared__ float s_lo[4], s_hi[4];
     const int gid = blockIdx.x * 256 + threadIdx.x;
-    const int row = gid >> 2, q = gid & 3;
+    const int row = gid / LR_EX_LANES, q = gid % LR_EX_LANES;
     if (na_dev) na = *na_dev;                  // compacted row list (reverse direction): lists by position, data by rowmap[]
-    if ((int)blockIdx.x * 64 >= na) return;
+    if ((int)blockIdx.x * (256 / LR_EX_LANES) >= na) return;
     const bool live = row < na;
     const int rowc = live ? row : na - 1;
     const int rowd = rowmap ? rowmap[rowc] : rowc;
@@ -571,14 +572,14 @@ nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, in
         for (int k = 0; k < 8; ++k) tn[k] = pb[k];
         nn = nC[jn];
     }
-    for (int c = q; c < ncand; c += 4) {
+    for (int c = q; c < ncand; c += LR_EX_LANES) {
         const int j = jn;
         f32x4 t[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) t[k] = tn[k];
         const float ncj = nn;
-        if (c + 4 < ncand) {
-            jn = cand[(size_t)rowc * LR_NN16_CAP + c + 4];
+        if (c + LR_EX_LANES < ncand) {
+            jn = cand[(size_t)rowc * LR_NN16_CAP + c + LR_EX_LANES];
             const f32x4 *pb = reinterpret_cast<const f32x4 *>(Fc + (size_t)jn * 32);
 #pragma unroll
             for (int k = 0; k < 8; ++k) tn[k] = pb[k];
@@ -603,7 +604,7 @@ nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, in
         // candidate list overflowed (duplicate-heavy input) or could not be filled (non-finite f16 values): the four
         // lanes of the row scan every column exactly -- slow, rare, and by construction the reference answer
         b1 = LR_INF; b2 = LR_INF; i1 = LR_IMAX; i2 = LR_IMAX;
-        for (int j = q; j < nb; j += 4) {
+        for (int j = q; j < nb; j += LR_EX_LANES) {
             const f32x4 *pb = reinterpret_cast<const f32x4 *>(Fc + (size_t)j * 32);
             float acc = 0.0f;
 #pragma unroll
@@ -623,7 +624,7 @@ nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, in
         if (q == 0 && live) atomicAdd(&counters[LR_CNT_FIX_TOTAL], 1);
     }
 #pragma unroll
-    for (int m = 1; m <= 2; m <<= 1) {
+    for (int m = 1; m < LR_EX_LANES; m <<= 1) {
         const float c1 = __shfl_xor(b1, m), c2 = __shfl_xor(b2, m);
         const int j1 = __shfl_xor(i1, m), j2 = __shfl_xor(i2, m);
         const bool cf = sj_lt(c1, j1, b1, i1);
@@ -694,7 +695,7 @@ int lr_nn16_run(lr_workspace *ws, const float *Fq, const _Float16 *Hq, const flo
                        tps, (const float *)nullptr, ws->cand_cnt, ws->cand, (const int32_t *)nullptr, (const float *)nullptr,
                        (const uint32_t *)nullptr, thr);
     if (ws->timing && !ws->ev_pending) { LR_HIP(hipEventRecord(ws->ev[1], st)); ws->ev_pending = 1; }
-    hipLaunchKernelGGL(nn16_exact_kernel, dim3(lr_cdiv(na, 64)), dim3(256), 0, st, Fq, nQ, na, Fc, nC, nb, ws->cand_cnt, ws->cand,
+    hipLaunchKernelGGL(nn16_exact_kernel, dim3(lr_cdiv(na, 256 / LR_EX_LANES)), dim3(256), 0, st, Fq, nQ, na, Fc, nC, nb, ws->cand_cnt, ws->cand,
                        need, (const int32_t *)nullptr, (const int32_t *)nullptr, idx1, idx2, s1, s2, ws->counters,
                        seed_reverse ? ws->rev_seed : (uint32_t *)nullptr, ws->rev_s1, reinterpret_cast<uint32_t *>(ws->counters + LR_CNT_RLO));
     LR_LAUNCH_CHECK();
@@ -896,7 +897,7 @@ int lr_nn16_reverse(lr_workspace *ws, const float *F0, const _Float16 *H0, const
                        (const _Float16 *)ws->Hs, (const float *)ws->nrms, nb, tps, ws->tau, ws->cand_cnt, ws->cand,
                        (const int32_t *)ws->rev_cols, (const float *)ws->rev_tmin, (const uint32_t *)seed, lr_thr_in{});
     if (timed) { LR_HIP(hipEventRecord(ws->ev[5], st)); ws->rev_recorded = 1; }
-    hipLaunchKernelGGL(nn16_exact_kernel, dim3(lr_cdiv(na, 64)), dim3(256), 0, st, F1, nrm1, na, F0, nrm0, nb, ws->cand_cnt, ws->cand,
+    hipLaunchKernelGGL(nn16_exact_kernel, dim3(lr_cdiv(na, 256 / LR_EX_LANES)), dim3(256), 0, st, F1, nrm1, na, F0, nrm0, nb, ws->cand_cnt, ws->cand,
                        1, (const int32_t *)ws->rev_rows, (const int32_t *)n_rows, rev, (int32_t *)nullptr, (float *)nullptr, (float *)nullptr,
                        ws->counters, (uint32_t *)nullptr, (float *)nullptr, (uint32_t *)nullptr);
     LR_LAUNCH_CHECK();
