@@ -138,17 +138,17 @@ def _prosac_growth_reference(M, ns, TN):
     return G
 
 
-def test_prosac_samples_follow_the_published_growth_function(oracle):
+@pytest.mark.parametrize("M,ns,TN", [(700, 3, 100000), (64, 4, 2000), (5000, 3, 100000), (37, 3, 500)])
+def test_prosac_samples_follow_the_published_growth_function(oracle, M, ns, TN):
     """Draw k uses ns-1 indices below n_k-1 plus index n_k-1, n_k from the growth function of Chum & Matas as tabulated
     by USAC (sequential recurrence); the oracle evaluates T_n in closed form, so allow the table to differ by rounding
     only: the subset size may be off by one where ceil() sits on an integer boundary."""
     rng = np.random.default_rng(5)
-    M, ns, TN = 700, 3, 100000
     src = rng.uniform(-50, 50, (M, 3)).astype(np.float32); tgt = src.copy()
     G = _prosac_growth_reference(M, ns, TN)
     n_seq = ns
     last_n = ns
-    for k in range(1, 3000):
+    for k in range(1, min(3000, TN)):
         if k >= G[n_seq - 1] and n_seq < M:          # one increment per draw (ProsacSampler::generateSample)
             n_seq += 1
         ok, T, s = oracle.hypothesis(src, tgt, k - 1, sample_size=ns, use_elc=False, sampler=1, prosac_growth=TN)
@@ -156,7 +156,7 @@ def test_prosac_samples_follow_the_published_growth_function(oracle):
         assert abs(n_k - n_seq) <= 1, (k, n_k, n_seq)
         assert n_k >= last_n and all(0 <= int(v) < n_k - 1 for v in s[:ns - 1])
         last_n = n_k
-    assert last_n > 100                              # the subset has grown well past the minimal sample
+    assert last_n > min(100, M // 2)                 # the subset has grown well past the minimal sample
     # past T_N draws the sampler is uniform over all correspondences
     seen = [oracle.hypothesis(src, tgt, TN + j, sample_size=ns, use_elc=False, sampler=1, prosac_growth=TN)[2] for j in range(200)]
     assert max(int(s.max()) for s in seen) > 0.9 * M and any(int(s[ns - 1]) < M - 1 for s in seen)
