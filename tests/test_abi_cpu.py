@@ -73,3 +73,26 @@ def test_mode_aliases_and_defaults():
     assert abs(p.refit_thr2 - 0.36) < 1e-15 and abs(p.ransac.thr2 - 0.36) < 1e-7
     with pytest.raises(AssertionError):
         fr.pair_params(Args(mode="bogus"))
+
+
+def test_pair_params_follow_the_reference_flags():
+    """args namespace (Experiments/test.py:294-313) -> lr_pair_params, no device needed."""
+    from lidarregistration_amd import FR
+    from tests.conftest import Args
+    p = FR.pair_params(Args(mode="GPF", codebase="GC", iters=None, prosac=True, GPF_factor=1.5, GPF_grid_wid=12))
+    assert (p.mode, p.refit, p.gpf_grid_wid, p.gpf_factor) == (_ext.LR_MODE_GPF, 2, 12, 1.5)
+    r = p.ransac
+    assert (r.sample_size, r.use_elc, r.iters, r.sampler, r.scoring) == (3, 1, 500000, 1, 1)       # FR.py:65-67, GC_RANSAC.py:19-37
+    assert abs(r.confidence - 0.999) < 1e-7 and abs(r.thr2 - 0.36) < 1e-7
+    p = FR.pair_params(Args(mode="MMN", codebase="GC", iters=1000, prosac=False, fast_rejection="NONE", GC_conf=0.9))
+    assert (p.mode, p.ransac.sampler, p.ransac.use_elc, p.ransac.iters) == (_ext.LR_MODE_MNN, 0, 0, 1000)
+    assert abs(p.ransac.confidence - 0.9) < 1e-7
+    p = FR.pair_params(Args(mode="no_filter", codebase="open3D", iters=2000))
+    r = p.ransac
+    assert (p.mode, p.refit, r.sample_size, r.use_elc, r.sampler, r.scoring) == (_ext.LR_MODE_NO_FILTER, 1, 4, 1, 0, 0)   # FR.py:128-137
+    assert abs(r.confidence - 0.9995) < 1e-7
+    import pytest
+    with pytest.raises(AssertionError):
+        FR.pair_params(Args(mode="bogus"))
+    with pytest.raises(AssertionError):
+        FR.pair_params(Args(codebase="other"))
