@@ -89,7 +89,7 @@ def main():
     out["is_bb"] = is_bb; out["num_bb"] = np.array(num_bb)
     out["ratio_nn"] = M.calc_distance_ratio_in_feature_space(tF0, tF1, i0, i1, i2).numpy()
     out["ratio_mnn"] = M.calc_distance_ratio_in_feature_space(tF0, tF1, m0, m1, m2).numpy()
-    for k, (factor, wid) in enumerate([(2.0, 10), (0.5, 10), (0.1, 4), (1.0, 7)]):
+    for k, (factor, wid) in enumerate([(2.0, 10), (0.5, 10), (0.1, 4), (1.0, 7), (0.3, 10), (1.0 / 3.0, 23), (0.37, 16)]):
         a = Args(GPF_grid_wid=wid, GPF_factor=factor, GPF_max_matches=10 ** 9)
         g = M.Grid_Prioritized_Filter(tF0, tF1, i0, i1, i2, torch.from_numpy(xyz0), a)
         out[f"gpf{k}_cfg"] = np.array([factor, wid])

@@ -163,7 +163,7 @@ def test_ratio_bit_exact(lr, oracle, filt):
     np.testing.assert_allclose(r.cpu().numpy(), filt["g"]["ratio_nn"], rtol=2e-6)
 
 
-@pytest.mark.parametrize("k", [0, 1, 2, 3])
+@pytest.mark.parametrize("k", [0, 1, 2, 3, 4, 5, 6])
 def test_gpf_golden(lr, oracle, filt, k):
     g = filt["g"]
     factor, wid = g[f"gpf{k}_cfg"]

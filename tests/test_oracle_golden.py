@@ -56,7 +56,7 @@ def test_g4_ratio(oracle, filt):
     np.testing.assert_allclose(r, g["ratio_mnn"], rtol=2e-6, atol=0)
 
 
-@pytest.mark.parametrize("k", [0, 1, 2, 3])
+@pytest.mark.parametrize("k", [0, 1, 2, 3, 4, 5, 6])
 def test_g5_gpf(oracle, filt, k):
     g = filt["g"]
     factor, wid = g[f"gpf{k}_cfg"]
