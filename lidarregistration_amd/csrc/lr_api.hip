@@ -100,6 +100,10 @@ extern "C" int lr_workspace_create(lr_workspace **out, int max_n0, int max_n1, i
         const char *b = getenv("LIDARREG_NN_BLOCKS");      // tuning knob: blocks per filter pass (default 512 = 2 per CU; measured best with many pairs in flight)
         ws->nn_blocks_target = b ? atoi(b) : 512;
         if (ws->nn_blocks_target < 1) ws->nn_blocks_target = 1;
+        const char *rs = getenv("LIDARREG_REV_STRIPS");
+        ws->rev_strips = rs ? atoi(rs) : 16;
+        if (ws->rev_strips < 1) ws->rev_strips = 1;
+        if (ws->rev_strips > 64) ws->rev_strips = 64;
         const char *sa = getenv("LIDARREG_NN_SECOND");
         ws->nn_second_auto = (sa && strcmp(sa, "auto") == 0) ? 1 : 0;
     }

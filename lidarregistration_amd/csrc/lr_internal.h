@@ -59,6 +59,7 @@ struct lr_workspace {
     _Float16 *Hs; float *nrms;   // [max_n0] f16 rows and norms of cloud 0 in rev_cols order
     int nn_path;                 // LR_NN_PATH_*
     int nn_blocks_target;        // column strips are chosen so that a pass launches about this many blocks
+    int rev_strips;              // strips offered to every row block of the reverse pass (LIDARREG_REV_STRIPS)
     int nn_second_auto;          // LIDARREG_NN_SECOND=auto: lr_register_pair computes the 2nd neighbour only when a stage reads it
     float *pb1, *pb2, *pb3;      // partial top-3 values [strips][max_n]
     int32_t *pi1, *pi2;          // partial top-2 indices

@@ -873,7 +873,7 @@ int lr_nn16_reverse(lr_workspace *ws, const float *F0, const _Float16 *H0, const
     const int ntiles = lr_cdiv(nb, 32);
     const int row_blocks = lr_cdiv(na, LR_BLOCK_ROWS);
     // the grid offers every row block the maximum number of strips; a block uses as many as its column prefix is worth
-    int strips = LR_NN_MAX_STRIPS;
+    int strips = ws->rev_strips;             // (no pass-A partial arrays on this path: not bound by LR_NN_MAX_STRIPS)
     int smax = ntiles / 8;
     if (strips > smax) strips = smax;
     if (strips < 1) strips = 1;
