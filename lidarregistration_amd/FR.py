@@ -105,6 +105,7 @@ def FR(A, B, A_feat, B_feat, args, T_gt):
     xyz0, xyz1 = _f32(A), _f32(B)
     f0, f1 = _f32(A_feat), _f32(B_feat)
     params = pair_params(args)
+    params.icp = 0                     # FR() returns the registration only (FR.py:119); ICP is the harness' stage (test.py:183-189)
     n0, n1 = f0.shape[0], f1.shape[0]
     ws = workspace(n0, n1, params.ransac.iters, f0.shape[1])
 

@@ -400,8 +400,7 @@ gpf_score_cell_kernel(int n0, int G, const uint32_t *__restrict__ mm, const uint
         float qy = floorf((float)G * ((xyz0[3 * pi + 1] - y0) / (deny)));
         int c = (int)qx * G + (int)qy;
         cell[i] = c;
-        if (c >= 0 && c < C) atomicAdd(&s_cnt[c], 1);
-        else atomicAdd(&cell_count[min(max(c, 0), LR_GPF_MAX_CELLS - 1)], 1);    // non-finite coordinates: keep the old behaviour
+        if (c >= 0 && c < C) atomicAdd(&s_cnt[c], 1);      // a pair with non-finite coordinates has no cell: it is never kept
     }
     __syncthreads();
     for (int k = threadIdx.x; k < C; k += 256) if (s_cnt[k]) atomicAdd(&cell_count[k], s_cnt[k]);
@@ -536,7 +535,7 @@ gpf_bucket_kernel(int n0, int G, const int32_t *__restrict__ cell, const int32_t
     if (i < n0) {
         c = cell[i];
         if (c >= 0 && c < C) local = atomicAdd(&s_cnt[c], 1);
-        else { const int cc = min(max(c, 0), LR_GPF_MAX_CELLS - 1); bucket[cell_off[cc] + atomicAdd(&cell_fill[cc], 1)] = i; c = -1; }
+        else c = -1;                                       // no cell (non-finite coordinates)
     }
     __syncthreads();
     for (int k = threadIdx.x; k < C; k += 256) if (s_cnt[k]) s_cnt[k] = atomicAdd(&cell_fill[k], s_cnt[k]);     // count -> base
@@ -550,12 +549,13 @@ __global__ void __launch_bounds__(256)
 gpf_select_kernel(int n0, const int32_t *__restrict__ cell, const int32_t *__restrict__ cell_off,
                   const int32_t *__restrict__ cell_count, const double *__restrict__ quota,
                   const int32_t *__restrict__ bucket, const float *__restrict__ score, uint8_t *__restrict__ keep,
-                  const int32_t *__restrict__ m_dev = nullptr)
+                  int C, const int32_t *__restrict__ m_dev = nullptr)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (m_dev) n0 = min(n0, *m_dev);
     if (i >= n0) return;
     const int c = cell[i];
+    if (c < 0 || c >= C) { keep[i] = 0; return; }          // non-finite coordinates: outside every cell
     const int q = (int)quota[c];
     bool k = false;
     if (q > 0) {
@@ -598,7 +598,7 @@ int lr_gpf_run(lr_workspace *ws, const float *F0, int n0, const float *F1, int d
     hipLaunchKernelGGL(gpf_waterfill_kernel, dim3(1), dim3(64), 0, st, G, factor, ws->counters, cell_count, quota, cell_off);
     hipLaunchKernelGGL(gpf_bucket_kernel, dim3(nb), dim3(256), 0, st, n0, G, ws->cell, cell_off, cell_fill, ws->cell_sorted);
     hipLaunchKernelGGL(gpf_select_kernel, dim3(nb), dim3(256), 0, st, n0, ws->cell, cell_off, cell_count, quota,
-                       ws->cell_sorted, ws->ratio, keep);
+                       ws->cell_sorted, ws->ratio, keep, G * G);
     hipLaunchKernelGGL(count_flags_kernel, dim3(nb), dim3(256), 0, st, n0, (const int32_t *)nullptr, keep, ws->blk_cnt);
     hipLaunchKernelGGL(compact_kernel, dim3(nb), dim3(256), 0, st, n0, keep, ws->blk_cnt, idx1, idx2, ws->ratio, o0, o1, o2, oscore,
                        n_out, (int32_t *)nullptr, xyz0, xyz1, corr8, ws->counters);
@@ -630,7 +630,7 @@ int lr_gpf_bb_run(lr_workspace *ws, const float *F0, int n0, const float *F1, in
                        mb_dev, has_score);
     hipLaunchKernelGGL(gpf_bucket_kernel, dim3(nb), dim3(256), 0, st, n0, G, ws->cell, cell_off, cell_fill, ws->cell_sorted, mb_dev);
     hipLaunchKernelGGL(gpf_select_kernel, dim3(nb), dim3(256), 0, st, n0, ws->cell, cell_off, cell_count, quota,
-                       ws->cell_sorted, ws->ratio, keep, mb_dev);
+                       ws->cell_sorted, ws->ratio, keep, G * G, mb_dev);
     hipLaunchKernelGGL(count_flags_kernel, dim3(nb), dim3(256), 0, st, n0, mb_dev, keep, ws->blk_cnt);
     hipLaunchKernelGGL(compact_kernel, dim3(nb), dim3(256), 0, st, n0, keep, ws->blk_cnt, b1, b2, ws->ratio, o0, o1, o2, oscore,
                        n_out, (int32_t *)nullptr, (const float *)nullptr, (const float *)nullptr, (float *)nullptr, ws->counters, mb_dev, b0);

@@ -889,13 +889,17 @@ int lr_nn16_reverse(lr_workspace *ws, const float *F0, const _Float16 *H0, const
     hipLaunchKernelGGL(nn16_rev_scatter_kernel, dim3(lr_cdiv(n0 + n1, 256)), dim3(256), 0, st, n0, n1, (const float *)ws->rev_s1,
                        (const uint32_t *)seed, (const uint32_t *)range, ws->rev_hist, H0, nrm0, bmax0, lr_cdiv(nb, 32), nrm1,
                        ws->rev_cols, ws->Hs, ws->nrms, tmin, ws->rev_rows, ws->tau, ws->cand_cnt, rev);
-    // grids are sized for all rows; blocks past the compacted count (or past their row block's strips) leave at once
+    // grids are sized for all rows; blocks past the compacted count (or past their row block's strips) leave at once.
+    // The column-prefix pruning (tile_min) rests on s1(i') = d(i', idx1[i']) being the true NN distance of i': that holds when
+    // the list comes from this library's own forward pass (`seeded`, lr_register_pair).  A caller-supplied list (lr_nn_to_mutual,
+    // lr_gpf*) may be anything -- the reference's nn_to_mutual accepts any corres_idx1 -- so every row block walks all column
+    // tiles there: the seeds are still upper bounds of the row minima, only the prefix cut is given up.
     dim3 grid(row_blocks, strips);
     const bool timed = ws->timing && ws->ev_pending == 1 && !ws->rev_recorded;
     if (timed) { LR_HIP(hipEventRecord(ws->ev[4], st)); }
     hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), 0, st, H1, na, (const int32_t *)ws->rev_rows, (const int32_t *)n_rows,
                        (const _Float16 *)ws->Hs, (const float *)ws->nrms, nb, tps, ws->tau, ws->cand_cnt, ws->cand,
-                       (const int32_t *)ws->rev_cols, (const float *)ws->rev_tmin, (const uint32_t *)seed, lr_thr_in{});
+                       (const int32_t *)ws->rev_cols, seeded ? (const float *)ws->rev_tmin : (const float *)nullptr, (const uint32_t *)seed, lr_thr_in{});
     if (timed) { LR_HIP(hipEventRecord(ws->ev[5], st)); ws->rev_recorded = 1; }
     hipLaunchKernelGGL(nn16_exact_kernel, dim3(lr_cdiv(na, 256 / LR_EX_LANES)), dim3(256), 0, st, F1, nrm1, na, F0, nrm0, nb, ws->cand_cnt, ws->cand,
                        1, (const int32_t *)ws->rev_rows, (const int32_t *)n_rows, rev, (int32_t *)nullptr, (float *)nullptr, (float *)nullptr,

@@ -62,10 +62,18 @@ class CacheSource:
         return dict(xyz0=xyz0, xyz1=xyz1, feats0=f0, feats1=f1, T_gt=self.pair_list["T_gt"][k])
 
 
+def registration_params(args):
+    """lr_pair_params of the timed registration call.  The harness times ICP on its own (test.py:183-193, stats column 11),
+    so the fused ICP stage of lr_register_pair stays off here: column 9 must not contain an ICP."""
+    params = fr.pair_params(args)
+    params.icp = 0
+    return params
+
+
 def eval_pairs(source, indices, args, device=None, in_flight=4, verbose=False):
     """Register source[k] for k in indices.  Returns (stats [n,22] float64, T [n,4,4] float64)."""
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
-    params = fr.pair_params(args)
+    params = registration_params(args)
     n = len(indices)
     stats = np.full((n, 22), np.nan)
     Ts = np.tile(np.eye(4), (n, 1, 1))
