@@ -1,18 +1,23 @@
 """Registration-pairs/sec benchmark (BASELINE.json config #2: 30k-pt x 32-d synthetic FCGF pairs,
 mutual-NN + 50k-iteration RANSAC + LS refit) on N GPUs of one node.
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W]            # N > 1 without a launcher: spawns one process per GPU itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A step = one pass of the hot path over one batch of `--pairs` resident pairs per GPU.  Pairs shard
-over ranks with no data-path collective (weak scaling); one RCCL all_gather per step returns the result rows.
-Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` for the dominant kernel
-(nn16_passb_kernel, the f16 matrix-core filter pass) and `cpu_baseline` (the oracle port timed on the host cores, rank 0, N=1).
+A step = one pass of the hot path over `--pairs` DISTINCT resident pairs per GPU (inputs in HBM before the timed region),
+registered as pair-batched launches (lr_register_batch, `--batch` pairs per call, round-robin over `--streams` streams), the
+4x4 transforms copied back to pinned host memory inside the timed region.  Pairs shard over ranks with no data-path
+collective (weak scaling); one RCCL all_gather per step returns the result rows.  Prints ONE JSON line on rank 0 with
+`roofline` for the dominant kernel (nn16_passb_kernel, the f16 matrix-core filter pass), `pair_roofline` (whole pair against
+the blended matrix / vector floor) and `cpu_baseline` (the reference's torch-einsum NN + numpy filter + OpenMP RANSAC on the
+host cores, rank 0, N=1).
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,101 +26,191 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# The pairs in flight live on separate HIP streams; the runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware
-# queues (default 4), and kernels that share a queue do not overlap.  16 queues for the 32 streams measured best
-# (measurements).  Must be in the environment before the HIP runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-
 MFMA_F32_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 MFMA_F16_PEAK_TFLOPS = 2500.0       # same table, "Peak BF16/FP16 MFMA ~2.5 PF dense"
+VALU_F32_PEAK_TFLOPS = 157.3        # same table, "Peak FP32 (vector)"
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=128, help="pairs per step per GPU")
+    ap.add_argument("--pairs", type=int, default=128, help="distinct resident pairs per step per GPU")
     ap.add_argument("--n", type=int, default=30000, help="points per cloud")
     ap.add_argument("--iters", type=int, default=50000)
     ap.add_argument("--mode", default="MNN")
-    ap.add_argument("--streams", type=int, default=32, help="pairs in flight per GPU")
-    ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic pairs generated per GPU")
+    ap.add_argument("--batch", type=int, default=0, help="pairs per batched call (0: 32, or 8 for clouds above 60k points)")
+    ap.add_argument("--streams", type=int, default=2, help="batched calls in flight per GPU")
     ap.add_argument("--include-h2d", action="store_true", help="copy each pair from pinned host memory inside the timed region (PCIe-inclusive rate; not the headline value)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-pairs", type=int, default=2)
-    return ap.parse_args()
+    ap.add_argument("--cpu-pairs", type=int, default=8)
+    ap.add_argument("--cpu-budget-s", type=float, default=45.0, help="stop the CPU baseline sample after this many seconds (at least 2 pairs)")
+    ap.add_argument("--dry-run", action="store_true", help="test hook: no GPU work, gloo collectives, fake result rows (exercises the launcher, the gather and the JSON line on CPU)")
+    return ap.parse_args(argv)
+
+
+# ----------------------------------------------------------------------------- self-launch (no torch.distributed.run)
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with no rendezvous environment: start one child per GPU (the launch shape of the
+    reference's test_parallel.sh:18-24) and wait.  The parent never touches HIP (no torch.cuda call, no exec after init)."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        for p in procs:
+            rc = max(rc, abs(p.wait()))
+            if rc:
+                break
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+# ----------------------------------------------------------------------------- helpers
+def transform_errors(T, G):
+    re = np.degrees(np.arccos(np.clip((np.trace(T[:3, :3].T @ G[:3, :3]) - 1) / 2, -1, 1)))
+    return re, np.linalg.norm(T[:3, 3] - G[:3, 3])
+
+
+def cpu_baseline(args, seed0):
+    """The reference's own way of computing a pair on host cores (oracle/torch_cpu.py: chunked torch.einsum NN with
+    nn_max_n = 250, numpy mutual filter, OpenMP RANSAC + refit), bounded sample; plus the scalar-fma oracle port on 2 pairs."""
+    import torch
+    from lidarregistration_amd import synth
+    from oracle import oracle as orc, torch_cpu
+    orc.build()
+    w = synth.make_pair(N=2000, seed=1)
+    torch_cpu.register_pair(w["xyz0"], w["xyz1"], w["feats0"], w["feats1"], mode=args.mode, iters=1000)     # page-in / thread pools: untimed
+    t_reg = 0.0; done = 0; parts = np.zeros(3)
+    for k in range(args.cpu_pairs):
+        p = synth.make_pair(N=args.n, seed=seed0 + k)
+        t1 = time.perf_counter()
+        r = torch_cpu.register_pair(p["xyz0"], p["xyz1"], p["feats0"], p["feats1"], mode=args.mode, iters=args.iters, sample_size=3, seed=51)
+        t_reg += time.perf_counter() - t1; done += 1
+        parts += [r["t_nn"], r["t_filter"], r["t_ransac"]]
+        if t_reg > args.cpu_budget_s and done >= 2:
+            break
+    t_port = 0.0
+    for k in range(2):
+        p = synth.make_pair(N=args.n, seed=seed0 + k)
+        t1 = time.perf_counter()
+        orc.register_pair(p["xyz0"], p["xyz1"], p["feats0"], p["feats1"], mode=args.mode, iters=args.iters, sample_size=3, seed=51)
+        t_port += time.perf_counter() - t1
+    model = ""
+    try:
+        model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        pass
+    return {"value": round(done / t_reg, 4), "unit": "pairs/s", "cores": int(torch.get_num_threads()), "kind": "port",
+            "impl": "restatement of the reference's Python path: torch-CPU chunked einsum NN (nn_max_n=250, matching.py:22-65) x2 directions + "
+                    "numpy mutual filter + OpenMP RANSAC/refit (oracle.c) -- oracle/torch_cpu.py",
+            "sample": f"{done} pairs of the same workload (N={args.n}, {args.mode}, {args.iters} iters); seconds per pair: NN {parts[0] / done:.2f}, "
+                      f"reverse NN + filter {parts[1] / done:.2f}, RANSAC + refit {parts[2] / done:.2f}",
+            "cpu_model": model, "omp_threads": int(orc.lib().orc_num_threads()),
+            "oracle_port_pairs_per_s": round(2 / t_port, 4)}
 
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
     import torch
     import torch.distributed as dist
-    from lidarregistration_amd import FR, _ext, shard, synth
+    from lidarregistration_amd import shard, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
-    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    dry = args.dry_run
+    if dry:
+        dev = torch.device("cpu")
+        if world > 1:
+            dist.init_process_group("gloo")
+    else:
+        assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        if world > 1:
+            dist.init_process_group("nccl", device_id=dev)
 
-    class A:
-        mode = args.mode; codebase = "open3D"; iters = args.iters; ransac_n = 3; GPF_factor = 2.0; GPF_grid_wid = 10
-        o3d_conf = 1.0          # every one of the --iters hypotheses is evaluated (no confidence-based early exit)
-    params = FR.pair_params(A)
-
-    # resident inputs: `distinct` synthetic pairs per GPU, cycled through the batch
-    pairs = []
-    for k in range(args.distinct):
-        p = synth.make_pair(N=args.n, seed=51 + rank * 1000 + k)
-        pairs.append(dict(xyz0=torch.from_numpy(p["xyz0"]).to(dev), xyz1=torch.from_numpy(p["xyz1"]).to(dev),
-                          f0=torch.from_numpy(p["feats0"]).to(dev), f1=torch.from_numpy(p["feats1"]).to(dev), T_gt=p["T_gt"]))
+    B = args.batch if args.batch > 0 else (32 if args.n <= 60000 else 8)
+    B = max(1, min(B, args.pairs, 64))
     nstreams = max(1, args.streams)
-    streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
-    wss = [_ext.Workspace(args.n, args.n, 32, args.iters) for _ in range(nstreams)]
-    outs = torch.zeros((args.pairs, ctypes.sizeof(_ext.PairResult)), dtype=torch.uint8, device=dev)
+    res_bytes = 496
+    pairs, T_gt = [], []
+    if not dry:
+        from lidarregistration_amd import FR, _ext
+
+        class A:
+            mode = args.mode; codebase = "open3D"; iters = args.iters; ransac_n = 3; GPF_factor = 2.0; GPF_grid_wid = 10
+            o3d_conf = 1.0          # every one of the --iters hypotheses is evaluated (no confidence-based early exit)
+        params = FR.pair_params(A)
+        res_bytes = ctypes.sizeof(_ext.PairResult)
+        # resident inputs: `pairs` DISTINCT synthetic pairs per GPU (~8.4 MB each at 30k points), generated on the device
+        for k in range(args.pairs):
+            p = synth.make_pair_dev(N=args.n, seed=51 + rank * 100003 + k, device=dev)
+            pairs.append((p["xyz0"], p["xyz1"], p["feats0"], p["feats1"])); T_gt.append(p["T_gt"])
+        streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
+        wss = [_ext.Workspace(args.n, args.n, 32, args.iters, max_pairs=B) for _ in range(nstreams)]
+    outs = torch.zeros((args.pairs, res_bytes), dtype=torch.uint8, device=dev)
     rows = torch.zeros((args.pairs, shard.ROW), dtype=torch.float64, device=dev)
     gathered = torch.zeros((world * args.pairs, shard.ROW), dtype=torch.float64, device=dev) if world > 1 else None
+    host_T = torch.zeros((args.pairs, 16), dtype=torch.float64)
+    if not dry:
+        host_T = host_T.pin_memory()
 
     host = None
-    if args.include_h2d:
-        host = [{k: v.cpu().pin_memory() for k, v in pr.items() if k != "T_gt"} for pr in pairs]
-        staged = [{k: torch.empty_like(pairs[0][k]) for k in ("xyz0", "xyz1", "f0", "f1")} for _ in range(nstreams)]
+    if args.include_h2d and not dry:
+        host = [tuple(t.cpu().pin_memory() for t in pr) for pr in pairs]
+        staged = [[tuple(torch.empty_like(t) for t in pairs[0]) for _ in range(B)] for _ in range(nstreams)]
 
     enq = [0.0]
 
     def step():
         t_enq = time.perf_counter()
-        for i in range(args.pairs):
-            s = i % nstreams
-            pr = pairs[i % len(pairs)]
-            if host is not None:
-                with torch.cuda.stream(streams[s]):
-                    for k in ("xyz0", "xyz1", "f0", "f1"):
-                        staged[s][k].copy_(host[i % len(pairs)][k], non_blocking=True)
-                pr = staged[s]
-            FR.register_pair_dev(pr["xyz0"], pr["xyz1"], pr["f0"], pr["f1"], params, out=outs[i], ws=wss[s],
-                                 stream=streams[s].cuda_stream)
+        if dry:
+            outs[:, :128] = torch.full((args.pairs, 128), rank + 1, dtype=torch.uint8)
+        else:
+            for c, lo in enumerate(range(0, args.pairs, B)):
+                s = c % nstreams
+                chunk = pairs[lo:lo + B]
+                if host is not None:
+                    with torch.cuda.stream(streams[s]):
+                        for j in range(len(chunk)):
+                            for dst, src in zip(staged[s][j], host[lo + j]):
+                                dst.copy_(src, non_blocking=True)
+                    chunk = staged[s][:len(chunk)]
+                FR.register_batch_dev(chunk, params, out=outs[lo:lo + len(chunk)], ws=wss[s], stream=streams[s].cuda_stream)
+            for s in streams:
+                torch.cuda.current_stream().wait_stream(s)
         enq[0] += time.perf_counter() - t_enq
-        for s in streams:
-            torch.cuda.current_stream().wait_stream(s)
+        # the step's product: the 4x4 transforms, on the host (128 bytes per pair, SURVEY 8d metric text)
+        Tdev = outs[:, :128].view(torch.float64).view(args.pairs, 16)
+        host_T.copy_(Tdev, non_blocking=not dry)
         if world > 1:
             # result rows = the 16 doubles of T (+ stats columns, zero here); one collective per step
-            rows[:, 22:38] = outs[:, :128].view(torch.float64).view(args.pairs, 16)
+            rows[:, 22:38] = Tdev
             dist.all_gather_into_tensor(gathered, rows)
 
     def sync_all():
-        torch.cuda.synchronize(dev)
+        if not dry:
+            torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
-            torch.cuda.synchronize(dev)
+            if not dry:
+                torch.cuda.synchronize(dev)
 
-    for s in streams:
-        s.wait_stream(torch.cuda.current_stream())
+    if not dry:
+        for s in streams:
+            s.wait_stream(torch.cuda.current_stream())
     for _ in range(args.warmup):
         step()
     sync_all()
@@ -130,83 +225,84 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
-    # ---- sanity of what was timed: every pair of the last step registered correctly
-    res = [_ext.PairResult.from_buffer_copy(outs[i].cpu().numpy().tobytes()) for i in range(args.pairs)]
-    ok = ok5 = 0
-    for i, r in enumerate(res):
-        T = np.array(r.T[:]).reshape(4, 4); G = pairs[i % len(pairs)]["T_gt"]
-        re = np.degrees(np.arccos(np.clip((np.trace(T[:3, :3].T @ G[:3, :3]) - 1) / 2, -1, 1)))
-        te = np.linalg.norm(T[:3, 3] - G[:3, 3])
-        ok += int(re < 2 and te < 0.6)           # BASELINE.json metric: recall@(2 deg, 0.6 m)
-        ok5 += int(re < 5 and te < 0.6)
-    recall = ok / len(res)
-    recall5 = ok5 / len(res)
+    # ---- sanity of what was timed: every distinct pair of the last step registered correctly (from the host copy of T)
+    recall = recall5 = None
+    n_corr_mean = n_valid_mean = 0.0
+    if not dry:
+        ok = ok5 = 0
+        Th = host_T.numpy().reshape(-1, 4, 4)
+        for i in range(args.pairs):
+            re, te = transform_errors(Th[i], T_gt[i])
+            ok += int(re < 2 and te < 0.6)           # BASELINE.json metric: recall@(2 deg, 0.6 m)
+            ok5 += int(re < 5 and te < 0.6)
+        recall, recall5 = ok / args.pairs, ok5 / args.pairs
+        res = [_ext.PairResult.from_buffer_copy(outs[i].cpu().numpy().tobytes()) for i in range(args.pairs)]
+        n_corr_mean = float(np.mean([r.n_corr for r in res])); n_valid_mean = float(np.mean([r.ransac.n_valid for r in res]))
+    elif world > 1:
+        g = gathered.view(world, args.pairs, shard.ROW)[:, 0, 22]
+        assert [float(v) for v in g] == [float(np.frombuffer(bytes([r + 1] * 8), np.float64)[0]) for r in range(world)], "gather order"
 
-    # ---- roofline of the dominant kernel (pass B of the f16 filter; nn_strip_kernel on the fp32 path): HIP events
-    #      recorded by the library on the launch stream around that kernel, averaged over `reps` pairs
-    roof = None
-    if rank == 0:
+    # ---- roofline of the dominant kernel (pass B of the f16 filter): HIP events recorded by the library on the launch
+    #      stream around the batched forward and reverse launches, averaged over `reps` batched calls
+    roof = pair_roof = None
+    total_pairs = world * args.pairs * args.steps
+    value = total_pairs / dt
+    if rank == 0 and not dry:
         L = _ext.lib()
         ws = wss[0]
-        fp32_path = os.environ.get("LIDARREG_NN_PATH") == "fp32"
         _ext.check(L.lr_workspace_timing(ws.handle, 1))
-        reps = 20
-        pr = pairs[0]
+        reps = 10
+        chunk = pairs[:B]
         nn_ms = ctypes.c_float(); rs_ms = ctypes.c_float(); ns = ctypes.c_int()
         for _ in range(reps):
-            FR.register_pair_dev(pr["xyz0"], pr["xyz1"], pr["f0"], pr["f1"], params, out=outs[0], ws=ws, stream=streams[0].cuda_stream)
+            FR.register_batch_dev(chunk, params, out=outs[:len(chunk)], ws=ws, stream=streams[0].cuda_stream)
             streams[0].synchronize()
             _ext.check(L.lr_workspace_timing_read(ws.handle, ctypes.byref(nn_ms), ctypes.byref(rs_ms), ctypes.byref(ns)))
         _ext.check(L.lr_workspace_timing(ws.handle, 0))
         flop_pass = 2.0 * 32 * args.n * args.n                  # W_NN = 2 D N0 N1 per pair (ONE pass is algorithmic)
-        launches_per_pair = 1 if args.mode == "no_filter" else 2  # forward + reverse NN are separate launches of the same kernel
-        # the library timed every pass-B launch of the pair (forward and reverse): average duration per launch, which is
-        # what the rocprofv3 summary's AverageNs of this kernel shows
-        timed_launches = 1 if fp32_path else launches_per_pair   # the fp32 path's hook times its first launch only
-        t_launch = nn_ms.value / max(ns.value, 1) / timed_launches * 1e-3
-        flop_launch = flop_pass / launches_per_pair            # algorithmic flops one launch accounts for
+        launches_per_call = 1 if args.mode == "no_filter" else 2  # forward + reverse NN are separate launches of the same kernel
+        # the library timed both pass-B launches of each batched call: average duration per launch = AverageNs of this kernel
+        # in the rocprofv3 summary of the same command
+        t_launch = nn_ms.value / max(ns.value, 1) / launches_per_call * 1e-3
+        flop_launch = flop_pass * len(chunk) / launches_per_call   # algorithmic flops one launch accounts for (len(chunk) pairs)
         achieved = flop_launch / t_launch / 1e12
-        peak = MFMA_F32_PEAK_TFLOPS if fp32_path else MFMA_F16_PEAK_TFLOPS
         traffic = None
         tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tj) and not fp32_path:
+        if os.path.exists(tj):
             traffic = json.load(open(tj)).get("nn16_passb_kernel", {}).get("hbm_bytes_per_launch")
-        roof = {"bound": "mfma", "kernel": "nn_strip_kernel" if fp32_path else "nn16_passb_kernel",
-                "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                "traffic": traffic, "launch_ms": round(t_launch * 1e3, 4), "launches_per_pair": launches_per_pair,
-                "note": "f16 MFMA filter + exact fp32 verification; launch_ms = average over the forward (all tiles) and the reverse "
-                        "(ordered, pruned) launch of the pair; the kernel is issue/LDS/latency-bound, not MFMA-bound (DESIGN.md)",
-                "ransac_gen_score_ms": round(rs_ms.value / max(ns.value, 1), 4)}
+        roof = {"bound": "mfma", "kernel": "nn16_passb_kernel", "achieved": round(achieved, 3), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4), "traffic": traffic, "launch_ms": round(t_launch * 1e3, 4),
+                "pairs_per_launch": len(chunk), "launches_per_call": launches_per_call,
+                "note": "f16 MFMA filter + exact fp32 verification; one launch covers all pairs of a batched call; launch_ms = average over the "
+                        "forward (all tiles) and the reverse (ordered, pruned) launch; achieved = (W/2 per pair x pairs per launch) / launch_ms",
+                "ransac_gen_score_ms_per_call": round(rs_ms.value / max(ns.value, 1), 4)}
+        # whole pair against the blended floor: one NN pass on the matrix pipe + V*M*27 flop of scoring on the vector pipe
+        t_min = flop_pass / (MFMA_F16_PEAK_TFLOPS * 1e12) + n_valid_mean * n_corr_mean * 27.0 / (VALU_F32_PEAK_TFLOPS * 1e12)
+        t_pair = dt / (args.pairs * args.steps)
+        pair_roof = {"t_min_us": round(t_min * 1e6, 2), "t_pair_us": round(t_pair * 1e6, 2), "frac": round(t_min / t_pair, 4),
+                     "note": "t_min = W/peak_f16 + V*M*27/peak_fp32 (V = hypotheses past the pre-check, M = filtered pairs, means over the step)",
+                     "V": round(n_valid_mean, 1), "M": round(n_corr_mean, 1)}
 
-    # ---- CPU baseline: the oracle port on the host cores, bounded sample (rank 0, N=1 only)
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import oracle as orc
-        orc.build()
-        # time only the registration calls (synthetic generation excluded)
-        t_reg = 0.0
-        for k in range(args.cpu_pairs):
-            p = synth.make_pair(N=args.n, seed=51 + k)
-            t1 = time.perf_counter()
-            orc.register_pair(p["xyz0"], p["xyz1"], p["feats0"], p["feats1"], mode=args.mode, iters=args.iters, sample_size=3, seed=51)
-            t_reg += time.perf_counter() - t1
-        cpu = {"value": round(args.cpu_pairs / t_reg, 4), "unit": "pairs/s", "cores": orc.lib().orc_num_threads(), "kind": "port",
-               "sample": f"{args.cpu_pairs} pairs of the same workload (N={args.n}, {args.mode}, {args.iters} iters), oracle/oracle.c with OpenMP"}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not dry:
+        cpu = cpu_baseline(args, seed0=51)
 
     if rank == 0:
-        total_pairs = world * args.pairs * args.steps
-        value = total_pairs / dt
         line = {
             "metric": f"registration pairs/sec ({args.n // 1000}k-pt FCGF pairs, {'mutual-NN' if args.mode in ('MNN', 'MMN') else args.mode} + {args.iters // 1000}k RANSAC iters + refit)",
             "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic" + (" (inputs copied from pinned host memory inside the timed region)" if args.include_h2d else ""),
             "config": {"workload": f"{'configs[1]' if args.n == 30000 else 'configs[4]-like dense'}: {args.n}-pt x32-d synthetic FCGF pair, --mode {args.mode} --iters {args.iters}, "
-                                   f"3-pt sampling + ELC + LS refit", "pairs_per_step_per_gpu": args.pairs,
-                       "pairs_in_flight_per_gpu": nstreams, "parallelism": f"pair-sharded x{world}"},
-            "recall_2deg_0.6m": round(recall, 4), "recall_5deg_0.6m": round(recall5, 4), "host_enqueue_ms_per_step": round(enq[0] / args.steps * 1e3, 3),
-            "roofline": roof, "cpu_baseline": cpu,
+                                   f"3-pt sampling + ELC + LS refit; {args.pairs} distinct resident pairs per GPU, T copied to the host inside the timed region",
+                       "pairs_per_step_per_gpu": args.pairs, "pairs_per_batched_call": B, "batched_calls_in_flight_per_gpu": nstreams,
+                       "parallelism": f"pair-sharded x{world}"},
+            "recall_2deg_0.6m": None if recall is None else round(recall, 4), "recall_5deg_0.6m": None if recall5 is None else round(recall5, 4),
+            "host_enqueue_ms_per_step": round(enq[0] / args.steps * 1e3, 3),
+            "roofline": roof, "pair_roofline": pair_roof, "cpu_baseline": cpu,
         }
+        if dry:
+            line["data"] = "dry-run (no GPU work)"
         if cpu:
             line["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)
         print(json.dumps(line), flush=True)

@@ -110,6 +110,9 @@ LR_API const char *lr_last_error(void);
 
 /* Scratch for clouds up to (max_n0, max_n1) points x dim and up to max_iters hypotheses. */
 LR_API int    lr_workspace_create(lr_workspace **ws, int max_n0, int max_n1, int dim, int max_iters);
+/* The same for up to max_pairs (<= 64) pairs registered by ONE call of lr_register_batch: max_pairs arenas of identical
+ * layout in one allocation.  The single-pair entry points below work on such a workspace too (they use arena 0).        */
+LR_API int    lr_workspace_create_batch(lr_workspace **ws, int max_pairs, int max_n0, int max_n1, int dim, int max_iters);
 LR_API int    lr_workspace_destroy(lr_workspace *ws);
 LR_API size_t lr_workspace_bytes(const lr_workspace *ws);
 /* Test hook (no reference counterpart): fill the scratch arena with one byte value; results must not depend on it. */
@@ -180,11 +183,23 @@ LR_API int lr_register_pair(lr_workspace *ws, const float *xyz0, const float *xy
                             const float *F0, const float *F1, int n0, int n1, int dim,
                             const lr_pair_params *p, lr_pair_result *out, void *stream);
 
+/* ---- a9 for many pairs: what Experiments/test.py:165-167 does pair after pair (one FR() per list row), as ONE sequence of
+ * kernel launches over `npairs` pairs: every kernel of the path is launched once with the pair as a grid dimension, so the
+ * GPU is filled by the batch instead of by many concurrent streams.  xyz0/xyz1/F0/F1/n0/n1 are HOST arrays of length npairs
+ * (device pointers / cloud sizes, which may differ from pair to pair); out is a DEVICE array of npairs result blocks.  The
+ * result of pair k is bit-identical to lr_register_pair on that pair.                                                      */
+LR_API int lr_register_batch(lr_workspace *ws, int npairs, const float *const *xyz0, const float *const *xyz1,
+                             const float *const *F0, const float *const *F1, const int32_t *n0, const int32_t *n1, int dim,
+                             const lr_pair_params *p, lr_pair_result *out, void *stream);
+
 /* Copies the correspondence lists of the last lr_register_pair on this workspace into caller-owned
  * device buffers (any may be NULL): the NN lists over all n0 rows (FR.py's corres_idx1_orig / idx1_2nd_orig)
  * and the filtered lists, of which the first out->n_corr entries are live (buffers sized n0).     */
 LR_API int lr_workspace_lists(lr_workspace *ws, int n0, int32_t *nn_idx1, int32_t *nn_idx2,
                               int32_t *corr_idx0, int32_t *corr_idx1, void *stream);
+/* ... and of pair `pair` of the last lr_register_batch */
+LR_API int lr_workspace_lists_at(lr_workspace *ws, int pair, int n0, int32_t *nn_idx1, int32_t *nn_idx2,
+                                 int32_t *corr_idx0, int32_t *corr_idx1, void *stream);
 
 /* ---- measurement hook for bench.py: duration of the last NN distance kernel(s) on this workspace,
  * from HIP events recorded on the launch stream.  Enable, run, synchronise, then read.            */

@@ -81,6 +81,25 @@ def register_pair_dev(xyz0, xyz1, feats0, feats1, params, out=None, ws=None, str
     return out
 
 
+def register_batch_dev(pairs, params, out=None, ws=None, stream=None):
+    """Enqueue `pairs` = [(xyz0, xyz1, feats0, feats1), ...] (float32 device tensors, sizes may differ from pair to pair) as
+    ONE batched call (lr_register_batch): every kernel of the path is launched once for all pairs.  Returns the device
+    result buffer uint8[len(pairs), 496].  No synchronisation; `ws` must have been created with max_pairs >= len(pairs)."""
+    P = len(pairs)
+    d = pairs[0][2].shape[1]
+    n0 = [int(p[2].shape[0]) for p in pairs]; n1 = [int(p[3].shape[0]) for p in pairs]
+    if ws is None:
+        ws = _ext.Workspace(max(n0), max(n1), d, params.ransac.iters, max_pairs=P)
+    if out is None:
+        out = torch.empty((P, ctypes.sizeof(_ext.PairResult)), dtype=torch.uint8, device=pairs[0][2].device)
+    VP, IP = ctypes.c_void_p * P, ctypes.c_int32 * P
+    _ext.check(_ext.lib().lr_register_batch(ws.handle, P, VP(*[p[0].data_ptr() for p in pairs]), VP(*[p[1].data_ptr() for p in pairs]),
+                                             VP(*[p[2].data_ptr() for p in pairs]), VP(*[p[3].data_ptr() for p in pairs]),
+                                             IP(*n0), IP(*n1), d, ctypes.byref(params), out.data_ptr(),
+                                             _stream() if stream is None else stream))
+    return out
+
+
 def read_result(out):
     """Device result block -> _ext.PairResult (synchronises on the copy)."""
     return _ext.PairResult.from_buffer_copy(out.cpu().numpy().tobytes())

@@ -17,6 +17,7 @@ SYMBOLS = [
     "lr_version", "lr_last_error", "lr_workspace_create", "lr_workspace_destroy", "lr_workspace_bytes", "lr_workspace_poison",
     "lr_nn_top2", "lr_nn_to_mutual", "lr_feat_ratio", "lr_gpf", "lr_gpf_bb_first", "lr_ransac", "lr_refit", "lr_icp", "lr_kabsch",
     "lr_register_pair", "lr_workspace_lists", "lr_workspace_timing", "lr_workspace_timing_read",
+    "lr_workspace_create_batch", "lr_register_batch", "lr_workspace_lists_at",
 ]
 
 
@@ -100,6 +101,10 @@ def lib():
         L.lr_kabsch.argtypes = [vp, vp, vp, ci, vp, vp]
         L.lr_register_pair.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ctypes.POINTER(PairParams), vp, vp]
         L.lr_workspace_lists.argtypes = [vp, ci, vp, vp, vp, vp, vp]
+        L.lr_workspace_lists_at.argtypes = [vp, ci, ci, vp, vp, vp, vp, vp]
+        L.lr_workspace_create_batch.argtypes = [ctypes.POINTER(ctypes.c_void_p), ci, ci, ci, ci, ci]
+        pp, ip = ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int32)
+        L.lr_register_batch.argtypes = [vp, ci, pp, pp, pp, pp, ip, ip, ci, ctypes.POINTER(PairParams), vp, vp]
         L.lr_workspace_timing.argtypes = [vp, ci]
         L.lr_workspace_timing_read.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ci)]
         _lib = L
@@ -112,12 +117,14 @@ def check(rc):
 
 
 class Workspace:
-    """Owns one lr_workspace (device scratch for one in-flight pair)."""
+    """Owns one lr_workspace: device scratch for one in-flight pair, or -- max_pairs > 1 -- for one in-flight batch of pairs
+    registered by a single lr_register_batch call."""
 
-    def __init__(self, max_n0, max_n1, dim=32, max_iters=50000):
+    def __init__(self, max_n0, max_n1, dim=32, max_iters=50000, max_pairs=1):
         self._h = ctypes.c_void_p()
         self.max_n0, self.max_n1, self.dim, self.max_iters = int(max_n0), int(max_n1), int(dim), int(max_iters)
-        check(lib().lr_workspace_create(ctypes.byref(self._h), self.max_n0, self.max_n1, self.dim, self.max_iters))
+        self.max_pairs = int(max_pairs)
+        check(lib().lr_workspace_create_batch(ctypes.byref(self._h), self.max_pairs, self.max_n0, self.max_n1, self.dim, self.max_iters))
 
     @property
     def handle(self):

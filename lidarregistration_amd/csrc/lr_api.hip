@@ -85,7 +85,13 @@ void carve(lr_workspace *ws, Carver &c)
 
 extern "C" int lr_workspace_create(lr_workspace **out, int max_n0, int max_n1, int dim, int max_iters)
 {
+    return lr_workspace_create_batch(out, 1, max_n0, max_n1, dim, max_iters);
+}
+
+extern "C" int lr_workspace_create_batch(lr_workspace **out, int max_pairs, int max_n0, int max_n1, int dim, int max_iters)
+{
     LR_REQUIRE(out, LR_EINVAL, "lr_workspace_create: null output");
+    LR_REQUIRE(max_pairs >= 1 && max_pairs <= LR_MAX_BATCH, LR_EINVAL, "lr_workspace_create_batch: max_pairs must be in [1, 64]");
     LR_REQUIRE(max_n0 > 0 && max_n1 > 0 && max_iters >= 0, LR_EINVAL, "lr_workspace_create: sizes must be positive");
     LR_REQUIRE(dim == LR_FEAT_DIM, LR_EINVAL, "lr_workspace_create: only 32-d descriptors (FCGF) are supported");
     LR_REQUIRE(max_n0 < (1 << 22) && max_n1 < (1 << 22), LR_ESIZE, "lr_workspace_create: clouds are limited to 2^22 points");
@@ -94,12 +100,16 @@ extern "C" int lr_workspace_create(lr_workspace **out, int max_n0, int max_n1, i
     memset(ws, 0, sizeof(*ws));
     ws->max_n0 = max_n0; ws->max_n1 = max_n1; ws->max_n = max_n0 > max_n1 ? max_n0 : max_n1;
     ws->dim = dim; ws->max_iters = max_iters > 0 ? max_iters : 1;
+    ws->max_pairs = max_pairs; ws->zP = 1; ws->z = lr_zargs{ 0, nullptr };
     {
         const char *e = getenv("LIDARREG_NN_PATH");
         ws->nn_path = (e && strcmp(e, "fp32") == 0) ? LR_NN_PATH_FP32_MFMA : LR_NN_PATH_F16_FILTER;
         const char *b = getenv("LIDARREG_NN_BLOCKS");      // tuning knob: blocks per filter pass (default 512 = 2 per CU; measured best with many pairs in flight)
         ws->nn_blocks_target = b ? atoi(b) : 512;
         if (ws->nn_blocks_target < 1) ws->nn_blocks_target = 1;
+        const char *bb = getenv("LIDARREG_NN_BLOCKS_BATCH");   // the same for a batched call: blocks per pass over all its pairs
+        ws->nn_blocks_batch = bb ? atoi(bb) : 3072;
+        if (ws->nn_blocks_batch < 1) ws->nn_blocks_batch = 1;
         const char *rs = getenv("LIDARREG_REV_STRIPS");
         ws->rev_strips = rs ? atoi(rs) : 16;
         if (ws->rev_strips < 1) ws->rev_strips = 1;
@@ -109,7 +119,9 @@ extern "C" int lr_workspace_create(lr_workspace **out, int max_n0, int max_n1, i
     }
     Carver sizing;
     carve(ws, sizing);
-    ws->bytes = sizing.off + 256;
+    ws->stride = (sizing.off + 511) & ~size_t(255);          // one arena per pair, identical layout
+    const size_t desc_off = ws->stride * (size_t)max_pairs;
+    ws->bytes = desc_off + sizeof(lr_pair_desc) * LR_MAX_BATCH + 256;
     hipError_t e = hipMalloc(&ws->base, ws->bytes);
     if (e != hipSuccess) {
         lr_set_error("lr_workspace_create: hipMalloc(%zu) -> %s", ws->bytes, hipGetErrorString(e));
@@ -119,6 +131,7 @@ extern "C" int lr_workspace_create(lr_workspace **out, int max_n0, int max_n1, i
     Carver real;
     real.base = ws->base;
     carve(ws, real);
+    ws->descs = reinterpret_cast<lr_pair_desc *>(ws->base + desc_off);
     if (hipMemset(ws->base, 0, ws->bytes) != hipSuccess) { (void)hipFree(ws->base); delete ws; lr_set_error("lr_workspace_create: hipMemset failed"); return LR_EHIP; }
     for (int k = 0; k < 6; ++k)
         if (hipEventCreate(&ws->ev[k]) != hipSuccess) { (void)hipFree(ws->base); delete ws; lr_set_error("lr_workspace_create: hipEventCreate failed"); return LR_EHIP; }
@@ -149,14 +162,30 @@ extern "C" int lr_workspace_poison(lr_workspace *ws, int byte, void *stream)
 extern "C" int lr_workspace_lists(lr_workspace *ws, int n0, int32_t *nn_idx1, int32_t *nn_idx2,
                                   int32_t *corr_idx0, int32_t *corr_idx1, void *stream)
 {
+    return lr_workspace_lists_at(ws, 0, n0, nn_idx1, nn_idx2, corr_idx0, corr_idx1, stream);
+}
+
+extern "C" int lr_workspace_lists_at(lr_workspace *ws, int pair, int n0, int32_t *nn_idx1, int32_t *nn_idx2,
+                                     int32_t *corr_idx0, int32_t *corr_idx1, void *stream)
+{
     LR_REQUIRE(ws, LR_EINVAL, "lr_workspace_lists: null workspace");
+    LR_REQUIRE(pair >= 0 && pair < ws->max_pairs, LR_EINVAL, "lr_workspace_lists: pair outside the workspace");
     LR_REQUIRE(n0 > 0 && n0 <= ws->max_n0, LR_ESIZE, "lr_workspace_lists: n0 exceeds the workspace");
     hipStream_t st = (hipStream_t)stream;
-    const size_t nb = sizeof(int32_t) * (size_t)n0;
-    if (nn_idx1) LR_HIP(hipMemcpyAsync(nn_idx1, ws->nn_idx1, nb, hipMemcpyDeviceToDevice, st));
-    if (nn_idx2) LR_HIP(hipMemcpyAsync(nn_idx2, ws->nn_idx2, nb, hipMemcpyDeviceToDevice, st));
-    if (corr_idx0) LR_HIP(hipMemcpyAsync(corr_idx0, ws->corr_idx0, nb, hipMemcpyDeviceToDevice, st));
-    if (corr_idx1) LR_HIP(hipMemcpyAsync(corr_idx1, ws->corr_idx1, nb, hipMemcpyDeviceToDevice, st));
+    const size_t nb = sizeof(int32_t) * (size_t)n0, off = (size_t)pair * ws->stride;
+    auto at = [&](const int32_t *p) { return reinterpret_cast<const char *>(p) + off; };
+    if (nn_idx1) LR_HIP(hipMemcpyAsync(nn_idx1, at(ws->nn_idx1), nb, hipMemcpyDeviceToDevice, st));
+    if (nn_idx2) LR_HIP(hipMemcpyAsync(nn_idx2, at(ws->nn_idx2), nb, hipMemcpyDeviceToDevice, st));
+    if (corr_idx0) LR_HIP(hipMemcpyAsync(corr_idx0, at(ws->corr_idx0), nb, hipMemcpyDeviceToDevice, st));
+    if (corr_idx1) LR_HIP(hipMemcpyAsync(corr_idx1, at(ws->corr_idx1), nb, hipMemcpyDeviceToDevice, st));
+    return LR_OK;
+}
+
+// zero `bytes` of scratch at p (an arena-0 pointer) in the arena of every pair of the call in flight
+int lr_zero_scratch(lr_workspace *ws, void *p, size_t bytes, hipStream_t st)
+{
+    if (ws->zP <= 1) LR_HIP(hipMemsetAsync(p, 0, bytes, st));
+    else LR_HIP(hipMemset2DAsync(p, ws->stride, 0, bytes, (size_t)ws->zP, st));
     return LR_OK;
 }
 
@@ -314,8 +343,11 @@ extern "C" int lr_icp(lr_workspace *ws, const float *xyz0, int n0, const float *
     return lr_icp_run(ws, xyz0, n0, xyz1, n1, T_init, nullptr, max_dist, max_iter, rel_fitness, rel_rmse, T_out, res, (hipStream_t)stream);
 }
 
-__global__ void pair_icp_kernel(const double *__restrict__ T_icp, const lr_icp_result *__restrict__ r, lr_pair_result *__restrict__ out, int have)
+__global__ void pair_icp_kernel(const double *__restrict__ T_icp, const lr_icp_result *__restrict__ r, lr_pair_result *__restrict__ out, int have,
+                                lr_zargs z)
 {
+    lr_z(T_icp, z, blockIdx.z); lr_z(r, z, blockIdx.z);
+    out += blockIdx.z;
     const int k = threadIdx.x;
     if (k < 16) out->T_icp[k] = have ? T_icp[k] : out->T[k];
     if (k == 0) {
@@ -327,8 +359,10 @@ __global__ void pair_icp_kernel(const double *__restrict__ T_icp, const lr_icp_r
 // ------------------------------------------------------------------ a9: the whole pair
 __global__ void pair_result_kernel(const double *__restrict__ T_ransac, const double *__restrict__ T_final,
                                    const lr_ransac_result *__restrict__ rr, const int32_t *__restrict__ counters,
-                                   const int32_t *__restrict__ n_refit, lr_pair_result *__restrict__ out)
+                                   const int32_t *__restrict__ n_refit, lr_pair_result *__restrict__ out, lr_zargs z)
 {
+    lr_z(T_ransac, z, blockIdx.z); lr_z(T_final, z, blockIdx.z); lr_z(rr, z, blockIdx.z); lr_z(counters, z, blockIdx.z); lr_z(n_refit, z, blockIdx.z);
+    out += blockIdx.z;
     const int k = threadIdx.x;
     if (k < 16) { out->T[k] = T_final[k]; out->T_ransac[k] = T_ransac[k]; }
     if (k == 0) {
@@ -343,14 +377,11 @@ __global__ void pair_result_kernel(const double *__restrict__ T_ransac, const do
     if (k < 16) out->T_icp[k] = T_final[k];      // overwritten by pair_icp_kernel when the ICP stage runs
 }
 
-extern "C" int lr_register_pair(lr_workspace *ws, const float *xyz0, const float *xyz1, const float *F0, const float *F1,
-                                int n0, int n1, int dim, const lr_pair_params *p, lr_pair_result *out, void *stream)
+// The stages of FR() for the call in flight: one pair with its pointers as given (ws->zP == 1, ws->z.descs == nullptr), or
+// ws->zP pairs described by ws->z.descs (n0 / n1 are then the largest cloud sizes of the batch: they size the grids).
+static int register_stages(lr_workspace *ws, const float *xyz0, const float *xyz1, const float *F0, const float *F1,
+                           int n0, int n1, int dim, const lr_pair_params *p, lr_pair_result *out, hipStream_t st)
 {
-    LR_TRY(check_nn_args(ws, F0, n0, F1, n1, dim, "lr_register_pair"));
-    LR_REQUIRE(xyz0 && xyz1 && p && out, LR_EINVAL, "lr_register_pair: null pointer");
-    LR_REQUIRE(p->mode == LR_MODE_NO_FILTER || p->mode == LR_MODE_MNN || p->mode == LR_MODE_GPF, LR_EINVAL,
-               "lr_register_pair: unknown mode");
-    hipStream_t st = (hipStream_t)stream;
     int32_t *m_dev = ws->counters + LR_CNT_NCORR;
     int32_t *n_refit = ws->counters + LR_CNT_COUNT - 2;
     // 1. coarse correspondences (FR.py:38): first + second NN of every cloud-0 descriptor
@@ -399,13 +430,57 @@ extern "C" int lr_register_pair(lr_workspace *ws, const float *xyz0, const float
                                 ws->T_tmp + 16, n_refit, ws->res_tmp, st, out));
         T_final = ws->T_tmp + 16;
     } else
-    hipLaunchKernelGGL(pair_result_kernel, dim3(1), dim3(64), 0, st, ws->T_tmp, T_final, ws->res_tmp, ws->counters,
-                       p->refit ? n_refit : (const int32_t *)nullptr, out);
+    hipLaunchKernelGGL(pair_result_kernel, dim3(1, 1, ws->zP), dim3(64), 0, st, ws->T_tmp, T_final, ws->res_tmp, ws->counters,
+                       p->refit ? n_refit : (const int32_t *)nullptr, out, ws->z);
     // 5. ICP refinement (test.py:183-189): max distance 2*voxel, Open3D's default criteria
     lr_icp_result *icp_res = reinterpret_cast<lr_icp_result *>(ws->icp_state + 24);
     if (p->icp)
         LR_TRY(lr_icp_run(ws, xyz0, n0, xyz1, n1, T_final, ws->res_tmp, 0.6, 30, 1e-6, 1e-6, ws->T_tmp, icp_res, st));
-    if (p->icp) hipLaunchKernelGGL(pair_icp_kernel, dim3(1), dim3(64), 0, st, ws->T_tmp, icp_res, out, 1);
+    if (p->icp) hipLaunchKernelGGL(pair_icp_kernel, dim3(1, 1, ws->zP), dim3(64), 0, st, ws->T_tmp, icp_res, out, 1, ws->z);
     LR_LAUNCH_CHECK();
     return LR_OK;
+}
+
+extern "C" int lr_register_pair(lr_workspace *ws, const float *xyz0, const float *xyz1, const float *F0, const float *F1,
+                                int n0, int n1, int dim, const lr_pair_params *p, lr_pair_result *out, void *stream)
+{
+    LR_TRY(check_nn_args(ws, F0, n0, F1, n1, dim, "lr_register_pair"));
+    LR_REQUIRE(xyz0 && xyz1 && p && out, LR_EINVAL, "lr_register_pair: null pointer");
+    LR_REQUIRE(p->mode == LR_MODE_NO_FILTER || p->mode == LR_MODE_MNN || p->mode == LR_MODE_GPF, LR_EINVAL,
+               "lr_register_pair: unknown mode");
+    ws->zP = 1; ws->z = lr_zargs{ 0, nullptr };
+    return register_stages(ws, xyz0, xyz1, F0, F1, n0, n1, dim, p, out, (hipStream_t)stream);
+}
+
+// descriptor table -> device memory (it travels as a kernel argument: no host staging buffer, no copy engine)
+__global__ void batch_setup_kernel(lr_desc_table t, lr_pair_desc *__restrict__ descs, int npairs)
+{
+    const int k = threadIdx.x;
+    if (k < npairs) descs[k] = t.d[k];
+}
+
+extern "C" int lr_register_batch(lr_workspace *ws, int npairs, const float *const *xyz0, const float *const *xyz1,
+                                 const float *const *F0, const float *const *F1, const int32_t *n0, const int32_t *n1, int dim,
+                                 const lr_pair_params *p, lr_pair_result *out, void *stream)
+{
+    LR_REQUIRE(ws && xyz0 && xyz1 && F0 && F1 && n0 && n1 && p && out, LR_EINVAL, "lr_register_batch: null pointer");
+    LR_REQUIRE(npairs >= 1 && npairs <= ws->max_pairs, LR_ESIZE, "lr_register_batch: npairs exceeds the workspace (lr_workspace_create_batch)");
+    LR_REQUIRE(p->mode == LR_MODE_NO_FILTER || p->mode == LR_MODE_MNN || p->mode == LR_MODE_GPF, LR_EINVAL,
+               "lr_register_batch: unknown mode");
+    LR_REQUIRE(ws->nn_path != LR_NN_PATH_FP32_MFMA, LR_EINVAL, "lr_register_batch: the fp32 cross-check path (LIDARREG_NN_PATH=fp32) is single-pair only");
+    lr_desc_table t;
+    int mx0 = 0, mx1 = 0;
+    for (int k = 0; k < npairs; ++k) {
+        LR_REQUIRE(xyz0[k] && xyz1[k], LR_EINVAL, "lr_register_batch: null pointer");
+        LR_TRY(check_nn_args(ws, F0[k], n0[k], F1[k], n1[k], dim, "lr_register_batch"));
+        t.d[k] = lr_pair_desc{ xyz0[k], xyz1[k], F0[k], F1[k], n0[k], n1[k] };
+        mx0 = n0[k] > mx0 ? n0[k] : mx0; mx1 = n1[k] > mx1 ? n1[k] : mx1;
+    }
+    for (int k = npairs; k < LR_MAX_BATCH; ++k) t.d[k] = lr_pair_desc{ nullptr, nullptr, nullptr, nullptr, 0, 0 };
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(batch_setup_kernel, dim3(1), dim3(64), 0, st, t, ws->descs, npairs);
+    ws->zP = npairs; ws->z = lr_zargs{ ws->stride, ws->descs };
+    const int rc = register_stages(ws, xyz0[0], xyz1[0], F0[0], F1[0], mx0, mx1, dim, p, out, st);
+    ws->zP = 1; ws->z = lr_zargs{ 0, nullptr };
+    return rc;
 }

@@ -26,8 +26,10 @@ __device__ __forceinline__ void block_count(bool k, int32_t *__restrict__ blk_cn
 // keep[i] = rev[idx1[i]] == i  (torch_intersect, matching.py:67-87, reduced to its gather-compare core)
 __global__ void __launch_bounds__(256)
 mutual_flag_kernel(int n0, const int32_t *__restrict__ idx1, const int32_t *__restrict__ rev,
-                   uint8_t *__restrict__ is_bb, int32_t *__restrict__ blk_cnt)
+                   uint8_t *__restrict__ is_bb, int32_t *__restrict__ blk_cnt, lr_zargs z)
 {
+    if (z.descs) n0 = z.descs[blockIdx.z].n0;
+    lr_z(idx1, z, blockIdx.z); lr_z(rev, z, blockIdx.z); lr_z(is_bb, z, blockIdx.z); lr_z(blk_cnt, z, blockIdx.z);
     const int i = blockIdx.x * 256 + threadIdx.x;
     const bool k = i < n0 && rev[idx1[i]] == i;
     if (i < n0) is_bb[i] = k ? 1 : 0;
@@ -35,8 +37,10 @@ mutual_flag_kernel(int n0, const int32_t *__restrict__ idx1, const int32_t *__re
 }
 
 __global__ void __launch_bounds__(256)
-count_flags_kernel(int n0, const int32_t *__restrict__ m_dev, const uint8_t *__restrict__ flags, int32_t *__restrict__ blk_cnt)
+count_flags_kernel(int n0, const int32_t *__restrict__ m_dev, const uint8_t *__restrict__ flags, int32_t *__restrict__ blk_cnt, lr_zargs z)
 {
+    if (z.descs) n0 = z.descs[blockIdx.z].n0;
+    lr_z(m_dev, z, blockIdx.z); lr_z(flags, z, blockIdx.z); lr_z(blk_cnt, z, blockIdx.z);
     if (m_dev) n0 = min(n0, *m_dev);
     const int i = blockIdx.x * 256 + threadIdx.x;
     block_count(i < n0 && flags[i] != 0, blk_cnt);
@@ -49,10 +53,12 @@ compact_kernel(int n0, const uint8_t *__restrict__ flags, const int32_t *__restr
                int32_t *__restrict__ o0, int32_t *__restrict__ o1, int32_t *__restrict__ o2, float *__restrict__ oscore,
                int32_t *__restrict__ n_out, int32_t *__restrict__ n_out2,
                const float *__restrict__ xyz0, const float *__restrict__ xyz1, float *__restrict__ corr8, int32_t *__restrict__ counters,
-               const int32_t *__restrict__ m_dev = nullptr, const int32_t *__restrict__ src0 = nullptr)
+               lr_zargs z, const int32_t *__restrict__ m_dev = nullptr, const int32_t *__restrict__ src0 = nullptr)
 {
     __shared__ int s_wave[4];
     __shared__ int s_part[4];
+    if (z.descs) { const lr_pair_desc d = z.descs[blockIdx.z]; n0 = d.n0; if (xyz0) { xyz0 = d.xyz0; xyz1 = d.xyz1; } }
+    lr_z(flags, z, blockIdx.z); lr_z(blk_cnt, z, blockIdx.z); lr_z(idx1, z, blockIdx.z); lr_z(idx2, z, blockIdx.z); lr_z(score, z, blockIdx.z); lr_z(o0, z, blockIdx.z); lr_z(o1, z, blockIdx.z); lr_z(o2, z, blockIdx.z); lr_z(oscore, z, blockIdx.z); lr_z(n_out, z, blockIdx.z); lr_z(n_out2, z, blockIdx.z); lr_z(corr8, z, blockIdx.z); lr_z(counters, z, blockIdx.z); lr_z(m_dev, z, blockIdx.z); lr_z(src0, z, blockIdx.z);
     if (m_dev) n0 = min(n0, *m_dev);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int c = 0;
@@ -99,18 +105,20 @@ int lr_mutual_run(lr_workspace *ws, int n0, const int32_t *idx1, const int32_t *
 {
     const int nb = lr_cdiv(n0, 256);
     uint8_t *flags = is_bb ? is_bb : ws->is_bb;
-    hipLaunchKernelGGL(mutual_flag_kernel, dim3(nb), dim3(256), 0, st, n0, idx1, rev, flags, ws->blk_cnt);
+    hipLaunchKernelGGL(mutual_flag_kernel, dim3(nb, 1, ws->zP), dim3(256), 0, st, n0, idx1, rev, flags, ws->blk_cnt, ws->z);
     // the number of best buddies is wanted even when no list is (GPF's TOTAL_NUM, matching.py:115-116)
-    hipLaunchKernelGGL(compact_kernel, dim3(nb), dim3(256), 0, st, n0, flags, ws->blk_cnt, idx1, idx2, (const float *)nullptr,
-                       o0, o1, o2, (float *)nullptr, n_out, ws->counters + LR_CNT_NBB, xyz0, xyz1, corr8, ws->counters);
+    hipLaunchKernelGGL(compact_kernel, dim3(nb, 1, ws->zP), dim3(256), 0, st, n0, flags, ws->blk_cnt, idx1, idx2, (const float *)nullptr,
+                       o0, o1, o2, (float *)nullptr, n_out, ws->counters + LR_CNT_NBB, xyz0, xyz1, corr8, ws->counters, ws->z);
     LR_LAUNCH_CHECK();
     return LR_OK;
 }
 
 // mode "no_filter" (FR.py:53-54): every NN pair survives
 __global__ void identity_corr_kernel(int n0, const int32_t *__restrict__ idx1, const int32_t *__restrict__ idx2,
-                                     int32_t *o0, int32_t *o1, int32_t *o2, int32_t *n_out)
+                                     int32_t *o0, int32_t *o1, int32_t *o2, int32_t *n_out, lr_zargs z)
 {
+    if (z.descs) n0 = z.descs[blockIdx.z].n0;
+    lr_z(idx1, z, blockIdx.z); lr_z(idx2, z, blockIdx.z); lr_z(o0, z, blockIdx.z); lr_z(o1, z, blockIdx.z); lr_z(o2, z, blockIdx.z); lr_z(n_out, z, blockIdx.z);
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n0) {
         o0[i] = i; o1[i] = idx1[i];
@@ -122,8 +130,7 @@ __global__ void identity_corr_kernel(int n0, const int32_t *__restrict__ idx1, c
 int lr_identity_corr(lr_workspace *ws, int n0, const int32_t *idx1, const int32_t *idx2,
                      int32_t *o0, int32_t *o1, int32_t *o2, int32_t *n_out, hipStream_t st)
 {
-    (void)ws;
-    hipLaunchKernelGGL(identity_corr_kernel, dim3(lr_cdiv(n0, 256)), dim3(256), 0, st, n0, idx1, idx2, o0, o1, o2, n_out);
+    hipLaunchKernelGGL(identity_corr_kernel, dim3(lr_cdiv(n0, 256), 1, ws->zP), dim3(256), 0, st, n0, idx1, idx2, o0, o1, o2, n_out, ws->z);
     LR_LAUNCH_CHECK();
     return LR_OK;
 }
@@ -134,8 +141,10 @@ int lr_identity_corr(lr_workspace *ws, int n0, const int32_t *idx1, const int32_
 __global__ void pack_corr_kernel(const float *__restrict__ xyz0, const float *__restrict__ xyz1,
                                  const int32_t *__restrict__ i0, const int32_t *__restrict__ i1,
                                  int m_max, const int32_t *__restrict__ m_dev, float *__restrict__ corr8,
-                                 int32_t *__restrict__ counters, const int32_t *__restrict__ rank)
+                                 int32_t *__restrict__ counters, const int32_t *__restrict__ rank, lr_zargs z)
 {
+    if (z.descs) { xyz0 = z.descs[blockIdx.z].xyz0; xyz1 = z.descs[blockIdx.z].xyz1; }
+    lr_z(i0, z, blockIdx.z); lr_z(i1, z, blockIdx.z); lr_z(m_dev, z, blockIdx.z); lr_z(corr8, z, blockIdx.z); lr_z(counters, z, blockIdx.z); lr_z(rank, z, blockIdx.z);
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < LR_CNT_TOTAL - LR_CNT_COUNT) counters[LR_CNT_COUNT + c] = 0;     // the RANSAC that follows starts from scratch
     if (c == 0) counters[LR_CNT_NVALID] = 0;
@@ -153,8 +162,8 @@ __global__ void pack_corr_kernel(const float *__restrict__ xyz0, const float *__
 int lr_pack_corr(lr_workspace *ws, const float *xyz0, const float *xyz1, const int32_t *i0, const int32_t *i1, int m_max,
                  const int32_t *m_dev, float *corr8, hipStream_t st, const int32_t *rank)
 {
-    hipLaunchKernelGGL(pack_corr_kernel, dim3(lr_cdiv(m_max > 0 ? m_max : 1, 256)), dim3(256), 0, st, xyz0, xyz1, i0, i1, m_max, m_dev, corr8,
-                       ws->counters, rank);
+    hipLaunchKernelGGL(pack_corr_kernel, dim3(lr_cdiv(m_max > 0 ? m_max : 1, 256), 1, ws->zP), dim3(256), 0, st, xyz0, xyz1, i0, i1, m_max, m_dev, corr8,
+                       ws->counters, rank, ws->z);
     LR_LAUNCH_CHECK();
     return LR_OK;
 }
@@ -176,8 +185,9 @@ __device__ __forceinline__ int pr_bucket(float v, float lo, float scale)
 // one block: range of the finite values, bucket histogram in LDS, exclusive offsets -> offs[0..B], fill = copy of offs
 __global__ void __launch_bounds__(1024)
 prosac_scan_kernel(const float *__restrict__ q, int m_max, const int32_t *__restrict__ m_dev, int32_t *__restrict__ offs,
-                   int32_t *__restrict__ fill, float *__restrict__ range)
+                   int32_t *__restrict__ fill, float *__restrict__ range, lr_zargs z)
 {
+    lr_z(q, z, blockIdx.z); lr_z(m_dev, z, blockIdx.z); lr_z(offs, z, blockIdx.z); lr_z(fill, z, blockIdx.z); lr_z(range, z, blockIdx.z);
     __shared__ int s_h[LR_PR_BUCKETS];
     __shared__ float s_lo[16], s_hi[16];
     __shared__ int s_w[16];
@@ -221,8 +231,9 @@ prosac_scan_kernel(const float *__restrict__ q, int m_max, const int32_t *__rest
 
 __global__ void __launch_bounds__(256)
 prosac_scatter_kernel(const float *__restrict__ q, int m_max, const int32_t *__restrict__ m_dev, const float *__restrict__ range,
-                      int32_t *__restrict__ fill, int32_t *__restrict__ members)
+                      int32_t *__restrict__ fill, int32_t *__restrict__ members, lr_zargs z)
 {
+    lr_z(q, z, blockIdx.z); lr_z(m_dev, z, blockIdx.z); lr_z(range, z, blockIdx.z); lr_z(fill, z, blockIdx.z); lr_z(members, z, blockIdx.z);
     const int m = m_dev ? min(*m_dev, m_max) : m_max;
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= m) return;
@@ -231,8 +242,9 @@ prosac_scatter_kernel(const float *__restrict__ q, int m_max, const int32_t *__r
 
 __global__ void __launch_bounds__(256)
 prosac_rank_kernel(const float *__restrict__ q, int m_max, const int32_t *__restrict__ m_dev, const float *__restrict__ range,
-                   const int32_t *__restrict__ offs, const int32_t *__restrict__ members, int32_t *__restrict__ rank)
+                   const int32_t *__restrict__ offs, const int32_t *__restrict__ members, int32_t *__restrict__ rank, lr_zargs z)
 {
+    lr_z(q, z, blockIdx.z); lr_z(m_dev, z, blockIdx.z); lr_z(range, z, blockIdx.z); lr_z(offs, z, blockIdx.z); lr_z(members, z, blockIdx.z); lr_z(rank, z, blockIdx.z);
     const int m = m_dev ? min(*m_dev, m_max) : m_max;
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= m) return;
@@ -250,7 +262,7 @@ prosac_rank_kernel(const float *__restrict__ q, int m_max, const int32_t *__rest
 
 __global__ void ratio_kernel(const float *__restrict__ F0, const float *__restrict__ F1, int dim, int m, const int32_t *__restrict__ m_dev,
                              const int32_t *__restrict__ i0, const int32_t *__restrict__ i1, const int32_t *__restrict__ i2,
-                             float *__restrict__ out, uint32_t *__restrict__ mm, const float *__restrict__ xyz0);
+                             float *__restrict__ out, uint32_t *__restrict__ mm, const float *__restrict__ xyz0, lr_zargs z);
 
 // quality = feature-distance ratio of the listed pairs (FR.py:77) unless the caller has one already (GPF's
 // norm_feat_dist, FR.py:75); then the ranks
@@ -259,17 +271,17 @@ int lr_prosac_order(lr_workspace *ws, const float *F0, const float *F1, int dim,
 {
     const int nb = lr_cdiv(m_max > 0 ? m_max : 1, 256);
     if (!quality) {
-        hipLaunchKernelGGL(ratio_kernel, dim3(nb), dim3(256), 0, st, F0, F1, dim, m_max, m_dev, (const int32_t *)ws->corr_idx0,
-                           (const int32_t *)ws->corr_idx1, (const int32_t *)ws->corr_idx2, ws->ratio, (uint32_t *)nullptr, (const float *)nullptr);
+        hipLaunchKernelGGL(ratio_kernel, dim3(nb, 1, ws->zP), dim3(256), 0, st, F0, F1, dim, m_max, m_dev, (const int32_t *)ws->corr_idx0,
+                           (const int32_t *)ws->corr_idx1, (const int32_t *)ws->corr_idx2, ws->ratio, (uint32_t *)nullptr, (const float *)nullptr, ws->z);
         quality = ws->ratio;
     }
     // GPF's scratch is free by now: offsets | fill | range in its cell arrays, bucket members in its sort buffer
     int32_t *offs = ws->gpf_cells, *fill = offs + LR_GPF_MAX_CELLS + 8;
     float *range = reinterpret_cast<float *>(fill + LR_GPF_MAX_CELLS + 8);
-    hipLaunchKernelGGL(prosac_scan_kernel, dim3(1), dim3(1024), 0, st, quality, m_max, m_dev, offs, fill, range);
-    hipLaunchKernelGGL(prosac_scatter_kernel, dim3(nb), dim3(256), 0, st, quality, m_max, m_dev, (const float *)range, fill, ws->cell_sorted);
-    hipLaunchKernelGGL(prosac_rank_kernel, dim3(nb), dim3(256), 0, st, quality, m_max, m_dev, (const float *)range, (const int32_t *)offs,
-                       (const int32_t *)ws->cell_sorted, ws->prosac_rank);
+    hipLaunchKernelGGL(prosac_scan_kernel, dim3(1, 1, ws->zP), dim3(1024), 0, st, quality, m_max, m_dev, offs, fill, range, ws->z);
+    hipLaunchKernelGGL(prosac_scatter_kernel, dim3(nb, 1, ws->zP), dim3(256), 0, st, quality, m_max, m_dev, (const float *)range, fill, ws->cell_sorted, ws->z);
+    hipLaunchKernelGGL(prosac_rank_kernel, dim3(nb, 1, ws->zP), dim3(256), 0, st, quality, m_max, m_dev, (const float *)range, (const int32_t *)offs,
+                       (const int32_t *)ws->cell_sorted, ws->prosac_rank, ws->z);
     LR_LAUNCH_CHECK();
     return LR_OK;
 }
@@ -285,9 +297,11 @@ __device__ __forceinline__ float lr_dec(uint32_t e) { return __uint_as_float((e 
 __global__ void __launch_bounds__(256)
 ratio_kernel(const float *__restrict__ F0, const float *__restrict__ F1, int dim, int m, const int32_t *__restrict__ m_dev,
              const int32_t *__restrict__ i0, const int32_t *__restrict__ i1, const int32_t *__restrict__ i2,
-             float *__restrict__ out, uint32_t *__restrict__ mm, const float *__restrict__ xyz0)
+             float *__restrict__ out, uint32_t *__restrict__ mm, const float *__restrict__ xyz0, lr_zargs z)
 {
     __shared__ float s_r[6][4];
+    if (z.descs) { const lr_pair_desc d = z.descs[blockIdx.z]; F0 = d.F0; F1 = d.F1; if (xyz0) xyz0 = d.xyz0; if (!m_dev) m = min(m, d.n0); }
+    lr_z(m_dev, z, blockIdx.z); lr_z(i0, z, blockIdx.z); lr_z(i1, z, blockIdx.z); lr_z(i2, z, blockIdx.z); lr_z(out, z, blockIdx.z); lr_z(mm, z, blockIdx.z);
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (m_dev) m = min(m, *m_dev);
     float v[3] = { 0.0f, 0.0f, 0.0f };
@@ -352,7 +366,7 @@ extern "C" int lr_feat_ratio(const float *F0, const float *F1, int dim, int m, c
     LR_REQUIRE(F0 && F1 && i1 && i2 && out && dim > 0 && m >= 0, LR_EINVAL, "lr_feat_ratio: bad argument");
     if (m == 0) return LR_OK;
     hipLaunchKernelGGL(ratio_kernel, dim3(lr_cdiv(m, 256)), dim3(256), 0, (hipStream_t)stream, F0, F1, dim, m,
-                       (const int32_t *)nullptr, i0, i1, i2, out, (uint32_t *)nullptr, (const float *)nullptr);
+                       (const int32_t *)nullptr, i0, i1, i2, out, (uint32_t *)nullptr, (const float *)nullptr, lr_zargs{ 0, nullptr });
     LR_LAUNCH_CHECK();
     return LR_OK;
 }
@@ -379,10 +393,12 @@ __device__ __forceinline__ float wave_max(float v) {
 __global__ void __launch_bounds__(256)
 gpf_score_cell_kernel(int n0, int G, const uint32_t *__restrict__ mm, const uint8_t *__restrict__ is_bb,
                       const float *__restrict__ xyz0, float *__restrict__ ratio_inout, int32_t *__restrict__ cell,
-                      int32_t *__restrict__ cell_count, const int32_t *__restrict__ m_dev = nullptr,
+                      int32_t *__restrict__ cell_count, lr_zargs z, const int32_t *__restrict__ m_dev = nullptr,
                       const int32_t *__restrict__ pidx = nullptr)
 {
     __shared__ int s_cnt[LR_GPF_MAX_CELLS];
+    if (z.descs) { n0 = z.descs[blockIdx.z].n0; xyz0 = z.descs[blockIdx.z].xyz0; }
+    lr_z(mm, z, blockIdx.z); lr_z(is_bb, z, blockIdx.z); lr_z(ratio_inout, z, blockIdx.z); lr_z(cell, z, blockIdx.z); lr_z(cell_count, z, blockIdx.z); lr_z(m_dev, z, blockIdx.z); lr_z(pidx, z, blockIdx.z);
     const int C = G * G;
     for (int k = threadIdx.x; k < C; k += 256) s_cnt[k] = 0;
     __syncthreads();
@@ -449,10 +465,11 @@ __device__ __forceinline__ double gpf_pairwise_sum(const double *m, int n, doubl
 __global__ void __launch_bounds__(64)
 gpf_waterfill_kernel(int G, double factor, const int32_t *__restrict__ counters,
                      const int32_t *__restrict__ cell_count, double *__restrict__ quota,
-                     int32_t *__restrict__ cell_off, double total_fixed = -1.0,
+                     int32_t *__restrict__ cell_off, lr_zargs z, double total_fixed = -1.0,
                      const int32_t *__restrict__ m_dev = nullptr, int32_t *__restrict__ has_score = nullptr)
 {
     __shared__ double s_m[LR_GPF_MAX_CELLS];
+    lr_z(counters, z, blockIdx.z); lr_z(cell_count, z, blockIdx.z); lr_z(quota, z, blockIdx.z); lr_z(cell_off, z, blockIdx.z); lr_z(m_dev, z, blockIdx.z); lr_z(has_score, z, blockIdx.z);
     __shared__ double s_hr;
     const int C = G * G;
     for (int c = threadIdx.x; c < C; c += 64) s_m[c] = (double)cell_count[c];
@@ -523,9 +540,11 @@ gpf_waterfill_kernel(int G, double factor, const int32_t *__restrict__ counters,
 // from LDS atomics, one global atomic per (block, occupied cell) reserves the block's range
 __global__ void __launch_bounds__(256)
 gpf_bucket_kernel(int n0, int G, const int32_t *__restrict__ cell, const int32_t *__restrict__ cell_off,
-                  int32_t *__restrict__ cell_fill, int32_t *__restrict__ bucket, const int32_t *__restrict__ m_dev = nullptr)
+                  int32_t *__restrict__ cell_fill, int32_t *__restrict__ bucket, lr_zargs z, const int32_t *__restrict__ m_dev = nullptr)
 {
     __shared__ int s_cnt[LR_GPF_MAX_CELLS];
+    if (z.descs) n0 = z.descs[blockIdx.z].n0;
+    lr_z(cell, z, blockIdx.z); lr_z(cell_off, z, blockIdx.z); lr_z(cell_fill, z, blockIdx.z); lr_z(bucket, z, blockIdx.z); lr_z(m_dev, z, blockIdx.z);
     const int C = G * G;
     for (int k = threadIdx.x; k < C; k += 256) s_cnt[k] = 0;
     __syncthreads();
@@ -549,8 +568,10 @@ __global__ void __launch_bounds__(256)
 gpf_select_kernel(int n0, const int32_t *__restrict__ cell, const int32_t *__restrict__ cell_off,
                   const int32_t *__restrict__ cell_count, const double *__restrict__ quota,
                   const int32_t *__restrict__ bucket, const float *__restrict__ score, uint8_t *__restrict__ keep,
-                  int C, const int32_t *__restrict__ m_dev = nullptr)
+                  int C, lr_zargs z, const int32_t *__restrict__ m_dev = nullptr)
 {
+    if (z.descs) n0 = z.descs[blockIdx.z].n0;
+    lr_z(cell, z, blockIdx.z); lr_z(cell_off, z, blockIdx.z); lr_z(cell_count, z, blockIdx.z); lr_z(quota, z, blockIdx.z); lr_z(bucket, z, blockIdx.z); lr_z(score, z, blockIdx.z); lr_z(keep, z, blockIdx.z); lr_z(m_dev, z, blockIdx.z);
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (m_dev) n0 = min(n0, *m_dev);
     if (i >= n0) return;
@@ -589,19 +610,20 @@ int lr_gpf_run(lr_workspace *ws, const float *F0, int n0, const float *F1, int d
     const int nb = lr_cdiv(n0, 256);
     // one memset clears the cell counters and the six min/max slots behind them (atomicMax on encoded values, 0 = identity)
     uint32_t *mm = reinterpret_cast<uint32_t *>(cell_fill + LR_GPF_MAX_CELLS);
-    LR_HIP(hipMemsetAsync(cell_count, 0, sizeof(int32_t) * 2 * (LR_GPF_MAX_CELLS + 8), st));
+    LR_TRY_HIP(lr_zero_scratch(ws, cell_count, sizeof(int32_t) * 2 * (LR_GPF_MAX_CELLS + 8), st));
+    const dim3 gN(nb, 1, ws->zP), g1(1, 1, ws->zP);
     // ratio over all n0 NN pairs (corres_idx0 == arange), and the extrema of ratio / x / y
-    hipLaunchKernelGGL(ratio_kernel, dim3(nb), dim3(256), 0, st, F0, F1, dim, n0, (const int32_t *)nullptr,
-                       (const int32_t *)nullptr, idx1, idx2, ws->ratio, mm, xyz0);
-    hipLaunchKernelGGL(gpf_score_cell_kernel, dim3(nb), dim3(256), 0, st, n0, G, (const uint32_t *)mm, is_bb, xyz0, ws->ratio,
-                       ws->cell, cell_count);
-    hipLaunchKernelGGL(gpf_waterfill_kernel, dim3(1), dim3(64), 0, st, G, factor, ws->counters, cell_count, quota, cell_off);
-    hipLaunchKernelGGL(gpf_bucket_kernel, dim3(nb), dim3(256), 0, st, n0, G, ws->cell, cell_off, cell_fill, ws->cell_sorted);
-    hipLaunchKernelGGL(gpf_select_kernel, dim3(nb), dim3(256), 0, st, n0, ws->cell, cell_off, cell_count, quota,
-                       ws->cell_sorted, ws->ratio, keep, G * G);
-    hipLaunchKernelGGL(count_flags_kernel, dim3(nb), dim3(256), 0, st, n0, (const int32_t *)nullptr, keep, ws->blk_cnt);
-    hipLaunchKernelGGL(compact_kernel, dim3(nb), dim3(256), 0, st, n0, keep, ws->blk_cnt, idx1, idx2, ws->ratio, o0, o1, o2, oscore,
-                       n_out, (int32_t *)nullptr, xyz0, xyz1, corr8, ws->counters);
+    hipLaunchKernelGGL(ratio_kernel, gN, dim3(256), 0, st, F0, F1, dim, n0, (const int32_t *)nullptr,
+                       (const int32_t *)nullptr, idx1, idx2, ws->ratio, mm, xyz0, ws->z);
+    hipLaunchKernelGGL(gpf_score_cell_kernel, gN, dim3(256), 0, st, n0, G, (const uint32_t *)mm, is_bb, xyz0, ws->ratio,
+                       ws->cell, cell_count, ws->z);
+    hipLaunchKernelGGL(gpf_waterfill_kernel, g1, dim3(64), 0, st, G, factor, ws->counters, cell_count, quota, cell_off, ws->z);
+    hipLaunchKernelGGL(gpf_bucket_kernel, gN, dim3(256), 0, st, n0, G, ws->cell, cell_off, cell_fill, ws->cell_sorted, ws->z);
+    hipLaunchKernelGGL(gpf_select_kernel, gN, dim3(256), 0, st, n0, ws->cell, cell_off, cell_count, quota,
+                       ws->cell_sorted, ws->ratio, keep, G * G, ws->z);
+    hipLaunchKernelGGL(count_flags_kernel, gN, dim3(256), 0, st, n0, (const int32_t *)nullptr, keep, ws->blk_cnt, ws->z);
+    hipLaunchKernelGGL(compact_kernel, gN, dim3(256), 0, st, n0, keep, ws->blk_cnt, idx1, idx2, ws->ratio, o0, o1, o2, oscore,
+                       n_out, (int32_t *)nullptr, xyz0, xyz1, corr8, ws->counters, ws->z);
     LR_LAUNCH_CHECK();
     return LR_OK;
 }
@@ -622,18 +644,20 @@ int lr_gpf_bb_run(lr_workspace *ws, const float *F0, int n0, const float *F1, in
     uint8_t *keep = ws->gpf_keep;
     const int nb = lr_cdiv(n0, 256);
     uint32_t *mm = reinterpret_cast<uint32_t *>(cell_fill + LR_GPF_MAX_CELLS);
+    // (single-pair operator only: the reference's TEASER wrapper is not on the batched path)
+    const lr_zargs z1 = { 0, nullptr };
     LR_HIP(hipMemsetAsync(cell_count, 0, sizeof(int32_t) * 2 * (LR_GPF_MAX_CELLS + 8), st));
-    hipLaunchKernelGGL(ratio_kernel, dim3(nb), dim3(256), 0, st, F0, F1, dim, n0, mb_dev, b0, b1, b2, ws->ratio, mm, xyz0);
+    hipLaunchKernelGGL(ratio_kernel, dim3(nb), dim3(256), 0, st, F0, F1, dim, n0, mb_dev, b0, b1, b2, ws->ratio, mm, xyz0, z1);
     hipLaunchKernelGGL(gpf_score_cell_kernel, dim3(nb), dim3(256), 0, st, n0, G, (const uint32_t *)mm, (const uint8_t *)nullptr, xyz0, ws->ratio,
-                       ws->cell, cell_count, mb_dev, b0);
-    hipLaunchKernelGGL(gpf_waterfill_kernel, dim3(1), dim3(64), 0, st, G, 0.0, ws->counters, cell_count, quota, cell_off, max_matches,
+                       ws->cell, cell_count, z1, mb_dev, b0);
+    hipLaunchKernelGGL(gpf_waterfill_kernel, dim3(1), dim3(64), 0, st, G, 0.0, ws->counters, cell_count, quota, cell_off, z1, max_matches,
                        mb_dev, has_score);
-    hipLaunchKernelGGL(gpf_bucket_kernel, dim3(nb), dim3(256), 0, st, n0, G, ws->cell, cell_off, cell_fill, ws->cell_sorted, mb_dev);
+    hipLaunchKernelGGL(gpf_bucket_kernel, dim3(nb), dim3(256), 0, st, n0, G, ws->cell, cell_off, cell_fill, ws->cell_sorted, z1, mb_dev);
     hipLaunchKernelGGL(gpf_select_kernel, dim3(nb), dim3(256), 0, st, n0, ws->cell, cell_off, cell_count, quota,
-                       ws->cell_sorted, ws->ratio, keep, G * G, mb_dev);
-    hipLaunchKernelGGL(count_flags_kernel, dim3(nb), dim3(256), 0, st, n0, mb_dev, keep, ws->blk_cnt);
+                       ws->cell_sorted, ws->ratio, keep, G * G, z1, mb_dev);
+    hipLaunchKernelGGL(count_flags_kernel, dim3(nb), dim3(256), 0, st, n0, mb_dev, keep, ws->blk_cnt, z1);
     hipLaunchKernelGGL(compact_kernel, dim3(nb), dim3(256), 0, st, n0, keep, ws->blk_cnt, b1, b2, ws->ratio, o0, o1, o2, oscore,
-                       n_out, (int32_t *)nullptr, (const float *)nullptr, (const float *)nullptr, (float *)nullptr, ws->counters, mb_dev, b0);
+                       n_out, (int32_t *)nullptr, (const float *)nullptr, (const float *)nullptr, (float *)nullptr, ws->counters, z1, mb_dev, b0);
     LR_LAUNCH_CHECK();
     return LR_OK;
 }

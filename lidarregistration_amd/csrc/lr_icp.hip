@@ -25,8 +25,10 @@ __device__ __forceinline__ uint32_t icp_hash(int ix, int iy, int iz)
 }
 
 __global__ void __launch_bounds__(256)
-icp_hist_kernel(const float *__restrict__ xyz, int n, double inv_cell, int32_t *__restrict__ bucket_of, int32_t *__restrict__ hist)
+icp_hist_kernel(const float *__restrict__ xyz, int n, double inv_cell, int32_t *__restrict__ bucket_of, int32_t *__restrict__ hist, lr_zargs z)
 {
+    if (z.descs) { xyz = z.descs[blockIdx.z].xyz1; n = z.descs[blockIdx.z].n1; }
+    lr_z(bucket_of, z, blockIdx.z); lr_z(hist, z, blockIdx.z);
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
     const int ix = (int)floor((double)xyz[3 * j] * inv_cell), iy = (int)floor((double)xyz[3 * j + 1] * inv_cell),
@@ -38,8 +40,9 @@ icp_hist_kernel(const float *__restrict__ xyz, int n, double inv_cell, int32_t *
 
 // exclusive scan of the LR_ICP_NB bucket counts (one block; each thread owns LR_ICP_NB/1024 consecutive buckets)
 __global__ void __launch_bounds__(1024)
-icp_scan_kernel(const int32_t *__restrict__ hist, int32_t *__restrict__ start)
+icp_scan_kernel(const int32_t *__restrict__ hist, int32_t *__restrict__ start, lr_zargs z)
 {
+    lr_z(hist, z, blockIdx.z); lr_z(start, z, blockIdx.z);
     __shared__ int s_w[16];
     constexpr int PER = LR_ICP_NB / 1024;
     int local[PER];
@@ -63,8 +66,10 @@ icp_scan_kernel(const int32_t *__restrict__ hist, int32_t *__restrict__ start)
 
 __global__ void __launch_bounds__(256)
 icp_scatter_kernel(int n, const int32_t *__restrict__ bucket_of, const int32_t *__restrict__ start, int32_t *__restrict__ fill,
-                   const float *__restrict__ tgt, float4 *__restrict__ pts)
+                   const float *__restrict__ tgt, float4 *__restrict__ pts, lr_zargs z)
 {
+    if (z.descs) { tgt = z.descs[blockIdx.z].xyz1; n = z.descs[blockIdx.z].n1; }
+    lr_z(bucket_of, z, blockIdx.z); lr_z(start, z, blockIdx.z); lr_z(fill, z, blockIdx.z); lr_z(pts, z, blockIdx.z);
     // the bucket holds the points themselves, { x, y, z, index bits }: the search loop then reads one contiguous 16-byte
     // record per candidate instead of chasing index -> coordinates
     const int j = blockIdx.x * 256 + threadIdx.x;
@@ -77,8 +82,9 @@ icp_scatter_kernel(int n, const int32_t *__restrict__ bucket_of, const int32_t *
 // [19] done flag, [20] fitness of the last evaluation, [21] its rmse, [22] its correspondence count, [23] ticket (as int)
 #define LR_ICP_STATE 32
 
-__global__ void icp_init_kernel(const double *__restrict__ T_init, const lr_ransac_result *__restrict__ gate, double *__restrict__ state)
+__global__ void icp_init_kernel(const double *__restrict__ T_init, const lr_ransac_result *__restrict__ gate, double *__restrict__ state, lr_zargs z)
 {
+    lr_z(T_init, z, blockIdx.z); lr_z(gate, z, blockIdx.z); lr_z(state, z, blockIdx.z);
     const int k = threadIdx.x;
     if (k < 16) state[k] = T_init[k];
     if (k >= 16 && k < LR_ICP_STATE) state[k] = 0.0;
@@ -88,8 +94,10 @@ __global__ void icp_init_kernel(const double *__restrict__ T_init, const lr_rans
 __global__ void __launch_bounds__(256)
 icp_iter_kernel(const float *__restrict__ src, int n0, const float *__restrict__ tgt, const int32_t *__restrict__ start,
                 const float4 *__restrict__ pts, double inv_cell, double max_d2, int max_iter, double rel_fit, double rel_rmse,
-                double *__restrict__ state, double *__restrict__ partial)
+                double *__restrict__ state, double *__restrict__ partial, lr_zargs z)
 {
+    if (z.descs) { const lr_pair_desc d = z.descs[blockIdx.z]; src = d.xyz0; n0 = d.n0; tgt = d.xyz1; }
+    lr_z(start, z, blockIdx.z); lr_z(pts, z, blockIdx.z); lr_z(state, z, blockIdx.z); lr_z(partial, z, blockIdx.z);
     __shared__ double sm[4][18];
     __shared__ int s_last;
     __shared__ double mom[18];
@@ -211,8 +219,9 @@ icp_iter_kernel(const float *__restrict__ src, int n0, const float *__restrict__
     }
 }
 
-__global__ void icp_result_kernel(const double *__restrict__ state, double *__restrict__ T_out, lr_icp_result *__restrict__ res)
+__global__ void icp_result_kernel(const double *__restrict__ state, double *__restrict__ T_out, lr_icp_result *__restrict__ res, lr_zargs z)
 {
+    lr_z(state, z, blockIdx.z); lr_z(T_out, z, blockIdx.z); lr_z(res, z, blockIdx.z);
     const int k = threadIdx.x;
     if (k < 12) T_out[k] = state[k];
     if (k >= 12 && k < 16) T_out[k] = k == 15 ? 1.0 : 0.0;
@@ -228,16 +237,17 @@ int lr_icp_run(lr_workspace *ws, const float *xyz0, int n0, const float *xyz1, i
     LR_REQUIRE(max_dist > 0.0 && max_iter >= 0 && max_iter <= 1000, LR_EINVAL, "lr_icp: bad max_dist / max_iter");
     const double inv_cell = 1.0 / max_dist;
     int32_t *hist = ws->icp_ints, *fill = hist + LR_ICP_NB + 8, *start = fill + LR_ICP_NB + 8;
-    LR_HIP(hipMemsetAsync(hist, 0, sizeof(int32_t) * 2 * (LR_ICP_NB + 8), st));
-    hipLaunchKernelGGL(icp_hist_kernel, dim3(lr_cdiv(n1, 256)), dim3(256), 0, st, xyz1, n1, inv_cell, ws->icp_bucket, hist);
-    hipLaunchKernelGGL(icp_scan_kernel, dim3(1), dim3(1024), 0, st, hist, start);
-    hipLaunchKernelGGL(icp_scatter_kernel, dim3(lr_cdiv(n1, 256)), dim3(256), 0, st, n1, ws->icp_bucket, start, fill, xyz1, reinterpret_cast<float4 *>(ws->icp_pts));
-    hipLaunchKernelGGL(icp_init_kernel, dim3(1), dim3(64), 0, st, T_init, gate, ws->icp_state);
+    LR_TRY_HIP(lr_zero_scratch(ws, hist, sizeof(int32_t) * 2 * (LR_ICP_NB + 8), st));
+    const int P = ws->zP;
+    hipLaunchKernelGGL(icp_hist_kernel, dim3(lr_cdiv(n1, 256), 1, P), dim3(256), 0, st, xyz1, n1, inv_cell, ws->icp_bucket, hist, ws->z);
+    hipLaunchKernelGGL(icp_scan_kernel, dim3(1, 1, P), dim3(1024), 0, st, hist, start, ws->z);
+    hipLaunchKernelGGL(icp_scatter_kernel, dim3(lr_cdiv(n1, 256), 1, P), dim3(256), 0, st, n1, ws->icp_bucket, start, fill, xyz1, reinterpret_cast<float4 *>(ws->icp_pts), ws->z);
+    hipLaunchKernelGGL(icp_init_kernel, dim3(1, 1, P), dim3(64), 0, st, T_init, gate, ws->icp_state, ws->z);
     const int nb = lr_cdiv(n0, 256);
     for (int k = 0; k <= max_iter; ++k)
-        hipLaunchKernelGGL(icp_iter_kernel, dim3(nb), dim3(256), 0, st, xyz0, n0, xyz1, start, reinterpret_cast<const float4 *>(ws->icp_pts), inv_cell,
-                           max_dist * max_dist, max_iter, rel_fit, rel_rmse, ws->icp_state, ws->icp_part);
-    hipLaunchKernelGGL(icp_result_kernel, dim3(1), dim3(64), 0, st, ws->icp_state, T_out, res);
+        hipLaunchKernelGGL(icp_iter_kernel, dim3(nb, 1, P), dim3(256), 0, st, xyz0, n0, xyz1, start, reinterpret_cast<const float4 *>(ws->icp_pts), inv_cell,
+                           max_dist * max_dist, max_iter, rel_fit, rel_rmse, ws->icp_state, ws->icp_part, ws->z);
+    hipLaunchKernelGGL(icp_result_kernel, dim3(1, 1, P), dim3(64), 0, st, ws->icp_state, T_out, res, ws->z);
     LR_LAUNCH_CHECK();
     return LR_OK;
 }

@@ -25,6 +25,8 @@ void lr_set_error(const char *fmt, ...);
 
 static inline int lr_cdiv(int a, int b) { return (a + b - 1) / b; }
 
+#define LR_TRY_HIP(x) do { int rc__ = (x); if (rc__ != LR_OK) return rc__; } while (0)
+
 // Column strips of the NN distance kernel: each wave owns 32 query rows x one strip.
 #define LR_NN_MAX_STRIPS 8
 #define LR_FEAT_DIM 32
@@ -39,10 +41,47 @@ static inline int lr_cdiv(int a, int b) { return (a + b - 1) / b; }
 #define LR_NN16_LIST 2048    // per-block LDS candidate list (256 rows x one strip); columns must be < 2^22
 enum { LR_NN_PATH_F16_FILTER = 0, LR_NN_PATH_FP32_MFMA = 1 };
 
+// ---- pair-batched launches -------------------------------------------------------------------------------------------
+// A workspace holds `max_pairs` arenas of identical layout, `stride` bytes apart; every scratch pointer below refers to
+// arena 0.  A batched call launches each kernel ONCE for all pairs: the pair is the grid's z index (or decoded from a
+// 1-D XCD-aware grid), scratch pointers are moved by pair * stride, and the pair's inputs / sizes come from a descriptor
+// table in device memory.  The single-pair operators pass z = { 0, nullptr }: pointers and sizes are used as given.
+struct lr_pair_desc {
+    const float *xyz0, *xyz1, *F0, *F1;
+    int32_t n0, n1;
+};
+struct lr_zargs {
+    size_t stride;               // bytes between the arenas of consecutive pairs (0: single pair)
+    const lr_pair_desc *descs;   // [pairs] device table, or nullptr: inputs and sizes are the kernel's own arguments
+};
+#define LR_MAX_BATCH 64          // pairs per batched call (the descriptor table travels as a kernel argument: 64 * 40 B)
+struct lr_desc_table { lr_pair_desc d[LR_MAX_BATCH]; };
+
+#ifdef __HIPCC__
+// scratch pointer of pair `pair` (null stays null: optional outputs).  A macro: the kernels' pointer parameters are
+// __restrict__-qualified, which a `T *&` template parameter does not bind to.
+#define lr_z(p, z, pair) \
+    do { if (p) p = reinterpret_cast<decltype(p)>(reinterpret_cast<uintptr_t>(p) + (size_t)(pair) * (z).stride); } while (0)
+// 1-D grid of 8 * ceil(total / 8) blocks -> logical block id such that the blocks an XCD receives (hardware ids congruent
+// mod 8) form one contiguous range of logical ids (cdna_hip_programming.md T1).  false: padding block.
+__device__ __forceinline__ bool lr_xcd_block(int total, int &logical)
+{
+    const int chunk = (int)gridDim.x >> 3;
+    logical = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
+    return logical < total;
+}
+#endif
+
 struct lr_workspace {
     int max_n0, max_n1, max_n, dim, max_iters;
+    int max_pairs;               // arenas in this workspace
+    size_t stride;               // bytes per arena
     size_t bytes;
     char *base;                  // one hipMalloc
+    lr_pair_desc *descs;         // [LR_MAX_BATCH] descriptor table of the batched call in flight (arena 0 only)
+    // call context of the entry point in flight (one stream at a time per workspace): grid z extent and the kernels' z argument
+    int zP;
+    lr_zargs z;
     // --- NN (both directions share these) ---
     float *Fp0, *Fp1;            // [n,32] de-interleaved copies (even k | odd k)
     float *nrm0, *nrm1;          // row norms
@@ -59,6 +98,7 @@ struct lr_workspace {
     _Float16 *Hs; float *nrms;   // [max_n0] f16 rows and norms of cloud 0 in rev_cols order
     int nn_path;                 // LR_NN_PATH_*
     int nn_blocks_target;        // column strips are chosen so that a pass launches about this many blocks
+    int nn_blocks_batch;         // the same for a batched call (all pairs together; LIDARREG_NN_BLOCKS_BATCH)
     int rev_strips;              // strips offered to every row block of the reverse pass (LIDARREG_REV_STRIPS)
     int nn_second_auto;          // LIDARREG_NN_SECOND=auto: lr_register_pair computes the 2nd neighbour only when a stage reads it
     float *pb1, *pb2, *pb3;      // partial top-3 values [strips][max_n]
@@ -136,6 +176,9 @@ struct lr_ransac_state {
     int32_t pad;
 };
 static_assert(sizeof(lr_ransac_state) <= (LR_CNT_TOTAL - LR_CNT_COUNT) * sizeof(int32_t), "lr_ransac_state does not fit");
+
+// lr_api.hip: zero `bytes` of scratch at `p` (arena 0) in the arena of every pair of the call in flight
+int lr_zero_scratch(lr_workspace *ws, void *p, size_t bytes, hipStream_t st);
 
 // lr_nn.hip
 int lr_nn_run(lr_workspace *ws, const float *Fa, const float *nrma, int na, const float *Fb, const float *nrmb, int nb,

@@ -47,9 +47,12 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 __global__ void __launch_bounds__(256)
 nn16_prep_kernel(const float *__restrict__ Fa, int na, _Float16 *__restrict__ Ha, float *__restrict__ nrma, float *__restrict__ bmaxa,
                  const float *__restrict__ Fb, int nb, _Float16 *__restrict__ Hb, float *__restrict__ nrmb, float *__restrict__ bmaxb,
-                 uint32_t *__restrict__ seed_b, int32_t *__restrict__ counters, int zero_counters)
+                 uint32_t *__restrict__ seed_b, int32_t *__restrict__ counters, int zero_counters, int nblk_a, lr_zargs z)
 {
     __shared__ float s_m[4];
+    if (z.descs) { const lr_pair_desc d = z.descs[blockIdx.z]; Fa = d.F0; na = d.n0; Fb = d.F1; nb = d.n1; }
+    lr_z(Ha, z, blockIdx.z); lr_z(nrma, z, blockIdx.z); lr_z(bmaxa, z, blockIdx.z); lr_z(Hb, z, blockIdx.z); lr_z(nrmb, z, blockIdx.z);
+    lr_z(bmaxb, z, blockIdx.z); lr_z(seed_b, z, blockIdx.z); lr_z(counters, z, blockIdx.z);
     // first kernel of a pair: the counter block starts from zero (lr_register_pair) and the distance range of
     // lr_nn16_reverse from { 0x7f7f7f7f, 0 }
     if (counters && blockIdx.x == 0 && (int)threadIdx.x < LR_CNT_TOTAL) {
@@ -57,8 +60,8 @@ nn16_prep_kernel(const float *__restrict__ Fa, int na, _Float16 *__restrict__ Ha
         if (k == LR_CNT_RLO) counters[k] = 0x7f7f7f7f;
         else if (k == LR_CNT_RHI || zero_counters) counters[k] = 0;
     }
-    // blocks [0, ceil(na/32)) prepare cloud a, the rest cloud b (one launch for the pair)
-    const int nblk_a = (na + 31) >> 5;
+    // blocks [0, nblk_a) prepare cloud a, the rest cloud b (one launch for the pair; nblk_a = ceil(na/32) of the largest
+    // cloud of a batch: blocks past a pair's own rows only write a zero maximum)
     const bool second = (int)blockIdx.x >= nblk_a;
     const float *__restrict__ F = second ? Fb : Fa;
     _Float16 *__restrict__ H = second ? Hb : Ha;
@@ -127,23 +130,30 @@ nn16_prep_kernel(const float *__restrict__ Fa, int na, _Float16 *__restrict__ Ha
 __global__ void __launch_bounds__(256)
 nn16_passa_kernel(const _Float16 *__restrict__ Hq, int na, const _Float16 *__restrict__ Hc, const float *__restrict__ nC, int nb,
                   int tiles_per_strip, int tile_stride, int part_stride, float *__restrict__ pg1, float *__restrict__ pg2,
-                  int32_t *__restrict__ cand_cnt)
+                  int32_t *__restrict__ cand_cnt, int gx, int gy, int total, lr_zargs z)
 {
+    // 1-D XCD-aware grid: (row block, strip, pair) from the logical block id -- the blocks one XCD receives are
+    // consecutive row blocks of the same (strip, pair), i.e. they stream the same columns through that XCD's L2
+    int logical;
+    if (!lr_xcd_block(total, logical)) return;
+    const int bx = logical % gx, strip = (logical / gx) % gy, pair = logical / (gx * gy);
+    if (z.descs) { const lr_pair_desc d = z.descs[pair]; na = d.n0; nb = d.n1; }
+    lr_z(Hq, z, pair); lr_z(Hc, z, pair); lr_z(nC, z, pair); lr_z(pg1, z, pair); lr_z(pg2, z, pair); lr_z(cand_cnt, z, pair);
+    if (bx * LR_BLOCK_ROWS >= na) return;
     constexpr int CH = LR_CH;
     constexpr int XOFF = CH * 32 * LR_LDS_ROW;
     constexpr int BUF = XOFF + CH * 32 * 4;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r = lane & 31, h = lane >> 5;
-    const int row0 = blockIdx.x * LR_BLOCK_ROWS + wave * 64;
-    const int strip = blockIdx.y;
+    const int row0 = bx * LR_BLOCK_ROWS + wave * 64;
     const int ntiles = (nb + 31) >> 5;
     const int t_begin = strip * tiles_per_strip;
     const int t_end = min(ntiles, t_begin + tiles_per_strip);
     const int nsamp = t_end > t_begin ? (t_end - t_begin + tile_stride - 1) / tile_stride : 0;   // tiles this block visits
     const int nchunks = (nsamp + CH - 1) / CH;
     // the candidate lists of pass B (which follows on the stream) start empty
-    if (strip == 0 && (int)blockIdx.x * LR_BLOCK_ROWS + tid < na) cand_cnt[blockIdx.x * LR_BLOCK_ROWS + tid] = 0;
+    if (strip == 0 && bx * LR_BLOCK_ROWS + tid < na) cand_cnt[bx * LR_BLOCK_ROWS + tid] = 0;
 
     f16x8 a[2][2];
 #pragma unroll
@@ -273,19 +283,33 @@ struct lr_thr_in {
     const float *block_max_c;    // per-32-row maxima of the column cloud's squared norms
     int nstrips, part_stride, nblk_c, need;
 };
+// grid shape of a 1-D XCD-aware launch + direction (0: rows = cloud 0, columns = cloud 1; 1: the reverse pass)
+struct lr_pb_grid { int gx, gy, total, dir; };
 
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *__restrict__ rowmap, const int32_t *__restrict__ na_dev,
                   const _Float16 *__restrict__ Hc, const float *__restrict__ nC, int nb,
                   int tiles_per_strip, const float *__restrict__ tau, int32_t *__restrict__ cand_cnt, int32_t *__restrict__ cand,
                   const int32_t *__restrict__ colmap, const float *__restrict__ tile_min, const uint32_t *__restrict__ row_bound,
-                  lr_thr_in thr)
+                  lr_thr_in thr, lr_pb_grid pg, lr_zargs z)
 {
+    // 1-D XCD-aware grid -> (row block, strip, pair): see nn16_passa_kernel
+    int logical;
+    if (!lr_xcd_block(pg.total, logical)) return;
+    const int bx = logical % pg.gx, by = (logical / pg.gx) % pg.gy, pair = logical / (pg.gx * pg.gy);
+    if (z.descs) {
+        const lr_pair_desc d = z.descs[pair];
+        na_host = pg.dir ? d.n1 : d.n0; nb = pg.dir ? d.n0 : d.n1;
+        thr.nblk_c = (nb + 31) >> 5;
+    }
+    lr_z(Hq, z, pair); lr_z(rowmap, z, pair); lr_z(na_dev, z, pair); lr_z(Hc, z, pair); lr_z(nC, z, pair); lr_z(tau, z, pair);
+    lr_z(cand_cnt, z, pair); lr_z(cand, z, pair); lr_z(colmap, z, pair); lr_z(tile_min, z, pair); lr_z(row_bound, z, pair);
+    lr_z(thr.pg1, z, pair); lr_z(thr.pg2, z, pair); lr_z(thr.nQ, z, pair); lr_z(thr.block_max_c, z, pair);
     // rows: either 0..na_host-1, or (reverse direction) the ordered list rowmap[0..*na_dev-1]; tau, cand_cnt and cand
     // are indexed by the position in that list.  Columns: Hc/nC as they lie; with colmap they are a permuted copy and
     // a candidate's column id is colmap[position].
     const int na = na_dev ? *na_dev : na_host;
-    if ((int)blockIdx.x * LR_BLOCK_ROWS >= na) return;
+    if (bx * LR_BLOCK_ROWS >= na) return;
     __shared__ int s_limit[4];
     constexpr int CH = LR_PB_CH;
     constexpr int XOFF = CH * 32 * LR_LDS_ROW;
@@ -294,7 +318,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     __shared__ uint2 wlist[4][LR_PB_WLIST];   // per wave: { column, (code << 8) | register mask }, code = rb*4 + (g0/8)*2 + h
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r = lane & 31, h = lane >> 5;
-    const int row0 = blockIdx.x * LR_BLOCK_ROWS + wave * 64;
+    const int row0 = bx * LR_BLOCK_ROWS + wave * 64;
     int ntiles = (nb + 31) >> 5;
     if (tile_min) {
         // Ordered reverse pass (lr_nn16_reverse): a column can only win a row if its own NN distance is <= the row's
@@ -302,7 +326,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         // block's largest bound -- all exact fp32 values, no margin.  The strips then split that prefix.
         float bmax = 0.0f;
         {
-            const int rw = (int)blockIdx.x * LR_BLOCK_ROWS + tid;
+            const int rw = bx * LR_BLOCK_ROWS + tid;
             if (rw < na) bmax = __uint_as_float(row_bound[rowmap[rw]]);
         }
 #pragma unroll
@@ -319,11 +343,11 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         __syncthreads();
         ntiles = max(max(s_limit[0], s_limit[1]), max(s_limit[2], s_limit[3])) + 1;
         // as many of the offered strips as the prefix is worth (a full-length row block uses all of them)
-        const int my_strips = min((int)gridDim.y, (ntiles + tiles_per_strip - 1) / tiles_per_strip);
-        if ((int)blockIdx.y >= my_strips) return;
+        const int my_strips = min(pg.gy, (ntiles + tiles_per_strip - 1) / tiles_per_strip);
+        if (by >= my_strips) return;
         tiles_per_strip = (ntiles + my_strips - 1) / my_strips;
     }
-    const int t_begin = blockIdx.y * tiles_per_strip;
+    const int t_begin = by * tiles_per_strip;
     const int t_end = min(ntiles, t_begin + tiles_per_strip);
     const int nchunks = t_end > t_begin ? (t_end - t_begin + CH - 1) / CH : 0;
 
@@ -332,7 +356,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     // slop (y = tau/2 is folded into the MFMA accumulator); +inf when fewer than `need` columns were sampled
     __shared__ float s_tau[LR_BLOCK_ROWS];
     {
-        const int rw = (int)blockIdx.x * LR_BLOCK_ROWS + tid;
+        const int rw = bx * LR_BLOCK_ROWS + tid;
         float tv = 0.0f;
         if (tau) { if (rw < na) tv = tau[rw]; }
         else {
@@ -373,7 +397,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
             const int lr = wave * 64 + 32 * rb + (g & 3) + 8 * (g >> 2) + 4 * h;
-            y[rb][g] = (int)blockIdx.x * LR_BLOCK_ROWS + lr < na ? 0.5f * s_tau[lr] : -LR_INF;        // rows past the end never pass the test
+            y[rb][g] = bx * LR_BLOCK_ROWS + lr < na ? 0.5f * s_tau[lr] : -LR_INF;        // rows past the end never pass the test
         }
     }
 
@@ -540,9 +564,16 @@ nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, in
                   const int32_t *__restrict__ rowmap, const int32_t *__restrict__ na_dev,
                   int32_t *__restrict__ idx1, int32_t *__restrict__ idx2, float *__restrict__ s1o, float *__restrict__ s2o,
                   int32_t *__restrict__ counters,
-                  uint32_t *__restrict__ seed_out, float *__restrict__ seed_s1, uint32_t *__restrict__ seed_range)
+                  uint32_t *__restrict__ seed_out, float *__restrict__ seed_s1, uint32_t *__restrict__ seed_range, int dir, lr_zargs z)
 {
     __shared__ float s_lo[4], s_hi[4];
+    if (z.descs) {      // dir 0: rows = cloud 0 against cloud 1; 1: the reverse direction
+        const lr_pair_desc d = z.descs[blockIdx.z];
+        Fq = dir ? d.F1 : d.F0; na = dir ? d.n1 : d.n0; Fc = dir ? d.F0 : d.F1; nb = dir ? d.n0 : d.n1;
+    }
+    lr_z(nQ, z, blockIdx.z); lr_z(nC, z, blockIdx.z); lr_z(cand_cnt, z, blockIdx.z); lr_z(cand, z, blockIdx.z); lr_z(rowmap, z, blockIdx.z);
+    lr_z(na_dev, z, blockIdx.z); lr_z(idx1, z, blockIdx.z); lr_z(idx2, z, blockIdx.z); lr_z(s1o, z, blockIdx.z); lr_z(s2o, z, blockIdx.z);
+    lr_z(counters, z, blockIdx.z); lr_z(seed_out, z, blockIdx.z); lr_z(seed_s1, z, blockIdx.z); lr_z(seed_range, z, blockIdx.z);
     const int gid = blockIdx.x * 256 + threadIdx.x;
     const int row = gid / LR_EX_LANES, q = gid % LR_EX_LANES;
     if (na_dev) na = *na_dev;                  // compacted row list (reverse direction): lists by position, data by rowmap[]
@@ -664,8 +695,8 @@ nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, in
 // ------------------------------------------------------------------ host side
 int lr_nn16_prep(lr_workspace *ws, const float *F0, int n0, const float *F1, int n1, hipStream_t st, bool zero_counters)
 {
-    hipLaunchKernelGGL(nn16_prep_kernel, dim3(lr_cdiv(n0, 32) + lr_cdiv(n1, 32)), dim3(256), 0, st, F0, n0, ws->H0, ws->nrm0, ws->bmax0,
-                       F1, n1, ws->H1, ws->nrm1, ws->bmax1, ws->rev_seed, ws->counters, zero_counters ? 1 : 0);
+    hipLaunchKernelGGL(nn16_prep_kernel, dim3(lr_cdiv(n0, 32) + lr_cdiv(n1, 32), 1, ws->zP), dim3(256), 0, st, F0, n0, ws->H0, ws->nrm0, ws->bmax0,
+                       F1, n1, ws->H1, ws->nrm1, ws->bmax1, ws->rev_seed, ws->counters, zero_counters ? 1 : 0, lr_cdiv(n0, 32), ws->z);
     LR_LAUNCH_CHECK();
     return LR_OK;
 }
@@ -680,24 +711,27 @@ int lr_nn16_run(lr_workspace *ws, const float *Fq, const _Float16 *Hq, const flo
     int stride = ntiles / 16;
     if (stride > LR_NN16_STRIDE) stride = LR_NN16_STRIDE;
     if (stride < 1) stride = 1;
-    // strips: enough blocks to fill 256 CUs a few times over, at least 8 sampled tiles per strip
-    int strips = lr_cdiv(ws->nn_blocks_target, row_blocks);
+    // strips: enough blocks (over all pairs of a batched call) to fill 256 CUs a few times over, at least 8 sampled tiles per strip
+    int strips = lr_cdiv(ws->zP > 1 ? ws->nn_blocks_batch : ws->nn_blocks_target, row_blocks * ws->zP);
     int smax = ntiles / (8 * stride);
     if (strips > smax) strips = smax;
     if (strips > LR_NN_MAX_STRIPS) strips = LR_NN_MAX_STRIPS;
     if (strips < 1) strips = 1;
     const int tps = lr_cdiv(lr_cdiv(ntiles, strips), stride) * stride;     // tiles per strip, multiple of the stride
-    dim3 grid(row_blocks, strips);
-    hipLaunchKernelGGL(nn16_passa_kernel, grid, dim3(256), 0, st, Hq, na, Hc, nC, nb, tps, stride, ws->max_n, ws->pb1, ws->pb2, ws->cand_cnt);
+    // 1-D XCD-aware grid over (row block, strip, pair), padded to a multiple of 8
+    const int total = row_blocks * strips * ws->zP;
+    dim3 grid(8 * lr_cdiv(total, 8));
+    hipLaunchKernelGGL(nn16_passa_kernel, grid, dim3(256), 0, st, Hq, na, Hc, nC, nb, tps, stride, ws->max_n, ws->pb1, ws->pb2, ws->cand_cnt,
+                       row_blocks, strips, total, ws->z);
     if (ws->timing && !ws->ev_pending) { LR_HIP(hipEventRecord(ws->ev[0], st)); }
     lr_thr_in thr = { ws->pb1, ws->pb2, nQ, block_max_c, strips, ws->max_n, lr_cdiv(nb, 32), need };
     hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), 0, st, Hq, na, (const int32_t *)nullptr, (const int32_t *)nullptr, Hc, nC, nb,
                        tps, (const float *)nullptr, ws->cand_cnt, ws->cand, (const int32_t *)nullptr, (const float *)nullptr,
-                       (const uint32_t *)nullptr, thr);
+                       (const uint32_t *)nullptr, thr, lr_pb_grid{ row_blocks, strips, total, 0 }, ws->z);
     if (ws->timing && !ws->ev_pending) { LR_HIP(hipEventRecord(ws->ev[1], st)); ws->ev_pending = 1; }
-    hipLaunchKernelGGL(nn16_exact_kernel, dim3(lr_cdiv(na, 256 / LR_EX_LANES)), dim3(256), 0, st, Fq, nQ, na, Fc, nC, nb, ws->cand_cnt, ws->cand,
+    hipLaunchKernelGGL(nn16_exact_kernel, dim3(lr_cdiv(na, 256 / LR_EX_LANES), 1, ws->zP), dim3(256), 0, st, Fq, nQ, na, Fc, nC, nb, ws->cand_cnt, ws->cand,
                        need, (const int32_t *)nullptr, (const int32_t *)nullptr, idx1, idx2, s1, s2, ws->counters,
-                       seed_reverse ? ws->rev_seed : (uint32_t *)nullptr, ws->rev_s1, reinterpret_cast<uint32_t *>(ws->counters + LR_CNT_RLO));
+                       seed_reverse ? ws->rev_seed : (uint32_t *)nullptr, ws->rev_s1, reinterpret_cast<uint32_t *>(ws->counters + LR_CNT_RLO), 0, ws->z);
     LR_LAUNCH_CHECK();
     return LR_OK;
 }
@@ -770,9 +804,12 @@ nn16_rev_seed_kernel(const float *__restrict__ F0, const float *__restrict__ n0v
 __global__ void __launch_bounds__(1024)
 nn16_rev_scan_kernel(int n0, int n1, const float *__restrict__ s1, const uint32_t *__restrict__ seed_bits,
                      const uint32_t *__restrict__ range, int32_t *__restrict__ offs, int32_t *__restrict__ n_rows,
-                     uint32_t *__restrict__ tile_min_bits)
+                     uint32_t *__restrict__ tile_min_bits, lr_zargs z)
 {
     __shared__ int s_h[2 * LR_RS_BUCKETS];
+    if (z.descs) { n0 = z.descs[blockIdx.z].n0; n1 = z.descs[blockIdx.z].n1; }
+    lr_z(s1, z, blockIdx.z); lr_z(seed_bits, z, blockIdx.z); lr_z(range, z, blockIdx.z); lr_z(offs, z, blockIdx.z); lr_z(n_rows, z, blockIdx.z);
+    lr_z(tile_min_bits, z, blockIdx.z);
     __shared__ int s_w[16];
     const float lo = __uint_as_float(range[0]), scale = rs_scale(lo, __uint_as_float(range[1]));
     for (int k = threadIdx.x; k < 2 * LR_RS_BUCKETS; k += 1024) s_h[k] = 0;
@@ -827,9 +864,15 @@ nn16_rev_scatter_kernel(int n0, int n1, const float *__restrict__ s1, const uint
                         const _Float16 *__restrict__ H0, const float *__restrict__ nrm0, const float *__restrict__ block_max_c, int nblk_c,
                         const float *__restrict__ nrm1,
                         int32_t *__restrict__ colmap, _Float16 *__restrict__ H0s, float *__restrict__ nrm0s, uint32_t *__restrict__ tile_min_bits,
-                        int32_t *__restrict__ rowmap, float *__restrict__ tau, int32_t *__restrict__ cand_cnt, int32_t *__restrict__ rev_out)
+                        int32_t *__restrict__ rowmap, float *__restrict__ tau, int32_t *__restrict__ cand_cnt, int32_t *__restrict__ rev_out,
+                        lr_zargs z)
 {
     __shared__ float s_m[4];
+    if (z.descs) { n0 = z.descs[blockIdx.z].n0; n1 = z.descs[blockIdx.z].n1; nblk_c = (n0 + 31) >> 5; }
+    lr_z(s1, z, blockIdx.z); lr_z(seed_bits, z, blockIdx.z); lr_z(range, z, blockIdx.z); lr_z(offs, z, blockIdx.z); lr_z(H0, z, blockIdx.z);
+    lr_z(nrm0, z, blockIdx.z); lr_z(block_max_c, z, blockIdx.z); lr_z(nrm1, z, blockIdx.z); lr_z(colmap, z, blockIdx.z); lr_z(H0s, z, blockIdx.z);
+    lr_z(nrm0s, z, blockIdx.z); lr_z(tile_min_bits, z, blockIdx.z); lr_z(rowmap, z, blockIdx.z); lr_z(tau, z, blockIdx.z);
+    lr_z(cand_cnt, z, blockIdx.z); lr_z(rev_out, z, blockIdx.z);
     const int t = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
     float mx = 0.0f;
     for (int b = threadIdx.x; b < nblk_c; b += 256) mx = fmaxf(mx, block_max_c[b]);
@@ -884,26 +927,28 @@ int lr_nn16_reverse(lr_workspace *ws, const float *F0, const _Float16 *H0, const
     uint32_t *tmin = reinterpret_cast<uint32_t *>(ws->rev_tmin);
     if (!seeded)     // (the forward pass of lr_register_pair seeds from its exact kernel: same values, one launch less)
         hipLaunchKernelGGL(nn16_rev_seed_kernel, dim3(lr_cdiv(n0, 256)), dim3(256), 0, st, F0, nrm0, n0, F1, nrm1, fwd_idx1, seed, ws->rev_s1, range);
-    hipLaunchKernelGGL(nn16_rev_scan_kernel, dim3(1), dim3(1024), 0, st, n0, n1, (const float *)ws->rev_s1, (const uint32_t *)seed,
-                       (const uint32_t *)range, ws->rev_hist, n_rows, tmin);
-    hipLaunchKernelGGL(nn16_rev_scatter_kernel, dim3(lr_cdiv(n0 + n1, 256)), dim3(256), 0, st, n0, n1, (const float *)ws->rev_s1,
+    hipLaunchKernelGGL(nn16_rev_scan_kernel, dim3(1, 1, ws->zP), dim3(1024), 0, st, n0, n1, (const float *)ws->rev_s1, (const uint32_t *)seed,
+                       (const uint32_t *)range, ws->rev_hist, n_rows, tmin, ws->z);
+    hipLaunchKernelGGL(nn16_rev_scatter_kernel, dim3(lr_cdiv(n0 + n1, 256), 1, ws->zP), dim3(256), 0, st, n0, n1, (const float *)ws->rev_s1,
                        (const uint32_t *)seed, (const uint32_t *)range, ws->rev_hist, H0, nrm0, bmax0, lr_cdiv(nb, 32), nrm1,
-                       ws->rev_cols, ws->Hs, ws->nrms, tmin, ws->rev_rows, ws->tau, ws->cand_cnt, rev);
+                       ws->rev_cols, ws->Hs, ws->nrms, tmin, ws->rev_rows, ws->tau, ws->cand_cnt, rev, ws->z);
     // grids are sized for all rows; blocks past the compacted count (or past their row block's strips) leave at once.
     // The column-prefix pruning (tile_min) rests on s1(i') = d(i', idx1[i']) being the true NN distance of i': that holds when
     // the list comes from this library's own forward pass (`seeded`, lr_register_pair).  A caller-supplied list (lr_nn_to_mutual,
     // lr_gpf*) may be anything -- the reference's nn_to_mutual accepts any corres_idx1 -- so every row block walks all column
     // tiles there: the seeds are still upper bounds of the row minima, only the prefix cut is given up.
-    dim3 grid(row_blocks, strips);
+    const int total = row_blocks * strips * ws->zP;
+    dim3 grid(8 * lr_cdiv(total, 8));
     const bool timed = ws->timing && ws->ev_pending == 1 && !ws->rev_recorded;
     if (timed) { LR_HIP(hipEventRecord(ws->ev[4], st)); }
     hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), 0, st, H1, na, (const int32_t *)ws->rev_rows, (const int32_t *)n_rows,
                        (const _Float16 *)ws->Hs, (const float *)ws->nrms, nb, tps, ws->tau, ws->cand_cnt, ws->cand,
-                       (const int32_t *)ws->rev_cols, seeded ? (const float *)ws->rev_tmin : (const float *)nullptr, (const uint32_t *)seed, lr_thr_in{});
+                       (const int32_t *)ws->rev_cols, seeded ? (const float *)ws->rev_tmin : (const float *)nullptr, (const uint32_t *)seed, lr_thr_in{},
+                       lr_pb_grid{ row_blocks, strips, total, 1 }, ws->z);
     if (timed) { LR_HIP(hipEventRecord(ws->ev[5], st)); ws->rev_recorded = 1; }
-    hipLaunchKernelGGL(nn16_exact_kernel, dim3(lr_cdiv(na, 256 / LR_EX_LANES)), dim3(256), 0, st, F1, nrm1, na, F0, nrm0, nb, ws->cand_cnt, ws->cand,
+    hipLaunchKernelGGL(nn16_exact_kernel, dim3(lr_cdiv(na, 256 / LR_EX_LANES), 1, ws->zP), dim3(256), 0, st, F1, nrm1, na, F0, nrm0, nb, ws->cand_cnt, ws->cand,
                        1, (const int32_t *)ws->rev_rows, (const int32_t *)n_rows, rev, (int32_t *)nullptr, (float *)nullptr, (float *)nullptr,
-                       ws->counters, (uint32_t *)nullptr, (float *)nullptr, (uint32_t *)nullptr);
+                       ws->counters, (uint32_t *)nullptr, (float *)nullptr, (uint32_t *)nullptr, 1, ws->z);
     LR_LAUNCH_CHECK();
     return LR_OK;
 }

@@ -78,8 +78,9 @@ __device__ __forceinline__ double prosac_Tn(int n, int M, int ns, double TN)
 }
 
 __global__ void __launch_bounds__(1024)
-prosac_growth_kernel(int m_max, const int32_t *__restrict__ m_dev, int ns, int TN, int32_t *__restrict__ G)
+prosac_growth_kernel(int m_max, const int32_t *__restrict__ m_dev, int ns, int TN, int32_t *__restrict__ G, lr_zargs z)
 {
+    lr_z(m_dev, z, blockIdx.z); lr_z(G, z, blockIdx.z);
     __shared__ long long s_w[16];
     __shared__ long long s_carry;
     const int M = m_dev ? min(*m_dev, m_max) : m_max;
@@ -161,10 +162,11 @@ __global__ void __launch_bounds__(256)
 ransac_gen_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__restrict__ m_dev, lr_ransac_params p,
                   int h_begin, int h_end, float *__restrict__ models, double *__restrict__ models64, int32_t *__restrict__ model_h,
                   uint32_t *__restrict__ score_cnt, unsigned long long *__restrict__ score_ssq,
-                  int32_t *__restrict__ counters, const int32_t *__restrict__ G, int TN, int model_stride)
+                  int32_t *__restrict__ counters, const int32_t *__restrict__ G, int TN, int model_stride, lr_zargs z)
 {
     __shared__ int s_pass[256];
     __shared__ int s_np, s_base;
+    lr_z(corr8, z, blockIdx.z); lr_z(m_dev, z, blockIdx.z); lr_z(models, z, blockIdx.z); lr_z(models64, z, blockIdx.z); lr_z(model_h, z, blockIdx.z); lr_z(score_cnt, z, blockIdx.z); lr_z(score_ssq, z, blockIdx.z); lr_z(counters, z, blockIdx.z); lr_z(G, z, blockIdx.z);
     const int m = m_dev ? min(*m_dev, m_max) : m_max;
     if (m <= 0 || reinterpret_cast<const lr_ransac_state *>(counters + LR_CNT_COUNT)->done) return;
     if (threadIdx.x == 0) s_np = 0;
@@ -201,8 +203,9 @@ ransac_gen_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__r
 __global__ void __launch_bounds__(64)
 ransac_score_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__restrict__ m_dev, float thr2,
                     const float *__restrict__ models, uint32_t *__restrict__ score_cnt,
-                    unsigned long long *__restrict__ score_ssq, const int32_t *__restrict__ counters, int sub, int model_stride)
+                    unsigned long long *__restrict__ score_ssq, const int32_t *__restrict__ counters, int sub, int model_stride, lr_zargs z)
 {
+    lr_z(corr8, z, blockIdx.z); lr_z(m_dev, z, blockIdx.z); lr_z(models, z, blockIdx.z); lr_z(score_cnt, z, blockIdx.z); lr_z(score_ssq, z, blockIdx.z); lr_z(counters, z, blockIdx.z);
     const int m = m_dev ? min(*m_dev, m_max) : m_max;
     const int V = counters[LR_CNT_NVALID];
     const int hb = (V + 63) >> 6;
@@ -285,9 +288,10 @@ __global__ void __launch_bounds__(1024)
 ransac_final_kernel(const uint32_t *__restrict__ score_cnt, const unsigned long long *__restrict__ score_ssq,
                     const int32_t *__restrict__ model_h, const double *__restrict__ models64,
                     int32_t *__restrict__ counters, int m_max, const int32_t *__restrict__ m_dev, lr_ransac_params p, int h_end,
-                    double *__restrict__ T_out, lr_ransac_result *__restrict__ res)
+                    double *__restrict__ T_out, lr_ransac_result *__restrict__ res, lr_zargs z)
 {
     __shared__ unsigned long long s_q[16];
+    lr_z(score_cnt, z, blockIdx.z); lr_z(score_ssq, z, blockIdx.z); lr_z(model_h, z, blockIdx.z); lr_z(models64, z, blockIdx.z); lr_z(counters, z, blockIdx.z); lr_z(m_dev, z, blockIdx.z); lr_z(T_out, z, blockIdx.z); lr_z(res, z, blockIdx.z);
     __shared__ uint32_t s_c[16];
     __shared__ int s_h[16], s_s[16];
     lr_ransac_state *state = reinterpret_cast<lr_ransac_state *>(counters + LR_CNT_COUNT);
@@ -366,23 +370,23 @@ int lr_ransac_run(lr_workspace *ws, const float *corr8, int m_max, const int32_t
     const int32_t *G = nullptr;
     if (ws->timing && ws->ev_pending == 1) { LR_HIP(hipEventRecord(ws->ev[2], st)); }
     if (p->sampler == 1) {
-        hipLaunchKernelGGL(prosac_growth_kernel, dim3(1), dim3(1024), 0, st, m_max, m_dev, p->sample_size, TN, ws->prosac_G);
+        hipLaunchKernelGGL(prosac_growth_kernel, dim3(1, 1, ws->zP), dim3(1024), 0, st, m_max, m_dev, p->sample_size, TN, ws->prosac_G, ws->z);
         G = ws->prosac_G;
     }
     for (int h0 = 0; h0 < (p->iters > 0 ? p->iters : 1); h0 += B) {
         const int h1 = h0 + B < p->iters ? h0 + B : p->iters;
         const int gb = lr_cdiv(h1 - h0 > 0 ? h1 - h0 : 1, 256);
         if (p->sample_size == 3)
-            hipLaunchKernelGGL(ransac_gen_kernel<3>, dim3(gb), dim3(256), 0, st, corr8, m_max, m_dev, *p, h0, h1, ws->models, ws->models64,
-                               ws->model_h, ws->score_cnt, ws->score_ssq, ws->counters, G, TN, ws->max_iters);
+            hipLaunchKernelGGL(ransac_gen_kernel<3>, dim3(gb, 1, ws->zP), dim3(256), 0, st, corr8, m_max, m_dev, *p, h0, h1, ws->models, ws->models64,
+                               ws->model_h, ws->score_cnt, ws->score_ssq, ws->counters, G, TN, ws->max_iters, ws->z);
         else
-            hipLaunchKernelGGL(ransac_gen_kernel<4>, dim3(gb), dim3(256), 0, st, corr8, m_max, m_dev, *p, h0, h1, ws->models, ws->models64,
-                               ws->model_h, ws->score_cnt, ws->score_ssq, ws->counters, G, TN, ws->max_iters);
-        hipLaunchKernelGGL(ransac_score_kernel, dim3(LR_SCORE_BLOCKS), dim3(64), 0, st, corr8, m_max, m_dev, p->thr2, ws->models,
-                           ws->score_cnt, ws->score_ssq, ws->counters, sub, ws->max_iters);
+            hipLaunchKernelGGL(ransac_gen_kernel<4>, dim3(gb, 1, ws->zP), dim3(256), 0, st, corr8, m_max, m_dev, *p, h0, h1, ws->models, ws->models64,
+                               ws->model_h, ws->score_cnt, ws->score_ssq, ws->counters, G, TN, ws->max_iters, ws->z);
+        hipLaunchKernelGGL(ransac_score_kernel, dim3(LR_SCORE_BLOCKS, 1, ws->zP), dim3(64), 0, st, corr8, m_max, m_dev, p->thr2, ws->models,
+                           ws->score_cnt, ws->score_ssq, ws->counters, sub, ws->max_iters, ws->z);
         if (h0 == 0 && ws->timing && ws->ev_pending == 1) { LR_HIP(hipEventRecord(ws->ev[3], st)); ws->ev_pending = 2; }
-        hipLaunchKernelGGL(ransac_final_kernel, dim3(1), dim3(1024), 0, st, ws->score_cnt, ws->score_ssq, ws->model_h, ws->models64,
-                           ws->counters, m_max, m_dev, *p, h1, T_out, res);
+        hipLaunchKernelGGL(ransac_final_kernel, dim3(1, 1, ws->zP), dim3(1024), 0, st, ws->score_cnt, ws->score_ssq, ws->model_h, ws->models64,
+                           ws->counters, m_max, m_dev, *p, h1, T_out, res, ws->z);
     }
     LR_LAUNCH_CHECK();
     return LR_OK;
@@ -447,10 +451,17 @@ refit_moments_kernel(const float *__restrict__ xyz0, int n0, const float *__rest
                      const int32_t *__restrict__ idx0, const int32_t *__restrict__ m_dev,
                      const float *__restrict__ F0, const float *__restrict__ F1,
                      int32_t *__restrict__ ticket, const lr_ransac_result *__restrict__ gate, double *__restrict__ T_out,
-                     int32_t *__restrict__ n_inl, lr_pair_result *__restrict__ pair_out, const int32_t *__restrict__ counters)
+                     int32_t *__restrict__ n_inl, lr_pair_result *__restrict__ pair_out, const int32_t *__restrict__ counters, lr_zargs z)
 {
     __shared__ double sm[4][16];
     __shared__ int s_last;
+    if (z.descs) {
+        const lr_pair_desc d = z.descs[blockIdx.z];
+        xyz0 = d.xyz0; xyz1 = d.xyz1; n0 = d.n0;
+        if (F0) { F0 = d.F0; F1 = d.F1; }
+    }
+    lr_z(idx1, z, blockIdx.z); lr_z(T_in, z, blockIdx.z); lr_z(partial, z, blockIdx.z); lr_z(idx0, z, blockIdx.z); lr_z(m_dev, z, blockIdx.z); lr_z(ticket, z, blockIdx.z); lr_z(gate, z, blockIdx.z); lr_z(T_out, z, blockIdx.z); lr_z(n_inl, z, blockIdx.z); lr_z(counters, z, blockIdx.z);
+    if (pair_out) pair_out += blockIdx.z;                  // the caller's result array, one block per pair
     double T[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) T[k] = T_in[k];
@@ -527,8 +538,8 @@ int lr_refit_run(lr_workspace *ws, const float *xyz0, int n0, const float *xyz1,
     const int nb = lr_cdiv(n0, 256);
     int32_t *ticket = ws->counters + LR_CNT_REFIT_TICKET;
     if (!pair_out) LR_HIP(hipMemsetAsync(ticket, 0, sizeof(int32_t), st));      // lr_register_pair starts from cleared counters
-    hipLaunchKernelGGL(refit_moments_kernel, dim3(nb), dim3(256), 0, st, xyz0, n0, xyz1, idx1, T_in, thr2, ws->refit_part, idx0, m_dev,
-                       F0, F1, ticket, gate, T_out, n_inl, pair_out, (const int32_t *)ws->counters);
+    hipLaunchKernelGGL(refit_moments_kernel, dim3(nb, 1, ws->zP), dim3(256), 0, st, xyz0, n0, xyz1, idx1, T_in, thr2, ws->refit_part, idx0, m_dev,
+                       F0, F1, ticket, gate, T_out, n_inl, pair_out, (const int32_t *)ws->counters, ws->z);
     LR_LAUNCH_CHECK();
     return LR_OK;
 }

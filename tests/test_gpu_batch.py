@@ -1,0 +1,121 @@
+"""Pair-batched launches (lr_register_batch): every pair of a batch must come out bit-identical to lr_register_pair on that
+pair alone -- result block, NN lists and filtered lists -- for ragged cloud sizes and every filter mode.  Needs an MI355X."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from lidarregistration_amd import synth
+from tests.conftest import Args
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lr():
+    import torch
+    assert torch.cuda.is_available(), "these tests need a GPU"
+    from lidarregistration_amd import FR, _ext
+    _ext.lib()
+    class NS: pass
+    ns = NS(); ns.FR = FR; ns.torch = torch; ns.ext = _ext
+    return ns
+
+
+def _dev_pairs(lr, sizes, seed0=200, clustered=False):
+    dev = lr.torch.device("cuda", 0)
+    host, devp = [], []
+    for k, (n0, n1) in enumerate(sizes):
+        p = synth.make_pair(N=n0, N1=n1, rho=0.5, s=0.9, seed=seed0 + k, clustered=clustered)
+        host.append(p)
+        devp.append(tuple(lr.torch.from_numpy(p[key]).to(dev) for key in ("xyz0", "xyz1", "feats0", "feats1")))
+    return host, devp
+
+
+def _lists(lr, ws, pair, n0, n_corr):
+    dev = lr.torch.device("cuda", 0)
+    bufs = [lr.torch.empty(n0, dtype=lr.torch.int32, device=dev) for _ in range(4)]
+    lr.ext.check(lr.ext.lib().lr_workspace_lists_at(ws.handle, pair, n0, *[b.data_ptr() for b in bufs], None))
+    nn1, nn2, c0, c1 = [b.cpu().numpy() for b in bufs]
+    return nn1, nn2, c0[:n_corr], c1[:n_corr]
+
+
+SIZES = [(3000, 3000), (4100, 2500), (257, 999), (5000, 5000), (1234, 4321), (3000, 3000), (64, 64)]
+
+
+@pytest.mark.parametrize("kw", [dict(mode="MNN", codebase="open3D", ransac_n=3, o3d_conf=1.0),
+                                dict(mode="MNN", codebase="GC", GC_conf=0.999),
+                                dict(mode="GPF", codebase="GC", GPF_factor=0.5, prosac=True),
+                                dict(mode="no_filter", codebase="open3D", ransac_n=4, o3d_conf=0.9995),
+                                dict(mode="GPF", codebase="open3D", GPF_factor=0.3, GPF_grid_wid=7, o3d_conf=1.0, icp=True)])
+def test_batch_is_bit_identical_to_single_pairs(lr, kw):
+    a = Args(iters=3000, **kw)
+    params = lr.FR.pair_params(a)
+    host, devp = _dev_pairs(lr, SIZES, clustered=(a.mode == "GPF"))
+    P = len(devp)
+    wsb = lr.ext.Workspace(5000, 5000, 32, a.iters, max_pairs=P)
+    wsb.poison(0xA5)
+    outb = lr.FR.register_batch_dev(devp, params, ws=wsb)
+    lr.torch.cuda.synchronize()
+    ws1 = lr.ext.Workspace(5000, 5000, 32, a.iters)
+    size = ctypes.sizeof(lr.ext.PairResult)
+    for k in range(P):
+        ws1.poison(0x3C + k)
+        out1 = lr.FR.register_pair_dev(*devp[k], params, ws=ws1)
+        lr.torch.cuda.synchronize()
+        b = outb[k].cpu().numpy().tobytes(); s = out1.cpu().numpy().tobytes()
+        rb, rs = lr.ext.PairResult.from_buffer_copy(b), lr.ext.PairResult.from_buffer_copy(s)
+        assert rb.n_corr == rs.n_corr and rb.ransac.best_h == rs.ransac.best_h and rb.ransac.best_count == rs.ransac.best_count, k
+        assert b == s and len(b) == size, f"pair {k}: result block differs"
+        n0 = SIZES[k][0]
+        lb, ls = _lists(lr, wsb, k, n0, rb.n_corr), _lists(lr, ws1, 0, n0, rs.n_corr)
+        for x, y in zip(lb, ls):
+            assert np.array_equal(x, y), k
+        assert rb.status == 0 or n0 < 100
+    # the big pairs register correctly (sanity of what was compared)
+    r = lr.ext.PairResult.from_buffer_copy(outb[3].cpu().numpy().tobytes())
+    T = np.array(r.T[:]).reshape(4, 4)
+    assert np.abs(T - host[3]["T_gt"]).max() < 0.2
+
+
+def test_batch_matches_oracle_pipeline(lr, oracle):
+    a = Args(mode="MNN", codebase="open3D", iters=2000, ransac_n=3, o3d_conf=1.0)
+    params = lr.FR.pair_params(a)
+    sizes = [(4000, 4000), (2500, 3500), (3500, 2500)]
+    host, devp = _dev_pairs(lr, sizes, seed0=900)
+    out = lr.FR.register_batch_dev(devp, params)
+    lr.torch.cuda.synchronize()
+    for k, p in enumerate(host):
+        r = lr.ext.PairResult.from_buffer_copy(out[k].cpu().numpy().tobytes())
+        e = oracle.register_pair(p["xyz0"], p["xyz1"], p["feats0"], p["feats1"], mode="MNN", iters=2000, sample_size=3, seed=51)
+        T = np.array(r.T[:]).reshape(4, 4)
+        assert r.n_corr == len(e["idx0"]) and r.ransac.best_h == e["ransac"]["best_h"]
+        np.testing.assert_allclose(T, e["T"], rtol=0, atol=1e-9)
+
+
+def test_batch_of_one_and_reuse_of_a_batch_workspace(lr):
+    a = Args(mode="MNN", codebase="open3D", iters=1500, ransac_n=3, o3d_conf=1.0)
+    params = lr.FR.pair_params(a)
+    _, devp = _dev_pairs(lr, [(3000, 2800), (2000, 2100), (2800, 3000)], seed0=300)
+    ws = lr.ext.Workspace(3000, 3000, 32, a.iters, max_pairs=4)
+    full = lr.FR.register_batch_dev(devp, params, ws=ws).cpu().numpy().copy()
+    # a shorter batch, a batch of one and a single-pair call on the same (batch) workspace: same bits every time
+    two = lr.FR.register_batch_dev(devp[1:], params, ws=ws).cpu().numpy()
+    one = lr.FR.register_batch_dev(devp[2:], params, ws=ws).cpu().numpy()
+    single = lr.FR.register_pair_dev(*devp[0], params, ws=ws).cpu().numpy()
+    assert np.array_equal(two[0], full[1]) and np.array_equal(two[1], full[2])
+    assert np.array_equal(one[0], full[2]) and np.array_equal(single, full[0])
+
+
+def test_batch_errors_are_loud(lr):
+    a = Args(mode="MNN", codebase="open3D", iters=500)
+    params = lr.FR.pair_params(a)
+    _, devp = _dev_pairs(lr, [(500, 500)] * 3, seed0=400)
+    ws = lr.ext.Workspace(500, 500, 32, 500, max_pairs=2)
+    with pytest.raises(lr.ext.LidarRegError):
+        lr.FR.register_batch_dev(devp, params, ws=ws)            # 3 pairs into a 2-pair workspace
+    small = lr.ext.Workspace(400, 400, 32, 500, max_pairs=4)
+    with pytest.raises(lr.ext.LidarRegError):
+        lr.FR.register_batch_dev(devp, params, ws=small)         # clouds exceed the workspace
+    with pytest.raises(lr.ext.LidarRegError):
+        lr.ext.Workspace(500, 500, 32, 500, max_pairs=65)
