@@ -43,7 +43,7 @@ void carve(lr_workspace *ws, Carver &c)
     ws->nrm0 = c.take<float>(n0); ws->nrm1 = c.take<float>(n1);
     ws->H0 = c.take<_Float16>(n0 * 32); ws->H1 = c.take<_Float16>(n1 * 32);
     ws->tau = c.take<float>(n);
-    ws->cand_cnt = c.take<int32_t>(n); ws->cand = c.take<int32_t>(n * LR_NN16_CAP);
+    ws->cand_cnt = c.take<int32_t>(LR_NN16_CNT_INTS(n)); ws->cand = c.take<int32_t>(LR_NN16_SEG_INTS(n));
     ws->pb1 = c.take<float>(n * LR_NN_MAX_STRIPS); ws->pb2 = c.take<float>(n * LR_NN_MAX_STRIPS);
     ws->pb3 = c.take<float>(n * LR_NN_MAX_STRIPS);
     ws->pi1 = c.take<int32_t>(n * LR_NN_MAX_STRIPS); ws->pi2 = c.take<int32_t>(n * LR_NN_MAX_STRIPS);

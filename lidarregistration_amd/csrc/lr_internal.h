@@ -23,7 +23,15 @@ void lr_set_error(const char *fmt, ...);
         if (!(cond)) { lr_set_error("%s", msg); return code; } \
     } while (0)
 
+// Candidate store of the f16 filter: every wave of a pass-B block (64 query rows x one column strip) owns a private segment
+// of { column, code | register mask } entries; the segments of one wave's rows over all strips hold at most
+// LR_NN16_SEG entries (8 bytes each).  Columns must be < 2^22.
+#define LR_NN16_SEG 4096
+#define LR_NN16_SEG_INTS(n) ((size_t)((n) / 256 + 1) * 4 * LR_NN16_SEG * 2)      // int32 words of the store for n query rows
+#define LR_NN16_CNT_INTS(n) ((size_t)((n) / 256 + 1) * 4 * 65)                   // segment counters (up to 64 strips) + strips used
 static inline int lr_cdiv(int a, int b) { return (a + b - 1) / b; }
+// entries per (row block, wave, strip) segment when a pass runs with `strips` column strips
+__host__ __device__ static inline int lr_seg_cap(int strips) { const int c = (LR_NN16_SEG / strips) & ~63; return c < 64 ? 64 : c; }
 
 #define LR_TRY_HIP(x) do { int rc__ = (x); if (rc__ != LR_OK) return rc__; } while (0)
 
@@ -37,8 +45,6 @@ static inline int lr_cdiv(int a, int b) { return (a + b - 1) / b; }
 #define LR_GPF_MAX_CELLS 4096
 // f16 filter path: pass A samples every LR_NN16_STRIDE-th column tile; candidate list capacity per row
 #define LR_NN16_STRIDE 4
-#define LR_NN16_CAP 128      // candidate slots per row (shared by all strips)
-#define LR_NN16_LIST 2048    // per-block LDS candidate list (256 rows x one strip); columns must be < 2^22
 enum { LR_NN_PATH_F16_FILTER = 0, LR_NN_PATH_FP32_MFMA = 1 };
 
 // ---- pair-batched launches -------------------------------------------------------------------------------------------
@@ -87,7 +93,7 @@ struct lr_workspace {
     float *nrm0, *nrm1;          // row norms
     _Float16 *H0, *H1;           // [n,32] f16 copies for the matrix-core filter passes
     float *tau;                  // [max_n] per-row candidate threshold
-    int32_t *cand_cnt, *cand;    // [max_n], [max_n][LR_NN16_CAP] candidate lists
+    int32_t *cand_cnt, *cand;    // segment counters [row blocks][4 waves][strips] and the candidate store (LR_NN16_SEG_INTS)
     float *bmax0, *bmax1;        // per-32-row maxima of the norms (f16 filter error bound)
     uint32_t *rev_seed;          // [max_n1] best forward distance pointing at each cloud-1 row (bit pattern)
     int32_t *rev_rows;           // [max_n1] the cloud-1 rows that have one, by descending seed

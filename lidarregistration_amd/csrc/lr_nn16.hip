@@ -116,11 +116,14 @@ nn16_prep_kernel(const float *__restrict__ Fa, int na, _Float16 *__restrict__ Ha
 //
 // Operand roles are swapped with respect to pass B: the column fragment is the MFMA's first operand, the query rows
 // the second, so a LANE holds one query row and its 16 accumulator registers are 16 different columns.  The
-// accumulator starts at -x_j = -n1[j]/2 (read from LDS as the C operand, no VALU), so after the two MFMAs it holds
-// g = dot16 - n1[j]/2 and the row's best column of the tile is an in-lane maximum tree (7 v_max3 + 1 v_max per 16
-// values); three more ops merge it into the running two largest tile maxima of the row.  Tile maxima belong to
-// different columns, so their second largest is a valid (and almost always exact) lower bound of the row's 2nd
-// largest g (u' = -2 g: the 2nd smallest u').  Output: partials pg1 / pg2 [strip][row].
+// accumulator starts at zero and holds dot16 after the two MFMAs; the row's value of the tile is
+//     b = max_j dot16(i, j) - max_j n1[j]/2      (in-lane maximum tree: 7 v_max3 + 1 v_max per 16 values, one subtraction)
+// which is a LOWER bound of the tile's best g = dot16 - n1[j]/2, attained up to the spread of the column norms inside the
+// tile (zero for unit-norm descriptors such as FCGF's) -- so no per-column operand has to be read at all: the C operand
+// costs neither LDS bandwidth nor 16 registers, and the kernel runs three waves per SIMD.  Three more ops merge b into the
+// running two largest tile values of the row.  They belong to different tiles, hence to different columns, so their second
+// largest is a valid lower bound of the row's 2nd largest g (u' = -2 g: an upper bound of the 2nd smallest u' -- any
+// valid bound keeps the result exact, a looser one only admits more candidates).  Output: partials pg1 / pg2 [strip][row].
 #define LR_CH 4
 #define LR_LDS_ROW 80
 #define LR_RB 2                  // 32-row MFMA blocks per wave (rows per wave = 64, rows per block = 256)
@@ -142,7 +145,7 @@ nn16_passa_kernel(const _Float16 *__restrict__ Hq, int na, const _Float16 *__res
     if (bx * LR_BLOCK_ROWS >= na) return;
     constexpr int CH = LR_CH;
     constexpr int XOFF = CH * 32 * LR_LDS_ROW;
-    constexpr int BUF = XOFF + CH * 32 * 4;
+    constexpr int BUF = XOFF + 16;           // CH column tiles + their CH maximum norms
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r = lane & 31, h = lane >> 5;
@@ -152,8 +155,8 @@ nn16_passa_kernel(const _Float16 *__restrict__ Hq, int na, const _Float16 *__res
     const int t_end = min(ntiles, t_begin + tiles_per_strip);
     const int nsamp = t_end > t_begin ? (t_end - t_begin + tile_stride - 1) / tile_stride : 0;   // tiles this block visits
     const int nchunks = (nsamp + CH - 1) / CH;
-    // the candidate lists of pass B (which follows on the stream) start empty
-    if (strip == 0 && bx * LR_BLOCK_ROWS + tid < na) cand_cnt[bx * LR_BLOCK_ROWS + tid] = 0;
+    // the candidate segments of pass B (which follows on the stream) start empty: count of (row block, wave, strip)
+    if (tid < 4) cand_cnt[(bx * 4 + tid) * (gy + 1) + strip] = 0;
 
     f16x8 a[2][2];
 #pragma unroll
@@ -166,7 +169,7 @@ nn16_passa_kernel(const _Float16 *__restrict__ Hq, int na, const _Float16 *__res
     // staging: thread t moves CH/2 16-byte pieces per chunk (piece p -> column p/4 of the chunk, 16-byte part p%4)
     f32x4 stage[CH / 2];
     float stage_n = 0.0f;        // raw norm of the staged column: NOT touched until store_chunk, so that the compiler's
-    bool stage_ok = false;       // s_waitcnt for it lands after the tile loop instead of right behind the prefetch
+                                 // s_waitcnt for it lands after the tile loop instead of right behind the prefetch
     auto chunk_col = [&](int c, int lc) {      // global column of local column lc (0..CH*32) of chunk c
         return (t_begin + (c * CH + (lc >> 5)) * tile_stride) * 32 + (lc & 31);
     };
@@ -179,8 +182,7 @@ nn16_passa_kernel(const _Float16 *__restrict__ Hq, int na, const _Float16 *__res
         }
         const int lc = tid & (CH * 32 - 1);
         const int col = chunk_col(c, lc);
-        stage_n = nC[min(col, nb - 1)];
-        stage_ok = col < nb && (col >> 5) < t_end;
+        stage_n = nC[min(col, nb - 1)];      // (columns past the end repeat the last one: same tile, same norm)
     };
     auto store_chunk = [&](int buf) {
 #pragma unroll
@@ -188,27 +190,25 @@ nn16_passa_kernel(const _Float16 *__restrict__ Hq, int na, const _Float16 *__res
             const int p = tid + 256 * q;
             *reinterpret_cast<f32x4 *>(&lds[buf * BUF + (p >> 2) * LR_LDS_ROW + (p & 3) * 16]) = stage[q];
         }
-        // -x_j = -n1[j]/2 ; -inf masks columns past the end of the cloud or of the strip
-        if (tid < CH * 32) *reinterpret_cast<float *>(&lds[buf * BUF + XOFF + tid * 4]) = stage_ok ? -0.5f * stage_n : -LR_INF;
+        // largest x_j = n1[j]/2 of every tile of the chunk: the threads tid < CH*32 hold one column each, 32 per tile
+        float xm = 0.5f * stage_n;
+#pragma unroll
+        for (int k = 16; k >= 1; k >>= 1) xm = fmaxf(xm, __shfl_xor(xm, k));
+        if (tid < CH * 32 && (tid & 31) == 0) *reinterpret_cast<float *>(&lds[buf * BUF + XOFF + (tid >> 5) * 4]) = xm;
     };
-    // fragment of tile k (lane = column r, K half h) and the C operand: register g <-> column (g&3) + 8 (g>>2) + 4 h
-    const int frag_lane = r * LR_LDS_ROW + 32 * h, x_lane = XOFF + 16 * h;
-    auto read_tile = [&](int buf, int k, f16x8 &b0, f16x8 &b1, f32x16 &cx) {
+    // fragment of tile k (lane = column r, K half h); accumulator register g <-> column (g&3) + 8 (g>>2) + 4 h of the tile
+    const int frag_lane = r * LR_LDS_ROW + 32 * h;
+    auto read_tile = [&](int buf, int k, f16x8 &b0, f16x8 &b1, float &xmax) {
         const unsigned char *bp = &lds[buf * BUF + frag_lane + k * 32 * LR_LDS_ROW];
         b0 = *reinterpret_cast<const f16x8 *>(bp);
         b1 = *reinterpret_cast<const f16x8 *>(bp + 16);
-        const unsigned char *xp = &lds[buf * BUF + x_lane + k * 32 * 4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(xp + 32 * q);
-            cx[4 * q] = v.x; cx[4 * q + 1] = v.y; cx[4 * q + 2] = v.z; cx[4 * q + 3] = v.w;
-        }
+        xmax = *reinterpret_cast<const float *>(&lds[buf * BUF + XOFF + k * 4]);
     };
 
     float m1[2] = { -LR_INF, -LR_INF }, m2[2] = { -LR_INF, -LR_INF };     // running two largest tile maxima of the lane's row
     // plain fmaxf (not inline asm): the compiler must see these reads of the MFMA results to place the wait states
     // the hardware requires between an MFMA and a VALU read of its destination
-    auto fold = [&](const f32x16 &acc, int rb) {
+    auto fold = [&](const f32x16 &acc, int rb, float xmax) {
         float t = fmaxf(fmaxf(acc[0], acc[1]), acc[2]);
         float u = fmaxf(fmaxf(acc[3], acc[4]), acc[5]);
         float v = fmaxf(fmaxf(acc[6], acc[7]), acc[8]);
@@ -216,14 +216,13 @@ nn16_passa_kernel(const _Float16 *__restrict__ Hq, int na, const _Float16 *__res
         float z = fmaxf(fmaxf(acc[12], acc[13]), acc[14]);
         t = fmaxf(fmaxf(t, u), acc[15]);
         v = fmaxf(fmaxf(v, w), z);
-        t = fmaxf(t, v);
+        t = fmaxf(t, v) - xmax;
         const float lo = fminf(m1[rb], t);
         m1[rb] = fmaxf(m1[rb], t);
         m2[rb] = fmaxf(m2[rb], lo);
     };
 
-    // (An explicit software pipeline -- fold tile t-1 under the MFMAs of tile t -- measured no faster: at 47-59 sampled
-    // tiles per block the kernel is bound by its per-block prologue, not by this loop; the plain loop needs 92 VGPRs.)
+    const f32x16 zero16 = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     if (nchunks > 0) {
         load_chunk(0); store_chunk(0);
         __syncthreads();
@@ -232,14 +231,15 @@ nn16_passa_kernel(const _Float16 *__restrict__ Hq, int na, const _Float16 *__res
             if (c + 1 < nchunks) load_chunk(c + 1);
 #pragma unroll
             for (int k = 0; k < CH; ++k) {
-                f16x8 b0, b1; f32x16 cx;
-                read_tile(buf, k, b0, b1, cx);
-                f32x16 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0, a[0][0], cx, 0, 0, 0);
-                f32x16 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0, a[1][0], cx, 0, 0, 0);
+                f16x8 b0, b1; float xmax;
+                read_tile(buf, k, b0, b1, xmax);
+                f32x16 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0, a[0][0], zero16, 0, 0, 0);
+                f32x16 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0, a[1][0], zero16, 0, 0, 0);
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b1, a[0][1], acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b1, a[1][1], acc1, 0, 0, 0);
-                fold(acc0, 0);
-                fold(acc1, 1);
+                // tiles past the end of the strip (the last chunk may reach into the next strip's sample) are not counted:
+                // a column must not enter two strips' maxima
+                if (t_begin + (c * CH + k) * tile_stride < t_end) { fold(acc0, 0, xmax); fold(acc1, 1, xmax); }
             }
             if (c + 1 < nchunks) store_chunk(buf ^ 1);
             __syncthreads();
@@ -320,6 +320,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     const int r = lane & 31, h = lane >> 5;
     const int row0 = bx * LR_BLOCK_ROWS + wave * 64;
     int ntiles = (nb + 31) >> 5;
+    int my_strips = pg.gy;           // strips this row block really uses (the ordered reverse pass: as many as its column prefix is worth)
     if (tile_min) {
         // Ordered reverse pass (lr_nn16_reverse): a column can only win a row if its own NN distance is <= the row's
         // bound, so this row block needs the column tiles up to the last one whose smallest NN distance is <= the
@@ -343,7 +344,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         __syncthreads();
         ntiles = max(max(s_limit[0], s_limit[1]), max(s_limit[2], s_limit[3])) + 1;
         // as many of the offered strips as the prefix is worth (a full-length row block uses all of them)
-        const int my_strips = min(pg.gy, (ntiles + tiles_per_strip - 1) / tiles_per_strip);
+        my_strips = min(pg.gy, (ntiles + tiles_per_strip - 1) / tiles_per_strip);
         if (by >= my_strips) return;
         tiles_per_strip = (ntiles + my_strips - 1) / my_strips;
     }
@@ -434,27 +435,29 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     };
 
     int wcnt = 0;            // entries in this wave's list (wave-uniform: lives in a scalar register)
-    // empty the wave's list into the per-row slots shared by all strips (global atomics, off the hot path)
+    // The wave owns one segment of the candidate store: seg[(row block, wave, strip)][seg_cap] entries { column, code | mask }
+    // exactly as they lie in its LDS list.  Emptying the list is a compacting copy with plain stores -- no atomics, nothing
+    // to wait for; nn16_exact_kernel expands the masks and bins the entries by row.  seg_fill < 0: the segment overflowed
+    // (duplicate-heavy input), the wave's 64 rows go through the exact full-row scan.
+    // (the LR_NN16_SEG entries of the wave's rows are divided among the strips the row block really uses)
+    const int seg_cap = lr_seg_cap(my_strips);
+    uint2 *__restrict__ seg = reinterpret_cast<uint2 *>(cand) + (size_t)(bx * 4 + wave) * LR_NN16_SEG + (size_t)by * seg_cap;
+    int seg_fill = 0;
     auto flush = [&]() {
-        if (wcnt > LR_PB_WLIST) {
-            // more hits than the list holds (duplicate-heavy input): the wave's rows go through the exact full-row scan
-            if (row0 + lane < na) atomicAdd(&cand_cnt[row0 + lane], LR_NN16_CAP + 1);
-        } else {
-            for (int e = lane; e < wcnt; e += 64) {
-                const uint2 v = wlist[wave][e];
-                int col = (int)v.x;
-                const int code = (int)(v.y >> 8);
-                if (col >= nb || (col >> 5) >= t_end) continue;      // padding columns pass the test only when tau is +inf
-                if (colmap) col = colmap[col];
-                const int rbase = row0 + 32 * (code >> 2) + 4 * (code & 1);
-                unsigned m = v.y & 0xffu;
-                while (m) {
-                    const int g = 8 * ((code >> 1) & 1) + __builtin_ctz(m);
-                    m &= m - 1;
-                    const int row = rbase + (g & 3) + 8 * (g >> 2);
-                    const int slot = atomicAdd(&cand_cnt[row], 1);
-                    if (slot < LR_NN16_CAP) cand[(size_t)row * LR_NN16_CAP + slot] = col;
-                }
+        if (wcnt > LR_PB_WLIST) seg_fill = -1;       // more hits between two chunk boundaries than the list holds
+        else if (seg_fill >= 0) {
+            for (int e0 = 0; e0 < wcnt; e0 += 64) {
+                const int e = e0 + lane;
+                uint2 v = make_uint2(0u, 0u);
+                if (e < wcnt) v = wlist[wave][e];
+                // padding columns pass the test only when tau is +inf
+                const bool keep = e < wcnt && (int)v.x < nb && ((int)v.x >> 5) < t_end;
+                const unsigned long long kb = __builtin_amdgcn_ballot_w64(keep);
+                const int pos = seg_fill + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(kb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)kb, 0u));
+                const int nk = __builtin_popcountll(kb);
+                if (seg_fill + nk > seg_cap) { seg_fill = -1; break; }
+                if (keep) { if (colmap) v.x = (unsigned)colmap[v.x]; seg[pos] = v; }
+                seg_fill += nk;
             }
         }
         wcnt = 0;
@@ -473,9 +476,14 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         const unsigned long long hit = __builtin_amdgcn_ballot_w64(m >= x);
         if (__builtin_expect(hit != 0ull, 0)) {       // rare: keeps the common path a fall-through
             if (m >= x) {
-                unsigned mask = 0;
+                // which of the 8 registers: the sign of (acc - x) is shifted into the mask register by register (2 VALU ops
+                // each, no SGPR round trip).  Register g0 + g ends up in bit 7 - g; a set bit means acc < x.  A NaN accumulator
+                // (non-finite f16 operands) may read as a hit: rows with such operands are re-done by the exact full-row
+                // scan (nn16_exact_kernel tests the query row), columns only add candidates that the exact stage orders.
+                unsigned below = 0;
 #pragma unroll
-                for (int g = 0; g < 8; ++g) mask |= acc[g0 + g] >= x ? 1u << g : 0u;
+                for (int g = 0; g < 8; ++g) below = __builtin_amdgcn_alignbit(below, __float_as_uint(acc[g0 + g] - x), 31);
+                const unsigned mask = ~below & 0xffu;
                 const int pos = wcnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(hit >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hit, 0u));
                 if (pos < LR_PB_WLIST) wlist[wave][pos] = make_uint2((unsigned)(tile * 32 + r), mask | (unsigned)((rb * 4 + (g0 >> 3) * 2 + h) << 8));
             }
@@ -548,19 +556,27 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         }
         flush();
     }
+    if (lane == 0) {
+        int32_t *cw = cand_cnt + (bx * 4 + wave) * (pg.gy + 1);
+        cw[by] = seg_fill;                     // entries in this wave's segment (< 0: overflow)
+        if (by == 0) cw[pg.gy] = my_strips;    // how the wave's store is divided (read by nn16_exact_kernel)
+    }
 }
 
 // ------------------------------------------------------------------ exact verification of the candidates
-// LR_EX_LANES (4; 8 measured slower: every lane reloads the query row) lanes per row: lane q takes the candidate slots q, q+4, ...; the partial (first, second) pairs are
-// merged under the (sqrt value, index) order with log2(lanes) shuffles.  Rows with an overflowing or too-short candidate list
-// are re-done by a full exact scan of all columns, in place.
+// A block takes the 64 query rows of one pass-B wave: it expands the register masks of that wave's segments (one per column
+// strip) and bins the candidates by row in LDS (count, prefix, scatter), then LR_EX_LANES (4; 8 measured slower: every lane
+// reloads the query row) lanes per row: lane q takes the row's candidates q, q+4, ...; the partial (first, second) pairs are
+// merged under the (sqrt value, index) order with log2(lanes) shuffles.  Rows whose segment or bin overflowed, whose list is
+// too short, or whose f16 copy is not finite are re-done by a full exact scan of all columns, in place.
 #define LR_EX_LANES 4
+#define LR_EX_LIST 6144          // binned candidates of the block's 64 rows (LDS)
 __device__ __forceinline__ bool sj_lt(float a, int ia, float b, int ib) { return a < b || (a == b && ia < ib); }
 
 __global__ void __launch_bounds__(256)
 nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, int na,
                   const float *__restrict__ Fc, const float *__restrict__ nC, int nb,
-                  const int32_t *__restrict__ cand_cnt, const int32_t *__restrict__ cand, int need,
+                  const int32_t *__restrict__ cand_cnt, const int32_t *__restrict__ cand, int nstrips, int need,
                   const int32_t *__restrict__ rowmap, const int32_t *__restrict__ na_dev,
                   int32_t *__restrict__ idx1, int32_t *__restrict__ idx2, float *__restrict__ s1o, float *__restrict__ s2o,
                   int32_t *__restrict__ counters,
@@ -588,13 +604,62 @@ nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, in
     const float nq = nQ[rowd];
     float b1 = LR_INF, b2 = LR_INF;
     int i1 = LR_IMAX, i2 = LR_IMAX;
-    const int total = cand_cnt[rowc];
-    const int over = total > LR_NN16_CAP ? 1 : 0;
-    // an overflowed list is not read at all: its slots are only partly written (the rest is stale from earlier pairs)
+    // ---- bin the candidates of the block's 64 rows
+    __shared__ int s_cnt[64], s_fill[64], s_off[65], s_bad;
+    __shared__ int s_list[LR_EX_LIST];
+    const int32_t *cw = cand_cnt + blockIdx.x * (nstrips + 1);
+    const int used = min(max(cw[nstrips], 1), nstrips);        // strips the pass-B row block really used
+    const int seg_cap = lr_seg_cap(used);
+    const uint2 *__restrict__ segs = reinterpret_cast<const uint2 *>(cand) + (size_t)blockIdx.x * LR_NN16_SEG;
+    if (threadIdx.x < 64) { s_cnt[threadIdx.x] = 0; s_fill[threadIdx.x] = 0; }
+    if (threadIdx.x == 0) s_bad = 0;
+    __syncthreads();
+    // entry { column, (code << 8) | mask }: code = rb*4 + (g0/8)*2 + h of the pass-B wave tile, mask bit 7-k <-> register g0 + k;
+    // row of register g: 32 rb + 4 h + (g & 3) + 8 (g >> 2)
+    auto for_each_candidate = [&](auto &&f) {
+        for (int sidx = 0; sidx < used; ++sidx) {
+            const int c = cw[sidx];
+            if (c < 0) { if (threadIdx.x == 0) s_bad = 1; continue; }
+            for (int e = threadIdx.x; e < c; e += 256) {
+                const uint2 v = segs[(size_t)sidx * seg_cap + e];
+                const int code = (int)(v.y >> 8);
+                const int rbase = 32 * (code >> 2) + 4 * (code & 1), g0 = 8 * ((code >> 1) & 1);
+                unsigned m = v.y & 0xffu;
+                while (m) {
+                    const int bit = __builtin_ctz(m);
+                    m &= m - 1;
+                    const int g = g0 + 7 - bit;
+                    f(rbase + (g & 3) + 8 * (g >> 2), (int)v.x);
+                }
+            }
+        }
+    };
+    for_each_candidate([&](int rl, int) { atomicAdd(&s_cnt[rl], 1); });
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int c = s_cnt[threadIdx.x];
+        int inc = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if ((int)threadIdx.x >= d) inc += o; }
+        s_off[threadIdx.x] = inc - c;
+        if (threadIdx.x == 63) { s_off[64] = inc; if (inc > LR_EX_LIST) s_bad = 1; }
+    }
+    __syncthreads();
+    const bool binned = s_bad == 0;
+    if (binned) for_each_candidate([&](int rl, int col) { s_list[s_off[rl] + atomicAdd(&s_fill[rl], 1)] = col; });
+    __syncthreads();
+    const int rl = (int)threadIdx.x / LR_EX_LANES;
+    const int lbase = s_off[rl];
+    const int total = binned ? s_off[rl + 1] - lbase : 0;
+    // a query row whose f16 copy is not finite never produced a meaningful filter value
+    bool bad_row = !binned;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) bad_row |= !(fabsf(a[k]) <= 65504.0f);
+    const int over = bad_row ? 1 : 0;
     const int ncand = over ? 0 : total;
     // the candidate loop is a chain index -> gather -> 32 dependent fmas: the next candidate's row is fetched while the
     // current chain runs
-    int jn = q < ncand ? cand[(size_t)rowc * LR_NN16_CAP + q] : 0;
+    int jn = q < ncand ? s_list[lbase + q] : 0;
     f32x4 tn[8];
     float nn = 0.0f;
     if (q < ncand) {
@@ -610,7 +675,7 @@ nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, in
         for (int k = 0; k < 8; ++k) t[k] = tn[k];
         const float ncj = nn;
         if (c + LR_EX_LANES < ncand) {
-            jn = cand[(size_t)rowc * LR_NN16_CAP + c + LR_EX_LANES];
+            jn = s_list[lbase + c + LR_EX_LANES];
             const f32x4 *pb = reinterpret_cast<const f32x4 *>(Fc + (size_t)jn * 32);
 #pragma unroll
             for (int k = 0; k < 8; ++k) tn[k] = pb[k];
@@ -631,7 +696,7 @@ nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, in
         if (sj_lt(sv, j, b1, i1)) { b2 = b1; i2 = i1; b1 = sv; i1 = j; }
         else if (sj_lt(sv, j, b2, i2)) { b2 = sv; i2 = j; }
     }
-    if (over || total < min(need, nb)) {
+    if (live && (over || total < min(need, nb))) {
         // candidate list overflowed (duplicate-heavy input) or could not be filled (non-finite f16 values): the four
         // lanes of the row scan every column exactly -- slow, rare, and by construction the reference answer
         b1 = LR_INF; b2 = LR_INF; i1 = LR_IMAX; i2 = LR_IMAX;
@@ -730,7 +795,7 @@ int lr_nn16_run(lr_workspace *ws, const float *Fq, const _Float16 *Hq, const flo
                        (const uint32_t *)nullptr, thr, lr_pb_grid{ row_blocks, strips, total, 0 }, ws->z);
     if (ws->timing && !ws->ev_pending) { LR_HIP(hipEventRecord(ws->ev[1], st)); ws->ev_pending = 1; }
     hipLaunchKernelGGL(nn16_exact_kernel, dim3(lr_cdiv(na, 256 / LR_EX_LANES), 1, ws->zP), dim3(256), 0, st, Fq, nQ, na, Fc, nC, nb, ws->cand_cnt, ws->cand,
-                       need, (const int32_t *)nullptr, (const int32_t *)nullptr, idx1, idx2, s1, s2, ws->counters,
+                       strips, need, (const int32_t *)nullptr, (const int32_t *)nullptr, idx1, idx2, s1, s2, ws->counters,
                        seed_reverse ? ws->rev_seed : (uint32_t *)nullptr, ws->rev_s1, reinterpret_cast<uint32_t *>(ws->counters + LR_CNT_RLO), 0, ws->z);
     LR_LAUNCH_CHECK();
     return LR_OK;
@@ -865,7 +930,7 @@ nn16_rev_scatter_kernel(int n0, int n1, const float *__restrict__ s1, const uint
                         const float *__restrict__ nrm1,
                         int32_t *__restrict__ colmap, _Float16 *__restrict__ H0s, float *__restrict__ nrm0s, uint32_t *__restrict__ tile_min_bits,
                         int32_t *__restrict__ rowmap, float *__restrict__ tau, int32_t *__restrict__ cand_cnt, int32_t *__restrict__ rev_out,
-                        lr_zargs z)
+                        int seg_counters, lr_zargs z)
 {
     __shared__ float s_m[4];
     if (z.descs) { n0 = z.descs[blockIdx.z].n0; n1 = z.descs[blockIdx.z].n1; nblk_c = (n0 + 31) >> 5; }
@@ -874,6 +939,9 @@ nn16_rev_scatter_kernel(int n0, int n1, const float *__restrict__ s1, const uint
     lr_z(nrm0s, z, blockIdx.z); lr_z(tile_min_bits, z, blockIdx.z); lr_z(rowmap, z, blockIdx.z); lr_z(tau, z, blockIdx.z);
     lr_z(cand_cnt, z, blockIdx.z); lr_z(rev_out, z, blockIdx.z);
     const int t = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+    // the segment counters of the reverse pass B start from zero (row blocks that use fewer strips than offered leave the
+    // others untouched)
+    for (int k = t; k < seg_counters; k += (int)gridDim.x * 256) cand_cnt[k] = 0;
     float mx = 0.0f;
     for (int b = threadIdx.x; b < nblk_c; b += 256) mx = fmaxf(mx, block_max_c[b]);
 #pragma unroll
@@ -903,8 +971,8 @@ nn16_rev_scatter_kernel(int n0, int n1, const float *__restrict__ s1, const uint
         const float d2hi = sv * sv * (1.0f + 6e-7f);               // every d2 whose sqrt rounds to <= sv lies below this
         rowmap[pos] = row;
         tau[pos] = (d2hi - nrm1[row]) + E + 6e-6f * scl + 2e-6f * d2hi;
-        cand_cnt[pos] = 0;
     }
+
 }
 
 int lr_nn16_reverse(lr_workspace *ws, const float *F0, const _Float16 *H0, const float *nrm0, const float *bmax0, int n0,
@@ -931,7 +999,7 @@ int lr_nn16_reverse(lr_workspace *ws, const float *F0, const _Float16 *H0, const
                        (const uint32_t *)range, ws->rev_hist, n_rows, tmin, ws->z);
     hipLaunchKernelGGL(nn16_rev_scatter_kernel, dim3(lr_cdiv(n0 + n1, 256), 1, ws->zP), dim3(256), 0, st, n0, n1, (const float *)ws->rev_s1,
                        (const uint32_t *)seed, (const uint32_t *)range, ws->rev_hist, H0, nrm0, bmax0, lr_cdiv(nb, 32), nrm1,
-                       ws->rev_cols, ws->Hs, ws->nrms, tmin, ws->rev_rows, ws->tau, ws->cand_cnt, rev, ws->z);
+                       ws->rev_cols, ws->Hs, ws->nrms, tmin, ws->rev_rows, ws->tau, ws->cand_cnt, rev, row_blocks * 4 * (strips + 1), ws->z);
     // grids are sized for all rows; blocks past the compacted count (or past their row block's strips) leave at once.
     // The column-prefix pruning (tile_min) rests on s1(i') = d(i', idx1[i']) being the true NN distance of i': that holds when
     // the list comes from this library's own forward pass (`seeded`, lr_register_pair).  A caller-supplied list (lr_nn_to_mutual,
@@ -947,7 +1015,7 @@ int lr_nn16_reverse(lr_workspace *ws, const float *F0, const _Float16 *H0, const
                        lr_pb_grid{ row_blocks, strips, total, 1 }, ws->z);
     if (timed) { LR_HIP(hipEventRecord(ws->ev[5], st)); ws->rev_recorded = 1; }
     hipLaunchKernelGGL(nn16_exact_kernel, dim3(lr_cdiv(na, 256 / LR_EX_LANES), 1, ws->zP), dim3(256), 0, st, F1, nrm1, na, F0, nrm0, nb, ws->cand_cnt, ws->cand,
-                       1, (const int32_t *)ws->rev_rows, (const int32_t *)n_rows, rev, (int32_t *)nullptr, (float *)nullptr, (float *)nullptr,
+                       strips, 1, (const int32_t *)ws->rev_rows, (const int32_t *)n_rows, rev, (int32_t *)nullptr, (float *)nullptr, (float *)nullptr,
                        ws->counters, (uint32_t *)nullptr, (float *)nullptr, (uint32_t *)nullptr, 1, ws->z);
     LR_LAUNCH_CHECK();
     return LR_OK;

@@ -1,0 +1,64 @@
+// Timing harness for the batched pass A / pass B kernels (development tool): P identical pairs in P arenas.
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form=1 [-DLR_PB_EXP=k] tools/pb_micro.hip -o tools/bin/pb_micro_k
+//   usage: pb_micro [n=30000] [P=32] [strips=1]
+#include "../lidarregistration_amd/csrc/lr_nn16.hip"
+#include <vector>
+#include <random>
+void lr_set_error(const char *, ...) {}
+template <class F> float timeit(F f, int reps = 8) {
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int w = 0; w < 2; ++w) f();
+    hipDeviceSynchronize();
+    float best = 1e9;
+    for (int r = 0; r < reps; ++r) { hipEventRecord(e0, 0); f(); hipEventRecord(e1, 0); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); best = ms < best ? ms : best; }
+    return best;
+}
+int main(int argc, char **argv)
+{
+    const int n = argc > 1 ? atoi(argv[1]) : 30000, P = argc > 2 ? atoi(argv[2]) : 32, strips = argc > 3 ? atoi(argv[3]) : 1;
+    std::vector<float> h((size_t)n * 32);
+    std::mt19937 rng(1); std::normal_distribution<float> nd;
+    for (size_t r = 0; r < (size_t)n; ++r) { double s = 0; for (int k = 0; k < 32; ++k) { h[r*32+k] = nd(rng); s += h[r*32+k]*h[r*32+k]; } for (int k = 0; k < 32; ++k) h[r*32+k] /= (float)sqrt(s); }
+    // arena layout (bytes): H | nrm | bmax | pu1 | pu2 | tau | cnt | cand
+    size_t off = 0; auto take = [&](size_t b) { size_t o = off; off = (off + b + 255) & ~size_t(255); return o; };
+    const size_t oH = take((size_t)n * 64), oN = take((size_t)n * 4), oB = take((size_t)(n / 32 + 2) * 4), o1 = take((size_t)n * 4 * 8), o2 = take((size_t)n * 4 * 8),
+                 oT = take((size_t)n * 4), oC = take(LR_NN16_CNT_INTS(n) * 4), oD = take(LR_NN16_SEG_INTS(n) * 4);
+    const size_t stride = off;
+    char *base; hipMalloc(&base, stride * P); hipMemset(base, 0, stride * P);
+    float *F; hipMalloc(&F, (size_t)n * 128); hipMemcpy(F, h.data(), (size_t)n * 128, hipMemcpyHostToDevice);
+    _Float16 *H = (_Float16 *)(base + oH); float *nrm = (float *)(base + oN), *bmax = (float *)(base + oB), *pu1 = (float *)(base + o1), *pu2 = (float *)(base + o2), *tau = (float *)(base + oT);
+    int32_t *cnt = (int32_t *)(base + oC), *cand = (int32_t *)(base + oD);
+    lr_zargs z0 = { 0, nullptr };
+    for (int p = 0; p < P; ++p)
+        hipLaunchKernelGGL(nn16_prep_kernel, dim3((n+31)/32), dim3(256), 0, 0, F, n, (_Float16 *)((char *)H + p * stride), (float *)((char *)nrm + p * stride), (float *)((char *)bmax + p * stride),
+                           F, 0, H, nrm, bmax, (uint32_t*)nullptr, (int32_t*)nullptr, 0, (n + 31) / 32, z0);
+    hipDeviceSynchronize();
+    lr_zargs z = { stride, nullptr };
+    const int ntiles = (n + 31) / 32, row_blocks = (n + LR_BLOCK_ROWS - 1) / LR_BLOCK_ROWS;
+    const int total = row_blocks * strips * P;
+    dim3 grid(8 * ((total + 7) / 8));
+    const int stride_a = 4;
+    const int tps = ((ntiles + strips - 1) / strips + stride_a - 1) / stride_a * stride_a;
+    float msa = timeit([&] { hipLaunchKernelGGL(nn16_passa_kernel, grid, dim3(256), 0, 0, H, n, H, nrm, n, tps, stride_a, n, pu1, pu2, cnt, row_blocks, strips, total, z); });
+    printf("EXP=%d n=%d P=%d strips=%d blocks=%d\n", LR_PB_EXP, n, P, strips, total);
+    printf("passA stride 4:            %8.3f ms  = %6.1f us/pair\n", msa, msa * 1e3 / P);
+    for (int need : {2, 1}) {
+        lr_thr_in thr = { pu1, pu2, nrm, bmax, strips, n, (n+31)/32, need };
+        auto run = [&] { hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), 0, 0, H, n, (const int32_t*)nullptr, (const int32_t*)nullptr, H, nrm, n, tps, (const float*)nullptr, cnt, cand,
+                                            (const int32_t*)nullptr, (const float*)nullptr, (const uint32_t*)nullptr, thr, lr_pb_grid{ row_blocks, strips, total, 0 }, z); };
+        float msp = timeit([&] { run(); });
+        run();
+        const int nseg = row_blocks * 4 * (strips + 1);
+        std::vector<int32_t> c1(nseg); hipMemcpy(c1.data(), cnt, (size_t)nseg * 4, hipMemcpyDeviceToHost);
+        double tot = 0; for (int i = 0; i < nseg; ++i) if (i % (strips + 1) != strips) tot += c1[i];
+        printf("passB need=%d:              %8.3f ms  = %6.1f us/pair   list entries/row %.2f\n", need, msp, msp * 1e3 / P, tot / n);
+    }
+    {
+        std::vector<float> t(n, -1e30f);
+        for (int p = 0; p < P; ++p) hipMemcpy((char *)tau + p * stride, t.data(), (size_t)n * 4, hipMemcpyHostToDevice);
+        float msp = timeit([&] { hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), 0, 0, H, n, (const int32_t*)nullptr, (const int32_t*)nullptr, H, nrm, n, tps, (const float*)tau, cnt, cand,
+                                                    (const int32_t*)nullptr, (const float*)nullptr, (const uint32_t*)nullptr, lr_thr_in{}, lr_pb_grid{ row_blocks, strips, total, 0 }, z); });
+        printf("passB no candidates:       %8.3f ms  = %6.1f us/pair\n", msp, msp * 1e3 / P);
+    }
+    return 0;
+}
