@@ -46,16 +46,24 @@ typedef struct lr_ransac_params {
                                for the best model so far.  >= 1 (or <= 0): every id is evaluated.             */
     int32_t  batch;         /* batch length of the early-exit test (0 -> 8192, or iters/8 rounded up to a multiple of
                                8192 when iters > 65536)                                                */
-    int32_t  sampler;       /* 0: uniform (GC_RANSAC.py:19 'sampler': 0); 1: PROSAC (--prosac, GC_RANSAC.py:24,39-43):
-                               the correspondences must come best quality first; hypothesis id h = PROSAC draw h+1:
-                               sample_size-1 indices uniformly from the first n-1 correspondences plus the n-th, n from
-                               the growth function of Chum & Matas 2005 (as in USAC / GC-RANSAC's prosac_sampler.h);
-                               ids past prosac_growth fall back to uniform sampling over all correspondences        */
+    int32_t  sampler;       /* 0: uniform WITH replacement (Open3D's RANSAC, FR.py:128-137); 2: uniform, unique indices
+                               (GC_RANSAC.py:19 'sampler': 0 -> GC-RANSAC's UniformSampler); 1: PROSAC (--prosac,
+                               GC_RANSAC.py:24,39-43): the correspondences must come best quality first; hypothesis id h =
+                               PROSAC draw h+1: sample_size-1 indices uniformly from the first n-1 correspondences plus the
+                               n-th, n from the growth function of Chum & Matas 2005 (as in USAC / GC-RANSAC's
+                               prosac_sampler.h); ids past prosac_growth fall back to uniform sampling over all
+                               correspondences.  Samplers 1 and 2 reject a draw with a repeated index (the id is consumed
+                               like a failed pre-check)                                                              */
     int32_t  prosac_growth; /* T_N of the growth function (0 -> 100000, GC-RANSAC's default)          */
     int32_t  scoring;       /* which model wins: 0 = more inliers, then lower squared-error sum (Open3D: fitness, then
                                inlier RMSE); 1 = MSAC, the truncated quadratic cost GC-RANSAC scores with: larger
                                sum over inliers of (thr2 - d^2), evaluated as count * (uint32)(thr2 * 2^20) - best_ssq */
-    int32_t  reserved0;
+    int32_t  local_opt;     /* 0: none -- the winning minimal-sample model is returned (Open3D); 1: GC-RANSAC's local
+                               optimisation (--GC_LO True, GC_RANSAC.py:36-37; gcransac_python.cpp:418-423,508-515): every new
+                               best model is re-estimated by an inner RANSAC over its inliers (<= 10 rounds of 20 least-squares
+                               fits on 21 inliers each, scored over all correspondences; spatial coherence weight 0), at the
+                               granularity of the early-exit batches, plus the final iterated least squares; 2: the final
+                               iterated least squares over the inliers only (--GC_LO False)                           */
 } lr_ransac_params;
 
 /* Written to device memory by lr_ransac / lr_register_pair. */
@@ -161,6 +169,16 @@ LR_API int lr_gpf_bb_first(lr_workspace *ws, const float *F0, int n0, const floa
  * m_dev, if not NULL, is a device int32 holding the live M (<= m).  Writes T_out[16] and *res.    */
 LR_API int lr_ransac(lr_workspace *ws, const float *src, const float *tgt, int m, const int32_t *m_dev,
                      const lr_ransac_params *p, double *T_out, lr_ransac_result *res, void *stream);
+
+/* The inlier mask findRigidTransform returns next to the pose (gcransac_python.cpp:594-603): mask[c] = 1 when
+ * |T src[c] - tgt[c]|^2 < thr2 in the fp32 arithmetic of the scoring kernel; *n_inliers (device, may be NULL) their number.
+ * T is a DEVICE pointer (e.g. T_out of lr_ransac); with T = NULL the model of the last lr_ransac / lr_register_pair on ws.  */
+LR_API int lr_inlier_mask(lr_workspace *ws, const float *src, const float *tgt, int m, const double *T, float thr2,
+                          uint8_t *mask, int32_t *n_inliers, void *stream);
+/* ... over the filtered pairs (corr_idx0[c], corr_idx1[c]) of pair `pair` of the last lr_register_pair / lr_register_batch,
+ * with that pair's RANSAC model (lr_pair_result.T_ransac); mask has room for n0 entries, the first n_corr are written.      */
+LR_API int lr_workspace_mask_at(lr_workspace *ws, int pair, const float *xyz0, const float *xyz1, int n0, float thr2,
+                                uint8_t *mask, int32_t *n_inliers, void *stream);
 
 /* ---- a11: LS refit on the original NN pairs within thr of T_in  (FR.py:99-111) -------------------- */
 LR_API int lr_refit(lr_workspace *ws, const float *xyz0, int n0, const float *xyz1, const int32_t *idx1,

@@ -40,12 +40,23 @@ def pair_params(args):
     iters = getattr(args, "iters", None)
     iters = 500 * 10 ** 3 if iters is None else int(iters)            # FR.py:65-67
     thr = 2 * VOXEL_SIZE
+    local_opt = 0
     if codebase == "GC":
         sample_size = 3
-        use_elc = getattr(args, "fast_rejection", "ELC") == "ELC"
+        fast_rejection = getattr(args, "fast_rejection", "ELC")
+        if fast_rejection == "SPRT":
+            # GC_RANSAC.py:29-34, gcransac_python.cpp:534-568: sequential probability ratio test -- not built; refusing beats
+            # silently running a different pre-verification
+            raise NotImplementedError("--fast_rejection SPRT is not implemented on the HIP path (use ELC or NONE)")
+        assert fast_rejection in ("ELC", "NONE"), "unknown fast_rejection"
+        if float(getattr(args, "spatial_coherence_weight", 0.0)) != 0.0:
+            # GC_RANSAC.py:22: the graph-cut term of the local optimisation; only weight 0 (the reference's default) is built
+            raise NotImplementedError("--spatial_coherence_weight != 0 is not implemented on the HIP path")
+        use_elc = fast_rejection == "ELC"
         conf = float(getattr(args, "GC_conf", 0.999))                  # GC_RANSAC.py:26, test.py:312
-        sampler = 1 if getattr(args, "prosac", True) else 0            # test.py:308 (default True), GC_RANSAC.py:24
+        sampler = 1 if getattr(args, "prosac", True) else 2            # test.py:308 (default True), GC_RANSAC.py:24; unique indices
         scoring = 1                                                    # MSAC, the cost pygcransac ranks models by
+        local_opt = 1 if getattr(args, "GC_LO", True) else 2           # GC_RANSAC.py:36-37; the final least squares always runs
     else:
         sampler = 0
         scoring = 0                                                    # Open3D: fitness, then inlier RMSE
@@ -54,12 +65,13 @@ def pair_params(args):
         conf = float(getattr(args, "o3d_conf", 0.9995))                # FR.py:136
     rp = _ext.RansacParams(sample_size, int(use_elc), np.float32(thr * thr), iters, int(getattr(args, "seed", DEFAULT_SEED)),
                            conf, int(getattr(args, "ransac_batch", 0)), sampler, int(getattr(args, "prosac_growth", 0)),
-                           int(getattr(args, "ransac_scoring", scoring)), 0)
+                           int(getattr(args, "ransac_scoring", scoring)), int(getattr(args, "ransac_local_opt", local_opt)))
     p = _ext.PairParams()
     p.mode = MODES[mode]
-    # open3D codebase: FR.py:99-111 refits over the original NN pairs; the GC codebase returns pygcransac's own final
-    # least squares over its inliers, i.e. over the filtered pairs it was given (GC_RANSAC.py:46-55)
-    p.refit = int(getattr(args, "refit", 2 if codebase == "GC" else 1))
+    # open3D codebase: FR.py:99-111 refits over the original NN pairs; the GC codebase returns what pygcransac returns --
+    # the locally optimised model after its own final least squares over the inliers among the pairs it was given
+    # (GC_RANSAC.py:46-55), which is part of the RANSAC call itself (ransac.local_opt), so no refit stage follows
+    p.refit = int(getattr(args, "refit", 0 if codebase == "GC" else 1))
     p.ransac = rp
     p.gpf_grid_wid = int(getattr(args, "GPF_grid_wid", 10))
     p.gpf_factor = float(getattr(args, "GPF_factor", 2.0))

@@ -17,7 +17,7 @@ SYMBOLS = [
     "lr_version", "lr_last_error", "lr_workspace_create", "lr_workspace_destroy", "lr_workspace_bytes", "lr_workspace_poison",
     "lr_nn_top2", "lr_nn_to_mutual", "lr_feat_ratio", "lr_gpf", "lr_gpf_bb_first", "lr_ransac", "lr_refit", "lr_icp", "lr_kabsch",
     "lr_register_pair", "lr_workspace_lists", "lr_workspace_timing", "lr_workspace_timing_read",
-    "lr_workspace_create_batch", "lr_register_batch", "lr_workspace_lists_at",
+    "lr_workspace_create_batch", "lr_register_batch", "lr_workspace_lists_at", "lr_inlier_mask", "lr_workspace_mask_at",
 ]
 
 
@@ -28,7 +28,7 @@ class LidarRegError(RuntimeError):
 class RansacParams(ctypes.Structure):
     _fields_ = [("sample_size", ctypes.c_int32), ("use_elc", ctypes.c_int32), ("thr2", ctypes.c_float),
                 ("iters", ctypes.c_int32), ("seed", ctypes.c_uint64), ("confidence", ctypes.c_float), ("batch", ctypes.c_int32),
-                ("sampler", ctypes.c_int32), ("prosac_growth", ctypes.c_int32), ("scoring", ctypes.c_int32), ("reserved0", ctypes.c_int32)]
+                ("sampler", ctypes.c_int32), ("prosac_growth", ctypes.c_int32), ("scoring", ctypes.c_int32), ("local_opt", ctypes.c_int32)]
 
 
 class RansacResult(ctypes.Structure):
@@ -102,6 +102,8 @@ def lib():
         L.lr_register_pair.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ctypes.POINTER(PairParams), vp, vp]
         L.lr_workspace_lists.argtypes = [vp, ci, vp, vp, vp, vp, vp]
         L.lr_workspace_lists_at.argtypes = [vp, ci, ci, vp, vp, vp, vp, vp]
+        L.lr_inlier_mask.argtypes = [vp, vp, vp, ci, vp, ctypes.c_float, vp, vp, vp]
+        L.lr_workspace_mask_at.argtypes = [vp, ci, vp, vp, ci, ctypes.c_float, vp, vp, vp]
         L.lr_workspace_create_batch.argtypes = [ctypes.POINTER(ctypes.c_void_p), ci, ci, ci, ci, ci]
         pp, ip = ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int32)
         L.lr_register_batch.argtypes = [vp, ci, pp, pp, pp, pp, ip, ip, ci, ctypes.POINTER(PairParams), vp, vp]

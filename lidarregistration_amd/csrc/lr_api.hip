@@ -78,8 +78,9 @@ void carve(lr_workspace *ws, Carver &c)
     ws->icp_ints = c.take<int32_t>(3 * (32768 + 8));
     ws->icp_bucket = c.take<int32_t>(n1); ws->icp_pts = c.take<float>(4 * n1);
     ws->icp_state = c.take<double>(32); ws->icp_part = c.take<double>((n0 / 256 + 2) * 18);
+    ws->lo_list = c.take<int32_t>(n0);
     ws->res_tmp = c.take<lr_ransac_result>(1);
-    ws->T_tmp = c.take<double>(32);
+    ws->T_tmp = c.take<double>(48);      // [0,16) RANSAC model, [16,32) refit, [32,48) ICP
 }
 }  // namespace
 
@@ -325,6 +326,29 @@ extern "C" int lr_ransac(lr_workspace *ws, const float *src, const float *tgt, i
     return lr_ransac_run(ws, ws->corr8, m, m_dev, p, T_out, res, st);
 }
 
+// the inlier mask pygcransac returns next to the pose (gcransac_python.cpp:594-603)
+extern "C" int lr_inlier_mask(lr_workspace *ws, const float *src, const float *tgt, int m, const double *T, float thr2,
+                              uint8_t *mask, int32_t *n_inliers, void *stream)
+{
+    LR_REQUIRE(src && tgt && mask && m >= 0, LR_EINVAL, "lr_inlier_mask: bad argument");
+    LR_REQUIRE(T || ws, LR_EINVAL, "lr_inlier_mask: neither a model nor a workspace");
+    LR_REQUIRE(thr2 > 0.0f, LR_EINVAL, "lr_inlier_mask: thr2 must be positive");
+    return lr_inlier_mask_run(src, tgt, nullptr, nullptr, m, nullptr, T ? T : ws->T_tmp, thr2, mask, n_inliers, (hipStream_t)stream);
+}
+
+extern "C" int lr_workspace_mask_at(lr_workspace *ws, int pair, const float *xyz0, const float *xyz1, int n0, float thr2,
+                                    uint8_t *mask, int32_t *n_inliers, void *stream)
+{
+    LR_REQUIRE(ws && xyz0 && xyz1 && mask, LR_EINVAL, "lr_workspace_mask_at: null pointer");
+    LR_REQUIRE(pair >= 0 && pair < ws->max_pairs, LR_EINVAL, "lr_workspace_mask_at: pair outside the workspace");
+    LR_REQUIRE(n0 > 0 && n0 <= ws->max_n0, LR_ESIZE, "lr_workspace_mask_at: n0 exceeds the workspace");
+    LR_REQUIRE(thr2 > 0.0f, LR_EINVAL, "lr_workspace_mask_at: thr2 must be positive");
+    const size_t off = (size_t)pair * ws->stride;
+    auto at = [&](auto *p) { return reinterpret_cast<decltype(p)>(reinterpret_cast<char *>(p) + off); };
+    return lr_inlier_mask_run(xyz0, xyz1, at(ws->corr_idx0), at(ws->corr_idx1), n0, at(ws->counters) + LR_CNT_NCORR, at(ws->T_tmp), thr2,
+                              mask, n_inliers, (hipStream_t)stream);
+}
+
 // ------------------------------------------------------------------ a11
 extern "C" int lr_refit(lr_workspace *ws, const float *xyz0, int n0, const float *xyz1, const int32_t *idx1,
                         const double *T_in, double thr2, double *T_out, int32_t *n_inl, void *stream)
@@ -435,8 +459,8 @@ static int register_stages(lr_workspace *ws, const float *xyz0, const float *xyz
     // 5. ICP refinement (test.py:183-189): max distance 2*voxel, Open3D's default criteria
     lr_icp_result *icp_res = reinterpret_cast<lr_icp_result *>(ws->icp_state + 24);
     if (p->icp)
-        LR_TRY(lr_icp_run(ws, xyz0, n0, xyz1, n1, T_final, ws->res_tmp, 0.6, 30, 1e-6, 1e-6, ws->T_tmp, icp_res, st));
-    if (p->icp) hipLaunchKernelGGL(pair_icp_kernel, dim3(1, 1, ws->zP), dim3(64), 0, st, ws->T_tmp, icp_res, out, 1, ws->z);
+        LR_TRY(lr_icp_run(ws, xyz0, n0, xyz1, n1, T_final, ws->res_tmp, 0.6, 30, 1e-6, 1e-6, ws->T_tmp + 32, icp_res, st));
+    if (p->icp) hipLaunchKernelGGL(pair_icp_kernel, dim3(1, 1, ws->zP), dim3(64), 0, st, ws->T_tmp + 32, icp_res, out, 1, ws->z);
     LR_LAUNCH_CHECK();
     return LR_OK;
 }

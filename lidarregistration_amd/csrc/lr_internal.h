@@ -136,6 +136,7 @@ struct lr_workspace {
     uint32_t *score_cnt;         // [max_iters]
     unsigned long long *score_ssq; // [max_iters]
     double *refit_part;          // [blocks][16] moment partials
+    int32_t *lo_list;            // [max_n0] inlier list of the model under local optimisation
     lr_ransac_result *res_tmp;
     double *T_tmp;               // [32]
     // --- ICP ---
@@ -179,6 +180,8 @@ struct lr_ransac_state {
     uint32_t cnt;
     int32_t h;                    // its id (valid when cnt > 0)
     int32_t done;                 // set when the confidence test says stop: later batches return immediately
+    int32_t lo_pending;           // the best model changed in the batch just merged: the local optimisation has to run on it
+    int32_t lo_calls;             // local optimisations run so far (part of the key of their sample stream)
     int32_t pad;
 };
 static_assert(sizeof(lr_ransac_state) <= (LR_CNT_TOTAL - LR_CNT_COUNT) * sizeof(int32_t), "lr_ransac_state does not fit");
@@ -230,6 +233,8 @@ int lr_icp_run(lr_workspace *ws, const float *xyz0, int n0, const float *xyz1, i
 // lr_ransac.hip
 int lr_ransac_run(lr_workspace *ws, const float *corr8, int m_max, const int32_t *m_dev, const lr_ransac_params *p,
                   double *T_out, lr_ransac_result *res, hipStream_t st);
+int lr_inlier_mask_run(const float *src, const float *tgt, const int32_t *i0, const int32_t *i1, int m_max, const int32_t *m_dev,
+                       const double *T, float thr2, uint8_t *mask, int32_t *n_inliers, hipStream_t st);
 int lr_refit_run(lr_workspace *ws, const float *xyz0, int n0, const float *xyz1, const int32_t *idx1,
                  const double *T_in, double thr2, double *T_out, int32_t *n_inl, const lr_ransac_result *gate,
                  hipStream_t st, lr_pair_result *pair_out = nullptr, const int32_t *idx0 = nullptr, const int32_t *m_dev = nullptr,

@@ -116,7 +116,7 @@ prosac_growth_kernel(int m_max, const int32_t *__restrict__ m_dev, int ns, int T
 template <int NS>
 __device__ __forceinline__ bool hypothesis_sample(const float *__restrict__ corr8, int m, uint64_t seed, uint64_t h,
                                                   int use_elc, double P[NS][3], double Q[NS][3],
-                                                  const int32_t *__restrict__ G, int TN)
+                                                  const int32_t *__restrict__ G, int TN, int unique = 0)
 {
     uint32_t c[4] = { (uint32_t)h, (uint32_t)(h >> 32), 0u, 0u };
     philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
@@ -128,18 +128,26 @@ __device__ __forceinline__ bool hypothesis_sample(const float *__restrict__ corr
         while (lo < hi) { const int mid = (lo + hi) >> 1; if (G[mid] <= k) lo = mid + 1; else hi = mid; }
         n_top = min(m, lo);                        // = NS + #{n : G[n] <= k}
     }
+    uint32_t sidx[NS];
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
         uint32_t s = __umulhi(c[k], (uint32_t)m);
         if (n_top) s = k < NS - 1 ? __umulhi(c[k], (uint32_t)(n_top - 1)) : (uint32_t)(n_top - 1);
+        sidx[k] = s;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             P[k][a] = (double)corr8[lr_corr_at((int)s, a)];
             Q[k][a] = (double)corr8[lr_corr_at((int)s, 3 + a)];
         }
     }
-    if (!use_elc) return true;
     bool ok = true;
+    if (unique) {       // GC-RANSAC's samplers draw distinct indices: a repeated index rejects the draw
+#pragma unroll
+        for (int i = 0; i < NS; ++i)
+#pragma unroll
+            for (int j = i + 1; j < NS; ++j) if (sidx[i] == sidx[j]) ok = false;
+    }
+    if (!use_elc) return ok;
 #pragma unroll
     for (int i = 0; i < NS; ++i)
 #pragma unroll
@@ -174,7 +182,7 @@ ransac_gen_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__r
     const int h = h_begin + blockIdx.x * 256 + threadIdx.x;
     {
         double P[NS][3], Q[NS][3];
-        if (h < h_end && hypothesis_sample<NS>(corr8, m, p.seed, (uint64_t)h, p.use_elc, P, Q, G, TN)) s_pass[atomicAdd(&s_np, 1)] = h;
+        if (h < h_end && hypothesis_sample<NS>(corr8, m, p.seed, (uint64_t)h, p.use_elc, P, Q, G, TN, p.sampler != 0)) s_pass[atomicAdd(&s_np, 1)] = h;
     }
     __syncthreads();
     const int np = s_np;
@@ -333,7 +341,11 @@ ransac_final_kernel(const uint32_t *__restrict__ score_cnt, const unsigned long 
         state->cnt = nc; state->ssq = nq; state->h = nh;
         state->n_valid += V; state->n_ids = h_end;
         counters[LR_CNT_NVALID] = 0;                       // the next batch appends from slot 0
-        if (p.confidence > 0.0f && p.confidence < 1.0f && nc > 0) {
+        // with local optimisation a new best model is optimised first (ransac_lo_kernel, next on the stream), and the exit
+        // test runs there on the optimised model
+        const bool to_lo = take && p.local_opt == 1;
+        if (to_lo) state->lo_pending = 1;
+        if (!to_lo && p.confidence > 0.0f && p.confidence < 1.0f && nc > 0) {
             // exit rule of Open3D's RANSAC / GC-RANSAC at batch granularity: stop once h_end >= log(1-conf)/log(1-(inl/M)^n)
             const int m = m_dev ? min(*m_dev, m_max) : m_max;
             const double f = (double)nc / (double)m;
@@ -347,6 +359,303 @@ ransac_final_kernel(const uint32_t *__restrict__ score_cnt, const unsigned long 
         r.n_valid = state->n_valid; r.n_ids = h_end;
         *res = r;
     }
+}
+
+
+// ------------------------------------------------------------------ local optimisation (GC-RANSAC, --GC_LO) + final polish
+// One block of 1024 threads per pair; see oracle/oracle.c (lo_optimise / lo_polish) for the algorithm and its sources.
+//   mode 0 (after a batch whose winner became the best model): <= LO_ROUNDS rounds of { inlier list of the model; LO_TRIALS
+//          least-squares fits on LO_SAMPLE inliers each (all of them when there are no more: one fit); every fit scored over
+//          ALL correspondences by 1024 / trials threads; the best replaces the model if strictly better, else stop }, then the
+//          confidence test on the optimised model
+//   mode 1 (once, after the last batch): iterated least squares over all inliers
+// All sums that decide anything are integers (order independent); the fp64 moments of the all-inlier fits run as 1024 strided
+// partials + a fixed halving tree, the order oracle.c reproduces, so the models agree bit for bit.
+#define LO_ROUNDS 10
+#define LO_TRIALS 20
+#define LO_SAMPLE 21
+#define LO_POLISH 10
+#define LO_THREADS 1024
+
+struct lo_shared {
+    double T[LO_TRIALS][12];         // candidate models of the round (fp64)
+    float Rt[LO_TRIALS][12];         // ... rounded for the scoring arithmetic
+    int pos[LO_TRIALS][LO_SAMPLE];   // sampled positions in the inlier list
+    unsigned cnt[LO_TRIALS];
+    unsigned long long ssq[LO_TRIALS];
+    double red[4][LO_THREADS];       // block reduction of the fp64 moments, four components at a time
+    double mom[16];
+    double curT[12];                 // model under optimisation
+    unsigned long long curq;
+    unsigned curc;
+    int wsum[16];
+    int nI, flag;
+};
+
+__device__ __forceinline__ float lo_d2(const float *Rt, float px, float py, float pz, float qx, float qy, float qz)
+{
+    const float x = __builtin_fmaf(Rt[0], px, __builtin_fmaf(Rt[1], py, __builtin_fmaf(Rt[2], pz, Rt[3])));
+    const float y = __builtin_fmaf(Rt[4], px, __builtin_fmaf(Rt[5], py, __builtin_fmaf(Rt[6], pz, Rt[7])));
+    const float z = __builtin_fmaf(Rt[8], px, __builtin_fmaf(Rt[9], py, __builtin_fmaf(Rt[10], pz, Rt[11])));
+    const float dx = x - qx, dy = y - qy, dz = z - qz;
+    return __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
+}
+
+// inliers of sh.curT over the m correspondences, in index order -> list[0 .. sh.nI)
+__device__ void lo_build_list(lo_shared &sh, const float *__restrict__ corr8, int m, float thr2, int32_t *__restrict__ list)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float Rt[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) Rt[k] = (float)sh.curT[k];
+    if (tid == 0) sh.nI = 0;
+    __syncthreads();
+    for (int base = 0; base < m; base += LO_THREADS) {
+        const int i = base + tid;
+        bool in = false;
+        if (i < m) {
+            const float d2 = lo_d2(Rt, corr8[lr_corr_at(i, 0)], corr8[lr_corr_at(i, 1)], corr8[lr_corr_at(i, 2)], corr8[lr_corr_at(i, 3)],
+                                   corr8[lr_corr_at(i, 4)], corr8[lr_corr_at(i, 5)]);
+            in = d2 < thr2;
+        }
+        const unsigned long long bal = __ballot(in);
+        if (lane == 0) sh.wsum[wave] = __popcll(bal);
+        __syncthreads();
+        int off = sh.nI;
+        for (int w = 0; w < wave; ++w) off += sh.wsum[w];
+        if (in) list[off + __popcll(bal & ((1ull << lane) - 1ull))] = i;
+        __syncthreads();
+        if (tid == 0) { int t = 0; for (int w = 0; w < LO_THREADS / 64; ++w) t += sh.wsum[w]; sh.nI += t; }
+        __syncthreads();
+    }
+}
+
+// least-squares fit over the listed correspondences -> sh.T[0] / sh.Rt[0]; false when fewer than 3 points
+__device__ bool lo_fit_all(lo_shared &sh, const float *__restrict__ corr8, const int32_t *__restrict__ list, int n)
+{
+    const int tid = threadIdx.x;
+    double v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = 0.0;
+    for (int e = tid; e < n; e += LO_THREADS) {
+        const int i = list[e];
+        const double p[3] = { (double)corr8[lr_corr_at(i, 0)], (double)corr8[lr_corr_at(i, 1)], (double)corr8[lr_corr_at(i, 2)] };
+        const double q[3] = { (double)corr8[lr_corr_at(i, 3)], (double)corr8[lr_corr_at(i, 4)], (double)corr8[lr_corr_at(i, 5)] };
+        v[0] += 1.0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { v[1 + a] += p[a]; v[4 + a] += q[a]; }
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) v[7 + 3 * a + b] += p[a] * q[b];
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sh.red[k][tid] = v[4 * g + k];
+        for (int sft = LO_THREADS / 2; sft >= 1; sft >>= 1) {
+            __syncthreads();
+            if (tid < sft) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sh.red[k][tid] += sh.red[k][tid + sft];
+            }
+        }
+        __syncthreads();
+        if (tid < 4) sh.mom[4 * g + tid] = sh.red[tid][0];
+    }
+    __syncthreads();
+    const bool ok = sh.mom[0] >= 3.0;
+    if (ok && tid == 0) {
+        const double nn = sh.mom[0];
+        double cp[3], cq[3], H[3][3], T[16];
+        for (int a = 0; a < 3; ++a) { cp[a] = sh.mom[1 + a] / nn; cq[a] = sh.mom[4 + a] / nn; }
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) H[a][b] = sh.mom[7 + 3 * a + b] - (nn * cp[a]) * cq[b];
+        lr_rt_from_cov(H, cp, cq, T);
+        for (int k = 0; k < 12; ++k) { sh.T[0][k] = T[k]; sh.Rt[0][k] = (float)T[k]; }
+    }
+    __syncthreads();
+    return ok;
+}
+
+// score sh.Rt[0 .. ntrial) over all m correspondences -> sh.cnt / sh.ssq (integer atomics in LDS)
+__device__ void lo_score(lo_shared &sh, const float *__restrict__ corr8, int m, float thr2, int ntrial)
+{
+    const int tid = threadIdx.x;
+    if (tid < LO_TRIALS) { sh.cnt[tid] = 0u; sh.ssq[tid] = 0ull; }
+    __syncthreads();
+    const int per = LO_THREADS / ntrial;           // threads per model
+    const int t = tid / per, l = tid % per;
+    if (t < ntrial) {
+        float Rt[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) Rt[k] = sh.Rt[t][k];
+        unsigned c = 0; unsigned long long q = 0;
+        for (int i = l; i < m; i += per) {
+            const float d2 = lo_d2(Rt, corr8[lr_corr_at(i, 0)], corr8[lr_corr_at(i, 1)], corr8[lr_corr_at(i, 2)], corr8[lr_corr_at(i, 3)],
+                                   corr8[lr_corr_at(i, 4)], corr8[lr_corr_at(i, 5)]);
+            if (d2 < thr2) { c += 1u; q += (unsigned long long)(uint32_t)(d2 * 1048576.0f); }
+        }
+        if (c) { atomicAdd(&sh.cnt[t], c); atomicAdd(&sh.ssq[t], q); }
+    }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(LO_THREADS)
+ransac_lo_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__restrict__ m_dev, lr_ransac_params p, int h_end, int mode,
+                 int32_t *__restrict__ counters, int32_t *__restrict__ list, double *__restrict__ T_out, lr_ransac_result *__restrict__ res,
+                 lr_zargs z)
+{
+    lr_z(corr8, z, blockIdx.z); lr_z(m_dev, z, blockIdx.z); lr_z(counters, z, blockIdx.z); lr_z(list, z, blockIdx.z); lr_z(T_out, z, blockIdx.z);
+    lr_z(res, z, blockIdx.z);
+    __shared__ lo_shared sh;
+    lr_ransac_state *state = reinterpret_cast<lr_ransac_state *>(counters + LR_CNT_COUNT);
+    const int m = m_dev ? min(*m_dev, m_max) : m_max;
+    const int tid = threadIdx.x;
+    if (state->cnt == 0 || m <= 0) return;                         // no model
+    if (mode == 0 && !state->lo_pending) return;                  // best model unchanged by the batch just merged
+    const uint32_t msac_T = p.scoring == 1 ? (uint32_t)(p.thr2 * 1048576.0f) : 0u;
+    if (tid < 12) sh.curT[tid] = state->T[tid];
+    if (tid == 0) { sh.curc = state->cnt; sh.curq = state->ssq; }
+    const int call = state->lo_calls;
+    __syncthreads();
+    if (mode == 0) {
+        for (int round = 0; round < LO_ROUNDS; ++round) {
+            lo_build_list(sh, corr8, m, p.thr2, list);
+            const int nI = sh.nI;
+            if (nI <= p.sample_size) break;
+            const int ntrial = nI > LO_SAMPLE ? LO_TRIALS : 1;
+            if (nI > LO_SAMPLE) {
+                // one thread per trial: LO_SAMPLE distinct positions (word stream keyed by seed, call, round, trial), then the
+                // least-squares fit on those points (the arithmetic of kabsch_points_kernel / orc_kabsch_points)
+                if (tid < LO_TRIALS) {
+                    int *pos = sh.pos[tid];
+                    int got = 0;
+                    const uint64_t key = p.seed ^ 0x4c4f43414c4f5054ull;
+                    for (int blk = 0; blk < 32 && got < LO_SAMPLE; ++blk) {
+                        const uint64_t ctr = ((uint64_t)call << 40) | ((uint64_t)round << 32) | ((uint64_t)tid << 8) | (uint64_t)blk;
+                        uint32_t w[4] = { (uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u };
+                        philox4x32_10(w, (uint32_t)key, (uint32_t)(key >> 32));
+                        for (int k = 0; k < 4 && got < LO_SAMPLE; ++k) {
+                            const int c = (int)__umulhi(w[k], (uint32_t)nI);
+                            bool dup = false;
+                            for (int j = 0; j < got; ++j) dup |= pos[j] == c;
+                            if (!dup) pos[got++] = c;
+                        }
+                    }
+                    for (int c = 0; got < LO_SAMPLE; ++c) {
+                        bool dup = false;
+                        for (int j = 0; j < got; ++j) dup |= pos[j] == c;
+                        if (!dup) pos[got++] = c;
+                    }
+                    double cp[3] = { 0, 0, 0 }, cq[3] = { 0, 0, 0 }, W = 0.0;
+                    for (int k = 0; k < LO_SAMPLE; ++k) {
+                        const int i = list[pos[k]];
+                        W = W + 1.0;
+                        for (int a = 0; a < 3; ++a) { cp[a] = cp[a] + 1.0 * (double)corr8[lr_corr_at(i, a)]; cq[a] = cq[a] + 1.0 * (double)corr8[lr_corr_at(i, 3 + a)]; }
+                    }
+                    for (int a = 0; a < 3; ++a) { cp[a] = cp[a] / W; cq[a] = cq[a] / W; }
+                    double H[3][3] = { { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 } };
+                    for (int k = 0; k < LO_SAMPLE; ++k) {
+                        const int i = list[pos[k]];
+                        double pc[3], qc[3];
+                        for (int a = 0; a < 3; ++a) { pc[a] = (double)corr8[lr_corr_at(i, a)] - cp[a]; qc[a] = (double)corr8[lr_corr_at(i, 3 + a)] - cq[a]; }
+                        for (int a = 0; a < 3; ++a)
+                            for (int b = 0; b < 3; ++b) H[a][b] = H[a][b] + (1.0 * pc[a]) * qc[b];
+                    }
+                    double T[16];
+                    lr_rt_from_cov(H, cp, cq, T);
+                    for (int k = 0; k < 12; ++k) { sh.T[tid][k] = T[k]; sh.Rt[tid][k] = (float)T[k]; }
+                }
+                __syncthreads();
+            } else if (!lo_fit_all(sh, corr8, list, nI)) break;
+            lo_score(sh, corr8, m, p.thr2, ntrial);
+            if (tid == 0) {
+                int bt = -1; unsigned bc = 0; unsigned long long bq = 0;
+                for (int t = 0; t < ntrial; ++t) {
+                    if (sh.cnt[t] == 0u) continue;
+                    if (bt < 0 || better(sh.cnt[t], sh.ssq[t], t, bc, bq, bt, msac_T)) { bt = t; bc = sh.cnt[t]; bq = sh.ssq[t]; }
+                }
+                // strictly better than the model under optimisation
+                sh.flag = (bt >= 0 && better(bc, bq, 1, sh.curc, sh.curq, 0, msac_T)) ? bt : -1;
+                if (sh.flag >= 0) { sh.curc = bc; sh.curq = bq; for (int k = 0; k < 12; ++k) sh.curT[k] = sh.T[bt][k]; }
+            }
+            __syncthreads();
+            if (sh.flag < 0) break;
+        }
+    } else {
+        for (int it = 0; it < LO_POLISH; ++it) {
+            lo_build_list(sh, corr8, m, p.thr2, list);
+            const int nI = sh.nI;
+            if (nI <= p.sample_size || !lo_fit_all(sh, corr8, list, nI)) break;
+            lo_score(sh, corr8, m, p.thr2, 1);
+            if (tid == 0) {
+                // a fit that loses inliers is discarded; an equal count is kept and ends the iteration; more: again
+                const unsigned tc = sh.cnt[0];
+                sh.flag = tc < sh.curc ? -1 : (tc == sh.curc ? 0 : 1);
+                if (sh.flag >= 0) { sh.curc = tc; sh.curq = sh.ssq[0]; for (int k = 0; k < 12; ++k) sh.curT[k] = sh.T[0][k]; }
+            }
+            __syncthreads();
+            if (sh.flag <= 0) break;
+        }
+    }
+    __syncthreads();
+    // back to the running state; outputs rewritten from it
+    if (tid < 16) {
+        double v = (tid % 5 == 0) ? 1.0 : 0.0;
+        if (tid < 12) { v = sh.curT[tid]; state->T[tid] = v; }
+        T_out[tid] = v;
+    }
+    if (tid == 0) {
+        state->cnt = sh.curc; state->ssq = sh.curq;
+        if (mode == 0) {
+            state->lo_pending = 0; state->lo_calls = call + 1;
+            if (p.confidence > 0.0f && p.confidence < 1.0f) {
+                const double f = (double)sh.curc / (double)m;
+                double fn = f;
+                for (int q = 1; q < p.sample_size; ++q) fn = fn * f;
+                const double kk = log(1.0 - (double)p.confidence) / log(1.0 - fn);
+                if ((double)h_end >= kk) state->done = 1;
+            }
+        }
+        lr_ransac_result r;
+        r.best_h = state->h; r.best_count = sh.curc; r.pad0 = 0; r.best_ssq = sh.curq;
+        r.n_valid = state->n_valid; r.n_ids = state->n_ids;
+        *res = r;
+    }
+}
+
+// ------------------------------------------------------------------ inlier mask (what findRigidTransform returns next to the pose)
+__global__ void __launch_bounds__(256)
+inlier_mask_kernel(const float *__restrict__ src, const float *__restrict__ tgt, const int32_t *__restrict__ i0, const int32_t *__restrict__ i1,
+                   int m_max, const int32_t *__restrict__ m_dev, const double *__restrict__ T, float thr2, uint8_t *__restrict__ mask,
+                   int32_t *__restrict__ n_inliers)
+{
+    const int m = m_dev ? min(*m_dev, m_max) : m_max;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    bool in = false;
+    if (c < m) {
+        float Rt[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) Rt[k] = (float)T[k];
+        const int a = i0 ? i0[c] : c, b = i1 ? i1[c] : c;
+        in = lo_d2(Rt, src[3 * a], src[3 * a + 1], src[3 * a + 2], tgt[3 * b], tgt[3 * b + 1], tgt[3 * b + 2]) < thr2;
+        mask[c] = in ? 1 : 0;
+    }
+    if (n_inliers) {
+        const unsigned long long bal = __ballot(in);
+        if ((threadIdx.x & 63) == 0 && bal) atomicAdd(n_inliers, (int)__popcll(bal));
+    }
+}
+
+int lr_inlier_mask_run(const float *src, const float *tgt, const int32_t *i0, const int32_t *i1, int m_max, const int32_t *m_dev,
+                       const double *T, float thr2, uint8_t *mask, int32_t *n_inliers, hipStream_t st)
+{
+    if (n_inliers) LR_HIP(hipMemsetAsync(n_inliers, 0, sizeof(int32_t), st));
+    hipLaunchKernelGGL(inlier_mask_kernel, dim3(lr_cdiv(m_max > 0 ? m_max : 1, 256)), dim3(256), 0, st, src, tgt, i0, i1, m_max, m_dev, T, thr2, mask, n_inliers);
+    LR_LAUNCH_CHECK();
+    return LR_OK;
 }
 
 int lr_ransac_run(lr_workspace *ws, const float *corr8, int m_max, const int32_t *m_dev, const lr_ransac_params *p,
@@ -363,7 +672,8 @@ int lr_ransac_run(lr_workspace *ws, const float *corr8, int m_max, const int32_t
     const bool use_exit = p->confidence > 0.0f && p->confidence < 1.0f;
     // default batch: 8192 ids, or an eighth of a long run (the launches of the batches after the exit still cost a few us each)
     const int B = use_exit ? (p->batch > 0 ? p->batch : (p->iters > 65536 ? ((p->iters / 8 + 8191) / 8192) * 8192 : 8192)) : (p->iters > 0 ? p->iters : 1);
-    LR_REQUIRE(p->sampler == 0 || p->sampler == 1, LR_EINVAL, "lr_ransac: sampler must be 0 (uniform) or 1 (PROSAC)");
+    LR_REQUIRE(p->sampler >= 0 && p->sampler <= 2, LR_EINVAL, "lr_ransac: sampler must be 0 (uniform), 1 (PROSAC) or 2 (uniform, unique indices)");
+    LR_REQUIRE(p->local_opt >= 0 && p->local_opt <= 2, LR_EINVAL, "lr_ransac: local_opt must be 0, 1 or 2");
     LR_REQUIRE(p->prosac_growth >= 0, LR_EINVAL, "lr_ransac: prosac_growth must be >= 0");
     LR_REQUIRE(p->scoring == 0 || p->scoring == 1, LR_EINVAL, "lr_ransac: scoring must be 0 (count, then error) or 1 (MSAC)");
     const int TN = p->prosac_growth > 0 ? p->prosac_growth : 100000;
@@ -387,7 +697,13 @@ int lr_ransac_run(lr_workspace *ws, const float *corr8, int m_max, const int32_t
         if (h0 == 0 && ws->timing && ws->ev_pending == 1) { LR_HIP(hipEventRecord(ws->ev[3], st)); ws->ev_pending = 2; }
         hipLaunchKernelGGL(ransac_final_kernel, dim3(1, 1, ws->zP), dim3(1024), 0, st, ws->score_cnt, ws->score_ssq, ws->model_h, ws->models64,
                            ws->counters, m_max, m_dev, *p, h1, T_out, res, ws->z);
+        if (p->local_opt == 1)
+            hipLaunchKernelGGL(ransac_lo_kernel, dim3(1, 1, ws->zP), dim3(LO_THREADS), 0, st, corr8, m_max, m_dev, *p, h1, 0, ws->counters, ws->lo_list,
+                               T_out, res, ws->z);
     }
+    if (p->local_opt)          // final iterated least squares over the inliers
+        hipLaunchKernelGGL(ransac_lo_kernel, dim3(1, 1, ws->zP), dim3(LO_THREADS), 0, st, corr8, m_max, m_dev, *p, p->iters, 1, ws->counters, ws->lo_list,
+                           T_out, res, ws->z);
     LR_LAUNCH_CHECK();
     return LR_OK;
 }

@@ -17,26 +17,36 @@ DEFAULT_SEED = 51          # Experiments/test.py:357
 
 
 def ransac_params(iters, sample_size=3, use_elc=True, thr=0.6, seed=DEFAULT_SEED, confidence=1.0, batch=0, sampler=0, prosac_growth=0,
-                  scoring=0):
+                  scoring=0, local_opt=0):
     """confidence < 1 enables the early exit between batches of `batch` hypothesis ids (0 -> 8192, an eighth of the run when iters > 65536); sampler 1 = PROSAC
-    (correspondences best quality first, growth parameter T_N = prosac_growth, 0 -> 100000); scoring 1 = MSAC."""
+    (correspondences best quality first, growth parameter T_N = prosac_growth, 0 -> 100000), 2 = uniform with unique indices; scoring 1 = MSAC;
+    local_opt 1 = GC-RANSAC's local optimisation + final iterated least squares, 2 = the latter only."""
     return _ext.RansacParams(int(sample_size), int(bool(use_elc)), np.float32(float(thr) * float(thr)), int(iters), int(seed),
-                             float(confidence), int(batch), int(sampler), int(prosac_growth), int(scoring), 0)
+                             float(confidence), int(batch), int(sampler), int(prosac_growth), int(scoring), int(local_opt))
 
 
 def ransac_dev(src, tgt, iters, sample_size=3, use_elc=True, thr=0.6, seed=DEFAULT_SEED, confidence=1.0, batch=0, sampler=0,
-               prosac_growth=0, scoring=0):
-    """RANSAC over M correspondences src[i] <-> tgt[i] ([M,3]).  Returns (T 4x4 float64 numpy, info dict)."""
+               prosac_growth=0, scoring=0, local_opt=0, want_mask=False):
+    """RANSAC over M correspondences src[i] <-> tgt[i] ([M,3]).  Returns (T 4x4 float64 numpy, info dict); with want_mask the
+    info holds the inlier mask of the returned model (what pygcransac.findRigidTransform returns next to the pose)."""
     src, tgt = _f32(src), _f32(tgt)
     m = src.shape[0]
     ws = workspace(max(m, 1), 1, iters)
     T = torch.empty(16, dtype=torch.float64, device=src.device)
     res = torch.zeros(ctypes.sizeof(_ext.RansacResult), dtype=torch.uint8, device=src.device)
-    p = ransac_params(iters, sample_size, use_elc, thr, seed, confidence, batch, sampler, prosac_growth, scoring)
+    p = ransac_params(iters, sample_size, use_elc, thr, seed, confidence, batch, sampler, prosac_growth, scoring, local_opt)
     _ext.check(_ext.lib().lr_ransac(ws.handle, src.data_ptr(), tgt.data_ptr(), m, None, ctypes.byref(p),
                                      T.data_ptr(), res.data_ptr(), _stream()))
+    mask = None
+    if want_mask:
+        mask = torch.zeros(max(m, 1), dtype=torch.uint8, device=src.device)
+        nin = torch.zeros(1, dtype=torch.int32, device=src.device)
+        _ext.check(_ext.lib().lr_inlier_mask(ws.handle, src.data_ptr(), tgt.data_ptr(), m, T.data_ptr(), ctypes.c_float(p.thr2),
+                                              mask.data_ptr(), nin.data_ptr(), _stream()))
     r = _ext.RansacResult.from_buffer_copy(res.cpu().numpy().tobytes())
     info = dict(best_h=r.best_h, best_count=r.best_count, best_ssq=r.best_ssq, n_valid=r.n_valid, n_ids=r.n_ids)
+    if want_mask:
+        info["mask"] = mask[:m].cpu().numpy().astype(bool); info["n_inliers"] = int(nin.item())
     return T.cpu().numpy().reshape(4, 4), info
 
 
@@ -79,16 +89,22 @@ def kabsch_dev(P, Q, w=None):
     return T.cpu().numpy().reshape(4, 4)
 
 
-def GC_RANSAC(A, B, distance_threshold, num_iterations, args, match_quality):
-    """GC_RANSAC.py:8-55: (pose 4x4 column-vector convention, elapsed seconds).
-
-    A, B: [M,3] float32 numpy.  Flags read from args: fast_rejection ("ELC" | "NONE" | "SPRT"; SPRT has no
-    device counterpart and is treated as ELC off), prosac (GC_RANSAC.py:24,39-43: pairs sorted by -match_quality,
-    ties by index, PROSAC sampler).  Local optimisation and the spatial-coherence term of the third-party
-    library are not part of this path."""
-    use_elc = getattr(args, "fast_rejection", "ELC") == "ELC"
+def GC_RANSAC(A, B, distance_threshold, num_iterations, args, match_quality, return_mask=False):
+    """GC_RANSAC.py:8-55: (pose 4x4 column-vector convention, elapsed seconds) -- the same estimator ``FR(codebase="GC")``
+    runs: 3-point samples drawn without repetition, pre-check by ``args.fast_rejection`` ("ELC" | "NONE"; "SPRT" raises),
+    PROSAC when ``args.prosac`` (pairs sorted by -match_quality, GC_RANSAC.py:39-43), MSAC scoring, GC-RANSAC's local
+    optimisation unless ``args.GC_LO`` is False (GC_RANSAC.py:36-37), the final iterated least squares, confidence
+    ``args.GC_conf``.  A non-zero ``args.spatial_coherence_weight`` raises (only the reference's default 0 is built).
+    With return_mask the inlier mask pygcransac returns next to the pose is appended (in the caller's pair order)."""
+    fast_rejection = getattr(args, "fast_rejection", "ELC")
+    if fast_rejection == "SPRT":
+        raise NotImplementedError("--fast_rejection SPRT is not implemented on the HIP path (use ELC or NONE)")
+    if float(getattr(args, "spatial_coherence_weight", 0.0)) != 0.0:
+        raise NotImplementedError("--spatial_coherence_weight != 0 is not implemented on the HIP path")
+    use_elc = fast_rejection == "ELC"
     A = np.ascontiguousarray(A, np.float32); B = np.ascontiguousarray(B, np.float32)
     prosac = bool(getattr(args, "prosac", False)) and match_quality is not None
+    order = None
     if prosac:
         fd = -np.asarray(match_quality, np.float32)
         fd[np.isnan(fd)] = np.inf
@@ -97,10 +113,17 @@ def GC_RANSAC(A, B, distance_threshold, num_iterations, args, match_quality):
     start_time = time()
     T, info = ransac_dev(A, B, num_iterations, sample_size=3, use_elc=use_elc, thr=distance_threshold,
                          seed=getattr(args, "seed", DEFAULT_SEED), confidence=getattr(args, "GC_conf", 0.999),      # GC_RANSAC.py:26
-                         sampler=1 if prosac else 0, scoring=1)                 # MSAC, as pygcransac scores models
+                         sampler=1 if prosac else 2, scoring=1,                 # MSAC, as pygcransac scores models
+                         local_opt=1 if getattr(args, "GC_LO", True) else 2, want_mask=return_mask)
     if info["best_h"] < 0:
         T = np.eye(4)                                       # GC_RANSAC.py:51-52
-    return T, time() - start_time
+    elapsed = time() - start_time
+    if return_mask:
+        mask = info["mask"]
+        if order is not None:
+            unsorted = np.zeros_like(mask); unsorted[order] = mask; mask = unsorted
+        return T, elapsed, mask
+    return T, elapsed
 
 
 def RANSAC_registration(pcd0, pcd1, idx0, idx1, distance_threshold, num_iterations, args):

@@ -335,10 +335,13 @@ typedef struct {
     uint64_t seed;
     float    confidence;      /* early exit between batches (FR.py:136, GC_RANSAC.py:26); >= 1 or <= 0: none */
     int32_t  batch;           /* batch length (0 -> 8192; iters > 65536: iters/8 rounded up to a multiple of 8192) */
-    int32_t  sampler;         /* 0 uniform; 1 PROSAC (GC_RANSAC.py:24,39-43): correspondences best first */
+    int32_t  sampler;         /* 0 uniform with replacement (Open3D); 1 PROSAC (GC_RANSAC.py:24,39-43): correspondences best
+                                 first; 2 uniform, unique indices (GC-RANSAC's UniformSampler).  1 and 2 reject a draw with a
+                                 repeated index: it consumes its id like a failed pre-check                                  */
     int32_t  prosac_growth;   /* T_N of the PROSAC growth function (0 -> 100000)       */
     int32_t  scoring;         /* 0: inlier count, then error sum (Open3D); 1: MSAC (GC-RANSAC's truncated quadratic cost) */
-    int32_t  reserved0;
+    int32_t  local_opt;       /* 0 none; 1 GC-RANSAC's local optimisation of every new best model + final iterated least
+                                 squares (GC_RANSAC.py:36-37 --GC_LO True); 2 the final iterated least squares only        */
 } orc_ransac_params;
 
 /* is model (c, q, h) better than (bc, bq, bh)?  msac_T = (uint32)(thr2 * 2^20) for MSAC scoring, else 0 */
@@ -366,6 +369,9 @@ static int hypothesis_T(const float *src, const float *tgt, int m, const orc_ran
     int32_t s[4];
     draw_sample_prosac(p->seed, h, m, p->sample_size, G, p->prosac_growth > 0 ? p->prosac_growth : 100000, s);
     if (sample_out) memcpy(sample_out, s, sizeof(int32_t) * p->sample_size);
+    if (p->sampler != 0)       /* unique-index samplers: a repeated index rejects the draw */
+        for (int a = 0; a < p->sample_size; ++a)
+            for (int b = a + 1; b < p->sample_size; ++b) if (s[a] == s[b]) return 0;
     if (p->use_elc && !elc_ok(src, tgt, s, p->sample_size)) return 0;
     double P[12], Q[12];
     for (int k = 0; k < p->sample_size; ++k)
@@ -408,6 +414,151 @@ ORC_API void orc_score(const float *src, const float *tgt, int m, const double T
     score_model(src, tgt, m, Rt, thr2, count, ssq);
 }
 
+
+/* ------------------------------------------------- local optimisation ---- */
+/* GC-RANSAC's local optimisation (Barath & Matas, "Graph-Cut RANSAC", CVPR 2018, Alg. 2; driver GC-RANSAC/src/pygcransac/
+ * src/gcransac_python.cpp:404-624 selects it with `neighborhood == 0`, GC_RANSAC.py:36-37) as the reference runs it: spatial
+ * coherence weight 0 (GC_RANSAC.py:15, test.py:302), where the graph-cut labelling reduces to its unary term, i.e. to the
+ * points within the threshold of the current model.  The library itself (graph-cut-ransac, pygcransac 0.1) is NOT vendored:
+ * parity unpinned; constants are those of gcransac_python.cpp:508-515 and the library's defaults.
+ *   rounds (<= 10, max_graph_cut_number):  I = inliers of the best model;  inner RANSAC: LO_TRIALS (20,
+ *   max_local_optimization_number) least-squares fits on LO_SAMPLE (7 x minimal sample = 21) points drawn uniformly without
+ *   repetition from I (all of I when it is not larger: one fit), each scored over ALL correspondences; the best of them
+ *   replaces the model if its score is strictly better, otherwise the optimisation stops.
+ * The 20 trials of a round depend only on I, so they are independent: that is what the HIP kernel exploits.
+ * Final polish (iterated least squares, <= 10 fits): refit on all inliers; a fit that loses inliers is discarded and ends
+ * the iteration, a fit with the same number of inliers is kept and ends it (converged), a fit with more is kept and
+ * refitted again.                                                                                                       */
+#define LO_ROUNDS 10
+#define LO_TRIALS 20
+#define LO_SAMPLE 21
+#define LO_POLISH 10
+#define LO_RED 1024         /* fp64 sums run as LO_RED strided partials + a fixed halving tree: the order the HIP block uses */
+
+/* sums v[k] over the listed points in the block-reduction order: partial[t] = sum_{e = t, t+LO_RED, ...}, then the tree */
+static void lo_moments(const float *src, const float *tgt, const int32_t *list, int n, double mom[16])
+{
+    static __thread double part[LO_RED][16];
+    for (int t = 0; t < LO_RED; ++t) {
+        double v[16];
+        for (int k = 0; k < 16; ++k) v[k] = 0.0;
+        for (int e = t; e < n; e += LO_RED) {
+            const int i = list[e];
+            const double p[3] = { src[3 * i], src[3 * i + 1], src[3 * i + 2] }, q[3] = { tgt[3 * i], tgt[3 * i + 1], tgt[3 * i + 2] };
+            v[0] += 1.0;
+            for (int a = 0; a < 3; ++a) { v[1 + a] += p[a]; v[4 + a] += q[a]; }
+            for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) v[7 + 3 * a + b] += p[a] * q[b];
+        }
+        for (int k = 0; k < 16; ++k) part[t][k] = v[k];
+    }
+    for (int sft = LO_RED / 2; sft >= 1; sft >>= 1)
+        for (int t = 0; t < sft; ++t) for (int k = 0; k < 16; ++k) part[t][k] += part[t + sft][k];
+    for (int k = 0; k < 16; ++k) mom[k] = part[0][k];
+}
+
+/* inliers of the fp32 model (the scoring arithmetic), in index order; returns their number */
+static int lo_inliers(const float *src, const float *tgt, int m, const double T[16], float thr2, int32_t *list)
+{
+    float Rt[12];
+    for (int k = 0; k < 12; ++k) Rt[k] = (float)T[k];
+    int n = 0;
+    for (int i = 0; i < m; ++i) {
+        float px = src[3 * i], py = src[3 * i + 1], pz = src[3 * i + 2];
+        float x = fmaf(Rt[0], px, fmaf(Rt[1], py, fmaf(Rt[2], pz, Rt[3])));
+        float y = fmaf(Rt[4], px, fmaf(Rt[5], py, fmaf(Rt[6], pz, Rt[7])));
+        float z = fmaf(Rt[8], px, fmaf(Rt[9], py, fmaf(Rt[10], pz, Rt[11])));
+        float dx = x - tgt[3 * i], dy = y - tgt[3 * i + 1], dz = z - tgt[3 * i + 2];
+        float d2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+        if (d2 < thr2) list[n++] = i;
+    }
+    return n;
+}
+
+static int lo_fit_all(const float *src, const float *tgt, const int32_t *list, int n, double T[16])
+{
+    double mom[16];
+    lo_moments(src, tgt, list, n, mom);
+    if (!(mom[0] >= 3.0)) return 0;
+    orc_kabsch_moments(mom[0], mom + 1, mom + 4, mom + 7, T);
+    return 1;
+}
+
+/* LO_SAMPLE distinct positions of [0, n): word w of the stream (seed, call, round, trial) -> position mulhi(word, n), a
+ * repeated position is skipped; after 128 words the sample is completed with the lowest positions not yet taken */
+static void lo_draw(uint64_t seed, int call, int round, int trial, int n, int32_t *pos)
+{
+    int got = 0;
+    for (int blk = 0; blk < 32 && got < LO_SAMPLE; ++blk) {
+        uint32_t w[4];
+        orc_philox(seed ^ 0x4c4f43414c4f5054ull, ((uint64_t)call << 40) | ((uint64_t)round << 32) | ((uint64_t)trial << 8) | (uint64_t)blk, w);
+        for (int k = 0; k < 4 && got < LO_SAMPLE; ++k) {
+            const int32_t c = (int32_t)(((uint64_t)w[k] * (uint64_t)(uint32_t)n) >> 32);
+            int dup = 0;
+            for (int j = 0; j < got; ++j) if (pos[j] == c) dup = 1;
+            if (!dup) pos[got++] = c;
+        }
+    }
+    for (int c = 0; got < LO_SAMPLE; ++c) {
+        int dup = 0;
+        for (int j = 0; j < got; ++j) if (pos[j] == c) dup = 1;
+        if (!dup) pos[got++] = c;
+    }
+}
+
+/* one local optimisation of (T, c, q); returns 1 when the model was replaced */
+static int lo_optimise(const float *src, const float *tgt, int m, const orc_ransac_params *p, int call, double T[16],
+                       uint32_t *c, uint64_t *q, int32_t *list)
+{
+    const uint32_t msac_T = p->scoring == 1 ? (uint32_t)(p->thr2 * 1048576.0f) : 0u;
+    int changed = 0;
+    for (int round = 0; round < LO_ROUNDS; ++round) {
+        const int nI = lo_inliers(src, tgt, m, T, p->thr2, list);
+        if (nI <= p->sample_size) break;
+        const int ntrial = nI > LO_SAMPLE ? LO_TRIALS : 1;
+        int bt = -1; uint32_t bc = 0; uint64_t bq = 0; double bT[16];
+        for (int t = 0; t < ntrial; ++t) {
+            double Tt[16];
+            if (nI > LO_SAMPLE) {
+                int32_t pos[LO_SAMPLE];
+                lo_draw(p->seed, call, round, t, nI, pos);
+                double P[3 * LO_SAMPLE], Q[3 * LO_SAMPLE];
+                for (int k = 0; k < LO_SAMPLE; ++k) {
+                    const int i = list[pos[k]];
+                    for (int a = 0; a < 3; ++a) { P[3 * k + a] = (double)src[3 * i + a]; Q[3 * k + a] = (double)tgt[3 * i + a]; }
+                }
+                orc_kabsch_points(P, Q, NULL, LO_SAMPLE, Tt);
+            } else if (!lo_fit_all(src, tgt, list, nI, Tt)) break;
+            uint32_t tc; uint64_t tq;
+            orc_score(src, tgt, m, Tt, p->thr2, &tc, &tq);
+            if (tc == 0) continue;
+            if (bt < 0 || model_better(tc, tq, t, bc, bq, bt, msac_T)) { bt = t; bc = tc; bq = tq; memcpy(bT, Tt, sizeof(bT)); }
+        }
+        /* strictly better than the current model (an equal score keeps it: the id of the current model counts as lower) */
+        if (bt < 0 || !model_better(bc, bq, 1, *c, *q, 0, msac_T)) break;
+        memcpy(T, bT, sizeof(bT)); *c = bc; *q = bq; changed = 1;
+    }
+    return changed;
+}
+
+/* final iterated least squares */
+static void lo_polish(const float *src, const float *tgt, int m, const orc_ransac_params *p, double T[16], uint32_t *c, uint64_t *q,
+                      int32_t *list)
+{
+    for (int it = 0; it < LO_POLISH; ++it) {
+        const int nI = lo_inliers(src, tgt, m, T, p->thr2, list);
+        double Tn[16];
+        if (nI <= p->sample_size || !lo_fit_all(src, tgt, list, nI, Tn)) break;
+        uint32_t tc; uint64_t tq;
+        orc_score(src, tgt, m, Tn, p->thr2, &tc, &tq);
+        if (tc < *c) break;
+        const int same = tc == *c;
+        memcpy(T, Tn, sizeof(Tn)); *c = tc; *q = tq;
+        if (same) break;
+    }
+}
+
+ORC_API void orc_lo_sample(uint64_t seed, int call, int round, int trial, int n, int32_t *pos) { lo_draw(seed, call, round, trial, n, pos); }
+
 /* Hypothesise-and-verify loop with Open3D ordering: more inliers wins, then lower error, then lower h.
  * Ids are processed in batches; after the batch ending at id e the loop stops when
  * e >= log(1-conf)/log(1-(inl/M)^n) for the best model so far (the exit rule of Open3D's
@@ -417,12 +568,16 @@ ORC_API void orc_ransac(const float *src, const float *tgt, int m, const orc_ran
                         double T_best[16], orc_ransac_result *res)
 {
     int64_t best_h = -1; uint32_t best_c = 0; uint64_t best_q = 0; int64_t n_valid = 0, n_ids = 0;
+    /* with local optimisation the best model is no longer the minimal-sample fit of best_h: it is carried along */
+    double Tb[16]; int have_T = 0, lo_calls = 0;
+    int32_t *lo_list = p->local_opt ? (int32_t *)malloc(sizeof(int32_t) * (size_t)(m > 0 ? m : 1)) : NULL;
     const int use_exit = p->confidence > 0.0f && p->confidence < 1.0f;
     const int64_t B = use_exit ? (p->batch > 0 ? p->batch : (p->iters > 65536 ? ((p->iters / 8 + 8191) / 8192) * 8192 : 8192)) : (p->iters > 0 ? p->iters : 1);
     int32_t *G = p->sampler == 1 ? prosac_table(m, p->sample_size, p->prosac_growth > 0 ? p->prosac_growth : 100000) : NULL;
     const uint32_t msac_T = p->scoring == 1 ? (uint32_t)(p->thr2 * 1048576.0f) : 0u;
     for (int64_t h0 = 0; h0 < p->iters; h0 += B) {
         const int64_t h1 = h0 + B < p->iters ? h0 + B : p->iters;
+        int64_t bb_h = -1; uint32_t bb_c = 0; uint64_t bb_q = 0;      /* winner of this batch */
 #pragma omp parallel
         {
             int64_t lh = -1; uint32_t lc = 0; uint64_t lq = 0; int64_t lv = 0;
@@ -441,10 +596,14 @@ ORC_API void orc_ransac(const float *src, const float *tgt, int m, const orc_ran
 #pragma omp critical
             {
                 n_valid += lv;
-                if (lh >= 0 && (best_h < 0 || model_better(lc, lq, lh, best_c, best_q, best_h, msac_T))) {
-                    best_h = lh; best_c = lc; best_q = lq;
-                }
+                if (lh >= 0 && (bb_h < 0 || model_better(lc, lq, lh, bb_c, bb_q, bb_h, msac_T))) { bb_h = lh; bb_c = lc; bb_q = lq; }
             }
+        }
+        /* the batch winner replaces the best so far when it scores better (an optimised model keeps the id of its seed) */
+        if (bb_h >= 0 && (best_h < 0 || model_better(bb_c, bb_q, bb_h, best_c, best_q, best_h, msac_T))) {
+            best_h = bb_h; best_c = bb_c; best_q = bb_q;
+            hypothesis_T(src, tgt, m, p, (uint64_t)best_h, Tb, NULL, G); have_T = 1;
+            if (p->local_opt == 1) { lo_optimise(src, tgt, m, p, lo_calls, Tb, &best_c, &best_q, lo_list); lo_calls += 1; }
         }
         n_ids = h1;
         if (use_exit && best_c > 0) {
@@ -456,8 +615,11 @@ ORC_API void orc_ransac(const float *src, const float *tgt, int m, const orc_ran
         }
     }
     for (int k = 0; k < 16; ++k) T_best[k] = (k % 5 == 0) ? 1.0 : 0.0;
-    if (best_h >= 0) hypothesis_T(src, tgt, m, p, (uint64_t)best_h, T_best, NULL, G);
-    free(G);
+    if (best_h >= 0 && have_T) {
+        if (p->local_opt) lo_polish(src, tgt, m, p, Tb, &best_c, &best_q, lo_list);
+        memcpy(T_best, Tb, sizeof(Tb));
+    }
+    free(G); free(lo_list);
     res->best_h = best_h; res->best_count = best_c; res->best_ssq = best_q; res->n_valid = n_valid; res->n_ids = n_ids;
 }
 

@@ -35,7 +35,7 @@ class RansacParams(ctypes.Structure):
     _fields_ = [("sample_size", ctypes.c_int32), ("use_elc", ctypes.c_int32),
                 ("thr2", ctypes.c_float), ("iters", ctypes.c_int32), ("seed", ctypes.c_uint64),
                 ("confidence", ctypes.c_float), ("batch", ctypes.c_int32),
-                ("sampler", ctypes.c_int32), ("prosac_growth", ctypes.c_int32), ("scoring", ctypes.c_int32), ("reserved0", ctypes.c_int32)]
+                ("sampler", ctypes.c_int32), ("prosac_growth", ctypes.c_int32), ("scoring", ctypes.c_int32), ("local_opt", ctypes.c_int32)]
 
 
 class RansacResult(ctypes.Structure):
@@ -283,9 +283,9 @@ def philox(seed, h):
 
 # ----------------------------------------------------------------------------- RANSAC (a10) + refit (a11)
 
-def _params(sample_size, use_elc, thr, iters, seed, confidence=1.0, batch=0, sampler=0, prosac_growth=0, scoring=0):
+def _params(sample_size, use_elc, thr, iters, seed, confidence=1.0, batch=0, sampler=0, prosac_growth=0, scoring=0, local_opt=0):
     return RansacParams(sample_size, int(use_elc), np.float32(float(thr) * float(thr)), iters, seed, confidence, batch,
-                        int(sampler), int(prosac_growth), int(scoring), 0)
+                        int(sampler), int(prosac_growth), int(scoring), int(local_opt))
 
 
 def prosac_order(feat_dist):
@@ -314,12 +314,13 @@ def score(src, tgt, T, thr=0.6):
 
 
 def ransac(src, tgt, iters, sample_size=3, use_elc=True, thr=0.6, seed=51, confidence=1.0, batch=0, sampler=0, prosac_growth=0,
-           scoring=0):
-    """RANSAC over M correspondences src[i] <-> tgt[i] (sampler=1: PROSAC, pairs best quality first).
+           scoring=0, local_opt=0):
+    """RANSAC over M correspondences src[i] <-> tgt[i] (sampler 1: PROSAC, pairs best quality first; 2: uniform with unique
+    indices; local_opt 1: GC-RANSAC's local optimisation + final iterated least squares, 2: the latter only).
     Returns (T 4x4 float64, info dict)."""
     src, tgt = _f32(src), _f32(tgt)
     T = np.empty(16, np.float64)
-    p = _params(sample_size, use_elc, thr, iters, seed, confidence, batch, sampler, prosac_growth, scoring)
+    p = _params(sample_size, use_elc, thr, iters, seed, confidence, batch, sampler, prosac_growth, scoring, local_opt)
     r = RansacResult()
     lib().orc_ransac(_p(src, c_f32p), _p(tgt, c_f32p), src.shape[0], ctypes.byref(p), _p(T, c_f64p), ctypes.byref(r))
     return T.reshape(4, 4), dict(best_h=r.best_h, best_count=r.best_count, best_ssq=r.best_ssq, n_valid=r.n_valid, n_ids=r.n_ids)
@@ -368,8 +369,16 @@ def translation_error_cm(T, T_gt):
 
 # ----------------------------------------------------------------------------- whole pair (a9)
 
+def lo_sample(seed, call, rnd, trial, n):
+    """The 21 distinct positions of [0, n) the local optimisation draws for (call, round, trial)."""
+    pos = np.zeros(21, np.int32)
+    lib().orc_lo_sample(ctypes.c_uint64(seed), int(call), int(rnd), int(trial), int(n), _p(pos, c_i32p))
+    return pos
+
+
 def register_pair(xyz0, xyz1, feats0, feats1, mode="MNN", iters=50000, sample_size=3, use_elc=True,
-                  thr=0.6, seed=51, args=None, refit_on_orig=True, confidence=1.0, batch=0, prosac=False, scoring=0):
+                  thr=0.6, seed=51, args=None, refit_on_orig=True, confidence=1.0, batch=0, prosac=False, scoring=0,
+                  local_opt=0, unique=False):
     """FR.py:16-119 with the open3D-codebase ordering: NN -> filter -> RANSAC -> LS refit on the
     original NN pairs.  Returns dict(T, idx0, idx1, idx1_orig, ransac=info)."""
     idx0, idx1, idx2, _ = find_2nn(feats0, feats1)
@@ -389,9 +398,11 @@ def register_pair(xyz0, xyz1, feats0, feats1, mode="MNN", iters=50000, sample_si
         if feat_dist is None:
             feat_dist = calc_distance_ratio_in_feature_space(feats0, feats1, f0, f1, f2)
         order = prosac_order(feat_dist)
-        T, info = ransac(src[order], tgt[order], iters, sample_size, use_elc, thr, seed, confidence, batch, sampler=1, scoring=scoring)
+        T, info = ransac(src[order], tgt[order], iters, sample_size, use_elc, thr, seed, confidence, batch, sampler=1, scoring=scoring,
+                         local_opt=local_opt)
     else:
-        T, info = ransac(src, tgt, iters, sample_size, use_elc, thr, seed, confidence, batch, scoring=scoring)
+        T, info = ransac(src, tgt, iters, sample_size, use_elc, thr, seed, confidence, batch, sampler=2 if unique else 0, scoring=scoring,
+                         local_opt=local_opt)
     n_ref = 0
     if refit_on_orig == 2 and info["best_h"] >= 0:
         # GC codebase: final least squares over the inliers among the filtered pairs

@@ -26,6 +26,14 @@ def golden(name):
     return np.load(os.path.join(GOLDEN, name))
 
 
+def gc_oracle_kwargs(a):
+    """Keyword arguments of oracle.register_pair that restate what --codebase GC runs for the flags in `a`
+    (FR.pair_params): MSAC, unique-index sampling (PROSAC when a.prosac), local optimisation unless a.GC_LO is False,
+    final iterated least squares inside the RANSAC call, no refit stage."""
+    return dict(sample_size=3, use_elc=a.fast_rejection == "ELC", confidence=a.GC_conf, refit_on_orig=0, scoring=1,
+                local_opt=1 if a.GC_LO else 2, prosac=bool(a.prosac), unique=not a.prosac)
+
+
 class Args:
     """argparse-like bag with the reference's hot-path defaults (Experiments/test.py:294-313)."""
     def __init__(self, **kw):

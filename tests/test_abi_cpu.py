@@ -35,6 +35,7 @@ def test_version_and_error_string(libpath):
 def test_struct_layouts_match_header():
     # sizes the C side static-asserts implicitly through its field order (include/lidarreg.h)
     assert ctypes.sizeof(_ext.RansacParams) == 48 and _ext.RansacParams.sampler.offset == 32 and _ext.RansacParams.scoring.offset == 40
+    assert _ext.RansacParams.local_opt.offset == 44
     assert ctypes.sizeof(_ext.RansacResult) == 40
     assert ctypes.sizeof(_ext.PairResult) == 496
     assert ctypes.sizeof(_ext.PairParams) == 80
@@ -67,7 +68,7 @@ def test_mode_aliases_and_defaults():
     from tests.conftest import Args
     p = fr.pair_params(Args(mode="MMN", codebase="GC", iters=None))
     assert p.mode == _ext.LR_MODE_MNN and p.ransac.iters == 500000 and p.ransac.sample_size == 3 and p.ransac.use_elc == 1
-    assert abs(p.ransac.confidence - 0.999) < 1e-6 and p.refit == 2
+    assert abs(p.ransac.confidence - 0.999) < 1e-6 and p.refit == 0 and p.ransac.local_opt == 1     # GC: LO + final LSQ inside the RANSAC call
     p = fr.pair_params(Args(mode="GPF", codebase="open3D", iters=1000, GPF_factor=0.5, GPF_grid_wid=4))
     assert p.mode == _ext.LR_MODE_GPF and p.ransac.sample_size == 4 and p.gpf_factor == 0.5 and p.gpf_grid_wid == 4 and p.refit == 1
     assert abs(p.refit_thr2 - 0.36) < 1e-15 and abs(p.ransac.thr2 - 0.36) < 1e-7
@@ -80,18 +81,25 @@ def test_pair_params_follow_the_reference_flags():
     from lidarregistration_amd import FR
     from tests.conftest import Args
     p = FR.pair_params(Args(mode="GPF", codebase="GC", iters=None, prosac=True, GPF_factor=1.5, GPF_grid_wid=12))
-    assert (p.mode, p.refit, p.gpf_grid_wid, p.gpf_factor) == (_ext.LR_MODE_GPF, 2, 12, 1.5)
+    assert (p.mode, p.refit, p.gpf_grid_wid, p.gpf_factor) == (_ext.LR_MODE_GPF, 0, 12, 1.5)
     r = p.ransac
-    assert (r.sample_size, r.use_elc, r.iters, r.sampler, r.scoring) == (3, 1, 500000, 1, 1)       # FR.py:65-67, GC_RANSAC.py:19-37
+    assert (r.sample_size, r.use_elc, r.iters, r.sampler, r.scoring, r.local_opt) == (3, 1, 500000, 1, 1, 1)       # FR.py:65-67, GC_RANSAC.py:19-37
     assert abs(r.confidence - 0.999) < 1e-7 and abs(r.thr2 - 0.36) < 1e-7
     p = FR.pair_params(Args(mode="MMN", codebase="GC", iters=1000, prosac=False, fast_rejection="NONE", GC_conf=0.9))
-    assert (p.mode, p.ransac.sampler, p.ransac.use_elc, p.ransac.iters) == (_ext.LR_MODE_MNN, 0, 0, 1000)
+    assert (p.mode, p.ransac.sampler, p.ransac.use_elc, p.ransac.iters) == (_ext.LR_MODE_MNN, 2, 0, 1000)     # uniform, unique indices
     assert abs(p.ransac.confidence - 0.9) < 1e-7
+    # --GC_LO False: only the final least squares (GC_RANSAC.py:36-37); flags the HIP path does not implement are refused
+    assert FR.pair_params(Args(codebase="GC", GC_LO=False)).ransac.local_opt == 2
+    import pytest
+    with pytest.raises(NotImplementedError):
+        FR.pair_params(Args(codebase="GC", fast_rejection="SPRT"))
+    with pytest.raises(NotImplementedError):
+        FR.pair_params(Args(codebase="GC", spatial_coherence_weight=0.1))
+    FR.pair_params(Args(codebase="open3D", fast_rejection="SPRT", spatial_coherence_weight=0.1))      # GC-only flags: ignored, as in FR.py:70-97
     p = FR.pair_params(Args(mode="no_filter", codebase="open3D", iters=2000))
     r = p.ransac
     assert (p.mode, p.refit, r.sample_size, r.use_elc, r.sampler, r.scoring) == (_ext.LR_MODE_NO_FILTER, 1, 4, 1, 0, 0)   # FR.py:128-137
-    assert abs(r.confidence - 0.9995) < 1e-7
-    import pytest
+    assert abs(r.confidence - 0.9995) < 1e-7 and r.local_opt == 0
     with pytest.raises(AssertionError):
         FR.pair_params(Args(mode="bogus"))
     with pytest.raises(AssertionError):

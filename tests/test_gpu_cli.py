@@ -43,10 +43,10 @@ def test_single_process_run(cli, tmp_path, oracle, mode_args):
     from tests.conftest import Args
     p = synth.make_pair(N=4000, seed=51 + 2)
     mode = mode_args[1]
-    ns = 4 if "open3D" in mode_args else 3
-    e = oracle.register_pair(p["xyz0"], p["xyz1"], p["feats0"], p["feats1"], mode=mode, iters=2000, sample_size=ns, seed=51,
-                             args=Args(GPF_factor=0.5), confidence=0.9995 if ns == 4 else 0.999, refit_on_orig=1 if ns == 4 else 2,
-                             scoring=0 if ns == 4 else 1, prosac=(ns == 3))
+    from tests.conftest import gc_oracle_kwargs
+    a = Args(GPF_factor=0.5, prosac=True)          # the CLI's defaults: --codebase GC --prosac True --GC_LO True
+    kw = dict(sample_size=4, confidence=0.9995, refit_on_orig=1, scoring=0) if "open3D" in mode_args else gc_oracle_kwargs(a)
+    e = oracle.register_pair(p["xyz0"], p["xyz1"], p["feats0"], p["feats1"], mode=mode, iters=2000, seed=51, args=a, **kw)
     assert np.radians(oracle.rotation_error_deg(T[2], e["T"])) <= 1e-4 and oracle.translation_error_cm(T[2], e["T"]) / 100 <= 1e-3
     assert raw[2, 17] == len(e["idx0"])
 

@@ -68,10 +68,9 @@ def test_FR_with_poisoned_scratch(lr, oracle, seed, mode, codebase, prosac):
     N = 2000 + 500 * seed
     p = synth.make_pair(N=N, rho=0.5, s=0.9, seed=60 + seed, clustered=(mode == "GPF"))
     a = Args(mode=mode, codebase=codebase, iters=1500, GPF_factor=0.5, prosac=prosac, icp=True)
-    ns = 3 if codebase == "GC" else 4
-    e = oracle.register_pair(p["xyz0"], p["xyz1"], p["feats0"], p["feats1"], mode=mode, iters=1500, sample_size=ns, use_elc=True,
-                             seed=51, args=a, confidence=a.GC_conf if codebase == "GC" else a.o3d_conf,
-                             refit_on_orig=2 if codebase == "GC" else 1, prosac=prosac, scoring=1 if codebase == "GC" else 0)
+    from tests.conftest import gc_oracle_kwargs
+    kw = gc_oracle_kwargs(a) if codebase == "GC" else dict(sample_size=4, use_elc=True, confidence=a.o3d_conf, refit_on_orig=1, scoring=0)
+    e = oracle.register_pair(p["xyz0"], p["xyz1"], p["feats0"], p["feats1"], mode=mode, iters=1500, seed=51, args=a, **kw)
     t = lr.torch.from_numpy
     outs = []
     for byte in (0x00, 0xFF, 0x7F):

@@ -1,0 +1,146 @@
+"""--codebase GC on the GPU (rows a12 / f3): unique-index sampling, GC-RANSAC's local optimisation, the final iterated least
+squares and the inlier mask -- HIP against the oracle's restatement (oracle.c: lo_optimise / lo_polish).  Needs an MI355X."""
+import numpy as np
+import pytest
+
+from lidarregistration_amd import synth
+from tests.conftest import Args, gc_oracle_kwargs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lr():
+    import torch
+    assert torch.cuda.is_available(), "these tests need a GPU"
+    from lidarregistration_amd import FR, _ext, matching, ransac
+    _ext.lib()
+    class NS: pass
+    ns = NS(); ns.FR = FR; ns.matching = matching; ns.ransac = ransac; ns.torch = torch; ns.ext = _ext
+    return ns
+
+
+def _planted(n=4000, inlier=0.3, seed=3, noise=0.05):
+    rng = np.random.default_rng(seed)
+    src = np.concatenate([rng.uniform(-80, 80, (n, 2)), rng.uniform(-3, 5, (n, 1))], 1).astype(np.float32)
+    T = synth.random_motion(rng)
+    tgt = (src.astype(np.float64) @ T[:3, :3].T + T[:3, 3] + rng.normal(0, noise, (n, 3))).astype(np.float32)
+    bad = rng.random(n) > inlier
+    tgt[bad] = np.concatenate([rng.uniform(-80, 80, (bad.sum(), 2)), rng.uniform(-3, 5, (bad.sum(), 1))], 1)
+    return src, tgt, T
+
+
+@pytest.mark.parametrize("n,iters,seed,sampler,scoring,lo,conf,batch", [
+    (4000, 3000, 51, 2, 1, 1, 1.0, 0), (4000, 3000, 51, 1, 1, 1, 1.0, 0), (2500, 4000, 7, 2, 1, 2, 1.0, 0), (3000, 3000, 9, 2, 0, 1, 1.0, 0),
+    (6000, 100000, 21, 2, 1, 1, 0.999, 512), (6000, 100000, 22, 1, 1, 1, 0.99, 1024), (17000, 20000, 5, 2, 1, 1, 0.999, 0),
+    (40, 500, 3, 2, 1, 1, 1.0, 0), (18, 300, 4, 1, 1, 1, 1.0, 0), (5, 64, 1, 2, 1, 1, 1.0, 0)])
+def test_local_optimisation_matches_oracle(lr, oracle, n, iters, seed, sampler, scoring, lo, conf, batch):
+    src, tgt, T_gt = _planted(n=n, inlier=0.3 if n > 100 else 0.8, seed=seed)
+    kw = dict(sample_size=3, seed=seed, sampler=sampler, scoring=scoring, local_opt=lo, confidence=conf, batch=batch)
+    T, info = lr.ransac.ransac_dev(src, tgt, iters, **kw)
+    Te, einfo = oracle.ransac(src, tgt, iters, **kw)
+    assert info == einfo                                   # seed hypothesis, optimised inlier count / error sum, ids examined
+    np.testing.assert_allclose(T, Te, rtol=0, atol=1e-12)
+    assert np.array_equal(T, Te)                           # same samples, same summation order: bit for bit
+    if n > 100:
+        assert oracle.rotation_error_deg(T, T_gt) < 0.5
+
+
+def test_local_optimisation_improves_on_the_minimal_sample_model(lr, oracle):
+    src, tgt, T_gt = _planted(n=5000, inlier=0.35, seed=11)
+    T0, i0 = lr.ransac.ransac_dev(src, tgt, 3000, sampler=2, scoring=1, local_opt=0)
+    T1, i1 = lr.ransac.ransac_dev(src, tgt, 3000, sampler=2, scoring=1, local_opt=1)
+    thrT = int(np.float32(0.36) * np.float32(1048576.0))
+    assert i1["best_count"] * thrT - i1["best_ssq"] > i0["best_count"] * thrT - i0["best_ssq"]       # MSAC score strictly better
+    assert i1["best_h"] == i0["best_h"]
+    assert oracle.translation_error_cm(T1, T_gt) < oracle.translation_error_cm(T0, T_gt)
+
+
+def test_unique_sampler_on_few_pairs(lr, oracle):
+    """with few pairs a sizeable share of the draws repeats an index; those are rejected, not scored."""
+    src, tgt, _ = _planted(n=12, inlier=1.0, seed=4)
+    for sampler in (0, 2, 1):
+        T, info = lr.ransac.ransac_dev(src, tgt, 400, use_elc=False, seed=5, sampler=sampler)
+        Te, einfo = oracle.ransac(src, tgt, 400, use_elc=False, seed=5, sampler=sampler)
+        assert info == einfo and np.array_equal(T, Te)
+    _, i0 = lr.ransac.ransac_dev(src, tgt, 400, use_elc=False, seed=5, sampler=0)
+    _, i2 = lr.ransac.ransac_dev(src, tgt, 400, use_elc=False, seed=5, sampler=2)
+    assert i0["n_valid"] == 400 and 250 < i2["n_valid"] < 360
+
+
+def test_inlier_mask_is_what_the_model_scores(lr, oracle):
+    """gcransac_python.cpp:594-603 returns (pose, mask); the mask of the returned model has best_count ones."""
+    src, tgt, _ = _planted(n=3000, inlier=0.4, seed=13)
+    T, info = lr.ransac.ransac_dev(src, tgt, 2000, sampler=2, scoring=1, local_opt=1, want_mask=True)
+    assert info["mask"].shape == (3000,) and info["mask"].sum() == info["best_count"] == info["n_inliers"]
+    # the oracle's scoring arithmetic on the same model
+    Rt = T.astype(np.float32)
+    p = src; x = [np.float32(0)] * 3
+    d2 = np.zeros(3000, np.float32)
+    for a in range(3):
+        v = (Rt[a, 0] * p[:, 0].astype(np.float64) + (Rt[a, 1] * p[:, 1].astype(np.float64) + (Rt[a, 2] * p[:, 2].astype(np.float64) + Rt[a, 3])))
+        d2 += ((v - tgt[:, a]) ** 2).astype(np.float32)
+    assert (info["mask"] != (d2 < np.float32(0.36))).sum() <= 2            # float64 re-computation: only threshold-edge points may differ
+    c, _ = oracle.score(src, tgt, T)
+    assert c == info["best_count"]
+    # the host-level mirror of GC_RANSAC.py returns it in the caller's order when PROSAC sorted the pairs
+    a = Args(codebase="GC", prosac=True, iters=2000)
+    q = np.random.default_rng(0).random(3000).astype(np.float32)
+    Tg, _, m = lr.ransac.GC_RANSAC(src, tgt, 0.6, 2000, a, q, return_mask=True)
+    c, _ = oracle.score(src, tgt, Tg)
+    assert m.sum() == c and oracle.score(src[m], tgt[m], Tg)[0] == c
+
+
+@pytest.mark.parametrize("lo", [True, False])
+def test_FR_gc_codebase_flags(lr, oracle, lo):
+    """--GC_LO switches the local optimisation; SPRT / a spatial-coherence weight are refused, not silently dropped."""
+    p = synth.make_pair(N=5000, rho=0.5, s=0.9, seed=77)
+    a = Args(mode="MNN", codebase="GC", iters=3000, GC_LO=lo, prosac=True)
+    t = lr.torch.from_numpy
+    T = lr.FR.FR(t(p["xyz0"]), t(p["xyz1"]), t(p["feats0"]), t(p["feats1"]), a, p["T_gt"])[0]
+    e = oracle.register_pair(p["xyz0"], p["xyz1"], p["feats0"], p["feats1"], mode="MNN", iters=3000, seed=51, args=a, **gc_oracle_kwargs(a))
+    np.testing.assert_allclose(T, e["T"], rtol=0, atol=1e-9)
+    for bad in (dict(fast_rejection="SPRT"), dict(spatial_coherence_weight=0.5)):
+        with pytest.raises(NotImplementedError):
+            lr.FR.FR(t(p["xyz0"]), t(p["xyz1"]), t(p["feats0"]), t(p["feats1"]), Args(mode="MNN", codebase="GC", iters=100, **bad), p["T_gt"])
+
+
+def test_register_batch_gc_mask_per_pair(lr, oracle):
+    """lr_workspace_mask_at: inlier mask over the filtered pairs of every pair of a batched call."""
+    import ctypes
+    a = Args(mode="MNN", codebase="GC", iters=2000, prosac=True)
+    params = lr.FR.pair_params(a)
+    dev = lr.torch.device("cuda", 0)
+    host = [synth.make_pair(N=n, rho=0.5, s=0.9, seed=500 + k) for k, n in enumerate((3000, 2200, 2600))]
+    devp = [tuple(lr.torch.from_numpy(p[key]).to(dev) for key in ("xyz0", "xyz1", "feats0", "feats1")) for p in host]
+    ws = lr.ext.Workspace(3000, 3000, 32, a.iters, max_pairs=3)
+    out = lr.FR.register_batch_dev(devp, params, ws=ws)
+    for k, p in enumerate(host):
+        r = lr.ext.PairResult.from_buffer_copy(out[k].cpu().numpy().tobytes())
+        n0 = p["xyz0"].shape[0]
+        mask = lr.torch.zeros(n0, dtype=lr.torch.uint8, device=dev); nin = lr.torch.zeros(1, dtype=lr.torch.int32, device=dev)
+        lr.ext.check(lr.ext.lib().lr_workspace_mask_at(ws.handle, k, devp[k][0].data_ptr(), devp[k][1].data_ptr(), n0, ctypes.c_float(0.36),
+                                                       mask.data_ptr(), nin.data_ptr(), None))
+        assert int(nin.item()) == r.ransac.best_count == int(mask[:r.n_corr].sum().item())
+        e = oracle.register_pair(p["xyz0"], p["xyz1"], p["feats0"], p["feats1"], mode="MNN", iters=2000, seed=51, args=a, **gc_oracle_kwargs(a))
+        np.testing.assert_allclose(np.array(r.T[:]).reshape(4, 4), e["T"], rtol=0, atol=1e-9)
+        assert r.ransac.best_count == e["ransac"]["best_count"]
+
+
+def test_nn_to_mutual_accepts_any_forward_list(lr, oracle):
+    """the reference's nn_to_mutual works for ANY corres_idx1, not only the true NN list (matching.py:222-239); the
+    standalone operator must not prune on the assumption that it is one."""
+    rng = np.random.default_rng(5)
+    F0, F1 = synth.make_features(1500, 1300, 32, 0.5, 1.0, 91)
+    i0, i1, i2, _ = oracle.find_2nn(F0, F1)
+    t = lr.torch.from_numpy
+    for kind in ("random", "second", "half"):
+        if kind == "random":
+            c1 = rng.integers(0, 1300, 1500)
+        elif kind == "second":
+            c1 = i2.copy()
+        else:
+            c1 = i1.copy(); c1[::2] = rng.integers(0, 1300, 750)
+        m = oracle.nn_to_mutual(F0, F1, i0, c1)
+        g = lr.matching.nn_to_mutual(t(F0), t(F1), t(i0), t(c1))
+        assert np.array_equal(g[0].numpy(), m[0]) and np.array_equal(g[1].numpy(), m[1]), kind

@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 
 from lidarregistration_amd import synth
-from tests.conftest import Args, golden
+from tests.conftest import Args, gc_oracle_kwargs, golden
 
 pytestmark = pytest.mark.gpu
 
@@ -268,10 +268,8 @@ def test_FR_matches_oracle_pipeline(lr, oracle, mode, codebase, N, iters):
     a = Args(mode=mode, codebase=codebase, iters=iters, GPF_factor=0.5)
     t = lr.torch.from_numpy
     T, elapsed, pcd0, pcd1, n_init, ir_init, n_filt, ir_filt = lr.FR.FR(t(p["xyz0"]), t(p["xyz1"]), t(p["feats0"]), t(p["feats1"]), a, p["T_gt"])
-    ns = 3 if codebase == "GC" else 4
-    e = oracle.register_pair(p["xyz0"], p["xyz1"], p["feats0"], p["feats1"], mode=mode, iters=iters, sample_size=ns,
-                             use_elc=True, seed=51, args=a, confidence=a.GC_conf if codebase == "GC" else a.o3d_conf,
-                             refit_on_orig=2 if codebase == "GC" else 1, scoring=1 if codebase == "GC" else 0)
+    kw = gc_oracle_kwargs(a) if codebase == "GC" else dict(sample_size=4, use_elc=True, confidence=a.o3d_conf, refit_on_orig=1, scoring=0)
+    e = oracle.register_pair(p["xyz0"], p["xyz1"], p["feats0"], p["feats1"], mode=mode, iters=iters, seed=51, args=a, **kw)
     assert n_init == N and n_filt == len(e["idx0"])
     # contract: <= 1e-4 rad rotation, <= 1e-3 m translation on identical correspondence inputs
     assert np.radians(oracle.rotation_error_deg(T, e["T"])) <= 1e-4
@@ -315,8 +313,7 @@ def test_FR_prosac_matches_oracle_pipeline(lr, oracle, mode, N, iters):
     a = Args(mode=mode, codebase="GC", iters=iters, GPF_factor=0.5, prosac=True)
     t = lr.torch.from_numpy
     T, _, _, _, n_init, _, n_filt, _ = lr.FR.FR(t(p["xyz0"]), t(p["xyz1"]), t(p["feats0"]), t(p["feats1"]), a, p["T_gt"])
-    e = oracle.register_pair(p["xyz0"], p["xyz1"], p["feats0"], p["feats1"], mode=mode, iters=iters, sample_size=3,
-                             use_elc=True, seed=51, args=a, confidence=a.GC_conf, refit_on_orig=2, prosac=True, scoring=1)
+    e = oracle.register_pair(p["xyz0"], p["xyz1"], p["feats0"], p["feats1"], mode=mode, iters=iters, seed=51, args=a, **gc_oracle_kwargs(a))
     assert n_filt == len(e["idx0"])
     assert np.radians(oracle.rotation_error_deg(T, e["T"])) <= 1e-4 and oracle.translation_error_cm(T, e["T"]) / 100 <= 1e-3
     np.testing.assert_allclose(T, e["T"], rtol=0, atol=1e-9)
@@ -328,8 +325,10 @@ def test_FR_prosac_matches_oracle_pipeline(lr, oracle, mode, N, iters):
         A = p["xyz0"][e["idx0"]].astype(np.float32); B = p["xyz1"][e["idx1"]].astype(np.float32)
         Tg, _ = lr.ransac.GC_RANSAC(A, B, 0.6, iters, a, -fd)
         order = oracle.prosac_order(fd)
-        Te, _ = oracle.ransac(A[order], B[order], iters, 3, True, 0.6, 51, a.GC_conf, 0, sampler=1, scoring=1)
+        # ... and with FR(codebase="GC"): one estimator behind both names (LO + final least squares included)
+        Te, _ = oracle.ransac(A[order], B[order], iters, 3, True, 0.6, 51, a.GC_conf, 0, sampler=1, scoring=1, local_opt=1)
         assert np.array_equal(Tg, Te)
+        np.testing.assert_allclose(Tg, T, rtol=0, atol=1e-9)
 
 
 def test_errors_are_loud(lr):
@@ -430,8 +429,7 @@ def test_FR_gpf_full_size(lr, oracle):
     a = Args(mode="GPF", codebase="GC", iters=20000, GPF_factor=0.5)
     t = lr.torch.from_numpy
     T, elapsed, _, _, n_init, _, n_filt, _ = lr.FR.FR(t(p["xyz0"]), t(p["xyz1"]), t(p["feats0"]), t(p["feats1"]), a, p["T_gt"])
-    e = oracle.register_pair(p["xyz0"], p["xyz1"], p["feats0"], p["feats1"], mode="GPF", iters=20000, sample_size=3, seed=51, args=a,
-                             confidence=a.GC_conf, refit_on_orig=2, scoring=1)
+    e = oracle.register_pair(p["xyz0"], p["xyz1"], p["feats0"], p["feats1"], mode="GPF", iters=20000, seed=51, args=a, **gc_oracle_kwargs(a))
     assert n_filt == len(e["idx0"]) and n_filt < n_init
     assert np.radians(oracle.rotation_error_deg(T, e["T"])) <= 1e-4 and oracle.translation_error_cm(T, e["T"]) / 100 <= 1e-3
 

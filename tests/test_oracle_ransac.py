@@ -182,3 +182,63 @@ def test_prosac_finds_the_model_sooner_when_quality_is_informative(oracle):
 def test_prosac_order_is_stable_and_puts_nan_last(oracle):
     fd = np.array([0.5, np.nan, 0.1, 0.5, -0.3, 0.1], np.float32)
     assert list(oracle.prosac_order(fd)) == [4, 2, 5, 0, 3, 1]
+
+
+# ----------------------------------------------------------------------------- GC-RANSAC options (rows a12 / f3)
+def test_unique_index_samplers_reject_repeated_draws(oracle):
+    """sampler 2 (GC-RANSAC's UniformSampler) and PROSAC draw distinct indices: a hypothesis id whose draw repeats an index is
+    consumed without a model; sampler 0 (Open3D) keeps it."""
+    src, tgt, _, _ = _planted(n=12, inlier=1.0, seed=4)
+    dup = uniq = 0
+    for h in range(400):
+        ok0, _, s0 = oracle.hypothesis(src, tgt, h, use_elc=False, seed=5, sampler=0)
+        ok2, _, s2 = oracle.hypothesis(src, tgt, h, use_elc=False, seed=5, sampler=2)
+        assert ok0 and np.array_equal(s0, s2)                    # same draw, different verdict
+        repeated = len(set(s0.tolist())) < 3
+        assert ok2 == (not repeated)
+        dup += repeated; uniq += not repeated
+    assert dup > 30 and uniq > 200                                # 12 pairs: about a quarter of the 3-point draws repeat
+    _, i0 = oracle.ransac(src, tgt, 400, use_elc=False, seed=5, sampler=0)
+    _, i2 = oracle.ransac(src, tgt, 400, use_elc=False, seed=5, sampler=2)
+    assert i0["n_valid"] == 400 and i2["n_valid"] == uniq
+
+
+def test_local_optimisation_sample_stream(oracle):
+    for n in (22, 30, 500, 15000):
+        for trial in range(5):
+            pos = oracle.lo_sample(51, 0, 1, trial, n)
+            assert len(set(pos.tolist())) == 21 and pos.min() >= 0 and pos.max() < n
+    assert not np.array_equal(oracle.lo_sample(51, 0, 0, 0, 500), oracle.lo_sample(51, 0, 0, 1, 500))
+    assert not np.array_equal(oracle.lo_sample(51, 0, 0, 0, 500), oracle.lo_sample(51, 1, 0, 0, 500))
+    assert np.array_equal(oracle.lo_sample(51, 2, 3, 4, 500), oracle.lo_sample(51, 2, 3, 4, 500))
+
+
+@pytest.mark.parametrize("scoring,sampler", [(1, 2), (1, 1), (0, 2)])
+def test_local_optimisation_never_lowers_the_score(oracle, scoring, sampler):
+    """GC-RANSAC's LO (GC_RANSAC.py:36-37) replaces the best model only by a strictly better one, so the final score can only
+    improve on plain hypothesise-and-verify with the same hypothesis stream; on noisy planted data it does improve, and the
+    model gets closer to the planted motion."""
+    src, tgt, T_gt, inl = _planted(n=5000, inlier=0.35, seed=11)
+    T0, i0 = oracle.ransac(src, tgt, 3000, seed=51, sampler=sampler, scoring=scoring, local_opt=0)
+    T2, i2 = oracle.ransac(src, tgt, 3000, seed=51, sampler=sampler, scoring=scoring, local_opt=2)
+    T1, i1 = oracle.ransac(src, tgt, 3000, seed=51, sampler=sampler, scoring=scoring, local_opt=1)
+    thrT = int(np.float32(0.36) * np.float32(1048576.0))
+
+    def key(i):
+        return (i["best_count"] * thrT - i["best_ssq"],) if scoring == 1 else (i["best_count"], -i["best_ssq"])
+    assert key(i1) >= key(i0) and i1["best_h"] == i0["best_h"] and i1["n_valid"] == i0["n_valid"]
+    assert i2["best_count"] >= i0["best_count"]                       # the polish never loses inliers
+    assert key(i1) > key(i0)                                          # 0.05 m noise: a 3-point fit is never the optimum
+    assert oracle.translation_error_cm(T1, T_gt) < oracle.translation_error_cm(T0, T_gt)
+    # the returned model scores exactly what the result block says
+    for T, i in ((T1, i1), (T2, i2)):
+        c, q = oracle.score(src, tgt, T)
+        assert (c, q) == (i["best_count"], i["best_ssq"])
+
+
+def test_local_optimisation_with_early_exit_stops_sooner(oracle):
+    """The exit rule runs on the optimised model: more inliers -> fewer hypothesis ids needed."""
+    src, tgt, _, _ = _planted(n=6000, inlier=0.25, seed=21)
+    _, i0 = oracle.ransac(src, tgt, 200000, seed=51, sampler=2, scoring=1, local_opt=0, confidence=0.999, batch=512)
+    _, i1 = oracle.ransac(src, tgt, 200000, seed=51, sampler=2, scoring=1, local_opt=1, confidence=0.999, batch=512)
+    assert i1["n_ids"] <= i0["n_ids"] and i1["best_count"] >= i0["best_count"]
