@@ -26,6 +26,14 @@ def golden(name):
     return np.load(os.path.join(GOLDEN, name))
 
 
+def rot_diff_rad(A, B):
+    """Rotation angle between two nearly equal transforms from the Frobenius distance of their rotation blocks
+    (|Ra - Rb|_F = 2 sqrt(2) sin(theta/2)).  Unlike arccos((tr - 1)/2) it has no sqrt(eps) noise floor, which matters when one
+    side is a float32-quantised golden (arccos of 1 - 1e-7 is 4e-4 rad)."""
+    d = np.linalg.norm(np.asarray(A, np.float64)[:3, :3] - np.asarray(B, np.float64)[:3, :3])
+    return float(2.0 * np.arcsin(min(1.0, d / (2.0 * np.sqrt(2.0)))))
+
+
 def gc_oracle_kwargs(a):
     """Keyword arguments of oracle.register_pair that restate what --codebase GC runs for the flags in `a`
     (FR.pair_params): MSAC, unique-index sampling (PROSAC when a.prosac), local optimisation unless a.GC_LO is False,

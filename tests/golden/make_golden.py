@@ -13,6 +13,7 @@ Reference entry points exercised (paths relative to /root/reference):
     DGR/util/procrustes.py              weighted_procrustes
     Experiments/libs/loss.py            TransformationLoss
     balanced_sets/*/test.txt + test.coarse_motions.txt   (data rows -> recall table)
+G11 composes them the way FR.py:16-119 does on one planted pair (lists per mode, PROSAC order, LS-refit transform).
 """
 import os
 import sys
@@ -194,6 +195,50 @@ def main():
         os.makedirs(d, exist_ok=True)
         with open(os.path.join(d, "test.txt"), "w") as f:
             f.write(lines[0] + "\n" + "\n".join(pick) + "\n")
+        # ... and the same rows of the reference's own coarse-motion file (output of FCGF_FAST/test.py:86-106): the byte
+        # format the build's writer has to reproduce
+        cm = open(os.path.join(REF, "balanced_sets", name, "test.coarse_motions.txt")).read().splitlines()
+        with open(os.path.join(d, "test.coarse_motions.txt"), "w") as f:
+            f.write(cm[0] + "\n" + "\n".join(cm[1:][i] for i in np.linspace(0, len(rows) - 1, 64).astype(int)) + "\n")
+    # ---------------- G11: composed FR() fixture ("a Python caller row (a9 FR) is pinned by G1-G5+G7 composed") ----
+    # For a seeded synthetic pair with a planted motion: the reference's own correspondence lists after each mode, and the
+    # transform the reference's LS-refit step (FR.py:99-111) yields from the planted motion: inliers of T_gt over the list
+    # (dist2 in float64, FR.py:104-105) -> weighted_procrustes with unit weights (fp64 SVD, DGR/util/procrustes.py:34-56) and
+    # rigid_transform_3d (fp32, models/common.py:7-45).  FR()'s own output must land within the north-star tolerance of it.
+    out = {}
+    N, seed = 6000, 1234
+    pr = synth.make_pair(N=N, rho=0.5, s=0.9, seed=seed, clustered=True)
+    out["shape"] = np.array([N, seed]); out["T_gt"] = pr["T_gt"]
+    tF0, tF1 = torch.from_numpy(pr["feats0"]), torch.from_numpy(pr["feats1"])
+    i0, i1, i2, _ = M.find_2nn(tF0, tF1)
+    out["idx1"] = i1.numpy().astype(np.int32); out["idx2"] = i2.numpy().astype(np.int32)
+    x0 = pr["xyz0"].astype(np.float64); x1 = pr["xyz1"].astype(np.float64)      # FR.py:26-27: float64 clouds
+    Tg = pr["T_gt"]
+
+    def refit_reference(c0, c1):
+        c0 = np.asarray(c0); c1 = np.asarray(c1)
+        moved = x0 @ Tg[:3, :3].T + Tg[:3, 3]
+        close = np.sum((moved[c0] - x1[c1]) ** 2, axis=1) < (2 * 0.3) ** 2
+        P, Q = pr["xyz0"][c0[close]], pr["xyz1"][c1[close]]
+        Rr, tt = proc.weighted_procrustes(torch.from_numpy(P).float(), torch.from_numpy(Q).float(), torch.ones(len(P), 1))
+        Tp = np.eye(4); Tp[:3, :3] = Rr.numpy(); Tp[:3, 3] = tt.numpy()
+        Tc = rigid_transform_3d(torch.from_numpy(P)[None].float(), torch.from_numpy(Q)[None].float(), None)[0].numpy()
+        return int(close.sum()), Tp, Tc
+
+    n, Tp, Tc = refit_reference(i0.numpy(), i1.numpy())
+    out["orig_n_inliers"] = np.array(n); out["orig_T_procrustes"] = Tp; out["orig_T_common"] = Tc
+    m0, m1, m2 = M.nn_to_mutual(tF0, tF1, i0, i1, i2)
+    out["mnn_idx0"] = m0.numpy().astype(np.int32); out["mnn_idx1"] = m1.numpy().astype(np.int32)
+    fd = M.calc_distance_ratio_in_feature_space(tF0, tF1, m0, m1, m2).numpy()
+    out["mnn_feat_dist"] = fd; out["mnn_prosac_order"] = np.argsort(-(-fd)).astype(np.int32)          # GC_RANSAC.py:41 on match_quality = -fd (FR.py:80)
+    n, Tp, Tc = refit_reference(m0.numpy(), m1.numpy())
+    out["mnn_n_inliers"] = np.array(n); out["mnn_T_procrustes"] = Tp; out["mnn_T_common"] = Tc
+    a = Args(GPF_grid_wid=10, GPF_factor=0.5, GPF_max_matches=10 ** 9)
+    g = M.Grid_Prioritized_Filter(tF0, tF1, i0, i1, i2, torch.from_numpy(pr["xyz0"]), a)
+    out["gpf_idx0"] = g[0].numpy().astype(np.int32); out["gpf_idx1"] = g[1].numpy().astype(np.int32); out["gpf_score"] = g[6].numpy()
+    n, Tp, Tc = refit_reference(g[0].numpy(), g[1].numpy())
+    out["gpf_n_inliers"] = np.array(n); out["gpf_T_procrustes"] = Tp; out["gpf_T_common"] = Tc
+    np.savez_compressed(os.path.join(HERE, "g11_fr_composed.npz"), **out)
     print("golden vectors written to", HERE)
 
 

@@ -1,0 +1,102 @@
+"""The final-transform clause of the north star on the GPU: FR()'s transform against (a) the composed reference fixture G11,
+(b) itself under other seeds / sample sizes / samplers (the refit makes T independent of which good hypothesis won), and
+(c) BASELINE config[4]'s 100k-point clouds.  Tolerance everywhere: 1e-4 rad rotation, 1e-3 m translation.  Needs an MI355X."""
+import numpy as np
+import pytest
+
+from lidarregistration_amd import synth
+from tests.conftest import Args, golden, rot_diff_rad
+
+pytestmark = pytest.mark.gpu
+ROT_TOL, TRANS_TOL = 1e-4, 1e-3          # BASELINE.json north_star
+
+
+@pytest.fixture(scope="module")
+def lr():
+    import torch
+    assert torch.cuda.is_available(), "these tests need a GPU"
+    from lidarregistration_amd import FR, _ext, matching
+    _ext.lib()
+    class NS: pass
+    ns = NS(); ns.FR = FR; ns.matching = matching; ns.torch = torch; ns.ext = _ext
+    return ns
+
+
+def _err(oracle, A, B):
+    return rot_diff_rad(A, B), oracle.translation_error_cm(A, B) / 100
+
+
+@pytest.mark.parametrize("mode,codebase,tag,nfilt", [("MNN", "open3D", "orig", "mnn"), ("GPF", "open3D", "orig", "gpf"),
+                                                    ("MNN", "GC", "mnn", "mnn"), ("GPF", "GC", "gpf", "gpf")])
+def test_FR_against_the_composed_reference_fixture(lr, oracle, mode, codebase, tag, nfilt):
+    """G11: lists and LS-refit transform produced by the imported reference (tests/golden/make_golden.py).  The open3D
+    codebase refits over the ORIGINAL NN pairs (FR.py:99-111), the GC codebase ends with least squares over the inliers
+    among the FILTERED pairs: each against the reference transform over the same list."""
+    g = golden("g11_fr_composed.npz")
+    N, seed = [int(v) for v in g["shape"]]
+    p = synth.make_pair(N=N, rho=0.5, s=0.9, seed=seed, clustered=True)
+    a = Args(mode=mode, codebase=codebase, iters=20000, GPF_factor=0.5, prosac=(codebase == "GC"))
+    t = lr.torch.from_numpy
+    T, _, _, _, n_init, _, n_filt, _ = lr.FR.FR(t(p["xyz0"]), t(p["xyz1"]), t(p["feats0"]), t(p["feats1"]), a, p["T_gt"])
+    assert n_init == N and n_filt == len(g[f"{nfilt}_idx0"])                  # the reference's list lengths
+    re, te = _err(oracle, T, g[f"{tag}_T_procrustes"])
+    assert re <= ROT_TOL and te <= TRANS_TOL, (re, te)
+    assert _err(oracle, T, g[f"{tag}_T_common"])[1] <= TRANS_TOL              # rigid_transform_3d (float32) agrees too
+
+
+def test_FR_transform_does_not_depend_on_the_winning_hypothesis(lr, oracle):
+    """30k-point pair (config 2) under 8 seeds x {3,4}-point open3D sampling and x {PROSAC, uniform} GC sampling: every run
+    picks a different winning hypothesis, the returned transforms agree within the north-star tolerance."""
+    p = synth.make_pair(N=30000, seed=51)
+    t = lr.torch.from_numpy
+    args = [t(p["xyz0"]), t(p["xyz1"]), t(p["feats0"]), t(p["feats1"])]
+    groups = {"open3D": [], "GC": []}
+    winners = set()
+    for seed in range(8):
+        for cfg in (dict(codebase="open3D", ransac_n=3), dict(codebase="open3D", ransac_n=4), dict(codebase="GC", prosac=True), dict(codebase="GC", prosac=False)):
+            a = Args(mode="MNN", iters=50000, seed=1000 + 17 * seed, **cfg)
+            T = lr.FR.FR(*args, a, p["T_gt"])[0]
+            groups[cfg["codebase"]].append(T)
+            winners.add(tuple(np.round(T[:3, 3], 9)))
+    for name, Ts in groups.items():
+        worst = (0.0, 0.0)
+        for i in range(len(Ts)):
+            for j in range(i + 1, len(Ts)):
+                re, te = _err(oracle, Ts[i], Ts[j])
+                worst = (max(worst[0], re), max(worst[1], te))
+        assert worst[0] <= ROT_TOL and worst[1] <= TRANS_TOL, (name, worst)
+        assert oracle.rotation_error_deg(Ts[0], p["T_gt"]) < 0.2 and oracle.translation_error_cm(Ts[0], p["T_gt"]) < 10
+    # the two codebases end with least squares over different pair lists (original NN pairs / filtered pairs): close, not equal
+    re, te = _err(oracle, groups["open3D"][0], groups["GC"][0])
+    assert re <= 5 * ROT_TOL and te <= 5 * TRANS_TOL
+
+
+def test_config4_100k_point_clouds(lr, oracle):
+    """BASELINE configs[4]: 100k-point dense clouds.  NN indices and distances bit-exact against the oracle on a row subset
+    (the oracle needs seconds per thousand rows at this size), the mutual list checked through the reverse NN of sampled
+    columns, and FR() recovers the planted motion."""
+    N = 100000
+    p = synth.make_pair(N=N, seed=404)
+    i1, i2, s1, s2 = lr.matching.nn_top2_dev(p["feats0"], p["feats1"], want_2nd=True, want_dist=True)
+    i1, i2, s1, s2 = (v.cpu().numpy() for v in (i1, i2, s1, s2))
+    rows = np.concatenate([np.arange(0, 300), np.random.default_rng(1).choice(N, 1200, replace=False), np.arange(N - 300, N)])
+    o1, o2, os1, os2 = oracle.nn_top2(p["feats0"][rows], p["feats1"])
+    assert np.array_equal(i1[rows], o1) and np.array_equal(i2[rows], o2)
+    assert np.array_equal(s1[rows].view(np.uint32), os1.view(np.uint32)) and np.array_equal(s2[rows].view(np.uint32), os2.view(np.uint32))
+    a = Args(mode="MNN", codebase="open3D", iters=50000, ransac_n=3, o3d_conf=1.0)
+    t = lr.torch.from_numpy
+    T, _, _, _, n_init, ir_init, n_filt, ir_filt = lr.FR.FR(t(p["xyz0"]), t(p["xyz1"]), t(p["feats0"]), t(p["feats1"]), a, p["T_gt"])
+    assert n_init == N and 0.3 * N < n_filt < 0.7 * N and ir_filt > ir_init
+    assert oracle.rotation_error_deg(T, p["T_gt"]) < 0.2 and oracle.translation_error_cm(T, p["T_gt"]) < 10
+    # mutual list: every kept pair (i, j) has idx1[i] == j, and for sampled columns the oracle's reverse NN agrees with membership
+    m0, m1 = lr.matching.nn_to_mutual(t(p["feats0"]), t(p["feats1"]), lr.torch.arange(N), t(i1.astype(np.int64)))
+    m0, m1 = m0.numpy(), m1.numpy()
+    assert len(m0) == n_filt and np.array_equal(i1[m0], m1) and np.all(np.diff(m0) > 0)
+    cols = np.random.default_rng(2).choice(np.unique(i1), 800, replace=False)
+    rev, _, _, _ = oracle.nn_top2(p["feats1"][cols], p["feats0"])
+    member = dict(zip(m1.tolist(), m0.tolist()))
+    for j, i in zip(cols.tolist(), rev.tolist()):
+        if i1[i] == j:
+            assert member.get(j) == i
+        else:
+            assert j not in member

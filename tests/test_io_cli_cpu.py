@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from lidarregistration_amd import io_lists, metrics
-from tests.conftest import golden
+from tests.conftest import GOLDEN, golden
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -75,3 +75,26 @@ def test_surrogate_source_replants_list_motion():
     from oracle import oracle as orc
     i0, i1, _ = orc.find_nn(p["feats0"], p["feats1"])
     assert orc.measure_inlier_ratio(i0, i1, p["xyz0"], p["xyz1"], p["T_gt"], 0.3) > 0.1
+
+
+def test_coarse_motion_writer_reproduces_the_reference_files_byte_for_byte():
+    """Rows of the reference's own balanced_sets/*/test.coarse_motions.txt (written by FCGF_FAST/test.py:86-106) read back and
+    written by write_coarse_motions must come out byte-identical: `%d %d %d ` + sixteen `%.16f`, sorted by source index then
+    stably by session.  (The Apollo file carries an older header line; NuScenes-Boston's is the writer's.)"""
+    import tempfile
+    for name, same_header in (("ApolloSouthbay", False), ("NuScenes_boston", True)):
+        src = os.path.join(GOLDEN, "balanced_sets_excerpt", name, "test.coarse_motions.txt")
+        ref = open(src, "rb").read().split(b"\n")
+        ids, T = io_lists.read_coarse_motions(src)
+        # feed the rows in a scrambled order: the writer has to restore the reference's ordering itself
+        perm = np.random.default_rng(0).permutation(len(ids))
+        with tempfile.TemporaryDirectory() as d:
+            out = os.path.join(d, "coarse_motions.txt")
+            io_lists.write_coarse_motions(out, ids[perm, 0], ids[perm, 1], ids[perm, 2], T[perm])
+            got = open(out, "rb").read().split(b"\n")
+        assert len(got) == len(ref) == 66 and got[1:] == ref[1:], name
+        assert (got[0] == ref[0]) == same_header
+        assert got[0] == b"session_ind source_ind target_ind " + b" ".join(b"mot%d" % k for k in range(16))
+        # and the ground-truth list of the same rows pairs up with it
+        lst = io_lists.read_pair_list(os.path.join(GOLDEN, "balanced_sets_excerpt", name, "test.txt"))
+        assert np.array_equal(np.stack([lst["session"], lst["src"], lst["tgt"]], 1), ids)
