@@ -6,6 +6,8 @@
 Same flags and defaults for the RANSAC path, same `test_parallel <start_time> <tmp_base> <world> <rank|analysis>` protocol,
 same outputs (`outputs/<dataset>.Test.<time>/{raw_stats.npy,log.txt}`) plus `coarse_motions.txt` (format of
 FCGF_FAST/test.py:86-106).  Datasets and FCGF weights are not part of this repo; pairs come from, in order:
+  0. the reference's cloud cache (env LIDARREG_CLOUD_CACHE=<dir with <session>_<idx>.npy>, voxel-deduplicated on the GPU like the
+     reference's loader) + a feature cache for the same voxelisation + LIDARREG_BALANCED_SETS,
   1. a feature cache  (env LIDARREG_FEATURE_CACHE=<dir> + LIDARREG_BALANCED_SETS=<dir with <set>/<phase>.txt>),
   2. the list-driven synthetic surrogate (LIDARREG_BALANCED_SETS only: GT motion + overlap from the list rows),
   3. plain synthetic pairs (--dataset synthetic --num_pairs P).
@@ -78,6 +80,9 @@ def make_source(args):
     sets, cache = os.environ.get("LIDARREG_BALANCED_SETS"), os.environ.get("LIDARREG_FEATURE_CACHE")
     if args.dataset in io_lists.DATASET_NAMES and sets:
         lst = io_lists.read_pair_list(os.path.join(sets, args.dataset_name, args.phase + ".txt"))
+        clouds = os.environ.get("LIDARREG_CLOUD_CACHE")
+        if clouds and cache:
+            return harness.RefCloudSource(lst, os.path.join(clouds, args.dataset_name), os.path.join(cache, args.dataset_name, args.phase))
         if cache:
             return harness.CacheSource(lst, os.path.join(cache, args.dataset_name, args.phase))
         return harness.SyntheticSource(len(lst["session"]), n=args.synthetic_n, seed=args.seed, pair_list=lst)

@@ -219,6 +219,16 @@ LR_API int lr_workspace_lists(lr_workspace *ws, int n0, int32_t *nn_idx1, int32_
 LR_API int lr_workspace_lists_at(lr_workspace *ws, int pair, int n0, int32_t *nn_idx1, int32_t *nn_idx2,
                                  int32_t *corr_idx0, int32_t *corr_idx1, void *stream);
 
+/* ---- f2: voxel de-duplication of a raw cloud -- ME.utils.sparse_quantize(xyz / voxel_size, return_index=True) as the
+ * reference's loaders call it (Experiments/dataloader/generic_balanced_loader.py:62-63; voxel_size 0.3).
+ * coords [n,3] float64 device = xyz / voxel_size (the division is the caller's, as in the reference); one point per occupied
+ * integer cell floor(coords) is kept -- the first in input order -- and the kept point indices are written to sel in ascending
+ * order, their number to *n_sel (device).  cells (optional, [n,3] int32) receives the integer cell of every kept point.
+ * Points with a non-finite coordinate or |cell| >= 2^20 are dropped.  scratch: lr_voxel_dedup_scratch_bytes(n) device bytes.  */
+LR_API size_t lr_voxel_dedup_scratch_bytes(int n);
+LR_API int    lr_voxel_dedup(const double *coords, int n, int32_t *sel, int32_t *n_sel, int32_t *cells, void *scratch,
+                             size_t scratch_bytes, void *stream);
+
 /* ---- measurement hook for bench.py: duration of the last NN distance kernel(s) on this workspace,
  * from HIP events recorded on the launch stream.  Enable, run, synchronise, then read.            */
 LR_API int lr_workspace_timing(lr_workspace *ws, int enable);

@@ -18,6 +18,7 @@ SYMBOLS = [
     "lr_nn_top2", "lr_nn_to_mutual", "lr_feat_ratio", "lr_gpf", "lr_gpf_bb_first", "lr_ransac", "lr_refit", "lr_icp", "lr_kabsch",
     "lr_register_pair", "lr_workspace_lists", "lr_workspace_timing", "lr_workspace_timing_read",
     "lr_workspace_create_batch", "lr_register_batch", "lr_workspace_lists_at", "lr_inlier_mask", "lr_workspace_mask_at",
+    "lr_voxel_dedup_scratch_bytes", "lr_voxel_dedup",
 ]
 
 
@@ -104,6 +105,9 @@ def lib():
         L.lr_workspace_lists_at.argtypes = [vp, ci, ci, vp, vp, vp, vp, vp]
         L.lr_inlier_mask.argtypes = [vp, vp, vp, ci, vp, ctypes.c_float, vp, vp, vp]
         L.lr_workspace_mask_at.argtypes = [vp, ci, vp, vp, ci, ctypes.c_float, vp, vp, vp]
+        L.lr_voxel_dedup_scratch_bytes.restype = ctypes.c_size_t
+        L.lr_voxel_dedup_scratch_bytes.argtypes = [ci]
+        L.lr_voxel_dedup.argtypes = [vp, ci, vp, vp, vp, vp, ctypes.c_size_t, vp]
         L.lr_workspace_create_batch.argtypes = [ctypes.POINTER(ctypes.c_void_p), ci, ci, ci, ci, ci]
         pp, ip = ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int32)
         L.lr_register_batch.argtypes = [vp, ci, pp, pp, pp, pp, ip, ip, ci, ctypes.POINTER(PairParams), vp, vp]

@@ -62,6 +62,39 @@ class CacheSource:
         return dict(xyz0=xyz0, xyz1=xyz1, feats0=f0, feats1=f1, T_gt=self.pair_list["T_gt"][k])
 
 
+class RefCloudSource:
+    """Pairs of a balanced list from the REFERENCE's cloud cache (io_lists.load_ref_cloud: raw scans, [N,3] float64): every
+    scan is voxel-deduplicated on the GPU exactly as the reference's loader does before the network sees it
+    (voxel.voxel_downsample == ME.utils.sparse_quantize(xyz / 0.3, return_index=True), generic_balanced_loader.py:62-66).
+    FCGF itself is out of scope, so the 32-d descriptors of the kept points come from a feature cache written for the same
+    voxelisation (io_lists.save_cloud(feat_dir, session, idx, xyz[sel], feats)); a missing or mismatching entry is an error."""
+
+    def __init__(self, pair_list, cloud_dir, feat_dir, voxel_size=0.3):
+        self.pair_list, self.cloud_dir, self.feat_dir, self.voxel_size = pair_list, cloud_dir, feat_dir, voxel_size
+
+    def __len__(self):
+        return len(self.pair_list["session"])
+
+    def ids(self, k):
+        return int(self.pair_list["session"][k]), int(self.pair_list["src"][k]), int(self.pair_list["tgt"][k])
+
+    def _cloud(self, s, i):
+        from . import voxel
+        raw = io_lists.load_ref_cloud(self.cloud_dir, s, i)
+        xyz, sel = voxel.voxel_downsample(raw, self.voxel_size)
+        xyz = xyz.cpu().numpy()
+        cx, feats = io_lists.load_cloud(self.feat_dir, s, i)
+        if feats.shape[0] != xyz.shape[0] or not np.allclose(cx, xyz, atol=1e-4):
+            raise ValueError(f"feature cache entry {s}_{i} was not computed for this voxelisation ({feats.shape[0]} vs {xyz.shape[0]} points)")
+        return xyz, feats
+
+    def get(self, k):
+        s, i, j = self.ids(k)
+        xyz0, f0 = self._cloud(s, i)
+        xyz1, f1 = self._cloud(s, j)
+        return dict(xyz0=xyz0, xyz1=xyz1, feats0=f0, feats1=f1, T_gt=self.pair_list["T_gt"][k])
+
+
 def registration_params(args):
     """lr_pair_params of the timed registration call.  The harness times ICP on its own (test.py:183-193, stats column 11),
     so the fused ICP stage of lr_register_pair stays off here: column 9 must not contain an ICP."""

@@ -7,6 +7,8 @@
   ``%.16f``, sorted by source index then stably by session).
 * a feature cache (new; the reference computes FCGF on the fly): ``<dir>/<session>_<idx>.npz`` with ``xyz`` [N,3] float32
   and ``feats`` [N,32] float32, so real data can be registered without MinkowskiEngine.
+* the reference's cloud cache: ``<cache_dir>/<session>_<idx>.npy``, the raw scan as an [N,3] float64 array
+  (Experiments/dataloader/balanced/ApolloSouthbay.py:148-158; written by ``load_PC(..., cache_file)``).
 """
 import os
 
@@ -43,6 +45,25 @@ def write_coarse_motions(path, session, src, tgt, T):
 def read_coarse_motions(path):
     rows = np.loadtxt(path, skiprows=1, ndmin=2)
     return rows[:, :3].astype(np.int64), rows[:, 3:19].reshape(-1, 4, 4)
+
+
+def ref_cloud_path(cache_dir, session, idx):
+    return os.path.join(cache_dir, "%d_%d.npy" % (session, idx))             # ApolloSouthbay.py:148,154
+
+
+def load_ref_cloud(cache_dir, session, idx):
+    """One scan of the reference's cloud cache: [N,3] float64 (extra columns, e.g. intensity, are dropped)."""
+    path = ref_cloud_path(cache_dir, session, idx)
+    if not os.path.isfile(path):
+        raise FileNotFoundError(f"{path}: not in the cloud cache (the reference fills it from the raw dataset, which is not part of this repo)")
+    a = np.load(path)
+    assert a.ndim == 2 and a.shape[1] >= 3, f"{path}: expected an [N,3] array, got {a.shape}"
+    return np.ascontiguousarray(a[:, :3], np.float64)
+
+
+def save_ref_cloud(cache_dir, session, idx, xyz):
+    os.makedirs(cache_dir, exist_ok=True)
+    np.save(ref_cloud_path(cache_dir, session, idx), np.asarray(xyz, np.float64))
 
 
 def cache_path(cache_dir, session, idx):

@@ -243,6 +243,19 @@ def Grid_Prioritized_Filter(fcgf_feats0, fcgf_feats1, corres_idx0, corres_idx1, 
     return corres_idx0, corres_idx1, idx1_2nd, corres_idx0_orig, corres_idx1_orig, idx1_2nd_orig, norm_feat_dist
 
 
+# ----------------------------------------------------------------------------- voxel de-duplication (f2)
+
+def sparse_quantize(coordinates, return_index=True):
+    """ME.utils.sparse_quantize(coordinates, return_index=True) as the reference's loaders use it
+    (dataloader/generic_balanced_loader.py:62-63).  MinkowskiEngine 0.5.4 (Requirements/conda_GC_full.yml:106) is not vendored:
+    PARITY UNPINNED.  Its CPU path floors the coordinates and inserts the rows one after the other into a hash map, so the
+    kept row of every occupied cell is its first one, and the kept indices come out in ascending order."""
+    cells = np.floor(np.asarray(coordinates, np.float64)).astype(np.int64)
+    _, first = np.unique(cells, axis=0, return_index=True)
+    sel = np.sort(first)
+    return (cells[sel].astype(np.int32), sel.astype(np.int64)) if return_index else cells[sel].astype(np.int32)
+
+
 # ----------------------------------------------------------------------------- stats (a8)
 
 def measure_inlier_ratio(corres_idx0, corres_idx1, xyz0, xyz1, T_gt, voxel_size):

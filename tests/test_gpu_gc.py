@@ -144,3 +144,65 @@ def test_nn_to_mutual_accepts_any_forward_list(lr, oracle):
         m = oracle.nn_to_mutual(F0, F1, i0, c1)
         g = lr.matching.nn_to_mutual(t(F0), t(F1), t(i0), t(c1))
         assert np.array_equal(g[0].numpy(), m[0]) and np.array_equal(g[1].numpy(), m[1]), kind
+
+
+# ----------------------------------------------------------------------------- f2: cloud cache + voxel de-duplication
+@pytest.mark.parametrize("n,seed,vs", [(120000, 1, 0.3), (30000, 2, 0.05), (257, 3, 0.3), (1, 4, 0.3), (5000, 5, 1e6)])
+def test_voxel_dedup_matches_oracle(lr, oracle, n, seed, vs):
+    from lidarregistration_amd import voxel
+    rng = np.random.default_rng(seed)
+    xyz = np.concatenate([rng.normal(0, 30, (n, 2)), rng.uniform(-3, 5, (n, 1))], 1)       # dense near the sensor, like a scan
+    if n > 1000:
+        xyz[n // 2:n // 2 + 500] = xyz[:500] + 1e-5                                        # exact cell collisions late in the scan
+    cells, sel = voxel.sparse_quantize(xyz / vs, return_index=True)
+    oc, osel = oracle.sparse_quantize(xyz / vs, return_index=True)
+    assert np.array_equal(sel.cpu().numpy(), osel) and np.array_equal(cells.cpu().numpy(), oc)
+    down, sel2 = voxel.voxel_downsample(xyz, vs)
+    assert np.array_equal(sel2.cpu().numpy(), osel) and np.array_equal(down.cpu().numpy(), xyz[osel].astype(np.float32))
+
+
+def test_voxel_dedup_edge_cases(lr, oracle):
+    from lidarregistration_amd import voxel
+    xyz = np.array([[0.1, 0.1, 0.1], [np.nan, 0, 0], [0.2, 0.2, 0.2], [np.inf, 1, 1], [-0.1, 0.1, 0.1], [1e9, 0, 0], [0.29, 0.29, 0.29]])
+    cells, sel = voxel.sparse_quantize(xyz / 0.3)
+    assert sel.cpu().numpy().tolist() == [0, 4] and cells.cpu().numpy().tolist() == [[0, 0, 0], [-1, 0, 0]]       # non-finite / out of range dropped
+    cells, sel = voxel.sparse_quantize(np.zeros((0, 3)))
+    assert sel.numel() == 0
+
+
+def test_reference_cloud_cache_source(lr, oracle, tmp_path):
+    """A balanced-list pair through the reference's cloud cache (<session>_<idx>.npy, raw [N,3] float64 scans): GPU voxel
+    de-duplication + feature cache for that voxelisation -> FR() recovers the list's motion."""
+    from lidarregistration_amd import harness, io_lists, voxel
+    rng = np.random.default_rng(9)
+    lst = io_lists.read_pair_list(str(__import__("pathlib").Path(__file__).parent / "golden" / "balanced_sets_excerpt" / "ApolloSouthbay" / "test.txt"))
+    k = 3
+    s, i, j = int(lst["session"][k]), int(lst["src"][k]), int(lst["tgt"][k])
+    T = lst["T_gt"][k]
+    # a synthetic "scan": 60k raw points, several per 0.3 m voxel; cloud j is the moved copy with noise and its own clutter
+    base = np.concatenate([rng.uniform(-40, 40, (60000, 2)), rng.uniform(-2, 3, (60000, 1))], 1)
+    raw_i = base
+    raw_j = np.concatenate([base[:40000] @ T[:3, :3].T + T[:3, 3] + rng.normal(0, 0.02, (40000, 3)),
+                            np.concatenate([rng.uniform(-40, 40, (20000, 2)), rng.uniform(-2, 3, (20000, 1))], 1)])
+    clouds, feats = str(tmp_path / "clouds"), str(tmp_path / "feats")
+    io_lists.save_ref_cloud(clouds, s, i, raw_i); io_lists.save_ref_cloud(clouds, s, j, raw_j)
+    assert np.array_equal(io_lists.load_ref_cloud(clouds, s, i), raw_i)
+    src = harness.RefCloudSource(lst, clouds, feats)
+    with pytest.raises(FileNotFoundError):
+        src.get(k)                                              # no feature cache yet
+    # descriptors "computed offline" for the voxelised points: a smooth function of the position in cloud i's frame
+    def describe(xyz_in_i):
+        W = np.random.default_rng(1).normal(0, 0.35, (3, 32))
+        f = np.sin(xyz_in_i @ W) + 0.05 * np.random.default_rng(2).normal(size=(len(xyz_in_i), 32))
+        return (f / np.linalg.norm(f, axis=1, keepdims=True)).astype(np.float32)
+    xi, _ = voxel.voxel_downsample(raw_i); xj, _ = voxel.voxel_downsample(raw_j)
+    xi, xj = xi.cpu().numpy(), xj.cpu().numpy()
+    io_lists.save_cloud(feats, s, i, xi, describe(xi.astype(np.float64)))
+    io_lists.save_cloud(feats, s, j, xj, describe((xj.astype(np.float64) - T[:3, 3]) @ T[:3, :3]))
+    p = src.get(k)
+    assert p["xyz0"].shape[0] == len(oracle.sparse_quantize(raw_i / 0.3)[1]) < 60000
+    stats, Ts = harness.eval_pairs(src, [k], Args(mode="MNN", codebase="GC", iters=20000, prosac=True), in_flight=1)
+    assert stats[0, 0] == 1 and stats[0, 1] < 1.0 and stats[0, 2] < 30 and stats[0, 19:22].tolist() == [s, i, j]
+    io_lists.save_cloud(feats, s, i, xi[:-5], describe(xi[:-5].astype(np.float64)))
+    with pytest.raises(ValueError):
+        src.get(k)                                              # feature cache does not belong to this voxelisation

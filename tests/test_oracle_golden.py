@@ -148,3 +148,23 @@ def test_composed_FR_fixture_g11(oracle):
         assert rot_diff_rad(T, g[f"{tag}_T_procrustes"]) < 2e-6
         assert oracle.translation_error_cm(T, g[f"{tag}_T_procrustes"]) / 100 < 1e-4, tag
         assert oracle.translation_error_cm(T, g[f"{tag}_T_common"]) / 100 < 2e-4
+
+
+def test_sparse_quantize_restatement_properties(oracle):
+    """f2: ME.utils.sparse_quantize(xyz / 0.3, return_index=True) (generic_balanced_loader.py:62-63; MinkowskiEngine is not
+    vendored -> unpinned): one point per occupied cell, the first in input order, indices ascending, cells = floor."""
+    rng = np.random.default_rng(0)
+    xyz = np.concatenate([rng.uniform(-60, 60, (20000, 2)), rng.uniform(-3, 5, (20000, 1))], 1)
+    xyz[5000:5200] = xyz[100:300] + 1e-4                      # near-duplicates: same cells as earlier points
+    cells, sel = oracle.sparse_quantize(xyz / 0.3, return_index=True)
+    assert np.all(np.diff(sel) > 0) and np.array_equal(cells, np.floor(xyz[sel] / 0.3).astype(np.int32))
+    assert len(np.unique(cells, axis=0)) == len(cells)        # one per cell
+    allc = np.floor(xyz / 0.3).astype(np.int64)
+    assert len(np.unique(allc, axis=0)) == len(cells)         # every occupied cell is represented
+    # first occurrence: no earlier point shares a kept point's cell
+    key = (allc[:, 0] * 4096 + allc[:, 1]) * 4096 + allc[:, 2]
+    seen = {}
+    for i, k in enumerate(key.tolist()):
+        seen.setdefault(k, i)
+    assert sorted(seen.values()) == sel.tolist()
+    assert not np.isin(np.arange(5000, 5200), sel).any() or (np.floor(xyz[5000:5200] / 0.3) != np.floor(xyz[100:300] / 0.3)).any()
