@@ -109,8 +109,8 @@ extern "C" size_t lr_voxel_dedup_scratch_bytes(int n)
 extern "C" int lr_voxel_dedup(const double *coords, int n, int32_t *sel, int32_t *n_sel, int32_t *cells, void *scratch,
                               size_t scratch_bytes, void *stream)
 {
-    LR_REQUIRE(coords && sel && n_sel && scratch, LR_EINVAL, "lr_voxel_dedup: null pointer");
     LR_REQUIRE(n >= 0, LR_EINVAL, "lr_voxel_dedup: negative point count");
+    LR_REQUIRE(n_sel && (n == 0 || (coords && sel && scratch)), LR_EINVAL, "lr_voxel_dedup: null pointer");
     LR_REQUIRE(scratch_bytes >= lr_voxel_dedup_scratch_bytes(n), LR_ESIZE, "lr_voxel_dedup: scratch too small (lr_voxel_dedup_scratch_bytes)");
     hipStream_t st = (hipStream_t)stream;
     if (n == 0) { LR_HIP(hipMemsetAsync(n_sel, 0, sizeof(int32_t), st)); return LR_OK; }
