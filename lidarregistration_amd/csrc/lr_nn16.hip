@@ -564,14 +564,27 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
 }
 
 // ------------------------------------------------------------------ exact verification of the candidates
-// A block takes the 64 query rows of one pass-B wave: it expands the register masks of that wave's segments (one per column
-// strip) and bins the candidates by row in LDS (count, prefix, scatter), then LR_EX_LANES (4; 8 measured slower: every lane
-// reloads the query row) lanes per row: lane q takes the row's candidates q, q+4, ...; the partial (first, second) pairs are
-// merged under the (sqrt value, index) order with log2(lanes) shuffles.  Rows whose segment or bin overflowed, whose list is
-// too short, or whose f16 copy is not finite are re-done by a full exact scan of all columns, in place.
-#define LR_EX_LANES 4
-#define LR_EX_LIST 6144          // binned candidates of the block's 64 rows (LDS)
+// A block takes the 64 query rows of one pass-B wave.  Their fp32 descriptors are staged in LDS once; then every thread
+// takes ENTRIES of that wave's segments (one segment per column strip): it gathers the entry's column row (128 B) once and,
+// for every register bit of the mask, forms the fp32 fma-chain distance to that query row.  The two best candidates of a row
+// under the (sqrt value, index) order -- torch.min's "first minimal value" -- are kept as 64-bit keys (value bits << 32 |
+// index) with two LDS atomics per candidate:  old = atomicMin(best, key);  atomicMin(second, max(old, key)).  Whatever the
+// order of arrival, `best` ends as the smallest key and `second` as the second smallest (every loser max(old, key) is at
+// least the second smallest, and the second smallest itself loses exactly once).  The work is spread over the threads by
+// entry, so a row with many candidates does not stall its neighbours, and nothing is binned or sorted.
+// Rows whose segment overflowed, whose list is too short, or whose f16 copy is not finite are re-done by the whole block
+// with an exact scan of all columns (slow, rare, and by construction the reference answer).
+#define LR_EX_ROWS 64
+#define LR_EX_STRIDE 33          // floats per staged query row (odd: conflict-free column-wise reads)
 __device__ __forceinline__ bool sj_lt(float a, int ia, float b, int ib) { return a < b || (a == b && ia < ib); }
+#define LR_EX_EMPTY 0xffffffffffffffffull
+
+__device__ __forceinline__ void ex_offer(unsigned long long *best, unsigned long long *second, float sv, int j)
+{
+    const unsigned long long key = ((unsigned long long)__float_as_uint(sv) << 32) | (unsigned)j;       // sv > 0: bits order like values
+    const unsigned long long old = atomicMin(best, key);
+    atomicMin(second, old > key ? old : key);
+}
 
 __global__ void __launch_bounds__(256)
 nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, int na,
@@ -582,7 +595,11 @@ nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, in
                   int32_t *__restrict__ counters,
                   uint32_t *__restrict__ seed_out, float *__restrict__ seed_s1, uint32_t *__restrict__ seed_range, int dir, lr_zargs z)
 {
-    __shared__ float s_lo[4], s_hi[4];
+    __shared__ float s_a[LR_EX_ROWS * LR_EX_STRIDE];
+    __shared__ float s_nq[LR_EX_ROWS];
+    __shared__ unsigned long long s_best[LR_EX_ROWS], s_second[LR_EX_ROWS];
+    __shared__ int s_cnt[LR_EX_ROWS], s_rowd[LR_EX_ROWS], s_badrow[LR_EX_ROWS];
+    __shared__ int s_bad, s_nredo, s_redo[LR_EX_ROWS];
     if (z.descs) {      // dir 0: rows = cloud 0 against cloud 1; 1: the reverse direction
         const lr_pair_desc d = z.descs[blockIdx.z];
         Fq = dir ? d.F1 : d.F0; na = dir ? d.n1 : d.n0; Fc = dir ? d.F0 : d.F1; nb = dir ? d.n0 : d.n1;
@@ -590,97 +607,32 @@ nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, in
     lr_z(nQ, z, blockIdx.z); lr_z(nC, z, blockIdx.z); lr_z(cand_cnt, z, blockIdx.z); lr_z(cand, z, blockIdx.z); lr_z(rowmap, z, blockIdx.z);
     lr_z(na_dev, z, blockIdx.z); lr_z(idx1, z, blockIdx.z); lr_z(idx2, z, blockIdx.z); lr_z(s1o, z, blockIdx.z); lr_z(s2o, z, blockIdx.z);
     lr_z(counters, z, blockIdx.z); lr_z(seed_out, z, blockIdx.z); lr_z(seed_s1, z, blockIdx.z); lr_z(seed_range, z, blockIdx.z);
-    const int gid = blockIdx.x * 256 + threadIdx.x;
-    const int row = gid / LR_EX_LANES, q = gid % LR_EX_LANES;
     if (na_dev) na = *na_dev;                  // compacted row list (reverse direction): lists by position, data by rowmap[]
-    if ((int)blockIdx.x * (256 / LR_EX_LANES) >= na) return;
-    const bool live = row < na;
-    const int rowc = live ? row : na - 1;
-    const int rowd = rowmap ? rowmap[rowc] : rowc;
-    float a[32];
-    const f32x4 *pa = reinterpret_cast<const f32x4 *>(Fq + (size_t)rowd * 32);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { f32x4 t = pa[k]; a[4 * k] = t.x; a[4 * k + 1] = t.y; a[4 * k + 2] = t.z; a[4 * k + 3] = t.w; }
-    const float nq = nQ[rowd];
-    float b1 = LR_INF, b2 = LR_INF;
-    int i1 = LR_IMAX, i2 = LR_IMAX;
-    // ---- bin the candidates of the block's 64 rows
-    __shared__ int s_cnt[64], s_fill[64], s_off[65], s_bad;
-    __shared__ int s_list[LR_EX_LIST];
-    const int32_t *cw = cand_cnt + blockIdx.x * (nstrips + 1);
-    const int used = min(max(cw[nstrips], 1), nstrips);        // strips the pass-B row block really used
-    const int seg_cap = lr_seg_cap(used);
-    const uint2 *__restrict__ segs = reinterpret_cast<const uint2 *>(cand) + (size_t)blockIdx.x * LR_NN16_SEG;
-    if (threadIdx.x < 64) { s_cnt[threadIdx.x] = 0; s_fill[threadIdx.x] = 0; }
-    if (threadIdx.x == 0) s_bad = 0;
-    __syncthreads();
-    // entry { column, (code << 8) | mask }: code = rb*4 + (g0/8)*2 + h of the pass-B wave tile, mask bit 7-k <-> register g0 + k;
-    // row of register g: 32 rb + 4 h + (g & 3) + 8 (g >> 2)
-    auto for_each_candidate = [&](auto &&f) {
-        for (int sidx = 0; sidx < used; ++sidx) {
-            const int c = cw[sidx];
-            if (c < 0) { if (threadIdx.x == 0) s_bad = 1; continue; }
-            for (int e = threadIdx.x; e < c; e += 256) {
-                const uint2 v = segs[(size_t)sidx * seg_cap + e];
-                const int code = (int)(v.y >> 8);
-                const int rbase = 32 * (code >> 2) + 4 * (code & 1), g0 = 8 * ((code >> 1) & 1);
-                unsigned m = v.y & 0xffu;
-                while (m) {
-                    const int bit = __builtin_ctz(m);
-                    m &= m - 1;
-                    const int g = g0 + 7 - bit;
-                    f(rbase + (g & 3) + 8 * (g >> 2), (int)v.x);
-                }
-            }
-        }
-    };
-    for_each_candidate([&](int rl, int) { atomicAdd(&s_cnt[rl], 1); });
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        const int c = s_cnt[threadIdx.x];
-        int inc = c;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if ((int)threadIdx.x >= d) inc += o; }
-        s_off[threadIdx.x] = inc - c;
-        if (threadIdx.x == 63) { s_off[64] = inc; if (inc > LR_EX_LIST) s_bad = 1; }
+    const int row0 = (int)blockIdx.x * LR_EX_ROWS;
+    if (row0 >= na) return;
+    const int tid = threadIdx.x;
+    // ---- stage the query rows: thread t moves floats [8 (t & 3) .. +8) of row t >> 2
+    {
+        const int rl = tid >> 2, part = tid & 3;
+        const int rowc = min(row0 + rl, na - 1);
+        const int rowd = rowmap ? rowmap[rowc] : rowc;
+        const f32x4 *pa = reinterpret_cast<const f32x4 *>(Fq + (size_t)rowd * 32 + 8 * part);
+        const f32x4 u = pa[0], v = pa[1];
+        float *dst = &s_a[rl * LR_EX_STRIDE + 8 * part];
+        dst[0] = u.x; dst[1] = u.y; dst[2] = u.z; dst[3] = u.w; dst[4] = v.x; dst[5] = v.y; dst[6] = v.z; dst[7] = v.w;
+        // a query row whose f16 copy is not finite never produced a meaningful filter value
+        const float big = fmaxf(fmaxf(fmaxf(fabsf(u.x), fabsf(u.y)), fmaxf(fabsf(u.z), fabsf(u.w))), fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        const bool bad = !(big <= 65504.0f) || u.x != u.x || u.y != u.y || u.z != u.z || u.w != u.w || v.x != v.x || v.y != v.y || v.z != v.z || v.w != v.w;
+        if (tid < LR_EX_ROWS) { s_best[tid] = LR_EX_EMPTY; s_second[tid] = LR_EX_EMPTY; s_cnt[tid] = 0; s_badrow[tid] = 0; }
+        if (tid == 0) { s_bad = 0; s_nredo = 0; }
+        if (part == 0) { s_nq[rl] = nQ[rowd]; s_rowd[rl] = rowd; }
+        __syncthreads();
+        if (bad) s_badrow[rl] = 1;
     }
     __syncthreads();
-    const bool binned = s_bad == 0;
-    if (binned) for_each_candidate([&](int rl, int col) { s_list[s_off[rl] + atomicAdd(&s_fill[rl], 1)] = col; });
-    __syncthreads();
-    const int rl = (int)threadIdx.x / LR_EX_LANES;
-    const int lbase = s_off[rl];
-    const int total = binned ? s_off[rl + 1] - lbase : 0;
-    // a query row whose f16 copy is not finite never produced a meaningful filter value
-    bool bad_row = !binned;
-#pragma unroll
-    for (int k = 0; k < 32; ++k) bad_row |= !(fabsf(a[k]) <= 65504.0f);
-    const int over = bad_row ? 1 : 0;
-    const int ncand = over ? 0 : total;
-    // the candidate loop is a chain index -> gather -> 32 dependent fmas: the next candidate's row is fetched while the
-    // current chain runs
-    int jn = q < ncand ? s_list[lbase + q] : 0;
-    f32x4 tn[8];
-    float nn = 0.0f;
-    if (q < ncand) {
-        const f32x4 *pb = reinterpret_cast<const f32x4 *>(Fc + (size_t)jn * 32);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) tn[k] = pb[k];
-        nn = nC[jn];
-    }
-    for (int c = q; c < ncand; c += LR_EX_LANES) {
-        const int j = jn;
-        f32x4 t[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) t[k] = tn[k];
-        const float ncj = nn;
-        if (c + LR_EX_LANES < ncand) {
-            jn = s_list[lbase + c + LR_EX_LANES];
-            const f32x4 *pb = reinterpret_cast<const f32x4 *>(Fc + (size_t)jn * 32);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) tn[k] = pb[k];
-            nn = nC[jn];
-        }
+    // exact distance of staged row rl to a column row held in registers, the arithmetic contract's fma chain
+    auto dist = [&](int rl, const f32x4 (&t)[8], float ncj) {
+        const float *a = &s_a[rl * LR_EX_STRIDE];
         float acc = 0.0f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -689,71 +641,92 @@ nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, in
             acc = __builtin_fmaf(a[4 * k + 2], t[k].z, acc);
             acc = __builtin_fmaf(a[4 * k + 3], t[k].w, acc);
         }
-        const float tt = nq + ncj;
-        const float d2 = __builtin_fmaf(-2.0f, acc, tt);
-        const float sv = __builtin_sqrtf(fmaxf(d2, 1e-30f));
-        // candidates arrive in arbitrary order: order by (sqrt value, index) == torch.min's first minimal value
-        if (sj_lt(sv, j, b1, i1)) { b2 = b1; i2 = i1; b1 = sv; i1 = j; }
-        else if (sj_lt(sv, j, b2, i2)) { b2 = sv; i2 = j; }
-    }
-    if (live && (over || total < min(need, nb))) {
-        // candidate list overflowed (duplicate-heavy input) or could not be filled (non-finite f16 values): the four
-        // lanes of the row scan every column exactly -- slow, rare, and by construction the reference answer
-        b1 = LR_INF; b2 = LR_INF; i1 = LR_IMAX; i2 = LR_IMAX;
-        for (int j = q; j < nb; j += LR_EX_LANES) {
-            const f32x4 *pb = reinterpret_cast<const f32x4 *>(Fc + (size_t)j * 32);
-            float acc = 0.0f;
+        const float d2 = __builtin_fmaf(-2.0f, acc, s_nq[rl] + ncj);
+        return __builtin_sqrtf(fmaxf(d2, 1e-30f));
+    };
+    // ---- the candidates: entry { column, (code << 8) | mask }, code = rb*4 + (g0/8)*2 + h of the pass-B wave tile, mask bit
+    //      7-k <-> register g0 + k; row of register g: 32 rb + 4 h + (g & 3) + 8 (g >> 2)
+    {
+        const int32_t *cw = cand_cnt + blockIdx.x * (nstrips + 1);
+        const int used = min(max(cw[nstrips], 1), nstrips);        // strips the pass-B row block really used
+        const int seg_cap = lr_seg_cap(used);
+        const uint2 *__restrict__ segs = reinterpret_cast<const uint2 *>(cand) + (size_t)blockIdx.x * LR_NN16_SEG;
+        for (int sidx = 0; sidx < used; ++sidx) {
+            const int c = cw[sidx];
+            if (c < 0) { if (tid == 0) s_bad = 1; continue; }      // segment overflowed: all 64 rows are re-done
+            // (two entries in flight per thread measured slower: 118 VGPRs, 4 instead of 6 waves per SIMD)
+            for (int e = tid; e < c; e += 256) {
+                const uint2 v = segs[(size_t)sidx * seg_cap + e];
+                const int j = (int)v.x;
+                f32x4 t[8];
+                const f32x4 *pb = reinterpret_cast<const f32x4 *>(Fc + (size_t)j * 32);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const f32x4 t = pb[k];
-                acc = __builtin_fmaf(a[4 * k], t.x, acc);
-                acc = __builtin_fmaf(a[4 * k + 1], t.y, acc);
-                acc = __builtin_fmaf(a[4 * k + 2], t.z, acc);
-                acc = __builtin_fmaf(a[4 * k + 3], t.w, acc);
+                for (int k = 0; k < 8; ++k) t[k] = pb[k];
+                const float ncj = nC[j];
+                const int code = (int)(v.y >> 8);
+                const int rbase = 32 * (code >> 2) + 4 * (code & 1), g0 = 8 * ((code >> 1) & 1);
+                unsigned m = v.y & 0xffu;
+                while (m) {
+                    const int bit = __builtin_ctz(m);
+                    m &= m - 1;
+                    const int g = g0 + 7 - bit;
+                    const int rl = rbase + (g & 3) + 8 * (g >> 2);
+                    ex_offer(&s_best[rl], &s_second[rl], dist(rl, t, ncj), j);
+                    atomicAdd(&s_cnt[rl], 1);
+                }
             }
-            const float tt = nq + nC[j];
-            const float d2 = __builtin_fmaf(-2.0f, acc, tt);
-            const float sv = __builtin_sqrtf(fmaxf(d2, 1e-30f));
-            if (sj_lt(sv, j, b1, i1)) { b2 = b1; i2 = i1; b1 = sv; i1 = j; }
-            else if (sj_lt(sv, j, b2, i2)) { b2 = sv; i2 = j; }
         }
-        if (q == 0 && live) atomicAdd(&counters[LR_CNT_FIX_TOTAL], 1);
     }
+    __syncthreads();
+    // ---- rows to re-do by an exact scan of all columns
+    if (tid < LR_EX_ROWS && row0 + tid < na && (s_bad || s_badrow[tid] || s_cnt[tid] < min(need, nb))) s_redo[atomicAdd(&s_nredo, 1)] = tid;
+    __syncthreads();
+    const int nredo = s_nredo;
+    for (int r = 0; r < nredo; ++r) {
+        const int rl = s_redo[r];
+        if (tid == 0) { s_best[rl] = LR_EX_EMPTY; s_second[rl] = LR_EX_EMPTY; atomicAdd(&counters[LR_CNT_FIX_TOTAL], 1); }
+        __syncthreads();
+        for (int j = tid; j < nb; j += 256) {
+            f32x4 t[8];
+            const f32x4 *pb = reinterpret_cast<const f32x4 *>(Fc + (size_t)j * 32);
 #pragma unroll
-    for (int m = 1; m < LR_EX_LANES; m <<= 1) {
-        const float c1 = __shfl_xor(b1, m), c2 = __shfl_xor(b2, m);
-        const int j1 = __shfl_xor(i1, m), j2 = __shfl_xor(i2, m);
-        const bool cf = sj_lt(c1, j1, b1, i1);
-        const float x1 = cf ? c1 : b1, x2 = cf ? c2 : b2, y1 = cf ? b1 : c1;
-        const int xi1 = cf ? j1 : i1, xi2 = cf ? j2 : i2, yi1 = cf ? i1 : j1;
-        const bool sy = sj_lt(y1, yi1, x2, xi2);
-        b1 = x1; i1 = xi1;
-        b2 = sy ? y1 : x2; i2 = sy ? yi1 : xi2;
+            for (int k = 0; k < 8; ++k) t[k] = pb[k];
+            ex_offer(&s_best[rl], &s_second[rl], dist(rl, t, nC[j]), j);
+        }
     }
-    const bool writer = live && q == 0;
-    if (writer) {
+    __syncthreads();
+    // ---- results: one thread per row
+    float sv = 3.0e38f;
+    bool writer = false;
+    int i1 = -1;
+    if (tid < LR_EX_ROWS && row0 + tid < na) {
+        writer = true;
+        const unsigned long long kb = s_best[tid], ks = s_second[tid];
+        const int rowd = s_rowd[tid];
+        i1 = kb == LR_EX_EMPTY ? -1 : (int)(unsigned)kb;
+        const float b1 = kb == LR_EX_EMPTY ? LR_INF : __uint_as_float((unsigned)(kb >> 32));
         idx1[rowd] = i1;
-        if (idx2) idx2[rowd] = i2;
+        if (idx2) idx2[rowd] = ks == LR_EX_EMPTY ? (nb > 1 ? LR_IMAX : -1) : (int)(unsigned)ks;
         if (s1o) s1o[rowd] = b1;
-        if (s2o) s2o[rowd] = b2;
+        if (s2o) s2o[rowd] = ks == LR_EX_EMPTY ? LR_INF : __uint_as_float((unsigned)(ks >> 32));
+        if (seed_out) {
+            // forward direction of a pair: seed the reverse pass here (what nn16_rev_seed_kernel would recompute bit for bit):
+            // best forward distance per target, the row's own NN distance, and the range of all of them
+            sv = b1;
+            if (!(sv < 3.0e38f)) sv = 3.0e38f;
+            if (i1 >= 0 && i1 < nb) atomicMin(&seed_out[i1], __float_as_uint(sv));
+            seed_s1[rowd] = sv;
+        }
     }
     if (!seed_out) return;
-    // forward direction of a pair: seed the reverse pass here (what nn16_rev_seed_kernel would recompute bit for bit):
-    // best forward distance per target, the row's own NN distance, and the range of all of them
-    float sv = b1;
-    if (!(sv < 3.0e38f)) sv = 3.0e38f;
-    if (writer) {
-        if (i1 >= 0 && i1 < nb) atomicMin(&seed_out[i1], __float_as_uint(sv));
-        seed_s1[rowd] = sv;
-    }
-    float lo = writer ? sv : 3.0e38f, hi = writer ? sv : 0.0f;
+    if (tid < 64) {          // the rows live in wave 0
+        float lo = writer ? sv : 3.0e38f, hi = writer ? sv : 0.0f;
 #pragma unroll
-    for (int k = 32; k >= 1; k >>= 1) { lo = fminf(lo, __shfl_xor(lo, k)); hi = fmaxf(hi, __shfl_xor(hi, k)); }
-    if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        atomicMin(&seed_range[0], __float_as_uint(fminf(fminf(s_lo[0], s_lo[1]), fminf(s_lo[2], s_lo[3]))));
-        atomicMax(&seed_range[1], __float_as_uint(fmaxf(fmaxf(s_hi[0], s_hi[1]), fmaxf(s_hi[2], s_hi[3]))));
+        for (int k = 32; k >= 1; k >>= 1) { lo = fminf(lo, __shfl_xor(lo, k)); hi = fmaxf(hi, __shfl_xor(hi, k)); }
+        if (tid == 0) {
+            atomicMin(&seed_range[0], __float_as_uint(lo));
+            atomicMax(&seed_range[1], __float_as_uint(hi));
+        }
     }
 }
 
@@ -794,7 +767,7 @@ int lr_nn16_run(lr_workspace *ws, const float *Fq, const _Float16 *Hq, const flo
                        tps, (const float *)nullptr, ws->cand_cnt, ws->cand, (const int32_t *)nullptr, (const float *)nullptr,
                        (const uint32_t *)nullptr, thr, lr_pb_grid{ row_blocks, strips, total, 0 }, ws->z);
     if (ws->timing && !ws->ev_pending) { LR_HIP(hipEventRecord(ws->ev[1], st)); ws->ev_pending = 1; }
-    hipLaunchKernelGGL(nn16_exact_kernel, dim3(lr_cdiv(na, 256 / LR_EX_LANES), 1, ws->zP), dim3(256), 0, st, Fq, nQ, na, Fc, nC, nb, ws->cand_cnt, ws->cand,
+    hipLaunchKernelGGL(nn16_exact_kernel, dim3(lr_cdiv(na, LR_EX_ROWS), 1, ws->zP), dim3(256), 0, st, Fq, nQ, na, Fc, nC, nb, ws->cand_cnt, ws->cand,
                        strips, need, (const int32_t *)nullptr, (const int32_t *)nullptr, idx1, idx2, s1, s2, ws->counters,
                        seed_reverse ? ws->rev_seed : (uint32_t *)nullptr, ws->rev_s1, reinterpret_cast<uint32_t *>(ws->counters + LR_CNT_RLO), 0, ws->z);
     LR_LAUNCH_CHECK();
@@ -1014,7 +987,7 @@ int lr_nn16_reverse(lr_workspace *ws, const float *F0, const _Float16 *H0, const
                        (const int32_t *)ws->rev_cols, seeded ? (const float *)ws->rev_tmin : (const float *)nullptr, (const uint32_t *)seed, lr_thr_in{},
                        lr_pb_grid{ row_blocks, strips, total, 1 }, ws->z);
     if (timed) { LR_HIP(hipEventRecord(ws->ev[5], st)); ws->rev_recorded = 1; }
-    hipLaunchKernelGGL(nn16_exact_kernel, dim3(lr_cdiv(na, 256 / LR_EX_LANES), 1, ws->zP), dim3(256), 0, st, F1, nrm1, na, F0, nrm0, nb, ws->cand_cnt, ws->cand,
+    hipLaunchKernelGGL(nn16_exact_kernel, dim3(lr_cdiv(na, LR_EX_ROWS), 1, ws->zP), dim3(256), 0, st, F1, nrm1, na, F0, nrm0, nb, ws->cand_cnt, ws->cand,
                        strips, 1, (const int32_t *)ws->rev_rows, (const int32_t *)n_rows, rev, (int32_t *)nullptr, (float *)nullptr, (float *)nullptr,
                        ws->counters, (uint32_t *)nullptr, (float *)nullptr, (uint32_t *)nullptr, 1, ws->z);
     LR_LAUNCH_CHECK();
