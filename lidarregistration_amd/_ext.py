@@ -9,7 +9,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "liblidarreg.so")
+LIB_PATH = os.environ.get("LIDARREG_LIB") or os.path.join(CSRC, "liblidarreg.so")      # LIDARREG_LIB: development hook (alternate builds)
 
 LR_MODE_NO_FILTER, LR_MODE_MNN, LR_MODE_GPF = 0, 1, 2
 

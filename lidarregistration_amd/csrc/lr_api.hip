@@ -111,6 +111,9 @@ extern "C" int lr_workspace_create_batch(lr_workspace **out, int max_pairs, int 
         const char *bb = getenv("LIDARREG_NN_BLOCKS_BATCH");   // the same for a batched call: blocks per pass over all its pairs
         ws->nn_blocks_batch = bb ? atoi(bb) : 3072;
         if (ws->nn_blocks_batch < 1) ws->nn_blocks_batch = 1;
+        const char *dl = getenv("LIDARREG_PB_DYNLDS");
+        ws->pb_dyn_lds = dl ? atoi(dl) : 0;
+        if (ws->pb_dyn_lds < 0 || ws->pb_dyn_lds > 24576) ws->pb_dyn_lds = 0;
         const char *rs = getenv("LIDARREG_REV_STRIPS");
         ws->rev_strips = rs ? atoi(rs) : 16;
         if (ws->rev_strips < 1) ws->rev_strips = 1;

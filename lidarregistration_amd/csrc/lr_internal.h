@@ -39,7 +39,7 @@ __host__ __device__ static inline int lr_seg_cap(int strips) { const int c = (LR
 #define LR_NN_MAX_STRIPS 8
 #define LR_FEAT_DIM 32
 
-// One wave per block in the scoring kernel; this many blocks are launched and map themselves onto
+// Waves of the scoring kernel (four per block); this many are launched and map themselves onto
 // (hypothesis group, correspondence chunk) from the live counts on device.
 #define LR_SCORE_BLOCKS 8192
 #define LR_GPF_MAX_CELLS 4096
@@ -65,9 +65,11 @@ struct lr_desc_table { lr_pair_desc d[LR_MAX_BATCH]; };
 
 #ifdef __HIPCC__
 // scratch pointer of pair `pair` (null stays null: optional outputs).  A macro: the kernels' pointer parameters are
-// __restrict__-qualified, which a `T *&` template parameter does not bind to.
+// __restrict__-qualified, which a `T *&` template parameter does not bind to.  The offset is applied as pointer arithmetic on
+// the parameter itself (never through an integer): the compiler then still knows that the address is global memory, uniform
+// and not clobbered by the kernel's own stores -- which is what lets wave-uniform streams stay on scalar loads.
 #define lr_z(p, z, pair) \
-    do { if (p) p = reinterpret_cast<decltype(p)>(reinterpret_cast<uintptr_t>(p) + (size_t)(pair) * (z).stride); } while (0)
+    do { if (p) p = (decltype(p))((const char *)(p) + (size_t)(pair) * (z).stride); } while (0)
 // 1-D grid of 8 * ceil(total / 8) blocks -> logical block id such that the blocks an XCD receives (hardware ids congruent
 // mod 8) form one contiguous range of logical ids (cdna_hip_programming.md T1).  false: padding block.
 __device__ __forceinline__ bool lr_xcd_block(int total, int &logical)
@@ -105,6 +107,7 @@ struct lr_workspace {
     int nn_path;                 // LR_NN_PATH_*
     int nn_blocks_target;        // column strips are chosen so that a pass launches about this many blocks
     int nn_blocks_batch;         // the same for a batched call (all pairs together; LIDARREG_NN_BLOCKS_BATCH)
+    int pb_dyn_lds;              // extra dynamic LDS requested by the pass-B launches (LIDARREG_PB_DYNLDS, development knob: caps the blocks per CU)
     int rev_strips;              // strips offered to every row block of the reverse pass (LIDARREG_REV_STRIPS)
     int nn_second_auto;          // LIDARREG_NN_SECOND=auto: lr_register_pair computes the 2nd neighbour only when a stage reads it
     float *pb1, *pb2, *pb3;      // partial top-3 values [strips][max_n]

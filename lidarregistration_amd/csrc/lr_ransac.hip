@@ -208,7 +208,7 @@ ransac_gen_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__r
 #ifndef LR_SCORE_CHUNK
 #define LR_SCORE_CHUNK 128
 #endif
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(256)
 ransac_score_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__restrict__ m_dev, float thr2,
                     const float *__restrict__ models, uint32_t *__restrict__ score_cnt,
                     unsigned long long *__restrict__ score_ssq, const int32_t *__restrict__ counters, int sub, int model_stride, lr_zargs z)
@@ -218,13 +218,16 @@ ransac_score_kernel(const float *__restrict__ corr8, int m_max, const int32_t *_
     const int V = counters[LR_CNT_NVALID];
     const int hb = (V + 63) >> 6;
     if (hb == 0 || m <= 0 || reinterpret_cast<const lr_ransac_state *>(counters + LR_CNT_COUNT)->done) return;
-    int chunks = (int)gridDim.x / hb;
+    // a block is four independent waves (one-wave blocks cap the CU at half its wave slots); wave w of the launch takes the
+    // work items w, w + W, ...
+    const int W = (int)gridDim.x * 4;
+    int chunks = W / hb;
     const int cmax = m / LR_SCORE_CHUNK > 0 ? m / LR_SCORE_CHUNK : 1;   // at least LR_SCORE_CHUNK correspondences per work item
     if (chunks > cmax) chunks = cmax;
     if (chunks < 1) chunks = 1;
     const int per = ((m + chunks - 1) / chunks + 1) & ~1;      // even: chunks start on a pair boundary
-    const int lane = threadIdx.x;
-    for (int w = blockIdx.x; w < hb * chunks; w += gridDim.x) {
+    const int lane = threadIdx.x & 63;
+    for (int w = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6); w < hb * chunks; w += W) {
         const int g = w % hb, c = w / hb;
         const int slot = g * 64 + lane;
         const bool active = slot < V;
@@ -692,7 +695,7 @@ int lr_ransac_run(lr_workspace *ws, const float *corr8, int m_max, const int32_t
         else
             hipLaunchKernelGGL(ransac_gen_kernel<4>, dim3(gb, 1, ws->zP), dim3(256), 0, st, corr8, m_max, m_dev, *p, h0, h1, ws->models, ws->models64,
                                ws->model_h, ws->score_cnt, ws->score_ssq, ws->counters, G, TN, ws->max_iters, ws->z);
-        hipLaunchKernelGGL(ransac_score_kernel, dim3(LR_SCORE_BLOCKS, 1, ws->zP), dim3(64), 0, st, corr8, m_max, m_dev, p->thr2, ws->models,
+        hipLaunchKernelGGL(ransac_score_kernel, dim3(LR_SCORE_BLOCKS / 4, 1, ws->zP), dim3(256), 0, st, corr8, m_max, m_dev, p->thr2, ws->models,
                            ws->score_cnt, ws->score_ssq, ws->counters, sub, ws->max_iters, ws->z);
         if (h0 == 0 && ws->timing && ws->ev_pending == 1) { LR_HIP(hipEventRecord(ws->ev[3], st)); ws->ev_pending = 2; }
         hipLaunchKernelGGL(ransac_final_kernel, dim3(1, 1, ws->zP), dim3(1024), 0, st, ws->score_cnt, ws->score_ssq, ws->model_h, ws->models64,

@@ -34,9 +34,10 @@ def per_kernel(path, counter):
 def main(fetch_csv, write_csv, out):
     f = per_kernel(fetch_csv, "FETCH_SIZE"); w = per_kernel(write_csv, "WRITE_SIZE")
     res = {"_how": "rocprofv3 --pmc FETCH_SIZE (and, in a separate run, --pmc WRITE_SIZE) --output-format csv -- python3 bench.py "
-                   "--steps 2 --warmup 1 --streams 1 --pairs 8 --no-cpu-baseline ; per-launch averages over all launches of the run; "
+                   "--steps 2 --warmup 1 --streams 1 --pairs 32 --no-cpu-baseline ; per-launch averages over all launches of the run "
+                   "(a launch of the batched path covers the 32 pairs of one lr_register_batch call); "
                    "FETCH_SIZE/WRITE_SIZE are KiB; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE reports half of a "
-                   "wide coalesced read, MI355X_MICROARCH.md section HBM); tools/prof_round.sh + tools/pmc_to_json.py"}
+                   "wide coalesced read, MI355X_MICROARCH.md section HBM); tools/prof_round2.sh + tools/pmc_to_json.py"}
     for k in sorted(set(f) | set(w)):
         fk, wk = f.get(k, 0.0), w.get(k, 0.0)
         res[k] = {"FETCH_SIZE_KiB": round(fk, 1), "WRITE_SIZE_KiB": round(wk, 1), "hbm_bytes_per_launch": int((2 * fk + wk) * 1024)}
