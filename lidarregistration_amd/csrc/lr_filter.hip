@@ -312,7 +312,25 @@ ratio_kernel(const float *__restrict__ F0, const float *__restrict__ F1, int dim
         const float *b1 = F1 + (size_t)i1[c] * dim;
         const float *b2 = F1 + (size_t)i2[c] * dim;
         float s1 = 0.0f, s2 = 0.0f;
-        if ((dim & 3) == 0) {
+        if (dim == 32) {
+            // FCGF's 32 dimensions: all 24 16-byte loads of the three rows are in flight before the first subtraction (the
+            // generic loop below pays one memory round trip per iteration); the sums still run over k = 0, 1, 2, ... in order
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            const f32x4 *a4 = reinterpret_cast<const f32x4 *>(a), *p4 = reinterpret_cast<const f32x4 *>(b1), *q4 = reinterpret_cast<const f32x4 *>(b2);
+            f32x4 av[8], pv[8], qv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { av[k] = a4[k]; pv[k] = p4[k]; qv[k] = q4[k]; }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    float e1 = av[k][t] - pv[k][t], e2 = av[k][t] - qv[k][t];
+                    float q1 = e1 * e1, q2 = e2 * e2;
+                    s1 = s1 + q1;
+                    s2 = s2 + q2;
+                }
+            }
+        } else if ((dim & 3) == 0) {
             // 16-byte loads; the sums still run over k = 0, 1, 2, ... in order (rows of a [n, dim] float array with
             // dim % 4 == 0 are 16-byte aligned whenever the array is, and torch / hipMalloc allocations are)
             typedef float f32x4 __attribute__((ext_vector_type(4)));
