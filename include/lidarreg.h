@@ -37,7 +37,10 @@ typedef struct lr_workspace lr_workspace;
  * FR.py:128-137, with explicit flags instead of the reference's sentinel overloading.            */
 typedef struct lr_ransac_params {
     int32_t  sample_size;   /* 3 = GC-RANSAC minimal solver, 4 = FR.py:134 ransac_n                  */
-    int32_t  use_elc;       /* edge-length pre-check, similarity 0.9 (preemption_edge_length.h:82)    */
+    int32_t  use_elc;       /* pre-verification (--fast_rejection, GC_RANSAC.py:29-34): 0 none; 1 edge-length check of the
+                               sample, similarity 0.9 (preemption_edge_length.h:82); 2 SPRT on the estimated model
+                               (gcransac_python.cpp:534-568, min_inlier_ratio_for_sprt 0.1): Wald's sequential test over
+                               the first 256 correspondences, design (eps, delta, A) updated between batches          */
     float    thr2;          /* squared inlier threshold; (2*voxel)^2 = 0.36 (FR.py:85,95)             */
     int32_t  iters;         /* hypothesis ids 0..iters-1 (--iters, FR.py:65-67)                       */
     uint64_t seed;          /* Philox4x32-10 key; sample of hypothesis h = philox(seed, h)            */

@@ -12,7 +12,7 @@ import torch
 
 from . import _ext
 from .matching import _device, _f32, _stream, measure_inlier_ratio, workspace
-from .ransac import DEFAULT_SEED
+from .ransac import DEFAULT_SEED, PRECHECK
 
 VOXEL_SIZE = 0.3            # FR.py:18
 MODES = {"MNN": _ext.LR_MODE_MNN, "MMN": _ext.LR_MODE_MNN,      # README.md:55 spells it MMN
@@ -44,15 +44,11 @@ def pair_params(args):
     if codebase == "GC":
         sample_size = 3
         fast_rejection = getattr(args, "fast_rejection", "ELC")
-        if fast_rejection == "SPRT":
-            # GC_RANSAC.py:29-34, gcransac_python.cpp:534-568: sequential probability ratio test -- not built; refusing beats
-            # silently running a different pre-verification
-            raise NotImplementedError("--fast_rejection SPRT is not implemented on the HIP path (use ELC or NONE)")
-        assert fast_rejection in ("ELC", "NONE"), "unknown fast_rejection"
+        assert fast_rejection in PRECHECK, "unknown fast_rejection"               # GC_RANSAC.py:29-34: NONE | ELC | SPRT
         if float(getattr(args, "spatial_coherence_weight", 0.0)) != 0.0:
             # GC_RANSAC.py:22: the graph-cut term of the local optimisation; only weight 0 (the reference's default) is built
             raise NotImplementedError("--spatial_coherence_weight != 0 is not implemented on the HIP path")
-        use_elc = fast_rejection == "ELC"
+        use_elc = PRECHECK[fast_rejection]
         conf = float(getattr(args, "GC_conf", 0.999))                  # GC_RANSAC.py:26, test.py:312
         sampler = 1 if getattr(args, "prosac", True) else 2            # test.py:308 (default True), GC_RANSAC.py:24; unique indices
         scoring = 1                                                    # MSAC, the cost pygcransac ranks models by

@@ -72,6 +72,7 @@ void carve(lr_workspace *ws, Carver &c)
     ws->models = c.take<float>(it * 12);
     ws->models64 = c.take<double>(it * 12);
     ws->model_h = c.take<int32_t>(it);
+    ws->models2 = c.take<float>(it * 12); ws->models64_2 = c.take<double>(it * 12); ws->model_h2 = c.take<int32_t>(it);
     ws->score_cnt = c.take<uint32_t>(it);
     ws->score_ssq = c.take<unsigned long long>(it);
     ws->refit_part = c.take<double>((n0 / 256 + 2) * 16);

@@ -90,7 +90,7 @@ compact_kernel(int n0, const uint8_t *__restrict__ flags, const int32_t *__restr
     }
     if (corr8 && blockIdx.x == 0 && tid < LR_CNT_TOTAL - LR_CNT_COUNT) {     // the RANSAC that follows starts from scratch
         counters[LR_CNT_COUNT + tid] = 0;
-        if (tid == 0) counters[LR_CNT_NVALID] = 0;
+        if (tid == 0) { counters[LR_CNT_NVALID] = 0; counters[LR_CNT_NVALID2] = 0; }
     }
     if (blockIdx.x == gridDim.x - 1 && tid == 0) {
         const int total = prefix + s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
@@ -147,7 +147,7 @@ __global__ void pack_corr_kernel(const float *__restrict__ xyz0, const float *__
     lr_z(i0, z, blockIdx.z); lr_z(i1, z, blockIdx.z); lr_z(m_dev, z, blockIdx.z); lr_z(corr8, z, blockIdx.z); lr_z(counters, z, blockIdx.z); lr_z(rank, z, blockIdx.z);
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < LR_CNT_TOTAL - LR_CNT_COUNT) counters[LR_CNT_COUNT + c] = 0;     // the RANSAC that follows starts from scratch
-    if (c == 0) counters[LR_CNT_NVALID] = 0;
+    if (c == 0) { counters[LR_CNT_NVALID] = 0; counters[LR_CNT_NVALID2] = 0; }
     int m = m_dev ? min(*m_dev, m_max) : m_max;
     if (c >= m) return;
     int a = i0 ? i0[c] : c, b = i1 ? i1[c] : c;

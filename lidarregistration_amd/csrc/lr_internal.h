@@ -136,6 +136,7 @@ struct lr_workspace {
     float *models;               // [max_iters][12] fp32 R|t rows of hypotheses that passed the pre-check
     double *models64;            // [max_iters][12] the same models in fp64 (the winner is returned from here)
     int32_t *model_h;            // [max_iters] their hypothesis ids
+    float *models2; double *models64_2; int32_t *model_h2;   // the same three for the models that survived the SPRT pre-verification
     uint32_t *score_cnt;         // [max_iters]
     unsigned long long *score_ssq; // [max_iters]
     double *refit_part;          // [blocks][16] moment partials
@@ -166,6 +167,7 @@ enum {
     LR_CNT_RLO,          // smallest / largest forward NN distance of the pair (float bit patterns)
     LR_CNT_RHI,
     LR_CNT_REFIT_TICKET, // blocks of the refit kernel that have finished (last-block-done; reset by the last block)
+    LR_CNT_NVALID2,      // SPRT pre-verification: models that survived it (dense second list, scored in full)
     LR_CNT_COUNT = 16,
     LR_CNT_TOTAL = 64        // counters[16..63] hold lr_ransac_state
 };
@@ -186,6 +188,10 @@ struct lr_ransac_state {
     int32_t lo_pending;           // the best model changed in the batch just merged: the local optimisation has to run on it
     int32_t lo_calls;             // local optimisations run so far (part of the key of their sample stream)
     int32_t pad;
+    // SPRT pre-verification (use_elc == 2): design of the current batch (0 = not designed yet: eps 0.1, delta 0.01) and the
+    // statistics of the models rejected so far
+    double sprt_eps, sprt_delta;
+    unsigned long long rej_inl, rej_pts;
 };
 static_assert(sizeof(lr_ransac_state) <= (LR_CNT_TOTAL - LR_CNT_COUNT) * sizeof(int32_t), "lr_ransac_state does not fit");
 

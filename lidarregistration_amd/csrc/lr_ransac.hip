@@ -182,7 +182,7 @@ ransac_gen_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__r
     const int h = h_begin + blockIdx.x * 256 + threadIdx.x;
     {
         double P[NS][3], Q[NS][3];
-        if (h < h_end && hypothesis_sample<NS>(corr8, m, p.seed, (uint64_t)h, p.use_elc, P, Q, G, TN, p.sampler != 0)) s_pass[atomicAdd(&s_np, 1)] = h;
+        if (h < h_end && hypothesis_sample<NS>(corr8, m, p.seed, (uint64_t)h, p.use_elc == 1, P, Q, G, TN, p.sampler != 0)) s_pass[atomicAdd(&s_np, 1)] = h;
     }
     __syncthreads();
     const int np = s_np;
@@ -203,6 +203,90 @@ ransac_gen_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__r
     score_ssq[slot] = 0ull;
 }
 
+
+// ------------------------------------------------------------------ SPRT pre-verification (--fast_rejection SPRT)
+// See oracle/oracle.c (sprt_test) for the test and its sources.  One LANE per model, the first LR_SPRT_HORIZON
+// correspondences in list order as a wave-uniform stream (scalar loads); a wave leaves as soon as all its models are
+// decided.  Survivors are appended to a second dense model list (their order does not matter: the winner is chosen by
+// score and hypothesis id); the consistent / verified point counts of the rejected models feed the next batch's design.
+#define LR_SPRT_HORIZON 256
+#define LR_SPRT_EPS0 0.1
+#define LR_SPRT_DELTA0 0.01
+__device__ __forceinline__ double lr_sprt_threshold(double eps, double delta)
+{
+    const double C = (1.0 - delta) * log((1.0 - delta) / (1.0 - eps)) + delta * log(delta / eps);
+    const double K = (200.0 * C) / 1.0 + 1.0;
+    double A = K;
+    for (int i = 0; i < 10; ++i) A = K + log(A);
+    return A;
+}
+
+__global__ void __launch_bounds__(256)
+ransac_sprt_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__restrict__ m_dev, float thr2,
+                   const float *__restrict__ models, const double *__restrict__ models64, const int32_t *__restrict__ model_h,
+                   float *__restrict__ models2, double *__restrict__ models64_2, int32_t *__restrict__ model_h2,
+                   uint32_t *__restrict__ score_cnt, unsigned long long *__restrict__ score_ssq, int32_t *__restrict__ counters,
+                   int model_stride, lr_zargs z)
+{
+    lr_z(corr8, z, blockIdx.z); lr_z(m_dev, z, blockIdx.z); lr_z(models, z, blockIdx.z); lr_z(models64, z, blockIdx.z); lr_z(model_h, z, blockIdx.z);
+    lr_z(models2, z, blockIdx.z); lr_z(models64_2, z, blockIdx.z); lr_z(model_h2, z, blockIdx.z); lr_z(score_cnt, z, blockIdx.z);
+    lr_z(score_ssq, z, blockIdx.z); lr_z(counters, z, blockIdx.z);
+    lr_ransac_state *state = reinterpret_cast<lr_ransac_state *>(counters + LR_CNT_COUNT);
+    const int m = m_dev ? min(*m_dev, m_max) : m_max;
+    const int V = counters[LR_CNT_NVALID];
+    if (V <= 0 || m <= 0 || state->done) return;
+    const int lane = threadIdx.x & 63;
+    const int group = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6);
+    if (group * 64 >= V) return;
+    const double eps = state->sprt_eps > 0.0 ? state->sprt_eps : LR_SPRT_EPS0, delta = state->sprt_delta > 0.0 ? state->sprt_delta : LR_SPRT_DELTA0;
+    const double A = lr_sprt_threshold(eps, delta), fin = delta / eps, fout = (1.0 - delta) / (1.0 - eps);
+    const int slot = group * 64 + lane;
+    const bool active = slot < V;
+    const float *mp = models + (active ? slot : 0);
+    const size_t ms = (size_t)model_stride;
+    const float r00 = mp[0], r01 = mp[ms], r02 = mp[2 * ms], tx = mp[3 * ms];
+    const float r10 = mp[4 * ms], r11 = mp[5 * ms], r12 = mp[6 * ms], ty = mp[7 * ms];
+    const float r20 = mp[8 * ms], r21 = mp[9 * ms], r22 = mp[10 * ms], tz = mp[11 * ms];
+    const int n = min(m, LR_SPRT_HORIZON);
+    double lambda = 1.0;
+    int inl = 0, k_rej = 0;
+    bool rejected = !active;
+    for (int i = 0; i < n; ++i) {
+        if (__builtin_amdgcn_ballot_w64(!rejected) == 0ull) break;
+        const float px = corr8[lr_corr_at(i, 0)], py = corr8[lr_corr_at(i, 1)], pz = corr8[lr_corr_at(i, 2)];
+        const float x = __builtin_fmaf(r00, px, __builtin_fmaf(r01, py, __builtin_fmaf(r02, pz, tx)));
+        const float y = __builtin_fmaf(r10, px, __builtin_fmaf(r11, py, __builtin_fmaf(r12, pz, ty)));
+        const float zz = __builtin_fmaf(r20, px, __builtin_fmaf(r21, py, __builtin_fmaf(r22, pz, tz)));
+        const float dx = x - corr8[lr_corr_at(i, 3)], dy = y - corr8[lr_corr_at(i, 4)], dz = zz - corr8[lr_corr_at(i, 5)];
+        const float d2 = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
+        if (!rejected) {
+            if (d2 < thr2) { inl += 1; lambda = lambda * fin; } else lambda = lambda * fout;
+            if (lambda > A) { rejected = true; k_rej = i + 1; }
+        }
+    }
+    const bool keep = active && !rejected;
+    // survivors -> the second list
+    const unsigned long long kb = __builtin_amdgcn_ballot_w64(keep);
+    int base = 0;
+    if (lane == 0 && kb) base = atomicAdd(&counters[LR_CNT_NVALID2], (int)__builtin_popcountll(kb));
+    base = __shfl(base, 0);
+    if (keep) {
+        const int dst = base + (int)__builtin_popcountll(kb & ((1ull << lane) - 1ull));
+        models2[dst] = r00; models2[ms + dst] = r01; models2[2 * ms + dst] = r02; models2[3 * ms + dst] = tx;
+        models2[4 * ms + dst] = r10; models2[5 * ms + dst] = r11; models2[6 * ms + dst] = r12; models2[7 * ms + dst] = ty;
+        models2[8 * ms + dst] = r20; models2[9 * ms + dst] = r21; models2[10 * ms + dst] = r22; models2[11 * ms + dst] = tz;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) models64_2[(size_t)dst * 12 + k] = models64[(size_t)slot * 12 + k];
+        model_h2[dst] = model_h[slot];
+        score_cnt[dst] = 0u; score_ssq[dst] = 0ull;
+    }
+    // rejected models: consistent / verified points (integer sums: order independent)
+    unsigned long long ri = (active && rejected) ? (unsigned long long)inl : 0ull, rp = (active && rejected) ? (unsigned long long)k_rej : 0ull;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { ri += __shfl_xor(ri, o); rp += __shfl_xor(rp, o); }
+    if (lane == 0 && rp) { atomicAdd(&state->rej_inl, ri); atomicAdd(&state->rej_pts, rp); }
+}
+
 // ------------------------------------------------------------------ score
 // Work items = (group of 64 hypotheses) x (chunk of correspondences); blocks stride over them.
 #ifndef LR_SCORE_CHUNK
@@ -211,11 +295,11 @@ ransac_gen_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__r
 __global__ void __launch_bounds__(256)
 ransac_score_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__restrict__ m_dev, float thr2,
                     const float *__restrict__ models, uint32_t *__restrict__ score_cnt,
-                    unsigned long long *__restrict__ score_ssq, const int32_t *__restrict__ counters, int sub, int model_stride, lr_zargs z)
+                    unsigned long long *__restrict__ score_ssq, const int32_t *__restrict__ counters, int sub, int model_stride, int vslot, lr_zargs z)
 {
     lr_z(corr8, z, blockIdx.z); lr_z(m_dev, z, blockIdx.z); lr_z(models, z, blockIdx.z); lr_z(score_cnt, z, blockIdx.z); lr_z(score_ssq, z, blockIdx.z); lr_z(counters, z, blockIdx.z);
     const int m = m_dev ? min(*m_dev, m_max) : m_max;
-    const int V = counters[LR_CNT_NVALID];
+    const int V = counters[vslot];           // LR_CNT_NVALID, or LR_CNT_NVALID2 behind the SPRT pre-verification
     const int hb = (V + 63) >> 6;
     if (hb == 0 || m <= 0 || reinterpret_cast<const lr_ransac_state *>(counters + LR_CNT_COUNT)->done) return;
     // a block is four independent waves (one-wave blocks cap the CU at half its wave slots); wave w of the launch takes the
@@ -299,7 +383,7 @@ __global__ void __launch_bounds__(1024)
 ransac_final_kernel(const uint32_t *__restrict__ score_cnt, const unsigned long long *__restrict__ score_ssq,
                     const int32_t *__restrict__ model_h, const double *__restrict__ models64,
                     int32_t *__restrict__ counters, int m_max, const int32_t *__restrict__ m_dev, lr_ransac_params p, int h_end,
-                    double *__restrict__ T_out, lr_ransac_result *__restrict__ res, lr_zargs z)
+                    double *__restrict__ T_out, lr_ransac_result *__restrict__ res, int vslot, lr_zargs z)
 {
     __shared__ unsigned long long s_q[16];
     lr_z(score_cnt, z, blockIdx.z); lr_z(score_ssq, z, blockIdx.z); lr_z(model_h, z, blockIdx.z); lr_z(models64, z, blockIdx.z); lr_z(counters, z, blockIdx.z); lr_z(m_dev, z, blockIdx.z); lr_z(T_out, z, blockIdx.z); lr_z(res, z, blockIdx.z);
@@ -308,7 +392,7 @@ ransac_final_kernel(const uint32_t *__restrict__ score_cnt, const unsigned long 
     lr_ransac_state *state = reinterpret_cast<lr_ransac_state *>(counters + LR_CNT_COUNT);
     if (state->done) return;
     const uint32_t msac_T = p.scoring == 1 ? (uint32_t)(p.thr2 * 1048576.0f) : 0u;
-    const int V = counters[LR_CNT_NVALID];
+    const int V = counters[vslot];
     uint32_t bc = 0; unsigned long long bq = ~0ull; int bh = 0x7fffffff, bs = -1;
     for (int s = threadIdx.x; s < V; s += 1024) {
         uint32_t c = score_cnt[s];
@@ -344,6 +428,19 @@ ransac_final_kernel(const uint32_t *__restrict__ score_cnt, const unsigned long 
         state->cnt = nc; state->ssq = nq; state->h = nh;
         state->n_valid += V; state->n_ids = h_end;
         counters[LR_CNT_NVALID] = 0;                       // the next batch appends from slot 0
+        counters[LR_CNT_NVALID2] = 0;
+        if (p.use_elc == 2) {
+            // re-design the SPRT for the next batch: eps follows the best model, delta the models rejected so far
+            const int mm = m_dev ? min(*m_dev, m_max) : m_max;
+            double eps = state->sprt_eps > 0.0 ? state->sprt_eps : LR_SPRT_EPS0, delta = state->sprt_delta > 0.0 ? state->sprt_delta : LR_SPRT_DELTA0;
+            if (nc > 0) { const double e = (double)nc / (double)mm; if (e > eps && e < 1.0) eps = e; }
+            if (state->rej_pts > 0) {
+                const double d = (double)state->rej_inl / (double)state->rej_pts;
+                if (d > 0.0 && d < 0.9 * eps && fabs(d - delta) > 0.05 * delta) delta = d;
+            }
+            if (!(delta < 0.9 * eps)) delta = 0.9 * eps * 0.5;
+            state->sprt_eps = eps; state->sprt_delta = delta;
+        }
         // with local optimisation a new best model is optimised first (ransac_lo_kernel, next on the stream), and the exit
         // test runs there on the optimised model
         const bool to_lo = take && p.local_opt == 1;
@@ -675,6 +772,7 @@ int lr_ransac_run(lr_workspace *ws, const float *corr8, int m_max, const int32_t
     const bool use_exit = p->confidence > 0.0f && p->confidence < 1.0f;
     // default batch: 8192 ids, or an eighth of a long run (the launches of the batches after the exit still cost a few us each)
     const int B = use_exit ? (p->batch > 0 ? p->batch : (p->iters > 65536 ? ((p->iters / 8 + 8191) / 8192) * 8192 : 8192)) : (p->iters > 0 ? p->iters : 1);
+    LR_REQUIRE(p->use_elc >= 0 && p->use_elc <= 2, LR_EINVAL, "lr_ransac: use_elc must be 0 (no pre-verification), 1 (edge-length check) or 2 (SPRT)");
     LR_REQUIRE(p->sampler >= 0 && p->sampler <= 2, LR_EINVAL, "lr_ransac: sampler must be 0 (uniform), 1 (PROSAC) or 2 (uniform, unique indices)");
     LR_REQUIRE(p->local_opt >= 0 && p->local_opt <= 2, LR_EINVAL, "lr_ransac: local_opt must be 0, 1 or 2");
     LR_REQUIRE(p->prosac_growth >= 0, LR_EINVAL, "lr_ransac: prosac_growth must be >= 0");
@@ -695,11 +793,18 @@ int lr_ransac_run(lr_workspace *ws, const float *corr8, int m_max, const int32_t
         else
             hipLaunchKernelGGL(ransac_gen_kernel<4>, dim3(gb, 1, ws->zP), dim3(256), 0, st, corr8, m_max, m_dev, *p, h0, h1, ws->models, ws->models64,
                                ws->model_h, ws->score_cnt, ws->score_ssq, ws->counters, G, TN, ws->max_iters, ws->z);
-        hipLaunchKernelGGL(ransac_score_kernel, dim3(LR_SCORE_BLOCKS / 4, 1, ws->zP), dim3(256), 0, st, corr8, m_max, m_dev, p->thr2, ws->models,
-                           ws->score_cnt, ws->score_ssq, ws->counters, sub, ws->max_iters, ws->z);
+        const bool sprt = p->use_elc == 2;
+        if (sprt)       // every estimated model is pre-verified; the survivors form a second dense list that is scored in full
+            hipLaunchKernelGGL(ransac_sprt_kernel, dim3(lr_cdiv(gb * 256, 256), 1, ws->zP), dim3(256), 0, st, corr8, m_max, m_dev, p->thr2,
+                               (const float *)ws->models, (const double *)ws->models64, (const int32_t *)ws->model_h, ws->models2, ws->models64_2, ws->model_h2,
+                               ws->score_cnt, ws->score_ssq, ws->counters, ws->max_iters, ws->z);
+        const int vslot = sprt ? LR_CNT_NVALID2 : LR_CNT_NVALID;
+        hipLaunchKernelGGL(ransac_score_kernel, dim3(LR_SCORE_BLOCKS / 4, 1, ws->zP), dim3(256), 0, st, corr8, m_max, m_dev, p->thr2,
+                           sprt ? (const float *)ws->models2 : (const float *)ws->models, ws->score_cnt, ws->score_ssq, ws->counters, sub, ws->max_iters, vslot, ws->z);
         if (h0 == 0 && ws->timing && ws->ev_pending == 1) { LR_HIP(hipEventRecord(ws->ev[3], st)); ws->ev_pending = 2; }
-        hipLaunchKernelGGL(ransac_final_kernel, dim3(1, 1, ws->zP), dim3(1024), 0, st, ws->score_cnt, ws->score_ssq, ws->model_h, ws->models64,
-                           ws->counters, m_max, m_dev, *p, h1, T_out, res, ws->z);
+        hipLaunchKernelGGL(ransac_final_kernel, dim3(1, 1, ws->zP), dim3(1024), 0, st, ws->score_cnt, ws->score_ssq,
+                           sprt ? (const int32_t *)ws->model_h2 : (const int32_t *)ws->model_h, sprt ? (const double *)ws->models64_2 : (const double *)ws->models64,
+                           ws->counters, m_max, m_dev, *p, h1, T_out, res, vslot, ws->z);
         if (p->local_opt == 1)
             hipLaunchKernelGGL(ransac_lo_kernel, dim3(1, 1, ws->zP), dim3(LO_THREADS), 0, st, corr8, m_max, m_dev, *p, h1, 0, ws->counters, ws->lo_list,
                                T_out, res, ws->z);

@@ -14,6 +14,7 @@ from . import _ext
 from .matching import _device, _f32, _i32, _stream, workspace
 
 DEFAULT_SEED = 51          # Experiments/test.py:357
+PRECHECK = {"NONE": 0, "ELC": 1, "SPRT": 2}      # --fast_rejection (test.py:306) -> lr_ransac_params.use_elc
 
 
 def ransac_params(iters, sample_size=3, use_elc=True, thr=0.6, seed=DEFAULT_SEED, confidence=1.0, batch=0, sampler=0, prosac_growth=0,
@@ -21,7 +22,7 @@ def ransac_params(iters, sample_size=3, use_elc=True, thr=0.6, seed=DEFAULT_SEED
     """confidence < 1 enables the early exit between batches of `batch` hypothesis ids (0 -> 8192, an eighth of the run when iters > 65536); sampler 1 = PROSAC
     (correspondences best quality first, growth parameter T_N = prosac_growth, 0 -> 100000), 2 = uniform with unique indices; scoring 1 = MSAC;
     local_opt 1 = GC-RANSAC's local optimisation + final iterated least squares, 2 = the latter only."""
-    return _ext.RansacParams(int(sample_size), int(bool(use_elc)), np.float32(float(thr) * float(thr)), int(iters), int(seed),
+    return _ext.RansacParams(int(sample_size), int(use_elc), np.float32(float(thr) * float(thr)), int(iters), int(seed),
                              float(confidence), int(batch), int(sampler), int(prosac_growth), int(scoring), int(local_opt))
 
 
@@ -91,17 +92,17 @@ def kabsch_dev(P, Q, w=None):
 
 def GC_RANSAC(A, B, distance_threshold, num_iterations, args, match_quality, return_mask=False):
     """GC_RANSAC.py:8-55: (pose 4x4 column-vector convention, elapsed seconds) -- the same estimator ``FR(codebase="GC")``
-    runs: 3-point samples drawn without repetition, pre-check by ``args.fast_rejection`` ("ELC" | "NONE"; "SPRT" raises),
+    runs: 3-point samples drawn without repetition, pre-verification by ``args.fast_rejection`` ("ELC" edge-length check |
+    "SPRT" sequential probability ratio test over the first 256 pairs | "NONE"),
     PROSAC when ``args.prosac`` (pairs sorted by -match_quality, GC_RANSAC.py:39-43), MSAC scoring, GC-RANSAC's local
     optimisation unless ``args.GC_LO`` is False (GC_RANSAC.py:36-37), the final iterated least squares, confidence
     ``args.GC_conf``.  A non-zero ``args.spatial_coherence_weight`` raises (only the reference's default 0 is built).
     With return_mask the inlier mask pygcransac returns next to the pose is appended (in the caller's pair order)."""
     fast_rejection = getattr(args, "fast_rejection", "ELC")
-    if fast_rejection == "SPRT":
-        raise NotImplementedError("--fast_rejection SPRT is not implemented on the HIP path (use ELC or NONE)")
+    assert fast_rejection in PRECHECK, "unknown fast_rejection"
     if float(getattr(args, "spatial_coherence_weight", 0.0)) != 0.0:
         raise NotImplementedError("--spatial_coherence_weight != 0 is not implemented on the HIP path")
-    use_elc = fast_rejection == "ELC"
+    use_elc = PRECHECK[fast_rejection]
     A = np.ascontiguousarray(A, np.float32); B = np.ascontiguousarray(B, np.float32)
     prosac = bool(getattr(args, "prosac", False)) and match_quality is not None
     order = None

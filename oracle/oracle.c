@@ -329,7 +329,7 @@ ORC_API void orc_kabsch_moments(double n, const double sp[3], const double sq[3]
 
 typedef struct {
     int32_t  sample_size;     /* 3 (GC minimal solver) or 4 (FR.py:134 ransac_n)      */
-    int32_t  use_elc;         /* edge-length pre-check on the sample                  */
+    int32_t  use_elc;         /* pre-verification: 0 none, 1 edge-length check on the sample (ELC), 2 SPRT on the model */
     float    thr2;            /* squared inlier threshold (0.6 m)^2                   */
     int32_t  iters;           /* hypotheses h = 0 .. iters-1                          */
     uint64_t seed;
@@ -372,7 +372,7 @@ static int hypothesis_T(const float *src, const float *tgt, int m, const orc_ran
     if (p->sampler != 0)       /* unique-index samplers: a repeated index rejects the draw */
         for (int a = 0; a < p->sample_size; ++a)
             for (int b = a + 1; b < p->sample_size; ++b) if (s[a] == s[b]) return 0;
-    if (p->use_elc && !elc_ok(src, tgt, s, p->sample_size)) return 0;
+    if (p->use_elc == 1 && !elc_ok(src, tgt, s, p->sample_size)) return 0;
     double P[12], Q[12];
     for (int k = 0; k < p->sample_size; ++k)
         for (int a = 0; a < 3; ++a) { P[3 * k + a] = (double)src[3 * s[k] + a]; Q[3 * k + a] = (double)tgt[3 * s[k] + a]; }
@@ -413,6 +413,58 @@ ORC_API void orc_score(const float *src, const float *tgt, int m, const double T
     for (int k = 0; k < 12; ++k) Rt[k] = (float)T[k];
     score_model(src, tgt, m, Rt, thr2, count, ssq);
 }
+
+
+/* ------------------------------------------------------------------ SPRT ---- */
+/* --fast_rejection SPRT (GC_RANSAC.py:29-34 -> use_sprt with min_inlier_ratio_for_sprt = 0.1; gcransac_python.cpp:534-568
+ * instantiates GC-RANSAC's SPRTPreemptiveVerfication): Wald's sequential probability ratio test on the model's residuals
+ * (Matas & Chum, "Randomized RANSAC with sequential probability ratio test", ICCV 2005; Chum & Matas, PAMI 2008).  The
+ * library is not vendored: PARITY UNPINNED; restated from the papers:
+ *   lambda = prod over the verified points of  delta/eps (consistent point)  or  (1-delta)/(1-eps) (inconsistent point);
+ *   the model is rejected as soon as lambda > A;   A solves A = K + ln A,  K = t_M C / m_S + 1,
+ *   C = (1-delta) ln((1-delta)/(1-eps)) + delta ln(delta/eps)   (t_M = 200 verifications per model estimate, m_S = 1 model
+ *   per sample);  eps starts at min_inlier_ratio_for_sprt and follows the best model's inlier ratio, delta starts at 0.01
+ *   and follows the inlier ratio observed on rejected models (re-designed when it moves by more than 5 %).
+ * Restated for a parallel machine: (i) eps / delta / A are frozen inside a batch of hypothesis ids and updated between
+ * batches (like the confidence test and the local optimisation); delta = sum of consistent points / sum of verified points
+ * over all models rejected so far; (ii) the test runs over the first SPRT_HORIZON correspondences in list order (a bad
+ * model is rejected after ~15-70 points; a model that survives the horizon is scored in full and competes as usual).   */
+#define SPRT_HORIZON 256
+#define SPRT_EPS0 0.1
+#define SPRT_DELTA0 0.01
+
+static double sprt_threshold(double eps, double delta)
+{
+    const double C = (1.0 - delta) * log((1.0 - delta) / (1.0 - eps)) + delta * log(delta / eps);
+    const double K = (200.0 * C) / 1.0 + 1.0;
+    double A = K;
+    for (int i = 0; i < 10; ++i) A = K + log(A);
+    return A;
+}
+
+/* 1: the model survives the horizon; 0: rejected after *k points of which *inl were consistent */
+static int sprt_test(const float *src, const float *tgt, int m, const float Rt[12], float thr2, double eps, double delta, double A,
+                     int *k_out, int *inl_out)
+{
+    const double fin = delta / eps, fout = (1.0 - delta) / (1.0 - eps);
+    const int n = m < SPRT_HORIZON ? m : SPRT_HORIZON;
+    double lambda = 1.0;
+    int inl = 0;
+    for (int i = 0; i < n; ++i) {
+        float px = src[3 * i], py = src[3 * i + 1], pz = src[3 * i + 2];
+        float x = fmaf(Rt[0], px, fmaf(Rt[1], py, fmaf(Rt[2], pz, Rt[3])));
+        float y = fmaf(Rt[4], px, fmaf(Rt[5], py, fmaf(Rt[6], pz, Rt[7])));
+        float z = fmaf(Rt[8], px, fmaf(Rt[9], py, fmaf(Rt[10], pz, Rt[11])));
+        float dx = x - tgt[3 * i], dy = y - tgt[3 * i + 1], dz = z - tgt[3 * i + 2];
+        float d2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+        if (d2 < thr2) { inl += 1; lambda = lambda * fin; } else lambda = lambda * fout;
+        if (lambda > A) { *k_out = i + 1; *inl_out = inl; return 0; }
+    }
+    *k_out = n; *inl_out = inl;
+    return 1;
+}
+
+ORC_API double orc_sprt_threshold(double eps, double delta) { return sprt_threshold(eps, delta); }
 
 
 /* ------------------------------------------------- local optimisation ---- */
@@ -571,6 +623,9 @@ ORC_API void orc_ransac(const float *src, const float *tgt, int m, const orc_ran
     /* with local optimisation the best model is no longer the minimal-sample fit of best_h: it is carried along */
     double Tb[16]; int have_T = 0, lo_calls = 0;
     int32_t *lo_list = p->local_opt ? (int32_t *)malloc(sizeof(int32_t) * (size_t)(m > 0 ? m : 1)) : NULL;
+    /* SPRT design of the current batch and the statistics of the rejected models (use_elc == 2) */
+    double sprt_eps = SPRT_EPS0, sprt_delta = SPRT_DELTA0;
+    uint64_t rej_inl = 0, rej_pts = 0;
     const int use_exit = p->confidence > 0.0f && p->confidence < 1.0f;
     const int64_t B = use_exit ? (p->batch > 0 ? p->batch : (p->iters > 65536 ? ((p->iters / 8 + 8191) / 8192) * 8192 : 8192)) : (p->iters > 0 ? p->iters : 1);
     int32_t *G = p->sampler == 1 ? prosac_table(m, p->sample_size, p->prosac_growth > 0 ? p->prosac_growth : 100000) : NULL;
@@ -578,16 +633,23 @@ ORC_API void orc_ransac(const float *src, const float *tgt, int m, const orc_ran
     for (int64_t h0 = 0; h0 < p->iters; h0 += B) {
         const int64_t h1 = h0 + B < p->iters ? h0 + B : p->iters;
         int64_t bb_h = -1; uint32_t bb_c = 0; uint64_t bb_q = 0;      /* winner of this batch */
+        const double sprt_A = p->use_elc == 2 ? sprt_threshold(sprt_eps, sprt_delta) : 0.0;
+        uint64_t b_inl = 0, b_pts = 0;
 #pragma omp parallel
         {
             int64_t lh = -1; uint32_t lc = 0; uint64_t lq = 0; int64_t lv = 0;
+            uint64_t l_inl = 0, l_pts = 0;
 #pragma omp for schedule(dynamic, 64)
             for (int64_t h = h0; h < h1; ++h) {
                 double T[16];
                 if (!hypothesis_T(src, tgt, m, p, (uint64_t)h, T, NULL, G)) continue;
-                lv += 1;
                 float Rt[12];
                 for (int k = 0; k < 12; ++k) Rt[k] = (float)T[k];
+                if (p->use_elc == 2) {
+                    int kk, ii;
+                    if (!sprt_test(src, tgt, m, Rt, p->thr2, sprt_eps, sprt_delta, sprt_A, &kk, &ii)) { l_inl += (uint64_t)ii; l_pts += (uint64_t)kk; continue; }
+                }
+                lv += 1;
                 uint32_t c; uint64_t q;
                 score_model(src, tgt, m, Rt, p->thr2, &c, &q);
                 if (c == 0) continue;
@@ -595,10 +657,11 @@ ORC_API void orc_ransac(const float *src, const float *tgt, int m, const orc_ran
             }
 #pragma omp critical
             {
-                n_valid += lv;
+                n_valid += lv; b_inl += l_inl; b_pts += l_pts;
                 if (lh >= 0 && (bb_h < 0 || model_better(lc, lq, lh, bb_c, bb_q, bb_h, msac_T))) { bb_h = lh; bb_c = lc; bb_q = lq; }
             }
         }
+        rej_inl += b_inl; rej_pts += b_pts;
         /* the batch winner replaces the best so far when it scores better (an optimised model keeps the id of its seed) */
         if (bb_h >= 0 && (best_h < 0 || model_better(bb_c, bb_q, bb_h, best_c, best_q, best_h, msac_T))) {
             best_h = bb_h; best_c = bb_c; best_q = bb_q;
@@ -606,6 +669,15 @@ ORC_API void orc_ransac(const float *src, const float *tgt, int m, const orc_ran
             if (p->local_opt == 1) { lo_optimise(src, tgt, m, p, lo_calls, Tb, &best_c, &best_q, lo_list); lo_calls += 1; }
         }
         n_ids = h1;
+        if (p->use_elc == 2) {
+            /* re-design the test for the next batch: eps follows the best model, delta the rejected ones */
+            if (best_c > 0) { const double e = (double)best_c / (double)m; if (e > sprt_eps && e < 1.0) sprt_eps = e; }
+            if (rej_pts > 0) {
+                const double d = (double)rej_inl / (double)rej_pts;
+                if (d > 0.0 && d < 0.9 * sprt_eps && fabs(d - sprt_delta) > 0.05 * sprt_delta) sprt_delta = d;
+            }
+            if (!(sprt_delta < 0.9 * sprt_eps)) sprt_delta = 0.9 * sprt_eps * 0.5;
+        }
         if (use_exit && best_c > 0) {
             double f = (double)best_c / (double)m;
             double fn = f;

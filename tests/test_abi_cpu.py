@@ -91,11 +91,12 @@ def test_pair_params_follow_the_reference_flags():
     # --GC_LO False: only the final least squares (GC_RANSAC.py:36-37); flags the HIP path does not implement are refused
     assert FR.pair_params(Args(codebase="GC", GC_LO=False)).ransac.local_opt == 2
     import pytest
-    with pytest.raises(NotImplementedError):
-        FR.pair_params(Args(codebase="GC", fast_rejection="SPRT"))
+    assert FR.pair_params(Args(codebase="GC", fast_rejection="SPRT")).ransac.use_elc == 2
     with pytest.raises(NotImplementedError):
         FR.pair_params(Args(codebase="GC", spatial_coherence_weight=0.1))
     FR.pair_params(Args(codebase="open3D", fast_rejection="SPRT", spatial_coherence_weight=0.1))      # GC-only flags: ignored, as in FR.py:70-97
+    with pytest.raises(AssertionError):
+        FR.pair_params(Args(codebase="GC", fast_rejection="bogus"))
     p = FR.pair_params(Args(mode="no_filter", codebase="open3D", iters=2000))
     r = p.ransac
     assert (p.mode, p.refit, r.sample_size, r.use_elc, r.sampler, r.scoring) == (_ext.LR_MODE_NO_FILTER, 1, 4, 1, 0, 0)   # FR.py:128-137

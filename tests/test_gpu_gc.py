@@ -93,14 +93,14 @@ def test_inlier_mask_is_what_the_model_scores(lr, oracle):
 
 @pytest.mark.parametrize("lo", [True, False])
 def test_FR_gc_codebase_flags(lr, oracle, lo):
-    """--GC_LO switches the local optimisation; SPRT / a spatial-coherence weight are refused, not silently dropped."""
+    """--GC_LO switches the local optimisation; a spatial-coherence weight is refused, not silently dropped."""
     p = synth.make_pair(N=5000, rho=0.5, s=0.9, seed=77)
     a = Args(mode="MNN", codebase="GC", iters=3000, GC_LO=lo, prosac=True)
     t = lr.torch.from_numpy
     T = lr.FR.FR(t(p["xyz0"]), t(p["xyz1"]), t(p["feats0"]), t(p["feats1"]), a, p["T_gt"])[0]
     e = oracle.register_pair(p["xyz0"], p["xyz1"], p["feats0"], p["feats1"], mode="MNN", iters=3000, seed=51, args=a, **gc_oracle_kwargs(a))
     np.testing.assert_allclose(T, e["T"], rtol=0, atol=1e-9)
-    for bad in (dict(fast_rejection="SPRT"), dict(spatial_coherence_weight=0.5)):
+    for bad in (dict(spatial_coherence_weight=0.5),):
         with pytest.raises(NotImplementedError):
             lr.FR.FR(t(p["xyz0"]), t(p["xyz1"]), t(p["feats0"]), t(p["feats1"]), Args(mode="MNN", codebase="GC", iters=100, **bad), p["T_gt"])
 
@@ -206,3 +206,31 @@ def test_reference_cloud_cache_source(lr, oracle, tmp_path):
     io_lists.save_cloud(feats, s, i, xi[:-5], describe(xi[:-5].astype(np.float64)))
     with pytest.raises(ValueError):
         src.get(k)                                              # feature cache does not belong to this voxelisation
+
+
+# ----------------------------------------------------------------------------- SPRT pre-verification (--fast_rejection SPRT)
+@pytest.mark.parametrize("n,iters,seed,sampler,lo,conf,batch", [(4000, 20000, 51, 2, 1, 0.999, 0), (4000, 6000, 7, 1, 0, 1.0, 2048),
+                                                                (9000, 30000, 9, 2, 1, 0.999, 4096), (100, 2000, 3, 2, 2, 1.0, 512), (5, 64, 1, 2, 0, 1.0, 0)])
+def test_sprt_preverification_matches_oracle(lr, oracle, n, iters, seed, sampler, lo, conf, batch):
+    src, tgt, T_gt = _planted(n=n, inlier=0.3 if n > 200 else 0.8, seed=seed)
+    kw = dict(sample_size=3, use_elc=2, seed=seed, sampler=sampler, scoring=1, local_opt=lo, confidence=conf, batch=batch)
+    T, info = lr.ransac.ransac_dev(src, tgt, iters, **kw)
+    Te, einfo = oracle.ransac(src, tgt, iters, **kw)
+    assert info == einfo                                   # incl. n_valid = models that survived the test and were scored
+    assert np.array_equal(T, Te)
+    if n > 200:
+        assert oracle.rotation_error_deg(T, T_gt) < 0.5
+        # the test throws away almost all models built on outliers: far fewer are scored than estimated
+        _, none = lr.ransac.ransac_dev(src, tgt, min(iters, 8192), **dict(kw, use_elc=0, confidence=1.0, batch=0))
+        _, sprt = lr.ransac.ransac_dev(src, tgt, min(iters, 8192), **dict(kw, confidence=1.0, batch=0))
+        assert sprt["n_valid"] < 0.2 * none["n_valid"] and sprt["best_count"] >= 0.95 * none["best_count"]
+
+
+def test_FR_with_sprt_flag(lr, oracle):
+    p = synth.make_pair(N=5000, rho=0.5, s=0.9, seed=78)
+    a = Args(mode="MNN", codebase="GC", iters=20000, fast_rejection="SPRT", prosac=True)
+    t = lr.torch.from_numpy
+    T = lr.FR.FR(t(p["xyz0"]), t(p["xyz1"]), t(p["feats0"]), t(p["feats1"]), a, p["T_gt"])[0]
+    e = oracle.register_pair(p["xyz0"], p["xyz1"], p["feats0"], p["feats1"], mode="MNN", iters=20000, seed=51, args=a, **gc_oracle_kwargs(a))
+    np.testing.assert_allclose(T, e["T"], rtol=0, atol=1e-9)
+    assert oracle.rotation_error_deg(T, p["T_gt"]) < 1.0

@@ -242,3 +242,21 @@ def test_local_optimisation_with_early_exit_stops_sooner(oracle):
     _, i0 = oracle.ransac(src, tgt, 200000, seed=51, sampler=2, scoring=1, local_opt=0, confidence=0.999, batch=512)
     _, i1 = oracle.ransac(src, tgt, 200000, seed=51, sampler=2, scoring=1, local_opt=1, confidence=0.999, batch=512)
     assert i1["n_ids"] <= i0["n_ids"] and i1["best_count"] >= i0["best_count"]
+
+
+def test_sprt_preverification_properties(oracle):
+    """--fast_rejection SPRT (GC_RANSAC.py:29-34): the sequential test rejects nearly every model built on outliers after a few
+    dozen points, keeps the good ones, and so reaches the same best model as exhaustive scoring."""
+    src, tgt, T_gt, inl = _planted(n=5000, inlier=0.3, seed=31)
+    kw = dict(sample_size=3, seed=51, sampler=2, scoring=1)
+    T0, i0 = oracle.ransac(src, tgt, 6000, use_elc=0, **kw)
+    T2, i2 = oracle.ransac(src, tgt, 6000, use_elc=2, **kw)
+    assert i2["n_valid"] < 0.1 * i0["n_valid"]                      # ~2.7 % of the samples are all-inlier at 30 % inliers
+    assert i2["best_h"] == i0["best_h"] and i2["best_count"] == i0["best_count"] and np.array_equal(T0, T2)
+    # batches: the design follows the best model (eps) -- later batches reject faster, the result does not change
+    T3, i3 = oracle.ransac(src, tgt, 6000, use_elc=2, confidence=0.9999999, batch=512, **kw)
+    assert i3["best_count"] >= i2["best_count"] * 0.98
+    import ctypes
+    f = oracle.lib().orc_sprt_threshold; f.restype = ctypes.c_double
+    A = f(ctypes.c_double(0.1), ctypes.c_double(0.01))
+    assert 15 < A < 25 and f(ctypes.c_double(0.4), ctypes.c_double(0.01)) > A       # a stricter design for a better model
