@@ -37,4 +37,7 @@ def summarize(all_stats, algo="RANSAC"):
     icpavg = okicp.mean(0) if len(okicp) else np.full(s.shape[1], np.nan)
     out += (f"{algo}+ICP | recall: {100*avg[12]:.2f}%, #failed/#total: {int((s[:,12]==0).sum())}/{n}, TE(cm): {icpavg[14]:.3f}, "
             f"RE(deg): {icpavg[13]:.3f}, ICP time(s): {avg[11]:.3f}, Total time(s) {avg[9]+avg[11]:.3f}\n")
+    # (not in the reference's block) what "reg time" covers here, so that the two are not compared line by line
+    out += ("note: reg time = device time of the whole path incl. the forward NN (the reference bills the 2nd-NN surcharge + filter + "
+            "RANSAC only, FR.py:117); ICP is timed on its own\n")
     return out

@@ -46,6 +46,7 @@ SIZES = [(3000, 3000), (4100, 2500), (257, 999), (5000, 5000), (1234, 4321), (30
 @pytest.mark.parametrize("kw", [dict(mode="MNN", codebase="open3D", ransac_n=3, o3d_conf=1.0),
                                 dict(mode="MNN", codebase="GC", GC_conf=0.999),
                                 dict(mode="GPF", codebase="GC", GPF_factor=0.5, prosac=True),
+                                dict(mode="MNN", codebase="GC", fast_rejection="SPRT", prosac=False, GC_conf=0.99),
                                 dict(mode="no_filter", codebase="open3D", ransac_n=4, o3d_conf=0.9995),
                                 dict(mode="GPF", codebase="open3D", GPF_factor=0.3, GPF_grid_wid=7, o3d_conf=1.0, icp=True)])
 def test_batch_is_bit_identical_to_single_pairs(lr, kw):

@@ -30,7 +30,8 @@ def _outputs(tmp_path):
     return np.load(d / "raw_stats.npy"), ids, T, (d / "log.txt").read_text()
 
 
-@pytest.mark.parametrize("mode_args", [["--mode", "MMN"], ["--mode", "GPF", "--GPF_factor", "0.5"], ["--mode", "no_filter", "--codebase", "open3D"]])
+@pytest.mark.parametrize("mode_args", [["--mode", "MMN"], ["--mode", "GPF", "--GPF_factor", "0.5"], ["--mode", "no_filter", "--codebase", "open3D"],
+                                       ["--mode", "MNN", "--fast_rejection", "SPRT", "--GC_LO", "False"]])
 def test_single_process_run(cli, tmp_path, oracle, mode_args):
     stats = cli.main(COMMON + mode_args)
     raw, ids, T, log = _outputs(tmp_path)
@@ -45,6 +46,8 @@ def test_single_process_run(cli, tmp_path, oracle, mode_args):
     mode = mode_args[1]
     from tests.conftest import gc_oracle_kwargs
     a = Args(GPF_factor=0.5, prosac=True)          # the CLI's defaults: --codebase GC --prosac True --GC_LO True
+    if "SPRT" in mode_args:
+        a.fast_rejection = "SPRT"; a.GC_LO = False
     kw = dict(sample_size=4, confidence=0.9995, refit_on_orig=1, scoring=0) if "open3D" in mode_args else gc_oracle_kwargs(a)
     e = oracle.register_pair(p["xyz0"], p["xyz1"], p["feats0"], p["feats1"], mode=mode, iters=2000, seed=51, args=a, **kw)
     assert np.radians(oracle.rotation_error_deg(T[2], e["T"])) <= 1e-4 and oracle.translation_error_cm(T[2], e["T"]) / 100 <= 1e-3
