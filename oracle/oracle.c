@@ -16,11 +16,18 @@
  *                                  Requirements/conda_GC_full.yml:115): uniform sampling with replacement,
  *                                  edge-length checker 0.9, inlier count then RMSE, threshold 0.6 m
  *   orc_refit                      Experiments/algorithms/FR.py:99-111
+ *   orc_ransac options             the GC codebase (Experiments/algorithms/GC_RANSAC.py:8-55 -> pygcransac 0.1, driver
+ *                                  GC-RANSAC/src/pygcransac/src/gcransac_python.cpp:404-624; library not vendored):
+ *                                  unique-index samplers, PROSAC, MSAC, SPRT pre-verification (sprt_test), GC-RANSAC's
+ *                                  local optimisation at spatial-coherence weight 0 and the final iterated least squares
+ *                                  (lo_optimise / lo_polish) -- restated from the published algorithms
+ *   orc_icp                        Experiments/test.py:183-189 (Open3D registration_icp)
  *
  * Parity status: NN / ratio / Kabsch are pinned by golden vectors generated from the importable
- * reference (tests/golden/make_golden.py).  The RANSAC loop itself lives in un-vendored third-party
- * code (Open3D / pygcransac): PARITY UNPINNED for that loop -- it is anchored on the reference's
- * call-site parameters and on planted-model recovery properties only.
+ * reference (tests/golden/make_golden.py), the composed pipeline by fixture G11.  The RANSAC loop itself, its
+ * options (PROSAC, SPRT, local optimisation) and ICP live in un-vendored third-party code (Open3D / pygcransac):
+ * PARITY UNPINNED for those -- they are anchored on the reference's call-site parameters, the in-tree ELC source,
+ * the published algorithms and on planted-model recovery properties only.
  *
  * Arithmetic contract (the HIP kernels implement exactly this; build with -ffp-contract=off):
  *   norm(x)   = chain n = fmaf(x[k], x[k], n), k = 0..D-1, n0 = +0

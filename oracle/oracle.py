@@ -12,9 +12,10 @@ logic (mutual intersection, Grid-Prioritized Filter) is restated in numpy below,
 citing the reference lines it follows (paths relative to the reference tree).
 
 Parity status: NN / MNN / best-buddies / ratio / GPF / Kabsch / metric are pinned by golden vectors
-captured from the importable reference (``tests/golden/make_golden.py``).  The RANSAC loop is
-third-party (Open3D 0.13.0 / pygcransac 0.1, neither vendored nor installable here): PARITY UNPINNED
-for the loop itself; see DESIGN.md.
+captured from the importable reference (``tests/golden/make_golden.py``), the composed ``FR()`` pipeline by
+fixture G11.  The RANSAC loop and its GC options (PROSAC, SPRT, local optimisation), ICP and
+``sparse_quantize`` are third-party (Open3D 0.13.0 / pygcransac 0.1 / MinkowskiEngine 0.5.4, neither
+vendored nor installable here): PARITY UNPINNED for those; see DESIGN.md section 5.
 """
 import ctypes
 import os
