@@ -120,3 +120,21 @@ def test_batch_errors_are_loud(lr):
         lr.FR.register_batch_dev(devp, params, ws=small)         # clouds exceed the workspace
     with pytest.raises(lr.ext.LidarRegError):
         lr.ext.Workspace(500, 500, 32, 500, max_pairs=65)
+
+
+def test_batch_with_tiny_and_degenerate_pairs(lr):
+    """Pairs of a few points (no valid hypothesis, status 1) next to ordinary ones in one batch: same bits as alone."""
+    a = Args(mode="MNN", codebase="open3D", iters=600, ransac_n=3, o3d_conf=1.0)
+    params = lr.FR.pair_params(a)
+    sizes = [(1, 40), (2000, 2100), (5, 3), (33, 1), (2, 2), (700, 650)]
+    _, devp = _dev_pairs(lr, sizes, seed0=700)
+    ws = lr.ext.Workspace(2100, 2100, 32, a.iters, max_pairs=len(sizes))
+    ws.poison(0x5A)
+    outb = lr.FR.register_batch_dev(devp, params, ws=ws).cpu().numpy().copy()
+    ws1 = lr.ext.Workspace(2100, 2100, 32, a.iters)
+    for k in range(len(sizes)):
+        ws1.poison(0x11 * (k + 1))
+        out1 = lr.FR.register_pair_dev(*devp[k], params, ws=ws1).cpu().numpy()
+        assert np.array_equal(outb[k], out1), (k, sizes[k])
+    r = lr.ext.PairResult.from_buffer_copy(outb[0].tobytes())
+    assert r.status in (0, 1) and r.n_corr <= 1
