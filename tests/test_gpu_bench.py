@@ -1,0 +1,41 @@
+"""bench.py on the GPU with a small workload: the JSON line carries the contract keys, the roofline / pair_roofline / cpu_baseline
+objects, and every timed pair registers correctly.  Needs an MI355X."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--n", "4000", "--iters", "3000", "--pairs", "12", "--batch", "4",
+                        "--steps", "2", "--warmup", "1"] + extra, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+def test_bench_line_small_workload():
+    line = _bench(["--cpu-pairs", "2", "--cpu-budget-s", "5"])
+    assert line["n_gpus"] == 1 and line["unit"] == "pairs/s" and line["value"] > 0 and line["scaling"] == "weak" and line["dtype"] == "f32"
+    assert line["recall_2deg_0.6m"] == 1.0 and line["nn_rows_redone_by_full_scan_per_pair"] == 0.0
+    assert line["config"]["pairs_per_batched_call"] == 4 and "workload" in line["config"]
+    roof = line["roofline"]
+    assert roof["bound"] == "mfma" and roof["kernel"] == "nn16_passb_kernel" and roof["unit"] == "TFLOP/s" and roof["peak"] == 2500.0
+    assert 0 < roof["frac"] < 1 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and roof["launch_ms"] > 0
+    pr = line["pair_roofline"]
+    assert 0 < pr["frac"] < 1 and pr["t_min_us"] < pr["t_pair_us"]
+    cpu = line["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["unit"] == "pairs/s" and cpu["value"] > 0 and cpu["cores"] >= 1 and "einsum" in cpu["impl"]
+    assert line["speedup_vs_cpu_baseline"] > 1
+
+
+def test_bench_gpf_mode_and_h2d_variant():
+    line = _bench(["--mode", "GPF", "--no-cpu-baseline", "--include-h2d"])
+    assert line["recall_5deg_0.6m"] == 1.0 and "GPF" in line["metric"] and "pinned host memory" in line["data"] and line["cpu_baseline"] is None
