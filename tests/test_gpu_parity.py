@@ -549,3 +549,29 @@ def test_fcgf_fast_and_dgr_callers(lr, oracle):
     e1 = oracle.register_pair(p["xyz0"], p["xyz1"], p["feats0"], p["feats1"], mode="no_filter", iters=20000, sample_size=4, seed=51,
                               confidence=0.9999, refit_on_orig=1)
     assert np.abs(e1["T"] - e["T"]).max() > 1e-7
+
+
+def test_nn_candidate_store_overflow_falls_back_to_the_exact_scan(lr, oracle):
+    """Every column identical (and many near-identical): each query row has thousands of candidates, far beyond a wave's list
+    and segment -- the rows must come out of the exact full-column scan with torch.min's first-index order intact."""
+    rng = np.random.default_rng(12)
+    for n0, n1, kind in ((700, 3000, "identical"), (300, 2500, "two_values"), (1000, 1500, "near")):
+        F0 = rng.normal(size=(n0, 32)).astype(np.float32); F0 /= np.linalg.norm(F0, axis=1, keepdims=True)
+        base = rng.normal(size=(1, 32)).astype(np.float32); base /= np.linalg.norm(base)
+        if kind == "identical":
+            F1 = np.repeat(base, n1, axis=0)
+        elif kind == "two_values":
+            other = rng.normal(size=(1, 32)).astype(np.float32); other /= np.linalg.norm(other)
+            F1 = np.where((np.arange(n1) % 3 == 0)[:, None], other, base).astype(np.float32)
+        else:
+            F1 = (base + 1e-6 * rng.normal(size=(n1, 32))).astype(np.float32)
+        i1, i2, s1, s2 = lr.matching.nn_top2_dev(F0, F1, want_2nd=True, want_dist=True)
+        o1, o2, os1, os2 = oracle.nn_top2(F0, F1)
+        assert np.array_equal(i1.cpu().numpy(), o1) and np.array_equal(i2.cpu().numpy(), o2), kind
+        assert np.array_equal(_bits(s1.cpu().numpy()), _bits(os1)) and np.array_equal(_bits(s2.cpu().numpy()), _bits(os2))
+        # and the mutual filter over the same degenerate clouds
+        e0 = np.arange(n0)
+        m = oracle.nn_to_mutual(F0, F1, e0, o1, o2)
+        g = lr.matching.nn_to_mutual(lr.torch.from_numpy(F0), lr.torch.from_numpy(F1), lr.torch.from_numpy(e0), lr.torch.from_numpy(o1.astype(np.int64)),
+                                     lr.torch.from_numpy(o2.astype(np.int64)))
+        assert all(np.array_equal(a.numpy(), b) for a, b in zip(g, m)), kind
