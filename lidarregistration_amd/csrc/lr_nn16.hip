@@ -147,7 +147,7 @@ nn16_passa_kernel(const _Float16 *__restrict__ Hq, int na, const _Float16 *__res
     constexpr int XOFF = CH * 32 * LR_LDS_ROW;
     constexpr int BUF = XOFF + 16;           // CH column tiles + their CH maximum norms
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int r = lane & 31, h = lane >> 5;
     const int row0 = bx * LR_BLOCK_ROWS + wave * 64;
     const int ntiles = (nb + 31) >> 5;
@@ -316,7 +316,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     constexpr int BUF = XOFF + CH * 32 * 4;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
     __shared__ uint2 wlist[4][LR_PB_WLIST];   // per wave: { column, (code << 8) | register mask }, code = rb*4 + (g0/8)*2 + h
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int r = lane & 31, h = lane >> 5;
     const int row0 = bx * LR_BLOCK_ROWS + wave * 64;
     int ntiles = (nb + 31) >> 5;

@@ -311,7 +311,9 @@ ransac_score_kernel(const float *__restrict__ corr8, int m_max, const int32_t *_
     if (chunks < 1) chunks = 1;
     const int per = ((m + chunks - 1) / chunks + 1) & ~1;      // even: chunks start on a pair boundary
     const int lane = threadIdx.x & 63;
-    for (int w = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6); w < hb * chunks; w += W) {
+    // the wave index is wave-uniform, which the compiler cannot see through threadIdx: without the readfirstlane the record
+    // loads below become per-lane global loads with VALU address arithmetic instead of scalar loads
+    for (int w = (int)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6); w < hb * chunks; w += W) {
         const int g = w % hb, c = w / hb;
         const int slot = g * 64 + lane;
         const bool active = slot < V;
