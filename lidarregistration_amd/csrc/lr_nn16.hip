@@ -32,6 +32,7 @@
 //   => E_ij <= 9.91e-4 (n0+n1) + 3.4e-7 ;  used: 1.05e-3 (n0_i + max_j n1_j) + 4e-7.
 #include "lr_internal.h"
 #include <math.h>
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -747,7 +748,11 @@ int lr_nn16_run(lr_workspace *ws, const float *Fq, const _Float16 *Hq, const flo
     const int row_blocks = lr_cdiv(na, LR_BLOCK_ROWS);
     // pass A samples every `stride`-th tile (any subset gives a valid, if looser, threshold)
     int stride = ntiles / 16;
-    if (stride > LR_NN16_STRIDE) stride = LR_NN16_STRIDE;
+    {
+        static int cap = -1;     // LIDARREG_NN_STRIDE: sampling stride of pass A (development knob; any value gives the exact result)
+        if (cap < 0) { const char *e = getenv("LIDARREG_NN_STRIDE"); cap = e && atoi(e) > 0 ? atoi(e) : LR_NN16_STRIDE; }
+        if (stride > cap) stride = cap;
+    }
     if (stride < 1) stride = 1;
     // strips: enough blocks (over all pairs of a batched call) to fill 256 CUs a few times over, at least 8 sampled tiles per strip
     int strips = lr_cdiv(ws->zP > 1 ? ws->nn_blocks_batch : ws->nn_blocks_target, row_blocks * ws->zP);

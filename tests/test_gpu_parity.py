@@ -250,6 +250,25 @@ def test_ransac_degenerate_inputs(lr, oracle):
     assert info == einfo and np.array_equal(np.isfinite(T), np.isfinite(Te))
 
 
+@pytest.mark.parametrize("n,n_in,iters,elc", [(40, 12, 300, False), (200, 150, 3000, False), (64, 20, 2000, True), (500, 3, 4000, False), (500, 3, 30000, False)])
+def test_ransac_equal_counts_are_decided_by_the_error_sum(lr, oracle, n, n_in, iters, elc):
+    """Noise-free inliers: every all-inlier sample reaches the same count, so the winner is picked by the fixed-point error sum
+    (then the hypothesis id) -- a handful of models at the top count (the per-model path of ransac_tie_kernel), hundreds of
+    them, and no consensus at all (thousands of models at a count of 1 or 2: its chunked path)."""
+    rng = np.random.default_rng(n + iters)
+    src = rng.uniform(-40, 40, (n, 3)).astype(np.float32)
+    ang = 0.4
+    R = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]])
+    tgt = (src.astype(np.float64) @ R.T + np.array([3.0, -2.0, 0.5])).astype(np.float32)
+    tgt[n_in:] = rng.uniform(-40, 40, (n - n_in, 3)).astype(np.float32)
+    perm = rng.permutation(n)
+    src, tgt = src[perm], tgt[perm]
+    T, info = lr.ransac.ransac_dev(src, tgt, iters, sample_size=3, use_elc=elc, seed=5)
+    Te, einfo = oracle.ransac(src, tgt, iters, sample_size=3, use_elc=elc, seed=5)
+    assert info == einfo and np.array_equal(T, Te)
+    assert info["best_count"] >= (n_in if n_in > 3 else 1)
+
+
 def test_refit_vs_oracle(lr, oracle):
     p = synth.make_pair(N=6000, rho=0.5, s=0.8, seed=17)
     i0, i1, i2, _ = oracle.find_2nn(p["feats0"], p["feats1"])
