@@ -37,7 +37,7 @@ def parse(argv=None):
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--pairs", type=int, default=128, help="distinct resident pairs per step per GPU")
-    ap.add_argument("--n", type=int, default=30000, help="points per cloud")
+    ap.add_argument("--n", "--points", dest="n", type=int, default=30000, help="points per cloud")
     ap.add_argument("--iters", type=int, default=50000)
     ap.add_argument("--mode", default="MNN")
     ap.add_argument("--batch", type=int, default=0, help="pairs per batched call (0: 32, or 8 for clouds above 60k points)")
@@ -129,16 +129,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # under a launcher (torch.distributed.run sets WORLD_SIZE) the process group and the per-step collectives run even with one
+    # rank, so that the RCCL branch is the same code at N = 1 as at N = 8
+    use_dist = "WORLD_SIZE" in os.environ
     dry = args.dry_run
     if dry:
         dev = torch.device("cpu")
-        if world > 1:
+        if use_dist:
             dist.init_process_group("gloo")
     else:
         assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
-        if world > 1:
+        if use_dist:
             dist.init_process_group("nccl", device_id=dev)
 
     B = args.batch if args.batch > 0 else (32 if args.n <= 60000 else 8)
@@ -162,7 +165,7 @@ def main():
         wss = [_ext.Workspace(args.n, args.n, 32, args.iters, max_pairs=B) for _ in range(nstreams)]
     outs = torch.zeros((args.pairs, res_bytes), dtype=torch.uint8, device=dev)
     rows = torch.zeros((args.pairs, shard.ROW), dtype=torch.float64, device=dev)
-    gathered = torch.zeros((world * args.pairs, shard.ROW), dtype=torch.float64, device=dev) if world > 1 else None
+    gathered = torch.zeros((world * args.pairs, shard.ROW), dtype=torch.float64, device=dev) if use_dist else None
     host_T = torch.zeros((args.pairs, 16), dtype=torch.float64)
     if not dry:
         host_T = host_T.pin_memory()
@@ -195,7 +198,7 @@ def main():
         # the step's product: the 4x4 transforms, on the host (128 bytes per pair, SURVEY 8d metric text)
         Tdev = outs[:, :128].view(torch.float64).view(args.pairs, 16)
         host_T.copy_(Tdev, non_blocking=not dry)
-        if world > 1:
+        if use_dist:
             # result rows = the 16 doubles of T (+ stats columns, zero here); one collective per step
             rows[:, 22:38] = Tdev
             dist.all_gather_into_tensor(gathered, rows)
@@ -203,7 +206,7 @@ def main():
     def sync_all():
         if not dry:
             torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
             if not dry:
                 torch.cuda.synchronize(dev)
@@ -220,7 +223,7 @@ def main():
         step()
     sync_all()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -240,7 +243,7 @@ def main():
         res = [_ext.PairResult.from_buffer_copy(outs[i].cpu().numpy().tobytes()) for i in range(args.pairs)]
         n_corr_mean = float(np.mean([r.n_corr for r in res])); n_valid_mean = float(np.mean([r.ransac.n_valid for r in res]))
         nn_fallback_rows = float(np.mean([r.n_nn_fixed for r in res]))
-    elif world > 1:
+    elif use_dist:
         g = gathered.view(world, args.pairs, shard.ROW)[:, 0, 22]
         assert [float(v) for v in g] == [float(np.frombuffer(bytes([r + 1] * 8), np.float64)[0]) for r in range(world)], "gather order"
 
@@ -309,7 +312,7 @@ def main():
         if cpu:
             line["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -39,3 +39,18 @@ def test_bench_line_small_workload():
 def test_bench_gpf_mode_and_h2d_variant():
     line = _bench(["--mode", "GPF", "--no-cpu-baseline", "--include-h2d"])
     assert line["recall_5deg_0.6m"] == 1.0 and "GPF" in line["metric"] and "pinned host memory" in line["data"] and line["cpu_baseline"] is None
+
+
+def test_bench_under_the_launcher_runs_the_rccl_branch_with_one_rank():
+    """`python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1`: the nccl process group, the per-step all_gather
+    of the result rows and the max-over-ranks all_reduce execute on this GPU exactly as they do at N = 8."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29631", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--points", "4000", "--iters", "3000", "--pairs", "12",
+                        "--batch", "4", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["recall_2deg_0.6m"] == 1.0
