@@ -40,8 +40,13 @@ def parse(argv=None):
     ap.add_argument("--n", "--points", dest="n", type=int, default=30000, help="points per cloud")
     ap.add_argument("--iters", type=int, default=50000)
     ap.add_argument("--mode", default="MNN")
+    ap.add_argument("--codebase", default="open3D", choices=["open3D", "GC"],
+                    help="open3D (default): 3-point samples, edge-length check, EVERY one of --iters hypotheses scored, refit over the NN pairs "
+                         "(the headline workload); GC: the reference CLI's defaults (test.py:301-313: PROSAC, ELC, MSAC, confidence 0.999 "
+                         "early exit, local optimisation + final least squares) -- an additional, lighter workload, never the headline")
     ap.add_argument("--batch", type=int, default=0, help="pairs per batched call (0: 32, or 8 for clouds above 60k points)")
-    ap.add_argument("--streams", type=int, default=2, help="batched calls in flight per GPU")
+    ap.add_argument("--streams", type=int, default=0, help="batched calls in flight per GPU (0: 2, or 4 with --codebase GC whose one-block-per-pair "
+                                                            "local optimisation leaves most CUs to the other calls)")
     ap.add_argument("--include-h2d", action="store_true", help="copy each pair from pinned host memory inside the timed region (PCIe-inclusive rate; not the headline value)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=8)
@@ -146,15 +151,16 @@ def main():
 
     B = args.batch if args.batch > 0 else (32 if args.n <= 60000 else 8)
     B = max(1, min(B, args.pairs, 64))
-    nstreams = max(1, args.streams)
+    nstreams = args.streams if args.streams > 0 else (4 if args.codebase == "GC" else 2)
     res_bytes = 496
     pairs, T_gt = [], []
     if not dry:
         from lidarregistration_amd import FR, _ext
 
         class A:
-            mode = args.mode; codebase = "open3D"; iters = args.iters; ransac_n = 3; GPF_factor = 2.0; GPF_grid_wid = 10
+            mode = args.mode; codebase = args.codebase; iters = args.iters; ransac_n = 3; GPF_factor = 2.0; GPF_grid_wid = 10
             o3d_conf = 1.0          # every one of the --iters hypotheses is evaluated (no confidence-based early exit)
+            # (--codebase GC: FR.pair_params takes the reference CLI's defaults for everything else)
         params = FR.pair_params(A)
         res_bytes = ctypes.sizeof(_ext.PairResult)
         # resident inputs: `pairs` DISTINCT synthetic pairs per GPU (~8.4 MB each at 30k points), generated on the device
@@ -289,7 +295,7 @@ def main():
                      "V": round(n_valid_mean, 1), "M": round(n_corr_mean, 1)}
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not dry:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not dry and args.codebase == "open3D":
         cpu = cpu_baseline(args, seed0=51)
 
     if rank == 0:
@@ -299,7 +305,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic" + (" (inputs copied from pinned host memory inside the timed region)" if args.include_h2d else ""),
             "config": {"workload": f"{'configs[1]' if args.n == 30000 else 'configs[4]-like dense'}: {args.n}-pt x32-d synthetic FCGF pair, --mode {args.mode} --iters {args.iters}, "
-                                   f"3-pt sampling + ELC + LS refit; {args.pairs} distinct resident pairs per GPU, T copied to the host inside the timed region",
+                                   f"{'3-pt sampling + ELC + LS refit' if args.codebase == 'open3D' else 'codebase GC defaults (PROSAC, ELC, MSAC, conf 0.999, LO + final LS)'}; {args.pairs} distinct resident pairs per GPU, T copied to the host inside the timed region",
                        "pairs_per_step_per_gpu": args.pairs, "pairs_per_batched_call": B, "batched_calls_in_flight_per_gpu": nstreams,
                        "parallelism": f"pair-sharded x{world}"},
             "recall_2deg_0.6m": None if recall is None else round(recall, 4), "recall_5deg_0.6m": None if recall5 is None else round(recall5, 4),

@@ -37,6 +37,7 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32
 #include "lr_kabsch.h"
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // unweighted Kabsch on NS (3 or 4) sample points held in registers
 template <int NS>
@@ -479,10 +480,12 @@ ransac_final_kernel(const uint32_t *__restrict__ score_cnt, const unsigned long 
 #define LO_POLISH 10
 #define LO_THREADS 1024
 
+#define LO_MAXIT 32              // records (two correspondences) per thread and pass of the list builder
 struct lo_shared {
     double T[LO_TRIALS][12];         // candidate models of the round (fp64)
-    float Rt[LO_TRIALS][12];         // ... rounded for the scoring arithmetic
+    __attribute__((aligned(16))) float Rt[LO_TRIALS][12];         // ... rounded for the scoring arithmetic
     int pos[LO_TRIALS][LO_SAMPLE];   // sampled positions in the inlier list
+    float pts[LO_TRIALS][LO_SAMPLE][6];     // the sampled correspondences (gathered by 420 threads, summed by one per trial)
     unsigned cnt[LO_TRIALS];
     unsigned long long ssq[LO_TRIALS];
     double red[4][LO_THREADS];       // block reduction of the fp64 moments, four components at a time
@@ -490,6 +493,7 @@ struct lo_shared {
     double curT[12];                 // model under optimisation
     unsigned long long curq;
     unsigned curc;
+    int wcnt[LO_MAXIT][LO_THREADS / 64];    // inliers per (step, wave) of a list-builder pass, then their offsets in the list
     int wsum[16];
     int nI, flag;
 };
@@ -503,33 +507,72 @@ __device__ __forceinline__ float lo_d2(const float *Rt, float px, float py, floa
     return __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
 }
 
-// inliers of sh.curT over the m correspondences, in index order -> list[0 .. sh.nI)
+// inliers of sh.curT over the m correspondences, in index order -> list[0 .. sh.nI).
+// A thread tests the two correspondences of one 64-byte record per step (three 16-byte loads, the packed arithmetic of the
+// scoring kernel: same fma order per component).  A pass covers LO_MAXIT * LO_THREADS records: every thread runs its LO_MAXIT steps
+// back to back (independent loads, no barrier in between), keeping the outcomes as a bit mask; the per-(step, wave) counts go to
+// LDS, one block-wide exclusive scan turns them into list offsets, and the threads write their inliers.  Four barriers per pass.
 __device__ void lo_build_list(lo_shared &sh, const float *__restrict__ corr8, int m, float thr2, int32_t *__restrict__ list)
 {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float Rt[12];
-#pragma unroll
-    for (int k = 0; k < 12; ++k) Rt[k] = (float)sh.curT[k];
-    if (tid == 0) sh.nI = 0;
-    __syncthreads();
-    for (int base = 0; base < m; base += LO_THREADS) {
-        const int i = base + tid;
-        bool in = false;
-        if (i < m) {
-            const float d2 = lo_d2(Rt, corr8[lr_corr_at(i, 0)], corr8[lr_corr_at(i, 1)], corr8[lr_corr_at(i, 2)], corr8[lr_corr_at(i, 3)],
-                                   corr8[lr_corr_at(i, 4)], corr8[lr_corr_at(i, 5)]);
-            in = d2 < thr2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const f32x2 R00 = { (float)sh.curT[0], (float)sh.curT[0] }, R01 = { (float)sh.curT[1], (float)sh.curT[1] }, R02 = { (float)sh.curT[2], (float)sh.curT[2] },
+                TX = { (float)sh.curT[3], (float)sh.curT[3] };
+    const f32x2 R10 = { (float)sh.curT[4], (float)sh.curT[4] }, R11 = { (float)sh.curT[5], (float)sh.curT[5] }, R12 = { (float)sh.curT[6], (float)sh.curT[6] },
+                TY = { (float)sh.curT[7], (float)sh.curT[7] };
+    const f32x2 R20 = { (float)sh.curT[8], (float)sh.curT[8] }, R21 = { (float)sh.curT[9], (float)sh.curT[9] }, R22 = { (float)sh.curT[10], (float)sh.curT[10] },
+                TZ = { (float)sh.curT[11], (float)sh.curT[11] };
+    const int nrec = (m + 1) >> 1;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int total = 0;
+    for (int sbase = 0; sbase < nrec; sbase += LO_MAXIT * LO_THREADS) {
+        const int nit = min(LO_MAXIT, (nrec - sbase + LO_THREADS - 1) / LO_THREADS);
+        unsigned long long bits = 0ull;          // bit 2 it + b: correspondence b of the record of step it
+#pragma unroll 2
+        for (int it = 0; it < nit; ++it) {
+            const int r = sbase + it * LO_THREADS + tid;
+            const f32x4 *rec = reinterpret_cast<const f32x4 *>(corr8) + (size_t)min(r, nrec - 1) * 4;
+            const f32x4 A = rec[0], B = rec[1], C = rec[2];
+            const f32x2 px = { A.x, A.y }, py = { A.z, A.w }, pz = { B.x, B.y }, qx = { B.z, B.w }, qy = { C.x, C.y }, qz = { C.z, C.w };
+            const f32x2 x = __builtin_elementwise_fma(R00, px, __builtin_elementwise_fma(R01, py, __builtin_elementwise_fma(R02, pz, TX)));
+            const f32x2 y = __builtin_elementwise_fma(R10, px, __builtin_elementwise_fma(R11, py, __builtin_elementwise_fma(R12, pz, TY)));
+            const f32x2 z = __builtin_elementwise_fma(R20, px, __builtin_elementwise_fma(R21, py, __builtin_elementwise_fma(R22, pz, TZ)));
+            const f32x2 dx = x - qx, dy = y - qy, dz = z - qz;
+            const f32x2 d2 = __builtin_elementwise_fma(dx, dx, __builtin_elementwise_fma(dy, dy, dz * dz));
+            const bool in0 = r < nrec && d2.x < thr2, in1 = r < nrec && 2 * r + 1 < m && d2.y < thr2;
+            bits |= (unsigned long long)((in0 ? 1u : 0u) | (in1 ? 2u : 0u)) << (2 * it);
         }
-        const unsigned long long bal = __ballot(in);
-        if (lane == 0) sh.wsum[wave] = __popcll(bal);
+        for (int it = 0; it < nit; ++it) {
+            const unsigned long long b0 = __ballot((bits >> (2 * it)) & 1ull), b1 = __ballot((bits >> (2 * it + 1)) & 1ull);
+            if (lane == 0) sh.wcnt[it][wave] = __popcll(b0) + __popcll(b1);
+        }
         __syncthreads();
-        int off = sh.nI;
-        for (int w = 0; w < wave; ++w) off += sh.wsum[w];
-        if (in) list[off + __popcll(bal & ((1ull << lane) - 1ull))] = i;
+        // exclusive scan over the entries e = step * 16 + wave (the order of the correspondence indices), one entry per thread
+        int *flat = &sh.wcnt[0][0];
+        const int ne = nit * (LO_THREADS / 64);
+        const int v = tid < ne ? flat[tid] : 0;
+        int inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+        if (lane == 63) sh.wsum[wave] = inc;
         __syncthreads();
-        if (tid == 0) { int t = 0; for (int w = 0; w < LO_THREADS / 64; ++w) t += sh.wsum[w]; sh.nI += t; }
+        int before = 0, all = 0;
+#pragma unroll
+        for (int w = 0; w < LO_THREADS / 64; ++w) { const int x = sh.wsum[w]; all += x; if (w < wave) before += x; }
+        if (tid < ne) flat[tid] = total + before + inc - v;
         __syncthreads();
+        for (int it = 0; it < nit; ++it) {
+            const bool in0 = (bits >> (2 * it)) & 1ull, in1 = (bits >> (2 * it + 1)) & 1ull;
+            const unsigned long long b0 = __ballot(in0), b1 = __ballot(in1);
+            const int pos = sh.wcnt[it][wave] + (int)__popcll(b0 & lt) + (int)__popcll(b1 & lt);
+            const int i = 2 * (sbase + it * LO_THREADS + tid);
+            if (in0) list[pos] = i;
+            if (in1) list[pos + (in0 ? 1 : 0)] = i + 1;
+        }
+        total += all;
+        __syncthreads();          // (the next pass rewrites wcnt / wsum)
     }
+    if (tid == 0) sh.nI = total;
+    __syncthreads();
 }
 
 // least-squares fit over the listed correspondences -> sh.T[0] / sh.Rt[0]; false when fewer than 3 points
@@ -551,12 +594,14 @@ __device__ bool lo_fit_all(lo_shared &sh, const float *__restrict__ corr8, const
 #pragma unroll
             for (int b = 0; b < 3; ++b) v[7 + 3 * a + b] += p[a] * q[b];
     }
+    // halving tree red[t] += red[t + s], s = 512 ... 1 (the order oracle.c reproduces): through LDS while the partners sit in
+    // different waves, by shuffles inside wave 0 for s <= 32 (the same additions, no barriers)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < 4; ++k) sh.red[k][tid] = v[4 * g + k];
-        for (int sft = LO_THREADS / 2; sft >= 1; sft >>= 1) {
+        for (int sft = LO_THREADS / 2; sft >= 64; sft >>= 1) {
             __syncthreads();
             if (tid < sft) {
 #pragma unroll
@@ -564,7 +609,15 @@ __device__ bool lo_fit_all(lo_shared &sh, const float *__restrict__ corr8, const
             }
         }
         __syncthreads();
-        if (tid < 4) sh.mom[4 * g + tid] = sh.red[tid][0];
+        if (tid < 64) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                double x = sh.red[k][tid];
+#pragma unroll
+                for (int sft = 32; sft >= 1; sft >>= 1) x = x + __shfl_down(x, sft);
+                if (tid == 0) sh.mom[4 * g + k] = x;
+            }
+        }
     }
     __syncthreads();
     const bool ok = sh.mom[0] >= 3.0;
@@ -581,8 +634,89 @@ __device__ bool lo_fit_all(lo_shared &sh, const float *__restrict__ corr8, const
     return ok;
 }
 
-// score sh.Rt[0 .. ntrial) over all m correspondences -> sh.cnt / sh.ssq (integer atomics in LDS)
-__device__ void lo_score(lo_shared &sh, const float *__restrict__ corr8, int m, float thr2, int ntrial)
+// score sh.Rt[0 .. ntrial) over all m correspondences -> sh.cnt / sh.ssq (integer atomics in LDS): three forms.
+// One model (the polish, or a round with at most LO_SAMPLE inliers): one thread per correspondence, four of them per step (24
+// independent loads in flight), 32-bit sums per thread (the caller guarantees that a thread's share of the correspondences
+// cannot overflow them), one wave reduction and one LDS atomic per wave at the end.
+__device__ void lo_score_one(lo_shared &sh, const float *__restrict__ corr8, int m, float thr2)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid < LO_TRIALS) { sh.cnt[tid] = 0u; sh.ssq[tid] = 0ull; }
+    __syncthreads();
+    float Rt[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) Rt[k] = sh.Rt[0][k];
+    uint32_t c = 0u, q = 0u;
+    for (int i0 = tid; i0 < m; i0 += 4 * LO_THREADS) {
+        float P[4][6];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = min(i0 + u * LO_THREADS, m - 1);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) P[u][k] = corr8[lr_corr_at(i, k)];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float d2 = lo_d2(Rt, P[u][0], P[u][1], P[u][2], P[u][3], P[u][4], P[u][5]);
+            const bool in = i0 + u * LO_THREADS < m && d2 < thr2;
+            c += in ? 1u : 0u;
+            q += in ? (uint32_t)(d2 * 1048576.0f) : 0u;
+        }
+    }
+    unsigned long long qq = q;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { c += (uint32_t)__shfl_xor((int)c, o); qq += __shfl_xor(qq, o); }
+    if (lane == 0 && c) { atomicAdd(&sh.cnt[0], c); atomicAdd(&sh.ssq[0], qq); }
+    __syncthreads();
+}
+
+// all LO_TRIALS models of a round: the arithmetic of ransac_score_kernel (one LANE per model, two correspondences per packed
+// step), with three correspondence streams side by side in a wave -- lanes [20 s, 20 s + 20) apply the 20 models to the records
+// 3 w + s, 3 w + s + 48, ... of wave w -- so 60 of the 64 lanes work and a wave's three 64-byte records come in as three
+// broadcast global_load_dwordx4 per lane.  12 coefficient + 12 record registers, sums per lane, 48 LDS atomics per model at the end.
+__device__ void lo_score_lanes(lo_shared &sh, const float *__restrict__ corr8, int m, float thr2)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid < LO_TRIALS) { sh.cnt[tid] = 0u; sh.ssq[tid] = 0ull; }
+    __syncthreads();
+    constexpr int NS = 64 / LO_TRIALS;                 // streams per wave (3)
+    constexpr int STRIDE = NS * (LO_THREADS / 64);     // records between two steps of a stream (48)
+    const int t = lane % LO_TRIALS, st = lane / LO_TRIALS;
+    const bool act = st < NS;
+    const f32x4 *rp = reinterpret_cast<const f32x4 *>(sh.Rt[t]);
+    const f32x4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
+    const f32x2 R00 = { r0.x, r0.x }, R01 = { r0.y, r0.y }, R02 = { r0.z, r0.z }, TX = { r0.w, r0.w };
+    const f32x2 R10 = { r1.x, r1.x }, R11 = { r1.y, r1.y }, R12 = { r1.z, r1.z }, TY = { r1.w, r1.w };
+    const f32x2 R20 = { r2.x, r2.x }, R21 = { r2.y, r2.y }, R22 = { r2.z, r2.z }, TZ = { r2.w, r2.w };
+    const f32x2 SC = { 1048576.0f, 1048576.0f };
+    const int nrec = (m + 1) >> 1;
+    uint32_t c = 0u;
+    unsigned long long q = 0ull;
+    const int first = wave * NS + (act ? st : 0);
+    const int steps = (nrec - wave * NS + STRIDE - 1) / STRIDE;        // (wave-uniform: the steps of the wave's first stream)
+#pragma unroll 2
+    for (int k = 0; k < steps; ++k) {
+        const int r = first + k * STRIDE;
+        const bool live = act && r < nrec;
+        const f32x4 *rec = reinterpret_cast<const f32x4 *>(corr8) + (size_t)(live ? r : 0) * 4;
+        const f32x4 A = rec[0], B = rec[1], C = rec[2];
+        const f32x2 px = { A.x, A.y }, py = { A.z, A.w }, pz = { B.x, B.y }, qx = { B.z, B.w }, qy = { C.x, C.y }, qz = { C.z, C.w };
+        const f32x2 x = __builtin_elementwise_fma(R00, px, __builtin_elementwise_fma(R01, py, __builtin_elementwise_fma(R02, pz, TX)));
+        const f32x2 y = __builtin_elementwise_fma(R10, px, __builtin_elementwise_fma(R11, py, __builtin_elementwise_fma(R12, pz, TY)));
+        const f32x2 z = __builtin_elementwise_fma(R20, px, __builtin_elementwise_fma(R21, py, __builtin_elementwise_fma(R22, pz, TZ)));
+        const f32x2 dx = x - qx, dy = y - qy, dz = z - qz;
+        const f32x2 d2 = __builtin_elementwise_fma(dx, dx, __builtin_elementwise_fma(dy, dy, dz * dz));
+        const f32x2 fx = d2 * SC;
+        const bool in0 = live && d2.x < thr2, in1 = live && 2 * r + 1 < m && d2.y < thr2;
+        c += (in0 ? 1u : 0u) + (in1 ? 1u : 0u);
+        q += (unsigned long long)((in0 ? (uint32_t)fx.x : 0u)) + (unsigned long long)((in1 ? (uint32_t)fx.y : 0u));
+    }
+    if (act && c) { atomicAdd(&sh.cnt[t], c); atomicAdd(&sh.ssq[t], q); }
+    __syncthreads();
+}
+
+// any number of models and any threshold (64-bit sums): LO_THREADS / ntrial threads per model, each striding over the correspondences
+__device__ void lo_score_wide(lo_shared &sh, const float *__restrict__ corr8, int m, float thr2, int ntrial)
 {
     const int tid = threadIdx.x;
     if (tid < LO_TRIALS) { sh.cnt[tid] = 0u; sh.ssq[tid] = 0ull; }
@@ -602,6 +736,15 @@ __device__ void lo_score(lo_shared &sh, const float *__restrict__ corr8, int m, 
         if (c) { atomicAdd(&sh.cnt[t], c); atomicAdd(&sh.ssq[t], q); }
     }
     __syncthreads();
+}
+
+__device__ __forceinline__ void lo_score(lo_shared &sh, const float *__restrict__ corr8, int m, float thr2, int ntrial)
+{
+    // 32-bit per-thread error sums hold when (correspondences per thread) * thr2 * 2^20 < 2^32
+    if (ntrial == LO_TRIALS) { lo_score_lanes(sh, corr8, m, thr2); return; }
+    const bool narrow = ((double)(m / LO_THREADS + 1)) * (double)thr2 * 1048576.0 < 4.0e9;
+    if (!narrow) lo_score_wide(sh, corr8, m, thr2, ntrial);
+    else lo_score_one(sh, corr8, m, thr2);
 }
 
 __global__ void __launch_bounds__(LO_THREADS)
@@ -651,18 +794,31 @@ ransac_lo_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__re
                         for (int j = 0; j < got; ++j) dup |= pos[j] == c;
                         if (!dup) pos[got++] = c;
                     }
+                }
+                __syncthreads();
+                // the LO_TRIALS * LO_SAMPLE sampled correspondences are fetched by as many threads at once (two dependent loads
+                // each instead of 42 in a row per trial) ...
+                if (tid < LO_TRIALS * LO_SAMPLE) {
+                    const int t = tid / LO_SAMPLE, k = tid % LO_SAMPLE;
+                    const int i = list[sh.pos[t][k]];
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) sh.pts[t][k][a] = corr8[lr_corr_at(i, a)];
+                }
+                __syncthreads();
+                // ... and summed by one thread per trial in the order of kabsch_points_kernel / orc_kabsch_points
+                if (tid < LO_TRIALS) {
                     double cp[3] = { 0, 0, 0 }, cq[3] = { 0, 0, 0 }, W = 0.0;
-                    for (int k = 0; k < LO_SAMPLE; ++k) {
-                        const int i = list[pos[k]];
+#pragma unroll 1
+                    for (int k = 0; k < LO_SAMPLE; ++k) {      // (rolled: unrolled, the 126 values of both loops are kept live and spill)
                         W = W + 1.0;
-                        for (int a = 0; a < 3; ++a) { cp[a] = cp[a] + 1.0 * (double)corr8[lr_corr_at(i, a)]; cq[a] = cq[a] + 1.0 * (double)corr8[lr_corr_at(i, 3 + a)]; }
+                        for (int a = 0; a < 3; ++a) { cp[a] = cp[a] + 1.0 * (double)sh.pts[tid][k][a]; cq[a] = cq[a] + 1.0 * (double)sh.pts[tid][k][3 + a]; }
                     }
                     for (int a = 0; a < 3; ++a) { cp[a] = cp[a] / W; cq[a] = cq[a] / W; }
                     double H[3][3] = { { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 } };
+#pragma unroll 1
                     for (int k = 0; k < LO_SAMPLE; ++k) {
-                        const int i = list[pos[k]];
                         double pc[3], qc[3];
-                        for (int a = 0; a < 3; ++a) { pc[a] = (double)corr8[lr_corr_at(i, a)] - cp[a]; qc[a] = (double)corr8[lr_corr_at(i, 3 + a)] - cq[a]; }
+                        for (int a = 0; a < 3; ++a) { pc[a] = (double)sh.pts[tid][k][a] - cp[a]; qc[a] = (double)sh.pts[tid][k][3 + a] - cq[a]; }
                         for (int a = 0; a < 3; ++a)
                             for (int b = 0; b < 3; ++b) H[a][b] = H[a][b] + (1.0 * pc[a]) * qc[b];
                     }
