@@ -928,8 +928,11 @@ int lr_ransac_run(lr_workspace *ws, const float *corr8, int m_max, const int32_t
     sub &= ~1;                  // the scoring loop takes correspondences two at a time
     if (sub < 2) sub = 2;       // 2 * thr2 * 2^20 < 2^32 for every admissible thr2 (< 2048)
     const bool use_exit = p->confidence > 0.0f && p->confidence < 1.0f;
-    // default batch: 8192 ids, or an eighth of a long run (the launches of the batches after the exit still cost a few us each)
-    const int B = use_exit ? (p->batch > 0 ? p->batch : (p->iters > 65536 ? ((p->iters / 8 + 8191) / 8192) * 8192 : 8192)) : (p->iters > 0 ? p->iters : 1);
+    // batch lengths: the given one, constant; by default 8192, 16384, 32768, ... -- doubling, so that the exit test is fine-grained
+    // where an easy pair stops (the reference tests after every iteration) while a long run still takes few batches (the launches
+    // of the batches after the exit cost a few us each): 3 batches for 50k ids, 6 for the CLI's default 500k
+    const bool geometric = use_exit && p->batch <= 0;
+    long long B = use_exit ? (p->batch > 0 ? p->batch : 8192) : (p->iters > 0 ? p->iters : 1);
     LR_REQUIRE(p->use_elc >= 0 && p->use_elc <= 2, LR_EINVAL, "lr_ransac: use_elc must be 0 (no pre-verification), 1 (edge-length check) or 2 (SPRT)");
     LR_REQUIRE(p->sampler >= 0 && p->sampler <= 2, LR_EINVAL, "lr_ransac: sampler must be 0 (uniform), 1 (PROSAC) or 2 (uniform, unique indices)");
     LR_REQUIRE(p->local_opt >= 0 && p->local_opt <= 2, LR_EINVAL, "lr_ransac: local_opt must be 0, 1 or 2");
@@ -942,8 +945,9 @@ int lr_ransac_run(lr_workspace *ws, const float *corr8, int m_max, const int32_t
         hipLaunchKernelGGL(prosac_growth_kernel, dim3(1, 1, ws->zP), dim3(1024), 0, st, m_max, m_dev, p->sample_size, TN, ws->prosac_G, ws->z);
         G = ws->prosac_G;
     }
-    for (int h0 = 0; h0 < (p->iters > 0 ? p->iters : 1); h0 += B) {
-        const int h1 = h0 + B < p->iters ? h0 + B : p->iters;
+    for (long long h0l = 0; h0l < (p->iters > 0 ? p->iters : 1); h0l += B, B = geometric ? 2 * B : B) {
+        const int h0 = (int)h0l;
+        const int h1 = h0l + B < p->iters ? (int)(h0l + B) : p->iters;
         const int gb = lr_cdiv(h1 - h0 > 0 ? h1 - h0 : 1, 256);
         if (p->sample_size == 3)
             hipLaunchKernelGGL(ransac_gen_kernel<3>, dim3(gb, 1, ws->zP), dim3(256), 0, st, corr8, m_max, m_dev, *p, h0, h1, ws->models, ws->models64,

@@ -19,7 +19,7 @@ PRECHECK = {"NONE": 0, "ELC": 1, "SPRT": 2}      # --fast_rejection (test.py:306
 
 def ransac_params(iters, sample_size=3, use_elc=True, thr=0.6, seed=DEFAULT_SEED, confidence=1.0, batch=0, sampler=0, prosac_growth=0,
                   scoring=0, local_opt=0):
-    """confidence < 1 enables the early exit between batches of `batch` hypothesis ids (0 -> 8192, an eighth of the run when iters > 65536); sampler 1 = PROSAC
+    """confidence < 1 enables the early exit between batches of `batch` hypothesis ids (0 -> 8192, 16384, 32768, ...: doubling); sampler 1 = PROSAC
     (correspondences best quality first, growth parameter T_N = prosac_growth, 0 -> 100000), 2 = uniform with unique indices; scoring 1 = MSAC;
     local_opt 1 = GC-RANSAC's local optimisation + final iterated least squares, 2 = the latter only."""
     return _ext.RansacParams(int(sample_size), int(use_elc), np.float32(float(thr) * float(thr)), int(iters), int(seed),
