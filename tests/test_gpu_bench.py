@@ -36,6 +36,13 @@ def test_bench_line_small_workload():
     assert line["speedup_vs_cpu_baseline"] > 1
 
 
+def test_bench_gc_codebase_workload():
+    """--codebase GC: the reference CLI's defaults (PROSAC, ELC, MSAC, confidence exit, local optimisation + final least squares)."""
+    line = _bench(["--codebase", "GC", "--no-cpu-baseline"])
+    assert line["recall_2deg_0.6m"] == 1.0 and "codebase GC defaults" in line["config"]["workload"] and line["cpu_baseline"] is None
+    assert line["config"]["batched_calls_in_flight_per_gpu"] == 4
+
+
 def test_bench_gpf_mode_and_h2d_variant():
     line = _bench(["--mode", "GPF", "--no-cpu-baseline", "--include-h2d"])
     assert line["recall_5deg_0.6m"] == 1.0 and "GPF" in line["metric"] and "pinned host memory" in line["data"] and line["cpu_baseline"] is None

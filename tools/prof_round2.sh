@@ -10,6 +10,7 @@ python bench.py > $O/bench_line.json 2> $O/bench_stderr.log
 tail -1 $O/bench_line.json | cut -c1-160
 python bench.py --n 100000 --pairs 32 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_line_n100k.json 2>> $O/bench_stderr.log
 python bench.py --mode GPF --no-cpu-baseline > $O/bench_line_gpf.json 2>> $O/bench_stderr.log
+python bench.py --codebase GC --no-cpu-baseline > $O/bench_line_gc.json 2>> $O/bench_stderr.log
 cd /tmp
 prof() {   # tag, then bench args
   tag=$1; shift
@@ -21,6 +22,7 @@ prof bench_streams1 --streams 1 --pairs 64 --steps 3 --warmup 1
 prof bench_default --steps 3 --warmup 1
 prof bench_gpf_streams1 --mode GPF --streams 1 --pairs 64 --steps 3 --warmup 1
 prof bench_n100k_streams1 --n 100000 --streams 1 --pairs 16 --batch 8 --steps 3 --warmup 1
+prof bench_gc_streams1 --codebase GC --streams 1 --pairs 64 --steps 3 --warmup 1
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/p_$c
   rocprofv3 --pmc $c --output-format csv -d /tmp/p_$c -o c -- python3 $R/bench.py --steps 2 --warmup 1 --streams 1 --pairs 32 --no-cpu-baseline > /tmp/p_$c.log 2>&1
