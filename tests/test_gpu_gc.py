@@ -46,6 +46,19 @@ def test_local_optimisation_matches_oracle(lr, oracle, n, iters, seed, sampler, 
         assert oracle.rotation_error_deg(T, T_gt) < 0.5
 
 
+@pytest.mark.parametrize("n", [7, 23, 47, 48, 49, 95, 96, 97, 191, 1023, 1025, 2047, 2049, 4099, 65537])
+def test_local_optimisation_size_sweep(lr, oracle, n):
+    """Sizes around the boundaries of the LO kernel's work split: 2 correspondences per record (odd counts), 48 records per step of
+    the 16 waves x 3 streams of the round scoring, 1024 records per step of the list builder, more than one pass of it (> 65536),
+    rounds with at most 21 inliers (one fit over all of them)."""
+    for k, (inl, noise, scoring) in enumerate([(0.5, 0.05, 1), (0.2, 0.15, 0), (0.9, 0.3, 1)]):
+        src, tgt, _ = _planted(n=n, inlier=inl, seed=1000 + n + k, noise=noise)
+        kw = dict(sample_size=3, seed=n + k, sampler=2, scoring=scoring, local_opt=1, confidence=1.0, batch=0)
+        T, info = lr.ransac.ransac_dev(src, tgt, 600, **kw)
+        Te, einfo = oracle.ransac(src, tgt, 600, **kw)
+        assert info == einfo and np.array_equal(T, Te), (n, k, info, einfo)
+
+
 def test_local_optimisation_improves_on_the_minimal_sample_model(lr, oracle):
     src, tgt, T_gt = _planted(n=5000, inlier=0.35, seed=11)
     T0, i0 = lr.ransac.ransac_dev(src, tgt, 3000, sampler=2, scoring=1, local_opt=0)
