@@ -484,8 +484,7 @@ ransac_final_kernel(const uint32_t *__restrict__ score_cnt, const unsigned long 
 struct lo_shared {
     double T[LO_TRIALS][12];         // candidate models of the round (fp64)
     __attribute__((aligned(16))) float Rt[LO_TRIALS][12];         // ... rounded for the scoring arithmetic
-    int pos[LO_TRIALS][LO_SAMPLE];   // sampled positions in the inlier list
-    float pts[LO_TRIALS][LO_SAMPLE][6];     // the sampled correspondences (gathered by 420 threads, summed by one per trial)
+    float pts[LO_TRIALS][LO_SAMPLE][6];     // the sampled correspondences (fetched by one lane each, summed by one thread per trial)
     unsigned cnt[LO_TRIALS];
     unsigned long long ssq[LO_TRIALS];
     double red[4][LO_THREADS];       // block reduction of the fp64 moments, four components at a time
@@ -772,37 +771,35 @@ ransac_lo_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__re
             if (nI <= p.sample_size) break;
             const int ntrial = nI > LO_SAMPLE ? LO_TRIALS : 1;
             if (nI > LO_SAMPLE) {
-                // one thread per trial: LO_SAMPLE distinct positions (word stream keyed by seed, call, round, trial), then the
-                // least-squares fit on those points (the arithmetic of kabsch_points_kernel / orc_kabsch_points)
-                if (tid < LO_TRIALS) {
-                    int *pos = sh.pos[tid];
-                    int got = 0;
-                    const uint64_t key = p.seed ^ 0x4c4f43414c4f5054ull;
-                    for (int blk = 0; blk < 32 && got < LO_SAMPLE; ++blk) {
-                        const uint64_t ctr = ((uint64_t)call << 40) | ((uint64_t)round << 32) | ((uint64_t)tid << 8) | (uint64_t)blk;
-                        uint32_t w[4] = { (uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u };
-                        philox4x32_10(w, (uint32_t)key, (uint32_t)(key >> 32));
-                        for (int k = 0; k < 4 && got < LO_SAMPLE; ++k) {
-                            const int c = (int)__umulhi(w[k], (uint32_t)nI);
-                            bool dup = false;
-                            for (int j = 0; j < got; ++j) dup |= pos[j] == c;
-                            if (!dup) pos[got++] = c;
+                // LO_SAMPLE distinct positions per trial (word stream keyed by seed, call, round, trial; a word that repeats a position is
+                // skipped): 32 lanes per trial, lane j keeps the j-th accepted position, so "already drawn?" is one ballot over the
+                // trial's half of the wave instead of a loop over LDS.  Lane j then fetches its correspondence (two dependent loads,
+                // all LO_TRIALS * LO_SAMPLE of them in flight at once).
+                {
+                    const int t = tid >> 5, j = tid & 31, half = (tid >> 5) & 1;
+                    if (t < LO_TRIALS) {
+                        int mine = -1, got = 0;
+                        const uint64_t key = p.seed ^ 0x4c4f43414c4f5054ull;
+                        for (int blk = 0; blk < 32 && got < LO_SAMPLE; ++blk) {
+                            const uint64_t ctr = ((uint64_t)call << 40) | ((uint64_t)round << 32) | ((uint64_t)t << 8) | (uint64_t)blk;
+                            uint32_t w[4] = { (uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u };
+                            philox4x32_10(w, (uint32_t)key, (uint32_t)(key >> 32));
+                            for (int k = 0; k < 4 && got < LO_SAMPLE; ++k) {
+                                const int c = (int)__umulhi(w[k], (uint32_t)nI);
+                                const bool dup = (uint32_t)(__ballot(mine == c) >> (32 * half)) != 0u;
+                                if (!dup) { if (j == got) mine = c; ++got; }
+                            }
+                        }
+                        for (int c = 0; got < LO_SAMPLE; ++c) {
+                            const bool dup = (uint32_t)(__ballot(mine == c) >> (32 * half)) != 0u;
+                            if (!dup) { if (j == got) mine = c; ++got; }
+                        }
+                        if (j < LO_SAMPLE) {
+                            const int i = list[mine];
+#pragma unroll
+                            for (int a = 0; a < 6; ++a) sh.pts[t][j][a] = corr8[lr_corr_at(i, a)];
                         }
                     }
-                    for (int c = 0; got < LO_SAMPLE; ++c) {
-                        bool dup = false;
-                        for (int j = 0; j < got; ++j) dup |= pos[j] == c;
-                        if (!dup) pos[got++] = c;
-                    }
-                }
-                __syncthreads();
-                // the LO_TRIALS * LO_SAMPLE sampled correspondences are fetched by as many threads at once (two dependent loads
-                // each instead of 42 in a row per trial) ...
-                if (tid < LO_TRIALS * LO_SAMPLE) {
-                    const int t = tid / LO_SAMPLE, k = tid % LO_SAMPLE;
-                    const int i = list[sh.pos[t][k]];
-#pragma unroll
-                    for (int a = 0; a < 6; ++a) sh.pts[t][k][a] = corr8[lr_corr_at(i, a)];
                 }
                 __syncthreads();
                 // ... and summed by one thread per trial in the order of kabsch_points_kernel / orc_kabsch_points
