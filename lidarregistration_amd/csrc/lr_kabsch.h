@@ -4,6 +4,32 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <string.h>
+
+// ------------------------------------------------------------------ logarithm for the decisions (fp64, + - * / only)
+// The confidence exit and the SPRT design compare against values made of logarithms; libm's and ocml's log differ in the last
+// place, which can flip such a comparison on one side only (found by tools/soak_gc.py).  Same text as oracle.c (det_log):
+// x = m 2^e with m in [sqrt(1/2), sqrt(2)), log x = e ln 2 + 2 atanh((m - 1) / (m + 1)), the odd series up to t^25.
+__host__ __device__ __forceinline__ double lr_det_log(double x)
+{
+    if (!(x > 0.0)) return x == 0.0 ? -HUGE_VAL : NAN;
+    if (x > 1.7976931348623157e308) return HUGE_VAL;      /* +inf */
+    unsigned long long b;
+    memcpy(&b, &x, 8);
+    int e = (int)((b >> 52) & 0x7ffull);
+    if (e == 0) { x = x * 18014398509481984.0; memcpy(&b, &x, 8); e = (int)((b >> 52) & 0x7ffull) - 54; }
+    e -= 1023;
+    b = (b & 0x000fffffffffffffull) | 0x3ff0000000000000ull;
+    double m;
+    memcpy(&m, &b, 8);
+    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
+    const double t = (m - 1.0) / (m + 1.0), t2 = t * t;
+    double s = 1.0 / 25.0;
+    s = s * t2 + 1.0 / 23.0; s = s * t2 + 1.0 / 21.0; s = s * t2 + 1.0 / 19.0; s = s * t2 + 1.0 / 17.0; s = s * t2 + 1.0 / 15.0;
+    s = s * t2 + 1.0 / 13.0; s = s * t2 + 1.0 / 11.0; s = s * t2 + 1.0 / 9.0; s = s * t2 + 1.0 / 7.0; s = s * t2 + 1.0 / 5.0;
+    s = s * t2 + 1.0 / 3.0; s = s * t2 + 1.0;
+    return (double)e * 0.6931471805599453 + (2.0 * t) * s;
+}
 
 // ------------------------------------------------------------------ Kabsch (fp64, + - * / sqrt only)
 #define LR_JACOBI_SWEEPS 10      // upper bound; sweeps stop once the off-diagonal mass is below 1e-15 of the diagonal

@@ -215,10 +215,10 @@ ransac_gen_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__r
 #define LR_SPRT_DELTA0 0.01
 __device__ __forceinline__ double lr_sprt_threshold(double eps, double delta)
 {
-    const double C = (1.0 - delta) * log((1.0 - delta) / (1.0 - eps)) + delta * log(delta / eps);
+    const double C = (1.0 - delta) * lr_det_log((1.0 - delta) / (1.0 - eps)) + delta * lr_det_log(delta / eps);
     const double K = (200.0 * C) / 1.0 + 1.0;
     double A = K;
-    for (int i = 0; i < 10; ++i) A = K + log(A);
+    for (int i = 0; i < 10; ++i) A = K + lr_det_log(A);
     return A;
 }
 
@@ -354,7 +354,7 @@ ransac_score_kernel(const float *__restrict__ corr8, int m_max, const int32_t *_
             }
             ssq += q32;
         }
-        if (pend < end) {
+        if (pend < end && begin < end) {      // (a chunk past the end -- begin > m -- owns nothing, not even the odd last correspondence)
             const int i = pend;
             const float px = corr8[lr_corr_at(i, 0)], py = corr8[lr_corr_at(i, 1)], pz = corr8[lr_corr_at(i, 2)];
             float x = __builtin_fmaf(r00, px, __builtin_fmaf(r01, py, __builtin_fmaf(r02, pz, tx)));
@@ -379,6 +379,20 @@ __device__ __forceinline__ bool better(uint32_t c, unsigned long long q, int h, 
     if (bc == 0u) return true;
     const long long k = (long long)c * (long long)msac_T - (long long)q, bk = (long long)bc * (long long)msac_T - (long long)bq;
     return k > bk || (k == bk && h < bh);
+}
+
+// re-design of the SPRT for the next batch: eps follows the best model (its inlier count `nc` of `mm` correspondences), delta the
+// models rejected so far
+__device__ __forceinline__ void lr_sprt_redesign(lr_ransac_state *state, uint32_t nc, int mm)
+{
+    double eps = state->sprt_eps > 0.0 ? state->sprt_eps : LR_SPRT_EPS0, delta = state->sprt_delta > 0.0 ? state->sprt_delta : LR_SPRT_DELTA0;
+    if (nc > 0) { const double e = (double)nc / (double)mm; if (e > eps && e < 1.0) eps = e; }
+    if (state->rej_pts > 0) {
+        const double d = (double)state->rej_inl / (double)state->rej_pts;
+        if (d > 0.0 && d < 0.9 * eps && fabs(d - delta) > 0.05 * delta) delta = d;
+    }
+    if (!(delta < 0.9 * eps)) delta = 0.9 * eps * 0.5;
+    state->sprt_eps = eps; state->sprt_delta = delta;
 }
 
 // best of this batch -> merged into the running state; confidence test; outputs rewritten from the state every batch
@@ -432,29 +446,18 @@ ransac_final_kernel(const uint32_t *__restrict__ score_cnt, const unsigned long 
         state->n_valid += V; state->n_ids = h_end;
         counters[LR_CNT_NVALID] = 0;                       // the next batch appends from slot 0
         counters[LR_CNT_NVALID2] = 0;
-        if (p.use_elc == 2) {
-            // re-design the SPRT for the next batch: eps follows the best model, delta the models rejected so far
-            const int mm = m_dev ? min(*m_dev, m_max) : m_max;
-            double eps = state->sprt_eps > 0.0 ? state->sprt_eps : LR_SPRT_EPS0, delta = state->sprt_delta > 0.0 ? state->sprt_delta : LR_SPRT_DELTA0;
-            if (nc > 0) { const double e = (double)nc / (double)mm; if (e > eps && e < 1.0) eps = e; }
-            if (state->rej_pts > 0) {
-                const double d = (double)state->rej_inl / (double)state->rej_pts;
-                if (d > 0.0 && d < 0.9 * eps && fabs(d - delta) > 0.05 * delta) delta = d;
-            }
-            if (!(delta < 0.9 * eps)) delta = 0.9 * eps * 0.5;
-            state->sprt_eps = eps; state->sprt_delta = delta;
-        }
-        // with local optimisation a new best model is optimised first (ransac_lo_kernel, next on the stream), and the exit
-        // test runs there on the optimised model
+        // with local optimisation a new best model is optimised first (ransac_lo_kernel, next on the stream); the exit test and the
+        // re-design of the SPRT run there, on the optimised model
         const bool to_lo = take && p.local_opt == 1;
         if (to_lo) state->lo_pending = 1;
+        if (p.use_elc == 2 && !to_lo) lr_sprt_redesign(state, nc, m_dev ? min(*m_dev, m_max) : m_max);
         if (!to_lo && p.confidence > 0.0f && p.confidence < 1.0f && nc > 0) {
             // exit rule of Open3D's RANSAC / GC-RANSAC at batch granularity: stop once h_end >= log(1-conf)/log(1-(inl/M)^n)
             const int m = m_dev ? min(*m_dev, m_max) : m_max;
             const double f = (double)nc / (double)m;
             double fn = f;
             for (int q = 1; q < p.sample_size; ++q) fn = fn * f;
-            const double kk = log(1.0 - (double)p.confidence) / log(1.0 - fn);
+            const double kk = lr_det_log(1.0 - (double)p.confidence) / lr_det_log(1.0 - fn);
             if ((double)h_end >= kk) state->done = 1;
         }
         lr_ransac_result r;
@@ -866,11 +869,12 @@ ransac_lo_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__re
         state->cnt = sh.curc; state->ssq = sh.curq;
         if (mode == 0) {
             state->lo_pending = 0; state->lo_calls = call + 1;
+            if (p.use_elc == 2) lr_sprt_redesign(state, sh.curc, m);
             if (p.confidence > 0.0f && p.confidence < 1.0f) {
                 const double f = (double)sh.curc / (double)m;
                 double fn = f;
                 for (int q = 1; q < p.sample_size; ++q) fn = fn * f;
-                const double kk = log(1.0 - (double)p.confidence) / log(1.0 - fn);
+                const double kk = lr_det_log(1.0 - (double)p.confidence) / lr_det_log(1.0 - fn);
                 if ((double)h_end >= kk) state->done = 1;
             }
         }

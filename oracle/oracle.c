@@ -423,6 +423,32 @@ ORC_API void orc_score(const float *src, const float *tgt, int m, const double T
 
 
 /* ------------------------------------------------------------------ SPRT ---- */
+
+/* Natural logarithm from + - * / only: the values the decisions compare against (confidence exit, SPRT design) must be the same
+ * bits on the host and on the device, and libm's and ocml's log differ in the last place.  Same text as lr_det_log
+ * (lidarregistration_amd/csrc/lr_kabsch.h): x = m 2^e with m in [sqrt(1/2), sqrt(2)), log x = e ln 2 + 2 atanh((m-1)/(m+1)). */
+static double det_log(double x)
+{
+    if (!(x > 0.0)) return x == 0.0 ? -HUGE_VAL : NAN;
+    if (x > 1.7976931348623157e308) return HUGE_VAL;      /* +inf */
+    unsigned long long b;
+    memcpy(&b, &x, 8);
+    int e = (int)((b >> 52) & 0x7ffull);
+    if (e == 0) { x = x * 18014398509481984.0; memcpy(&b, &x, 8); e = (int)((b >> 52) & 0x7ffull) - 54; }
+    e -= 1023;
+    b = (b & 0x000fffffffffffffull) | 0x3ff0000000000000ull;
+    double m;
+    memcpy(&m, &b, 8);
+    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
+    const double t = (m - 1.0) / (m + 1.0), t2 = t * t;
+    double s = 1.0 / 25.0;
+    s = s * t2 + 1.0 / 23.0; s = s * t2 + 1.0 / 21.0; s = s * t2 + 1.0 / 19.0; s = s * t2 + 1.0 / 17.0; s = s * t2 + 1.0 / 15.0;
+    s = s * t2 + 1.0 / 13.0; s = s * t2 + 1.0 / 11.0; s = s * t2 + 1.0 / 9.0; s = s * t2 + 1.0 / 7.0; s = s * t2 + 1.0 / 5.0;
+    s = s * t2 + 1.0 / 3.0; s = s * t2 + 1.0;
+    return (double)e * 0.6931471805599453 + (2.0 * t) * s;
+}
+ORC_API double orc_det_log(double x) { return det_log(x); }
+
 /* --fast_rejection SPRT (GC_RANSAC.py:29-34 -> use_sprt with min_inlier_ratio_for_sprt = 0.1; gcransac_python.cpp:534-568
  * instantiates GC-RANSAC's SPRTPreemptiveVerfication): Wald's sequential probability ratio test on the model's residuals
  * (Matas & Chum, "Randomized RANSAC with sequential probability ratio test", ICCV 2005; Chum & Matas, PAMI 2008).  The
@@ -442,10 +468,10 @@ ORC_API void orc_score(const float *src, const float *tgt, int m, const double T
 
 static double sprt_threshold(double eps, double delta)
 {
-    const double C = (1.0 - delta) * log((1.0 - delta) / (1.0 - eps)) + delta * log(delta / eps);
+    const double C = (1.0 - delta) * det_log((1.0 - delta) / (1.0 - eps)) + delta * det_log(delta / eps);
     const double K = (200.0 * C) / 1.0 + 1.0;
     double A = K;
-    for (int i = 0; i < 10; ++i) A = K + log(A);
+    for (int i = 0; i < 10; ++i) A = K + det_log(A);
     return A;
 }
 
@@ -692,7 +718,7 @@ ORC_API void orc_ransac(const float *src, const float *tgt, int m, const orc_ran
             double f = (double)best_c / (double)m;
             double fn = f;
             for (int k = 1; k < p->sample_size; ++k) fn = fn * f;
-            double kk = log(1.0 - (double)p->confidence) / log(1.0 - fn);
+            double kk = det_log(1.0 - (double)p->confidence) / det_log(1.0 - fn);
             if ((double)h1 >= kk) break;
         }
     }

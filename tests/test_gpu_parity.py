@@ -269,6 +269,18 @@ def test_ransac_equal_counts_are_decided_by_the_error_sum(lr, oracle, n, n_in, i
     assert info["best_count"] >= (n_in if n_in > 3 else 1)
 
 
+@pytest.mark.parametrize("n,iters", [(33817, 300), (33817, 64), (12345, 130), (5001, 64), (129, 64), (257, 1000)])
+def test_ransac_odd_counts_with_few_hypotheses(lr, oracle, n, iters):
+    """Few hypotheses over many correspondences: the scoring kernel splits the correspondences into more chunks than there are, and
+    with an odd count the last correspondence must be counted by the one chunk that owns it (found by tools/soak_gc.py: the chunks
+    past the end each counted it again)."""
+    src, tgt, T_gt = _planted(n=n, seed=n)
+    tgt[-1] = (src[-1].astype(np.float64) @ T_gt[:3, :3].T + T_gt[:3, 3]).astype(np.float32)      # the last correspondence is an inlier
+    T, info = lr.ransac.ransac_dev(src, tgt, iters, sample_size=3, use_elc=False, seed=7)
+    Te, einfo = oracle.ransac(src, tgt, iters, sample_size=3, use_elc=False, seed=7)
+    assert info == einfo and np.array_equal(T, Te)
+
+
 def test_refit_vs_oracle(lr, oracle):
     p = synth.make_pair(N=6000, rho=0.5, s=0.8, seed=17)
     i0, i1, i2, _ = oracle.find_2nn(p["feats0"], p["feats1"])

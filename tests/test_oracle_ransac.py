@@ -260,3 +260,17 @@ def test_sprt_preverification_properties(oracle):
     f = oracle.lib().orc_sprt_threshold; f.restype = ctypes.c_double
     A = f(ctypes.c_double(0.1), ctypes.c_double(0.01))
     assert 15 < A < 25 and f(ctypes.c_double(0.4), ctypes.c_double(0.01)) > A       # a stricter design for a better model
+
+
+def test_deterministic_logarithm(oracle):
+    """det_log (+ - * / only; the same text runs on the device as lr_det_log) is the natural logarithm to within 2 ulp, exact at
+    1, and keeps libm's conventions at 0, below 0, inf and NaN -- the confidence exit and the SPRT design compare against it."""
+    import ctypes, math
+    f = oracle.lib().orc_det_log; f.restype = ctypes.c_double; f.argtypes = [ctypes.c_double]
+    rng = np.random.default_rng(2)
+    xs = np.concatenate([10.0 ** rng.uniform(-300, 300, 2000), rng.uniform(0.5, 2.0, 2000), 1.0 - 10.0 ** rng.uniform(-16, -1, 500),
+                         [1.0, 2.0, 0.5, math.sqrt(2.0), 1.4142135623730951, 5e-324, 2.2250738585072014e-308, 1.7976931348623157e308]])
+    for x in xs:
+        got, want = f(float(x)), math.log(float(x))
+        assert abs(got - want) <= 2.0 * abs(np.spacing(want)) + 1e-300, (x, got, want)
+    assert f(1.0) == 0.0 and f(0.0) == -math.inf and f(math.inf) == math.inf and math.isnan(f(-1.0)) and math.isnan(f(math.nan))
