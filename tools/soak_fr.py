@@ -1,0 +1,45 @@
+"""One-off soak of the whole path behind FR(): random ragged cloud sizes, modes, codebases and flags, one pair at a time and the
+same pairs as one batched call, against oracle.register_pair (not part of the suite)."""
+import sys, os, time, ctypes, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from lidarregistration_amd import FR, synth, _ext
+from oracle import oracle
+from tests.conftest import Args, gc_oracle_kwargs
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+t = torch.from_numpy
+t0 = time.time()
+batch = []
+for case in range(n_cases):
+    rng = np.random.default_rng(7000 + case)
+    N = int(rng.choice([rng.integers(40, 400), rng.integers(400, 3000), rng.integers(3000, 9000)]))
+    N1 = int(N * rng.uniform(0.6, 1.4))
+    mode = str(rng.choice(["MNN", "GPF", "no_filter"])); cb = str(rng.choice(["GC", "open3D"]))
+    iters = int(rng.choice([300, 2000, 12000]))
+    a = Args(mode=mode, codebase=cb, iters=iters, GPF_factor=float(rng.choice([0.3, 0.5, 1.0, 2.0])), GPF_grid_wid=int(rng.choice([3, 7, 10, 16])),
+             prosac=bool(rng.integers(2)), fast_rejection=str(rng.choice(["ELC", "NONE", "SPRT"])), GC_LO=bool(rng.integers(2)),
+             GC_conf=float(rng.choice([0.999, 0.99, 1.0])), o3d_conf=float(rng.choice([0.9995, 1.0])), ransac_n=int(rng.choice([3, 4])))
+    p = synth.make_pair(N=N, N1=N1, rho=float(rng.uniform(0.2, 0.8)), s=float(rng.uniform(0.5, 0.95)), seed=case, clustered=(mode == "GPF"))
+    T, *_rest, n_filt, _ir = FR.FR(t(p["xyz0"]), t(p["xyz1"]), t(p["feats0"]), t(p["feats1"]), a, p["T_gt"])
+    kw = gc_oracle_kwargs(a) if cb == "GC" else dict(sample_size=a.ransac_n, use_elc=True, confidence=a.o3d_conf, refit_on_orig=1, scoring=0)
+    e = oracle.register_pair(p["xyz0"], p["xyz1"], p["feats0"], p["feats1"], mode=mode, iters=iters, seed=51, args=a, **kw)
+    assert n_filt == len(e["idx0"]), (case, N, N1, mode, cb, n_filt, len(e["idx0"]))
+    assert np.abs(T - e["T"]).max() <= 1e-9, (case, N, N1, mode, cb, vars(a), np.abs(T - e["T"]).max())
+    batch.append((case, p, a, T))
+    # every 8 cases with the same flags object would be needed for one batched call: batches share params, so re-run the last
+    # pair's flags on the 4 most recent clouds as one batch and compare with single calls
+    if len(batch) == 4:
+        params = FR.pair_params(a)
+        dev = [tuple(t(q[k]).cuda() for k in ("xyz0", "xyz1", "feats0", "feats1")) for _, q, _, _ in batch]
+        nmax = max(max(d[0].shape[0], d[1].shape[0]) for d in dev)
+        wsb = _ext.Workspace(nmax, nmax, 32, params.ransac.iters, max_pairs=4)
+        ob = FR.register_batch_dev(dev, params, ws=wsb).cpu().numpy()
+        ws1 = _ext.Workspace(nmax, nmax, 32, params.ransac.iters)
+        for k in range(4):
+            o1 = FR.register_pair_dev(*dev[k], params, ws=ws1).cpu().numpy()
+            ob[k][304:308] = 0; o1 = o1.copy(); o1[304:308] = 0      # n_nn_fixed: a diagnostic (rows re-done by the full scan) that depends on the grid
+            if not np.array_equal(ob[k], o1):
+                rb, r1 = _ext.PairResult.from_buffer_copy(ob[k].tobytes()), _ext.PairResult.from_buffer_copy(o1.tobytes())
+                def dump(r): return dict(n_corr=r.n_corr, status=r.status, best_h=r.ransac.best_h, cnt=r.ransac.best_count, ssq=r.ransac.best_ssq, n_valid=r.ransac.n_valid, n_ids=r.ransac.n_ids, T=list(r.T[:4]))
+                raise AssertionError((case, k, [d[0].shape[0] for d in dev], [d[1].shape[0] for d in dev], vars(a), dump(rb), dump(r1), np.nonzero(ob[k] != o1)[0][:20]))
+        batch = []
+print(f"FR soak ok: {n_cases} cases in {time.time() - t0:.0f} s")
