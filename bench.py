@@ -290,7 +290,12 @@ def main():
         # whole pair against the blended floor: one NN pass on the matrix pipe + V*M*27 flop of scoring on the vector pipe
         t_min = flop_pass / (MFMA_F16_PEAK_TFLOPS * 1e12) + n_valid_mean * n_corr_mean * 27.0 / (VALU_F32_PEAK_TFLOPS * 1e12)
         t_pair = dt / (args.pairs * args.steps)
+        hbm_pair = None      # HBM bytes of ALL the library's kernels per pair (PMC passes of the default workload, profiles/pmc_traffic.json)
+        if os.path.exists(tj) and args.n == 30000 and args.mode in ("MNN", "MMN") and args.codebase == "open3D" and args.iters == 50000:
+            hbm_pair = json.load(open(tj)).get("_pair", {}).get("hbm_bytes_per_pair")
         pair_roof = {"t_min_us": round(t_min * 1e6, 2), "t_pair_us": round(t_pair * 1e6, 2), "frac": round(t_min / t_pair, 4),
+                     "hbm_bytes_per_pair": hbm_pair, "hbm_GBps": None if hbm_pair is None else round(hbm_pair / t_pair / 1e9, 1),
+                     "hbm_frac_of_8TBps": None if hbm_pair is None else round(hbm_pair / t_pair / 8.0e12, 4),
                      "note": "t_min = W/peak_f16 + V*M*27/peak_fp32 (V = hypotheses past the pre-check, M = filtered pairs, means over the step)",
                      "V": round(n_valid_mean, 1), "M": round(n_corr_mean, 1)}
 
