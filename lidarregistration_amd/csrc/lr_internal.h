@@ -98,10 +98,11 @@ struct lr_workspace {
     int32_t *cand_cnt, *cand;    // segment counters [row blocks][4 waves][strips] and the candidate store (LR_NN16_SEG_INTS)
     float *bmax0, *bmax1;        // per-32-row maxima of the norms (f16 filter error bound)
     uint32_t *rev_seed;          // [max_n1] best forward distance pointing at each cloud-1 row (bit pattern)
+    unsigned long long *rev_seed64;  // [max_n1] ... and who: (distance bits << 32) | smallest cloud-0 index at that distance
     int32_t *rev_rows;           // [max_n1] the cloud-1 rows that have one, by descending seed
     int32_t *rev_cols;           // [max_n0] cloud-0 points by ascending NN distance (columns of the reverse pass)
-    float *rev_s1;               // [max_n0] forward NN distance per cloud-0 point
-    float *rev_tmin;             // [max_n0/32+1] smallest rev_s1s of each column tile
+    float *rev_s1;               // [max_n0] column key of the reverse pass per cloud-0 point: its 2nd-NN distance (NN distance when no 2nd was asked for)
+    float *rev_tmin;             // [max_n0/32+1] smallest key of each column tile
     int32_t *rev_hist;           // [2][4096] counting-sort offsets
     _Float16 *Hs; float *nrms;   // [max_n0] f16 rows and norms of cloud 0 in rev_cols order
     int nn_path;                 // LR_NN_PATH_*

@@ -48,12 +48,12 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 __global__ void __launch_bounds__(256)
 nn16_prep_kernel(const float *__restrict__ Fa, int na, _Float16 *__restrict__ Ha, float *__restrict__ nrma, float *__restrict__ bmaxa,
                  const float *__restrict__ Fb, int nb, _Float16 *__restrict__ Hb, float *__restrict__ nrmb, float *__restrict__ bmaxb,
-                 uint32_t *__restrict__ seed_b, int32_t *__restrict__ counters, int zero_counters, int nblk_a, lr_zargs z)
+                 uint32_t *__restrict__ seed_b, unsigned long long *__restrict__ seed64_b, int32_t *__restrict__ counters, int zero_counters, int nblk_a, lr_zargs z)
 {
     __shared__ float s_m[4];
     if (z.descs) { const lr_pair_desc d = z.descs[blockIdx.z]; Fa = d.F0; na = d.n0; Fb = d.F1; nb = d.n1; }
     lr_z(Ha, z, blockIdx.z); lr_z(nrma, z, blockIdx.z); lr_z(bmaxa, z, blockIdx.z); lr_z(Hb, z, blockIdx.z); lr_z(nrmb, z, blockIdx.z);
-    lr_z(bmaxb, z, blockIdx.z); lr_z(seed_b, z, blockIdx.z); lr_z(counters, z, blockIdx.z);
+    lr_z(bmaxb, z, blockIdx.z); lr_z(seed_b, z, blockIdx.z); lr_z(seed64_b, z, blockIdx.z); lr_z(counters, z, blockIdx.z);
     // first kernel of a pair: the counter block starts from zero (lr_register_pair) and the distance range of
     // lr_nn16_reverse from { 0x7f7f7f7f, 0 }
     if (counters && blockIdx.x == 0 && (int)threadIdx.x < LR_CNT_TOTAL) {
@@ -90,7 +90,7 @@ nn16_prep_kernel(const float *__restrict__ Fa, int na, _Float16 *__restrict__ Ha
     if (live) {
         if (t == 0) {
             nrm[row] = norm;
-            if (second && seed_b) seed_b[row] = 0x7f7f7f7fu;      // "no query points at this row yet" (lr_nn16_reverse)
+            if (second && seed_b) { seed_b[row] = 0x7f7f7f7fu; seed64_b[row] = ~0ull; }      // "no query points at this row yet" (lr_nn16_reverse)
         }
         // k = 4t..4t+3 sits in 8-element chunk c = t/2; chunks are stored in the order 0, 2, 1, 3
         const int c = t >> 1;
@@ -594,7 +594,8 @@ nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, in
                   const int32_t *__restrict__ rowmap, const int32_t *__restrict__ na_dev,
                   int32_t *__restrict__ idx1, int32_t *__restrict__ idx2, float *__restrict__ s1o, float *__restrict__ s2o,
                   int32_t *__restrict__ counters,
-                  uint32_t *__restrict__ seed_out, float *__restrict__ seed_s1, uint32_t *__restrict__ seed_range, int dir, lr_zargs z)
+                  uint32_t *__restrict__ seed_out, float *__restrict__ seed_s1, uint32_t *__restrict__ seed_range,
+                  unsigned long long *__restrict__ seed64, int dir, lr_zargs z)
 {
     __shared__ float s_a[LR_EX_ROWS * LR_EX_STRIDE];
     __shared__ float s_nq[LR_EX_ROWS];
@@ -607,7 +608,7 @@ nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, in
     }
     lr_z(nQ, z, blockIdx.z); lr_z(nC, z, blockIdx.z); lr_z(cand_cnt, z, blockIdx.z); lr_z(cand, z, blockIdx.z); lr_z(rowmap, z, blockIdx.z);
     lr_z(na_dev, z, blockIdx.z); lr_z(idx1, z, blockIdx.z); lr_z(idx2, z, blockIdx.z); lr_z(s1o, z, blockIdx.z); lr_z(s2o, z, blockIdx.z);
-    lr_z(counters, z, blockIdx.z); lr_z(seed_out, z, blockIdx.z); lr_z(seed_s1, z, blockIdx.z); lr_z(seed_range, z, blockIdx.z);
+    lr_z(counters, z, blockIdx.z); lr_z(seed_out, z, blockIdx.z); lr_z(seed_s1, z, blockIdx.z); lr_z(seed_range, z, blockIdx.z); lr_z(seed64, z, blockIdx.z);
     if (na_dev) na = *na_dev;                  // compacted row list (reverse direction): lists by position, data by rowmap[]
     const int row0 = (int)blockIdx.x * LR_EX_ROWS;
     if (row0 >= na) return;
@@ -629,6 +630,9 @@ nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, in
         if (part == 0) { s_nq[rl] = nQ[rowd]; s_rowd[rl] = rowd; }
         __syncthreads();
         if (bad) s_badrow[rl] = 1;
+        // reverse direction seeded by this library's forward pass: the best of the points that POINT AT the row is known (distance and
+        // smallest index at that distance); the scan below only adds points that do not point at it (see lr_nn16_reverse)
+        if (dir == 1 && seed64 && tid < LR_EX_ROWS && row0 + tid < na) { s_best[tid] = seed64[s_rowd[tid]]; s_cnt[tid] = 1; }
     }
     __syncthreads();
     // exact distance of staged row rl to a column row held in registers, the arithmetic contract's fma chain
@@ -697,7 +701,7 @@ nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, in
     }
     __syncthreads();
     // ---- results: one thread per row
-    float sv = 3.0e38f;
+    float sv = 3.0e38f, key = 0.0f;
     bool writer = false;
     int i1 = -1;
     if (tid < LR_EX_ROWS && row0 + tid < na) {
@@ -715,13 +719,20 @@ nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, in
             // best forward distance per target, the row's own NN distance, and the range of all of them
             sv = b1;
             if (!(sv < 3.0e38f)) sv = 3.0e38f;
-            if (i1 >= 0 && i1 < nb) atomicMin(&seed_out[i1], __float_as_uint(sv));
-            seed_s1[rowd] = sv;
+            if (i1 >= 0 && i1 < nb) {
+                atomicMin(&seed_out[i1], __float_as_uint(sv));
+                atomicMin(&seed64[i1], ((unsigned long long)__float_as_uint(sv) << 32) | (unsigned)rowd);
+            }
+            // column key of the reverse pass: a lower bound of the row's distance to every point it does NOT point at -- its exact
+            // second-smallest distance when the second neighbour was asked for (the thresholds then guarantee it), else the smallest
+            key = sv;
+            if (need >= 2) { key = ks == LR_EX_EMPTY ? 3.0e38f : __uint_as_float((unsigned)(ks >> 32)); if (!(key < 3.0e38f)) key = 3.0e38f; }
+            seed_s1[rowd] = key;
         }
     }
     if (!seed_out) return;
     if (tid < 64) {          // the rows live in wave 0
-        float lo = writer ? sv : 3.0e38f, hi = writer ? sv : 0.0f;
+        float lo = writer ? sv : 3.0e38f, hi = writer ? fmaxf(sv, key) : 0.0f;      // the range the ordering buckets span: seeds and keys
 #pragma unroll
         for (int k = 32; k >= 1; k >>= 1) { lo = fminf(lo, __shfl_xor(lo, k)); hi = fmaxf(hi, __shfl_xor(hi, k)); }
         if (tid == 0) {
@@ -735,7 +746,7 @@ nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, in
 int lr_nn16_prep(lr_workspace *ws, const float *F0, int n0, const float *F1, int n1, hipStream_t st, bool zero_counters)
 {
     hipLaunchKernelGGL(nn16_prep_kernel, dim3(lr_cdiv(n0, 32) + lr_cdiv(n1, 32), 1, ws->zP), dim3(256), 0, st, F0, n0, ws->H0, ws->nrm0, ws->bmax0,
-                       F1, n1, ws->H1, ws->nrm1, ws->bmax1, ws->rev_seed, ws->counters, zero_counters ? 1 : 0, lr_cdiv(n0, 32), ws->z);
+                       F1, n1, ws->H1, ws->nrm1, ws->bmax1, ws->rev_seed, ws->rev_seed64, ws->counters, zero_counters ? 1 : 0, lr_cdiv(n0, 32), ws->z);
     LR_LAUNCH_CHECK();
     return LR_OK;
 }
@@ -774,7 +785,8 @@ int lr_nn16_run(lr_workspace *ws, const float *Fq, const _Float16 *Hq, const flo
     if (ws->timing && !ws->ev_pending) { LR_HIP(hipEventRecord(ws->ev[1], st)); ws->ev_pending = 1; }
     hipLaunchKernelGGL(nn16_exact_kernel, dim3(lr_cdiv(na, LR_EX_ROWS), 1, ws->zP), dim3(256), 0, st, Fq, nQ, na, Fc, nC, nb, ws->cand_cnt, ws->cand,
                        strips, need, (const int32_t *)nullptr, (const int32_t *)nullptr, idx1, idx2, s1, s2, ws->counters,
-                       seed_reverse ? ws->rev_seed : (uint32_t *)nullptr, ws->rev_s1, reinterpret_cast<uint32_t *>(ws->counters + LR_CNT_RLO), 0, ws->z);
+                       seed_reverse ? ws->rev_seed : (uint32_t *)nullptr, ws->rev_s1, reinterpret_cast<uint32_t *>(ws->counters + LR_CNT_RLO),
+                       ws->rev_seed64, 0, ws->z);
     LR_LAUNCH_CHECK();
     return LR_OK;
 }
@@ -994,7 +1006,8 @@ int lr_nn16_reverse(lr_workspace *ws, const float *F0, const _Float16 *H0, const
     if (timed) { LR_HIP(hipEventRecord(ws->ev[5], st)); ws->rev_recorded = 1; }
     hipLaunchKernelGGL(nn16_exact_kernel, dim3(lr_cdiv(na, LR_EX_ROWS), 1, ws->zP), dim3(256), 0, st, F1, nrm1, na, F0, nrm0, nb, ws->cand_cnt, ws->cand,
                        strips, 1, (const int32_t *)ws->rev_rows, (const int32_t *)n_rows, rev, (int32_t *)nullptr, (float *)nullptr, (float *)nullptr,
-                       ws->counters, (uint32_t *)nullptr, (float *)nullptr, (uint32_t *)nullptr, 1, ws->z);
+                       ws->counters, (uint32_t *)nullptr, (float *)nullptr, (uint32_t *)nullptr,
+                       seeded ? ws->rev_seed64 : (unsigned long long *)nullptr, 1, ws->z);
     LR_LAUNCH_CHECK();
     return LR_OK;
 }

@@ -31,7 +31,7 @@ int main(int argc, char **argv)
     lr_zargs z0 = { 0, nullptr };
     for (int p = 0; p < P; ++p)
         hipLaunchKernelGGL(nn16_prep_kernel, dim3((n+31)/32), dim3(256), 0, 0, F, n, (_Float16 *)((char *)H + p * stride), (float *)((char *)nrm + p * stride), (float *)((char *)bmax + p * stride),
-                           F, 0, H, nrm, bmax, (uint32_t*)nullptr, (int32_t*)nullptr, 0, (n + 31) / 32, z0);
+                           F, 0, H, nrm, bmax, (uint32_t*)nullptr, (unsigned long long*)nullptr, (int32_t*)nullptr, 0, (n + 31) / 32, z0);
     hipDeviceSynchronize();
     lr_zargs z = { stride, nullptr };
     const int ntiles = (n + 31) / 32, row_blocks = (n + LR_BLOCK_ROWS - 1) / LR_BLOCK_ROWS;
