@@ -595,22 +595,27 @@ nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, in
                   int32_t *__restrict__ idx1, int32_t *__restrict__ idx2, float *__restrict__ s1o, float *__restrict__ s2o,
                   int32_t *__restrict__ counters,
                   uint32_t *__restrict__ seed_out, float *__restrict__ seed_s1, uint32_t *__restrict__ seed_range,
-                  unsigned long long *__restrict__ seed64, int dir, lr_zargs z)
+                  unsigned long long *__restrict__ seed64, int dir, int gx, int total, lr_zargs z)
 {
+    // 1-D XCD-aware grid -> (row block, pair): the blocks one XCD receives are consecutive row blocks of the same pairs, so the
+    // column cloud they gather from (3.84 MB of fp32 rows at 30k points) stays in that XCD's L2
+    int logical;
+    if (!lr_xcd_block(total, logical)) return;
+    const int bxi = logical % gx, pair = logical / gx;
     __shared__ float s_a[LR_EX_ROWS * LR_EX_STRIDE];
     __shared__ float s_nq[LR_EX_ROWS];
     __shared__ unsigned long long s_best[LR_EX_ROWS], s_second[LR_EX_ROWS];
     __shared__ int s_cnt[LR_EX_ROWS], s_rowd[LR_EX_ROWS], s_badrow[LR_EX_ROWS];
     __shared__ int s_bad, s_nredo, s_redo[LR_EX_ROWS];
     if (z.descs) {      // dir 0: rows = cloud 0 against cloud 1; 1: the reverse direction
-        const lr_pair_desc d = z.descs[blockIdx.z];
+        const lr_pair_desc d = z.descs[pair];
         Fq = dir ? d.F1 : d.F0; na = dir ? d.n1 : d.n0; Fc = dir ? d.F0 : d.F1; nb = dir ? d.n0 : d.n1;
     }
-    lr_z(nQ, z, blockIdx.z); lr_z(nC, z, blockIdx.z); lr_z(cand_cnt, z, blockIdx.z); lr_z(cand, z, blockIdx.z); lr_z(rowmap, z, blockIdx.z);
-    lr_z(na_dev, z, blockIdx.z); lr_z(idx1, z, blockIdx.z); lr_z(idx2, z, blockIdx.z); lr_z(s1o, z, blockIdx.z); lr_z(s2o, z, blockIdx.z);
-    lr_z(counters, z, blockIdx.z); lr_z(seed_out, z, blockIdx.z); lr_z(seed_s1, z, blockIdx.z); lr_z(seed_range, z, blockIdx.z); lr_z(seed64, z, blockIdx.z);
+    lr_z(nQ, z, pair); lr_z(nC, z, pair); lr_z(cand_cnt, z, pair); lr_z(cand, z, pair); lr_z(rowmap, z, pair);
+    lr_z(na_dev, z, pair); lr_z(idx1, z, pair); lr_z(idx2, z, pair); lr_z(s1o, z, pair); lr_z(s2o, z, pair);
+    lr_z(counters, z, pair); lr_z(seed_out, z, pair); lr_z(seed_s1, z, pair); lr_z(seed_range, z, pair); lr_z(seed64, z, pair);
     if (na_dev) na = *na_dev;                  // compacted row list (reverse direction): lists by position, data by rowmap[]
-    const int row0 = (int)blockIdx.x * LR_EX_ROWS;
+    const int row0 = bxi * LR_EX_ROWS;
     if (row0 >= na) return;
     const int tid = threadIdx.x;
     // ---- stage the query rows: thread t moves floats [8 (t & 3) .. +8) of row t >> 2
@@ -652,10 +657,10 @@ nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, in
     // ---- the candidates: entry { column, (code << 8) | mask }, code = rb*4 + (g0/8)*2 + h of the pass-B wave tile, mask bit
     //      7-k <-> register g0 + k; row of register g: 32 rb + 4 h + (g & 3) + 8 (g >> 2)
     {
-        const int32_t *cw = cand_cnt + blockIdx.x * (nstrips + 1);
+        const int32_t *cw = cand_cnt + bxi * (nstrips + 1);
         const int used = min(max(cw[nstrips], 1), nstrips);        // strips the pass-B row block really used
         const int seg_cap = lr_seg_cap(used);
-        const uint2 *__restrict__ segs = reinterpret_cast<const uint2 *>(cand) + (size_t)blockIdx.x * LR_NN16_SEG;
+        const uint2 *__restrict__ segs = reinterpret_cast<const uint2 *>(cand) + (size_t)bxi * LR_NN16_SEG;
         for (int sidx = 0; sidx < used; ++sidx) {
             const int c = cw[sidx];
             if (c < 0) { if (tid == 0) s_bad = 1; continue; }      // segment overflowed: all 64 rows are re-done
@@ -783,10 +788,11 @@ int lr_nn16_run(lr_workspace *ws, const float *Fq, const _Float16 *Hq, const flo
                        tps, (const float *)nullptr, ws->cand_cnt, ws->cand, (const int32_t *)nullptr, (const float *)nullptr,
                        (const uint32_t *)nullptr, thr, lr_pb_grid{ row_blocks, strips, total, 0 }, ws->z);
     if (ws->timing && !ws->ev_pending) { LR_HIP(hipEventRecord(ws->ev[1], st)); ws->ev_pending = 1; }
-    hipLaunchKernelGGL(nn16_exact_kernel, dim3(lr_cdiv(na, LR_EX_ROWS), 1, ws->zP), dim3(256), 0, st, Fq, nQ, na, Fc, nC, nb, ws->cand_cnt, ws->cand,
+    const int ex_gx = lr_cdiv(na, LR_EX_ROWS), ex_total = ex_gx * ws->zP;
+    hipLaunchKernelGGL(nn16_exact_kernel, dim3(8 * lr_cdiv(ex_total, 8)), dim3(256), 0, st, Fq, nQ, na, Fc, nC, nb, ws->cand_cnt, ws->cand,
                        strips, need, (const int32_t *)nullptr, (const int32_t *)nullptr, idx1, idx2, s1, s2, ws->counters,
                        seed_reverse ? ws->rev_seed : (uint32_t *)nullptr, ws->rev_s1, reinterpret_cast<uint32_t *>(ws->counters + LR_CNT_RLO),
-                       ws->rev_seed64, 0, ws->z);
+                       ws->rev_seed64, 0, ex_gx, ex_total, ws->z);
     LR_LAUNCH_CHECK();
     return LR_OK;
 }
@@ -1004,10 +1010,11 @@ int lr_nn16_reverse(lr_workspace *ws, const float *F0, const _Float16 *H0, const
                        (const int32_t *)ws->rev_cols, seeded ? (const float *)ws->rev_tmin : (const float *)nullptr, (const uint32_t *)seed, lr_thr_in{},
                        lr_pb_grid{ row_blocks, strips, total, 1 }, ws->z);
     if (timed) { LR_HIP(hipEventRecord(ws->ev[5], st)); ws->rev_recorded = 1; }
-    hipLaunchKernelGGL(nn16_exact_kernel, dim3(lr_cdiv(na, LR_EX_ROWS), 1, ws->zP), dim3(256), 0, st, F1, nrm1, na, F0, nrm0, nb, ws->cand_cnt, ws->cand,
+    const int ex_gx = lr_cdiv(na, LR_EX_ROWS), ex_total = ex_gx * ws->zP;
+    hipLaunchKernelGGL(nn16_exact_kernel, dim3(8 * lr_cdiv(ex_total, 8)), dim3(256), 0, st, F1, nrm1, na, F0, nrm0, nb, ws->cand_cnt, ws->cand,
                        strips, 1, (const int32_t *)ws->rev_rows, (const int32_t *)n_rows, rev, (int32_t *)nullptr, (float *)nullptr, (float *)nullptr,
                        ws->counters, (uint32_t *)nullptr, (float *)nullptr, (uint32_t *)nullptr,
-                       seeded ? ws->rev_seed64 : (unsigned long long *)nullptr, 1, ws->z);
+                       seeded ? ws->rev_seed64 : (unsigned long long *)nullptr, 1, ex_gx, ex_total, ws->z);
     LR_LAUNCH_CHECK();
     return LR_OK;
 }
