@@ -765,8 +765,13 @@ int lr_nn16_run(lr_workspace *ws, const float *Fq, const _Float16 *Hq, const flo
     // pass A samples every `stride`-th tile (any subset gives a valid, if looser, threshold)
     int stride = ntiles / 16;
     {
-        static int cap = -1;     // LIDARREG_NN_STRIDE: sampling stride of pass A (development knob; any value gives the exact result)
-        if (cap < 0) { const char *e = getenv("LIDARREG_NN_STRIDE"); cap = e && atoi(e) > 0 ? atoi(e) : LR_NN16_STRIDE; }
+        // Pass A costs ~ tiles / stride per row, the candidates the looser thresholds admit ~ stride per row: the best stride grows
+        // like sqrt(tiles).  4 up to ~30k points (measured flat from 4 to 8 there), 8 at 100k points (+7 % pairs/s over 4).
+        // LIDARREG_NN_STRIDE overrides (development knob; any value gives the exact result).
+        static int env_cap = -1;
+        if (env_cap < 0) { const char *e = getenv("LIDARREG_NN_STRIDE"); env_cap = e && atoi(e) > 0 ? atoi(e) : 0; }
+        int cap = env_cap > 0 ? env_cap : (int)(sqrt((double)ntiles) / 7.0);
+        if (env_cap <= 0 && cap < LR_NN16_STRIDE) cap = LR_NN16_STRIDE;
         if (stride > cap) stride = cap;
     }
     if (stride < 1) stride = 1;
