@@ -296,16 +296,22 @@ ransac_sprt_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__
 __global__ void __launch_bounds__(256)
 ransac_score_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__restrict__ m_dev, float thr2,
                     const float *__restrict__ models, uint32_t *__restrict__ score_cnt,
-                    unsigned long long *__restrict__ score_ssq, const int32_t *__restrict__ counters, int sub, int model_stride, int vslot, lr_zargs z)
+                    unsigned long long *__restrict__ score_ssq, const int32_t *__restrict__ counters, int sub, int model_stride, int vslot,
+                    int gx, int total, lr_zargs z)
 {
-    lr_z(corr8, z, blockIdx.z); lr_z(m_dev, z, blockIdx.z); lr_z(models, z, blockIdx.z); lr_z(score_cnt, z, blockIdx.z); lr_z(score_ssq, z, blockIdx.z); lr_z(counters, z, blockIdx.z);
+    // 1-D XCD-aware grid -> (block of the pair, pair): the blocks of one pair run on one XCD, whose L2 then serves the pair's
+    // record stream (0.5 MB, read by every wave) and its models
+    int logical;
+    if (!lr_xcd_block(total, logical)) return;
+    const int bxi = logical % gx, pair = logical / gx;
+    lr_z(corr8, z, pair); lr_z(m_dev, z, pair); lr_z(models, z, pair); lr_z(score_cnt, z, pair); lr_z(score_ssq, z, pair); lr_z(counters, z, pair);
     const int m = m_dev ? min(*m_dev, m_max) : m_max;
     const int V = counters[vslot];           // LR_CNT_NVALID, or LR_CNT_NVALID2 behind the SPRT pre-verification
     const int hb = (V + 63) >> 6;
     if (hb == 0 || m <= 0 || reinterpret_cast<const lr_ransac_state *>(counters + LR_CNT_COUNT)->done) return;
-    // a block is four independent waves (one-wave blocks cap the CU at half its wave slots); wave w of the launch takes the
-    // work items w, w + W, ...
-    const int W = (int)gridDim.x * 4;
+    // a block is four independent waves (one-wave blocks cap the CU at half its wave slots); wave w of the pair's gx blocks takes
+    // the work items w, w + W, ...
+    const int W = gx * 4;
     int chunks = W / hb;
     const int cmax = m / LR_SCORE_CHUNK > 0 ? m / LR_SCORE_CHUNK : 1;   // at least LR_SCORE_CHUNK correspondences per work item
     if (chunks > cmax) chunks = cmax;
@@ -314,7 +320,7 @@ ransac_score_kernel(const float *__restrict__ corr8, int m_max, const int32_t *_
     const int lane = threadIdx.x & 63;
     // the wave index is wave-uniform, which the compiler cannot see through threadIdx: without the readfirstlane the record
     // loads below become per-lane global loads with VALU address arithmetic instead of scalar loads
-    for (int w = (int)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6); w < hb * chunks; w += W) {
+    for (int w = bxi * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6); w < hb * chunks; w += W) {
         const int g = w % hb, c = w / hb;
         const int slot = g * 64 + lane;
         const bool active = slot < V;
@@ -962,8 +968,12 @@ int lr_ransac_run(lr_workspace *ws, const float *corr8, int m_max, const int32_t
                                (const float *)ws->models, (const double *)ws->models64, (const int32_t *)ws->model_h, ws->models2, ws->models64_2, ws->model_h2,
                                ws->score_cnt, ws->score_ssq, ws->counters, ws->max_iters, ws->z);
         const int vslot = sprt ? LR_CNT_NVALID2 : LR_CNT_NVALID;
-        hipLaunchKernelGGL(ransac_score_kernel, dim3(LR_SCORE_BLOCKS / 4, 1, ws->zP), dim3(256), 0, st, corr8, m_max, m_dev, p->thr2,
-                           sprt ? (const float *)ws->models2 : (const float *)ws->models, ws->score_cnt, ws->score_ssq, ws->counters, sub, ws->max_iters, vslot, ws->z);
+        {
+            const int sgx = LR_SCORE_BLOCKS / 4, stotal = sgx * ws->zP;
+            hipLaunchKernelGGL(ransac_score_kernel, dim3(8 * lr_cdiv(stotal, 8)), dim3(256), 0, st, corr8, m_max, m_dev, p->thr2,
+                               sprt ? (const float *)ws->models2 : (const float *)ws->models, ws->score_cnt, ws->score_ssq, ws->counters, sub, ws->max_iters,
+                               vslot, sgx, stotal, ws->z);
+        }
         if (h0 == 0 && ws->timing && ws->ev_pending == 1) { LR_HIP(hipEventRecord(ws->ev[3], st)); ws->ev_pending = 2; }
         hipLaunchKernelGGL(ransac_final_kernel, dim3(1, 1, ws->zP), dim3(1024), 0, st, ws->score_cnt, ws->score_ssq,
                            sprt ? (const int32_t *)ws->model_h2 : (const int32_t *)ws->model_h, sprt ? (const double *)ws->models64_2 : (const double *)ws->models64,
