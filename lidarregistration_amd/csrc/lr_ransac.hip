@@ -969,6 +969,8 @@ int lr_ransac_run(lr_workspace *ws, const float *corr8, int m_max, const int32_t
                                ws->score_cnt, ws->score_ssq, ws->counters, ws->max_iters, ws->z);
         const int vslot = sprt ? LR_CNT_NVALID2 : LR_CNT_NVALID;
         {
+            // (LR_SCORE_BLOCKS / 4 blocks for EVERY pair of a batched call: 64 per pair -- the GPU filled exactly once -- measured 32 %
+            // slower, the few large work items of a pair do not balance)
             const int sgx = LR_SCORE_BLOCKS / 4, stotal = sgx * ws->zP;
             hipLaunchKernelGGL(ransac_score_kernel, dim3(8 * lr_cdiv(stotal, 8)), dim3(256), 0, st, corr8, m_max, m_dev, p->thr2,
                                sprt ? (const float *)ws->models2 : (const float *)ws->models, ws->score_cnt, ws->score_ssq, ws->counters, sub, ws->max_iters,
