@@ -277,6 +277,17 @@ nn16_passa_kernel(const _Float16 *__restrict__ Hq, int na, const _Float16 *__res
 #endif
 #define LR_PB_WLIST 512          // entries per wave (8 bytes each)
 
+#define LR_RS_BUCKETS 4096
+
+// monotone map distance -> bucket: linear over the pair's range of forward NN distances [lo, hi] (well spread keys keep
+// the sort's atomics apart); any monotone map is valid, a coarser one only prunes less
+__device__ __forceinline__ int rs_bucket(float v, float lo, float scale)
+{
+    const int b = (int)((v - lo) * scale);
+    return min(max(b, 0), LR_RS_BUCKETS - 1);
+}
+__device__ __forceinline__ float rs_scale(float lo, float hi) { return hi > lo ? (float)LR_RS_BUCKETS / (hi - lo) : 0.0f; }
+
 // what the thresholds of the forward direction are made of (pass A partials); the reverse direction passes tau instead
 struct lr_thr_in {
     const float *pg1, *pg2;      // [strips][part_stride] two largest sampled g per row and strip
@@ -292,7 +303,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
                   const _Float16 *__restrict__ Hc, const float *__restrict__ nC, int nb,
                   int tiles_per_strip, const float *__restrict__ tau, int32_t *__restrict__ cand_cnt, int32_t *__restrict__ cand,
                   const int32_t *__restrict__ colmap, const float *__restrict__ tile_min, const uint32_t *__restrict__ row_bound,
-                  lr_thr_in thr, lr_pb_grid pg, lr_zargs z)
+                  const int32_t *__restrict__ rev_offs, const uint32_t *__restrict__ rev_range, lr_thr_in thr, lr_pb_grid pg, lr_zargs z)
 {
     // 1-D XCD-aware grid -> (row block, strip, pair): see nn16_passa_kernel
     int logical;
@@ -304,7 +315,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         thr.nblk_c = (nb + 31) >> 5;
     }
     lr_z(Hq, z, pair); lr_z(rowmap, z, pair); lr_z(na_dev, z, pair); lr_z(Hc, z, pair); lr_z(nC, z, pair); lr_z(tau, z, pair);
-    lr_z(cand_cnt, z, pair); lr_z(cand, z, pair); lr_z(colmap, z, pair); lr_z(tile_min, z, pair); lr_z(row_bound, z, pair);
+    lr_z(cand_cnt, z, pair); lr_z(cand, z, pair); lr_z(colmap, z, pair); lr_z(tile_min, z, pair); lr_z(row_bound, z, pair); lr_z(rev_offs, z, pair); lr_z(rev_range, z, pair);
     lr_z(thr.pg1, z, pair); lr_z(thr.pg2, z, pair); lr_z(thr.nQ, z, pair); lr_z(thr.block_max_c, z, pair);
     // rows: either 0..na_host-1, or (reverse direction) the ordered list rowmap[0..*na_dev-1]; tau, cand_cnt and cand
     // are indexed by the position in that list.  Columns: Hc/nC as they lie; with colmap they are a permuted copy and
@@ -323,27 +334,19 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     int ntiles = (nb + 31) >> 5;
     int my_strips = pg.gy;           // strips this row block really uses (the ordered reverse pass: as many as its column prefix is worth)
     if (tile_min) {
-        // Ordered reverse pass (lr_nn16_reverse): a column can only win a row if its own NN distance is <= the row's
-        // bound, so this row block needs the column tiles up to the last one whose smallest NN distance is <= the
-        // block's largest bound -- all exact fp32 values, no margin.  The strips then split that prefix.
-        float bmax = 0.0f;
-        {
-            const int rw = bx * LR_BLOCK_ROWS + tid;
-            if (rw < na) bmax = __uint_as_float(row_bound[rowmap[rw]]);
+        // Ordered reverse pass (lr_nn16_reverse): a column can only win a row if its key (a lower bound of its distance to every row
+        // it does not point at) is <= the row's bound.  Rows lie by descending bucket of their bound, columns by ascending bucket of
+        // their key (one monotone map, nn16_rev_scan / _scatter), so the block's FIRST row has its largest bucket b and the columns
+        // that can matter to the block are the first offs[b] of the order (after the scatter offs[b] is the end of bucket b): three
+        // dependent loads by one thread instead of 256 bounds + all tile minima reduced by the block -- most of the (row block, strip)
+        // blocks of this launch only find out here that they are not needed.
+        if (tid == 0) {
+            const float lo = __uint_as_float(rev_range[0]), scale = rs_scale(lo, __uint_as_float(rev_range[1]));
+            const float sv = __uint_as_float(row_bound[rowmap[bx * LR_BLOCK_ROWS]]);
+            s_limit[0] = (rev_offs[rs_bucket(sv, lo, scale)] + 31) >> 5;
         }
-#pragma unroll
-        for (int k = 32; k >= 1; k >>= 1) bmax = fmaxf(bmax, __shfl_xor(bmax, k));
-        __shared__ float s_b[4];
-        if (lane == 0) s_b[wave] = bmax;
         __syncthreads();
-        bmax = fmaxf(fmaxf(s_b[0], s_b[1]), fmaxf(s_b[2], s_b[3]));
-        int last = -1;
-        for (int t = tid; t < ntiles; t += 256) if (tile_min[t] <= bmax) last = t;
-#pragma unroll
-        for (int k = 32; k >= 1; k >>= 1) last = max(last, __shfl_xor(last, k));
-        if (lane == 0) s_limit[wave] = last;
-        __syncthreads();
-        ntiles = max(max(s_limit[0], s_limit[1]), max(s_limit[2], s_limit[3])) + 1;
+        ntiles = min(ntiles, s_limit[0]);
         // as many of the offered strips as the prefix is worth (a full-length row block uses all of them)
         my_strips = min(pg.gy, (ntiles + tiles_per_strip - 1) / tiles_per_strip);
         if (by >= my_strips) return;
@@ -791,7 +794,7 @@ int lr_nn16_run(lr_workspace *ws, const float *Fq, const _Float16 *Hq, const flo
     lr_thr_in thr = { ws->pb1, ws->pb2, nQ, block_max_c, strips, ws->max_n, lr_cdiv(nb, 32), need };
     hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), ws->pb_dyn_lds, st, Hq, na, (const int32_t *)nullptr, (const int32_t *)nullptr, Hc, nC, nb,
                        tps, (const float *)nullptr, ws->cand_cnt, ws->cand, (const int32_t *)nullptr, (const float *)nullptr,
-                       (const uint32_t *)nullptr, thr, lr_pb_grid{ row_blocks, strips, total, 0 }, ws->z);
+                       (const uint32_t *)nullptr, (const int32_t *)nullptr, (const uint32_t *)nullptr, thr, lr_pb_grid{ row_blocks, strips, total, 0 }, ws->z);
     if (ws->timing && !ws->ev_pending) { LR_HIP(hipEventRecord(ws->ev[1], st)); ws->ev_pending = 1; }
     const int ex_gx = lr_cdiv(na, LR_EX_ROWS), ex_total = ex_gx * ws->zP;
     hipLaunchKernelGGL(nn16_exact_kernel, dim3(8 * lr_cdiv(ex_total, 8)), dim3(256), 0, st, Fq, nQ, na, Fc, nC, nb, ws->cand_cnt, ws->cand,
@@ -808,22 +811,13 @@ int lr_nn16_run(lr_workspace *ws, const float *Fq, const _Float16 *Hq, const flo
 // IS an upper bound of j's minimum, and pass B looks for points with u' <= s*^2 (1 + 4e-7) - n_j + E.
 //   - points j nobody points at are left out (their reverse NN is reported as -1; the reference does not compute it
 //     either, matching.py:224-225);
-//   - a cloud-0 point i' can only win j if its own NN distance s1(i') -- a by-product of the seeding kernel -- is
-//     <= s*_j: d(i', j) >= s1(i') holds exactly in fp32 because both directions form bit-identical distances.  The rows
-//     (pointed-at j) are therefore ordered by descending s*, the columns (all i') by ascending s1 (a counting sort on
-//     LR_RS_BUCKETS linear buckets; any order is valid, a better one only prunes more), and each 256-row block walks
-//     only the prefix of column tiles that can matter to it (nn16_passb_kernel, tile_min / row_bound).
-#define LR_RS_BUCKETS 4096
-
-// monotone map distance -> bucket: linear over the pair's range of forward NN distances [lo, hi] (well spread keys keep
-// the sort's atomics apart); any monotone map is valid, a coarser one only prunes less
-__device__ __forceinline__ int rs_bucket(float v, float lo, float scale)
-{
-    const int b = (int)((v - lo) * scale);
-    return min(max(b, 0), LR_RS_BUCKETS - 1);
-}
-__device__ __forceinline__ float rs_scale(float lo, float hi) { return hi > lo ? (float)LR_RS_BUCKETS / (hi - lo) : 0.0f; }
-
+//   - a cloud-0 point i' that does NOT point at j is at least as far from j as from its own second neighbour: d(i', j) >= s2(i')
+//     holds exactly in fp32 because both directions form bit-identical distances (key = s2, or s1 when no second neighbour was
+//     asked for; a by-product of the forward exact kernel).  The points that DO point at j need no search: the forward exact kernel
+//     leaves the best of them per target, with the smallest index among equals, in a 64-bit seed.  The rows (pointed-at j) are
+//     therefore ordered by descending s*, the columns (all i') by ascending key (a counting sort on LR_RS_BUCKETS linear buckets;
+//     any order is valid, a better one only prunes more), and each 256-row block walks only the prefix of column tiles that can
+//     matter to it: the columns in the buckets up to the bucket of its first row's bound (nn16_passb_kernel).
 // seeds: seed_bits[j] = min over i with idx1[i] == j of the exact distance; s1[i] = that distance; range = their min / max
 __global__ void __launch_bounds__(256)
 nn16_rev_seed_kernel(const float *__restrict__ F0, const float *__restrict__ n0v, int n0, const float *__restrict__ F1,
@@ -866,7 +860,7 @@ nn16_rev_seed_kernel(const float *__restrict__ F0, const float *__restrict__ n0v
 
 // counting sort, passes 1 + 2 in one block: bucket histograms in LDS (cloud-0 points keyed by s1, ascending; cloud-1
 // points with a seed keyed by s*, descending), exclusive prefix sums -> offs[2][LR_RS_BUCKETS]; the row total is the
-// length of the reverse pass; tile_min is reset for the scatter kernel's atomicMin
+// length of the reverse pass
 __global__ void __launch_bounds__(1024)
 nn16_rev_scan_kernel(int n0, int n1, const float *__restrict__ s1, const uint32_t *__restrict__ seed_bits,
                      const uint32_t *__restrict__ range, int32_t *__restrict__ offs, int32_t *__restrict__ n_rows,
@@ -879,7 +873,6 @@ nn16_rev_scan_kernel(int n0, int n1, const float *__restrict__ s1, const uint32_
     __shared__ int s_w[16];
     const float lo = __uint_as_float(range[0]), scale = rs_scale(lo, __uint_as_float(range[1]));
     for (int k = threadIdx.x; k < 2 * LR_RS_BUCKETS; k += 1024) s_h[k] = 0;
-    for (int t = threadIdx.x; t < (n0 + 31) / 32; t += 1024) tile_min_bits[t] = 0x7f800000u;
     __syncthreads();
     // eight independent loads in flight per thread (a single block: the loop is bound by load latency, not by the atomics)
     for (int i0 = threadIdx.x; i0 < n0; i0 += 8 * 1024) {
@@ -921,8 +914,7 @@ nn16_rev_scan_kernel(int n0, int n1, const float *__restrict__ s1, const uint32_
 }
 
 // pass 3: scatter.  Cloud-0 points: position in ascending-s1 order -> colmap, and the f16 row /
-// norm copied there (pass B streams the permuted copy, no indirection in its loop); tile_min = smallest s1 of every
-// column tile of that copy.  Cloud-1 points with a seed: position in descending-s* order -> rowmap, threshold and empty
+// norm copied there (pass B streams the permuted copy, no indirection in its loop).  Cloud-1 points with a seed: position in descending-s* order -> rowmap, threshold and empty
 // candidate list at that position; the others get rev = -1.
 __global__ void __launch_bounds__(256)
 nn16_rev_scatter_kernel(int n0, int n1, const float *__restrict__ s1, const uint32_t *__restrict__ seed_bits,
@@ -961,7 +953,6 @@ nn16_rev_scatter_kernel(int n0, int n1, const float *__restrict__ s1, const uint
         dst[0] = v0; dst[1] = v1; dst[2] = v2; dst[3] = v3;
         colmap[pos] = t;
         nrm0s[pos] = nt;
-        atomicMin(&tile_min_bits[pos >> 5], __float_as_uint(sv));
     } else if (t < n0 + n1) {
         const int row = t - n0;
         const float sv = __uint_as_float(seed_bits[row]);
@@ -1002,7 +993,7 @@ int lr_nn16_reverse(lr_workspace *ws, const float *F0, const _Float16 *H0, const
                        (const uint32_t *)seed, (const uint32_t *)range, ws->rev_hist, H0, nrm0, bmax0, lr_cdiv(nb, 32), nrm1,
                        ws->rev_cols, ws->Hs, ws->nrms, tmin, ws->rev_rows, ws->tau, ws->cand_cnt, rev, row_blocks * 4 * (strips + 1), ws->z);
     // grids are sized for all rows; blocks past the compacted count (or past their row block's strips) leave at once.
-    // The column-prefix pruning (tile_min) rests on s1(i') = d(i', idx1[i']) being the true NN distance of i': that holds when
+    // The column-prefix pruning (flagged by a non-null tile_min) rests on the keys being true lower bounds: that holds when
     // the list comes from this library's own forward pass (`seeded`, lr_register_pair).  A caller-supplied list (lr_nn_to_mutual,
     // lr_gpf*) may be anything -- the reference's nn_to_mutual accepts any corres_idx1 -- so every row block walks all column
     // tiles there: the seeds are still upper bounds of the row minima, only the prefix cut is given up.
@@ -1012,7 +1003,8 @@ int lr_nn16_reverse(lr_workspace *ws, const float *F0, const _Float16 *H0, const
     if (timed) { LR_HIP(hipEventRecord(ws->ev[4], st)); }
     hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), ws->pb_dyn_lds, st, H1, na, (const int32_t *)ws->rev_rows, (const int32_t *)n_rows,
                        (const _Float16 *)ws->Hs, (const float *)ws->nrms, nb, tps, ws->tau, ws->cand_cnt, ws->cand,
-                       (const int32_t *)ws->rev_cols, seeded ? (const float *)ws->rev_tmin : (const float *)nullptr, (const uint32_t *)seed, lr_thr_in{},
+                       (const int32_t *)ws->rev_cols, seeded ? (const float *)ws->rev_tmin : (const float *)nullptr, (const uint32_t *)seed,
+                       (const int32_t *)ws->rev_hist, (const uint32_t *)range, lr_thr_in{},
                        lr_pb_grid{ row_blocks, strips, total, 1 }, ws->z);
     if (timed) { LR_HIP(hipEventRecord(ws->ev[5], st)); ws->rev_recorded = 1; }
     const int ex_gx = lr_cdiv(na, LR_EX_ROWS), ex_total = ex_gx * ws->zP;
