@@ -117,8 +117,8 @@ extern "C" int lr_workspace_create_batch(lr_workspace **out, int max_pairs, int 
         ws->pb_dyn_lds = dl ? atoi(dl) : 0;
         if (ws->pb_dyn_lds < 0 || ws->pb_dyn_lds > 24576) ws->pb_dyn_lds = 0;
         const char *rs = getenv("LIDARREG_REV_STRIPS");
-        ws->rev_strips = rs ? atoi(rs) : 16;
-        if (ws->rev_strips < 1) ws->rev_strips = 1;
+        ws->rev_strips = rs ? atoi(rs) : 0;            // 0: by the number of pairs of the call (lr_nn16_reverse)
+        if (ws->rev_strips < 0) ws->rev_strips = 0;
         if (ws->rev_strips > 64) ws->rev_strips = 64;
         const char *sa = getenv("LIDARREG_NN_SECOND");
         ws->nn_second_auto = (sa && strcmp(sa, "auto") == 0) ? 1 : 0;

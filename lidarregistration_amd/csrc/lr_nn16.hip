@@ -976,7 +976,11 @@ int lr_nn16_reverse(lr_workspace *ws, const float *F0, const _Float16 *H0, const
     const int ntiles = lr_cdiv(nb, 32);
     const int row_blocks = lr_cdiv(na, LR_BLOCK_ROWS);
     // the grid offers every row block the maximum number of strips; a block uses as many as its column prefix is worth
-    int strips = ws->rev_strips;             // (no pass-A partial arrays on this path: not bound by LR_NN_MAX_STRIPS)
+    // strips offered to every row block (no pass-A partial arrays on this path: not bound by LR_NN_MAX_STRIPS).  A block that is
+    // not needed leaves after three loads, but tens of thousands of them still cost: 8 for one pair (parallelism for the row blocks
+    // with long prefixes), fewer the more pairs a batched call brings (2 at 32 pairs: 7 990 against 7 740 pairs/s with 16)
+    int strips = ws->rev_strips > 0 ? ws->rev_strips : 48 / ws->zP;
+    if (ws->rev_strips <= 0) { if (strips > 8) strips = 8; if (strips < 2) strips = 2; }
     int smax = ntiles / 8;
     if (strips > smax) strips = smax;
     if (strips < 1) strips = 1;
