@@ -606,3 +606,34 @@ def test_nn_candidate_store_overflow_falls_back_to_the_exact_scan(lr, oracle):
         g = lr.matching.nn_to_mutual(lr.torch.from_numpy(F0), lr.torch.from_numpy(F1), lr.torch.from_numpy(e0), lr.torch.from_numpy(o1.astype(np.int64)),
                                      lr.torch.from_numpy(o2.astype(np.int64)))
         assert all(np.array_equal(a.numpy(), b) for a, b in zip(g, m)), kind
+
+
+def test_tuning_knobs_do_not_change_results(lr):
+    """LIDARREG_NN_STRIDE (pass-A sampling), LIDARREG_REV_STRIPS (reverse strips), LIDARREG_NN_BLOCKS (forward strips): any value gives
+    the same lists and the same transform -- each setting in its own process (the stride is read once per process)."""
+    import hashlib, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, hashlib, numpy as np, torch\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "from lidarregistration_amd import FR, synth, matching\n"
+        "from tests.conftest import Args\n"
+        "p = synth.make_pair(N=9000, N1=7000, rho=0.4, s=0.8, seed=77)\n"
+        "t = torch.from_numpy\n"
+        "i0, i1, i2, _ = matching.find_2nn(t(p['feats0']), t(p['feats1']))\n"
+        "m = matching.nn_to_mutual(t(p['feats0']), t(p['feats1']), i0, i1, i2)\n"
+        "a = Args(mode='MNN', codebase='open3D', iters=3000, ransac_n=3, o3d_conf=1.0)\n"
+        "T = FR.FR(t(p['xyz0']), t(p['xyz1']), t(p['feats0']), t(p['feats1']), a, p['T_gt'])[0]\n"
+        "h = hashlib.sha256()\n"
+        "for x in (i1, i2, m[0], m[1]): h.update(np.ascontiguousarray(x.numpy()).tobytes())\n"
+        "h.update(np.ascontiguousarray(T).tobytes())\n"
+        "print('HASH', h.hexdigest())\n")
+    def run(extra):
+        env = dict(os.environ, **extra)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-1500:]
+        return [l for l in r.stdout.splitlines() if l.startswith("HASH")][0]
+    ref = run({})
+    for extra in ({"LIDARREG_NN_STRIDE": "1"}, {"LIDARREG_NN_STRIDE": "16"}, {"LIDARREG_REV_STRIPS": "1"}, {"LIDARREG_REV_STRIPS": "64"},
+                  {"LIDARREG_NN_BLOCKS": "64"}, {"LIDARREG_NN_BLOCKS": "4096"}):
+        assert run(extra) == ref, extra
