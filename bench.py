@@ -237,6 +237,7 @@ def main():
     # ---- sanity of what was timed: every distinct pair of the last step registered correctly (from the host copy of T)
     recall = recall5 = None
     nn_fallback_rows = None
+    score_frac = None
     n_corr_mean = n_valid_mean = 0.0
     if not dry:
         ok = ok5 = 0
@@ -249,6 +250,7 @@ def main():
         res = [_ext.PairResult.from_buffer_copy(outs[i].cpu().numpy().tobytes()) for i in range(args.pairs)]
         n_corr_mean = float(np.mean([r.n_corr for r in res])); n_valid_mean = float(np.mean([r.ransac.n_valid for r in res]))
         nn_fallback_rows = float(np.mean([r.n_nn_fixed for r in res]))
+        score_frac = float(np.mean([r.reserved[0] for r in res])) / 1e6      # (model, correspondence) evaluations done / V*M (pilot-ordered scoring)
     elif use_dist:
         g = gathered.view(world, args.pairs, shard.ROW)[:, 0, 22]
         assert [float(v) for v in g] == [float(np.frombuffer(bytes([r + 1] * 8), np.float64)[0]) for r in range(world)], "gather order"
@@ -316,6 +318,7 @@ def main():
             "recall_2deg_0.6m": None if recall is None else round(recall, 4), "recall_5deg_0.6m": None if recall5 is None else round(recall5, 4),
             "host_enqueue_ms_per_step": round(enq[0] / args.steps * 1e3, 3),
             "nn_rows_redone_by_full_scan_per_pair": nn_fallback_rows,
+            "ransac_score_evaluations_frac_of_VxM": score_frac,
             "roofline": roof, "pair_roofline": pair_roof, "cpu_baseline": cpu,
         }
         if dry:

@@ -43,6 +43,7 @@ __host__ __device__ static inline int lr_seg_cap(int strips) { const int c = (LR
 // (hypothesis group, correspondence chunk) from the live counts on device.
 #define LR_SCORE_BLOCKS 8192
 #define LR_GPF_MAX_CELLS 4096
+#define LR_SC_INFO_BYTES 2048
 // f16 filter path: pass A samples every LR_NN16_STRIDE-th column tile; candidate list capacity per row
 #define LR_NN16_STRIDE 4
 enum { LR_NN_PATH_F16_FILTER = 0, LR_NN_PATH_FP32_MFMA = 1 };
@@ -142,6 +143,13 @@ struct lr_workspace {
     unsigned long long *score_ssq; // [max_iters]
     double *refit_part;          // [blocks][16] moment partials
     int32_t *lo_list;            // [max_n0] inlier list of the model under local optimisation
+    // pilot-ordered scoring (lr_ransac.hip, "score"): head / order passes -> main pass
+    void *sc_info;               // lr_score_info (LR_SC_INFO_BYTES)
+    float *corr8s;               // the records behind the head, sorted by their residual under the pilot model (layout of corr8)
+    int32_t *sc_perm;            // [max_iters] model slots by descending reach
+    float *models_s;             // [12][max_iters] the fp32 models in that order
+    int32_t *sc_glen;            // [max_iters/64+1] records every group of 64 sorted models has to scan
+    uint8_t *sc_mb, *sc_cb;      // [max_iters] reach bucket per model, [max_n0] residual bucket per correspondence
     lr_ransac_result *res_tmp;
     double *T_tmp;               // [32]
     // --- ICP ---
@@ -193,6 +201,8 @@ struct lr_ransac_state {
     // statistics of the models rejected so far
     double sprt_eps, sprt_delta;
     unsigned long long rej_inl, rej_pts;
+    // statistics of the scoring passes: (model, correspondence) evaluations done / what scanning every list in full would take
+    unsigned long long evals, evals_full;
 };
 static_assert(sizeof(lr_ransac_state) <= (LR_CNT_TOTAL - LR_CNT_COUNT) * sizeof(int32_t), "lr_ransac_state does not fit");
 

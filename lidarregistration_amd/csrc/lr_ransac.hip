@@ -20,6 +20,7 @@
 // Arithmetic is spelled out op by op and must stay identical to oracle/oracle.c (build: -ffp-contract=off).
 #include "lr_internal.h"
 #include <math.h>
+#define LR_INF_F __builtin_huge_valf()
 
 // ------------------------------------------------------------------ Philox4x32-10
 __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1)
@@ -162,6 +163,37 @@ __device__ __forceinline__ bool hypothesis_sample(const float *__restrict__ corr
     return ok;
 }
 
+// ------------------------------------------------------------------ pilot-ordered scoring: shared state (see "score" below)
+#define LR_SC_HEAD 256
+#define LR_SC_NB 128
+#define LR_SC_W 0.0625f
+#define LR_SC_MIN_M 2048
+#define LR_SC_MIN_V 128
+// what the head and order passes leave for the main pass (one per pair arena)
+struct lr_score_info {
+    unsigned long long pilot_key;     // max over the models of (head inliers << 32 | ~slot): the pilot
+    int32_t prune;                    // 1: corr8s / perm / glen describe this batch
+    int32_t n_sorted;                 // records in the sorted copy (M - head)
+    uint32_t box[6];                  // bounding box of the source points (lr_ford: order-preserving bit patterns; min x y z, max x y z)
+    int32_t bad;                      // a source coordinate is not finite: no pruning
+    int32_t pad;
+    int32_t hist[LR_SC_NB];           // records per residual bucket
+    int32_t fill[LR_SC_NB];           // next free position of every bucket while the sorted copy is written
+    int32_t offs[LR_SC_NB + 1];       // start of every residual bucket in the sorted copy (offs[b + 1]: its end)
+};
+// float <-> unsigned with the same order (atomicMin / atomicMax on floats of either sign)
+__device__ __forceinline__ uint32_t lr_ford(float f) { const uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float lr_ford_inv(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
+static_assert(sizeof(lr_score_info) <= LR_SC_INFO_BYTES, "lr_score_info does not fit its scratch block");
+
+__device__ __forceinline__ void lr_score_info_reset(lr_score_info *info)      // by one block of >= LR_SC_NB threads
+{
+    const int t = threadIdx.x;
+    if (t < LR_SC_NB) info->hist[t] = 0;
+    if (t < 3) { info->box[t] = 0xffffffffu; info->box[3 + t] = 0u; }
+    if (t == 0) { info->pilot_key = 0ull; info->bad = 0; info->prune = 0; }
+}
+
 // ------------------------------------------------------------------ gen
 // 256 hypothesis ids per block.  Phase 1: every thread draws its sample and runs the pre-check (cheap, ~93 % fail on
 // 3-point samples at a 40 % inlier ratio).  Phase 2: the survivors are compacted through LDS so that the expensive fp64
@@ -171,10 +203,13 @@ __global__ void __launch_bounds__(256)
 ransac_gen_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__restrict__ m_dev, lr_ransac_params p,
                   int h_begin, int h_end, float *__restrict__ models, double *__restrict__ models64, int32_t *__restrict__ model_h,
                   uint32_t *__restrict__ score_cnt, unsigned long long *__restrict__ score_ssq,
-                  int32_t *__restrict__ counters, const int32_t *__restrict__ G, int TN, int model_stride, lr_zargs z)
+                  int32_t *__restrict__ counters, const int32_t *__restrict__ G, int TN, int model_stride,
+                  lr_score_info *__restrict__ info, lr_zargs z)
 {
     __shared__ int s_pass[256];
     __shared__ int s_np, s_base;
+    lr_z(info, z, blockIdx.z);
+    if (blockIdx.x == 0) lr_score_info_reset(info);       // the scoring passes of this batch elect their pilot model afresh
     lr_z(corr8, z, blockIdx.z); lr_z(m_dev, z, blockIdx.z); lr_z(models, z, blockIdx.z); lr_z(models64, z, blockIdx.z); lr_z(model_h, z, blockIdx.z); lr_z(score_cnt, z, blockIdx.z); lr_z(score_ssq, z, blockIdx.z); lr_z(counters, z, blockIdx.z); lr_z(G, z, blockIdx.z);
     const int m = m_dev ? min(*m_dev, m_max) : m_max;
     if (m <= 0 || reinterpret_cast<const lr_ransac_state *>(counters + LR_CNT_COUNT)->done) return;
@@ -290,13 +325,91 @@ ransac_sprt_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__
 
 // ------------------------------------------------------------------ score
 // Work items = (group of 64 hypotheses) x (chunk of correspondences); blocks stride over them.
+//
+// Pilot-ordered scoring (exact; the oracle scores everything and gets the same integers).  Most of the models that pass the
+// pre-check are GOOD models -- all-inlier samples: 83 % of the survivors on the benchmark pair -- and they agree with each other
+// to within the sensor noise, so they share their inlier set: scoring each of them over all M correspondences re-discovers the
+// same 60 % of outliers thousands of times.  For two models v, * and a correspondence (p, q):
+//     |T_v p - q| >= |T_* p - q| - |T_v p - T_* p|  >=  r_*(p, q) - eps_v,     eps_v = |R_v - R_*|_F rho + |(R_v - R_*) c0 + t_v - t_*|
+// (c0, rho: centre and radius of a ball around the source points), so (p, q) can only be an inlier of v when r_* < thr + eps_v.
+//   head    every model over the first LR_SC_HEAD correspondences in list order; the model with the most inliers there is the
+//           pilot * (ransac_score_kernel<1>)
+//   order   residuals r_* of the other correspondences -> LR_SC_NB buckets of LR_SC_W metres -> a copy of the records sorted
+//           by bucket; per model the last bucket it has to look at, and the models sorted by that bucket, longest first
+//           (ransac_order_kernel: one block per pair)
+//   main    a group of 64 models of similar reach scans its prefix of the sorted records (ransac_score_kernel<0>)
+// Counts and error sums are integer sums over the inliers, so neither the order of the records nor the skipped outliers change
+// them.  A pilot that is a bad model only costs the saving (eps is large for everyone), never the result.  Rounding: r_*, eps
+// and the scoring arithmetic are fp32 evaluations of quantities of the size of the coordinates; `slack` (1 cm + 4e-6 of that
+// size) is two orders of magnitude above their rounding errors.  Not worth its set-up below LR_SC_MIN_M correspondences or
+// LR_SC_MIN_V models: then the head is empty and the main pass scans the list as it lies.
 #ifndef LR_SCORE_CHUNK
-#define LR_SCORE_CHUNK 128
+#define LR_SCORE_CHUNK 256
 #endif
+__device__ __forceinline__ int lr_sc_head(int m, int V) { return (m >= LR_SC_MIN_M && V >= LR_SC_MIN_V) ? LR_SC_HEAD : 0; }
+
+// one lane's model over the records [begin, end) of a stream (begin even; a trailing odd correspondence is taken alone)
+struct lr_model12 { float r00, r01, r02, tx, r10, r11, r12, ty, r20, r21, r22, tz; };
+__device__ __forceinline__ lr_model12 lr_load_model(const float *__restrict__ mp, size_t ms)
+{
+    lr_model12 M;
+    M.r00 = mp[0]; M.r01 = mp[ms]; M.r02 = mp[2 * ms]; M.tx = mp[3 * ms];
+    M.r10 = mp[4 * ms]; M.r11 = mp[5 * ms]; M.r12 = mp[6 * ms]; M.ty = mp[7 * ms];
+    M.r20 = mp[8 * ms]; M.r21 = mp[9 * ms]; M.r22 = mp[10 * ms]; M.tz = mp[11 * ms];
+    return M;
+}
+__device__ __forceinline__ float lr_model_d2(const lr_model12 &M, const float *__restrict__ corr8, int i)
+{
+    const float px = corr8[lr_corr_at(i, 0)], py = corr8[lr_corr_at(i, 1)], pz = corr8[lr_corr_at(i, 2)];
+    const float x = __builtin_fmaf(M.r00, px, __builtin_fmaf(M.r01, py, __builtin_fmaf(M.r02, pz, M.tx)));
+    const float y = __builtin_fmaf(M.r10, px, __builtin_fmaf(M.r11, py, __builtin_fmaf(M.r12, pz, M.ty)));
+    const float z = __builtin_fmaf(M.r20, px, __builtin_fmaf(M.r21, py, __builtin_fmaf(M.r22, pz, M.tz)));
+    const float dx = x - corr8[lr_corr_at(i, 3)], dy = y - corr8[lr_corr_at(i, 4)], dz = z - corr8[lr_corr_at(i, 5)];
+    return __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
+}
+__device__ __forceinline__ void lr_score_stream(const float *__restrict__ corr8, int begin, int end, int sub, float thr2,
+                                                const lr_model12 &M, uint32_t &cnt, unsigned long long &ssq)
+{
+    // two correspondences per iteration: the record of a pair is wave-uniform (scalar load) and its halves feed
+    // packed fp32 instructions directly; every component keeps the fma order of the arithmetic contract.
+    // The error sum runs in 32 bits over sub-blocks short enough not to overflow (sub * thr2 * 2^20 < 2^32).
+    const f32x2 *rec = reinterpret_cast<const f32x2 *>(corr8);
+    const f32x2 R00 = { M.r00, M.r00 }, R01 = { M.r01, M.r01 }, R02 = { M.r02, M.r02 }, TX = { M.tx, M.tx };
+    const f32x2 R10 = { M.r10, M.r10 }, R11 = { M.r11, M.r11 }, R12 = { M.r12, M.r12 }, TY = { M.ty, M.ty };
+    const f32x2 R20 = { M.r20, M.r20 }, R21 = { M.r21, M.r21 }, R22 = { M.r22, M.r22 }, TZ = { M.tz, M.tz };
+    const f32x2 SC = { 1048576.0f, 1048576.0f };
+    const int pend = end & ~1;
+    for (int b0 = begin; b0 < pend; b0 += sub) {
+        const int b1 = min(pend, b0 + sub);
+        uint32_t q32 = 0;
+#pragma unroll 4
+        for (int i = b0; i < b1; i += 2) {
+            const f32x2 *q = rec + (size_t)(i >> 1) * 8;
+            const f32x2 px = q[0], py = q[1], pz = q[2], qx = q[3], qy = q[4], qz = q[5];
+            const f32x2 x = __builtin_elementwise_fma(R00, px, __builtin_elementwise_fma(R01, py, __builtin_elementwise_fma(R02, pz, TX)));
+            const f32x2 y = __builtin_elementwise_fma(R10, px, __builtin_elementwise_fma(R11, py, __builtin_elementwise_fma(R12, pz, TY)));
+            const f32x2 z = __builtin_elementwise_fma(R20, px, __builtin_elementwise_fma(R21, py, __builtin_elementwise_fma(R22, pz, TZ)));
+            const f32x2 dx = x - qx, dy = y - qy, dz = z - qz;
+            const f32x2 d2 = __builtin_elementwise_fma(dx, dx, __builtin_elementwise_fma(dy, dy, dz * dz));
+            const f32x2 fx = d2 * SC;
+            const bool in0 = d2.x < thr2, in1 = d2.y < thr2;
+            cnt += (in0 ? 1u : 0u) + (in1 ? 1u : 0u);
+            q32 += (in0 ? (uint32_t)fx.x : 0u) + (in1 ? (uint32_t)fx.y : 0u);
+        }
+        ssq += q32;
+    }
+    if (pend < end && begin < end) {      // (a chunk past the end -- begin > end -- owns nothing, not even the odd last correspondence)
+        const float d2 = lr_model_d2(M, corr8, pend);
+        if (d2 < thr2) { cnt += 1u; ssq += (uint32_t)(d2 * 1048576.0f); }
+    }
+}
+
+template <int HEAD>
 __global__ void __launch_bounds__(256)
-ransac_score_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__restrict__ m_dev, float thr2,
-                    const float *__restrict__ models, uint32_t *__restrict__ score_cnt,
-                    unsigned long long *__restrict__ score_ssq, const int32_t *__restrict__ counters, int sub, int model_stride, int vslot,
+ransac_score_kernel(const float *__restrict__ corr8, const float *__restrict__ corr8s, int m_max, const int32_t *__restrict__ m_dev, float thr2,
+                    const float *__restrict__ models, const float *__restrict__ models_s, uint32_t *__restrict__ score_cnt,
+                    unsigned long long *__restrict__ score_ssq, const int32_t *__restrict__ counters, lr_score_info *__restrict__ info,
+                    const int32_t *__restrict__ perm, const int32_t *__restrict__ glen, int sub, int model_stride, int vslot,
                     int gx, int total, lr_zargs z)
 {
     // 1-D XCD-aware grid -> (block of the pair, pair): the blocks of one pair run on one XCD, whose L2 then serves the pair's
@@ -304,73 +417,250 @@ ransac_score_kernel(const float *__restrict__ corr8, int m_max, const int32_t *_
     int logical;
     if (!lr_xcd_block(total, logical)) return;
     const int bxi = logical % gx, pair = logical / gx;
-    lr_z(corr8, z, pair); lr_z(m_dev, z, pair); lr_z(models, z, pair); lr_z(score_cnt, z, pair); lr_z(score_ssq, z, pair); lr_z(counters, z, pair);
+    lr_z(corr8, z, pair); lr_z(corr8s, z, pair); lr_z(m_dev, z, pair); lr_z(models, z, pair); lr_z(models_s, z, pair); lr_z(score_cnt, z, pair); lr_z(score_ssq, z, pair);
+    lr_z(counters, z, pair); lr_z(info, z, pair); lr_z(perm, z, pair); lr_z(glen, z, pair);
     const int m = m_dev ? min(*m_dev, m_max) : m_max;
     const int V = counters[vslot];           // LR_CNT_NVALID, or LR_CNT_NVALID2 behind the SPRT pre-verification
     const int hb = (V + 63) >> 6;
     if (hb == 0 || m <= 0 || reinterpret_cast<const lr_ransac_state *>(counters + LR_CNT_COUNT)->done) return;
+    const int K0 = lr_sc_head(m, V);
+    const int lane = threadIdx.x & 63;
+    const size_t ms = (size_t)model_stride;
     // a block is four independent waves (one-wave blocks cap the CU at half its wave slots); wave w of the pair's gx blocks takes
     // the work items w, w + W, ...
-    const int W = gx * 4;
+    // (the wave index is wave-uniform, which the compiler cannot see through threadIdx: without the readfirstlane the record
+    // loads become per-lane global loads with VALU address arithmetic instead of scalar loads)
+    const int W = gx * 4, w0 = bxi * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    if (HEAD) {
+        if (K0 == 0) return;
+        for (int g = w0; g < hb; g += W) {
+            const int slot = g * 64 + lane;
+            const bool active = slot < V;
+            const lr_model12 M = lr_load_model(models + (active ? slot : 0), ms);
+            uint32_t cnt = 0; unsigned long long ssq = 0;
+            lr_score_stream(corr8, 0, K0, sub, thr2, M, cnt, ssq);
+            unsigned long long key = 0ull;
+            if (active) {
+                if (cnt) { atomicAdd(&score_cnt[slot], cnt); atomicAdd(&score_ssq[slot], ssq); }
+                key = ((unsigned long long)cnt << 32) | (unsigned long long)(0xffffffffu - (uint32_t)slot);
+            }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) { const unsigned long long k2 = __shfl_xor(key, o); key = k2 > key ? k2 : key; }
+            if (lane == 0) atomicMax(&info->pilot_key, key);
+        }
+        return;
+    }
+    const bool prune = K0 > 0;
+    const float *__restrict__ stream = prune ? corr8s : corr8;
+    const int L = prune ? m - K0 : m;
     int chunks = W / hb;
-    const int cmax = m / LR_SCORE_CHUNK > 0 ? m / LR_SCORE_CHUNK : 1;   // at least LR_SCORE_CHUNK correspondences per work item
+    const int cmax = L / LR_SCORE_CHUNK > 0 ? L / LR_SCORE_CHUNK : 1;   // at least LR_SCORE_CHUNK correspondences per work item
     if (chunks > cmax) chunks = cmax;
     if (chunks < 1) chunks = 1;
-    const int per = ((m + chunks - 1) / chunks + 1) & ~1;      // even: chunks start on a pair boundary
-    const int lane = threadIdx.x & 63;
-    // the wave index is wave-uniform, which the compiler cannot see through threadIdx: without the readfirstlane the record
-    // loads below become per-lane global loads with VALU address arithmetic instead of scalar loads
-    for (int w = bxi * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6); w < hb * chunks; w += W) {
+    const int per = ((L + chunks - 1) / chunks + 1) & ~1;      // even: chunks start on a pair boundary
+    for (int w = w0; w < hb * chunks; w += W) {
         const int g = w % hb, c = w / hb;
-        const int slot = g * 64 + lane;
-        const bool active = slot < V;
-        const float *mp = models + (active ? slot : 0);
-        const size_t ms = (size_t)model_stride;
-        const float r00 = mp[0], r01 = mp[ms], r02 = mp[2 * ms], tx = mp[3 * ms];
-        const float r10 = mp[4 * ms], r11 = mp[5 * ms], r12 = mp[6 * ms], ty = mp[7 * ms];
-        const float r20 = mp[8 * ms], r21 = mp[9 * ms], r22 = mp[10 * ms], tz = mp[11 * ms];
-        const int begin = c * per, end = min(m, begin + per);
+        const int len = prune ? min(glen[g], (L + 1) & ~1) : L;      // records this group has to look at
+        const int begin = c * per, end = min(len, begin + per);
+        if (begin >= end) continue;
+        const int spos = g * 64 + lane;        // position in the model order of this batch's scoring (reach-sorted, or the list as it lies)
+        const bool active = spos < V;
+        const lr_model12 M = lr_load_model((prune ? models_s : models) + (active ? spos : 0), ms);
         uint32_t cnt = 0;
         unsigned long long ssq = 0;
-        // two correspondences per iteration: the record of a pair is wave-uniform (scalar load) and its halves feed
-        // packed fp32 instructions directly; every component keeps the fma order of the arithmetic contract.
-        // The error sum runs in 32 bits over sub-blocks short enough not to overflow (sub * thr2 * 2^20 < 2^32).
-        const f32x2 *rec = reinterpret_cast<const f32x2 *>(corr8);
-        const f32x2 R00 = { r00, r00 }, R01 = { r01, r01 }, R02 = { r02, r02 }, TX = { tx, tx };
-        const f32x2 R10 = { r10, r10 }, R11 = { r11, r11 }, R12 = { r12, r12 }, TY = { ty, ty };
-        const f32x2 R20 = { r20, r20 }, R21 = { r21, r21 }, R22 = { r22, r22 }, TZ = { tz, tz };
-        const f32x2 SC = { 1048576.0f, 1048576.0f };
-        const int pend = end & ~1;                       // `begin` is even; a trailing odd correspondence is done alone below
-        for (int b0 = begin; b0 < pend; b0 += sub) {
-            const int b1 = min(pend, b0 + sub);
-            uint32_t q32 = 0;
-#pragma unroll 4
-            for (int i = b0; i < b1; i += 2) {
-                const f32x2 *q = rec + (size_t)(i >> 1) * 8;
-                const f32x2 px = q[0], py = q[1], pz = q[2], qx = q[3], qy = q[4], qz = q[5];
-                const f32x2 x = __builtin_elementwise_fma(R00, px, __builtin_elementwise_fma(R01, py, __builtin_elementwise_fma(R02, pz, TX)));
-                const f32x2 y = __builtin_elementwise_fma(R10, px, __builtin_elementwise_fma(R11, py, __builtin_elementwise_fma(R12, pz, TY)));
-                const f32x2 z = __builtin_elementwise_fma(R20, px, __builtin_elementwise_fma(R21, py, __builtin_elementwise_fma(R22, pz, TZ)));
-                const f32x2 dx = x - qx, dy = y - qy, dz = z - qz;
-                const f32x2 d2 = __builtin_elementwise_fma(dx, dx, __builtin_elementwise_fma(dy, dy, dz * dz));
-                const f32x2 fx = d2 * SC;
-                const bool in0 = d2.x < thr2, in1 = d2.y < thr2;
-                cnt += (in0 ? 1u : 0u) + (in1 ? 1u : 0u);
-                q32 += (in0 ? (uint32_t)fx.x : 0u) + (in1 ? (uint32_t)fx.y : 0u);
-            }
-            ssq += q32;
+        lr_score_stream(stream, begin, end, sub, thr2, M, cnt, ssq);
+        if (active && cnt) {
+            const int slot = prune ? perm[spos] : spos;
+            atomicAdd(&score_cnt[slot], cnt); atomicAdd(&score_ssq[slot], ssq);
         }
-        if (pend < end && begin < end) {      // (a chunk past the end -- begin > m -- owns nothing, not even the odd last correspondence)
-            const int i = pend;
-            const float px = corr8[lr_corr_at(i, 0)], py = corr8[lr_corr_at(i, 1)], pz = corr8[lr_corr_at(i, 2)];
-            float x = __builtin_fmaf(r00, px, __builtin_fmaf(r01, py, __builtin_fmaf(r02, pz, tx)));
-            float y = __builtin_fmaf(r10, px, __builtin_fmaf(r11, py, __builtin_fmaf(r12, pz, ty)));
-            float z = __builtin_fmaf(r20, px, __builtin_fmaf(r21, py, __builtin_fmaf(r22, pz, tz)));
-            float dx = x - corr8[lr_corr_at(i, 3)], dy = y - corr8[lr_corr_at(i, 4)], dz = z - corr8[lr_corr_at(i, 5)];
-            float d2 = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
-            if (d2 < thr2) { cnt += 1u; ssq += (uint32_t)(d2 * 1048576.0f); }
+    }
+}
+
+// order pass, part 1 (a thread per correspondence): residual under the pilot model -> bucket; bucket histogram and the bounding box of
+// the source points through one atomic per block and value
+__global__ void __launch_bounds__(256)
+ransac_resid_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__restrict__ m_dev, const float *__restrict__ models,
+                    const int32_t *__restrict__ counters, lr_score_info *__restrict__ info, uint8_t *__restrict__ cb, int model_stride, int vslot, lr_zargs z)
+{
+    __shared__ int s_h[LR_SC_NB];
+    __shared__ float s_red[4][6];
+    __shared__ int s_bad;
+    lr_z(corr8, z, blockIdx.z); lr_z(m_dev, z, blockIdx.z); lr_z(models, z, blockIdx.z); lr_z(counters, z, blockIdx.z); lr_z(info, z, blockIdx.z); lr_z(cb, z, blockIdx.z);
+    const int m = m_dev ? min(*m_dev, m_max) : m_max;
+    const int V = counters[vslot];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = blockIdx.x * 256 + tid;
+    if (V <= 0 || blockIdx.x * 256 >= m || reinterpret_cast<const lr_ransac_state *>(counters + LR_CNT_COUNT)->done) return;
+    const int K0 = lr_sc_head(m, V);
+    if (K0 == 0) return;
+    if (tid < LR_SC_NB) s_h[tid] = 0;
+    if (tid == 0) s_bad = 0;
+    __syncthreads();
+    int ps = (int)(0xffffffffu - (uint32_t)info->pilot_key);
+    ps = min(max(ps, 0), V - 1);
+    const lr_model12 P = lr_load_model(models + ps, (size_t)model_stride);
+    float lo[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, hi[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
+    if (c < m) {
+        bool bad = false;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { const float v = corr8[lr_corr_at(c, a)]; bad |= !(fabsf(v) < 3.0e38f); lo[a] = v; hi[a] = v; }
+        if (bad) s_bad = 1;
+        if (c >= K0) {
+            constexpr float INVW = 1.0f / LR_SC_W, RMAX = LR_SC_NB * LR_SC_W;
+            const float r = sqrtf(lr_model_d2(P, corr8, c));
+            int b = LR_SC_NB - 1;
+            if (r < RMAX) b = min((int)(r * INVW), LR_SC_NB - 1);      // (NaN, inf: last bucket)
+            cb[c] = (uint8_t)b;
+            atomicAdd(&s_h[b], 1);
         }
-        if (active && cnt) { atomicAdd(&score_cnt[slot], cnt); atomicAdd(&score_ssq[slot], ssq); }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], o)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o)); }
+    if (lane == 0) { for (int a = 0; a < 3; ++a) { s_red[wave][a] = lo[a]; s_red[wave][3 + a] = hi[a]; } }
+    __syncthreads();
+    if (tid < LR_SC_NB && s_h[tid]) atomicAdd(&info->hist[tid], s_h[tid]);
+    if (tid < 6) {
+        float v = s_red[0][tid];
+        for (int w = 1; w < 4; ++w) v = tid < 3 ? fminf(v, s_red[w][tid]) : fmaxf(v, s_red[w][tid]);
+        if (tid < 3) atomicMin(&info->box[tid], lr_ford(v)); else atomicMax(&info->box[tid], lr_ford(v));
+    }
+    if (tid == 0 && s_bad) info->bad = 1;
+}
+
+// order pass, part 2 (one block per pair): bucket offsets; reach of every model = the last bucket it has to look at; models sorted by
+// reach, longest first; records every group of 64 sorted models scans
+__global__ void __launch_bounds__(1024)
+ransac_order_kernel(int m_max, const int32_t *__restrict__ m_dev, float thr2, const float *__restrict__ models, int32_t *__restrict__ counters,
+                    lr_score_info *__restrict__ info, int32_t *__restrict__ perm, int32_t *__restrict__ glen, uint8_t *__restrict__ mb,
+                    float *__restrict__ models_s, int model_stride, int vslot, lr_zargs z)
+{
+    __shared__ int s_h[LR_SC_NB], s_off[LR_SC_NB + 1], s_fill[LR_SC_NB];
+    __shared__ unsigned long long s_ev[16];
+    lr_z(m_dev, z, blockIdx.z); lr_z(models, z, blockIdx.z); lr_z(counters, z, blockIdx.z); lr_z(models_s, z, blockIdx.z);
+    lr_z(info, z, blockIdx.z); lr_z(perm, z, blockIdx.z); lr_z(glen, z, blockIdx.z); lr_z(mb, z, blockIdx.z);
+    lr_ransac_state *state = reinterpret_cast<lr_ransac_state *>(counters + LR_CNT_COUNT);
+    const int m = m_dev ? min(*m_dev, m_max) : m_max;
+    const int V = counters[vslot];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (V <= 0 || m <= 0 || state->done) return;
+    const int K0 = lr_sc_head(m, V);
+    if (K0 == 0) return;      // the main pass scans the list as it lies (prune stays 0)
+    const size_t ms = (size_t)model_stride;
+    int ps = (int)(0xffffffffu - (uint32_t)info->pilot_key);
+    ps = min(max(ps, 0), V - 1);
+    const lr_model12 P = lr_load_model(models + ps, ms);
+    // exclusive scan of the bucket histogram: wave 0, two buckets per lane
+    if (tid < 64) {
+        const int h0 = info->hist[2 * tid], h1 = info->hist[2 * tid + 1];
+        int inc = h0 + h1;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o); if (tid >= o) inc += v; }
+        const int ex = inc - (h0 + h1);
+        s_off[2 * tid] = ex; s_off[2 * tid + 1] = ex + h0;
+        info->offs[2 * tid] = ex; info->offs[2 * tid + 1] = ex + h0;
+        info->fill[2 * tid] = ex; info->fill[2 * tid + 1] = ex + h0;
+        if (tid == 63) { s_off[LR_SC_NB] = inc; info->offs[LR_SC_NB] = inc; }
+    }
+    if (tid < LR_SC_NB) s_h[tid] = 0;
+    __syncthreads();
+    // ball around the source points: centre and half diagonal of their bounding box
+    const float b0 = lr_ford_inv(info->box[0]), b1 = lr_ford_inv(info->box[1]), b2 = lr_ford_inv(info->box[2]);
+    const float b3 = lr_ford_inv(info->box[3]), b4 = lr_ford_inv(info->box[4]), b5 = lr_ford_inv(info->box[5]);
+    const float cx = 0.5f * (b0 + b3), cy = 0.5f * (b1 + b4), cz = 0.5f * (b2 + b5);
+    const float ex = b3 - b0, ey = b4 - b1, ez = b5 - b2;
+    float rho = 0.5f * sqrtf(ex * ex + ey * ey + ez * ez) * 1.0001f + 1e-6f;
+    if (info->bad) rho = LR_INF_F;                       // a non-finite coordinate: every model keeps the whole list (eps below is inf or NaN)
+    const float amax = fmaxf(fmaxf(fmaxf(fabsf(b0), fabsf(b3)), fmaxf(fabsf(b1), fabsf(b4))), fmaxf(fabsf(b2), fabsf(b5)));
+    constexpr float INVW = 1.0f / LR_SC_W, RMAX = LR_SC_NB * LR_SC_W;
+    const float thr = sqrtf(thr2);
+    const float pt1 = fabsf(P.tx) + fabsf(P.ty) + fabsf(P.tz);
+    for (int v = tid; v < V; v += 1024) {
+        const lr_model12 M = lr_load_model(models + v, ms);
+        const float d00 = M.r00 - P.r00, d01 = M.r01 - P.r01, d02 = M.r02 - P.r02, d10 = M.r10 - P.r10, d11 = M.r11 - P.r11, d12 = M.r12 - P.r12,
+                    d20 = M.r20 - P.r20, d21 = M.r21 - P.r21, d22 = M.r22 - P.r22;
+        const float F = sqrtf(d00 * d00 + d01 * d01 + d02 * d02 + d10 * d10 + d11 * d11 + d12 * d12 + d20 * d20 + d21 * d21 + d22 * d22);
+        const float ux = d00 * cx + d01 * cy + d02 * cz + (M.tx - P.tx), uy = d10 * cx + d11 * cy + d12 * cz + (M.ty - P.ty),
+                    uz = d20 * cx + d21 * cy + d22 * cz + (M.tz - P.tz);
+        const float eps = (F * rho + sqrtf(ux * ux + uy * uy + uz * uz)) * 1.001f;
+        const float slack = 0.01f + 4e-6f * (3.0f * amax + pt1 + fabsf(M.tx) + fabsf(M.ty) + fabsf(M.tz));
+        const float cut = thr + eps + slack;
+        int bv = LR_SC_NB - 1;
+        if (cut < RMAX) bv = min((int)(cut * INVW), LR_SC_NB - 1);      // (NaN, inf: everything)
+        mb[v] = (uint8_t)bv;
+        atomicAdd(&s_h[LR_SC_NB - 1 - bv], 1);      // longest reach first
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int h0 = s_h[2 * tid], h1 = s_h[2 * tid + 1];
+        int inc = h0 + h1;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o); if (tid >= o) inc += v; }
+        s_fill[2 * tid] = inc - (h0 + h1); s_fill[2 * tid + 1] = inc - h1;
+    }
+    __syncthreads();
+    // the models in that order: a copy (the main pass then reads a group's 64 models with coalesced loads) and the way back to their slots
+    for (int v = tid; v < V; v += 1024) {
+        const int pos = atomicAdd(&s_fill[LR_SC_NB - 1 - (int)mb[v]], 1);
+        perm[pos] = v;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) models_s[(size_t)k * ms + pos] = models[(size_t)k * ms + v];
+    }
+    __syncthreads();
+    const int L = m - K0;
+    const int hb = (V + 63) >> 6;
+    unsigned long long ev = 0;
+    for (int g = tid; g < hb; g += 1024) {
+        const int len = (s_off[(int)mb[perm[g * 64]] + 1] + 1) & ~1;       // the group's first model reaches furthest
+        glen[g] = len;
+        ev += (unsigned long long)min(len, L) * (unsigned long long)min(64, V - g * 64);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) ev += __shfl_xor(ev, o);
+    if (lane == 0) s_ev[wave] = ev;
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 16; ++w) ev += s_ev[w];
+        state->evals += ev + (unsigned long long)V * (unsigned long long)K0;
+        state->evals_full += (unsigned long long)V * (unsigned long long)m;
+        info->prune = 1; info->n_sorted = L;
+    }
+}
+
+// order pass, part 3 (a thread per correspondence): the records behind the head copied in bucket order (within a bucket in any order:
+// the sums are integers).  A block reserves its share of every bucket with one atomic, its threads take positions inside that.
+__global__ void __launch_bounds__(256)
+ransac_scatter_kernel(const float *__restrict__ corr8, float *__restrict__ corr8s, int m_max, const int32_t *__restrict__ m_dev,
+                      const int32_t *__restrict__ counters, lr_score_info *__restrict__ info, const uint8_t *__restrict__ cb, int vslot, lr_zargs z)
+{
+    __shared__ int s_h[LR_SC_NB], s_base[LR_SC_NB];
+    lr_z(corr8, z, blockIdx.z); lr_z(corr8s, z, blockIdx.z); lr_z(m_dev, z, blockIdx.z); lr_z(counters, z, blockIdx.z); lr_z(info, z, blockIdx.z); lr_z(cb, z, blockIdx.z);
+    const int m = m_dev ? min(*m_dev, m_max) : m_max;
+    const int V = counters[vslot];
+    const int tid = threadIdx.x;
+    const int c = blockIdx.x * 256 + tid;
+    if (V <= 0 || blockIdx.x * 256 >= m || reinterpret_cast<const lr_ransac_state *>(counters + LR_CNT_COUNT)->done) return;
+    const int K0 = lr_sc_head(m, V);
+    if (K0 == 0) return;
+    if (tid < LR_SC_NB) s_h[tid] = 0;
+    __syncthreads();
+    const bool live = c >= K0 && c < m;
+    const int b = live ? (int)cb[c] : 0;
+    int rank = 0;
+    if (live) rank = atomicAdd(&s_h[b], 1);
+    __syncthreads();
+    if (tid < LR_SC_NB && s_h[tid]) s_base[tid] = atomicAdd(&info->fill[tid], s_h[tid]);
+    __syncthreads();
+    if (live) {
+        const int pos = s_base[b] + rank;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) corr8s[lr_corr_at(pos, k)] = corr8[lr_corr_at(c, k)];
+    }
+    const int L = m - K0;
+    if (blockIdx.x == 0 && tid == 0 && (L & 1)) {      // an odd list ends with a record that is nobody's inlier
+#pragma unroll
+        for (int k = 0; k < 6; ++k) corr8s[lr_corr_at(L, k)] = k < 3 ? 0.0f : 3.0e38f;
     }
 }
 
@@ -956,12 +1246,13 @@ int lr_ransac_run(lr_workspace *ws, const float *corr8, int m_max, const int32_t
         const int h0 = (int)h0l;
         const int h1 = h0l + B < p->iters ? (int)(h0l + B) : p->iters;
         const int gb = lr_cdiv(h1 - h0 > 0 ? h1 - h0 : 1, 256);
+        lr_score_info *info = reinterpret_cast<lr_score_info *>(ws->sc_info);
         if (p->sample_size == 3)
             hipLaunchKernelGGL(ransac_gen_kernel<3>, dim3(gb, 1, ws->zP), dim3(256), 0, st, corr8, m_max, m_dev, *p, h0, h1, ws->models, ws->models64,
-                               ws->model_h, ws->score_cnt, ws->score_ssq, ws->counters, G, TN, ws->max_iters, ws->z);
+                               ws->model_h, ws->score_cnt, ws->score_ssq, ws->counters, G, TN, ws->max_iters, info, ws->z);
         else
             hipLaunchKernelGGL(ransac_gen_kernel<4>, dim3(gb, 1, ws->zP), dim3(256), 0, st, corr8, m_max, m_dev, *p, h0, h1, ws->models, ws->models64,
-                               ws->model_h, ws->score_cnt, ws->score_ssq, ws->counters, G, TN, ws->max_iters, ws->z);
+                               ws->model_h, ws->score_cnt, ws->score_ssq, ws->counters, G, TN, ws->max_iters, info, ws->z);
         const bool sprt = p->use_elc == 2;
         if (sprt)       // every estimated model is pre-verified; the survivors form a second dense list that is scored in full
             hipLaunchKernelGGL(ransac_sprt_kernel, dim3(lr_cdiv(gb * 256, 256), 1, ws->zP), dim3(256), 0, st, corr8, m_max, m_dev, p->thr2,
@@ -969,12 +1260,28 @@ int lr_ransac_run(lr_workspace *ws, const float *corr8, int m_max, const int32_t
                                ws->score_cnt, ws->score_ssq, ws->counters, ws->max_iters, ws->z);
         const int vslot = sprt ? LR_CNT_NVALID2 : LR_CNT_NVALID;
         {
-            // (LR_SCORE_BLOCKS / 4 blocks for EVERY pair of a batched call: 64 per pair -- the GPU filled exactly once -- measured 32 %
-            // slower, the few large work items of a pair do not balance)
+            // pilot-ordered scoring: head (every model over the first records) -> order (one block per pair) -> main.
+            // (main: LR_SCORE_BLOCKS / 4 blocks for EVERY pair of a batched call: 64 per pair -- the GPU filled exactly once -- measured
+            // 32 % slower, the few large work items of a pair do not balance)
+            const float *mdl = sprt ? (const float *)ws->models2 : (const float *)ws->models;
+            const bool may_prune = m_max >= LR_SC_MIN_M && h1 - h0 >= LR_SC_MIN_V;      // (the device decides from the live counts)
+            if (may_prune) {
+                const int hgx = 64, htotal = hgx * ws->zP;
+                hipLaunchKernelGGL(ransac_score_kernel<1>, dim3(8 * lr_cdiv(htotal, 8)), dim3(256), 0, st, corr8, (const float *)ws->corr8s, m_max, m_dev, p->thr2,
+                                   mdl, (const float *)ws->models_s, ws->score_cnt, ws->score_ssq, ws->counters, info, (const int32_t *)ws->sc_perm, (const int32_t *)ws->sc_glen, sub,
+                                   ws->max_iters, vslot, hgx, htotal, ws->z);
+                const dim3 cgrid(lr_cdiv(m_max, 256), 1, ws->zP);
+                hipLaunchKernelGGL(ransac_resid_kernel, cgrid, dim3(256), 0, st, corr8, m_max, m_dev, mdl, (const int32_t *)ws->counters, info, ws->sc_cb,
+                                   ws->max_iters, vslot, ws->z);
+                hipLaunchKernelGGL(ransac_order_kernel, dim3(1, 1, ws->zP), dim3(1024), 0, st, m_max, m_dev, p->thr2, mdl, ws->counters, info,
+                                   ws->sc_perm, ws->sc_glen, ws->sc_mb, ws->models_s, ws->max_iters, vslot, ws->z);
+                hipLaunchKernelGGL(ransac_scatter_kernel, cgrid, dim3(256), 0, st, corr8, ws->corr8s, m_max, m_dev, (const int32_t *)ws->counters, info,
+                                   (const uint8_t *)ws->sc_cb, vslot, ws->z);
+            }
             const int sgx = LR_SCORE_BLOCKS / 4, stotal = sgx * ws->zP;
-            hipLaunchKernelGGL(ransac_score_kernel, dim3(8 * lr_cdiv(stotal, 8)), dim3(256), 0, st, corr8, m_max, m_dev, p->thr2,
-                               sprt ? (const float *)ws->models2 : (const float *)ws->models, ws->score_cnt, ws->score_ssq, ws->counters, sub, ws->max_iters,
-                               vslot, sgx, stotal, ws->z);
+            hipLaunchKernelGGL(ransac_score_kernel<0>, dim3(8 * lr_cdiv(stotal, 8)), dim3(256), 0, st, corr8, (const float *)ws->corr8s, m_max, m_dev, p->thr2,
+                               mdl, (const float *)ws->models_s, ws->score_cnt, ws->score_ssq, ws->counters, info, (const int32_t *)ws->sc_perm, (const int32_t *)ws->sc_glen, sub,
+                               ws->max_iters, vslot, sgx, stotal, ws->z);
         }
         if (h0 == 0 && ws->timing && ws->ev_pending == 1) { LR_HIP(hipEventRecord(ws->ev[3], st)); ws->ev_pending = 2; }
         hipLaunchKernelGGL(ransac_final_kernel, dim3(1, 1, ws->zP), dim3(1024), 0, st, ws->score_cnt, ws->score_ssq,
@@ -1037,6 +1344,10 @@ __device__ void refit_solve_body(const double *__restrict__ partial, int nblocks
         pair_out->n_nn_fixed = counters[LR_CNT_FIX_TOTAL];
         pair_out->status = gate->best_h < 0 ? 1 : 0;
         for (int q = 0; q < 8; ++q) pair_out->reserved[q] = 0;
+        {   // reserved[0]: (model, correspondence) evaluations of the scoring passes, in ppm of scanning every list in full (0: not recorded)
+            const lr_ransac_state *state = reinterpret_cast<const lr_ransac_state *>(counters + LR_CNT_COUNT);
+            if (state->evals_full > 0) pair_out->reserved[0] = (int32_t)((double)state->evals / (double)state->evals_full * 1e6);
+        }
         for (int k = 0; k < 16; ++k) pair_out->T_icp[k] = T[k];      // overwritten by pair_icp_kernel when the ICP stage runs
         pair_out->icp.fitness = 0.0; pair_out->icp.inlier_rmse = 0.0; pair_out->icp.n_corr = 0; pair_out->icp.iterations = 0;
     }

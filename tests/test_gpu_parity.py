@@ -281,6 +281,43 @@ def test_ransac_odd_counts_with_few_hypotheses(lr, oracle, n, iters):
     assert info == einfo and np.array_equal(T, Te)
 
 
+@pytest.mark.parametrize("case", ["far_from_origin", "few_good_models", "nonfinite", "msac_4pt", "noise_free_ties", "just_above_limits",
+                                  "odd_tail", "huge_noise", "two_motions"])
+def test_ransac_pilot_ordered_scoring_is_exact(lr, oracle, case):
+    """The scoring passes skip records a model cannot reach (csrc/lr_ransac.hip, "score": pilot model, residual buckets, reach of
+    every model); the oracle scores every model over every correspondence.  Winner id, inlier count, error sum and model must agree
+    where the pruning bound is under stress: coordinates of 1e4 m (fp32 rounding against the slack), a pilot that is a bad model,
+    non-finite coordinates, MSAC, ties decided by the error sum, sizes at the switch-on limits, an odd sorted list, inlier noise of
+    the size of the threshold, and two planted motions of similar support."""
+    kw = dict(sample_size=3, use_elc=True, seed=11)
+    n, iters, inlier, noise = 6000, 6000, 0.3, 0.05
+    if case == "few_good_models": n, iters, inlier = 9000, 30000, 0.06; kw.update(use_elc=False)
+    if case == "msac_4pt": kw.update(sample_size=4, scoring=1, use_elc=False); iters = 3000
+    if case == "just_above_limits": n, iters = 2048, 2200; kw.update(use_elc=False)
+    if case == "odd_tail": n, iters = 2305, 1000; kw.update(use_elc=False)
+    if case == "huge_noise": noise = 0.4
+    rng = np.random.default_rng(len(case))
+    src = np.concatenate([rng.uniform(-80, 80, (n, 2)), rng.uniform(-3, 5, (n, 1))], 1)
+    T_gt = synth.random_motion(rng)
+    tgt = src @ T_gt[:3, :3].T + T_gt[:3, 3] + (0.0 if case == "noise_free_ties" else rng.normal(0, noise, (n, 3)))
+    bad = rng.random(n) > inlier
+    tgt[bad] = np.concatenate([rng.uniform(-80, 80, (bad.sum(), 2)), rng.uniform(-3, 5, (bad.sum(), 1))], 1)
+    if case == "two_motions":          # a second consistent motion with nearly as many inliers
+        T2 = synth.random_motion(rng)
+        second = bad & (rng.random(n) < 0.4)
+        tgt[second] = src[second] @ T2[:3, :3].T + T2[:3, 3] + rng.normal(0, noise, (second.sum(), 3))
+    if case == "far_from_origin":
+        src = src + np.array([9000.0, -7000.0, 300.0]); tgt = tgt + np.array([-8000.0, 9500.0, -200.0])
+    src, tgt = src.astype(np.float32), tgt.astype(np.float32)
+    if case == "nonfinite":
+        src[5] = np.nan; tgt[700, 1] = np.inf; src[3000, 2] = -np.inf; tgt[4000] = np.nan
+    T, info = lr.ransac.ransac_dev(src, tgt, iters, **kw)
+    Te, einfo = oracle.ransac(src, tgt, iters, **kw)
+    assert info == einfo, (case, info, einfo)
+    assert np.array_equal(T, Te)
+    assert info["n_valid"] >= 128 and info["best_count"] > 3          # the pruned path really ran (its switch-on limits) and found something
+
+
 def test_refit_vs_oracle(lr, oracle):
     p = synth.make_pair(N=6000, rho=0.5, s=0.8, seed=17)
     i0, i1, i2, _ = oracle.find_2nn(p["feats0"], p["feats1"])
