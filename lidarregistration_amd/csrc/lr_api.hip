@@ -118,9 +118,8 @@ extern "C" int lr_workspace_create_batch(lr_workspace **out, int max_pairs, int 
         const char *bb = getenv("LIDARREG_NN_BLOCKS_BATCH");   // the same for a batched call: blocks per pass over all its pairs
         ws->nn_blocks_batch = bb ? atoi(bb) : 3072;
         if (ws->nn_blocks_batch < 1) ws->nn_blocks_batch = 1;
-        const char *dl = getenv("LIDARREG_PB_DYNLDS");
-        ws->pb_dyn_lds = dl ? atoi(dl) : 0;
-        if (ws->pb_dyn_lds < 0 || ws->pb_dyn_lds > 24576) ws->pb_dyn_lds = 0;
+        const char *ss = getenv("LIDARREG_NN_STRIDE");      // development knob: sampling stride of the filter pass (any value gives the exact result)
+        ws->nn_sample_stride = ss && atoi(ss) > 0 ? atoi(ss) : 0;
         const char *rs = getenv("LIDARREG_REV_STRIPS");
         ws->rev_strips = rs ? atoi(rs) : 0;            // 0: by the number of pairs of the call (lr_nn16_reverse)
         if (ws->rev_strips < 0) ws->rev_strips = 0;

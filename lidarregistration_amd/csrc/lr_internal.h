@@ -109,7 +109,7 @@ struct lr_workspace {
     int nn_path;                 // LR_NN_PATH_*
     int nn_blocks_target;        // column strips are chosen so that a pass launches about this many blocks
     int nn_blocks_batch;         // the same for a batched call (all pairs together; LIDARREG_NN_BLOCKS_BATCH)
-    int pb_dyn_lds;              // extra dynamic LDS requested by the pass-B launches (LIDARREG_PB_DYNLDS, development knob: caps the blocks per CU)
+    int nn_sample_stride;        // phase 1 of the filter pass samples every this-many-th column tile (0: by the strip length)
     int rev_strips;              // strips offered to every row block of the reverse pass (LIDARREG_REV_STRIPS)
     int nn_second_auto;          // LIDARREG_NN_SECOND=auto: lr_register_pair computes the 2nd neighbour only when a stage reads it
     float *pb1, *pb2, *pb3;      // partial top-3 values [strips][max_n]

@@ -109,173 +109,56 @@ nn16_prep_kernel(const float *__restrict__ Fa, int na, _Float16 *__restrict__ Ha
     if (threadIdx.x == 0) block_max[blk] = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
 }
 
-// ------------------------------------------------------------------ pass A
-// Block = 4 waves x 64 query rows = 256 rows; the block walks every `tile_stride`-th column tile of its strip in chunks
-// of LR_CH tiles that are staged once through LDS (register-staged, double-buffered, one barrier per chunk) and shared
-// by the four waves.  LDS image: one 80-byte row per column (64 B of f16 + 16 B pad): with that stride the two
-// ds_read_b128 of a fragment are bank-conflict-free for the b128 lane groups.
+// ------------------------------------------------------------------ filter pass: sample phase + candidate walk in one kernel
+// Block = 4 waves x 64 query rows = 256 rows of one column strip.  Column tiles (32 columns) are staged once per block through
+// LDS in chunks of LR_PB_CH tiles (register-staged, double-buffered, one barrier per chunk) and shared by the four waves.  LDS
+// image: one 80-byte row per column (64 B of f16 + 16 B pad): with that stride the two ds_read_b128 of a fragment are
+// bank-conflict-free for the b128 lane groups.
 //
-// Operand roles are swapped with respect to pass B: the column fragment is the MFMA's first operand, the query rows
-// the second, so a LANE holds one query row and its 16 accumulator registers are 16 different columns.  The
-// accumulator starts at zero and holds dot16 after the two MFMAs; the row's value of the tile is
+// Phase 1 (forward direction; the reverse direction gets its thresholds from the forward result): the block walks every
+// `sstride`-th tile of its strip with the operand roles SWAPPED -- the column fragment is the MFMA's first operand, the query
+// rows the second, so a LANE holds one query row and its 16 accumulator registers are 16 different columns.  The accumulator
+// starts at zero and holds dot16 after the two MFMAs; the row's value of the tile is
 //     b = max_j dot16(i, j) - max_j n1[j]/2      (in-lane maximum tree: 7 v_max3 + 1 v_max per 16 values, one subtraction)
-// which is a LOWER bound of the tile's best g = dot16 - n1[j]/2, attained up to the spread of the column norms inside the
-// tile (zero for unit-norm descriptors such as FCGF's) -- so no per-column operand has to be read at all: the C operand
-// costs neither LDS bandwidth nor 16 registers, and the kernel runs three waves per SIMD.  Three more ops merge b into the
-// running two largest tile values of the row.  They belong to different tiles, hence to different columns, so their second
-// largest is a valid lower bound of the row's 2nd largest g (u' = -2 g: an upper bound of the 2nd smallest u' -- any
-// valid bound keeps the result exact, a looser one only admits more candidates).  Output: partials pg1 / pg2 [strip][row].
+// a LOWER bound of the tile's best g = dot16 - n1[j]/2, attained up to the spread of the column norms inside the tile (zero for
+// unit-norm descriptors such as FCGF's) -- no per-column operand is read.  Three more ops merge b into the running two largest
+// tile values of the row; they belong to different tiles, hence to different columns, so their second largest is a valid lower
+// bound of the row's 2nd largest g (u' = -2 g: an upper bound of the 2nd smallest u' -- any valid bound keeps the result exact, a
+// looser one only admits more candidates).  Round 2 ran this phase as a kernel of its own over every 4th tile (16 us per pair, 13 %
+// of the pair); here it shares the staging buffers and the row fragments with the walk, samples every 16th tile, and the thresholds
+// it yields are only the START of the walk:
+//
+// Phase 2: f16 MFMA over ALL tiles of the strip, columns on the lanes.  The accumulator is started at y_i = tau_i / 2 instead of 0,
+// so the candidate test u' <= tau_i  <=>  dot16 + y_i >= n1[j]/2 needs no per-element arithmetic: the lane's largest of 8
+// accumulator registers is compared with x_j = n1[j]/2 once.  A 32x32x16 MFMA occupies the matrix pipe for 32 cycles but holds the
+// SIMD's vector issue for only 8 of them, so the candidate test of tile t-1 (3 v_max3 + 1 v_max + 1 v_cmp + 1 scalar branch per 8
+// accumulator registers) is placed in the shadow of the MFMAs of tile t: every test group follows one MFMA in program order and
+// its branch ends the basic block, so the compiler cannot pull the pieces apart again.  The column fragments of tile t+1 are read
+// from LDS one step ahead, which moves the chunk barrier one step forward.  Hits are parked in a wave-private LDS list whose fill
+// count lives in a scalar register: no atomics and no LDS round trip in the loop.
+//
+// Thresholds tighten while the walk runs.  A hit entry also keeps h = (largest register) - x_j.  Whenever LR_PB_TIGHTEN new
+// entries have gathered, the wave goes through them ONE LANE PER ENTRY: an entry whose mask has a single bit names its row, and
+// g = h - y_row is that row's filter value of that column; the two largest g of every row (of the walk: distinct columns) are kept
+// in LDS with two float atomics per entry, y_row <- min(y_row, E_row - g2 + ...), and the lanes reload their 32 threshold
+// registers with 8 ds_read_b128.  All of it is wave-local (a wave owns its 64 rows for the whole strip) and costs ~60 instructions
+// per 48 hits.  The number of hits of a row then grows like 2 + 2 ln(tiles / sampled tiles) instead of 2 tiles / sampled tiles,
+// which is what lets the sample be small.  (The test of a tile lags one tile behind its MFMAs: hits of the one tile whose
+// accumulators were started with the thresholds of before a reload are flagged and not used for tightening.)
 #define LR_CH 4
 #define LR_LDS_ROW 80
 #define LR_RB 2                  // 32-row MFMA blocks per wave (rows per wave = 64, rows per block = 256)
 #define LR_BLOCK_ROWS (128 * LR_RB)
-
-
-__global__ void __launch_bounds__(256)
-nn16_passa_kernel(const _Float16 *__restrict__ Hq, int na, const _Float16 *__restrict__ Hc, const float *__restrict__ nC, int nb,
-                  int tiles_per_strip, int tile_stride, int part_stride, float *__restrict__ pg1, float *__restrict__ pg2,
-                  int32_t *__restrict__ cand_cnt, int gx, int gy, int total, lr_zargs z)
-{
-    // 1-D XCD-aware grid: (row block, strip, pair) from the logical block id -- the blocks one XCD receives are
-    // consecutive row blocks of the same (strip, pair), i.e. they stream the same columns through that XCD's L2
-    int logical;
-    if (!lr_xcd_block(total, logical)) return;
-    const int bx = logical % gx, strip = (logical / gx) % gy, pair = logical / (gx * gy);
-    if (z.descs) { const lr_pair_desc d = z.descs[pair]; na = d.n0; nb = d.n1; }
-    lr_z(Hq, z, pair); lr_z(Hc, z, pair); lr_z(nC, z, pair); lr_z(pg1, z, pair); lr_z(pg2, z, pair); lr_z(cand_cnt, z, pair);
-    if (bx * LR_BLOCK_ROWS >= na) return;
-    constexpr int CH = LR_CH;
-    constexpr int XOFF = CH * 32 * LR_LDS_ROW;
-    constexpr int BUF = XOFF + 16;           // CH column tiles + their CH maximum norms
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
-    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int r = lane & 31, h = lane >> 5;
-    const int row0 = bx * LR_BLOCK_ROWS + wave * 64;
-    const int ntiles = (nb + 31) >> 5;
-    const int t_begin = strip * tiles_per_strip;
-    const int t_end = min(ntiles, t_begin + tiles_per_strip);
-    const int nsamp = t_end > t_begin ? (t_end - t_begin + tile_stride - 1) / tile_stride : 0;   // tiles this block visits
-    const int nchunks = (nsamp + CH - 1) / CH;
-    // the candidate segments of pass B (which follows on the stream) start empty: count of (row block, wave, strip)
-    if (tid < 4) cand_cnt[(bx * 4 + tid) * (gy + 1) + strip] = 0;
-
-    f16x8 a[2][2];
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
-        const int row = min(row0 + 32 * rb + r, na - 1);
-        const f16x8 *p = reinterpret_cast<const f16x8 *>(Hq + (size_t)row * 32 + 16 * h);
-        a[rb][0] = p[0]; a[rb][1] = p[1];
-    }
-
-    // staging: thread t moves CH/2 16-byte pieces per chunk (piece p -> column p/4 of the chunk, 16-byte part p%4)
-    f32x4 stage[CH / 2];
-    float stage_n = 0.0f;        // raw norm of the staged column: NOT touched until store_chunk, so that the compiler's
-                                 // s_waitcnt for it lands after the tile loop instead of right behind the prefetch
-    auto chunk_col = [&](int c, int lc) {      // global column of local column lc (0..CH*32) of chunk c
-        return (t_begin + (c * CH + (lc >> 5)) * tile_stride) * 32 + (lc & 31);
-    };
-    auto load_chunk = [&](int c) {
-#pragma unroll
-        for (int q = 0; q < CH / 2; ++q) {
-            const int p = tid + 256 * q;
-            const int col = chunk_col(c, p >> 2);
-            stage[q] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const unsigned char *>(Hc) + (size_t)min(col, nb - 1) * 64 + (p & 3) * 16);
-        }
-        const int lc = tid & (CH * 32 - 1);
-        const int col = chunk_col(c, lc);
-        stage_n = nC[min(col, nb - 1)];      // (columns past the end repeat the last one: same tile, same norm)
-    };
-    auto store_chunk = [&](int buf) {
-#pragma unroll
-        for (int q = 0; q < CH / 2; ++q) {
-            const int p = tid + 256 * q;
-            *reinterpret_cast<f32x4 *>(&lds[buf * BUF + (p >> 2) * LR_LDS_ROW + (p & 3) * 16]) = stage[q];
-        }
-        // largest x_j = n1[j]/2 of every tile of the chunk: the threads tid < CH*32 hold one column each, 32 per tile
-        float xm = 0.5f * stage_n;
-#pragma unroll
-        for (int k = 16; k >= 1; k >>= 1) xm = fmaxf(xm, __shfl_xor(xm, k));
-        if (tid < CH * 32 && (tid & 31) == 0) *reinterpret_cast<float *>(&lds[buf * BUF + XOFF + (tid >> 5) * 4]) = xm;
-    };
-    // fragment of tile k (lane = column r, K half h); accumulator register g <-> column (g&3) + 8 (g>>2) + 4 h of the tile
-    const int frag_lane = r * LR_LDS_ROW + 32 * h;
-    auto read_tile = [&](int buf, int k, f16x8 &b0, f16x8 &b1, float &xmax) {
-        const unsigned char *bp = &lds[buf * BUF + frag_lane + k * 32 * LR_LDS_ROW];
-        b0 = *reinterpret_cast<const f16x8 *>(bp);
-        b1 = *reinterpret_cast<const f16x8 *>(bp + 16);
-        xmax = *reinterpret_cast<const float *>(&lds[buf * BUF + XOFF + k * 4]);
-    };
-
-    float m1[2] = { -LR_INF, -LR_INF }, m2[2] = { -LR_INF, -LR_INF };     // running two largest tile maxima of the lane's row
-    // plain fmaxf (not inline asm): the compiler must see these reads of the MFMA results to place the wait states
-    // the hardware requires between an MFMA and a VALU read of its destination
-    auto fold = [&](const f32x16 &acc, int rb, float xmax) {
-        float t = fmaxf(fmaxf(acc[0], acc[1]), acc[2]);
-        float u = fmaxf(fmaxf(acc[3], acc[4]), acc[5]);
-        float v = fmaxf(fmaxf(acc[6], acc[7]), acc[8]);
-        float w = fmaxf(fmaxf(acc[9], acc[10]), acc[11]);
-        float z = fmaxf(fmaxf(acc[12], acc[13]), acc[14]);
-        t = fmaxf(fmaxf(t, u), acc[15]);
-        v = fmaxf(fmaxf(v, w), z);
-        t = fmaxf(t, v) - xmax;
-        const float lo = fminf(m1[rb], t);
-        m1[rb] = fmaxf(m1[rb], t);
-        m2[rb] = fmaxf(m2[rb], lo);
-    };
-
-    const f32x16 zero16 = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-    if (nchunks > 0) {
-        load_chunk(0); store_chunk(0);
-        __syncthreads();
-        for (int c = 0; c < nchunks; ++c) {
-            const int buf = c & 1;
-            if (c + 1 < nchunks) load_chunk(c + 1);
-#pragma unroll
-            for (int k = 0; k < CH; ++k) {
-                f16x8 b0, b1; float xmax;
-                read_tile(buf, k, b0, b1, xmax);
-                f32x16 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0, a[0][0], zero16, 0, 0, 0);
-                f32x16 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0, a[1][0], zero16, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b1, a[0][1], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b1, a[1][1], acc1, 0, 0, 0);
-                // tiles past the end of the strip (the last chunk may reach into the next strip's sample) are not counted:
-                // a column must not enter two strips' maxima
-                if (t_begin + (c * CH + k) * tile_stride < t_end) { fold(acc0, 0, xmax); fold(acc1, 1, xmax); }
-            }
-            if (c + 1 < nchunks) store_chunk(buf ^ 1);
-            __syncthreads();
-        }
-    }
-
-    // the two lanes of a row (h = 0, 1: different columns) merge their pairs; lane h = 0 writes
-    const size_t base = (size_t)strip * part_stride;
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
-        const float c1 = __shfl_xor(m1[rb], 32), c2 = __shfl_xor(m2[rb], 32);
-        const float hi = fmaxf(m1[rb], c1), lo = fminf(m1[rb], c1);
-        const float second = fmaxf(lo, fmaxf(m2[rb], c2));
-        const int row = row0 + 32 * rb + r;
-        if (h == 0 && row < na) { pg1[base + row] = hi; pg2[base + row] = second; }
-    }
-}
-
-// ------------------------------------------------------------------ pass B, software-pipelined
-// The accumulator is started at y_i = tau_i / 2 instead of 0, so the candidate test u' <= tau_i  <=>  dot16 + y_i >= n1[j]/2
-// needs no per-element arithmetic: the lane's largest of 8 accumulator registers is compared with x_j = n1[j]/2 once.
-// A 32x32x16 MFMA occupies the matrix pipe for
-// 32 cycles but holds the SIMD's vector issue for only 8 of them, so the candidate test of tile t-1 (3 v_max3 + 1 v_max +
-// 1 v_cmp + 1 scalar branch per 8 accumulator registers) is placed in the shadow of the MFMAs of tile t: every test
-// group follows one MFMA in program order and its branch ends the basic block, so the compiler cannot pull the pieces
-// apart again.  The column fragments of tile t+1 are read from LDS one step ahead, which moves the chunk barrier one
-// step forward.  Hits are parked in a wave-private LDS list whose fill count lives in a scalar register: no atomics and
-// no LDS round trip in the loop; the wave empties its own list into the per-row slots whenever it is half full.
 #ifndef LR_PB_CH
 #define LR_PB_CH 4
 #endif
 #ifndef LR_PB_EXP
-#define LR_PB_EXP 0     // development switches (tools/nn16_micro.hip): 1 no staging, 2 no tests
+#define LR_PB_EXP 0     // development switches (tools/pb_micro.hip): 1 no staging, 2 no tests, 4 no tightening
 #endif
-#define LR_PB_WLIST 512          // entries per wave (8 bytes each)
+#define LR_PB_WLIST 512          // entries per wave (12 bytes each)
+#ifndef LR_PB_TIGHTEN
+#define LR_PB_TIGHTEN 48         // new entries of a wave that trigger a tightening round
+#endif
 
 #define LR_RS_BUCKETS 4096
 
@@ -288,12 +171,12 @@ __device__ __forceinline__ int rs_bucket(float v, float lo, float scale)
 }
 __device__ __forceinline__ float rs_scale(float lo, float hi) { return hi > lo ? (float)LR_RS_BUCKETS / (hi - lo) : 0.0f; }
 
-// what the thresholds of the forward direction are made of (pass A partials); the reverse direction passes tau instead
+// what the thresholds are made of: squared norms of the query rows (by data row), per-32-row maxima of the column cloud's squared
+// norms, how many neighbours are wanted, and the sampling stride of phase 1 (forward direction)
 struct lr_thr_in {
-    const float *pg1, *pg2;      // [strips][part_stride] two largest sampled g per row and strip
-    const float *nQ;             // squared norms of the query rows
-    const float *block_max_c;    // per-32-row maxima of the column cloud's squared norms
-    int nstrips, part_stride, nblk_c, need;
+    const float *nQ;
+    const float *block_max_c;
+    int nblk_c, need, sstride;
 };
 // grid shape of a 1-D XCD-aware launch + direction (0: rows = cloud 0, columns = cloud 1; 1: the reverse pass)
 struct lr_pb_grid { int gx, gy, total, dir; };
@@ -305,7 +188,8 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
                   const int32_t *__restrict__ colmap, const float *__restrict__ tile_min, const uint32_t *__restrict__ row_bound,
                   const int32_t *__restrict__ rev_offs, const uint32_t *__restrict__ rev_range, lr_thr_in thr, lr_pb_grid pg, lr_zargs z)
 {
-    // 1-D XCD-aware grid -> (row block, strip, pair): see nn16_passa_kernel
+    // 1-D XCD-aware grid -> (row block, strip, pair): the blocks one XCD receives are consecutive row blocks of the same
+    // (strip, pair), i.e. they stream the same columns through that XCD's L2
     int logical;
     if (!lr_xcd_block(pg.total, logical)) return;
     const int bx = logical % pg.gx, by = (logical / pg.gx) % pg.gy, pair = logical / (pg.gx * pg.gy);
@@ -316,7 +200,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     }
     lr_z(Hq, z, pair); lr_z(rowmap, z, pair); lr_z(na_dev, z, pair); lr_z(Hc, z, pair); lr_z(nC, z, pair); lr_z(tau, z, pair);
     lr_z(cand_cnt, z, pair); lr_z(cand, z, pair); lr_z(colmap, z, pair); lr_z(tile_min, z, pair); lr_z(row_bound, z, pair); lr_z(rev_offs, z, pair); lr_z(rev_range, z, pair);
-    lr_z(thr.pg1, z, pair); lr_z(thr.pg2, z, pair); lr_z(thr.nQ, z, pair); lr_z(thr.block_max_c, z, pair);
+    lr_z(thr.nQ, z, pair); lr_z(thr.block_max_c, z, pair);
     // rows: either 0..na_host-1, or (reverse direction) the ordered list rowmap[0..*na_dev-1]; tau, cand_cnt and cand
     // are indexed by the position in that list.  Columns: Hc/nC as they lie; with colmap they are a permuted copy and
     // a candidate's column id is colmap[position].
@@ -327,7 +211,11 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     constexpr int XOFF = CH * 32 * LR_LDS_ROW;
     constexpr int BUF = XOFF + CH * 32 * 4;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
-    __shared__ uint2 wlist[4][LR_PB_WLIST];   // per wave: { column, (code << 8) | register mask }, code = rb*4 + (g0/8)*2 + h
+    __shared__ uint2 wlist[4][LR_PB_WLIST];   // per wave: { column, (stale << 31) | (code << 8) | register mask }, code = rb*4 + (g0/8)*2 + h
+    __shared__ float whval[4][LR_PB_WLIST];   //           largest register - x_j of the entry
+    // per row of the block: y = tau/2 (what the accumulators start from), the row's error term, the two largest g of the walk
+    __shared__ __attribute__((aligned(16))) float s_Y[LR_BLOCK_ROWS];
+    __shared__ float s_D[LR_BLOCK_ROWS], s_N1[LR_BLOCK_ROWS], s_N2[LR_BLOCK_ROWS];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int r = lane & 31, h = lane >> 5;
     const int row0 = bx * LR_BLOCK_ROWS + wave * 64;
@@ -356,59 +244,148 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     const int t_end = min(ntiles, t_begin + tiles_per_strip);
     const int nchunks = t_end > t_begin ? (t_end - t_begin + CH - 1) / CH : 0;
 
-    // thresholds of the block's 256 rows -> LDS: given (reverse direction), or made here from the pass-A partials:
-    // U = need-th smallest sampled u' = -2 * (need-th largest g); tau = U + 2E + sqrt band 2^-21 (n0 + U + E) + rounding
-    // slop (y = tau/2 is folded into the MFMA accumulator); +inf when fewer than `need` columns were sampled
-    __shared__ float s_tau[LR_BLOCK_ROWS];
-    {
-        const int rw = bx * LR_BLOCK_ROWS + tid;
-        float tv = 0.0f;
-        if (tau) { if (rw < na) tv = tau[rw]; }
-        else {
-            __shared__ float s_m[4];
-            float mx = 0.0f;       // max_j n1_j of the column cloud from the per-block maxima of its prep kernel
-            for (int b = tid; b < thr.nblk_c; b += 256) mx = fmaxf(mx, thr.block_max_c[b]);
-#pragma unroll
-            for (int k = 32; k >= 1; k >>= 1) mx = fmaxf(mx, __shfl_xor(mx, k));
-            if (lane == 0) s_m[wave] = mx;
-            __syncthreads();
-            const float max_nc = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
-            if (rw < na) {
-                float a1 = thr.pg1[rw], a2 = thr.pg2[rw];
-                for (int sidx = 1; sidx < thr.nstrips; ++sidx) {
-                    const float c1 = thr.pg1[(size_t)sidx * thr.part_stride + rw], c2 = thr.pg2[(size_t)sidx * thr.part_stride + rw];
-                    const float hi = fmaxf(a1, c1), lo = fminf(a1, c1);
-                    a2 = fmaxf(lo, fmaxf(a2, c2));
-                    a1 = hi;
-                }
-                const float U = -2.0f * (thr.need >= 2 ? a2 : a1);
-                const float scale = thr.nQ[rw] + max_nc;
-                const float E = 1.05e-3f * scale + 4e-7f;
-                tv = U + 2.0f * E + 6e-6f * scale + 2e-6f * fabsf(U);
-            }
-        }
-        s_tau[tid] = tv;
-        __syncthreads();
-    }
-
+    // row fragments: lane (r, h) holds K half h of rows r and 32 + r of the wave -- the same registers serve as the MFMA's first
+    // operand (phase 2: rows x columns) and as its second (phase 1: columns x rows)
     f16x8 a[2][2];
-    f32x16 y[2];
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
         int row = min(row0 + 32 * rb + r, na - 1);
         if (rowmap) row = rowmap[row];
         const f16x8 *p = reinterpret_cast<const f16x8 *>(Hq + (size_t)row * 32 + 16 * h);
         a[rb][0] = p[0]; a[rb][1] = p[1];
-#pragma unroll
-        for (int g = 0; g < 16; ++g) {
-            const int lr = wave * 64 + 32 * rb + (g & 3) + 8 * (g >> 2) + 4 * h;
-            y[rb][g] = bx * LR_BLOCK_ROWS + lr < na ? 0.5f * s_tau[lr] : -LR_INF;        // rows past the end never pass the test
-        }
     }
 
     f32x4 stage[CH / 2];
-    float stage_n = 0.0f;
+    float stage_n = 0.0f;        // raw norm of the staged column: NOT touched until store_chunk, so that the compiler's
+                                 // s_waitcnt for it lands after the tile loop instead of right behind the prefetch
     bool stage_ok = false;
+    const int frag_lane = r * LR_LDS_ROW + 32 * h;
+
+    // ---------------------------------------------------------------- thresholds of the block's 256 rows -> LDS
+    // given (reverse direction), or made here by phase 1: U = need-th smallest sampled u' = -2 * (need-th largest g);
+    // tau = U + 2E + sqrt band 2^-21 (n0 + U + E) + rounding slop; y = tau/2; +inf when fewer than `need` tiles were sampled
+    {
+        __shared__ float s_m[4];
+        float mx = 0.0f;       // max_j n1_j of the column cloud from the per-block maxima of its prep kernel
+        if (thr.block_max_c) for (int b = tid; b < thr.nblk_c; b += 256) mx = fmaxf(mx, thr.block_max_c[b]);
+#pragma unroll
+        for (int k = 32; k >= 1; k >>= 1) mx = fmaxf(mx, __shfl_xor(mx, k));
+        if (lane == 0) s_m[wave] = mx;
+        __syncthreads();
+        const float max_nc = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+        const int rw = bx * LR_BLOCK_ROWS + tid;
+        // error term of the row for thresholds made from a filter value found during the walk: y = E' - g (+ 2e-6 |g|)
+        float Dv = LR_INF;
+        if (thr.nQ && rw < na) {
+            const float scale = thr.nQ[rowmap ? rowmap[rw] : rw] + max_nc;
+            Dv = (1.05e-3f * scale + 4e-7f) + 8e-6f * scale;
+        }
+        s_D[tid] = Dv; s_N1[tid] = -LR_INF; s_N2[tid] = -LR_INF;
+        if (tau) s_Y[tid] = rw < na ? 0.5f * tau[rw] : -LR_INF;          // rows past the end never pass the test
+        else {
+            // ---- phase 1: every sstride-th tile of the strip, rows on the lanes
+            const int sstride = thr.sstride;
+            const int nsamp = t_end > t_begin ? (t_end - t_begin + sstride - 1) / sstride : 0;     // tiles this block samples
+            const int nsch = (nsamp + CH - 1) / CH;
+            auto tile_s = [&](int c, int k) { return t_begin + (c * CH + k) * sstride; };
+            auto load_s = [&](int c) {
+#pragma unroll
+                for (int q = 0; q < CH / 2; ++q) {
+                    const int p = tid + 256 * q;
+                    const int col = tile_s(c, p >> 7) * 32 + ((p >> 2) & 31);
+                    stage[q] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const unsigned char *>(Hc) + (size_t)min(col, nb - 1) * 64 + (p & 3) * 16);
+                }
+                const int lc = tid & (CH * 32 - 1);
+                const int col = tile_s(c, lc >> 5) * 32 + (lc & 31);
+                stage_n = nC[min(col, nb - 1)];      // (columns past the end repeat the last one: same tile, same norm)
+            };
+            auto store_s = [&](int buf) {
+#pragma unroll
+                for (int q = 0; q < CH / 2; ++q) {
+                    const int p = tid + 256 * q;
+                    *reinterpret_cast<f32x4 *>(&lds[buf * BUF + (p >> 2) * LR_LDS_ROW + (p & 3) * 16]) = stage[q];
+                }
+                // largest x_j = n1[j]/2 of every tile of the chunk: the threads tid < CH*32 hold one column each, 32 per tile
+                float xm = 0.5f * stage_n;
+#pragma unroll
+                for (int k = 16; k >= 1; k >>= 1) xm = fmaxf(xm, __shfl_xor(xm, k));
+                if (tid < CH * 32 && (tid & 31) == 0) *reinterpret_cast<float *>(&lds[buf * BUF + XOFF + (tid >> 5) * 4]) = xm;
+            };
+            float m1[2] = { -LR_INF, -LR_INF }, m2[2] = { -LR_INF, -LR_INF };     // running two largest tile maxima of the lane's row
+            // plain fmaxf (not inline asm): the compiler must see these reads of the MFMA results to place the wait states
+            // the hardware requires between an MFMA and a VALU read of its destination
+            auto fold = [&](const f32x16 &acc, int rb, float xmax) {
+                float t = fmaxf(fmaxf(acc[0], acc[1]), acc[2]);
+                float u = fmaxf(fmaxf(acc[3], acc[4]), acc[5]);
+                float v = fmaxf(fmaxf(acc[6], acc[7]), acc[8]);
+                float w = fmaxf(fmaxf(acc[9], acc[10]), acc[11]);
+                float zz = fmaxf(fmaxf(acc[12], acc[13]), acc[14]);
+                t = fmaxf(fmaxf(t, u), acc[15]);
+                v = fmaxf(fmaxf(v, w), zz);
+                t = fmaxf(t, v) - xmax;
+                const float lo = fminf(m1[rb], t);
+                m1[rb] = fmaxf(m1[rb], t);
+                m2[rb] = fmaxf(m2[rb], lo);
+            };
+            const f32x16 zero16 = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+            if (nsch > 0) {
+                load_s(0); store_s(0);
+                __syncthreads();
+                for (int c = 0; c < nsch; ++c) {
+                    const int buf = c & 1;
+                    if (c + 1 < nsch) load_s(c + 1);
+#pragma unroll
+                    for (int k = 0; k < CH; ++k) {
+                        // fragment of tile k (lane = column r, K half h); accumulator register g <-> column (g&3) + 8 (g>>2) + 4 h of the tile
+                        const unsigned char *bp = &lds[buf * BUF + frag_lane + k * 32 * LR_LDS_ROW];
+                        const f16x8 b0 = *reinterpret_cast<const f16x8 *>(bp), b1 = *reinterpret_cast<const f16x8 *>(bp + 16);
+                        const float xmax = *reinterpret_cast<const float *>(&lds[buf * BUF + XOFF + k * 4]);
+                        f32x16 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0, a[0][0], zero16, 0, 0, 0);
+                        f32x16 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0, a[1][0], zero16, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b1, a[0][1], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b1, a[1][1], acc1, 0, 0, 0);
+                        // tiles past the end of the strip (the last chunk may reach beyond it) are not counted
+                        if (tile_s(c, k) < t_end) { fold(acc0, 0, xmax); fold(acc1, 1, xmax); }
+                    }
+                    if (c + 1 < nsch) store_s(buf ^ 1);
+                    __syncthreads();
+                }
+            }
+            // the two lanes of a row (h = 0, 1: different columns) merge their pairs; lane h = 0 writes the row's start value
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                const float c1 = __shfl_xor(m1[rb], 32), c2 = __shfl_xor(m2[rb], 32);
+                const float hi = fmaxf(m1[rb], c1), lo = fminf(m1[rb], c1);
+                const float second = fmaxf(lo, fmaxf(m2[rb], c2));
+                const int rl = wave * 64 + 32 * rb + r, row = bx * LR_BLOCK_ROWS + rl;
+                if (h == 0) {
+                    float yv = -LR_INF;
+                    if (row < na) {
+                        const float U = -2.0f * (thr.need >= 2 ? second : hi);
+                        const float scale = thr.nQ[rowmap ? rowmap[row] : row] + max_nc;
+                        const float E = 1.05e-3f * scale + 4e-7f;
+                        yv = 0.5f * (U + 2.0f * E + 6e-6f * scale + 2e-6f * fabsf(U));
+                    }
+                    s_Y[rl] = yv;
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    f32x16 y[2];
+    // the lane's 16 + 16 threshold registers: register g of row block rb <-> row 32 rb + (g&3) + 8 (g>>2) + 4 h of the wave
+    auto load_y = [&]() {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(&s_Y[wave * 64 + 32 * rb + 8 * q + 4 * h]);
+                y[rb][4 * q] = v.x; y[rb][4 * q + 1] = v.y; y[rb][4 * q + 2] = v.z; y[rb][4 * q + 3] = v.w;
+            }
+    };
+    load_y();
+
     auto load_chunk = [&](int c) {
 #pragma unroll
         for (int q = 0; q < CH / 2; ++q) {
@@ -430,7 +407,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         if (tid < CH * 32) *reinterpret_cast<float *>(&lds[buf * BUF + XOFF + tid * 4]) = stage_ok ? 0.5f * stage_n : LR_INF;
     };
     // per-lane byte offsets of the fragment / x_j of tile 0 of the current and the other buffer; tile k adds a constant
-    const int frag_lane = r * LR_LDS_ROW + 32 * h, x_lane = XOFF + r * 4;
+    const int x_lane = XOFF + r * 4;
     int fo_cur = frag_lane, fo_oth = frag_lane + BUF, xo_cur = x_lane, xo_oth = x_lane + BUF;
     auto read_b = [&](int fo, int xo, int k, f16x8 &b0, f16x8 &b1, float &xj) {
         b0 = *reinterpret_cast<const f16x8 *>(&lds[fo + k * 32 * LR_LDS_ROW]);
@@ -439,6 +416,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     };
 
     int wcnt = 0;            // entries in this wave's list (wave-uniform: lives in a scalar register)
+    int wdone = 0;           // ... of which the tightening has seen this many
     // The wave owns one segment of the candidate store: seg[(row block, wave, strip)][seg_cap] entries { column, code | mask }
     // exactly as they lie in its LDS list.  Emptying the list is a compacting copy with plain stores -- no atomics, nothing
     // to wait for; nn16_exact_kernel expands the masks and bins the entries by row.  seg_fill < 0: the segment overflowed
@@ -447,13 +425,47 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     const int seg_cap = lr_seg_cap(my_strips);
     uint2 *__restrict__ seg = reinterpret_cast<uint2 *>(cand) + (size_t)(bx * 4 + wave) * LR_NN16_SEG + (size_t)by * seg_cap;
     int seg_fill = 0;
+    const bool tightening = thr.nQ != nullptr && !(LR_PB_EXP & 4);
+    // one tightening round (wave-local): entries [wdone, wcnt) -> the rows' two largest g -> y -> threshold registers.
+    // Returns with every lane's registers reloaded; the accumulators in flight were started from the OLD values (see `stale`).
+    auto tighten = [&]() {
+        const int nlist = min(wcnt, LR_PB_WLIST);
+        for (int e0 = wdone; e0 < nlist; e0 += 64) {
+            const int e = e0 + lane;
+            if (e < nlist) {
+                const uint2 v = wlist[wave][e];
+                const unsigned mask = v.y & 0xffu;
+                if ((mask & (mask - 1u)) == 0u && !(v.y >> 31)) {       // exactly one register (the mask of a hit is never empty)
+                    const int code = (int)(v.y >> 8) & 0xf;
+                    const int g = 8 * ((code >> 1) & 1) + 7 - __builtin_ctz(mask);
+                    const int rl = wave * 64 + 32 * (code >> 2) + (g & 3) + 8 * (g >> 2) + 4 * (code & 1);
+                    // the register held y_row + dot16 and h = register - x_j, so g = dot16 - x_j = h - y_row (the y of now: entries
+                    // made before the last reload have been seen by the round that did it, the tile in between is flagged stale)
+                    const float gv = whval[wave][e] - s_Y[rl];
+                    const float old = atomicMax(&s_N1[rl], gv);
+                    atomicMax(&s_N2[rl], fminf(old, gv));
+                }
+            }
+        }
+        wdone = nlist;
+        // lane = row: y <- min(y, E' - g_need + 2e-6 |g_need|)   (g_need: the need-th largest g of the walk so far; -inf: no change)
+        {
+            const int rl = wave * 64 + lane;
+            const float gn = thr.need >= 2 ? s_N2[rl] : s_N1[rl];
+            const float yn = (s_D[rl] - gn) + 2e-6f * fabsf(gn);
+            if (yn < s_Y[rl]) s_Y[rl] = yn;                 // (NaN compares false: the row keeps its threshold)
+        }
+        load_y();
+    };
     auto flush = [&]() {
+        if (tightening && wdone < wcnt) tighten();
         if (wcnt > LR_PB_WLIST) seg_fill = -1;       // more hits between two chunk boundaries than the list holds
         else if (seg_fill >= 0) {
             for (int e0 = 0; e0 < wcnt; e0 += 64) {
                 const int e = e0 + lane;
                 uint2 v = make_uint2(0u, 0u);
                 if (e < wcnt) v = wlist[wave][e];
+                v.y &= 0x7fffffffu;
                 // padding columns pass the test only when tau is +inf
                 const bool keep = e < wcnt && (int)v.x < nb && ((int)v.x >> 5) < t_end;
                 const unsigned long long kb = __builtin_amdgcn_ballot_w64(keep);
@@ -464,10 +476,10 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
                 seg_fill += nk;
             }
         }
-        wcnt = 0;
+        wcnt = 0; wdone = 0;
     };
     // candidate test of 8 accumulator registers (16 rows x 32 columns of the wave's tile)
-    auto check = [&](const f32x16 &acc, int g0, float x, int tile, int rb) {
+    auto check = [&](const f32x16 &acc, int g0, float x, int tile, int rb, unsigned stale) {
 #if LR_PB_EXP & 2
         if (g0 == 0) asm volatile("" :: "v"(acc));
         return;
@@ -489,7 +501,10 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
                 for (int g = 0; g < 8; ++g) below = __builtin_amdgcn_alignbit(below, __float_as_uint(acc[g0 + g] - x), 31);
                 const unsigned mask = ~below & 0xffu;
                 const int pos = wcnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(hit >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hit, 0u));
-                if (pos < LR_PB_WLIST) wlist[wave][pos] = make_uint2((unsigned)(tile * 32 + r), mask | (unsigned)((rb * 4 + (g0 >> 3) * 2 + h) << 8));
+                if (pos < LR_PB_WLIST) {
+                    wlist[wave][pos] = make_uint2((unsigned)(tile * 32 + r), mask | (unsigned)((rb * 4 + (g0 >> 3) * 2 + h) << 8) | (stale << 31));
+                    whval[wave][pos] = m - x;
+                }
             }
             wcnt += __builtin_popcountll(hit);
         }
@@ -504,22 +519,23 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         for (int g = 0; g < 16; ++g) { accA[q][g] = -LR_INF; accB[q][g] = -LR_INF; }
 
     // one pipeline step: MFMAs of tile (c, k) into accN, tests of the previous tile in accC, LDS read of the next tile
-    auto step = [&](int c, int k, f32x16 (&accN)[2], const f32x16 (&accC)[2]) {
+    auto step = [&](int c, int k, f32x16 (&accN)[2], const f32x16 (&accC)[2], unsigned stale) {
         f16x8 n0, n1; float nx;
         if (k + 1 < CH) read_b(fo_cur, xo_cur, k + 1, n0, n1, nx);
         else read_b(fo_oth, xo_oth, 0, n0, n1, nx);
         const int tileC = t_begin + c * CH + k - 1;
         accN[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][0], b0, y[0], 0, 0, 0);
-        check(accC[0], 0, xC, tileC, 0);
+        check(accC[0], 0, xC, tileC, 0, stale);
         accN[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][0], b0, y[1], 0, 0, 0);
-        check(accC[0], 8, xC, tileC, 0);
+        check(accC[0], 8, xC, tileC, 0, stale);
         accN[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][1], b1, accN[0], 0, 0, 0);
-        check(accC[1], 0, xC, tileC, 1);
+        check(accC[1], 0, xC, tileC, 1, stale);
         accN[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][1], b1, accN[1], 0, 0, 0);
-        check(accC[1], 8, xC, tileC, 1);
+        check(accC[1], 8, xC, tileC, 1, stale);
         b0 = n0; b1 = n1; xC = xN; xN = nx;
     };
 
+    unsigned stale = 0u;     // 1: the accumulators awaiting their test were started from thresholds that have been reloaded since
     if (nchunks > 0) {
         load_chunk(0); store_chunk(0);
         __syncthreads();
@@ -528,24 +544,35 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
         if (nchunks > 1) load_chunk(1);
         read_b(fo_cur, xo_cur, 0, b0, b1, xN);
-        for (int c = 0; c < nchunks; ++c) {
+        // The walk is a loop nest: the inner loop is the hot one and contains no tightening code (the compiler then keeps the threshold
+        // registers loop-invariant and its wait counts exact); it is left whenever the hit list wants attention.
+        int c = 0;
+        while (c < nchunks) {
+            bool attention = false;
+            for (; c < nchunks && !attention; ++c) {
 #pragma unroll
-            for (int k = 0; k < CH; k += 2) {
-                step(c, k, accA, accB);
-                if (k == CH - 2) {
-                    // the last step of a chunk reads the first fragment of the next one: make that chunk visible now.  All
-                    // reads of the buffer it goes to were issued before the previous barrier (the step above read this
-                    // chunk's own last tile), so one barrier per chunk still orders everything.
+                for (int k = 0; k < CH; k += 2) {
+                    step(c, k, accA, accB, k == 0 ? stale : 0u);
+                    if (k == 0) stale = 0u;
+                    if (k == CH - 2) {
+                        // the last step of a chunk reads the first fragment of the next one: make that chunk visible now.  All
+                        // reads of the buffer it goes to were issued before the previous barrier (the step above read this
+                        // chunk's own last tile), so one barrier per chunk still orders everything.
 #if !(LR_PB_EXP & 1)
-                    if (c + 1 < nchunks) store_chunk((c & 1) ^ 1);
-                    __syncthreads();
-                    if (c + 2 < nchunks) load_chunk(c + 2);
+                        if (c + 1 < nchunks) store_chunk((c & 1) ^ 1);
+                        __syncthreads();
+                        if (c + 2 < nchunks) load_chunk(c + 2);
 #endif
+                    }
+                    step(c, k + 1, accB, accA, 0u);
                 }
-                step(c, k + 1, accB, accA);
+                { const int t0 = fo_cur; fo_cur = fo_oth; fo_oth = t0; const int t1 = xo_cur; xo_cur = xo_oth; xo_oth = t1; }
+                attention = wcnt >= LR_PB_WLIST / 2 || (tightening && wcnt - wdone >= LR_PB_TIGHTEN);
             }
-            { const int t0 = fo_cur; fo_cur = fo_oth; fo_oth = t0; const int t1 = xo_cur; xo_cur = xo_oth; xo_oth = t1; }
-            if (wcnt >= LR_PB_WLIST / 2) flush();
+            if (attention) {
+                if (wcnt >= LR_PB_WLIST / 2) flush(); else tighten();
+                stale = tightening ? 1u : 0u;
+            }
         }
         // drain: the last tile of the last chunk sits in accB.  The inline-asm maxima below read MFMA results the
         // compiler cannot see them read (no automatic wait states): inside the loop every such read is at least two
@@ -553,11 +580,12 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         {
             asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
             const int tileC = t_begin + nchunks * CH - 1;
-            check(accB[0], 0, xC, tileC, 0);
-            check(accB[0], 8, xC, tileC, 0);
-            check(accB[1], 0, xC, tileC, 1);
-            check(accB[1], 8, xC, tileC, 1);
+            check(accB[0], 0, xC, tileC, 0, stale);
+            check(accB[0], 8, xC, tileC, 0, stale);
+            check(accB[1], 0, xC, tileC, 1, stale);
+            check(accB[1], 8, xC, tileC, 1, stale);
         }
+        wdone = wcnt;      // (nothing left to tighten for)
         flush();
     }
     if (lane == 0) {
@@ -765,34 +793,25 @@ int lr_nn16_run(lr_workspace *ws, const float *Fq, const _Float16 *Hq, const flo
 {
     const int ntiles = lr_cdiv(nb, 32);
     const int row_blocks = lr_cdiv(na, LR_BLOCK_ROWS);
-    // pass A samples every `stride`-th tile (any subset gives a valid, if looser, threshold)
-    int stride = ntiles / 16;
-    {
-        // Pass A costs ~ tiles / stride per row, the candidates the looser thresholds admit ~ stride per row: the best stride grows
-        // like sqrt(tiles).  4 up to ~30k points (measured flat from 4 to 8 there), 8 at 100k points (+7 % pairs/s over 4).
-        // LIDARREG_NN_STRIDE overrides (development knob; any value gives the exact result).
-        static int env_cap = -1;
-        if (env_cap < 0) { const char *e = getenv("LIDARREG_NN_STRIDE"); env_cap = e && atoi(e) > 0 ? atoi(e) : 0; }
-        int cap = env_cap > 0 ? env_cap : (int)(sqrt((double)ntiles) / 7.0);
-        if (env_cap <= 0 && cap < LR_NN16_STRIDE) cap = LR_NN16_STRIDE;
-        if (stride > cap) stride = cap;
-    }
-    if (stride < 1) stride = 1;
-    // strips: enough blocks (over all pairs of a batched call) to fill 256 CUs a few times over, at least 8 sampled tiles per strip
+    // strips: enough blocks (over all pairs of a batched call) to fill 256 CUs a few times over, at least 64 tiles per strip
     int strips = lr_cdiv(ws->zP > 1 ? ws->nn_blocks_batch : ws->nn_blocks_target, row_blocks * ws->zP);
-    int smax = ntiles / (8 * stride);
+    int smax = ntiles / 64;
     if (strips > smax) strips = smax;
     if (strips > LR_NN_MAX_STRIPS) strips = LR_NN_MAX_STRIPS;
     if (strips < 1) strips = 1;
-    const int tps = lr_cdiv(lr_cdiv(ntiles, strips), stride) * stride;     // tiles per strip, multiple of the stride
+    const int tps = lr_cdiv(ntiles, strips);
+    // phase 1 of the filter pass samples every `sstride`-th tile of a strip (any subset gives a valid, if looser, start; the walk
+    // tightens it).  Its cost is ~ tiles / stride per row, the extra hits of a looser start ~ 2 ln(stride) per row: about 32
+    // sampled tiles per strip, a stride of at most 16 (32 for very long strips).
+    int sstride = ws->nn_sample_stride > 0 ? ws->nn_sample_stride : tps / 32;
+    if (ws->nn_sample_stride <= 0) { const int cap = tps > 2048 ? 32 : 16; if (sstride > cap) sstride = cap; }
+    if (sstride < 1) sstride = 1;
     // 1-D XCD-aware grid over (row block, strip, pair), padded to a multiple of 8
     const int total = row_blocks * strips * ws->zP;
     dim3 grid(8 * lr_cdiv(total, 8));
-    hipLaunchKernelGGL(nn16_passa_kernel, grid, dim3(256), 0, st, Hq, na, Hc, nC, nb, tps, stride, ws->max_n, ws->pb1, ws->pb2, ws->cand_cnt,
-                       row_blocks, strips, total, ws->z);
     if (ws->timing && !ws->ev_pending) { LR_HIP(hipEventRecord(ws->ev[0], st)); }
-    lr_thr_in thr = { ws->pb1, ws->pb2, nQ, block_max_c, strips, ws->max_n, lr_cdiv(nb, 32), need };
-    hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), ws->pb_dyn_lds, st, Hq, na, (const int32_t *)nullptr, (const int32_t *)nullptr, Hc, nC, nb,
+    lr_thr_in thr = { nQ, block_max_c, lr_cdiv(nb, 32), need, sstride };
+    hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), 0, st, Hq, na, (const int32_t *)nullptr, (const int32_t *)nullptr, Hc, nC, nb,
                        tps, (const float *)nullptr, ws->cand_cnt, ws->cand, (const int32_t *)nullptr, (const float *)nullptr,
                        (const uint32_t *)nullptr, (const int32_t *)nullptr, (const uint32_t *)nullptr, thr, lr_pb_grid{ row_blocks, strips, total, 0 }, ws->z);
     if (ws->timing && !ws->ev_pending) { LR_HIP(hipEventRecord(ws->ev[1], st)); ws->ev_pending = 1; }
@@ -1005,7 +1024,7 @@ int lr_nn16_reverse(lr_workspace *ws, const float *F0, const _Float16 *H0, const
     dim3 grid(8 * lr_cdiv(total, 8));
     const bool timed = ws->timing && ws->ev_pending == 1 && !ws->rev_recorded;
     if (timed) { LR_HIP(hipEventRecord(ws->ev[4], st)); }
-    hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), ws->pb_dyn_lds, st, H1, na, (const int32_t *)ws->rev_rows, (const int32_t *)n_rows,
+    hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), 0, st, H1, na, (const int32_t *)ws->rev_rows, (const int32_t *)n_rows,
                        (const _Float16 *)ws->Hs, (const float *)ws->nrms, nb, tps, ws->tau, ws->cand_cnt, ws->cand,
                        (const int32_t *)ws->rev_cols, seeded ? (const float *)ws->rev_tmin : (const float *)nullptr, (const uint32_t *)seed,
                        (const int32_t *)ws->rev_hist, (const uint32_t *)range, lr_thr_in{},

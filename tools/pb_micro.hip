@@ -1,4 +1,4 @@
-// Timing harness for the batched pass A / pass B kernels (development tool): P identical pairs in P arenas.
+// Timing harness for the batched filter pass (nn16_passb_kernel: sample phase + walk) (development tool): P identical pairs in P arenas.
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form=1 [-DLR_PB_EXP=k] tools/pb_micro.hip -o tools/bin/pb_micro_k
 //   usage: pb_micro [n=30000] [P=32] [strips=1]
 #include "../lidarregistration_amd/csrc/lr_nn16.hip"
@@ -37,28 +37,26 @@ int main(int argc, char **argv)
     const int ntiles = (n + 31) / 32, row_blocks = (n + LR_BLOCK_ROWS - 1) / LR_BLOCK_ROWS;
     const int total = row_blocks * strips * P;
     dim3 grid(8 * ((total + 7) / 8));
-    const int stride_a = 4;
-    const int tps = ((ntiles + strips - 1) / strips + stride_a - 1) / stride_a * stride_a;
-    float msa = timeit([&] { hipLaunchKernelGGL(nn16_passa_kernel, grid, dim3(256), 0, 0, H, n, H, nrm, n, tps, stride_a, n, pu1, pu2, cnt, row_blocks, strips, total, z); });
-    printf("EXP=%d n=%d P=%d strips=%d blocks=%d\n", LR_PB_EXP, n, P, strips, total);
-    printf("passA stride 4:            %8.3f ms  = %6.1f us/pair\n", msa, msa * 1e3 / P);
-    for (int need : {2, 1}) {
-        lr_thr_in thr = { pu1, pu2, nrm, bmax, strips, n, (n+31)/32, need };
+    const int tps = (ntiles + strips - 1) / strips;
+    printf("EXP=%d TIGHTEN=%d n=%d P=%d strips=%d blocks=%d\n", LR_PB_EXP, LR_PB_TIGHTEN, n, P, strips, total);
+    for (int need : {2, 1})
+    for (int sstride : {2, 4, 8, 16, 32, 64}) {
+        lr_thr_in thr = { nrm, bmax, (n+31)/32, need, sstride };
         auto run = [&] { hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), 0, 0, H, n, (const int32_t*)nullptr, (const int32_t*)nullptr, H, nrm, n, tps, (const float*)nullptr, cnt, cand,
                                             (const int32_t*)nullptr, (const float*)nullptr, (const uint32_t*)nullptr, (const int32_t*)nullptr, (const uint32_t*)nullptr, thr, lr_pb_grid{ row_blocks, strips, total, 0 }, z); };
         float msp = timeit([&] { run(); });
         run();
         const int nseg = row_blocks * 4 * (strips + 1);
         std::vector<int32_t> c1(nseg); hipMemcpy(c1.data(), cnt, (size_t)nseg * 4, hipMemcpyDeviceToHost);
-        double tot = 0; for (int i = 0; i < nseg; ++i) if (i % (strips + 1) != strips) tot += c1[i];
-        printf("passB need=%d:              %8.3f ms  = %6.1f us/pair   list entries/row %.2f\n", need, msp, msp * 1e3 / P, tot / n);
+        double tot = 0; int over = 0; for (int i = 0; i < nseg; ++i) if (i % (strips + 1) != strips) { if (c1[i] < 0) over++; else tot += c1[i]; }
+        printf("filter pass need=%d sample stride %2d: %8.3f ms  = %6.1f us/pair   list entries/row %.2f  overflowed segments %d\n", need, sstride, msp, msp * 1e3 / P, tot / n, over);
     }
     {
         std::vector<float> t(n, -1e30f);
         for (int p = 0; p < P; ++p) hipMemcpy((char *)tau + p * stride, t.data(), (size_t)n * 4, hipMemcpyHostToDevice);
         float msp = timeit([&] { hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), 0, 0, H, n, (const int32_t*)nullptr, (const int32_t*)nullptr, H, nrm, n, tps, (const float*)tau, cnt, cand,
                                                     (const int32_t*)nullptr, (const float*)nullptr, (const uint32_t*)nullptr, (const int32_t*)nullptr, (const uint32_t*)nullptr, lr_thr_in{}, lr_pb_grid{ row_blocks, strips, total, 0 }, z); });
-        printf("passB no candidates:       %8.3f ms  = %6.1f us/pair\n", msp, msp * 1e3 / P);
+        printf("walk only, no candidates:       %8.3f ms  = %6.1f us/pair\n", msp, msp * 1e3 / P);
     }
     return 0;
 }
