@@ -58,14 +58,25 @@ typedef struct lr_ransac_params {
                                like a failed pre-check)                                                              */
     int32_t  prosac_growth; /* T_N of the growth function (0 -> 100000, GC-RANSAC's default)          */
     int32_t  scoring;       /* which model wins: 0 = more inliers, then lower squared-error sum (Open3D: fitness, then
-                               inlier RMSE); 1 = MSAC, the truncated quadratic cost GC-RANSAC scores with: larger
-                               sum over inliers of (thr2 - d^2), evaluated as count * (uint32)(thr2 * 2^20) - best_ssq */
+                               inlier RMSE); 1 = MSAC, the truncated quadratic cost: larger sum over inliers of (thr2 - d^2),
+                               evaluated as count * (uint32)(thr2 * 2^20) - best_ssq; 2 = MSAC as GC-RANSAC runs it
+                               (MSACScoringFunction behind gcransac_python.cpp:507-512; --codebase GC): inlier test, cost, exit
+                               rule, local optimisation, final least squares and inlier mask all use the TRUNCATED threshold
+                               (3/2 thr)^2 = 2.25 thr2 (upstream-recalled) -- i.e. scoring 1 at 1.5 x the threshold */
     int32_t  local_opt;     /* 0: none -- the winning minimal-sample model is returned (Open3D); 1: GC-RANSAC's local
                                optimisation (--GC_LO True, GC_RANSAC.py:36-37; gcransac_python.cpp:418-423,508-515): every new
                                best model is re-estimated by an inner RANSAC over its inliers (<= 10 rounds of 20 least-squares
                                fits on 21 inliers each, scored over all correspondences; spatial coherence weight 0), at the
                                granularity of the early-exit batches, plus the final iterated least squares; 2: the final
                                iterated least squares over the inliers only (--GC_LO False)                           */
+    /* Three settings of gcransac_python.cpp:513-517 (553-556, 579-582) whose meaning lives in the un-vendored library; 0 = default.
+     * `max_local_optimization_number = 20` (50 without a pre-verification) admits two readings -- least-squares fits per round of
+     * one optimisation (lo_trials) or optimisations per run (lo_max_calls); both are knobs, both default to that number.         */
+    int32_t  lo_rounds;     /* rounds of one local optimisation (upstream max_graph_cut_number), default 10             */
+    int32_t  lo_trials;     /* least-squares fits per round, 1..20, default 20                                          */
+    int32_t  lo_max_calls;  /* local optimisations per run, default 20 (use_elc != 0) / 50 (use_elc == 0)               */
+    int32_t  min_iters;     /* the exit rule is not consulted before this many ids (min_iteration_number), default 20 / 50;
+                               only matters with batches shorter than that                                              */
 } lr_ransac_params;
 
 /* Written to device memory by lr_ransac / lr_register_pair. */

@@ -51,8 +51,10 @@ def pair_params(args):
         use_elc = PRECHECK[fast_rejection]
         conf = float(getattr(args, "GC_conf", 0.999))                  # GC_RANSAC.py:26, test.py:312
         sampler = 1 if getattr(args, "prosac", True) else 2            # test.py:308 (default True), GC_RANSAC.py:24; unique indices
-        scoring = 1                                                    # MSAC, the cost pygcransac ranks models by
-        local_opt = 1 if getattr(args, "GC_LO", True) else 2           # GC_RANSAC.py:36-37; the final least squares always runs
+        scoring = 2                                                    # MSAC at the truncated threshold (3/2 thr)^2, as GC-RANSAC scores models
+        # GC_RANSAC.py:36-37; the final least squares always runs.  gcransac_python.cpp:518-521,553-556 switch the optimisation off
+        # only inside the branches with a pre-verification: with --fast_rejection NONE the wrapper ignores --GC_LO False (:571-591)
+        local_opt = 1 if (getattr(args, "GC_LO", True) or fast_rejection == "NONE") else 2
     else:
         sampler = 0
         scoring = 0                                                    # Open3D: fitness, then inlier RMSE
@@ -61,7 +63,9 @@ def pair_params(args):
         conf = float(getattr(args, "o3d_conf", 0.9995))                # FR.py:136
     rp = _ext.RansacParams(sample_size, int(use_elc), np.float32(thr * thr), iters, int(getattr(args, "seed", DEFAULT_SEED)),
                            conf, int(getattr(args, "ransac_batch", 0)), sampler, int(getattr(args, "prosac_growth", 0)),
-                           int(getattr(args, "ransac_scoring", scoring)), int(getattr(args, "ransac_local_opt", local_opt)))
+                           int(getattr(args, "ransac_scoring", scoring)), int(getattr(args, "ransac_local_opt", local_opt)),
+                           int(getattr(args, "lo_rounds", 0)), int(getattr(args, "lo_trials", 0)), int(getattr(args, "lo_max_calls", 0)),
+                           int(getattr(args, "min_iters", 0)))           # 0: the defaults of gcransac_python.cpp:513-517 (lidarreg.h)
     p = _ext.PairParams()
     p.mode = MODES[mode]
     # open3D codebase: FR.py:99-111 refits over the original NN pairs; the GC codebase returns what pygcransac returns --

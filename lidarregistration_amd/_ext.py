@@ -29,7 +29,13 @@ class LidarRegError(RuntimeError):
 class RansacParams(ctypes.Structure):
     _fields_ = [("sample_size", ctypes.c_int32), ("use_elc", ctypes.c_int32), ("thr2", ctypes.c_float),
                 ("iters", ctypes.c_int32), ("seed", ctypes.c_uint64), ("confidence", ctypes.c_float), ("batch", ctypes.c_int32),
-                ("sampler", ctypes.c_int32), ("prosac_growth", ctypes.c_int32), ("scoring", ctypes.c_int32), ("local_opt", ctypes.c_int32)]
+                ("sampler", ctypes.c_int32), ("prosac_growth", ctypes.c_int32), ("scoring", ctypes.c_int32), ("local_opt", ctypes.c_int32),
+                ("lo_rounds", ctypes.c_int32), ("lo_trials", ctypes.c_int32), ("lo_max_calls", ctypes.c_int32), ("min_iters", ctypes.c_int32)]
+
+    def effective_thr2(self):
+        """The squared threshold the estimator really tests inliers against: scoring 2 (MSAC as GC-RANSAC runs it) uses the
+        truncated threshold (3/2 thr)^2 -- what lr_inlier_mask has to be given to reproduce the estimator's own inlier set."""
+        return float(self.thr2) * 2.25 if self.scoring == 2 else float(self.thr2)
 
 
 class RansacResult(ctypes.Structure):

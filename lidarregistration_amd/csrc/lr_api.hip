@@ -16,7 +16,7 @@ void lr_set_error(const char *fmt, ...)
     va_end(ap);
 }
 
-static_assert(sizeof(lr_ransac_params) == 48 && sizeof(lr_pair_params) == 80 && sizeof(lr_pair_result) == 496,
+static_assert(sizeof(lr_ransac_params) == 64 && sizeof(lr_pair_params) == 96 && sizeof(lr_pair_result) == 496,
               "ABI structs changed: update include/lidarreg.h, _ext.py, INTEGRATION.md and tests/test_abi_cpu.py together");
 
 extern "C" int lr_version(void) { return 100; }

@@ -386,23 +386,26 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     };
     load_y();
 
+    // staging of the walk: buffer loads -- the chunk's position is a scalar offset, the thread's place in it a constant vector
+    // offset (no address arithmetic on the vector pipe), and rows past the end of the cloud read as zeros (range check of the
+    // buffer descriptor) instead of being clamped: their x_j is +inf below, so they never pass the test.  Thread t moves the two
+    // adjacent 16-byte pieces 2 (t & 1), 2 (t & 1) + 1 of column t >> 1 of the chunk.
+    static_assert(CH == 4, "the staging maps 256 threads onto 128 columns x 2 halves");
+    const __amdgpu_buffer_rsrc_t rsrcH = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(Hc), 0, nb * 64, 0x27000);
+    const __amdgpu_buffer_rsrc_t rsrcN = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(nC), 0, nb * 4, 0x27000);
+    const int st_voff = tid * 32, st_noff = (tid & (CH * 32 - 1)) * 4;
+    const int st_lds = (tid >> 1) * LR_LDS_ROW + (tid & 1) * 32;
     auto load_chunk = [&](int c) {
-#pragma unroll
-        for (int q = 0; q < CH / 2; ++q) {
-            const int p = tid + 256 * q;
-            const int col = (t_begin + c * CH) * 32 + (p >> 2);
-            stage[q] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const unsigned char *>(Hc) + (size_t)min(col, nb - 1) * 64 + (p & 3) * 16);
-        }
-        const int col = (t_begin + c * CH) * 32 + (tid & (CH * 32 - 1));
-        stage_n = nC[min(col, nb - 1)];
+        const int col0 = (t_begin + c * CH) * 32;       // wave-uniform
+        stage[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcH, st_voff, col0 * 64, 0));
+        stage[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcH, st_voff + 16, col0 * 64, 0));
+        stage_n = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrcN, st_noff, col0 * 4, 0));
+        const int col = col0 + (tid & (CH * 32 - 1));
         stage_ok = col < nb && (col >> 5) < t_end;
     };
     auto store_chunk = [&](int buf) {
-#pragma unroll
-        for (int q = 0; q < CH / 2; ++q) {
-            const int p = tid + 256 * q;
-            *reinterpret_cast<f32x4 *>(&lds[buf * BUF + (p >> 2) * LR_LDS_ROW + (p & 3) * 16]) = stage[q];
-        }
+        *reinterpret_cast<f32x4 *>(&lds[buf * BUF + st_lds]) = stage[0];
+        *reinterpret_cast<f32x4 *>(&lds[buf * BUF + st_lds + 16]) = stage[1];
         // x_j = n1[j]/2 ; +inf masks columns past the end of the cloud or of the strip
         if (tid < CH * 32) *reinterpret_cast<float *>(&lds[buf * BUF + XOFF + tid * 4]) = stage_ok ? 0.5f * stage_n : LR_INF;
     };

@@ -744,7 +744,7 @@ ransac_final_kernel(const uint32_t *__restrict__ score_cnt, const unsigned long 
         counters[LR_CNT_NVALID2] = 0;
         // with local optimisation a new best model is optimised first (ransac_lo_kernel, next on the stream); the exit test and the
         // re-design of the SPRT run there, on the optimised model
-        const bool to_lo = take && p.local_opt == 1;
+        const bool to_lo = take && p.local_opt == 1 && state->lo_calls < p.lo_max_calls;
         if (to_lo) state->lo_pending = 1;
         if (p.use_elc == 2 && !to_lo) lr_sprt_redesign(state, nc, m_dev ? min(*m_dev, m_max) : m_max);
         if (!to_lo && p.confidence > 0.0f && p.confidence < 1.0f && nc > 0) {
@@ -754,7 +754,7 @@ ransac_final_kernel(const uint32_t *__restrict__ score_cnt, const unsigned long 
             double fn = f;
             for (int q = 1; q < p.sample_size; ++q) fn = fn * f;
             const double kk = lr_det_log(1.0 - (double)p.confidence) / lr_det_log(1.0 - fn);
-            if ((double)h_end >= kk) state->done = 1;
+            if ((double)h_end >= kk && h_end >= p.min_iters) state->done = 1;
         }
         lr_ransac_result r;
         r.best_h = nc > 0 ? nh : -1; r.best_count = nc; r.pad0 = 0; r.best_ssq = nc > 0 ? nq : 0;
@@ -1039,7 +1039,7 @@ __device__ void lo_score_wide(lo_shared &sh, const float *__restrict__ corr8, in
 __device__ __forceinline__ void lo_score(lo_shared &sh, const float *__restrict__ corr8, int m, float thr2, int ntrial)
 {
     // 32-bit per-thread error sums hold when (correspondences per thread) * thr2 * 2^20 < 2^32
-    if (ntrial == LO_TRIALS) { lo_score_lanes(sh, corr8, m, thr2); return; }
+    if (ntrial > 1) { lo_score_lanes(sh, corr8, m, thr2); return; }      // (lanes of trials >= ntrial score stale models nobody reads)
     const bool narrow = ((double)(m / LO_THREADS + 1)) * (double)thr2 * 1048576.0 < 4.0e9;
     if (!narrow) lo_score_wide(sh, corr8, m, thr2, ntrial);
     else lo_score_one(sh, corr8, m, thr2);
@@ -1064,11 +1064,11 @@ ransac_lo_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__re
     const int call = state->lo_calls;
     __syncthreads();
     if (mode == 0) {
-        for (int round = 0; round < LO_ROUNDS; ++round) {
+        for (int round = 0; round < p.lo_rounds; ++round) {
             lo_build_list(sh, corr8, m, p.thr2, list);
             const int nI = sh.nI;
             if (nI <= p.sample_size) break;
-            const int ntrial = nI > LO_SAMPLE ? LO_TRIALS : 1;
+            const int ntrial = nI > LO_SAMPLE ? p.lo_trials : 1;
             if (nI > LO_SAMPLE) {
                 // LO_SAMPLE distinct positions per trial (word stream keyed by seed, call, round, trial; a word that repeats a position is
                 // skipped): 32 lanes per trial, lane j keeps the j-th accepted position, so "already drawn?" is one ballot over the
@@ -1076,7 +1076,7 @@ ransac_lo_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__re
                 // all LO_TRIALS * LO_SAMPLE of them in flight at once).
                 {
                     const int t = tid >> 5, j = tid & 31, half = (tid >> 5) & 1;
-                    if (t < LO_TRIALS) {
+                    if (t < ntrial) {
                         int mine = -1, got = 0;
                         const uint64_t key = p.seed ^ 0x4c4f43414c4f5054ull;
                         for (int blk = 0; blk < 32 && got < LO_SAMPLE; ++blk) {
@@ -1102,7 +1102,7 @@ ransac_lo_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__re
                 }
                 __syncthreads();
                 // ... and summed by one thread per trial in the order of kabsch_points_kernel / orc_kabsch_points
-                if (tid < LO_TRIALS) {
+                if (tid < ntrial) {
                     double cp[3] = { 0, 0, 0 }, cq[3] = { 0, 0, 0 }, W = 0.0;
 #pragma unroll 1
                     for (int k = 0; k < LO_SAMPLE; ++k) {      // (rolled: unrolled, the 126 values of both loops are kept live and spill)
@@ -1171,7 +1171,7 @@ ransac_lo_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__re
                 double fn = f;
                 for (int q = 1; q < p.sample_size; ++q) fn = fn * f;
                 const double kk = lr_det_log(1.0 - (double)p.confidence) / lr_det_log(1.0 - fn);
-                if ((double)h_end >= kk) state->done = 1;
+                if ((double)h_end >= kk && h_end >= p.min_iters) state->done = 1;
             }
         }
         lr_ransac_result r;
@@ -1213,9 +1213,20 @@ int lr_inlier_mask_run(const float *src, const float *tgt, const int32_t *i0, co
     return LR_OK;
 }
 
-int lr_ransac_run(lr_workspace *ws, const float *corr8, int m_max, const int32_t *m_dev, const lr_ransac_params *p,
+int lr_ransac_run(lr_workspace *ws, const float *corr8, int m_max, const int32_t *m_dev, const lr_ransac_params *p_in,
                   double *T_out, lr_ransac_result *res, hipStream_t st)
 {
+    LR_REQUIRE(p_in->scoring >= 0 && p_in->scoring <= 2, LR_EINVAL, "lr_ransac: scoring must be 0 (count, then error), 1 (MSAC) or 2 (MSAC at GC-RANSAC's truncated threshold)");
+    LR_REQUIRE(p_in->lo_rounds >= 0 && p_in->lo_trials >= 0 && p_in->lo_trials <= 20 && p_in->lo_max_calls >= 0 && p_in->min_iters >= 0, LR_EINVAL,
+               "lr_ransac: lo_rounds, lo_trials (<= 20), lo_max_calls and min_iters must be >= 0 (0 = default)");
+    // the parameters as the kernels use them: defaults resolved, the truncated threshold applied (same text as oracle.c eff_params)
+    lr_ransac_params pe = *p_in;
+    if (pe.scoring == 2) { pe.thr2 = pe.thr2 * 2.25f; pe.scoring = 1; }
+    if (pe.lo_rounds <= 0) pe.lo_rounds = 10;
+    if (pe.lo_trials <= 0) pe.lo_trials = 20;
+    if (pe.lo_max_calls <= 0) pe.lo_max_calls = pe.use_elc ? 20 : 50;
+    if (pe.min_iters <= 0) pe.min_iters = pe.use_elc ? 20 : 50;
+    const lr_ransac_params *p = &pe;
     LR_REQUIRE(p->sample_size == 3 || p->sample_size == 4, LR_EINVAL, "lr_ransac: sample_size must be 3 or 4");
     LR_REQUIRE(p->iters >= 0 && p->iters <= ws->max_iters, LR_ESIZE, "lr_ransac: iters exceeds the workspace");
     LR_REQUIRE(m_max >= 0 && m_max <= ws->max_n0, LR_ESIZE, "lr_ransac: m exceeds the workspace");
@@ -1234,7 +1245,6 @@ int lr_ransac_run(lr_workspace *ws, const float *corr8, int m_max, const int32_t
     LR_REQUIRE(p->sampler >= 0 && p->sampler <= 2, LR_EINVAL, "lr_ransac: sampler must be 0 (uniform), 1 (PROSAC) or 2 (uniform, unique indices)");
     LR_REQUIRE(p->local_opt >= 0 && p->local_opt <= 2, LR_EINVAL, "lr_ransac: local_opt must be 0, 1 or 2");
     LR_REQUIRE(p->prosac_growth >= 0, LR_EINVAL, "lr_ransac: prosac_growth must be >= 0");
-    LR_REQUIRE(p->scoring == 0 || p->scoring == 1, LR_EINVAL, "lr_ransac: scoring must be 0 (count, then error) or 1 (MSAC)");
     const int TN = p->prosac_growth > 0 ? p->prosac_growth : 100000;
     const int32_t *G = nullptr;
     if (ws->timing && ws->ev_pending == 1) { LR_HIP(hipEventRecord(ws->ev[2], st)); }

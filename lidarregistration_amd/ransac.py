@@ -18,16 +18,18 @@ PRECHECK = {"NONE": 0, "ELC": 1, "SPRT": 2}      # --fast_rejection (test.py:306
 
 
 def ransac_params(iters, sample_size=3, use_elc=True, thr=0.6, seed=DEFAULT_SEED, confidence=1.0, batch=0, sampler=0, prosac_growth=0,
-                  scoring=0, local_opt=0):
+                  scoring=0, local_opt=0, lo_rounds=0, lo_trials=0, lo_max_calls=0, min_iters=0):
     """confidence < 1 enables the early exit between batches of `batch` hypothesis ids (0 -> 8192, 16384, 32768, ...: doubling); sampler 1 = PROSAC
-    (correspondences best quality first, growth parameter T_N = prosac_growth, 0 -> 100000), 2 = uniform with unique indices; scoring 1 = MSAC;
-    local_opt 1 = GC-RANSAC's local optimisation + final iterated least squares, 2 = the latter only."""
+    (correspondences best quality first, growth parameter T_N = prosac_growth, 0 -> 100000), 2 = uniform with unique indices; scoring 1 = MSAC,
+    2 = MSAC at GC-RANSAC's truncated threshold (3/2 thr)^2; local_opt 1 = GC-RANSAC's local optimisation + final iterated least squares,
+    2 = the latter only; lo_rounds / lo_trials / lo_max_calls / min_iters: 0 = the defaults of gcransac_python.cpp:513-517 (lidarreg.h)."""
     return _ext.RansacParams(int(sample_size), int(use_elc), np.float32(float(thr) * float(thr)), int(iters), int(seed),
-                             float(confidence), int(batch), int(sampler), int(prosac_growth), int(scoring), int(local_opt))
+                             float(confidence), int(batch), int(sampler), int(prosac_growth), int(scoring), int(local_opt),
+                             int(lo_rounds), int(lo_trials), int(lo_max_calls), int(min_iters))
 
 
 def ransac_dev(src, tgt, iters, sample_size=3, use_elc=True, thr=0.6, seed=DEFAULT_SEED, confidence=1.0, batch=0, sampler=0,
-               prosac_growth=0, scoring=0, local_opt=0, want_mask=False):
+               prosac_growth=0, scoring=0, local_opt=0, want_mask=False, lo_rounds=0, lo_trials=0, lo_max_calls=0, min_iters=0):
     """RANSAC over M correspondences src[i] <-> tgt[i] ([M,3]).  Returns (T 4x4 float64 numpy, info dict); with want_mask the
     info holds the inlier mask of the returned model (what pygcransac.findRigidTransform returns next to the pose)."""
     src, tgt = _f32(src), _f32(tgt)
@@ -35,19 +37,24 @@ def ransac_dev(src, tgt, iters, sample_size=3, use_elc=True, thr=0.6, seed=DEFAU
     ws = workspace(max(m, 1), 1, iters)
     T = torch.empty(16, dtype=torch.float64, device=src.device)
     res = torch.zeros(ctypes.sizeof(_ext.RansacResult), dtype=torch.uint8, device=src.device)
-    p = ransac_params(iters, sample_size, use_elc, thr, seed, confidence, batch, sampler, prosac_growth, scoring, local_opt)
+    p = ransac_params(iters, sample_size, use_elc, thr, seed, confidence, batch, sampler, prosac_growth, scoring, local_opt,
+                      lo_rounds, lo_trials, lo_max_calls, min_iters)
     _ext.check(_ext.lib().lr_ransac(ws.handle, src.data_ptr(), tgt.data_ptr(), m, None, ctypes.byref(p),
                                      T.data_ptr(), res.data_ptr(), _stream()))
     mask = None
     if want_mask:
+        # the estimator's own inlier set: same enqueue, no synchronisation in between (scoring 2 tests against the truncated threshold)
         mask = torch.zeros(max(m, 1), dtype=torch.uint8, device=src.device)
         nin = torch.zeros(1, dtype=torch.int32, device=src.device)
-        _ext.check(_ext.lib().lr_inlier_mask(ws.handle, src.data_ptr(), tgt.data_ptr(), m, T.data_ptr(), ctypes.c_float(p.thr2),
+        _ext.check(_ext.lib().lr_inlier_mask(ws.handle, src.data_ptr(), tgt.data_ptr(), m, T.data_ptr(), ctypes.c_float(p.effective_thr2()),
                                               mask.data_ptr(), nin.data_ptr(), _stream()))
-    r = _ext.RansacResult.from_buffer_copy(res.cpu().numpy().tobytes())
+    r = _ext.RansacResult.from_buffer_copy(res.cpu().numpy().tobytes())          # (the one synchronisation of the call)
     info = dict(best_h=r.best_h, best_count=r.best_count, best_ssq=r.best_ssq, n_valid=r.n_valid, n_ids=r.n_ids)
     if want_mask:
-        info["mask"] = mask[:m].cpu().numpy().astype(bool); info["n_inliers"] = int(nin.item())
+        if r.best_h < 0:          # no model (pygcransac returns pose None there): the mask of nothing
+            info["mask"] = np.zeros(m, bool); info["n_inliers"] = 0
+        else:
+            info["mask"] = mask[:m].cpu().numpy().astype(bool); info["n_inliers"] = int(nin.item())
     return T.cpu().numpy().reshape(4, 4), info
 
 
@@ -94,8 +101,9 @@ def GC_RANSAC(A, B, distance_threshold, num_iterations, args, match_quality, ret
     """GC_RANSAC.py:8-55: (pose 4x4 column-vector convention, elapsed seconds) -- the same estimator ``FR(codebase="GC")``
     runs: 3-point samples drawn without repetition, pre-verification by ``args.fast_rejection`` ("ELC" edge-length check |
     "SPRT" sequential probability ratio test over the first 256 pairs | "NONE"),
-    PROSAC when ``args.prosac`` (pairs sorted by -match_quality, GC_RANSAC.py:39-43), MSAC scoring, GC-RANSAC's local
-    optimisation unless ``args.GC_LO`` is False (GC_RANSAC.py:36-37), the final iterated least squares, confidence
+    PROSAC when ``args.prosac`` (pairs sorted by -match_quality, GC_RANSAC.py:39-43), MSAC scoring at GC-RANSAC's truncated
+    threshold, GC-RANSAC's local optimisation unless ``args.GC_LO`` is False and a pre-verification is selected (GC_RANSAC.py:36-37;
+    gcransac_python.cpp:518-521 honours the switch only in those branches), the final iterated least squares, confidence
     ``args.GC_conf``.  A non-zero ``args.spatial_coherence_weight`` raises (only the reference's default 0 is built).
     With return_mask the inlier mask pygcransac returns next to the pose is appended (in the caller's pair order)."""
     fast_rejection = getattr(args, "fast_rejection", "ELC")
@@ -114,8 +122,8 @@ def GC_RANSAC(A, B, distance_threshold, num_iterations, args, match_quality, ret
     start_time = time()
     T, info = ransac_dev(A, B, num_iterations, sample_size=3, use_elc=use_elc, thr=distance_threshold,
                          seed=getattr(args, "seed", DEFAULT_SEED), confidence=getattr(args, "GC_conf", 0.999),      # GC_RANSAC.py:26
-                         sampler=1 if prosac else 2, scoring=1,                 # MSAC, as pygcransac scores models
-                         local_opt=1 if getattr(args, "GC_LO", True) else 2, want_mask=return_mask)
+                         sampler=1 if prosac else 2, scoring=2,                 # MSAC at the truncated threshold, as pygcransac scores models
+                         local_opt=1 if (getattr(args, "GC_LO", True) or fast_rejection == "NONE") else 2, want_mask=return_mask)
     if info["best_h"] < 0:
         T = np.eye(4)                                       # GC_RANSAC.py:51-52
     elapsed = time() - start_time

@@ -346,10 +346,31 @@ typedef struct {
                                  first; 2 uniform, unique indices (GC-RANSAC's UniformSampler).  1 and 2 reject a draw with a
                                  repeated index: it consumes its id like a failed pre-check                                  */
     int32_t  prosac_growth;   /* T_N of the PROSAC growth function (0 -> 100000)       */
-    int32_t  scoring;         /* 0: inlier count, then error sum (Open3D); 1: MSAC (GC-RANSAC's truncated quadratic cost) */
+    int32_t  scoring;         /* 0: inlier count, then error sum (Open3D); 1: MSAC at thr2; 2: MSAC at GC-RANSAC's TRUNCATED
+                                 threshold (3/2 thr)^2 -- inlier test, cost, exit rule, local optimisation and polish all use
+                                 2.25 thr2 (upstream-recalled: GCRANSAC::run sets truncated_threshold = 3/2 threshold and
+                                 MSACScoringFunction tests and scores against its square)                  */
     int32_t  local_opt;       /* 0 none; 1 GC-RANSAC's local optimisation of every new best model + final iterated least
                                  squares (GC_RANSAC.py:36-37 --GC_LO True); 2 the final iterated least squares only        */
+    /* gcransac_python.cpp:513-517,553-556,579-582 -- three settings whose meaning lives in un-vendored code; 0 = default */
+    int32_t  lo_rounds;       /* rounds of one local optimisation (upstream max_graph_cut_number; default 10)           */
+    int32_t  lo_trials;       /* least-squares fits per round, 1..20 (one reading of max_local_optimization_number = 20) */
+    int32_t  lo_max_calls;    /* local optimisations per run (the other reading: upstream counts INVOCATIONS against
+                                 max_local_optimization_number: 20 with a pre-verification, 50 without)                  */
+    int32_t  min_iters;       /* the exit rule is not consulted before this many ids (min_iteration_number: 20 / 50)     */
 } orc_ransac_params;
+
+/* the parameters as the loop uses them: defaults resolved, the truncated threshold applied */
+static orc_ransac_params eff_params(const orc_ransac_params *in)
+{
+    orc_ransac_params p = *in;
+    if (p.scoring == 2) { p.thr2 = p.thr2 * 2.25f; p.scoring = 1; }
+    if (p.lo_rounds <= 0) p.lo_rounds = 10;
+    if (p.lo_trials <= 0 || p.lo_trials > 20) p.lo_trials = 20;
+    if (p.lo_max_calls <= 0) p.lo_max_calls = p.use_elc ? 20 : 50;
+    if (p.min_iters <= 0) p.min_iters = p.use_elc ? 20 : 50;
+    return p;
+}
 
 /* is model (c, q, h) better than (bc, bq, bh)?  msac_T = (uint32)(thr2 * 2^20) for MSAC scoring, else 0 */
 static int model_better(uint32_t c, uint64_t q, int64_t h, uint32_t bc, uint64_t bq, int64_t bh, uint32_t msac_T)
@@ -596,10 +617,10 @@ static int lo_optimise(const float *src, const float *tgt, int m, const orc_rans
 {
     const uint32_t msac_T = p->scoring == 1 ? (uint32_t)(p->thr2 * 1048576.0f) : 0u;
     int changed = 0;
-    for (int round = 0; round < LO_ROUNDS; ++round) {
+    for (int round = 0; round < p->lo_rounds; ++round) {
         const int nI = lo_inliers(src, tgt, m, T, p->thr2, list);
         if (nI <= p->sample_size) break;
-        const int ntrial = nI > LO_SAMPLE ? LO_TRIALS : 1;
+        const int ntrial = nI > LO_SAMPLE ? p->lo_trials : 1;
         int bt = -1; uint32_t bc = 0; uint64_t bq = 0; double bT[16];
         for (int t = 0; t < ntrial; ++t) {
             double Tt[16];
@@ -649,9 +670,10 @@ ORC_API void orc_lo_sample(uint64_t seed, int call, int round, int trial, int n,
  * e >= log(1-conf)/log(1-(inl/M)^n) for the best model so far (the exit rule of Open3D's
  * RegistrationRANSACBasedOnCorrespondence / GC-RANSAC, applied at batch granularity so that a parallel
  * evaluation is deterministic).  confidence >= 1 disables it: every id is evaluated.              */
-ORC_API void orc_ransac(const float *src, const float *tgt, int m, const orc_ransac_params *p,
+ORC_API void orc_ransac(const float *src, const float *tgt, int m, const orc_ransac_params *p_in,
                         double T_best[16], orc_ransac_result *res)
 {
+    const orc_ransac_params pe = eff_params(p_in), *p = &pe;
     int64_t best_h = -1; uint32_t best_c = 0; uint64_t best_q = 0; int64_t n_valid = 0, n_ids = 0;
     /* with local optimisation the best model is no longer the minimal-sample fit of best_h: it is carried along */
     double Tb[16]; int have_T = 0, lo_calls = 0;
@@ -702,7 +724,7 @@ ORC_API void orc_ransac(const float *src, const float *tgt, int m, const orc_ran
         if (bb_h >= 0 && (best_h < 0 || model_better(bb_c, bb_q, bb_h, best_c, best_q, best_h, msac_T))) {
             best_h = bb_h; best_c = bb_c; best_q = bb_q;
             hypothesis_T(src, tgt, m, p, (uint64_t)best_h, Tb, NULL, G); have_T = 1;
-            if (p->local_opt == 1) { lo_optimise(src, tgt, m, p, lo_calls, Tb, &best_c, &best_q, lo_list); lo_calls += 1; }
+            if (p->local_opt == 1 && lo_calls < p->lo_max_calls) { lo_optimise(src, tgt, m, p, lo_calls, Tb, &best_c, &best_q, lo_list); lo_calls += 1; }
         }
         n_ids = h1;
         if (p->use_elc == 2) {
@@ -719,9 +741,90 @@ ORC_API void orc_ransac(const float *src, const float *tgt, int m, const orc_ran
             double fn = f;
             for (int k = 1; k < p->sample_size; ++k) fn = fn * f;
             double kk = det_log(1.0 - (double)p->confidence) / det_log(1.0 - fn);
-            if ((double)h1 >= kk) break;
+            if ((double)h1 >= kk && h1 >= (int64_t)p->min_iters) break;
         }
     }
+    for (int k = 0; k < 16; ++k) T_best[k] = (k % 5 == 0) ? 1.0 : 0.0;
+    if (best_h >= 0 && have_T) {
+        if (p->local_opt) lo_polish(src, tgt, m, p, Tb, &best_c, &best_q, lo_list);
+        memcpy(T_best, Tb, sizeof(Tb));
+    }
+    free(G); free(lo_list);
+    res->best_h = best_h; res->best_count = best_c; res->best_ssq = best_q; res->n_valid = n_valid; res->n_ids = n_ids;
+}
+
+/* SEQUENTIAL-SEMANTICS REFERENCE MODE.  The loop above (and the HIP kernels) evaluate hypothesis ids in batches: exit rule, local
+ * optimisation and SPRT re-design happen between batches of >= 8192 ids, and the SPRT looks at the first 256 correspondences only.
+ * The third-party loops behind the reference work per iteration (Open3D RegistrationRANSACBasedOnCorrespondence, FR.py:128-137;
+ * GCRANSAC::run behind GC_RANSAC.py:24-37 / gcransac_python.cpp:513-517).  This function restates THAT order over the same
+ * hypothesis stream (id h -> the same sample, pre-check and model):
+ *   for h = 0, 1, ...: stop when h >= min_iters and h >= k(best) = log(1-conf)/log(1-(inl/M)^n)   [GCRANSAC::run's while condition]
+ *     sample h -> pre-check -> model -> (SPRT: Wald's test over ALL correspondences, re-designed after every rejected model and
+ *     every new best) -> score -> a strictly better model becomes the best at once, is locally optimised at once (at most
+ *     lo_max_calls times) and k is updated from the optimised model
+ *   then the final iterated least squares.
+ * tests/test_oracle_ransac.py measures how far the batched result is from this one (final T after the last least squares) and how
+ * many more ids the batched loop examines.  n_ids = ids examined.                                                                */
+ORC_API void orc_ransac_seq(const float *src, const float *tgt, int m, const orc_ransac_params *p_in,
+                            double T_best[16], orc_ransac_result *res)
+{
+    const orc_ransac_params pe = eff_params(p_in), *p = &pe;
+    int64_t best_h = -1; uint32_t best_c = 0; uint64_t best_q = 0; int64_t n_valid = 0, n_ids = 0;
+    double Tb[16]; int have_T = 0, lo_calls = 0;
+    int32_t *lo_list = (int32_t *)malloc(sizeof(int32_t) * (size_t)(m > 0 ? m : 1));
+    double sprt_eps = SPRT_EPS0, sprt_delta = SPRT_DELTA0, sprt_A = p->use_elc == 2 ? sprt_threshold(SPRT_EPS0, SPRT_DELTA0) : 0.0;
+    uint64_t rej_inl = 0, rej_pts = 0;
+    const int use_exit = p->confidence > 0.0f && p->confidence < 1.0f;
+    int32_t *G = p->sampler == 1 ? prosac_table(m, p->sample_size, p->prosac_growth > 0 ? p->prosac_growth : 100000) : NULL;
+    const uint32_t msac_T = p->scoring == 1 ? (uint32_t)(p->thr2 * 1048576.0f) : 0u;
+    double k_needed = INFINITY;
+    int64_t h = 0;
+    for (; h < p->iters; ++h) {
+        if (use_exit && h >= (int64_t)p->min_iters && (double)h >= k_needed) break;
+        double T[16];
+        if (!hypothesis_T(src, tgt, m, p, (uint64_t)h, T, NULL, G)) continue;
+        float Rt[12];
+        for (int k = 0; k < 12; ++k) Rt[k] = (float)T[k];
+        if (p->use_elc == 2) {
+            /* Wald's test to the end of the list */
+            const double fin = sprt_delta / sprt_eps, fout = (1.0 - sprt_delta) / (1.0 - sprt_eps);
+            double lambda = 1.0; int inl = 0, rejected = 0, kk = m;
+            for (int i = 0; i < m; ++i) {
+                float px = src[3 * i], py = src[3 * i + 1], pz = src[3 * i + 2];
+                float x = fmaf(Rt[0], px, fmaf(Rt[1], py, fmaf(Rt[2], pz, Rt[3])));
+                float y = fmaf(Rt[4], px, fmaf(Rt[5], py, fmaf(Rt[6], pz, Rt[7])));
+                float z = fmaf(Rt[8], px, fmaf(Rt[9], py, fmaf(Rt[10], pz, Rt[11])));
+                float dx = x - tgt[3 * i], dy = y - tgt[3 * i + 1], dz = z - tgt[3 * i + 2];
+                float d2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+                if (d2 < p->thr2) { inl += 1; lambda = lambda * fin; } else lambda = lambda * fout;
+                if (lambda > sprt_A) { rejected = 1; kk = i + 1; break; }
+            }
+            if (rejected) {
+                rej_inl += (uint64_t)inl; rej_pts += (uint64_t)kk;
+                const double d = (double)rej_inl / (double)rej_pts;
+                if (d > 0.0 && d < 0.9 * sprt_eps && fabs(d - sprt_delta) > 0.05 * sprt_delta) { sprt_delta = d; sprt_A = sprt_threshold(sprt_eps, sprt_delta); }
+                continue;
+            }
+        }
+        n_valid += 1;
+        uint32_t c; uint64_t q;
+        score_model(src, tgt, m, Rt, p->thr2, &c, &q);
+        if (c == 0) continue;
+        if (best_h < 0 || model_better(c, q, h, best_c, best_q, best_h, msac_T)) {
+            best_h = h; best_c = c; best_q = q; memcpy(Tb, T, sizeof(Tb)); have_T = 1;
+            if (p->local_opt == 1 && lo_calls < p->lo_max_calls) { lo_optimise(src, tgt, m, p, lo_calls, Tb, &best_c, &best_q, lo_list); lo_calls += 1; }
+            if (p->use_elc == 2) {
+                const double e = (double)best_c / (double)m;
+                if (e > sprt_eps && e < 1.0) { sprt_eps = e; if (!(sprt_delta < 0.9 * sprt_eps)) sprt_delta = 0.9 * sprt_eps * 0.5; sprt_A = sprt_threshold(sprt_eps, sprt_delta); }
+            }
+            if (use_exit) {
+                double f = (double)best_c / (double)m, fn = f;
+                for (int k = 1; k < p->sample_size; ++k) fn = fn * f;
+                k_needed = det_log(1.0 - (double)p->confidence) / det_log(1.0 - fn);
+            }
+        }
+    }
+    n_ids = h;
     for (int k = 0; k < 16; ++k) T_best[k] = (k % 5 == 0) ? 1.0 : 0.0;
     if (best_h >= 0 && have_T) {
         if (p->local_opt) lo_polish(src, tgt, m, p, Tb, &best_c, &best_q, lo_list);

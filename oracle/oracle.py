@@ -36,7 +36,8 @@ class RansacParams(ctypes.Structure):
     _fields_ = [("sample_size", ctypes.c_int32), ("use_elc", ctypes.c_int32),
                 ("thr2", ctypes.c_float), ("iters", ctypes.c_int32), ("seed", ctypes.c_uint64),
                 ("confidence", ctypes.c_float), ("batch", ctypes.c_int32),
-                ("sampler", ctypes.c_int32), ("prosac_growth", ctypes.c_int32), ("scoring", ctypes.c_int32), ("local_opt", ctypes.c_int32)]
+                ("sampler", ctypes.c_int32), ("prosac_growth", ctypes.c_int32), ("scoring", ctypes.c_int32), ("local_opt", ctypes.c_int32),
+                ("lo_rounds", ctypes.c_int32), ("lo_trials", ctypes.c_int32), ("lo_max_calls", ctypes.c_int32), ("min_iters", ctypes.c_int32)]
 
 
 class RansacResult(ctypes.Structure):
@@ -297,9 +298,11 @@ def philox(seed, h):
 
 # ----------------------------------------------------------------------------- RANSAC (a10) + refit (a11)
 
-def _params(sample_size, use_elc, thr, iters, seed, confidence=1.0, batch=0, sampler=0, prosac_growth=0, scoring=0, local_opt=0):
+def _params(sample_size, use_elc, thr, iters, seed, confidence=1.0, batch=0, sampler=0, prosac_growth=0, scoring=0, local_opt=0,
+            lo_rounds=0, lo_trials=0, lo_max_calls=0, min_iters=0):
     return RansacParams(sample_size, int(use_elc), np.float32(float(thr) * float(thr)), iters, seed, confidence, batch,
-                        int(sampler), int(prosac_growth), int(scoring), int(local_opt))
+                        int(sampler), int(prosac_growth), int(scoring), int(local_opt), int(lo_rounds), int(lo_trials), int(lo_max_calls),
+                        int(min_iters))
 
 
 def prosac_order(feat_dist):
@@ -318,25 +321,31 @@ def hypothesis(src, tgt, h, sample_size=3, use_elc=True, thr=0.6, seed=51, sampl
     return bool(ok), T.reshape(4, 4), s[:sample_size]
 
 
-def score(src, tgt, T, thr=0.6):
+TRUNCATED_THR2 = float(np.float32(0.6 * 0.6) * np.float32(2.25))      # scoring = 2 at the reference's 0.6 m: the float the loops test against
+
+
+def score(src, tgt, T, thr=0.6, thr2=None):
     src, tgt = _f32(src), _f32(tgt)
     T = np.ascontiguousarray(T, np.float64)
     c = ctypes.c_uint32(); q = ctypes.c_uint64()
     lib().orc_score(_p(src, c_f32p), _p(tgt, c_f32p), src.shape[0], _p(T, c_f64p),
-                    ctypes.c_float(np.float32(float(thr) * float(thr))), ctypes.byref(c), ctypes.byref(q))
+                    ctypes.c_float(np.float32(float(thr) * float(thr)) if thr2 is None else np.float32(thr2)), ctypes.byref(c), ctypes.byref(q))
     return c.value, q.value
 
 
 def ransac(src, tgt, iters, sample_size=3, use_elc=True, thr=0.6, seed=51, confidence=1.0, batch=0, sampler=0, prosac_growth=0,
-           scoring=0, local_opt=0):
+           scoring=0, local_opt=0, lo_rounds=0, lo_trials=0, lo_max_calls=0, min_iters=0, sequential=False):
     """RANSAC over M correspondences src[i] <-> tgt[i] (sampler 1: PROSAC, pairs best quality first; 2: uniform with unique
-    indices; local_opt 1: GC-RANSAC's local optimisation + final iterated least squares, 2: the latter only).
-    Returns (T 4x4 float64, info dict)."""
+    indices; scoring 1: MSAC, 2: MSAC at GC-RANSAC's truncated threshold; local_opt 1: GC-RANSAC's local optimisation + final
+    iterated least squares, 2: the latter only).  sequential=True: the per-iteration reference mode (orc_ransac_seq) instead of the
+    batched loop the HIP kernels implement.  Returns (T 4x4 float64, info dict)."""
     src, tgt = _f32(src), _f32(tgt)
     T = np.empty(16, np.float64)
-    p = _params(sample_size, use_elc, thr, iters, seed, confidence, batch, sampler, prosac_growth, scoring, local_opt)
+    p = _params(sample_size, use_elc, thr, iters, seed, confidence, batch, sampler, prosac_growth, scoring, local_opt, lo_rounds, lo_trials,
+                lo_max_calls, min_iters)
     r = RansacResult()
-    lib().orc_ransac(_p(src, c_f32p), _p(tgt, c_f32p), src.shape[0], ctypes.byref(p), _p(T, c_f64p), ctypes.byref(r))
+    fn = lib().orc_ransac_seq if sequential else lib().orc_ransac
+    fn(_p(src, c_f32p), _p(tgt, c_f32p), src.shape[0], ctypes.byref(p), _p(T, c_f64p), ctypes.byref(r))
     return T.reshape(4, 4), dict(best_h=r.best_h, best_count=r.best_count, best_ssq=r.best_ssq, n_valid=r.n_valid, n_ids=r.n_ids)
 
 

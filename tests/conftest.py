@@ -36,10 +36,11 @@ def rot_diff_rad(A, B):
 
 def gc_oracle_kwargs(a):
     """Keyword arguments of oracle.register_pair that restate what --codebase GC runs for the flags in `a`
-    (FR.pair_params): MSAC, unique-index sampling (PROSAC when a.prosac), local optimisation unless a.GC_LO is False,
-    final iterated least squares inside the RANSAC call, no refit stage."""
-    return dict(sample_size=3, use_elc={"NONE": 0, "ELC": 1, "SPRT": 2}[a.fast_rejection], confidence=a.GC_conf, refit_on_orig=0, scoring=1,
-                local_opt=1 if a.GC_LO else 2, prosac=bool(a.prosac), unique=not a.prosac)
+    (FR.pair_params): MSAC at the truncated threshold, unique-index sampling (PROSAC when a.prosac), local optimisation unless
+    a.GC_LO is False (and a pre-verification is selected: gcransac_python.cpp:518-521), final iterated least squares inside the
+    RANSAC call, no refit stage."""
+    return dict(sample_size=3, use_elc={"NONE": 0, "ELC": 1, "SPRT": 2}[a.fast_rejection], confidence=a.GC_conf, refit_on_orig=0, scoring=2,
+                local_opt=1 if (a.GC_LO or a.fast_rejection == "NONE") else 2, prosac=bool(a.prosac), unique=not a.prosac)
 
 
 class Args:

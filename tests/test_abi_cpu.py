@@ -34,12 +34,12 @@ def test_version_and_error_string(libpath):
 
 def test_struct_layouts_match_header():
     # sizes the C side static-asserts implicitly through its field order (include/lidarreg.h)
-    assert ctypes.sizeof(_ext.RansacParams) == 48 and _ext.RansacParams.sampler.offset == 32 and _ext.RansacParams.scoring.offset == 40
-    assert _ext.RansacParams.local_opt.offset == 44
+    assert ctypes.sizeof(_ext.RansacParams) == 64 and _ext.RansacParams.sampler.offset == 32 and _ext.RansacParams.scoring.offset == 40
+    assert _ext.RansacParams.local_opt.offset == 44 and _ext.RansacParams.lo_rounds.offset == 48 and _ext.RansacParams.min_iters.offset == 60
     assert ctypes.sizeof(_ext.RansacResult) == 40
     assert ctypes.sizeof(_ext.PairResult) == 496
-    assert ctypes.sizeof(_ext.PairParams) == 80
-    assert _ext.PairParams.ransac.offset == 8 and _ext.PairParams.gpf_factor.offset == 64
+    assert ctypes.sizeof(_ext.PairParams) == 96
+    assert _ext.PairParams.ransac.offset == 8 and _ext.PairParams.gpf_factor.offset == 80
 
 
 def test_bad_arguments_are_reported_not_crashed(libpath):
@@ -83,13 +83,17 @@ def test_pair_params_follow_the_reference_flags():
     p = FR.pair_params(Args(mode="GPF", codebase="GC", iters=None, prosac=True, GPF_factor=1.5, GPF_grid_wid=12))
     assert (p.mode, p.refit, p.gpf_grid_wid, p.gpf_factor) == (_ext.LR_MODE_GPF, 0, 12, 1.5)
     r = p.ransac
-    assert (r.sample_size, r.use_elc, r.iters, r.sampler, r.scoring, r.local_opt) == (3, 1, 500000, 1, 1, 1)       # FR.py:65-67, GC_RANSAC.py:19-37
+    assert (r.sample_size, r.use_elc, r.iters, r.sampler, r.scoring, r.local_opt) == (3, 1, 500000, 1, 2, 1)       # FR.py:65-67, GC_RANSAC.py:19-37
+    assert (r.lo_rounds, r.lo_trials, r.lo_max_calls, r.min_iters) == (0, 0, 0, 0) and abs(r.effective_thr2() - 0.81) < 1e-6   # library defaults; (3/2 * 0.6)^2
     assert abs(r.confidence - 0.999) < 1e-7 and abs(r.thr2 - 0.36) < 1e-7
     p = FR.pair_params(Args(mode="MMN", codebase="GC", iters=1000, prosac=False, fast_rejection="NONE", GC_conf=0.9))
     assert (p.mode, p.ransac.sampler, p.ransac.use_elc, p.ransac.iters) == (_ext.LR_MODE_MNN, 2, 0, 1000)     # uniform, unique indices
     assert abs(p.ransac.confidence - 0.9) < 1e-7
     # --GC_LO False: only the final least squares (GC_RANSAC.py:36-37); flags the HIP path does not implement are refused
     assert FR.pair_params(Args(codebase="GC", GC_LO=False)).ransac.local_opt == 2
+    # ... but gcransac_python.cpp:518-521,553-556 honour that switch only in the branches with a pre-verification (:571-591 do not)
+    assert FR.pair_params(Args(codebase="GC", GC_LO=False, fast_rejection="NONE")).ransac.local_opt == 1
+    assert FR.pair_params(Args(codebase="GC", lo_trials=5, lo_max_calls=3, min_iters=100)).ransac.lo_trials == 5
     import pytest
     assert FR.pair_params(Args(codebase="GC", fast_rejection="SPRT")).ransac.use_elc == 2
     with pytest.raises(NotImplementedError):

@@ -46,6 +46,24 @@ def test_local_optimisation_matches_oracle(lr, oracle, n, iters, seed, sampler, 
         assert oracle.rotation_error_deg(T, T_gt) < 0.5
 
 
+@pytest.mark.parametrize("knobs", [dict(scoring=2), dict(scoring=2, lo_trials=5), dict(scoring=2, lo_trials=1, lo_rounds=3), dict(scoring=1, lo_rounds=1),
+                                   dict(scoring=2, lo_max_calls=1, confidence=0.999, batch=64), dict(scoring=2, min_iters=700, confidence=0.999, batch=100),
+                                   dict(scoring=2, use_elc=0, confidence=0.999, batch=16), dict(scoring=2, use_elc=2, lo_max_calls=2, confidence=0.99, batch=256)])
+def test_gc_semantics_knobs_match_oracle(lr, oracle, knobs):
+    """scoring = 2 (MSAC at GC-RANSAC's truncated threshold) and the settings of gcransac_python.cpp:513-517 as explicit fields
+    (rounds and fits per round of one local optimisation, optimisations per run, minimum ids before the exit rule): HIP == oracle."""
+    src, tgt, T_gt = _planted(n=5000, inlier=0.35, seed=77)
+    kw = dict(sample_size=3, seed=13, sampler=2, local_opt=1, confidence=1.0, batch=0)
+    kw.update(knobs)
+    T, info = lr.ransac.ransac_dev(src, tgt, 6000, **kw)
+    Te, einfo = oracle.ransac(src, tgt, 6000, **kw)
+    assert info == einfo, (knobs, info, einfo)
+    assert np.array_equal(T, Te)
+    assert oracle.rotation_error_deg(T, T_gt) < 0.5
+    if knobs.get("min_iters"):
+        assert info["n_ids"] == 700          # 35 % inliers: the rule would stop after the first batch of 100 ids
+
+
 @pytest.mark.parametrize("n", [7, 23, 47, 48, 49, 95, 96, 97, 191, 1023, 1025, 2047, 2049, 4099, 65537])
 def test_local_optimisation_size_sweep(lr, oracle, n):
     """Sizes around the boundaries of the LO kernel's work split: 2 correspondences per record (odd counts), 48 records per step of
@@ -100,8 +118,8 @@ def test_inlier_mask_is_what_the_model_scores(lr, oracle):
     a = Args(codebase="GC", prosac=True, iters=2000)
     q = np.random.default_rng(0).random(3000).astype(np.float32)
     Tg, _, m = lr.ransac.GC_RANSAC(src, tgt, 0.6, 2000, a, q, return_mask=True)
-    c, _ = oracle.score(src, tgt, Tg)
-    assert m.sum() == c and oracle.score(src[m], tgt[m], Tg)[0] == c
+    c, _ = oracle.score(src, tgt, Tg, thr2=oracle.TRUNCATED_THR2)            # --codebase GC tests inliers against the truncated threshold 3/2 * 0.6
+    assert m.sum() == c and oracle.score(src[m], tgt[m], Tg, thr2=oracle.TRUNCATED_THR2)[0] == c
 
 
 @pytest.mark.parametrize("lo", [True, False])
@@ -132,8 +150,8 @@ def test_register_batch_gc_mask_per_pair(lr, oracle):
         r = lr.ext.PairResult.from_buffer_copy(out[k].cpu().numpy().tobytes())
         n0 = p["xyz0"].shape[0]
         mask = lr.torch.zeros(n0, dtype=lr.torch.uint8, device=dev); nin = lr.torch.zeros(1, dtype=lr.torch.int32, device=dev)
-        lr.ext.check(lr.ext.lib().lr_workspace_mask_at(ws.handle, k, devp[k][0].data_ptr(), devp[k][1].data_ptr(), n0, ctypes.c_float(0.36),
-                                                       mask.data_ptr(), nin.data_ptr(), None))
+        lr.ext.check(lr.ext.lib().lr_workspace_mask_at(ws.handle, k, devp[k][0].data_ptr(), devp[k][1].data_ptr(), n0,
+                                                       ctypes.c_float(params.ransac.effective_thr2()), mask.data_ptr(), nin.data_ptr(), None))
         assert int(nin.item()) == r.ransac.best_count == int(mask[:r.n_corr].sum().item())
         e = oracle.register_pair(p["xyz0"], p["xyz1"], p["feats0"], p["feats1"], mode="MNN", iters=2000, seed=51, args=a, **gc_oracle_kwargs(a))
         np.testing.assert_allclose(np.array(r.T[:]).reshape(4, 4), e["T"], rtol=0, atol=1e-9)

@@ -394,7 +394,7 @@ def test_FR_prosac_matches_oracle_pipeline(lr, oracle, mode, N, iters):
         Tg, _ = lr.ransac.GC_RANSAC(A, B, 0.6, iters, a, -fd)
         order = oracle.prosac_order(fd)
         # ... and with FR(codebase="GC"): one estimator behind both names (LO + final least squares included)
-        Te, _ = oracle.ransac(A[order], B[order], iters, 3, True, 0.6, 51, a.GC_conf, 0, sampler=1, scoring=1, local_opt=1)
+        Te, _ = oracle.ransac(A[order], B[order], iters, 3, True, 0.6, 51, a.GC_conf, 0, sampler=1, scoring=2, local_opt=1)
         assert np.array_equal(Tg, Te)
         np.testing.assert_allclose(Tg, T, rtol=0, atol=1e-9)
 

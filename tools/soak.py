@@ -29,7 +29,7 @@ for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 60):
         ns = 3 if cb == "GC" else 4
         e = oracle.register_pair(p["xyz0"], p["xyz1"], p["feats0"], p["feats1"], mode=mode, iters=1200, sample_size=ns, seed=51, args=a,
                                  confidence=a.GC_conf if cb == "GC" else a.o3d_conf, refit_on_orig=0 if cb == "GC" else 1,
-                                 prosac=(cb == "GC"), scoring=1 if cb == "GC" else 0, local_opt=1 if cb == "GC" else 0)
+                                 prosac=(cb == "GC"), scoring=2 if cb == "GC" else 0, local_opt=1 if cb == "GC" else 0)
         ws.poison(int(rng.integers(256)))
         T = FR.FR(t(p["xyz0"]), t(p["xyz1"]), t(p["feats0"]), t(p["feats1"]), a, p["T_gt"])[0]
         np.testing.assert_allclose(T, e["T"], rtol=0, atol=1e-9)
