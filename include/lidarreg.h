@@ -138,6 +138,16 @@ LR_API int    lr_workspace_destroy(lr_workspace *ws);
 LR_API size_t lr_workspace_bytes(const lr_workspace *ws);
 /* Test hook (no reference counterpart): fill the scratch arena with one byte value; results must not depend on it. */
 LR_API int    lr_workspace_poison(lr_workspace *ws, int byte, void *stream);
+/* Tuning options of a workspace (no reference counterpart; NONE of them changes a result, tests/test_gpu_parity.py; the library
+ * reads no environment variable).  value 0 restores the default.                                                          */
+enum {
+    LR_OPT_NN_BLOCKS        = 1,  /* a single-pair filter pass is cut into column strips so that it launches about this many blocks (512) */
+    LR_OPT_NN_BLOCKS_BATCH  = 2,  /* the same for a batched call, over all its pairs (3072)                                  */
+    LR_OPT_NN_SAMPLE_STRIDE = 3,  /* the filter pass samples every k-th column tile for its start thresholds (default: strip tiles / 32, at most 16) */
+    LR_OPT_REV_STRIPS       = 4,  /* column strips offered to each row block of the reverse NN pass (default 48 / pairs, within 2..8) */
+    LR_OPT_NN_SECOND_AUTO   = 5   /* 1: lr_register_pair / _batch compute the second neighbour only when a stage of the call reads it */
+};
+LR_API int    lr_workspace_option(lr_workspace *ws, int option, int value);
 
 /* ---- a1/a2: find_nn / find_2nn  (Experiments/algorithms/matching.py:6-65) ------------------------
  * For every row of F0 [n0,dim] the nearest and second nearest row of F1 [n1,dim] under L2, first
@@ -218,7 +228,10 @@ LR_API int lr_register_pair(lr_workspace *ws, const float *xyz0, const float *xy
  * kernel launches over `npairs` pairs: every kernel of the path is launched once with the pair as a grid dimension, so the
  * GPU is filled by the batch instead of by many concurrent streams.  xyz0/xyz1/F0/F1/n0/n1 are HOST arrays of length npairs
  * (device pointers / cloud sizes, which may differ from pair to pair); out is a DEVICE array of npairs result blocks.  The
- * result of pair k is bit-identical to lr_register_pair on that pair.                                                      */
+ * result of pair k is bit-identical to lr_register_pair on that pair.
+ * ONE CALL IN FLIGHT PER WORKSPACE: the call's descriptor table and scratch arenas belong to the workspace, so a second call on
+ * the same workspace -- from any stream -- may only be enqueued behind the first on the SAME stream; concurrent batches need one
+ * workspace each (bench.py: one per stream).  The *_at accessors read pair < npairs of the LAST call only.                  */
 LR_API int lr_register_batch(lr_workspace *ws, int npairs, const float *const *xyz0, const float *const *xyz1,
                              const float *const *F0, const float *const *F1, const int32_t *n0, const int32_t *n1, int dim,
                              const lr_pair_params *p, lr_pair_result *out, void *stream);
@@ -246,6 +259,12 @@ LR_API int    lr_voxel_dedup(const double *coords, int n, int32_t *sel, int32_t 
  * from HIP events recorded on the launch stream.  Enable, run, synchronise, then read.            */
 LR_API int lr_workspace_timing(lr_workspace *ws, int enable);
 LR_API int lr_workspace_timing_read(lr_workspace *ws, float *nn_ms, float *ransac_ms, int *n_samples);
+/* Stage times of the timed lr_register_pair / _batch calls since lr_workspace_timing(ws, 1), sums in ms over *n_samples calls
+ * (read after synchronising the stream): out[0] whole call; out[1] forward NN = find_nn of matching.py:22-65 incl. the second
+ * neighbour (norms + f16 copies, filter pass, exact verification); out[2] / out[3] the forward / reverse filter-pass launch;
+ * out[4] hypothesis generation + scoring of the first RANSAC batch; out[5..7] reserved (0).  The registration time FR.py:117
+ * bills -- filter + RANSAC + refit + the second neighbour's surcharge, matching.py:12-18 -- is out[0] - out[1] + that surcharge.  */
+LR_API int lr_workspace_stage_times(lr_workspace *ws, float out[8], int *n_samples);
 
 #ifdef __cplusplus
 }

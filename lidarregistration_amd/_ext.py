@@ -18,8 +18,13 @@ SYMBOLS = [
     "lr_nn_top2", "lr_nn_to_mutual", "lr_feat_ratio", "lr_gpf", "lr_gpf_bb_first", "lr_ransac", "lr_refit", "lr_icp", "lr_kabsch",
     "lr_register_pair", "lr_workspace_lists", "lr_workspace_timing", "lr_workspace_timing_read",
     "lr_workspace_create_batch", "lr_register_batch", "lr_workspace_lists_at", "lr_inlier_mask", "lr_workspace_mask_at",
-    "lr_voxel_dedup_scratch_bytes", "lr_voxel_dedup",
+    "lr_voxel_dedup_scratch_bytes", "lr_voxel_dedup", "lr_workspace_option", "lr_workspace_stage_times",
 ]
+
+# lr_workspace_option ids (include/lidarreg.h).  DEFAULT_OPTIONS is applied to every Workspace this module creates (a hook for
+# tuning experiments and for the test that no option changes a result; the library itself reads no environment variable).
+OPTIONS = {"nn_blocks": 1, "nn_blocks_batch": 2, "nn_sample_stride": 3, "rev_strips": 4, "nn_second_auto": 5}
+DEFAULT_OPTIONS = {}
 
 
 class LidarRegError(RuntimeError):
@@ -117,6 +122,8 @@ def lib():
         L.lr_workspace_create_batch.argtypes = [ctypes.POINTER(ctypes.c_void_p), ci, ci, ci, ci, ci]
         pp, ip = ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int32)
         L.lr_register_batch.argtypes = [vp, ci, pp, pp, pp, pp, ip, ip, ci, ctypes.POINTER(PairParams), vp, vp]
+        L.lr_workspace_option.argtypes = [vp, ci, ci]
+        L.lr_workspace_stage_times.argtypes = [vp, ctypes.POINTER(ctypes.c_float * 8), ctypes.POINTER(ci)]
         L.lr_workspace_timing.argtypes = [vp, ci]
         L.lr_workspace_timing_read.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ci)]
         _lib = L
@@ -137,6 +144,22 @@ class Workspace:
         self.max_n0, self.max_n1, self.dim, self.max_iters = int(max_n0), int(max_n1), int(dim), int(max_iters)
         self.max_pairs = int(max_pairs)
         check(lib().lr_workspace_create_batch(ctypes.byref(self._h), self.max_pairs, self.max_n0, self.max_n1, self.dim, self.max_iters))
+        for name, value in DEFAULT_OPTIONS.items():
+            self.set_option(name, value)
+
+    def set_option(self, name, value):
+        """Tuning option of this workspace (OPTIONS; none changes a result)."""
+        check(lib().lr_workspace_option(self._h, OPTIONS[name], int(value)))
+
+    def stage_times(self):
+        """(sums in ms [whole call, forward NN, forward filter pass, reverse filter pass, RANSAC gen+score], timed calls) since
+        lr_workspace_timing(ws, 1); the stream must be synchronised."""
+        out = (ctypes.c_float * 8)(); n = ctypes.c_int()
+        check(lib().lr_workspace_stage_times(self._h, out, ctypes.byref(n)))
+        return list(out[:5]), n.value
+
+    def timing(self, enable):
+        check(lib().lr_workspace_timing(self._h, int(bool(enable))))
 
     @property
     def handle(self):

@@ -39,15 +39,10 @@ struct Carver {
 void carve(lr_workspace *ws, Carver &c)
 {
     const size_t n0 = ws->max_n0, n1 = ws->max_n1, n = ws->max_n, it = ws->max_iters;
-    ws->Fp0 = c.take<float>(n0 * 32); ws->Fp1 = c.take<float>(n1 * 32);
     ws->nrm0 = c.take<float>(n0); ws->nrm1 = c.take<float>(n1);
     ws->H0 = c.take<_Float16>(n0 * 32); ws->H1 = c.take<_Float16>(n1 * 32);
     ws->tau = c.take<float>(n);
     ws->cand_cnt = c.take<int32_t>(LR_NN16_CNT_INTS(n)); ws->cand = c.take<int32_t>(LR_NN16_SEG_INTS(n));
-    ws->pb1 = c.take<float>(n * LR_NN_MAX_STRIPS); ws->pb2 = c.take<float>(n * LR_NN_MAX_STRIPS);
-    ws->pb3 = c.take<float>(n * LR_NN_MAX_STRIPS);
-    ws->pi1 = c.take<int32_t>(n * LR_NN_MAX_STRIPS); ws->pi2 = c.take<int32_t>(n * LR_NN_MAX_STRIPS);
-    ws->fix_list = c.take<int32_t>(n);
     ws->counters = c.take<int32_t>(LR_CNT_TOTAL);
     ws->bmax0 = c.take<float>(n0 / 32 + 2); ws->bmax1 = c.take<float>(n1 / 32 + 2);
     ws->rev_seed = c.take<uint32_t>(n1); ws->rev_rows = c.take<int32_t>(n1);
@@ -109,24 +104,10 @@ extern "C" int lr_workspace_create_batch(lr_workspace **out, int max_pairs, int 
     ws->max_n0 = max_n0; ws->max_n1 = max_n1; ws->max_n = max_n0 > max_n1 ? max_n0 : max_n1;
     ws->dim = dim; ws->max_iters = max_iters > 0 ? max_iters : 1;
     ws->max_pairs = max_pairs; ws->zP = 1; ws->z = lr_zargs{ 0, nullptr };
-    {
-        const char *e = getenv("LIDARREG_NN_PATH");
-        ws->nn_path = (e && strcmp(e, "fp32") == 0) ? LR_NN_PATH_FP32_MFMA : LR_NN_PATH_F16_FILTER;
-        const char *b = getenv("LIDARREG_NN_BLOCKS");      // tuning knob: blocks per filter pass (default 512 = 2 per CU; measured best with many pairs in flight)
-        ws->nn_blocks_target = b ? atoi(b) : 512;
-        if (ws->nn_blocks_target < 1) ws->nn_blocks_target = 1;
-        const char *bb = getenv("LIDARREG_NN_BLOCKS_BATCH");   // the same for a batched call: blocks per pass over all its pairs
-        ws->nn_blocks_batch = bb ? atoi(bb) : 3072;
-        if (ws->nn_blocks_batch < 1) ws->nn_blocks_batch = 1;
-        const char *ss = getenv("LIDARREG_NN_STRIDE");      // development knob: sampling stride of the filter pass (any value gives the exact result)
-        ws->nn_sample_stride = ss && atoi(ss) > 0 ? atoi(ss) : 0;
-        const char *rs = getenv("LIDARREG_REV_STRIPS");
-        ws->rev_strips = rs ? atoi(rs) : 0;            // 0: by the number of pairs of the call (lr_nn16_reverse)
-        if (ws->rev_strips < 0) ws->rev_strips = 0;
-        if (ws->rev_strips > 64) ws->rev_strips = 64;
-        const char *sa = getenv("LIDARREG_NN_SECOND");
-        ws->nn_second_auto = (sa && strcmp(sa, "auto") == 0) ? 1 : 0;
-    }
+    // tuning defaults (lr_workspace_option changes them; no environment variable is read anywhere in this library)
+    ws->nn_blocks_target = 512;          // 2 blocks per CU: measured best with many single-pair calls in flight
+    ws->nn_blocks_batch = 3072;
+    ws->nn_sample_stride = 0; ws->rev_strips = 0; ws->nn_second_auto = 0;
     Carver sizing;
     carve(ws, sizing);
     ws->stride = (sizing.off + 511) & ~size_t(255);          // one arena per pair, identical layout
@@ -143,7 +124,7 @@ extern "C" int lr_workspace_create_batch(lr_workspace **out, int max_pairs, int 
     carve(ws, real);
     ws->descs = reinterpret_cast<lr_pair_desc *>(ws->base + desc_off);
     if (hipMemset(ws->base, 0, ws->bytes) != hipSuccess) { (void)hipFree(ws->base); delete ws; lr_set_error("lr_workspace_create: hipMemset failed"); return LR_EHIP; }
-    for (int k = 0; k < 6; ++k)
+    for (int k = 0; k < LR_NEV; ++k)
         if (hipEventCreate(&ws->ev[k]) != hipSuccess) { (void)hipFree(ws->base); delete ws; lr_set_error("lr_workspace_create: hipEventCreate failed"); return LR_EHIP; }
     *out = ws;
     return LR_OK;
@@ -152,13 +133,28 @@ extern "C" int lr_workspace_create_batch(lr_workspace **out, int max_pairs, int 
 extern "C" int lr_workspace_destroy(lr_workspace *ws)
 {
     if (!ws) return LR_OK;
-    for (int k = 0; k < 6; ++k) (void)hipEventDestroy(ws->ev[k]);
+    for (int k = 0; k < LR_NEV; ++k) (void)hipEventDestroy(ws->ev[k]);
     (void)hipFree(ws->base);
     delete ws;
     return LR_OK;
 }
 
 extern "C" size_t lr_workspace_bytes(const lr_workspace *ws) { return ws ? ws->bytes : 0; }
+
+extern "C" int lr_workspace_option(lr_workspace *ws, int option, int value)
+{
+    LR_REQUIRE(ws, LR_EINVAL, "lr_workspace_option: null workspace");
+    LR_REQUIRE(value >= 0, LR_EINVAL, "lr_workspace_option: value must be >= 0");
+    switch (option) {
+    case LR_OPT_NN_BLOCKS: ws->nn_blocks_target = value > 0 ? value : 512; break;
+    case LR_OPT_NN_BLOCKS_BATCH: ws->nn_blocks_batch = value > 0 ? value : 3072; break;
+    case LR_OPT_NN_SAMPLE_STRIDE: ws->nn_sample_stride = value; break;
+    case LR_OPT_REV_STRIPS: ws->rev_strips = value > 64 ? 64 : value; break;
+    case LR_OPT_NN_SECOND_AUTO: ws->nn_second_auto = value ? 1 : 0; break;
+    default: lr_set_error("lr_workspace_option: unknown option %d", option); return LR_EINVAL;
+    }
+    return LR_OK;
+}
 
 // test hook: overwrite the whole scratch arena with one byte value.  No entry point may depend on what an earlier call
 // (or hipMalloc) left in the scratch; the parity tests poison it with different patterns and expect identical results.
@@ -180,6 +176,7 @@ extern "C" int lr_workspace_lists_at(lr_workspace *ws, int pair, int n0, int32_t
 {
     LR_REQUIRE(ws, LR_EINVAL, "lr_workspace_lists: null workspace");
     LR_REQUIRE(pair >= 0 && pair < ws->max_pairs, LR_EINVAL, "lr_workspace_lists: pair outside the workspace");
+    LR_REQUIRE(pair < ws->last_npairs, LR_EINVAL, "lr_workspace_lists: the last registration call on this workspace had fewer pairs");
     LR_REQUIRE(n0 > 0 && n0 <= ws->max_n0, LR_ESIZE, "lr_workspace_lists: n0 exceeds the workspace");
     hipStream_t st = (hipStream_t)stream;
     const size_t nb = sizeof(int32_t) * (size_t)n0, off = (size_t)pair * ws->stride;
@@ -203,6 +200,26 @@ extern "C" int lr_workspace_timing(lr_workspace *ws, int enable)
 {
     LR_REQUIRE(ws, LR_EINVAL, "lr_workspace_timing: null workspace");
     ws->timing = enable; ws->ev_pending = 0; ws->rev_recorded = 0; ws->nn_ms_acc = 0; ws->ransac_ms_acc = 0; ws->n_samples = 0;
+    ws->call_ms_acc = 0; ws->fwd_ms_acc = 0; ws->fwd_filter_ms_acc = 0; ws->rev_filter_ms_acc = 0;
+    return LR_OK;
+}
+
+// folds the events of the last timed call into the sums
+static int lr_timing_collect(lr_workspace *ws)
+{
+    if (ws->ev_pending >= 1) {
+        float ms = 0;
+        LR_HIP(hipEventElapsedTime(&ms, ws->ev[0], ws->ev[1]));
+        ws->nn_ms_acc += ms; ws->fwd_filter_ms_acc += ms;
+        if (ws->rev_recorded) { LR_HIP(hipEventElapsedTime(&ms, ws->ev[4], ws->ev[5])); ws->nn_ms_acc += ms; ws->rev_filter_ms_acc += ms; ws->rev_recorded = 0; }
+        if (ws->ev_pending >= 2) { LR_HIP(hipEventElapsedTime(&ms, ws->ev[2], ws->ev[3])); ws->ransac_ms_acc += ms; }
+        if (ws->ev_pending >= 3) {
+            LR_HIP(hipEventElapsedTime(&ms, ws->ev[6], ws->ev[8])); ws->call_ms_acc += ms;
+            LR_HIP(hipEventElapsedTime(&ms, ws->ev[6], ws->ev[7])); ws->fwd_ms_acc += ms;
+        }
+        ws->n_samples += 1;
+        ws->ev_pending = 0;
+    }
     return LR_OK;
 }
 
@@ -210,17 +227,23 @@ extern "C" int lr_workspace_timing(lr_workspace *ws, int enable)
 extern "C" int lr_workspace_timing_read(lr_workspace *ws, float *nn_ms, float *ransac_ms, int *n_samples)
 {
     LR_REQUIRE(ws, LR_EINVAL, "lr_workspace_timing_read: null workspace");
-    if (ws->ev_pending >= 1) {
-        float ms = 0;
-        LR_HIP(hipEventElapsedTime(&ms, ws->ev[0], ws->ev[1]));
-        ws->nn_ms_acc += ms;
-        if (ws->rev_recorded) { LR_HIP(hipEventElapsedTime(&ms, ws->ev[4], ws->ev[5])); ws->nn_ms_acc += ms; ws->rev_recorded = 0; }
-        if (ws->ev_pending >= 2) { LR_HIP(hipEventElapsedTime(&ms, ws->ev[2], ws->ev[3])); ws->ransac_ms_acc += ms; }
-        ws->n_samples += 1;
-        ws->ev_pending = 0;
-    }
+    LR_TRY_HIP(lr_timing_collect(ws));
     if (nn_ms) *nn_ms = ws->nn_ms_acc;
     if (ransac_ms) *ransac_ms = ws->ransac_ms_acc;
+    if (n_samples) *n_samples = ws->n_samples;
+    return LR_OK;
+}
+
+// Stage times of the timed pair-pipeline calls so far (sums in ms over *n_samples calls; the caller has synchronised the stream):
+// out[0] the whole call, out[1] the forward NN (norms + f16 copies, filter pass, exact verification: find_nn of matching.py:22-65 with
+// the second neighbour), out[2] / out[3] the forward / reverse filter-pass launch, out[4] hypothesis generation + scoring of the
+// first RANSAC batch.  What FR.py:117 bills as registration time is out[0] - out[1] + (the second neighbour's share of out[1]).
+extern "C" int lr_workspace_stage_times(lr_workspace *ws, float out[8], int *n_samples)
+{
+    LR_REQUIRE(ws && out, LR_EINVAL, "lr_workspace_stage_times: null pointer");
+    LR_TRY_HIP(lr_timing_collect(ws));
+    out[0] = ws->call_ms_acc; out[1] = ws->fwd_ms_acc; out[2] = ws->fwd_filter_ms_acc; out[3] = ws->rev_filter_ms_acc; out[4] = ws->ransac_ms_acc;
+    out[5] = out[6] = out[7] = 0.0f;
     if (n_samples) *n_samples = ws->n_samples;
     return LR_OK;
 }
@@ -237,14 +260,9 @@ static int check_nn_args(const lr_workspace *ws, const void *F0, int n0, const v
 
 #define LR_TRY(x) do { int rc_ = (x); if (rc_ != LR_OK) return rc_; } while (0)
 
-// norms + operand copies of both clouds for whichever NN path the workspace uses
+// norms + f16 operand copies of both clouds
 static int prep_both(lr_workspace *ws, const float *F0, int n0, const float *F1, int n1, hipStream_t st, bool zero_counters = false)
 {
-    if (ws->nn_path == LR_NN_PATH_FP32_MFMA) {
-        if (zero_counters) LR_HIP(hipMemsetAsync(ws->counters, 0, sizeof(int32_t) * LR_CNT_TOTAL, st));
-        LR_TRY(lr_nn_prep(ws, F0, n0, ws->Fp0, ws->nrm0, st));
-        return lr_nn_prep(ws, F1, n1, ws->Fp1, ws->nrm1, st);
-    }
     return lr_nn16_prep(ws, F0, n0, F1, n1, st, zero_counters);      // the prep kernel clears the counter block itself
 }
 
@@ -252,8 +270,6 @@ static int prep_both(lr_workspace *ws, const float *F0, int n0, const float *F1,
 static int nn_forward(lr_workspace *ws, const float *F0, int n0, const float *F1, int n1,
                       int32_t *idx1, int32_t *idx2, float *s1, float *s2, hipStream_t st, bool seed_reverse = false)
 {
-    if (ws->nn_path == LR_NN_PATH_FP32_MFMA)
-        return lr_nn_run(ws, ws->Fp0, ws->nrm0, n0, ws->Fp1, ws->nrm1, n1, idx1, idx2, s1, s2, st);
     return lr_nn16_run(ws, F0, ws->H0, ws->nrm0, n0, F1, ws->H1, ws->nrm1, ws->bmax1, n1,
                        idx2 ? 2 : 1, idx1, idx2, s1, idx2 ? s2 : nullptr, st, seed_reverse);
 }
@@ -263,8 +279,6 @@ static int nn_forward(lr_workspace *ws, const float *F0, int n0, const float *F1
 static int nn_reverse(lr_workspace *ws, const float *F0, int n0, const float *F1, int n1, const int32_t *fwd_idx1,
                       int32_t *rev, hipStream_t st, bool seeded = false)
 {
-    if (ws->nn_path == LR_NN_PATH_FP32_MFMA)
-        return lr_nn_run(ws, ws->Fp1, ws->nrm1, n1, ws->Fp0, ws->nrm0, n0, rev, nullptr, nullptr, nullptr, st);
     // seeded by the forward pairs: only columns some query points at are resolved (others get -1)
     return lr_nn16_reverse(ws, F0, ws->H0, ws->nrm0, ws->bmax0, n0, F1, ws->H1, ws->nrm1, n1, fwd_idx1, rev, st, seeded);
 }
@@ -350,6 +364,7 @@ extern "C" int lr_workspace_mask_at(lr_workspace *ws, int pair, const float *xyz
 {
     LR_REQUIRE(ws && xyz0 && xyz1 && mask, LR_EINVAL, "lr_workspace_mask_at: null pointer");
     LR_REQUIRE(pair >= 0 && pair < ws->max_pairs, LR_EINVAL, "lr_workspace_mask_at: pair outside the workspace");
+    LR_REQUIRE(pair < ws->last_npairs, LR_EINVAL, "lr_workspace_mask_at: the last registration call on this workspace had fewer pairs");
     LR_REQUIRE(n0 > 0 && n0 <= ws->max_n0, LR_ESIZE, "lr_workspace_mask_at: n0 exceeds the workspace");
     LR_REQUIRE(thr2 > 0.0f, LR_EINVAL, "lr_workspace_mask_at: thr2 must be positive");
     const size_t off = (size_t)pair * ws->stride;
@@ -419,14 +434,17 @@ static int register_stages(lr_workspace *ws, const float *xyz0, const float *xyz
     int32_t *n_refit = ws->counters + LR_CNT_COUNT - 2;
     // 1. coarse correspondences (FR.py:38): first + second NN of every cloud-0 descriptor
     LR_TRY(prep_both(ws, F0, n0, F1, n1, st, true));
-    const bool fuse_seed = p->mode != LR_MODE_NO_FILTER && ws->nn_path != LR_NN_PATH_FP32_MFMA;   // the forward exact kernel seeds the reverse pass
+    const bool fuse_seed = p->mode != LR_MODE_NO_FILTER;   // the forward exact kernel seeds the reverse pass
+    const bool timed = ws->timing && !ws->ev_pending;
+    if (timed) LR_HIP(hipEventRecord(ws->ev[6], st));
     // The second neighbour (find_2nn, FR.py:38) feeds the feature-distance ratio only: GPF (matching.py:116) and the PROSAC
-    // quality (FR.py:77).  By default it is computed as the reference does; with LIDARREG_NN_SECOND=auto it is left out when
-    // no stage of this call reads it (plain mutual-NN / no filter with uniform sampling): the outputs are the same, the
-    // candidate lists of the forward pass are half as long.
-    const bool want2 = !(ws->nn_second_auto && ws->nn_path != LR_NN_PATH_FP32_MFMA && p->mode != LR_MODE_GPF && p->ransac.sampler == 0);
+    // quality (FR.py:77).  By default it is computed as the reference does; with the option LR_OPT_NN_SECOND_AUTO it is left out
+    // when no stage of this call reads it (plain mutual-NN / no filter with uniform sampling): the outputs are the same, the
+    // candidate lists of the forward pass are half as long (and the reverse pass prunes less: not a gain on its own).
+    const bool want2 = !(ws->nn_second_auto && p->mode != LR_MODE_GPF && p->ransac.sampler == 0);
     int32_t *idx2 = want2 ? ws->nn_idx2 : nullptr;
     LR_TRY(nn_forward(ws, F0, n0, F1, n1, ws->nn_idx1, idx2, ws->nn_s1, ws->nn_s2, st, fuse_seed));
+    if (timed) LR_HIP(hipEventRecord(ws->ev[7], st));
     // 2. filter (FR.py:48-56)
     if (p->mode == LR_MODE_NO_FILTER) {
         LR_TRY(lr_identity_corr(ws, n0, ws->nn_idx1, idx2, ws->corr_idx0, ws->corr_idx1, idx2 ? ws->corr_idx2 : nullptr, m_dev, st));
@@ -470,6 +488,7 @@ static int register_stages(lr_workspace *ws, const float *xyz0, const float *xyz
     if (p->icp)
         LR_TRY(lr_icp_run(ws, xyz0, n0, xyz1, n1, T_final, ws->res_tmp, 0.6, 30, 1e-6, 1e-6, ws->T_tmp + 32, icp_res, st));
     if (p->icp) hipLaunchKernelGGL(pair_icp_kernel, dim3(1, 1, ws->zP), dim3(64), 0, st, ws->T_tmp + 32, icp_res, out, 1, ws->z);
+    if (timed && ws->ev_pending == 2) { LR_HIP(hipEventRecord(ws->ev[8], st)); ws->ev_pending = 3; }
     LR_LAUNCH_CHECK();
     return LR_OK;
 }
@@ -482,6 +501,7 @@ extern "C" int lr_register_pair(lr_workspace *ws, const float *xyz0, const float
     LR_REQUIRE(p->mode == LR_MODE_NO_FILTER || p->mode == LR_MODE_MNN || p->mode == LR_MODE_GPF, LR_EINVAL,
                "lr_register_pair: unknown mode");
     ws->zP = 1; ws->z = lr_zargs{ 0, nullptr };
+    ws->last_npairs = 1;
     return register_stages(ws, xyz0, xyz1, F0, F1, n0, n1, dim, p, out, (hipStream_t)stream);
 }
 
@@ -500,7 +520,6 @@ extern "C" int lr_register_batch(lr_workspace *ws, int npairs, const float *cons
     LR_REQUIRE(npairs >= 1 && npairs <= ws->max_pairs, LR_ESIZE, "lr_register_batch: npairs exceeds the workspace (lr_workspace_create_batch)");
     LR_REQUIRE(p->mode == LR_MODE_NO_FILTER || p->mode == LR_MODE_MNN || p->mode == LR_MODE_GPF, LR_EINVAL,
                "lr_register_batch: unknown mode");
-    LR_REQUIRE(ws->nn_path != LR_NN_PATH_FP32_MFMA, LR_EINVAL, "lr_register_batch: the fp32 cross-check path (LIDARREG_NN_PATH=fp32) is single-pair only");
     lr_desc_table t;
     int mx0 = 0, mx1 = 0;
     for (int k = 0; k < npairs; ++k) {
@@ -513,6 +532,7 @@ extern "C" int lr_register_batch(lr_workspace *ws, int npairs, const float *cons
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(batch_setup_kernel, dim3(1), dim3(64), 0, st, t, ws->descs, npairs);
     ws->zP = npairs; ws->z = lr_zargs{ ws->stride, ws->descs };
+    ws->last_npairs = npairs;
     const int rc = register_stages(ws, xyz0[0], xyz1[0], F0[0], F1[0], mx0, mx1, dim, p, out, st);
     ws->zP = 1; ws->z = lr_zargs{ 0, nullptr };
     return rc;

@@ -44,9 +44,7 @@ __host__ __device__ static inline int lr_seg_cap(int strips) { const int c = (LR
 #define LR_SCORE_BLOCKS 8192
 #define LR_GPF_MAX_CELLS 4096
 #define LR_SC_INFO_BYTES 2048
-// f16 filter path: pass A samples every LR_NN16_STRIDE-th column tile; candidate list capacity per row
-#define LR_NN16_STRIDE 4
-enum { LR_NN_PATH_F16_FILTER = 0, LR_NN_PATH_FP32_MFMA = 1 };
+#define LR_NEV 9
 
 // ---- pair-batched launches -------------------------------------------------------------------------------------------
 // A workspace holds `max_pairs` arenas of identical layout, `stride` bytes apart; every scratch pointer below refers to
@@ -84,6 +82,7 @@ __device__ __forceinline__ bool lr_xcd_block(int total, int &logical)
 struct lr_workspace {
     int max_n0, max_n1, max_n, dim, max_iters;
     int max_pairs;               // arenas in this workspace
+    int last_npairs;             // pairs of the last lr_register_pair / _batch call (0: none yet): what the *_at accessors may read
     size_t stride;               // bytes per arena
     size_t bytes;
     char *base;                  // one hipMalloc
@@ -92,7 +91,6 @@ struct lr_workspace {
     int zP;
     lr_zargs z;
     // --- NN (both directions share these) ---
-    float *Fp0, *Fp1;            // [n,32] de-interleaved copies (even k | odd k)
     float *nrm0, *nrm1;          // row norms
     _Float16 *H0, *H1;           // [n,32] f16 copies for the matrix-core filter passes
     float *tau;                  // [max_n] per-row candidate threshold
@@ -106,15 +104,12 @@ struct lr_workspace {
     float *rev_tmin;             // [max_n0/32+1] smallest key of each column tile
     int32_t *rev_hist;           // [2][4096] counting-sort offsets
     _Float16 *Hs; float *nrms;   // [max_n0] f16 rows and norms of cloud 0 in rev_cols order
-    int nn_path;                 // LR_NN_PATH_*
-    int nn_blocks_target;        // column strips are chosen so that a pass launches about this many blocks
-    int nn_blocks_batch;         // the same for a batched call (all pairs together; LIDARREG_NN_BLOCKS_BATCH)
-    int nn_sample_stride;        // phase 1 of the filter pass samples every this-many-th column tile (0: by the strip length)
-    int rev_strips;              // strips offered to every row block of the reverse pass (LIDARREG_REV_STRIPS)
-    int nn_second_auto;          // LIDARREG_NN_SECOND=auto: lr_register_pair computes the 2nd neighbour only when a stage reads it
-    float *pb1, *pb2, *pb3;      // partial top-3 values [strips][max_n]
-    int32_t *pi1, *pi2;          // partial top-2 indices
-    int32_t *fix_list;           // rows needing the exact tie-break path [max_n]
+    // tuning options (lr_workspace_option; none of them changes a result)
+    int nn_blocks_target;        // LR_OPT_NN_BLOCKS: column strips are chosen so that a filter pass launches about this many blocks
+    int nn_blocks_batch;         // LR_OPT_NN_BLOCKS_BATCH: the same for a batched call (all pairs together)
+    int nn_sample_stride;        // LR_OPT_NN_SAMPLE_STRIDE: phase 1 of the filter pass samples every this-many-th column tile (0: by the strip length)
+    int rev_strips;              // LR_OPT_REV_STRIPS: strips offered to every row block of the reverse pass (0: by the number of pairs)
+    int nn_second_auto;          // LR_OPT_NN_SECOND_AUTO: the pair pipeline computes the 2nd neighbour only when a stage reads it
     int32_t *counters;           // small int block, see LR_CNT_*
     // --- per-pair lists ---
     int32_t *nn_idx1, *nn_idx2;  // forward NN over n0 rows
@@ -159,8 +154,8 @@ struct lr_workspace {
     double *icp_state, *icp_part;
     // --- timing hook ---
     int timing;
-    hipEvent_t ev[6];            // [0,1] forward pass B, [2,3] RANSAC gen+score, [4,5] reverse pass B
-    float nn_ms_acc, ransac_ms_acc;
+    hipEvent_t ev[LR_NEV];       // [0,1] forward filter pass, [2,3] RANSAC gen+score, [4,5] reverse filter pass, [6] call start, [7] forward NN done, [8] call end
+    float nn_ms_acc, ransac_ms_acc, call_ms_acc, fwd_ms_acc, fwd_filter_ms_acc, rev_filter_ms_acc;
     int n_samples;
     int ev_pending;
     int rev_recorded;
@@ -209,11 +204,6 @@ static_assert(sizeof(lr_ransac_state) <= (LR_CNT_TOTAL - LR_CNT_COUNT) * sizeof(
 // lr_api.hip: zero `bytes` of scratch at `p` (arena 0) in the arena of every pair of the call in flight
 int lr_zero_scratch(lr_workspace *ws, void *p, size_t bytes, hipStream_t st);
 
-// lr_nn.hip
-int lr_nn_run(lr_workspace *ws, const float *Fa, const float *nrma, int na, const float *Fb, const float *nrmb, int nb,
-              int32_t *idx1, int32_t *idx2, float *s1, float *s2, hipStream_t st);
-int lr_nn_prep(lr_workspace *ws, const float *F, int n, float *Fp, float *nrm, hipStream_t st);
-
 // lr_nn16.hip
 int lr_nn16_prep(lr_workspace *ws, const float *F0, int n0, const float *F1, int n1, hipStream_t st, bool zero_counters = false);
 int lr_nn16_run(lr_workspace *ws, const float *Fq, const _Float16 *Hq, const float *nQ, int na,
@@ -222,8 +212,6 @@ int lr_nn16_run(lr_workspace *ws, const float *Fq, const _Float16 *Hq, const flo
 int lr_nn16_reverse(lr_workspace *ws, const float *F0, const _Float16 *H0, const float *nrm0, const float *bmax0, int n0,
                     const float *F1, const _Float16 *H1, const float *nrm1, int n1, const int32_t *fwd_idx1,
                     int32_t *rev, hipStream_t st, bool seeded = false);
-int lr_nn_fix_rows(lr_workspace *ws, bool permuted, const float *Fa, const float *nrma, const float *Fb, const float *nrmb, int nb,
-                   int32_t *idx1, int32_t *idx2, float *s1, float *s2, hipStream_t st);
 
 // lr_filter.hip
 int lr_mutual_run(lr_workspace *ws, int n0, const int32_t *idx1, const int32_t *idx2, const int32_t *rev,

@@ -453,8 +453,8 @@ def test_nn_tiny_clouds(lr, oracle, n0, n1):
 
 
 @pytest.mark.parametrize("mode", ["MNN", "no_filter", "GPF"])
-def test_second_neighbour_auto_mode_gives_the_same_pair_result(lr, oracle, monkeypatch, mode):
-    """LIDARREG_NN_SECOND=auto drops the second neighbour where no stage reads it; the result block must not change."""
+def test_second_neighbour_auto_mode_gives_the_same_pair_result(lr, oracle, mode):
+    """The workspace option nn_second_auto drops the second neighbour where no stage reads it; the result block must not change."""
     from lidarregistration_amd import _ext
     p = synth.make_pair(N=4000, rho=0.5, s=0.9, seed=71, clustered=(mode == "GPF"))
     a = Args(mode=mode, codebase="open3D", iters=1500, GPF_factor=0.5)
@@ -462,33 +462,15 @@ def test_second_neighbour_auto_mode_gives_the_same_pair_result(lr, oracle, monke
     t = lr.torch.from_numpy
     dev = [t(p[k]).cuda() for k in ("xyz0", "xyz1", "feats0", "feats1")]
     blocks = []
-    for env in (None, "auto"):
-        if env:
-            monkeypatch.setenv("LIDARREG_NN_SECOND", env)
+    for auto in (0, 1):
         ws = _ext.Workspace(4000, 4000, 32, 1500)
+        ws.set_option("nn_second_auto", auto)
         ws.poison(0xA5)
         out = lr.FR.register_pair_dev(*dev, params, ws=ws)
         r = lr.FR.read_result(out)
         blocks.append((np.array(r.T[:]), r.n_corr, r.ransac.best_h, r.ransac.best_count, r.n_refit))
         ws.close()
     assert np.array_equal(blocks[0][0], blocks[1][0]) and blocks[0][1:] == blocks[1][1:]
-
-
-def test_fp32_mfma_path_agrees(lr, oracle, monkeypatch):
-    # the exact fp32-MFMA kernel (LIDARREG_NN_PATH=fp32) stays available and must give the same answers
-    import ctypes
-    from lidarregistration_amd import _ext
-    monkeypatch.setenv("LIDARREG_NN_PATH", "fp32")
-    F0, F1 = synth.make_features(3000, 2500, 32, 0.5, 1.0, 2)
-    ws = _ext.Workspace(3000, 2500, 32, 1)
-    t = lr.torch
-    f0, f1 = t.from_numpy(F0).cuda(), t.from_numpy(F1).cuda()
-    i1 = t.empty(3000, dtype=t.int32, device="cuda"); i2 = t.empty_like(i1)
-    _ext.check(_ext.lib().lr_nn_top2(ws.handle, f0.data_ptr(), 3000, f1.data_ptr(), 2500, 32, i1.data_ptr(), i2.data_ptr(), None, None,
-                                      t.cuda.current_stream().cuda_stream))
-    o1, o2, _, _ = oracle.nn_top2(F0, F1)
-    assert np.array_equal(i1.cpu().numpy(), o1) and np.array_equal(i2.cpu().numpy(), o2)
-    ws.close()
 
 
 def test_FR_gpf_full_size(lr, oracle):
@@ -645,32 +627,39 @@ def test_nn_candidate_store_overflow_falls_back_to_the_exact_scan(lr, oracle):
         assert all(np.array_equal(a.numpy(), b) for a, b in zip(g, m)), kind
 
 
-def test_tuning_knobs_do_not_change_results(lr):
-    """LIDARREG_NN_STRIDE (pass-A sampling), LIDARREG_REV_STRIPS (reverse strips), LIDARREG_NN_BLOCKS (forward strips): any value gives
-    the same lists and the same transform -- each setting in its own process (the stride is read once per process)."""
-    import hashlib, os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = (
-        "import sys, hashlib, numpy as np, torch\n"
-        f"sys.path.insert(0, {root!r})\n"
-        "from lidarregistration_amd import FR, synth, matching\n"
-        "from tests.conftest import Args\n"
-        "p = synth.make_pair(N=9000, N1=7000, rho=0.4, s=0.8, seed=77)\n"
-        "t = torch.from_numpy\n"
-        "i0, i1, i2, _ = matching.find_2nn(t(p['feats0']), t(p['feats1']))\n"
-        "m = matching.nn_to_mutual(t(p['feats0']), t(p['feats1']), i0, i1, i2)\n"
-        "a = Args(mode='MNN', codebase='open3D', iters=3000, ransac_n=3, o3d_conf=1.0)\n"
-        "T = FR.FR(t(p['xyz0']), t(p['xyz1']), t(p['feats0']), t(p['feats1']), a, p['T_gt'])[0]\n"
-        "h = hashlib.sha256()\n"
-        "for x in (i1, i2, m[0], m[1]): h.update(np.ascontiguousarray(x.numpy()).tobytes())\n"
-        "h.update(np.ascontiguousarray(T).tobytes())\n"
-        "print('HASH', h.hexdigest())\n")
-    def run(extra):
-        env = dict(os.environ, **extra)
-        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
-        assert r.returncode == 0, r.stderr[-1500:]
-        return [l for l in r.stdout.splitlines() if l.startswith("HASH")][0]
+def test_tuning_options_do_not_change_results(lr):
+    """lr_workspace_option: the sampling stride of the filter pass, the strips of the reverse pass, the blocks (column strips) of the
+    forward pass and the second-neighbour switch: any value gives the same lists and the same transform.  (The library reads no
+    environment variable; _ext.DEFAULT_OPTIONS applies options to the workspaces the host mirror creates.)"""
+    import hashlib
+    from lidarregistration_amd import _ext, matching
+    p = synth.make_pair(N=9000, N1=7000, rho=0.4, s=0.8, seed=77)
+    t = lr.torch.from_numpy
+
+    def run(options):
+        _ext.DEFAULT_OPTIONS.clear(); _ext.DEFAULT_OPTIONS.update(options)
+        for ws in matching._WS.values():
+            ws.close()
+        matching._WS.clear()
+        try:
+            i0, i1, i2, _ = matching.find_2nn(t(p["feats0"]), t(p["feats1"]))
+            m = matching.nn_to_mutual(t(p["feats0"]), t(p["feats1"]), i0, i1, i2)
+            a = Args(mode="MNN", codebase="open3D", iters=3000, ransac_n=3, o3d_conf=1.0)
+            T = lr.FR.FR(t(p["xyz0"]), t(p["xyz1"]), t(p["feats0"]), t(p["feats1"]), a, p["T_gt"])[0]
+        finally:
+            _ext.DEFAULT_OPTIONS.clear()
+        h = hashlib.sha256()
+        for x in (i1, i2, m[0], m[1]):
+            h.update(np.ascontiguousarray(x.numpy()).tobytes())
+        h.update(np.ascontiguousarray(T).tobytes())
+        return h.hexdigest()
+
     ref = run({})
-    for extra in ({"LIDARREG_NN_STRIDE": "1"}, {"LIDARREG_NN_STRIDE": "16"}, {"LIDARREG_REV_STRIPS": "1"}, {"LIDARREG_REV_STRIPS": "64"},
-                  {"LIDARREG_NN_BLOCKS": "64"}, {"LIDARREG_NN_BLOCKS": "4096"}):
-        assert run(extra) == ref, extra
+    for options in ({"nn_sample_stride": 1}, {"nn_sample_stride": 3}, {"nn_sample_stride": 64}, {"rev_strips": 1}, {"rev_strips": 64},
+                    {"nn_blocks": 64}, {"nn_blocks": 4096}, {"nn_second_auto": 1}):
+        assert run(options) == ref, options
+    for ws in matching._WS.values():
+        ws.close()
+    matching._WS.clear()
+    with pytest.raises(lr.ext.LidarRegError):
+        lr.ext.Workspace(100, 100, 32, 10).set_option("nn_blocks", -1)
