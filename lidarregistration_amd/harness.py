@@ -95,6 +95,112 @@ class RefCloudSource:
         return dict(xyz0=xyz0, xyz1=xyz1, feats0=f0, feats1=f1, T_gt=self.pair_list["T_gt"][k])
 
 
+def load_list_fixture(dataset):
+    """The reference's balanced test list of `dataset` ("A" | "B") from tests/golden/lists (made by tests/golden/make_lists.py from
+    balanced_sets/<set>/test.txt) in the dict form of io_lists.read_pair_list."""
+    import os
+    name = io_lists.DATASET_NAMES[dataset]
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "lists", f"{name}_test.npz")
+    z = np.load(path)
+    return dict(session=z["session"].astype(np.int64), src=z["src"].astype(np.int64), tgt=z["tgt"].astype(np.int64),
+                T_gt=z["T_gt"].reshape(-1, 4, 4).astype(np.float64), overlap=z["overlap"].astype(np.float64))
+
+
+def second_nn_share(n, device, reps=5):
+    """What FR.py:117 adds to the billed time: find_nn with the second neighbour minus find_nn without (matching.py:12-18), as a
+    SHARE of the former -- measured here on one synthetic pair of this size with two timed calls each way, applied by the callers
+    to the forward-NN time of the calls they really made."""
+    p = synth.make_pair_dev(N=n, seed=7, device=device)
+    ws = _ext.Workspace(n, n, 32, 1)
+    i1 = torch.empty(n, dtype=torch.int32, device=device); i2 = torch.empty_like(i1)
+    st = torch.cuda.current_stream(device)
+    t = [0.0, 0.0]
+    for k in range(2 * (reps + 1)):
+        two = k % 2
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        _ext.check(_ext.lib().lr_nn_top2(ws.handle, p["feats0"].data_ptr(), n, p["feats1"].data_ptr(), n, 32, i1.data_ptr(),
+                                          i2.data_ptr() if two else None, None, None, st.cuda_stream))
+        e1.record(st); e1.synchronize()
+        if k >= 2:
+            t[two] += e0.elapsed_time(e1)
+    ws.close()
+    return max(0.0, 1.0 - t[0] / t[1]) if t[1] > 0 else 0.0
+
+
+def eval_list_batched(pair_list, indices, args, n=30000, s=1.2, batch=32, nstreams=2, resident=256, device=None, seed=51, verbose=False):
+    """The list-driven synthetic surrogate for the rows `indices` of a balanced list, registered the way bench.py
+    registers its pairs: `resident` pairs are synthesised on the device (row k: its ground-truth motion, overlap -> rho), then
+    registered by batched calls (`batch` pairs per lr_register_batch, round-robin over `nstreams` streams / workspaces) inside
+    a timed region that contains nothing else; repeat.  Returns dict(T [P,4,4], re_deg, te_m, n_corr, n_ids, seconds = the timed
+    regions' sum, stage_ms = per-pair means of [whole call, forward NN, forward filter, reverse filter, RANSAC gen+score] from the
+    library's own events, second_nn_share)."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    params = registration_params(args)
+    P = len(indices)
+    batch = max(1, min(batch, 64))
+    streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
+    wss = [_ext.Workspace(n, n, 32, params.ransac.iters, max_pairs=batch) for _ in range(nstreams)]
+    size = ctypes.sizeof(_ext.PairResult)
+    Ts = np.tile(np.eye(4), (P, 1, 1)); re = np.zeros(P); te = np.zeros(P); n_corr = np.zeros(P, np.int64); n_ids = np.zeros(P, np.int64)
+    status = np.zeros(P, np.int64)
+    seconds = 0.0
+    for lo in range(0, P, resident):
+        rows = indices[lo:lo + resident]
+        pairs, gts = [], []
+        for k in rows:
+            rho = float(np.clip(pair_list["overlap"][k], 0.05, 0.95))
+            p = synth.make_pair_dev(N=n, rho=rho, s=s, seed=seed + int(k), device=dev, T_gt=pair_list["T_gt"][k])
+            pairs.append((p["xyz0"], p["xyz1"], p["feats0"], p["feats1"])); gts.append(p["T_gt"])
+        outs = torch.zeros((len(rows), size), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize(dev)
+        for st in streams:
+            st.wait_stream(torch.cuda.current_stream(dev))
+        t0 = time.perf_counter()
+        for c, b0 in enumerate(range(0, len(rows), batch)):
+            sidx = c % nstreams
+            chunk = pairs[b0:b0 + batch]
+            fr.register_batch_dev(chunk, params, out=outs[b0:b0 + len(chunk)], ws=wss[sidx], stream=streams[sidx].cuda_stream)
+        for st in streams:
+            torch.cuda.current_stream(dev).wait_stream(st)
+        host = outs.cpu()                              # the step's product on the host (the D2H copy is inside the timed region)
+        seconds += time.perf_counter() - t0
+        hb = host.numpy()
+        for j, k in enumerate(rows):
+            r = _ext.PairResult.from_buffer_copy(hb[j].tobytes())
+            T = np.array(r.T[:], np.float64).reshape(4, 4) if r.status == 0 else np.eye(4)
+            Ts[lo + j] = T
+            re[lo + j] = metrics.rotation_error_deg(T, gts[j]); te[lo + j] = metrics.translation_error_cm(T, gts[j]) / 100.0
+            n_corr[lo + j] = r.n_corr; n_ids[lo + j] = r.ransac.n_ids; status[lo + j] = r.status
+        if verbose:
+            print(f"{time.strftime('%m/%d %H:%M:%S')} {lo + len(rows)}/{P} pairs, {(lo + len(rows)) / max(seconds, 1e-9):.0f} pairs/s", flush=True)
+        del pairs, outs
+    # stage times: a separate, serialised pass over a sample of the rows (one timed call at a time per workspace, events read after
+    # each call) -- the throughput loop above keeps several calls in flight and cannot attribute time to stages
+    sample = indices[:min(P, 4 * batch)]
+    stage = np.zeros(5); timed_pairs = 0
+    pairs = []
+    for k in sample:
+        rho = float(np.clip(pair_list["overlap"][k], 0.05, 0.95))
+        p = synth.make_pair_dev(N=n, rho=rho, s=s, seed=seed + int(k), device=dev, T_gt=pair_list["T_gt"][k])
+        pairs.append((p["xyz0"], p["xyz1"], p["feats0"], p["feats1"]))
+    outs = torch.zeros((len(sample), size), dtype=torch.uint8, device=dev)
+    for rep in range(2):                               # first pass warms up, second is read
+        wss[0].timing(True)
+        for b0 in range(0, len(sample), batch):
+            chunk = pairs[b0:b0 + batch]
+            fr.register_batch_dev(chunk, params, out=outs[b0:b0 + len(chunk)], ws=wss[0], stream=streams[0].cuda_stream)
+            streams[0].synchronize()
+            if rep == 1:
+                ms, _ = wss[0].stage_times()
+                stage = np.array(ms); timed_pairs = b0 + len(chunk)
+    share = second_nn_share(n, dev)
+    for w in wss:
+        w.close()
+    return dict(T=Ts, re_deg=re, te_m=te, n_corr=n_corr, n_ids=n_ids, status=status, seconds=seconds,
+                stage_ms_per_pair=(stage / max(timed_pairs, 1)).tolist(), stage_sample_pairs=int(timed_pairs), second_nn_share=share)
+
+
 def registration_params(args):
     """lr_pair_params of the timed registration call.  The harness times ICP on its own (test.py:183-193, stats column 11),
     so the fused ICP stage of lr_register_pair stays off here: column 9 must not contain an ICP."""

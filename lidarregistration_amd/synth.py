@@ -80,9 +80,10 @@ def make_pair(N=30000, D=32, rho=0.5, s=1.2, seed=51, N1=None, clustered=False):
     return dict(xyz0=xyz0, xyz1=xyz1, feats0=F0, feats1=F1, T_gt=T)
 
 
-def make_pair_dev(N=30000, D=32, rho=0.5, s=1.2, seed=51, device=None, noise=0.05):
+def make_pair_dev(N=30000, D=32, rho=0.5, s=1.2, seed=51, device=None, noise=0.05, T_gt=None):
     """The recipe of ``make_pair`` drawn with torch's generator on `device` (milliseconds instead of a quarter second per
     30k-point pair, so a benchmark can hold hundreds of distinct pairs): same distributions, different numbers.
+    T_gt: plant this 4x4 motion instead of a random one (the list-driven surrogate: a row's ground truth and overlap).
     Returns dict(xyz0, xyz1, feats0, feats1) of float32 device tensors and T_gt (4x4 float64 numpy)."""
     import torch
     g = torch.Generator(device=device)
@@ -103,7 +104,7 @@ def make_pair_dev(N=30000, D=32, rho=0.5, s=1.2, seed=51, device=None, noise=0.0
     F1 = torch.empty((N, D), device=device)
     F1[order1[:k]] = unit(F0[src_rows] + s * torch.randn((k, D), generator=g, device=device) / np.sqrt(D))
     F1[order1[k:]] = unit(torch.randn((N - k, D), generator=g, device=device))
-    T = random_motion(np.random.default_rng(seed + 1000003))
+    T = random_motion(np.random.default_rng(seed + 1000003)) if T_gt is None else np.asarray(T_gt, np.float64).reshape(4, 4)
     Tt = torch.from_numpy(T).to(device=device, dtype=torch.float32)
     xyz0 = box(N)
     xyz1 = torch.empty((N, 3), device=device)

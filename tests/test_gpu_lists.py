@@ -1,0 +1,59 @@
+"""BASELINE.json configs[2] / configs[3] as far as this environment allows: the reference's README commands (README.md:54-55) over its own
+balanced test lists with the list-driven synthetic surrogate at 30k points -- every 512th row here, all rows with `bench.py --list A|B`.
+Needs an MI355X."""
+import os
+import subprocess
+import sys
+import json
+
+import numpy as np
+import pytest
+
+from tests.conftest import Args, gc_oracle_kwargs
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _args(dataset):
+    if dataset == "A":
+        return Args(mode="GPF", codebase="GC", iters=50000, prosac=True, GC_conf=0.999)
+    return Args(mode="MMN", codebase="GC", iters=1000000, prosac=True, GC_conf=0.9995)
+
+
+@pytest.mark.parametrize("dataset,rows", [("A", 7008), ("B", 2592)])
+def test_list_rows_every_512th(oracle, dataset, rows):
+    import torch
+    from lidarregistration_amd import harness, synth
+    L = harness.load_list_fixture(dataset)
+    assert len(L["session"]) == rows and L["T_gt"].shape == (rows, 4, 4) and 0.2 <= L["overlap"].min() and L["overlap"].max() < 1.0
+    idx = list(range(0, rows, 512))
+    a = _args(dataset)
+    res = harness.eval_list_batched(L, idx, a, n=30000, batch=8, nstreams=2)
+    ok5 = (res["re_deg"] < 5.0) & (res["te_m"] < 0.6); ok2 = (res["re_deg"] < 2.0) & (res["te_m"] < 0.6)
+    assert ok5.all() and ok2.all(), (res["re_deg"], res["te_m"])                  # surrogate data: every row is recovered
+    assert (res["status"] == 0).all() and (res["n_corr"] > 1000).all()
+    # early exit: an easy pair stops after the first batch of ids, never later than --iters
+    assert (res["n_ids"] >= 8192).all() and (res["n_ids"] <= a.iters).all()
+    call, fwd = res["stage_ms_per_pair"][0], res["stage_ms_per_pair"][1]
+    assert 0.0 < fwd < call and 0.0 <= res["second_nn_share"] < 0.5
+    # one row against the oracle pipeline on the same synthetic pair (the device generator's numbers copied to the host)
+    k = idx[1]
+    p = synth.make_pair_dev(N=30000, rho=float(np.clip(L["overlap"][k], 0.05, 0.95)), s=1.2, seed=51 + k, device=torch.device("cuda", 0), T_gt=L["T_gt"][k])
+    h = {q: p[q].cpu().numpy() for q in ("xyz0", "xyz1", "feats0", "feats1")}
+    e = oracle.register_pair(h["xyz0"], h["xyz1"], h["feats0"], h["feats1"], mode=a.mode, iters=a.iters, seed=51, args=a, **gc_oracle_kwargs(a))
+    T = res["T"][1]
+    assert np.radians(oracle.rotation_error_deg(T, e["T"])) <= 1e-4 and oracle.translation_error_cm(T, e["T"]) / 100 <= 1e-3
+    assert res["n_corr"][1] == len(e["idx0"]) and res["n_ids"][1] == e["ransac"]["n_ids"]
+
+
+def test_bench_list_mode_prints_one_json_line():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--list", "B", "--list-stride", "216", "--batch", "4", "--streams", "2"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["pairs"] == 12 and d["unit"] == "pairs/s" and d["value"] > 0 and d["recall_5deg_0.6m"] == 1.0
+    t = d["time_per_pair_us"]
+    assert t["forward_nn"] < t["whole_call_serialised"] and t["reference_style_FR.py:117"] < t["whole_call_serialised"]
