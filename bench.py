@@ -51,6 +51,10 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=8)
     ap.add_argument("--cpu-budget-s", type=float, default=45.0, help="stop the CPU baseline sample after this many seconds (at least 2 pairs)")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="collective backend of the N > 1 run: nccl (= RCCL over xGMI, the product path) or gloo (host tensors; lets two ranks share "
+                         "one GPU so that the launcher, rendezvous, per-rank seeds and max-over-ranks timing can be exercised on a 1-GPU box)")
+    ap.add_argument("--devices", type=str, default=None, help="comma-separated device index per rank (default: rank r -> device r); e.g. 0,0 with --dist-backend gloo")
     ap.add_argument("--list", choices=["A", "B"], default=None,
                     help="instead of the headline workload: the reference's README commands over a FULL balanced test list with the list-driven "
                          "synthetic surrogate (SURVEY 8d; every row's ground-truth motion and overlap, --n points): A = Apollo-Southbay, 7008 rows, "
@@ -73,14 +77,26 @@ def spawn_ranks(args):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
     try:
-        for p in procs:
-            rc = max(rc, abs(p.wait()))
-            if rc:
-                break
+        # poll ALL children: a rank that dies during init would otherwise leave the parent waiting on rank 0 until the collective's
+        # timeout; the first non-zero exit ends the run and the remaining ranks are killed
+        live = list(procs)
+        while live and rc == 0:
+            for p in list(live):
+                r = p.poll()
+                if r is not None:
+                    live.remove(p)
+                    rc = max(rc, abs(r))
+            if live and rc == 0:
+                time.sleep(0.05)
     finally:
         for p in procs:
             if p.poll() is None:
                 p.kill()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except Exception:
+                pass
     return rc
 
 
@@ -223,10 +239,15 @@ def main():
             dist.init_process_group("gloo")
     else:
         assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
-        torch.cuda.set_device(local_rank)
-        dev = torch.device("cuda", local_rank)
+        dev_index = local_rank if not args.devices else int(args.devices.split(",")[local_rank])
+        torch.cuda.set_device(dev_index)
+        dev = torch.device("cuda", dev_index)
         if use_dist:
-            dist.init_process_group("nccl", device_id=dev)
+            if args.dist_backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group("gloo")
+    host_coll = use_dist and (dry or args.dist_backend == "gloo")      # collectives on host tensors
 
     B = args.batch if args.batch > 0 else (32 if args.n <= 60000 else 8)
     B = max(1, min(B, args.pairs, 64))
@@ -250,7 +271,7 @@ def main():
         wss = [_ext.Workspace(args.n, args.n, 32, args.iters, max_pairs=B) for _ in range(nstreams)]
     outs = torch.zeros((args.pairs, res_bytes), dtype=torch.uint8, device=dev)
     rows = torch.zeros((args.pairs, shard.ROW), dtype=torch.float64, device=dev)
-    gathered = torch.zeros((world * args.pairs, shard.ROW), dtype=torch.float64, device=dev) if use_dist else None
+    gathered = torch.zeros((world * args.pairs, shard.ROW), dtype=torch.float64, device="cpu" if host_coll else dev) if use_dist else None
     host_T = torch.zeros((args.pairs, 16), dtype=torch.float64)
     if not dry:
         host_T = host_T.pin_memory()
@@ -286,7 +307,7 @@ def main():
         if use_dist:
             # result rows = the 16 doubles of T (+ stats columns, zero here); one collective per step
             rows[:, 22:38] = Tdev
-            dist.all_gather_into_tensor(gathered, rows)
+            dist.all_gather_into_tensor(gathered, rows.cpu() if host_coll and not dry else rows)
 
     def sync_all():
         if not dry:
@@ -309,7 +330,7 @@ def main():
     sync_all()
     dt = time.perf_counter() - t0
     if use_dist:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if host_coll else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -330,6 +351,9 @@ def main():
         n_corr_mean = float(np.mean([r.n_corr for r in res])); n_valid_mean = float(np.mean([r.ransac.n_valid for r in res]))
         nn_fallback_rows = float(np.mean([r.n_nn_fixed for r in res]))
         score_frac = float(np.mean([r.reserved[0] for r in res])) / 1e6      # (model, correspondence) evaluations done / V*M (pilot-ordered scoring)
+        if use_dist:      # the gathered table holds this rank's rows where the shard order says
+            mine = gathered.view(world, args.pairs, shard.ROW)[rank, :, 22:38].cpu().numpy()
+            assert np.array_equal(mine, host_T.numpy()), "gather order"
     elif use_dist:
         g = gathered.view(world, args.pairs, shard.ROW)[:, 0, 22]
         assert [float(v) for v in g] == [float(np.frombuffer(bytes([r + 1] * 8), np.float64)[0]) for r in range(world)], "gather order"
@@ -340,43 +364,54 @@ def main():
     total_pairs = world * args.pairs * args.steps
     value = total_pairs / dt
     if rank == 0 and not dry:
-        L = _ext.lib()
         ws = wss[0]
-        _ext.check(L.lr_workspace_timing(ws.handle, 1))
         reps = 10
         chunk = pairs[:B]
-        nn_ms = ctypes.c_float(); rs_ms = ctypes.c_float(); ns = ctypes.c_int()
-        for _ in range(reps):
+        ws.timing(True)
+        for _ in range(reps):      # one timed call at a time: the library's events of a call are folded in before the next one
             FR.register_batch_dev(chunk, params, out=outs[:len(chunk)], ws=ws, stream=streams[0].cuda_stream)
             streams[0].synchronize()
-            _ext.check(L.lr_workspace_timing_read(ws.handle, ctypes.byref(nn_ms), ctypes.byref(rs_ms), ctypes.byref(ns)))
-        _ext.check(L.lr_workspace_timing(ws.handle, 0))
+            stage, ns = ws.stage_times()
+        ws.timing(False)
+        call_ms, fwd_nn_ms, fwd_filter_ms, rev_filter_ms, rs_ms, rev_nn_ms = [v / max(ns, 1) for v in stage]
         flop_pass = 2.0 * 32 * args.n * args.n                  # W_NN = 2 D N0 N1 per pair (ONE pass is algorithmic)
         launches_per_call = 1 if args.mode == "no_filter" else 2  # forward + reverse NN are separate launches of the same kernel
-        # the library timed both pass-B launches of each batched call: average duration per launch = AverageNs of this kernel
+        # the library timed both filter-pass launches of each batched call: average duration per launch = AverageNs of this kernel
         # in the rocprofv3 summary of the same command
-        t_launch = nn_ms.value / max(ns.value, 1) / launches_per_call * 1e-3
+        t_launch = (fwd_filter_ms + rev_filter_ms) / launches_per_call * 1e-3
         flop_launch = flop_pass * len(chunk) / launches_per_call   # algorithmic flops one launch accounts for (len(chunk) pairs)
         achieved = flop_launch / t_launch / 1e12
-        traffic = None
         tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tj):
-            traffic = json.load(open(tj)).get("nn16_passb_kernel", {}).get("hbm_bytes_per_launch")
+        tdoc = json.load(open(tj)) if os.path.exists(tj) else {}
+        traffic = tdoc.get("nn16_passb_kernel", {}).get("hbm_bytes_per_launch")
+        traffic_source = None if traffic is None else ("NOT measured in this run: profiles/pmc_traffic.json, the builder's separate rocprofv3 --pmc passes of this "
+                                                       "command (" + str(tdoc.get("_meta", {}).get("commit", "commit unrecorded")) + "), per launch")
+        nn_stage_s = (fwd_nn_ms + rev_nn_ms) * 1e-3
         roof = {"bound": "mfma", "kernel": "nn16_passb_kernel", "achieved": round(achieved, 3), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4), "traffic": traffic, "launch_ms": round(t_launch * 1e3, 4),
+                "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source, "launch_ms": round(t_launch * 1e3, 4),
+                "forward_launch_ms": round(fwd_filter_ms, 4), "reverse_launch_ms": round(rev_filter_ms, 4),
                 "pairs_per_launch": len(chunk), "launches_per_call": launches_per_call,
-                "note": "f16 MFMA filter + exact fp32 verification; one launch covers all pairs of a batched call; launch_ms = average over the "
-                        "forward (all tiles) and the reverse (ordered, pruned) launch; achieved = (W/2 per pair x pairs per launch) / launch_ms",
-                "ransac_gen_score_ms_per_call": round(rs_ms.value / max(ns.value, 1), 4)}
+                # the ladder from the kernel to the step, all from this run's events (one batched call at a time):
+                "forward_launch_frac": round(flop_pass * len(chunk) / (fwd_filter_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4),
+                "nn_stage_frac": round(flop_pass * len(chunk) / nn_stage_s / 1e12 / MFMA_F16_PEAK_TFLOPS, 4),
+                "whole_call_frac": round(flop_pass * len(chunk) / (call_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4),
+                "filter_pass_share_of_call": round((fwd_filter_ms + rev_filter_ms) / call_ms, 4),
+                "call_ms": round(call_ms, 4), "forward_nn_ms": round(fwd_nn_ms, 4), "reverse_nn_ms": round(rev_nn_ms, 4),
+                "note": "f16 MFMA filter (sample phase + walk in one kernel) + exact fp32 verification; one launch covers all pairs of a batched call; "
+                        "launch_ms = average over the forward (all tiles) and the reverse (ordered, pruned) launch; achieved = (W/2 per pair x pairs per "
+                        "launch) / launch_ms; forward_launch_frac credits the forward launch with all of W, nn_stage_frac = W / (forward NN + reverse NN: "
+                        "prep, filter passes, exact verification, reverse ordering), whole_call_frac = W / the whole batched call",
+                "ransac_gen_score_ms_per_call": round(rs_ms, 4)}
         # whole pair against the blended floor: one NN pass on the matrix pipe + V*M*27 flop of scoring on the vector pipe
         t_min = flop_pass / (MFMA_F16_PEAK_TFLOPS * 1e12) + n_valid_mean * n_corr_mean * 27.0 / (VALU_F32_PEAK_TFLOPS * 1e12)
         t_pair = dt / (args.pairs * args.steps)
         hbm_pair = None      # HBM bytes of ALL the library's kernels per pair (PMC passes of the default workload, profiles/pmc_traffic.json)
-        if os.path.exists(tj) and args.n == 30000 and args.mode in ("MNN", "MMN") and args.codebase == "open3D" and args.iters == 50000:
-            hbm_pair = json.load(open(tj)).get("_pair", {}).get("hbm_bytes_per_pair")
+        if tdoc and args.n == 30000 and args.mode in ("MNN", "MMN") and args.codebase == "open3D" and args.iters == 50000:
+            hbm_pair = tdoc.get("_pair", {}).get("hbm_bytes_per_pair")
         pair_roof = {"t_min_us": round(t_min * 1e6, 2), "t_pair_us": round(t_pair * 1e6, 2), "frac": round(t_min / t_pair, 4),
                      "hbm_bytes_per_pair": hbm_pair, "hbm_GBps": None if hbm_pair is None else round(hbm_pair / t_pair / 1e9, 1),
                      "hbm_frac_of_8TBps": None if hbm_pair is None else round(hbm_pair / t_pair / 8.0e12, 4),
+                     "hbm_source": None if hbm_pair is None else traffic_source,
                      "note": "t_min = W/peak_f16 + V*M*27/peak_fp32 (V = hypotheses past the pre-check, M = filtered pairs, means over the step)",
                      "V": round(n_valid_mean, 1), "M": round(n_corr_mean, 1)}
 
@@ -403,7 +438,11 @@ def main():
         if dry:
             line["data"] = "dry-run (no GPU work)"
         if cpu:
-            line["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)
+            # against BOTH host implementations, the headline ratio against the FASTER one (the OpenMP port of the oracle, not the
+            # reference-style torch path whose 250-row einsum chunks leave most of the cores idle)
+            line["speedup_vs_reference_python_path"] = round(value / cpu["value"], 1)
+            line["speedup_vs_openmp_port"] = round(value / cpu["oracle_port_pairs_per_s"], 1)
+            line["speedup_vs_cpu_baseline"] = round(value / max(cpu["value"], cpu["oracle_port_pairs_per_s"]), 1)
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.barrier()

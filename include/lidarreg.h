@@ -262,7 +262,8 @@ LR_API int lr_workspace_timing_read(lr_workspace *ws, float *nn_ms, float *ransa
 /* Stage times of the timed lr_register_pair / _batch calls since lr_workspace_timing(ws, 1), sums in ms over *n_samples calls
  * (read after synchronising the stream): out[0] whole call; out[1] forward NN = find_nn of matching.py:22-65 incl. the second
  * neighbour (norms + f16 copies, filter pass, exact verification); out[2] / out[3] the forward / reverse filter-pass launch;
- * out[4] hypothesis generation + scoring of the first RANSAC batch; out[5..7] reserved (0).  The registration time FR.py:117
+ * out[4] hypothesis generation + scoring of the first RANSAC batch; out[5] the reverse NN (ordering, filter pass, exact
+ * verification; 0 with --mode no_filter); out[6..7] reserved (0).  The registration time FR.py:117
  * bills -- filter + RANSAC + refit + the second neighbour's surcharge, matching.py:12-18 -- is out[0] - out[1] + that surcharge.  */
 LR_API int lr_workspace_stage_times(lr_workspace *ws, float out[8], int *n_samples);
 

@@ -152,11 +152,11 @@ class Workspace:
         check(lib().lr_workspace_option(self._h, OPTIONS[name], int(value)))
 
     def stage_times(self):
-        """(sums in ms [whole call, forward NN, forward filter pass, reverse filter pass, RANSAC gen+score], timed calls) since
-        lr_workspace_timing(ws, 1); the stream must be synchronised."""
+        """(sums in ms [whole call, forward NN, forward filter pass, reverse filter pass, RANSAC gen+score, reverse NN], timed calls)
+        since lr_workspace_timing(ws, 1); the stream must be synchronised."""
         out = (ctypes.c_float * 8)(); n = ctypes.c_int()
         check(lib().lr_workspace_stage_times(self._h, out, ctypes.byref(n)))
-        return list(out[:5]), n.value
+        return list(out[:6]), n.value
 
     def timing(self, enable):
         check(lib().lr_workspace_timing(self._h, int(bool(enable))))

@@ -200,7 +200,7 @@ extern "C" int lr_workspace_timing(lr_workspace *ws, int enable)
 {
     LR_REQUIRE(ws, LR_EINVAL, "lr_workspace_timing: null workspace");
     ws->timing = enable; ws->ev_pending = 0; ws->rev_recorded = 0; ws->nn_ms_acc = 0; ws->ransac_ms_acc = 0; ws->n_samples = 0;
-    ws->call_ms_acc = 0; ws->fwd_ms_acc = 0; ws->fwd_filter_ms_acc = 0; ws->rev_filter_ms_acc = 0;
+    ws->call_ms_acc = 0; ws->fwd_ms_acc = 0; ws->fwd_filter_ms_acc = 0; ws->rev_filter_ms_acc = 0; ws->rev_ms_acc = 0; ws->rev_done_recorded = 0;
     return LR_OK;
 }
 
@@ -216,7 +216,9 @@ static int lr_timing_collect(lr_workspace *ws)
         if (ws->ev_pending >= 3) {
             LR_HIP(hipEventElapsedTime(&ms, ws->ev[6], ws->ev[8])); ws->call_ms_acc += ms;
             LR_HIP(hipEventElapsedTime(&ms, ws->ev[6], ws->ev[7])); ws->fwd_ms_acc += ms;
+            if (ws->rev_done_recorded) { LR_HIP(hipEventElapsedTime(&ms, ws->ev[7], ws->ev[9])); ws->rev_ms_acc += ms; }
         }
+        ws->rev_done_recorded = 0;
         ws->n_samples += 1;
         ws->ev_pending = 0;
     }
@@ -243,7 +245,8 @@ extern "C" int lr_workspace_stage_times(lr_workspace *ws, float out[8], int *n_s
     LR_REQUIRE(ws && out, LR_EINVAL, "lr_workspace_stage_times: null pointer");
     LR_TRY_HIP(lr_timing_collect(ws));
     out[0] = ws->call_ms_acc; out[1] = ws->fwd_ms_acc; out[2] = ws->fwd_filter_ms_acc; out[3] = ws->rev_filter_ms_acc; out[4] = ws->ransac_ms_acc;
-    out[5] = out[6] = out[7] = 0.0f;
+    out[5] = ws->rev_ms_acc;
+    out[6] = out[7] = 0.0f;
     if (n_samples) *n_samples = ws->n_samples;
     return LR_OK;
 }
@@ -450,6 +453,7 @@ static int register_stages(lr_workspace *ws, const float *xyz0, const float *xyz
         LR_TRY(lr_identity_corr(ws, n0, ws->nn_idx1, idx2, ws->corr_idx0, ws->corr_idx1, idx2 ? ws->corr_idx2 : nullptr, m_dev, st));
     } else {
         LR_TRY(nn_reverse(ws, F0, n0, F1, n1, ws->nn_idx1, ws->rev_idx1, st, fuse_seed));
+        if (timed) { LR_HIP(hipEventRecord(ws->ev[9], st)); ws->rev_done_recorded = 1; }
         if (p->mode == LR_MODE_MNN) {
             LR_TRY(lr_mutual_run(ws, n0, ws->nn_idx1, idx2, ws->rev_idx1, ws->is_bb, ws->corr_idx0, ws->corr_idx1,
                                  idx2 ? ws->corr_idx2 : nullptr, m_dev, st, xyz0, xyz1, ws->corr8));

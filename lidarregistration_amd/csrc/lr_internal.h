@@ -44,7 +44,7 @@ __host__ __device__ static inline int lr_seg_cap(int strips) { const int c = (LR
 #define LR_SCORE_BLOCKS 8192
 #define LR_GPF_MAX_CELLS 4096
 #define LR_SC_INFO_BYTES 2048
-#define LR_NEV 9
+#define LR_NEV 10
 
 // ---- pair-batched launches -------------------------------------------------------------------------------------------
 // A workspace holds `max_pairs` arenas of identical layout, `stride` bytes apart; every scratch pointer below refers to
@@ -154,8 +154,9 @@ struct lr_workspace {
     double *icp_state, *icp_part;
     // --- timing hook ---
     int timing;
-    hipEvent_t ev[LR_NEV];       // [0,1] forward filter pass, [2,3] RANSAC gen+score, [4,5] reverse filter pass, [6] call start, [7] forward NN done, [8] call end
-    float nn_ms_acc, ransac_ms_acc, call_ms_acc, fwd_ms_acc, fwd_filter_ms_acc, rev_filter_ms_acc;
+    hipEvent_t ev[LR_NEV];       // [0,1] forward filter pass, [2,3] RANSAC gen+score, [4,5] reverse filter pass, [6] call start, [7] forward NN done, [8] call end, [9] reverse NN done
+    float nn_ms_acc, ransac_ms_acc, call_ms_acc, fwd_ms_acc, fwd_filter_ms_acc, rev_filter_ms_acc, rev_ms_acc;
+    int rev_done_recorded;
     int n_samples;
     int ev_pending;
     int rev_recorded;

@@ -168,7 +168,7 @@ def eval_list_batched(pair_list, indices, args, n=30000, s=1.2, batch=32, nstrea
     # stage times: a separate, serialised pass over a sample of the rows (one timed call at a time per workspace, events read after
     # each call) -- the throughput loop above keeps several calls in flight and cannot attribute time to stages
     sample = indices[:min(P, 4 * batch)]
-    stage = np.zeros(5); timed_pairs = 0
+    stage = np.zeros(6); timed_pairs = 0
     pairs = []
     for k in sample:
         rho = float(np.clip(pair_list["overlap"][k], 0.05, 0.95))
@@ -269,7 +269,7 @@ def eval_pairs(source, indices, args, device=None, in_flight=4, verbose=False):
             fresh = ((n0 + 1023) // 1024, (n1 + 1023) // 1024) not in fr._SHARE
             share = fr.second_nn_share(f0, f1, wss[s])
             if fresh or seen[s] is None:
-                wss[s].timing(True); seen[s] = [0.0] * 5
+                wss[s].timing(True); seen[s] = [0.0] * 6
             out = torch.empty(ctypes.sizeof(_ext.PairResult), dtype=torch.uint8, device=dev)
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record(streams[s])

@@ -33,7 +33,8 @@ def test_bench_line_small_workload():
     assert 0 < pr["frac"] < 1 and pr["t_min_us"] < pr["t_pair_us"]
     cpu = line["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["unit"] == "pairs/s" and cpu["value"] > 0 and cpu["cores"] >= 1 and "einsum" in cpu["impl"]
-    assert line["speedup_vs_cpu_baseline"] > 1
+    assert line["speedup_vs_cpu_baseline"] > 1 and line["speedup_vs_cpu_baseline"] == min(line["speedup_vs_reference_python_path"], line["speedup_vs_openmp_port"])
+    assert 0 < roof["whole_call_frac"] <= roof["nn_stage_frac"] <= roof["forward_launch_frac"] < 1 and roof["forward_launch_ms"] > roof["reverse_launch_ms"] > 0
 
 
 def test_bench_gc_codebase_workload():
@@ -61,3 +62,26 @@ def test_bench_under_the_launcher_runs_the_rccl_branch_with_one_rank():
     assert len(lines) == 1
     line = json.loads(lines[0])
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["recall_2deg_0.6m"] == 1.0
+
+
+def test_two_ranks_share_this_gpu_through_the_self_launcher():
+    """`python bench.py --gpus 2 --dist-backend gloo --devices 0,0`: the N > 1 path on a 1-GPU box -- spawn_ranks starts both ranks from a
+    parent that never touches HIP, they rendezvous on 127.0.0.1, register their own (differently seeded) pairs on device 0, gather the
+    result rows with one collective per step (host tensors: gloo) and take the max-over-ranks time.  The launch shape of the reference's
+    test_parallel.sh:18-24; the same code runs with --dist-backend nccl at 8 GPUs."""
+    line = _bench(["--gpus", "2", "--dist-backend", "gloo", "--devices", "0,0", "--no-cpu-baseline"])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["recall_2deg_0.6m"] == 1.0 and line["scaling"] == "weak"
+    assert line["config"]["parallelism"] == "pair-sharded x2"
+    roof = line["roofline"]
+    assert roof["traffic_source"] is None or "NOT measured in this run" in roof["traffic_source"]
+    assert 0 < roof["whole_call_frac"] <= roof["nn_stage_frac"] <= roof["forward_launch_frac"] < 1 and 0 < roof["filter_pass_share_of_call"] < 1
+
+
+def test_a_dying_rank_ends_the_self_launched_run_quickly():
+    """spawn_ranks polls all children: a rank that exits non-zero ends the run at once instead of after the collective's timeout."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--devices", "0,7", "--n", "4000",
+                        "--iters", "3000", "--pairs", "4", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0 and time.time() - t0 < 120          # rank 1 has no device 7 on this box
