@@ -42,6 +42,7 @@ void carve(lr_workspace *ws, Carver &c)
     ws->nrm0 = c.take<float>(n0); ws->nrm1 = c.take<float>(n1);
     ws->H0 = c.take<_Float16>(n0 * 32); ws->H1 = c.take<_Float16>(n1 * 32);
     ws->tau = c.take<float>(n);
+    ws->yfin = c.take<float>(n * LR_NN_MAX_STRIPS);
     ws->cand_cnt = c.take<int32_t>(LR_NN16_CNT_INTS(n)); ws->cand = c.take<int32_t>(LR_NN16_SEG_INTS(n));
     ws->counters = c.take<int32_t>(LR_CNT_TOTAL);
     ws->bmax0 = c.take<float>(n0 / 32 + 2); ws->bmax1 = c.take<float>(n1 / 32 + 2);

@@ -94,6 +94,7 @@ struct lr_workspace {
     float *nrm0, *nrm1;          // row norms
     _Float16 *H0, *H1;           // [n,32] f16 copies for the matrix-core filter passes
     float *tau;                  // [max_n] per-row candidate threshold
+    float *yfin;                 // [LR_NN_MAX_STRIPS][max_n] the rows' final thresholds (y = tau/2) of the forward filter pass, per strip
     int32_t *cand_cnt, *cand;    // segment counters [row blocks][4 waves][strips] and the candidate store (LR_NN16_SEG_INTS)
     float *bmax0, *bmax1;        // per-32-row maxima of the norms (f16 filter error bound)
     uint32_t *rev_seed;          // [max_n1] best forward distance pointing at each cloud-1 row (bit pattern)

@@ -156,6 +156,7 @@ nn16_prep_kernel(const float *__restrict__ Fa, int na, _Float16 *__restrict__ Ha
 #define LR_PB_EXP 0     // development switches (tools/pb_micro.hip): 1 no staging, 2 no tests, 4 no tightening
 #endif
 #define LR_PB_WLIST 512          // entries per wave (12 bytes each)
+#define LR_PB_HASG 0x1000u       // entry flag: whval holds the entry's filter value g (single-row entries seen by a tightening round)
 #ifndef LR_PB_TIGHTEN
 #define LR_PB_TIGHTEN 48         // new entries of a wave that trigger a tightening round
 #endif
@@ -186,7 +187,8 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
                   const _Float16 *__restrict__ Hc, const float *__restrict__ nC, int nb,
                   int tiles_per_strip, const float *__restrict__ tau, int32_t *__restrict__ cand_cnt, int32_t *__restrict__ cand,
                   const int32_t *__restrict__ colmap, const float *__restrict__ tile_min, const uint32_t *__restrict__ row_bound,
-                  const int32_t *__restrict__ rev_offs, const uint32_t *__restrict__ rev_range, lr_thr_in thr, lr_pb_grid pg, lr_zargs z)
+                  const int32_t *__restrict__ rev_offs, const uint32_t *__restrict__ rev_range, float *__restrict__ yfin, int yfin_stride,
+                  lr_thr_in thr, lr_pb_grid pg, lr_zargs z)
 {
     // 1-D XCD-aware grid -> (row block, strip, pair): the blocks one XCD receives are consecutive row blocks of the same
     // (strip, pair), i.e. they stream the same columns through that XCD's L2
@@ -200,7 +202,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     }
     lr_z(Hq, z, pair); lr_z(rowmap, z, pair); lr_z(na_dev, z, pair); lr_z(Hc, z, pair); lr_z(nC, z, pair); lr_z(tau, z, pair);
     lr_z(cand_cnt, z, pair); lr_z(cand, z, pair); lr_z(colmap, z, pair); lr_z(tile_min, z, pair); lr_z(row_bound, z, pair); lr_z(rev_offs, z, pair); lr_z(rev_range, z, pair);
-    lr_z(thr.nQ, z, pair); lr_z(thr.block_max_c, z, pair);
+    lr_z(thr.nQ, z, pair); lr_z(thr.block_max_c, z, pair); lr_z(yfin, z, pair);
     // rows: either 0..na_host-1, or (reverse direction) the ordered list rowmap[0..*na_dev-1]; tau, cand_cnt and cand
     // are indexed by the position in that list.  Columns: Hc/nC as they lie; with colmap they are a permuted copy and
     // a candidate's column id is colmap[position].
@@ -447,6 +449,10 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
                     const float gv = whval[wave][e] - s_Y[rl];
                     const float old = atomicMax(&s_N1[rl], gv);
                     atomicMax(&s_N2[rl], fminf(old, gv));
+                    // the entry keeps its g: an entry admitted by an early, loose threshold is dropped again -- when the list is
+                    // emptied, or by nn16_exact_kernel -- once the row's threshold has moved past it (no gather, no distance)
+                    whval[wave][e] = gv;
+                    wlist[wave][e].y = v.y | LR_PB_HASG;
                 }
             }
         }
@@ -470,7 +476,21 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
                 if (e < wcnt) v = wlist[wave][e];
                 v.y &= 0x7fffffffu;
                 // padding columns pass the test only when tau is +inf
-                const bool keep = e < wcnt && (int)v.x < nb && ((int)v.x >> 5) < t_end;
+                bool keep = e < wcnt && (int)v.x < nb && ((int)v.x >> 5) < t_end;
+                if (v.y & LR_PB_HASG) {
+                    // g of the entry against the row's threshold of NOW (candidate <=> g >= -y): what an earlier, looser threshold let
+                    // in is dropped here; what stays carries g rounded UP to 16 bits for the same test against the final threshold
+                    const float gv = whval[wave][min(e, LR_PB_WLIST - 1)];
+                    const unsigned mask = v.y & 0xffu;
+                    const int code = (int)(v.y >> 8) & 0xf;
+                    const int g = 8 * ((code >> 1) & 1) + 7 - __builtin_ctz(mask | 0x100u);
+                    const int rl = wave * 64 + 32 * (code >> 2) + (g & 3) + 8 * (g >> 2) + 4 * (code & 1);
+                    const float yr = s_Y[rl];
+                    if (gv + 1e-5f * (fabsf(gv) + fabsf(yr)) < -yr) keep = false;
+                    const unsigned gb = __float_as_uint(gv);
+                    const unsigned up16 = (gb & 0x80000000u) ? (gb >> 16) : ((gb + 0xffffu) >> 16);      // towards +inf
+                    v.y = (v.y & 0x1fffu) | (up16 << 15);
+                }
                 const unsigned long long kb = __builtin_amdgcn_ballot_w64(keep);
                 const int pos = seg_fill + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(kb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)kb, 0u));
                 const int nk = __builtin_popcountll(kb);
@@ -588,13 +608,17 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
             check(accB[1], 0, xC, tileC, 1, stale);
             check(accB[1], 8, xC, tileC, 1, stale);
         }
-        wdone = wcnt;      // (nothing left to tighten for)
-        flush();
+        flush();           // (with a last tightening round: the entries get their g, the rows their final thresholds)
     }
     if (lane == 0) {
         int32_t *cw = cand_cnt + (bx * 4 + wave) * (pg.gy + 1);
         cw[by] = seg_fill;                     // entries in this wave's segment (< 0: overflow)
         if (by == 0) cw[pg.gy] = my_strips;    // how the wave's store is divided (read by nn16_exact_kernel)
+    }
+    // the rows' final thresholds (wave-local: every wave writes its own 64 rows): nn16_exact_kernel drops the entries they exclude
+    if (yfin) {
+        const int rw = row0 + lane;
+        if (rw < na) yfin[(size_t)by * yfin_stride + rw] = tightening ? s_Y[wave * 64 + lane] : LR_INF;
     }
 }
 
@@ -625,6 +649,7 @@ __global__ void __launch_bounds__(256)
 nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, int na,
                   const float *__restrict__ Fc, const float *__restrict__ nC, int nb,
                   const int32_t *__restrict__ cand_cnt, const int32_t *__restrict__ cand, int nstrips, int need,
+                  const float *__restrict__ yfin, int yfin_stride,
                   const int32_t *__restrict__ rowmap, const int32_t *__restrict__ na_dev,
                   int32_t *__restrict__ idx1, int32_t *__restrict__ idx2, float *__restrict__ s1o, float *__restrict__ s2o,
                   int32_t *__restrict__ counters,
@@ -645,7 +670,7 @@ nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, in
         const lr_pair_desc d = z.descs[pair];
         Fq = dir ? d.F1 : d.F0; na = dir ? d.n1 : d.n0; Fc = dir ? d.F0 : d.F1; nb = dir ? d.n0 : d.n1;
     }
-    lr_z(nQ, z, pair); lr_z(nC, z, pair); lr_z(cand_cnt, z, pair); lr_z(cand, z, pair); lr_z(rowmap, z, pair);
+    lr_z(nQ, z, pair); lr_z(nC, z, pair); lr_z(cand_cnt, z, pair); lr_z(cand, z, pair); lr_z(rowmap, z, pair); lr_z(yfin, z, pair);
     lr_z(na_dev, z, pair); lr_z(idx1, z, pair); lr_z(idx2, z, pair); lr_z(s1o, z, pair); lr_z(s2o, z, pair);
     lr_z(counters, z, pair); lr_z(seed_out, z, pair); lr_z(seed_s1, z, pair); lr_z(seed_range, z, pair); lr_z(seed64, z, pair);
     if (na_dev) na = *na_dev;                  // compacted row list (reverse direction): lists by position, data by rowmap[]
@@ -694,6 +719,15 @@ nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, in
         const int32_t *cw = cand_cnt + bxi * (nstrips + 1);
         const int used = min(max(cw[nstrips], 1), nstrips);        // strips the pass-B row block really used
         const int seg_cap = lr_seg_cap(used);
+        // the rows' final thresholds of the filter pass (the tightest over the strips: a threshold is a property of the row, any valid
+        // one applies to all of its entries): an entry that carries its filter value g and fails g >= -y is not a candidate any more
+        __shared__ float s_yf[LR_EX_ROWS];
+        if (tid < LR_EX_ROWS) {
+            float yv = LR_INF;
+            if (yfin && row0 + tid < na) for (int sidx = 0; sidx < used; ++sidx) yv = fminf(yv, yfin[(size_t)sidx * yfin_stride + row0 + tid]);
+            s_yf[tid] = yv;
+        }
+        __syncthreads();
         const uint2 *__restrict__ segs = reinterpret_cast<const uint2 *>(cand) + (size_t)bxi * LR_NN16_SEG;
         for (int sidx = 0; sidx < used; ++sidx) {
             const int c = cw[sidx];
@@ -702,12 +736,19 @@ nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, in
             for (int e = tid; e < c; e += 256) {
                 const uint2 v = segs[(size_t)sidx * seg_cap + e];
                 const int j = (int)v.x;
+                if (v.y & LR_PB_HASG) {       // (single-row entry with its g, rounded up to 16 bits)
+                    const int code = (int)(v.y >> 8) & 0xf;
+                    const int g = 8 * ((code >> 1) & 1) + 7 - __builtin_ctz((v.y & 0xffu) | 0x100u);
+                    const int rl = 32 * (code >> 2) + 4 * (code & 1) + (g & 3) + 8 * (g >> 2);
+                    const float gv = __uint_as_float((v.y >> 15) << 16), yr = s_yf[rl];
+                    if (gv + 1e-5f * (fabsf(gv) + fabsf(yr)) < -yr) continue;
+                }
                 f32x4 t[8];
                 const f32x4 *pb = reinterpret_cast<const f32x4 *>(Fc + (size_t)j * 32);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) t[k] = pb[k];
                 const float ncj = nC[j];
-                const int code = (int)(v.y >> 8);
+                const int code = (int)(v.y >> 8) & 0xf;
                 const int rbase = 32 * (code >> 2) + 4 * (code & 1), g0 = 8 * ((code >> 1) & 1);
                 unsigned m = v.y & 0xffu;
                 while (m) {
@@ -816,11 +857,12 @@ int lr_nn16_run(lr_workspace *ws, const float *Fq, const _Float16 *Hq, const flo
     lr_thr_in thr = { nQ, block_max_c, lr_cdiv(nb, 32), need, sstride };
     hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), 0, st, Hq, na, (const int32_t *)nullptr, (const int32_t *)nullptr, Hc, nC, nb,
                        tps, (const float *)nullptr, ws->cand_cnt, ws->cand, (const int32_t *)nullptr, (const float *)nullptr,
-                       (const uint32_t *)nullptr, (const int32_t *)nullptr, (const uint32_t *)nullptr, thr, lr_pb_grid{ row_blocks, strips, total, 0 }, ws->z);
+                       (const uint32_t *)nullptr, (const int32_t *)nullptr, (const uint32_t *)nullptr, ws->yfin, ws->max_n, thr,
+                       lr_pb_grid{ row_blocks, strips, total, 0 }, ws->z);
     if (ws->timing && !ws->ev_pending) { LR_HIP(hipEventRecord(ws->ev[1], st)); ws->ev_pending = 1; }
     const int ex_gx = lr_cdiv(na, LR_EX_ROWS), ex_total = ex_gx * ws->zP;
     hipLaunchKernelGGL(nn16_exact_kernel, dim3(8 * lr_cdiv(ex_total, 8)), dim3(256), 0, st, Fq, nQ, na, Fc, nC, nb, ws->cand_cnt, ws->cand,
-                       strips, need, (const int32_t *)nullptr, (const int32_t *)nullptr, idx1, idx2, s1, s2, ws->counters,
+                       strips, need, (const float *)ws->yfin, ws->max_n, (const int32_t *)nullptr, (const int32_t *)nullptr, idx1, idx2, s1, s2, ws->counters,
                        seed_reverse ? ws->rev_seed : (uint32_t *)nullptr, ws->rev_s1, reinterpret_cast<uint32_t *>(ws->counters + LR_CNT_RLO),
                        ws->rev_seed64, 0, ex_gx, ex_total, ws->z);
     LR_LAUNCH_CHECK();
@@ -1030,12 +1072,12 @@ int lr_nn16_reverse(lr_workspace *ws, const float *F0, const _Float16 *H0, const
     hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), 0, st, H1, na, (const int32_t *)ws->rev_rows, (const int32_t *)n_rows,
                        (const _Float16 *)ws->Hs, (const float *)ws->nrms, nb, tps, ws->tau, ws->cand_cnt, ws->cand,
                        (const int32_t *)ws->rev_cols, seeded ? (const float *)ws->rev_tmin : (const float *)nullptr, (const uint32_t *)seed,
-                       (const int32_t *)ws->rev_hist, (const uint32_t *)range, lr_thr_in{},
+                       (const int32_t *)ws->rev_hist, (const uint32_t *)range, (float *)nullptr, 0, lr_thr_in{},
                        lr_pb_grid{ row_blocks, strips, total, 1 }, ws->z);
     if (timed) { LR_HIP(hipEventRecord(ws->ev[5], st)); ws->rev_recorded = 1; }
     const int ex_gx = lr_cdiv(na, LR_EX_ROWS), ex_total = ex_gx * ws->zP;
     hipLaunchKernelGGL(nn16_exact_kernel, dim3(8 * lr_cdiv(ex_total, 8)), dim3(256), 0, st, F1, nrm1, na, F0, nrm0, nb, ws->cand_cnt, ws->cand,
-                       strips, 1, (const int32_t *)ws->rev_rows, (const int32_t *)n_rows, rev, (int32_t *)nullptr, (float *)nullptr, (float *)nullptr,
+                       strips, 1, (const float *)nullptr, 0, (const int32_t *)ws->rev_rows, (const int32_t *)n_rows, rev, (int32_t *)nullptr, (float *)nullptr, (float *)nullptr,
                        ws->counters, (uint32_t *)nullptr, (float *)nullptr, (uint32_t *)nullptr,
                        seeded ? ws->rev_seed64 : (unsigned long long *)nullptr, 1, ex_gx, ex_total, ws->z);
     LR_LAUNCH_CHECK();

@@ -43,7 +43,7 @@ int main(int argc, char **argv)
     for (int sstride : {2, 4, 8, 16, 32, 64}) {
         lr_thr_in thr = { nrm, bmax, (n+31)/32, need, sstride };
         auto run = [&] { hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), 0, 0, H, n, (const int32_t*)nullptr, (const int32_t*)nullptr, H, nrm, n, tps, (const float*)nullptr, cnt, cand,
-                                            (const int32_t*)nullptr, (const float*)nullptr, (const uint32_t*)nullptr, (const int32_t*)nullptr, (const uint32_t*)nullptr, thr, lr_pb_grid{ row_blocks, strips, total, 0 }, z); };
+                                            (const int32_t*)nullptr, (const float*)nullptr, (const uint32_t*)nullptr, (const int32_t*)nullptr, (const uint32_t*)nullptr, (float*)nullptr, 0, thr, lr_pb_grid{ row_blocks, strips, total, 0 }, z); };
         float msp = timeit([&] { run(); });
         run();
         const int nseg = row_blocks * 4 * (strips + 1);
@@ -55,7 +55,7 @@ int main(int argc, char **argv)
         std::vector<float> t(n, -1e30f);
         for (int p = 0; p < P; ++p) hipMemcpy((char *)tau + p * stride, t.data(), (size_t)n * 4, hipMemcpyHostToDevice);
         float msp = timeit([&] { hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), 0, 0, H, n, (const int32_t*)nullptr, (const int32_t*)nullptr, H, nrm, n, tps, (const float*)tau, cnt, cand,
-                                                    (const int32_t*)nullptr, (const float*)nullptr, (const uint32_t*)nullptr, (const int32_t*)nullptr, (const uint32_t*)nullptr, lr_thr_in{}, lr_pb_grid{ row_blocks, strips, total, 0 }, z); });
+                                                    (const int32_t*)nullptr, (const float*)nullptr, (const uint32_t*)nullptr, (const int32_t*)nullptr, (const uint32_t*)nullptr, (float*)nullptr, 0, lr_thr_in{}, lr_pb_grid{ row_blocks, strips, total, 0 }, z); });
         printf("walk only, no candidates:       %8.3f ms  = %6.1f us/pair\n", msp, msp * 1e3 / P);
     }
     return 0;
