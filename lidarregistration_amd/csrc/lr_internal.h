@@ -41,7 +41,9 @@ __host__ __device__ static inline int lr_seg_cap(int strips) { const int c = (LR
 
 // Waves of the scoring kernel (four per block); this many are launched and map themselves onto
 // (hypothesis group, correspondence chunk) from the live counts on device.
-#define LR_SCORE_BLOCKS 8192
+#ifndef LR_SCORE_BLOCKS
+#define LR_SCORE_BLOCKS 2048      // 512 blocks per pair (8192: one work item per wave, +4 % time: measured round 3)
+#endif
 #define LR_GPF_MAX_CELLS 4096
 #define LR_SC_INFO_BYTES 2048
 #define LR_NEV 10

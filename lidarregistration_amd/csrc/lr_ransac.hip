@@ -213,30 +213,36 @@ ransac_gen_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__r
     lr_z(corr8, z, blockIdx.z); lr_z(m_dev, z, blockIdx.z); lr_z(models, z, blockIdx.z); lr_z(models64, z, blockIdx.z); lr_z(model_h, z, blockIdx.z); lr_z(score_cnt, z, blockIdx.z); lr_z(score_ssq, z, blockIdx.z); lr_z(counters, z, blockIdx.z); lr_z(G, z, blockIdx.z);
     const int m = m_dev ? min(*m_dev, m_max) : m_max;
     if (m <= 0 || reinterpret_cast<const lr_ransac_state *>(counters + LR_CNT_COUNT)->done) return;
-    if (threadIdx.x == 0) s_np = 0;
-    __syncthreads();
-    const int h = h_begin + blockIdx.x * 256 + threadIdx.x;
-    {
-        double P[NS][3], Q[NS][3];
-        if (h < h_end && hypothesis_sample<NS>(corr8, m, p.seed, (uint64_t)h, p.use_elc == 1, P, Q, G, TN, p.sampler != 0)) s_pass[atomicAdd(&s_np, 1)] = h;
-    }
-    __syncthreads();
-    const int np = s_np;
-    if (threadIdx.x == 0 && np > 0) s_base = atomicAdd(&counters[LR_CNT_NVALID], np);
-    __syncthreads();
-    if ((int)threadIdx.x >= np) return;
-    const int hh = s_pass[threadIdx.x];
-    double P[NS][3], Q[NS][3], T[16];
-    hypothesis_sample<NS>(corr8, m, p.seed, (uint64_t)hh, 0, P, Q, G, TN);
-    kabsch_sample<NS>(P, Q, T);
-    const int slot = s_base + threadIdx.x;
+    // (a capped grid strides over the 256-id groups: the launches of the batches behind an early exit then cost a few hundred
+    // idle blocks instead of tens of thousands)
+    for (int blk = blockIdx.x; blk * 256 < h_end - h_begin; blk += gridDim.x) {
+        if (threadIdx.x == 0) s_np = 0;
+        __syncthreads();
+        const int h = h_begin + blk * 256 + threadIdx.x;
+        {
+            double P[NS][3], Q[NS][3];
+            if (h < h_end && hypothesis_sample<NS>(corr8, m, p.seed, (uint64_t)h, p.use_elc == 1, P, Q, G, TN, p.sampler != 0)) s_pass[atomicAdd(&s_np, 1)] = h;
+        }
+        __syncthreads();
+        const int np = s_np;
+        if (threadIdx.x == 0 && np > 0) s_base = atomicAdd(&counters[LR_CNT_NVALID], np);
+        __syncthreads();
+        if ((int)threadIdx.x < np) {
+            const int hh = s_pass[threadIdx.x];
+            double P[NS][3], Q[NS][3], T[16];
+            hypothesis_sample<NS>(corr8, m, p.seed, (uint64_t)hh, 0, P, Q, G, TN);
+            kabsch_sample<NS>(P, Q, T);
+            const int slot = s_base + threadIdx.x;
 #pragma unroll
-    // fp32 models component-major ([12][model_stride]: the scoring kernel's 64 lanes read 64 consecutive floats per
-    // component), fp64 models row-major (only the winner is ever read back)
-    for (int k = 0; k < 12; ++k) { models[(size_t)k * model_stride + slot] = (float)T[k]; models64[(size_t)slot * 12 + k] = T[k]; }
-    model_h[slot] = hh;
-    score_cnt[slot] = 0u;
-    score_ssq[slot] = 0ull;
+            // fp32 models component-major ([12][model_stride]: the scoring kernel's 64 lanes read 64 consecutive floats per
+            // component), fp64 models row-major (only the winner is ever read back)
+            for (int k = 0; k < 12; ++k) { models[(size_t)k * model_stride + slot] = (float)T[k]; models64[(size_t)slot * 12 + k] = T[k]; }
+            model_h[slot] = hh;
+            score_cnt[slot] = 0u;
+            score_ssq[slot] = 0ull;
+        }
+        __syncthreads();
+    }
 }
 
 
@@ -1255,7 +1261,8 @@ int lr_ransac_run(lr_workspace *ws, const float *corr8, int m_max, const int32_t
     for (long long h0l = 0; h0l < (p->iters > 0 ? p->iters : 1); h0l += B, B = geometric ? 2 * B : B) {
         const int h0 = (int)h0l;
         const int h1 = h0l + B < p->iters ? (int)(h0l + B) : p->iters;
-        const int gb = lr_cdiv(h1 - h0 > 0 ? h1 - h0 : 1, 256);
+        const int gb_all = lr_cdiv(h1 - h0 > 0 ? h1 - h0 : 1, 256);      // 256-id groups of the batch
+        const int gb = gb_all < 1024 ? gb_all : 1024;                       // blocks per pair (they stride over the groups)
         lr_score_info *info = reinterpret_cast<lr_score_info *>(ws->sc_info);
         if (p->sample_size == 3)
             hipLaunchKernelGGL(ransac_gen_kernel<3>, dim3(gb, 1, ws->zP), dim3(256), 0, st, corr8, m_max, m_dev, *p, h0, h1, ws->models, ws->models64,
@@ -1265,7 +1272,7 @@ int lr_ransac_run(lr_workspace *ws, const float *corr8, int m_max, const int32_t
                                ws->model_h, ws->score_cnt, ws->score_ssq, ws->counters, G, TN, ws->max_iters, info, ws->z);
         const bool sprt = p->use_elc == 2;
         if (sprt)       // every estimated model is pre-verified; the survivors form a second dense list that is scored in full
-            hipLaunchKernelGGL(ransac_sprt_kernel, dim3(lr_cdiv(gb * 256, 256), 1, ws->zP), dim3(256), 0, st, corr8, m_max, m_dev, p->thr2,
+            hipLaunchKernelGGL(ransac_sprt_kernel, dim3(gb_all, 1, ws->zP), dim3(256), 0, st, corr8, m_max, m_dev, p->thr2,
                                (const float *)ws->models, (const double *)ws->models64, (const int32_t *)ws->model_h, ws->models2, ws->models64_2, ws->model_h2,
                                ws->score_cnt, ws->score_ssq, ws->counters, ws->max_iters, ws->z);
         const int vslot = sprt ? LR_CNT_NVALID2 : LR_CNT_NVALID;
