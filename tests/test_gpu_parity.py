@@ -530,7 +530,7 @@ def test_ransac_one_million_iterations_config4(lr, oracle):
     T, info = lr.ransac.ransac_dev(src, tgt, 1_000_000, seed=51)                       # every id evaluated
     Te, einfo = oracle.ransac(src, tgt, 1_000_000, seed=51)
     assert info == einfo and np.array_equal(T, Te) and info["n_ids"] == 1_000_000
-    T2, info2 = lr.ransac.ransac_dev(src, tgt, 1_000_000, seed=51, confidence=0.999)   # default batches: 8192, 16384, ... (doubling)
+    T2, info2 = lr.ransac.ransac_dev(src, tgt, 1_000_000, seed=51, confidence=0.999)   # default batches: 8192, 32768, ... (fourfold)
     Te2, einfo2 = oracle.ransac(src, tgt, 1_000_000, seed=51, confidence=0.999)
     assert info2 == einfo2 and np.array_equal(T2, Te2) and info2["n_ids"] == 8192
     assert oracle.rotation_error_deg(T2, T_gt) < 1.0
