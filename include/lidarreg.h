@@ -106,7 +106,9 @@ typedef struct lr_pair_result {
     int32_t  n_refit;       /* inliers used by the refit (FR.py:104-108)                              */
     int32_t  n_nn_fixed;    /* NN rows/cols that needed the exact sqrt tie-break path                 */
     int32_t  status;        /* 0 ok, 1 = no valid hypothesis (T = identity, GC_RANSAC.py:51-52)       */
-    int32_t  reserved[8];
+    int32_t  reserved[8];   /* [0]: diagnostic, like n_nn_fixed -- (model, correspondence) evaluations of the scoring passes in ppm of
+                               scanning every list in full (0: not recorded); may differ between runs (the pilot among models with
+                               equal head counts depends on scheduling), no result does.  [1..7]: 0                              */
     double   T_icp[16];     /* T refined by point-to-point ICP (test.py:183-189) when icp != 0, else = T */
     lr_icp_result icp;
 } lr_pair_result;

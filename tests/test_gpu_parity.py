@@ -452,6 +452,37 @@ def test_nn_tiny_clouds(lr, oracle, n0, n1):
     assert np.array_equal(_bits(s1.cpu().numpy()), _bits(os1))
 
 
+@pytest.mark.parametrize("n0,n1,stride", [(6840, 7499, 0), (3000, 2017, 1), (5000, 4097, 2), (2600, 3231, 0), (900, 33, 0), (700, 95, 1)])
+def test_nn_best_neighbour_in_the_partial_last_tile(lr, oracle, n0, n1, stride):
+    """Rows whose nearest neighbour is the LAST column of a cloud whose size is not a multiple of the 32-column tile: the staged image
+    of that tile repeats the last column in its padding, and phase 1 of the filter pass must not take it for two different columns
+    (found by tools/soak_fr.py in round 3: one wrong second neighbour per such row)."""
+    from lidarregistration_amd import _ext, matching
+    F0, F1 = synth.make_features(n0, n1, 32, 0.5, 1.0, n0 + n1)
+    rng = np.random.default_rng(n1)
+    rows = rng.choice(n0, 40, replace=False)
+    F0[rows] = F1[-1] + rng.normal(0, 0.02, (40, 32)).astype(np.float32)
+    F0[rows] /= np.linalg.norm(F0[rows], axis=1, keepdims=True)
+    o1, o2, os1, os2 = oracle.nn_top2(F0, F1)
+    assert (o1[rows] == n1 - 1).all()
+    _ext.DEFAULT_OPTIONS.clear()
+    if stride:
+        _ext.DEFAULT_OPTIONS["nn_sample_stride"] = stride
+    for ws in matching._WS.values():
+        ws.close()
+    matching._WS.clear()
+    try:
+        t = lr.torch.from_numpy
+        i1, i2, s1, s2 = lr.matching.nn_top2_dev(F0, F1, want_dist=True)
+    finally:
+        _ext.DEFAULT_OPTIONS.clear()
+        for ws in matching._WS.values():
+            ws.close()
+        matching._WS.clear()
+    assert np.array_equal(i1.cpu().numpy(), o1) and np.array_equal(i2.cpu().numpy(), o2)
+    assert np.array_equal(_bits(s1.cpu().numpy()), _bits(os1)) and np.array_equal(_bits(s2.cpu().numpy()), _bits(os2))
+
+
 @pytest.mark.parametrize("mode", ["MNN", "no_filter", "GPF"])
 def test_second_neighbour_auto_mode_gives_the_same_pair_result(lr, oracle, mode):
     """The workspace option nn_second_auto drops the second neighbour where no stage reads it; the result block must not change."""

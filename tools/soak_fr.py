@@ -37,6 +37,7 @@ for case in range(n_cases):
         for k in range(4):
             o1 = FR.register_pair_dev(*dev[k], params, ws=ws1).cpu().numpy()
             ob[k][304:308] = 0; o1 = o1.copy(); o1[304:308] = 0      # n_nn_fixed: a diagnostic (rows re-done by the full scan) that depends on the grid
+            ob[k][312:316] = 0; o1[312:316] = 0                        # reserved[0]: scoring evaluations in ppm, a diagnostic (the pilot among equal head counts depends on slot order)
             if not np.array_equal(ob[k], o1):
                 rb, r1 = _ext.PairResult.from_buffer_copy(ob[k].tobytes()), _ext.PairResult.from_buffer_copy(o1.tobytes())
                 def dump(r): return dict(n_corr=r.n_corr, status=r.status, best_h=r.ransac.best_h, cnt=r.ransac.best_count, ssq=r.ransac.best_ssq, n_valid=r.ransac.n_valid, n_ids=r.ransac.n_ids, T=list(r.T[:4]))

@@ -15,9 +15,10 @@ for case in range(n_cases):
     tgt = (src.astype(np.float64) @ T[:3, :3].T + T[:3, 3] + rng.normal(0, noise, (n, 3))).astype(np.float32)
     bad = rng.random(n) > inl
     tgt[bad] = np.concatenate([rng.uniform(-80, 80, (bad.sum(), 2)), rng.uniform(-3, 5, (bad.sum(), 1))], 1)
-    kw = dict(sample_size=3, seed=int(rng.integers(1 << 30)), sampler=int(rng.choice([1, 2])), scoring=int(rng.choice([0, 1])),
+    kw = dict(sample_size=3, seed=int(rng.integers(1 << 30)), sampler=int(rng.choice([1, 2])), scoring=int(rng.choice([0, 1, 2])),
               local_opt=int(rng.choice([1, 1, 2])), confidence=float(rng.choice([1.0, 0.999, 0.99])), batch=int(rng.choice([0, 0, 512, 4096])),
-              use_elc=int(rng.choice([0, 1, 1, 2])))
+              use_elc=int(rng.choice([0, 1, 1, 2])), lo_rounds=int(rng.choice([0, 0, 1, 3])), lo_trials=int(rng.choice([0, 0, 1, 7])),
+              lo_max_calls=int(rng.choice([0, 0, 1, 2])), min_iters=int(rng.choice([0, 0, 600])))
     iters = int(rng.choice([300, 3000, 20000]))
     Tg, info = ransac.ransac_dev(src, tgt, iters, **kw)
     Te, einfo = oracle.ransac(src, tgt, iters, **kw)
