@@ -47,7 +47,7 @@ typedef struct lr_ransac_params {
     float    confidence;    /* early exit (--GC_conf / FR.py:136): ids are evaluated in batches of `batch`; after a
                                batch ending at id e the run stops when e >= log(1-confidence) / log(1 - (inl/M)^sample_size)
                                for the best model so far.  >= 1 (or <= 0): every id is evaluated.             */
-    int32_t  batch;         /* batch length of the early-exit test, constant; 0 -> 8192, 32768, 131072, ... (fourfold) */
+    int32_t  batch;         /* batch length of the early-exit test, constant; 0 -> 1024, 8192, 65536, ... (eightfold) */
     int32_t  sampler;       /* 0: uniform WITH replacement (Open3D's RANSAC, FR.py:128-137); 2: uniform, unique indices
                                (GC_RANSAC.py:19 'sampler': 0 -> GC-RANSAC's UniformSampler); 1: PROSAC (--prosac,
                                GC_RANSAC.py:24,39-43): the correspondences must come best quality first; hypothesis id h =

@@ -1242,11 +1242,11 @@ int lr_ransac_run(lr_workspace *ws, const float *corr8, int m_max, const int32_t
     sub &= ~1;                  // the scoring loop takes correspondences two at a time
     if (sub < 2) sub = 2;       // 2 * thr2 * 2^20 < 2^32 for every admissible thr2 (< 2048)
     const bool use_exit = p->confidence > 0.0f && p->confidence < 1.0f;
-    // batch lengths: the given one, constant; by default 8192, 32768, 131072, ... -- growing fourfold, so that the exit test is fine-grained
+    // batch lengths: the given one, constant; by default 1024, 8192, 65536, ... -- growing eightfold, so that the exit test is fine-grained
     // where an easy pair stops (the reference tests after every iteration) while a long run still takes few batches (the launches
-    // of the batches after the exit cost ~5 us per kernel, ~40 us per batch: measured on the full-list run): 3 batches for 50k ids, 4 for the CLI's default 500k, 5 for 1M
+    // of the batches after the exit cost ~5 us per kernel, ~40 us per batch: measured on the full-list run): 3 batches for 50k ids, 4 for the CLI's default 500k, 5 for 1M; an easy pair scores 1024 ids instead of the 8192 of round 2
     const bool geometric = use_exit && p->batch <= 0;
-    long long B = use_exit ? (p->batch > 0 ? p->batch : 8192) : (p->iters > 0 ? p->iters : 1);
+    long long B = use_exit ? (p->batch > 0 ? p->batch : 1024) : (p->iters > 0 ? p->iters : 1);
     LR_REQUIRE(p->use_elc >= 0 && p->use_elc <= 2, LR_EINVAL, "lr_ransac: use_elc must be 0 (no pre-verification), 1 (edge-length check) or 2 (SPRT)");
     LR_REQUIRE(p->sampler >= 0 && p->sampler <= 2, LR_EINVAL, "lr_ransac: sampler must be 0 (uniform), 1 (PROSAC) or 2 (uniform, unique indices)");
     LR_REQUIRE(p->local_opt >= 0 && p->local_opt <= 2, LR_EINVAL, "lr_ransac: local_opt must be 0, 1 or 2");
@@ -1258,7 +1258,7 @@ int lr_ransac_run(lr_workspace *ws, const float *corr8, int m_max, const int32_t
         hipLaunchKernelGGL(prosac_growth_kernel, dim3(1, 1, ws->zP), dim3(1024), 0, st, m_max, m_dev, p->sample_size, TN, ws->prosac_G, ws->z);
         G = ws->prosac_G;
     }
-    for (long long h0l = 0; h0l < (p->iters > 0 ? p->iters : 1); h0l += B, B = geometric ? 4 * B : B) {
+    for (long long h0l = 0; h0l < (p->iters > 0 ? p->iters : 1); h0l += B, B = geometric ? 8 * B : B) {
         const int h0 = (int)h0l;
         const int h1 = h0l + B < p->iters ? (int)(h0l + B) : p->iters;
         const int gb_all = lr_cdiv(h1 - h0 > 0 ? h1 - h0 : 1, 256);      // 256-id groups of the batch

@@ -19,7 +19,7 @@ PRECHECK = {"NONE": 0, "ELC": 1, "SPRT": 2}      # --fast_rejection (test.py:306
 
 def ransac_params(iters, sample_size=3, use_elc=True, thr=0.6, seed=DEFAULT_SEED, confidence=1.0, batch=0, sampler=0, prosac_growth=0,
                   scoring=0, local_opt=0, lo_rounds=0, lo_trials=0, lo_max_calls=0, min_iters=0):
-    """confidence < 1 enables the early exit between batches of `batch` hypothesis ids (0 -> 8192, 32768, 131072, ...: fourfold); sampler 1 = PROSAC
+    """confidence < 1 enables the early exit between batches of `batch` hypothesis ids (0 -> 1024, 8192, 65536, ...: eightfold); sampler 1 = PROSAC
     (correspondences best quality first, growth parameter T_N = prosac_growth, 0 -> 100000), 2 = uniform with unique indices; scoring 1 = MSAC,
     2 = MSAC at GC-RANSAC's truncated threshold (3/2 thr)^2; local_opt 1 = GC-RANSAC's local optimisation + final iterated least squares,
     2 = the latter only; lo_rounds / lo_trials / lo_max_calls / min_iters: 0 = the defaults of gcransac_python.cpp:513-517 (lidarreg.h)."""

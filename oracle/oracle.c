@@ -341,7 +341,7 @@ typedef struct {
     int32_t  iters;           /* hypotheses h = 0 .. iters-1                          */
     uint64_t seed;
     float    confidence;      /* early exit between batches (FR.py:136, GC_RANSAC.py:26); >= 1 or <= 0: none */
-    int32_t  batch;           /* batch length, constant (0 -> 8192, 32768, 131072, ...: fourfold) */
+    int32_t  batch;           /* batch length, constant (0 -> 1024, 8192, 65536, ...: eightfold) */
     int32_t  sampler;         /* 0 uniform with replacement (Open3D); 1 PROSAC (GC_RANSAC.py:24,39-43): correspondences best
                                  first; 2 uniform, unique indices (GC-RANSAC's UniformSampler).  1 and 2 reject a draw with a
                                  repeated index: it consumes its id like a failed pre-check                                  */
@@ -682,13 +682,13 @@ ORC_API void orc_ransac(const float *src, const float *tgt, int m, const orc_ran
     double sprt_eps = SPRT_EPS0, sprt_delta = SPRT_DELTA0;
     uint64_t rej_inl = 0, rej_pts = 0;
     const int use_exit = p->confidence > 0.0f && p->confidence < 1.0f;
-    /* batch lengths: the given one, constant; by default 8192, 32768, 131072, ... (fourfold: the exit test is fine-grained where an
+    /* batch lengths: the given one, constant; by default 1024, 8192, 65536, ... (eightfold: the exit test is fine-grained where an
      * easy pair stops, and a long run still takes few batches) */
     const int geometric = use_exit && p->batch <= 0;
-    int64_t B = use_exit ? (p->batch > 0 ? p->batch : 8192) : (p->iters > 0 ? p->iters : 1);
+    int64_t B = use_exit ? (p->batch > 0 ? p->batch : 1024) : (p->iters > 0 ? p->iters : 1);
     int32_t *G = p->sampler == 1 ? prosac_table(m, p->sample_size, p->prosac_growth > 0 ? p->prosac_growth : 100000) : NULL;
     const uint32_t msac_T = p->scoring == 1 ? (uint32_t)(p->thr2 * 1048576.0f) : 0u;
-    for (int64_t h0 = 0; h0 < p->iters; h0 += B, B = geometric ? 4 * B : B) {
+    for (int64_t h0 = 0; h0 < p->iters; h0 += B, B = geometric ? 8 * B : B) {
         const int64_t h1 = h0 + B < p->iters ? h0 + B : p->iters;
         int64_t bb_h = -1; uint32_t bb_c = 0; uint64_t bb_q = 0;      /* winner of this batch */
         const double sprt_A = p->use_elc == 2 ? sprt_threshold(sprt_eps, sprt_delta) : 0.0;

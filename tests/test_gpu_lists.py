@@ -34,7 +34,7 @@ def test_list_rows_every_512th(oracle, dataset, rows):
     assert ok5.all() and ok2.all(), (res["re_deg"], res["te_m"])                  # surrogate data: every row is recovered
     assert (res["status"] == 0).all() and (res["n_corr"] > 1000).all()
     # early exit: an easy pair stops after the first batch of ids, never later than --iters
-    assert (res["n_ids"] >= 8192).all() and (res["n_ids"] <= a.iters).all()
+    assert (res["n_ids"] >= 1024).all() and (res["n_ids"] <= a.iters).all()
     call, fwd = res["stage_ms_per_pair"][0], res["stage_ms_per_pair"][1]
     assert 0.0 < fwd < call and 0.0 <= res["second_nn_share"] < 0.5
     # one row against the oracle pipeline on the same synthetic pair (the device generator's numbers copied to the host)

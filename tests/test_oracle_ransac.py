@@ -276,11 +276,11 @@ def test_deterministic_logarithm(oracle):
     assert f(1.0) == 0.0 and f(0.0) == -math.inf and f(math.inf) == math.inf and math.isnan(f(-1.0)) and math.isnan(f(math.nan))
 
 
-def test_default_exit_batches_grow_fourfold(oracle):
-    """With no batch length given the exit test runs after 8192, 40960, 172032, ... hypothesis ids (batches of 8192, 32768,
-    131072, ...); a given batch length stays constant.  The ids examined are reported in n_ids."""
+def test_default_exit_batches_grow_eightfold(oracle):
+    """With no batch length given the exit test runs after 1024, 9216, 74752, ... hypothesis ids (batches of 1024, 8192,
+    65536, ...); a given batch length stays constant.  The ids examined are reported in n_ids."""
     rng = np.random.default_rng(5)
-    boundaries = {8192 * (4 ** k - 1) // 3 for k in range(1, 8)}
+    boundaries = {1024 * (8 ** k - 1) // 7 for k in range(1, 8)}
     for inlier, conf in [(0.5, 0.999), (0.08, 0.999), (0.045, 0.99), (0.03, 0.9)]:
         src, tgt, _, _ = _planted(n=3000, inlier=inlier, seed=int(rng.integers(1000)))
         _, info = oracle.ransac(src, tgt, 200000, seed=3, sampler=2, confidence=conf)
