@@ -1371,6 +1371,7 @@ __device__ void refit_solve_body(const double *__restrict__ partial, int nblocks
 }
 
 // ------------------------------------------------------------------ refit (FR.py:99-111)
+#define LR_REFIT_PER 4
 // partial[b][0] = n, [1..3] = sum p, [4..6] = sum q, [7..15] = sum p q^T over the inliers of block b
 __global__ void __launch_bounds__(256)
 refit_moments_kernel(const float *__restrict__ xyz0, int n0, const float *__restrict__ xyz1, const int32_t *__restrict__ idx1,
@@ -1392,15 +1393,24 @@ refit_moments_kernel(const float *__restrict__ xyz0, int n0, const float *__rest
     double T[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) T[k] = T_in[k];
-    const int i = blockIdx.x * 256 + threadIdx.x;
     double v[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) v[k] = 0.0;
     // pairs (i, idx1[i]) over all n0 rows, or -- with idx0 -- the listed pairs (idx0[c], idx1[c]), c < *m_dev
     if (m_dev) n0 = min(n0, *m_dev);
-    if (i < n0) {
-        const int j = idx1[i];
-        const int pi = idx0 ? idx0[i] : i;
+    // LR_REFIT_PER pairs per thread (the 16 fp64 wave reductions below cost far more than a pair's moments: one pair per thread spent
+    // most of the kernel in shuffles); the loads of all of them are issued before the first use
+    int jj[LR_REFIT_PER], pp[LR_REFIT_PER];
+#pragma unroll
+    for (int u = 0; u < LR_REFIT_PER; ++u) {
+        const int i = (blockIdx.x * LR_REFIT_PER + u) * 256 + threadIdx.x;
+        jj[u] = i < n0 ? idx1[i] : -1;
+        pp[u] = i < n0 ? (idx0 ? idx0[i] : i) : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < LR_REFIT_PER; ++u) {
+        if (jj[u] < 0) continue;
+        const int j = jj[u], pi = pp[u];
         double p[3] = { (double)xyz0[3 * pi], (double)xyz0[3 * pi + 1], (double)xyz0[3 * pi + 2] };
         double q[3] = { (double)xyz1[3 * j], (double)xyz1[3 * j + 1], (double)xyz1[3 * j + 2] };
         double r[3];
@@ -1418,13 +1428,13 @@ refit_moments_kernel(const float *__restrict__ xyz0, int n0, const float *__rest
                 for (int k = 0; k < 32; ++k) { const float e = fa[k] - fb[k]; const float q2 = e * e; acc = acc + q2; }
                 w = 1.0 / (double)fmaxf(__builtin_sqrtf(acc), 1e-12f);
             }
-            v[0] = w;
+            v[0] += w;
 #pragma unroll
-            for (int a = 0; a < 3; ++a) { v[1 + a] = w * p[a]; v[4 + a] = w * q[a]; }
+            for (int a = 0; a < 3; ++a) { v[1 + a] += w * p[a]; v[4 + a] += w * q[a]; }
 #pragma unroll
             for (int a = 0; a < 3; ++a)
 #pragma unroll
-                for (int b = 0; b < 3; ++b) v[7 + 3 * a + b] = (w * p[a]) * q[b];
+                for (int b = 0; b < 3; ++b) v[7 + 3 * a + b] += (w * p[a]) * q[b];
         }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1462,7 +1472,7 @@ int lr_refit_run(lr_workspace *ws, const float *xyz0, int n0, const float *xyz1,
                  hipStream_t st, lr_pair_result *pair_out, const int32_t *idx0, const int32_t *m_dev,
                  const float *F0, const float *F1)
 {
-    const int nb = lr_cdiv(n0, 256);
+    const int nb = lr_cdiv(n0, 256 * LR_REFIT_PER);
     int32_t *ticket = ws->counters + LR_CNT_REFIT_TICKET;
     if (!pair_out) LR_HIP(hipMemsetAsync(ticket, 0, sizeof(int32_t), st));      // lr_register_pair starts from cleared counters
     hipLaunchKernelGGL(refit_moments_kernel, dim3(nb, 1, ws->zP), dim3(256), 0, st, xyz0, n0, xyz1, idx1, T_in, thr2, ws->refit_part, idx0, m_dev,
