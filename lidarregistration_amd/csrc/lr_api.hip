@@ -77,6 +77,7 @@ void carve(lr_workspace *ws, Carver &c)
     ws->icp_bucket = c.take<int32_t>(n1); ws->icp_pts = c.take<float>(4 * n1);
     ws->icp_state = c.take<double>(32); ws->icp_part = c.take<double>((n0 / 256 + 2) * 18);
     ws->lo_list = c.take<int32_t>(n0);
+    ws->lo_ctl = c.take<char>(LR_LO_CTL_BYTES);
     ws->sc_info = c.take<char>(LR_SC_INFO_BYTES);
     ws->corr8s = c.take<float>((n0 + 4) * 8);
     ws->sc_perm = c.take<int32_t>(it); ws->sc_glen = c.take<int32_t>(it / 64 + 2);

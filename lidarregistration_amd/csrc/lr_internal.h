@@ -46,6 +46,7 @@ __host__ __device__ static inline int lr_seg_cap(int strips) { const int c = (LR
 #endif
 #define LR_GPF_MAX_CELLS 4096
 #define LR_SC_INFO_BYTES 2048
+#define LR_LO_CTL_BYTES 20480      // lr_lo_ctl: control block of the local optimisation's helper blocks
 #define LR_NEV 10
 
 // ---- pair-batched launches -------------------------------------------------------------------------------------------
@@ -141,6 +142,7 @@ struct lr_workspace {
     unsigned long long *score_ssq; // [max_iters]
     double *refit_part;          // [blocks][16] moment partials
     int32_t *lo_list;            // [max_n0] inlier list of the model under local optimisation
+    void *lo_ctl;                // lr_lo_ctl (LR_LO_CTL_BYTES): jobs the master block of a local optimisation publishes for its helper blocks
     // pilot-ordered scoring (lr_ransac.hip, "score"): head / order passes -> main pass
     void *sc_info;               // lr_score_info (LR_SC_INFO_BYTES)
     float *corr8s;               // the records behind the head, sorted by their residual under the pilot model (layout of corr8)

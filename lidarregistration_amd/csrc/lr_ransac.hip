@@ -702,9 +702,15 @@ __global__ void __launch_bounds__(1024)
 ransac_final_kernel(const uint32_t *__restrict__ score_cnt, const unsigned long long *__restrict__ score_ssq,
                     const int32_t *__restrict__ model_h, const double *__restrict__ models64,
                     int32_t *__restrict__ counters, int m_max, const int32_t *__restrict__ m_dev, lr_ransac_params p, int h_end,
-                    double *__restrict__ T_out, lr_ransac_result *__restrict__ res, int vslot, lr_zargs z)
+                    double *__restrict__ T_out, lr_ransac_result *__restrict__ res, int vslot, int32_t *__restrict__ lo_ctl_words, lr_zargs z)
 {
     __shared__ unsigned long long s_q[16];
+    // the control block of the local optimisation's helper blocks starts from zero at every launch that may use it (before any way out
+    // of this kernel: the launch that follows runs whatever happens here)
+    if (lo_ctl_words) {
+        lr_z(lo_ctl_words, z, blockIdx.z);
+        for (int k = threadIdx.x; k < LR_LO_CTL_BYTES / 4; k += 1024) lo_ctl_words[k] = 0;
+    }
     lr_z(score_cnt, z, blockIdx.z); lr_z(score_ssq, z, blockIdx.z); lr_z(model_h, z, blockIdx.z); lr_z(models64, z, blockIdx.z); lr_z(counters, z, blockIdx.z); lr_z(m_dev, z, blockIdx.z); lr_z(T_out, z, blockIdx.z); lr_z(res, z, blockIdx.z);
     __shared__ uint32_t s_c[16];
     __shared__ int s_h[16], s_s[16];
@@ -978,11 +984,10 @@ __device__ void lo_score_one(lo_shared &sh, const float *__restrict__ corr8, int
 // step), with three correspondence streams side by side in a wave -- lanes [20 s, 20 s + 20) apply the 20 models to the records
 // 3 w + s, 3 w + s + 48, ... of wave w -- so 60 of the 64 lanes work and a wave's three 64-byte records come in as three
 // broadcast global_load_dwordx4 per lane.  12 coefficient + 12 record registers, sums per lane, 48 LDS atomics per model at the end.
-__device__ void lo_score_lanes(lo_shared &sh, const float *__restrict__ corr8, int m, float thr2)
+__device__ void lo_score_lanes_range(lo_shared &sh, const float *__restrict__ corr8, int m, float thr2, int rec_begin, int rec_end)
 {
+    // (adds to sh.cnt / sh.ssq: the caller zeroes them; records [rec_begin, rec_end))
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (tid < LO_TRIALS) { sh.cnt[tid] = 0u; sh.ssq[tid] = 0ull; }
-    __syncthreads();
     constexpr int NS = 64 / LO_TRIALS;                 // streams per wave (3)
     constexpr int STRIDE = NS * (LO_THREADS / 64);     // records between two steps of a stream (48)
     const int t = lane % LO_TRIALS, st = lane / LO_TRIALS;
@@ -993,15 +998,15 @@ __device__ void lo_score_lanes(lo_shared &sh, const float *__restrict__ corr8, i
     const f32x2 R10 = { r1.x, r1.x }, R11 = { r1.y, r1.y }, R12 = { r1.z, r1.z }, TY = { r1.w, r1.w };
     const f32x2 R20 = { r2.x, r2.x }, R21 = { r2.y, r2.y }, R22 = { r2.z, r2.z }, TZ = { r2.w, r2.w };
     const f32x2 SC = { 1048576.0f, 1048576.0f };
-    const int nrec = (m + 1) >> 1;
     uint32_t c = 0u;
     unsigned long long q = 0ull;
-    const int first = wave * NS + (act ? st : 0);
-    const int steps = (nrec - wave * NS + STRIDE - 1) / STRIDE;        // (wave-uniform: the steps of the wave's first stream)
+    const int first = rec_begin + wave * NS + (act ? st : 0);
+    const int span = rec_end - rec_begin - wave * NS;
+    const int steps = span > 0 ? (span + STRIDE - 1) / STRIDE : 0;        // (wave-uniform: the steps of the wave's first stream)
 #pragma unroll 2
     for (int k = 0; k < steps; ++k) {
         const int r = first + k * STRIDE;
-        const bool live = act && r < nrec;
+        const bool live = act && r < rec_end;
         const f32x4 *rec = reinterpret_cast<const f32x4 *>(corr8) + (size_t)(live ? r : 0) * 4;
         const f32x4 A = rec[0], B = rec[1], C = rec[2];
         const f32x2 px = { A.x, A.y }, py = { A.z, A.w }, pz = { B.x, B.y }, qx = { B.z, B.w }, qy = { C.x, C.y }, qz = { C.z, C.w };
@@ -1017,6 +1022,130 @@ __device__ void lo_score_lanes(lo_shared &sh, const float *__restrict__ corr8, i
     }
     if (act && c) { atomicAdd(&sh.cnt[t], c); atomicAdd(&sh.ssq[t], q); }
     __syncthreads();
+}
+__device__ void lo_score_lanes(lo_shared &sh, const float *__restrict__ corr8, int m, float thr2)
+{
+    if (threadIdx.x < LO_TRIALS) { sh.cnt[threadIdx.x] = 0u; sh.ssq[threadIdx.x] = 0ull; }
+    __syncthreads();
+    lo_score_lanes_range(sh, corr8, m, thr2, 0, (m + 1) >> 1);
+}
+
+// ---- helper blocks (single-pair and small-batch calls: the GPU is idle while one block per pair optimises its model).
+// The scoring of a round's 20 models over all correspondences is 2/3 of a round and embarrassingly parallel.  The master block (block 0
+// of the pair) PUBLISHES it as a job -- the 20 rounded models, the chunk count -- in a control block in device memory; every block of
+// the pair's group, the master included, claims chunks of LO_CHUNK_REC records from the job's counter, scores them with
+// lo_score_lanes_range, adds its integer sums to the job's totals and reports the chunks it did.  The master waits only for chunks that
+// were CLAIMED, i.e. for blocks that are running: a helper that was never scheduled (other kernels hold the CUs) costs nothing, and no
+// block ever waits for a block that is not running -- there is no grid barrier.  Every job has its own slot (counters are never reused
+// within a launch, so a slow helper cannot touch a later job); the slots are zeroed by ransac_final_kernel, which precedes every launch.
+// Release / acquire follow MI355X_MICROARCH.md ("inter-workgroup visibility"): stores, vmcnt(0), barrier, agent-scope release, flag;
+// agent-scope acquire by one lane, vmcnt(0), barrier, plain loads.  Spins are bounded by the wall clock; a master that gives up
+// recomputes the job alone.
+#define LO_CHUNK_REC 384
+#define LO_JOBS 16
+struct lr_lo_job { int32_t next_chunk, done_chunks, nchunks, pad; float Rt[LO_TRIALS][12]; unsigned cnt[LO_TRIALS]; unsigned long long ssq[LO_TRIALS]; };
+struct lr_lo_ctl { int32_t phase, pad[3]; lr_lo_job job[LO_JOBS]; };      // phase: 0 nothing yet; k > 0: job k - 1 is published; -1: the master is done
+static_assert(sizeof(lr_lo_ctl) <= LR_LO_CTL_BYTES, "lr_lo_ctl does not fit its scratch block");
+
+// this block's share of job `jb` (models already in sh.Rt): claims chunks until none is left, then adds its sums to the job's totals
+__device__ void lo_job_work(lo_shared &sh, lr_lo_job *jb, const float *__restrict__ corr8, int m, float thr2)
+{
+    const int tid = threadIdx.x;
+    const int nrec = (m + 1) >> 1;
+    const int nchunks = (nrec + LO_CHUNK_REC - 1) / LO_CHUNK_REC;
+    if (tid < LO_TRIALS) { sh.cnt[tid] = 0u; sh.ssq[tid] = 0ull; }
+    __syncthreads();
+    int mine = 0;
+    for (;;) {
+        if (tid == 0) sh.flag = __hip_atomic_fetch_add(&jb->next_chunk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const int c = sh.flag;
+        __syncthreads();
+        if (c >= nchunks) break;
+        lo_score_lanes_range(sh, corr8, m, thr2, c * LO_CHUNK_REC, min(nrec, (c + 1) * LO_CHUNK_REC));
+        mine += 1;
+    }
+    if (mine > 0) {
+        if (tid < LO_TRIALS && sh.cnt[tid]) {
+            __hip_atomic_fetch_add(&jb->cnt[tid], sh.cnt[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(&jb->ssq[tid], sh.ssq[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __hip_atomic_fetch_add(&jb->done_chunks, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+}
+
+// master: score sh.Rt[0 .. LO_TRIALS) over all correspondences with whoever helps -> sh.cnt / sh.ssq
+__device__ void lo_score_shared(lo_shared &sh, lr_lo_ctl *ctl, int job, const float *__restrict__ corr8, int m, float thr2)
+{
+    const int tid = threadIdx.x;
+    lr_lo_job *jb = &ctl->job[job];
+    const int nrec = (m + 1) >> 1;
+    const int nchunks = (nrec + LO_CHUNK_REC - 1) / LO_CHUNK_REC;
+    for (int k = tid; k < LO_TRIALS * 12; k += LO_THREADS) jb->Rt[k / 12][k % 12] = sh.Rt[k / 12][k % 12];
+    if (tid == 0) jb->nchunks = nchunks;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_store(&ctl->phase, job + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    lo_job_work(sh, jb, corr8, m, thr2);
+    // wait for the chunks other blocks claimed (they are running: this ends), bounded by the wall clock
+    if (tid == 0) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        int ok = 1;
+        while (__hip_atomic_load(&jb->done_chunks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nchunks) {
+            __builtin_amdgcn_s_sleep(2);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 20000000ull) { ok = 0; break; }      // 0.2 s at 100 MHz
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        sh.flag = ok;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int ok = sh.flag;
+    __syncthreads();
+    if (!ok) { lo_score_lanes(sh, corr8, m, thr2); return; }          // (never observed; the sums of the job are abandoned)
+    if (tid < LO_TRIALS) {
+        sh.cnt[tid] = __hip_atomic_load(&jb->cnt[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sh.ssq[tid] = __hip_atomic_load(&jb->ssq[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+}
+
+// helper block: serves the jobs the master publishes until it says it is done (or nothing happens for 0.2 s)
+__device__ void lo_helper_loop(lo_shared &sh, lr_lo_ctl *ctl, const float *__restrict__ corr8, int m, float thr2)
+{
+    const int tid = threadIdx.x;
+    int seen = 0;
+    for (;;) {
+        if (tid == 0) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            int p;
+            while ((p = __hip_atomic_load(&ctl->phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == seen) {
+                __builtin_amdgcn_s_sleep(8);
+                if (__builtin_amdgcn_s_memrealtime() - t0 > 20000000ull) { p = -1; break; }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            sh.flag = p;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int p = sh.flag;
+        __syncthreads();
+        if (p <= 0) return;                       // -1: done (0 cannot be observed as a change)
+        seen = p;
+        lr_lo_job *jb = &ctl->job[p - 1];
+        for (int k = tid; k < LO_TRIALS * 12; k += LO_THREADS) sh.Rt[k / 12][k % 12] = jb->Rt[k / 12][k % 12];
+        __syncthreads();
+        lo_job_work(sh, jb, corr8, m, thr2);
+    }
 }
 
 // any number of models and any threshold (64-bit sums): LO_THREADS / ntrial threads per model, each striding over the correspondences
@@ -1042,10 +1171,14 @@ __device__ void lo_score_wide(lo_shared &sh, const float *__restrict__ corr8, in
     __syncthreads();
 }
 
-__device__ __forceinline__ void lo_score(lo_shared &sh, const float *__restrict__ corr8, int m, float thr2, int ntrial)
+__device__ __forceinline__ void lo_score(lo_shared &sh, const float *__restrict__ corr8, int m, float thr2, int ntrial, lr_lo_ctl *ctl = nullptr, int job = -1)
 {
     // 32-bit per-thread error sums hold when (correspondences per thread) * thr2 * 2^20 < 2^32
-    if (ntrial > 1) { lo_score_lanes(sh, corr8, m, thr2); return; }      // (lanes of trials >= ntrial score stale models nobody reads)
+    if (ntrial > 1) {      // (lanes of trials >= ntrial score stale models nobody reads)
+        if (ctl && job >= 0 && job < LO_JOBS) lo_score_shared(sh, ctl, job, corr8, m, thr2);
+        else lo_score_lanes(sh, corr8, m, thr2);
+        return;
+    }
     const bool narrow = ((double)(m / LO_THREADS + 1)) * (double)thr2 * 1048576.0 < 4.0e9;
     if (!narrow) lo_score_wide(sh, corr8, m, thr2, ntrial);
     else lo_score_one(sh, corr8, m, thr2);
@@ -1054,16 +1187,23 @@ __device__ __forceinline__ void lo_score(lo_shared &sh, const float *__restrict_
 __global__ void __launch_bounds__(LO_THREADS)
 ransac_lo_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__restrict__ m_dev, lr_ransac_params p, int h_end, int mode,
                  int32_t *__restrict__ counters, int32_t *__restrict__ list, double *__restrict__ T_out, lr_ransac_result *__restrict__ res,
-                 lr_zargs z)
+                 lr_lo_ctl *__restrict__ ctl, lr_zargs z)
 {
     lr_z(corr8, z, blockIdx.z); lr_z(m_dev, z, blockIdx.z); lr_z(counters, z, blockIdx.z); lr_z(list, z, blockIdx.z); lr_z(T_out, z, blockIdx.z);
-    lr_z(res, z, blockIdx.z);
+    lr_z(res, z, blockIdx.z); lr_z(ctl, z, blockIdx.z);
     __shared__ lo_shared sh;
     lr_ransac_state *state = reinterpret_cast<lr_ransac_state *>(counters + LR_CNT_COUNT);
     const int m = m_dev ? min(*m_dev, m_max) : m_max;
     const int tid = threadIdx.x;
-    if (state->cnt == 0 || m <= 0) return;                         // no model
-    if (mode == 0 && !state->lo_pending) return;                  // best model unchanged by the batch just merged
+    const bool helpers = gridDim.x > 1 && mode == 0;              // blocks 1.. of the pair's group serve the master's scoring jobs
+    if (blockIdx.x > 0) {
+        if (helpers && m > 0) lo_helper_loop(sh, ctl, corr8, m, p.thr2);
+        return;
+    }
+    // (every way out of the master tells the helpers: they must not wait for jobs that never come)
+    auto release_helpers = [&]() { if (helpers && tid == 0) __hip_atomic_store(&ctl->phase, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    if (state->cnt == 0 || m <= 0) { release_helpers(); return; }                         // no model
+    if (mode == 0 && !state->lo_pending) { release_helpers(); return; }                  // best model unchanged by the batch just merged
     const uint32_t msac_T = p.scoring == 1 ? (uint32_t)(p.thr2 * 1048576.0f) : 0u;
     if (tid < 12) sh.curT[tid] = state->T[tid];
     if (tid == 0) { sh.curc = state->cnt; sh.curq = state->ssq; }
@@ -1130,7 +1270,7 @@ ransac_lo_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__re
                 }
                 __syncthreads();
             } else if (!lo_fit_all(sh, corr8, list, nI)) break;
-            lo_score(sh, corr8, m, p.thr2, ntrial);
+            lo_score(sh, corr8, m, p.thr2, ntrial, helpers ? ctl : nullptr, round);
             if (tid == 0) {
                 int bt = -1; unsigned bc = 0; unsigned long long bq = 0;
                 for (int t = 0; t < ntrial; ++t) {
@@ -1161,6 +1301,7 @@ ransac_lo_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__re
         }
     }
     __syncthreads();
+    release_helpers();
     // back to the running state; outputs rewritten from it
     if (tid < 16) {
         double v = (tid % 5 == 0) ? 1.0 : 0.0;
@@ -1253,6 +1394,9 @@ int lr_ransac_run(lr_workspace *ws, const float *corr8, int m_max, const int32_t
     LR_REQUIRE(p->prosac_growth >= 0, LR_EINVAL, "lr_ransac: prosac_growth must be >= 0");
     const int TN = p->prosac_growth > 0 ? p->prosac_growth : 100000;
     const int32_t *G = nullptr;
+    // blocks per pair of the local-optimisation launches: with one or a few pairs in the call the GPU is idle next to the one block
+    // that optimises a pair's model, so helper blocks take shares of its scoring jobs (lo_score_shared); a full batch fills the GPU anyway
+    const int lo_groups = (p->local_opt == 1 && m_max >= 4 * LO_CHUNK_REC) ? (ws->zP <= 2 ? 16 : ws->zP <= 4 ? 8 : 1) : 1;
     if (ws->timing && ws->ev_pending == 1) { LR_HIP(hipEventRecord(ws->ev[2], st)); }
     if (p->sampler == 1) {
         hipLaunchKernelGGL(prosac_growth_kernel, dim3(1, 1, ws->zP), dim3(1024), 0, st, m_max, m_dev, p->sample_size, TN, ws->prosac_G, ws->z);
@@ -1303,14 +1447,14 @@ int lr_ransac_run(lr_workspace *ws, const float *corr8, int m_max, const int32_t
         if (h0 == 0 && ws->timing && ws->ev_pending == 1) { LR_HIP(hipEventRecord(ws->ev[3], st)); ws->ev_pending = 2; }
         hipLaunchKernelGGL(ransac_final_kernel, dim3(1, 1, ws->zP), dim3(1024), 0, st, ws->score_cnt, ws->score_ssq,
                            sprt ? (const int32_t *)ws->model_h2 : (const int32_t *)ws->model_h, sprt ? (const double *)ws->models64_2 : (const double *)ws->models64,
-                           ws->counters, m_max, m_dev, *p, h1, T_out, res, vslot, ws->z);
+                           ws->counters, m_max, m_dev, *p, h1, T_out, res, vslot, lo_groups > 1 ? reinterpret_cast<int32_t *>(ws->lo_ctl) : (int32_t *)nullptr, ws->z);
         if (p->local_opt == 1)
-            hipLaunchKernelGGL(ransac_lo_kernel, dim3(1, 1, ws->zP), dim3(LO_THREADS), 0, st, corr8, m_max, m_dev, *p, h1, 0, ws->counters, ws->lo_list,
-                               T_out, res, ws->z);
+            hipLaunchKernelGGL(ransac_lo_kernel, dim3(lo_groups, 1, ws->zP), dim3(LO_THREADS), 0, st, corr8, m_max, m_dev, *p, h1, 0, ws->counters, ws->lo_list,
+                               T_out, res, reinterpret_cast<lr_lo_ctl *>(ws->lo_ctl), ws->z);
     }
     if (p->local_opt)          // final iterated least squares over the inliers
         hipLaunchKernelGGL(ransac_lo_kernel, dim3(1, 1, ws->zP), dim3(LO_THREADS), 0, st, corr8, m_max, m_dev, *p, p->iters, 1, ws->counters, ws->lo_list,
-                           T_out, res, ws->z);
+                           T_out, res, reinterpret_cast<lr_lo_ctl *>(ws->lo_ctl), ws->z);
     LR_LAUNCH_CHECK();
     return LR_OK;
 }
