@@ -55,6 +55,8 @@ def parse(argv=None):
                     help="collective backend of the N > 1 run: nccl (= RCCL over xGMI, the product path) or gloo (host tensors; lets two ranks share "
                          "one GPU so that the launcher, rendezvous, per-rank seeds and max-over-ranks timing can be exercised on a 1-GPU box)")
     ap.add_argument("--devices", type=str, default=None, help="comma-separated device index per rank (default: rank r -> device r); e.g. 0,0 with --dist-backend gloo")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="tuning option for every workspace (lr_workspace_option: nn_blocks, nn_blocks_batch, nn_sample_stride, rev_strips, nn_second_auto); none changes a result")
     ap.add_argument("--list", choices=["A", "B"], default=None,
                     help="instead of the headline workload: the reference's README commands over a FULL balanced test list with the list-driven "
                          "synthetic surrogate (SURVEY 8d; every row's ground-truth motion and overlap, --n points): A = Apollo-Southbay, 7008 rows, "
@@ -219,6 +221,11 @@ def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args))
+    if args.opt:
+        from lidarregistration_amd import _ext as _e
+        for kv in args.opt:
+            k, v = kv.split("=")
+            _e.DEFAULT_OPTIONS[k] = int(v)
     if args.list:
         return list_run(args)
     import torch

@@ -241,7 +241,7 @@ ransac_gen_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__r
             score_cnt[slot] = 0u;
             score_ssq[slot] = 0ull;
         }
-        __syncthreads();
+        if ((blk + (int)gridDim.x) * 256 < h_end - h_begin) __syncthreads();      // (only when the block takes another group)
     }
 }
 
