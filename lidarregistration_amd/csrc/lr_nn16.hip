@@ -36,6 +36,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 #define LR_INF __builtin_huge_valf()
@@ -160,6 +161,20 @@ nn16_prep_kernel(const float *__restrict__ Fa, int na, _Float16 *__restrict__ Ha
 #ifndef LR_PB_TIGHTEN
 #define LR_PB_TIGHTEN 48         // new entries of a wave that trigger a tightening round
 #endif
+
+#ifndef LR_PB_M16
+#define LR_PB_M16 1              // walk on v_mfma_f32_16x16x32_f16 (1) or 32x32x16 (0)
+#endif
+// row (0..63 of the wave) of register i (0..7: mask bit 7 - i) of an entry with the given code
+__device__ __forceinline__ int lr_pb_row(int code, int i)
+{
+#if LR_PB_M16
+    return 32 * (code >> 2) + 16 * (i >> 2) + 4 * (code & 3) + (i & 3);       // code = (row-block pair q) * 4 + (lane / 16)
+#else
+    const int g = 8 * ((code >> 1) & 1) + i;                                  // code = rb * 4 + (g0 / 8) * 2 + h
+    return 32 * (code >> 2) + (g & 3) + 8 * (g >> 2) + 4 * (code & 1);
+#endif
+}
 
 #define LR_RS_BUCKETS 4096
 
@@ -380,6 +395,26 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         __syncthreads();
     }
 
+#if LR_PB_M16
+    // The walk runs on v_mfma_f32_16x16x32_f16 (all 32 K in one instruction; under the board's power limit it sustains ~20 % more
+    // flops than 32x32x16, tools/mfma_clock.hip): lane (c, kb) = (lane % 16, lane / 16) supplies K bytes 16 kb.. of row / column c of
+    // a 16-block and receives rows 4 kb + 0..3, column c of the 16 x 16 result.  Row fragments of the wave's four 16-row blocks:
+    const int c16 = lane & 15, kb = lane >> 4;
+    f16x8 a16[4];
+#pragma unroll
+    for (int rbk = 0; rbk < 4; ++rbk) {
+        int row = min(row0 + 16 * rbk + c16, na - 1);
+        if (rowmap) row = rowmap[row];
+        a16[rbk] = *reinterpret_cast<const f16x8 *>(Hq + (size_t)row * 32 + 8 * kb);
+    }
+    // the lane's 4 x 4 threshold registers: register g of row block rbk <-> row 16 rbk + 4 kb + g of the wave
+    f32x4 y4[4];
+    auto load_y = [&]() {
+#pragma unroll
+        for (int rbk = 0; rbk < 4; ++rbk) y4[rbk] = *reinterpret_cast<const f32x4 *>(&s_Y[wave * 64 + 16 * rbk + 4 * kb]);
+    };
+    load_y();
+#else
     f32x16 y[2];
     // the lane's 16 + 16 threshold registers: register g of row block rb <-> row 32 rb + (g&3) + 8 (g>>2) + 4 h of the wave
     auto load_y = [&]() {
@@ -393,6 +428,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     };
     load_y();
 
+#endif
     // staging of the walk: buffer loads -- the chunk's position is a scalar offset, the thread's place in it a constant vector
     // offset (no address arithmetic on the vector pipe), and rows past the end of the cloud read as zeros (range check of the
     // buffer descriptor) instead of being clamped: their x_j is +inf below, so they never pass the test.  Thread t moves the two
@@ -416,6 +452,18 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         // x_j = n1[j]/2 ; +inf masks columns past the end of the cloud or of the strip
         if (tid < CH * 32) *reinterpret_cast<float *>(&lds[buf * BUF + XOFF + tid * 4]) = stage_ok ? 0.5f * stage_n : LR_INF;
     };
+#if LR_PB_M16
+    // per-lane byte offsets of the fragment / x_j of tile 0 of the current and the other buffer; tile k adds a constant.  The lane
+    // reads piece kb of columns c and 16 + c of the tile, and their x_j
+    const int frag16 = c16 * LR_LDS_ROW + 16 * kb, x_lane = XOFF + c16 * 4;
+    int fo_cur = frag16, fo_oth = frag16 + BUF, xo_cur = x_lane, xo_oth = x_lane + BUF;
+    auto read_b = [&](int fo, int xo, int k, f16x8 &b0, f16x8 &b1, f32x2 &xj) {
+        b0 = *reinterpret_cast<const f16x8 *>(&lds[fo + k * 32 * LR_LDS_ROW]);
+        b1 = *reinterpret_cast<const f16x8 *>(&lds[fo + k * 32 * LR_LDS_ROW + 16 * LR_LDS_ROW]);
+        xj.x = *reinterpret_cast<const float *>(&lds[xo + k * 32 * 4]);
+        xj.y = *reinterpret_cast<const float *>(&lds[xo + k * 32 * 4 + 64]);
+    };
+#else
     // per-lane byte offsets of the fragment / x_j of tile 0 of the current and the other buffer; tile k adds a constant
     const int x_lane = XOFF + r * 4;
     int fo_cur = frag_lane, fo_oth = frag_lane + BUF, xo_cur = x_lane, xo_oth = x_lane + BUF;
@@ -425,6 +473,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         xj = *reinterpret_cast<const float *>(&lds[xo + k * 32 * 4]);
     };
 
+#endif
     int wcnt = 0;            // entries in this wave's list (wave-uniform: lives in a scalar register)
     int wdone = 0;           // ... of which the tightening has seen this many
     // The wave owns one segment of the candidate store: seg[(row block, wave, strip)][seg_cap] entries { column, code | mask }
@@ -446,9 +495,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
                 const uint2 v = wlist[wave][e];
                 const unsigned mask = v.y & 0xffu;
                 if ((mask & (mask - 1u)) == 0u && !(v.y >> 31)) {       // exactly one register (the mask of a hit is never empty)
-                    const int code = (int)(v.y >> 8) & 0xf;
-                    const int g = 8 * ((code >> 1) & 1) + 7 - __builtin_ctz(mask);
-                    const int rl = wave * 64 + 32 * (code >> 2) + (g & 3) + 8 * (g >> 2) + 4 * (code & 1);
+                    const int rl = wave * 64 + lr_pb_row((int)(v.y >> 8) & 0xf, 7 - __builtin_ctz(mask));
                     // the register held y_row + dot16 and h = register - x_j, so g = dot16 - x_j = h - y_row (the y of now: entries
                     // made before the last reload have been seen by the round that did it, the tile in between is flagged stale)
                     const float gv = whval[wave][e] - s_Y[rl];
@@ -487,9 +534,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
                     // in is dropped here; what stays carries g rounded UP to 16 bits for the same test against the final threshold
                     const float gv = whval[wave][min(e, LR_PB_WLIST - 1)];
                     const unsigned mask = v.y & 0xffu;
-                    const int code = (int)(v.y >> 8) & 0xf;
-                    const int g = 8 * ((code >> 1) & 1) + 7 - __builtin_ctz(mask | 0x100u);
-                    const int rl = wave * 64 + 32 * (code >> 2) + (g & 3) + 8 * (g >> 2) + 4 * (code & 1);
+                    const int rl = wave * 64 + lr_pb_row((int)(v.y >> 8) & 0xf, 7 - __builtin_ctz((mask & 0xffu) | 0x80u));
                     const float yr = s_Y[rl];
                     if (gv + 1e-5f * (fabsf(gv) + fabsf(yr)) < -yr) keep = false;
                     const unsigned gb = __float_as_uint(gv);
@@ -506,6 +551,78 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         }
         wcnt = 0; wdone = 0;
     };
+#if LR_PB_M16
+    // candidate test of 8 accumulator registers: row blocks 2q, 2q + 1 (32 rows) x column block cb (16 columns) of the wave's tile
+    auto check = [&](const f32x4 &lo4, const f32x4 &hi4, float x, int col, int q, unsigned stale) {
+#if LR_PB_EXP & 2
+        if (q == 0) asm volatile("" :: "v"(lo4), "v"(hi4));
+        return;
+#endif
+        float m;
+        asm("v_max3_f32 %0, %1, %2, %3\n\tv_max3_f32 %0, %0, %4, %5\n\tv_max3_f32 %0, %0, %6, %7\n\tv_max_f32 %0, %0, %8"
+            : "=&v"(m)
+            : "v"(lo4[0]), "v"(lo4[1]), "v"(lo4[2]), "v"(lo4[3]), "v"(hi4[0]), "v"(hi4[1]), "v"(hi4[2]), "v"(hi4[3]));
+        const unsigned long long hit = __builtin_amdgcn_ballot_w64(m >= x);
+        if (__builtin_expect(hit != 0ull, 0)) {       // rare: keeps the common path a fall-through
+            if (m >= x) {
+                // which of the 8 registers: the sign of (acc - x) is shifted into the mask register by register (2 VALU ops
+                // each, no SGPR round trip).  Register i ends up in bit 7 - i; a set bit means acc < x.  A NaN accumulator
+                // (non-finite f16 operands) may read as a hit: rows with such operands are re-done by the exact full-row
+                // scan (nn16_exact_kernel tests the query row), columns only add candidates that the exact stage orders.
+                unsigned below = 0;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) below = __builtin_amdgcn_alignbit(below, __float_as_uint(lo4[g] - x), 31);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) below = __builtin_amdgcn_alignbit(below, __float_as_uint(hi4[g] - x), 31);
+                const unsigned mask = ~below & 0xffu;
+                const int pos = wcnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(hit >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hit, 0u));
+                if (pos < LR_PB_WLIST) {
+                    wlist[wave][pos] = make_uint2((unsigned)col, mask | (unsigned)((q * 4 + kb) << 8) | (stale << 31));
+                    whval[wave][pos] = m - x;
+                }
+            }
+            wcnt += __builtin_popcountll(hit);
+        }
+    };
+
+    f16x8 b0, b1;
+    f32x2 xN = { LR_INF, LR_INF }, xC = { LR_INF, LR_INF };
+    f32x4 accA[4][2], accB[4][2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { accA[q][cb][g] = -LR_INF; accB[q][cb][g] = -LR_INF; }
+
+    // one pipeline step: MFMAs of tile (c, k) into accN, tests of the previous tile in accC, LDS read of the next tile
+    auto step = [&](int c, int k, f32x4 (&accN)[4][2], const f32x4 (&accC)[4][2], unsigned stale) {
+        f16x8 n0, n1; f32x2 nx;
+        if (k + 1 < CH) read_b(fo_cur, xo_cur, k + 1, n0, n1, nx);
+        else read_b(fo_oth, xo_oth, 0, n0, n1, nx);
+        const int colC = (t_begin + c * CH + k - 1) * 32 + c16;
+        accN[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[0], b0, y4[0], 0, 0, 0);
+        accN[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[1], b0, y4[1], 0, 0, 0);
+        check(accC[0][0], accC[1][0], xC.x, colC, 0, stale);
+        accN[2][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[2], b0, y4[2], 0, 0, 0);
+        accN[3][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[3], b0, y4[3], 0, 0, 0);
+        check(accC[2][0], accC[3][0], xC.x, colC, 1, stale);
+        accN[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[0], b1, y4[0], 0, 0, 0);
+        accN[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[1], b1, y4[1], 0, 0, 0);
+        check(accC[0][1], accC[1][1], xC.y, colC + 16, 0, stale);
+        accN[2][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[2], b1, y4[2], 0, 0, 0);
+        accN[3][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[3], b1, y4[3], 0, 0, 0);
+        check(accC[2][1], accC[3][1], xC.y, colC + 16, 1, stale);
+        b0 = n0; b1 = n1; xC = xN; xN = nx;
+    };
+    auto drain = [&](unsigned stale) {
+        const int colC = (t_begin + nchunks * CH - 1) * 32 + c16;
+        check(accB[0][0], accB[1][0], xC.x, colC, 0, stale);
+        check(accB[2][0], accB[3][0], xC.x, colC, 1, stale);
+        check(accB[0][1], accB[1][1], xC.y, colC + 16, 0, stale);
+        check(accB[2][1], accB[3][1], xC.y, colC + 16, 1, stale);
+    };
+#else
     // candidate test of 8 accumulator registers (16 rows x 32 columns of the wave's tile)
     auto check = [&](const f32x16 &acc, int g0, float x, int tile, int rb, unsigned stale) {
 #if LR_PB_EXP & 2
@@ -563,6 +680,14 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         b0 = n0; b1 = n1; xC = xN; xN = nx;
     };
 
+    auto drain = [&](unsigned stale) {
+        const int tileC = t_begin + nchunks * CH - 1;
+        check(accB[0], 0, xC, tileC, 0, stale);
+        check(accB[0], 8, xC, tileC, 0, stale);
+        check(accB[1], 0, xC, tileC, 1, stale);
+        check(accB[1], 8, xC, tileC, 1, stale);
+    };
+#endif
     unsigned stale = 0u;     // 1: the accumulators awaiting their test were started from thresholds that have been reloaded since
     if (nchunks > 0) {
         load_chunk(0); store_chunk(0);
@@ -607,11 +732,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         // MFMAs behind its producer; here an explicit wait covers the 8-pass MFMA write latency.
         {
             asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-            const int tileC = t_begin + nchunks * CH - 1;
-            check(accB[0], 0, xC, tileC, 0, stale);
-            check(accB[0], 8, xC, tileC, 0, stale);
-            check(accB[1], 0, xC, tileC, 1, stale);
-            check(accB[1], 8, xC, tileC, 1, stale);
+            drain(stale);
         }
         flush();           // (with a last tightening round: the entries get their g, the rows their final thresholds)
     }
@@ -742,9 +863,7 @@ nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, in
                 const uint2 v = segs[(size_t)sidx * seg_cap + e];
                 const int j = (int)v.x;
                 if (v.y & LR_PB_HASG) {       // (single-row entry with its g, rounded up to 16 bits)
-                    const int code = (int)(v.y >> 8) & 0xf;
-                    const int g = 8 * ((code >> 1) & 1) + 7 - __builtin_ctz((v.y & 0xffu) | 0x100u);
-                    const int rl = 32 * (code >> 2) + 4 * (code & 1) + (g & 3) + 8 * (g >> 2);
+                    const int rl = lr_pb_row((int)(v.y >> 8) & 0xf, 7 - __builtin_ctz((v.y & 0xffu) | 0x80u));
                     const float gv = __uint_as_float((v.y >> 15) << 16), yr = s_yf[rl];
                     if (gv + 1e-5f * (fabsf(gv) + fabsf(yr)) < -yr) continue;
                 }
@@ -754,13 +873,11 @@ nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, in
                 for (int k = 0; k < 8; ++k) t[k] = pb[k];
                 const float ncj = nC[j];
                 const int code = (int)(v.y >> 8) & 0xf;
-                const int rbase = 32 * (code >> 2) + 4 * (code & 1), g0 = 8 * ((code >> 1) & 1);
                 unsigned m = v.y & 0xffu;
                 while (m) {
                     const int bit = __builtin_ctz(m);
                     m &= m - 1;
-                    const int g = g0 + 7 - bit;
-                    const int rl = rbase + (g & 3) + 8 * (g >> 2);
+                    const int rl = lr_pb_row(code, 7 - bit);
                     ex_offer(&s_best[rl], &s_second[rl], dist(rl, t, ncj), j);
                     atomicAdd(&s_cnt[rl], 1);
                 }

@@ -439,20 +439,23 @@ ransac_score_kernel(const float *__restrict__ corr8, const float *__restrict__ c
     const int W = gx * 4, w0 = bxi * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     if (HEAD) {
         if (K0 == 0) return;
-        for (int g = w0; g < hb; g += W) {
+        // work item = (group of 64 models, quarter of the head): the head is short, so a group per wave would leave three waves in four
+        // idle; the pilot is elected on the first quarter's counts alone (any model is a valid pilot, see above)
+        constexpr int HQ = 4, QL = LR_SC_HEAD / HQ;
+        for (int w = w0; w < hb * HQ; w += W) {
+            const int g = w % hb, qi = w / hb;
             const int slot = g * 64 + lane;
             const bool active = slot < V;
             const lr_model12 M = lr_load_model(models + (active ? slot : 0), ms);
             uint32_t cnt = 0; unsigned long long ssq = 0;
-            lr_score_stream(corr8, 0, K0, sub, thr2, M, cnt, ssq);
-            unsigned long long key = 0ull;
-            if (active) {
-                if (cnt) { atomicAdd(&score_cnt[slot], cnt); atomicAdd(&score_ssq[slot], ssq); }
-                key = ((unsigned long long)cnt << 32) | (unsigned long long)(0xffffffffu - (uint32_t)slot);
-            }
+            lr_score_stream(corr8, qi * QL, (qi + 1) * QL, sub, thr2, M, cnt, ssq);
+            if (active && cnt) { atomicAdd(&score_cnt[slot], cnt); atomicAdd(&score_ssq[slot], ssq); }
+            if (qi == 0) {
+                unsigned long long key = active ? ((unsigned long long)cnt << 32) | (unsigned long long)(0xffffffffu - (uint32_t)slot) : 0ull;
 #pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) { const unsigned long long k2 = __shfl_xor(key, o); key = k2 > key ? k2 : key; }
-            if (lane == 0) atomicMax(&info->pilot_key, key);
+                for (int o = 32; o >= 1; o >>= 1) { const unsigned long long k2 = __shfl_xor(key, o); key = k2 > key ? k2 : key; }
+                if (lane == 0) atomicMax(&info->pilot_key, key);
+            }
         }
         return;
     }
