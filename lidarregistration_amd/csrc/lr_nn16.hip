@@ -147,7 +147,12 @@ nn16_prep_kernel(const float *__restrict__ Fa, int na, _Float16 *__restrict__ Ha
 // which is what lets the sample be small.  (The test of a tile lags one tile behind its MFMAs: hits of the one tile whose
 // accumulators were started with the thresholds of before a reload are flagged and not used for tightening.)
 #define LR_CH 4
-#define LR_LDS_ROW 80
+#define LR_LDS_ROW 64
+// byte offset of 16-byte piece p (K 8p..8p+7) of staged column j of a chunk: rows of 64 bytes, the piece index XOR-swizzled with bits
+// 1..2 of the column.  ds_read_b128 is served in four fixed groups of 16 lanes ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ...); with
+// the walk's lane map (column = lane % 16, piece = lane / 16) every group then reads 16 different 16-byte slots of the 256-byte bank
+// row -- conflict-free (unswizzled 64- or 80-byte rows: 2-way).  The sample phase's reads (column = lane % 32) are 2-way.
+__device__ __forceinline__ int lr_lds_off(int j, int p) { return j * LR_LDS_ROW + ((p ^ ((j >> 1) & 3)) << 4); }
 #define LR_RB 2                  // 32-row MFMA blocks per wave (rows per wave = 64, rows per block = 256)
 #define LR_BLOCK_ROWS (128 * LR_RB)
 #ifndef LR_PB_CH
@@ -162,18 +167,10 @@ nn16_prep_kernel(const float *__restrict__ Fa, int na, _Float16 *__restrict__ Ha
 #define LR_PB_TIGHTEN 48         // new entries of a wave that trigger a tightening round
 #endif
 
-#ifndef LR_PB_M16
-#define LR_PB_M16 1              // walk on v_mfma_f32_16x16x32_f16 (1) or 32x32x16 (0)
-#endif
 // row (0..63 of the wave) of register i (0..7: mask bit 7 - i) of an entry with the given code
 __device__ __forceinline__ int lr_pb_row(int code, int i)
 {
-#if LR_PB_M16
     return 32 * (code >> 2) + 16 * (i >> 2) + 4 * (code & 3) + (i & 3);       // code = (row-block pair q) * 4 + (lane / 16)
-#else
-    const int g = 8 * ((code >> 1) & 1) + i;                                  // code = rb * 4 + (g0 / 8) * 2 + h
-    return 32 * (code >> 2) + (g & 3) + 8 * (g >> 2) + 4 * (code & 1);
-#endif
 }
 
 #define LR_RS_BUCKETS 4096
@@ -197,6 +194,9 @@ struct lr_thr_in {
 // grid shape of a 1-D XCD-aware launch + direction (0: rows = cloud 0, columns = cloud 1; 1: the reverse pass)
 struct lr_pb_grid { int gx, gy, total, dir; };
 
+#if LR_PB_EXP & 8
+__device__ unsigned long long lr_pb_clk[4096 * 2];      // development probe: shader clocks / 100 MHz ticks a block spent
+#endif
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *__restrict__ rowmap, const int32_t *__restrict__ na_dev,
                   const _Float16 *__restrict__ Hc, const float *__restrict__ nC, int nb,
@@ -209,6 +209,9 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     // (strip, pair), i.e. they stream the same columns through that XCD's L2
     int logical;
     if (!lr_xcd_block(pg.total, logical)) return;
+#if LR_PB_EXP & 8
+    const unsigned long long clk0 = __builtin_readcyclecounter(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int bx = logical % pg.gx, by = (logical / pg.gx) % pg.gy, pair = logical / (pg.gx * pg.gy);
     if (z.descs) {
         const lr_pair_desc d = z.descs[pair];
@@ -276,7 +279,6 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     float stage_n = 0.0f;        // raw norm of the staged column: NOT touched until store_chunk, so that the compiler's
                                  // s_waitcnt for it lands after the tile loop instead of right behind the prefetch
     bool stage_ok = false;
-    const int frag_lane = r * LR_LDS_ROW + 32 * h;
 
     // ---------------------------------------------------------------- thresholds of the block's 256 rows -> LDS
     // given (reverse direction), or made here by phase 1: U = need-th smallest sampled u' = -2 * (need-th largest g);
@@ -320,7 +322,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
 #pragma unroll
                 for (int q = 0; q < CH / 2; ++q) {
                     const int p = tid + 256 * q;
-                    *reinterpret_cast<f32x4 *>(&lds[buf * BUF + (p >> 2) * LR_LDS_ROW + (p & 3) * 16]) = stage[q];
+                    *reinterpret_cast<f32x4 *>(&lds[buf * BUF + lr_lds_off(p >> 2, p & 3)]) = stage[q];
                 }
                 // largest x_j = n1[j]/2 of every tile of the chunk: the threads tid < CH*32 hold one column each, 32 per tile
                 float xm = 0.5f * stage_n;
@@ -354,8 +356,8 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
 #pragma unroll
                     for (int k = 0; k < CH; ++k) {
                         // fragment of tile k (lane = column r, K half h); accumulator register g <-> column (g&3) + 8 (g>>2) + 4 h of the tile
-                        const unsigned char *bp = &lds[buf * BUF + frag_lane + k * 32 * LR_LDS_ROW];
-                        const f16x8 b0 = *reinterpret_cast<const f16x8 *>(bp), b1 = *reinterpret_cast<const f16x8 *>(bp + 16);
+                        const unsigned char *bp = &lds[buf * BUF + k * 32 * LR_LDS_ROW];
+                        const f16x8 b0 = *reinterpret_cast<const f16x8 *>(bp + lr_lds_off(r, 2 * h)), b1 = *reinterpret_cast<const f16x8 *>(bp + lr_lds_off(r, 2 * h + 1));
                         const float xmax = *reinterpret_cast<const float *>(&lds[buf * BUF + XOFF + k * 4]);
                         f32x16 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0, a[0][0], zero16, 0, 0, 0);
                         f32x16 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0, a[1][0], zero16, 0, 0, 0);
@@ -395,7 +397,6 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         __syncthreads();
     }
 
-#if LR_PB_M16
     // The walk runs on v_mfma_f32_16x16x32_f16 (all 32 K in one instruction; under the board's power limit it sustains ~20 % more
     // flops than 32x32x16, tools/mfma_clock.hip): lane (c, kb) = (lane % 16, lane / 16) supplies K bytes 16 kb.. of row / column c of
     // a 16-block and receives rows 4 kb + 0..3, column c of the 16 x 16 result.  Row fragments of the wave's four 16-row blocks:
@@ -414,21 +415,6 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         for (int rbk = 0; rbk < 4; ++rbk) y4[rbk] = *reinterpret_cast<const f32x4 *>(&s_Y[wave * 64 + 16 * rbk + 4 * kb]);
     };
     load_y();
-#else
-    f32x16 y[2];
-    // the lane's 16 + 16 threshold registers: register g of row block rb <-> row 32 rb + (g&3) + 8 (g>>2) + 4 h of the wave
-    auto load_y = [&]() {
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(&s_Y[wave * 64 + 32 * rb + 8 * q + 4 * h]);
-                y[rb][4 * q] = v.x; y[rb][4 * q + 1] = v.y; y[rb][4 * q + 2] = v.z; y[rb][4 * q + 3] = v.w;
-            }
-    };
-    load_y();
-
-#endif
     // staging of the walk: buffer loads -- the chunk's position is a scalar offset, the thread's place in it a constant vector
     // offset (no address arithmetic on the vector pipe), and rows past the end of the cloud read as zeros (range check of the
     // buffer descriptor) instead of being clamped: their x_j is +inf below, so they never pass the test.  Thread t moves the two
@@ -437,7 +423,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     const __amdgpu_buffer_rsrc_t rsrcH = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(Hc), 0, nb * 64, 0x27000);
     const __amdgpu_buffer_rsrc_t rsrcN = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(nC), 0, nb * 4, 0x27000);
     const int st_voff = tid * 32, st_noff = (tid & (CH * 32 - 1)) * 4;
-    const int st_lds = (tid >> 1) * LR_LDS_ROW + (tid & 1) * 32;
+    const int st_lds0 = lr_lds_off(tid >> 1, 2 * (tid & 1)), st_lds1 = lr_lds_off(tid >> 1, 2 * (tid & 1) + 1);
     auto load_chunk = [&](int c) {
         const int col0 = (t_begin + c * CH) * 32;       // wave-uniform
         stage[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcH, st_voff, col0 * 64, 0));
@@ -447,15 +433,14 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         stage_ok = col < nb && (col >> 5) < t_end;
     };
     auto store_chunk = [&](int buf) {
-        *reinterpret_cast<f32x4 *>(&lds[buf * BUF + st_lds]) = stage[0];
-        *reinterpret_cast<f32x4 *>(&lds[buf * BUF + st_lds + 16]) = stage[1];
+        *reinterpret_cast<f32x4 *>(&lds[buf * BUF + st_lds0]) = stage[0];
+        *reinterpret_cast<f32x4 *>(&lds[buf * BUF + st_lds1]) = stage[1];
         // x_j = n1[j]/2 ; +inf masks columns past the end of the cloud or of the strip
         if (tid < CH * 32) *reinterpret_cast<float *>(&lds[buf * BUF + XOFF + tid * 4]) = stage_ok ? 0.5f * stage_n : LR_INF;
     };
-#if LR_PB_M16
     // per-lane byte offsets of the fragment / x_j of tile 0 of the current and the other buffer; tile k adds a constant.  The lane
     // reads piece kb of columns c and 16 + c of the tile, and their x_j
-    const int frag16 = c16 * LR_LDS_ROW + 16 * kb, x_lane = XOFF + c16 * 4;
+    const int frag16 = lr_lds_off(c16, kb), x_lane = XOFF + c16 * 4;
     int fo_cur = frag16, fo_oth = frag16 + BUF, xo_cur = x_lane, xo_oth = x_lane + BUF;
     auto read_b = [&](int fo, int xo, int k, f16x8 &b0, f16x8 &b1, f32x2 &xj) {
         b0 = *reinterpret_cast<const f16x8 *>(&lds[fo + k * 32 * LR_LDS_ROW]);
@@ -463,17 +448,6 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         xj.x = *reinterpret_cast<const float *>(&lds[xo + k * 32 * 4]);
         xj.y = *reinterpret_cast<const float *>(&lds[xo + k * 32 * 4 + 64]);
     };
-#else
-    // per-lane byte offsets of the fragment / x_j of tile 0 of the current and the other buffer; tile k adds a constant
-    const int x_lane = XOFF + r * 4;
-    int fo_cur = frag_lane, fo_oth = frag_lane + BUF, xo_cur = x_lane, xo_oth = x_lane + BUF;
-    auto read_b = [&](int fo, int xo, int k, f16x8 &b0, f16x8 &b1, float &xj) {
-        b0 = *reinterpret_cast<const f16x8 *>(&lds[fo + k * 32 * LR_LDS_ROW]);
-        b1 = *reinterpret_cast<const f16x8 *>(&lds[fo + k * 32 * LR_LDS_ROW + 16]);
-        xj = *reinterpret_cast<const float *>(&lds[xo + k * 32 * 4]);
-    };
-
-#endif
     int wcnt = 0;            // entries in this wave's list (wave-uniform: lives in a scalar register)
     int wdone = 0;           // ... of which the tightening has seen this many
     // The wave owns one segment of the candidate store: seg[(row block, wave, strip)][seg_cap] entries { column, code | mask }
@@ -551,11 +525,10 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         }
         wcnt = 0; wdone = 0;
     };
-#if LR_PB_M16
     // candidate test of 8 accumulator registers: row blocks 2q, 2q + 1 (32 rows) x column block cb (16 columns) of the wave's tile
     auto check = [&](const f32x4 &lo4, const f32x4 &hi4, float x, int col, int q, unsigned stale) {
 #if LR_PB_EXP & 2
-        if (q == 0) asm volatile("" :: "v"(lo4), "v"(hi4));
+        asm volatile("" :: "v"(lo4), "v"(hi4));
         return;
 #endif
         float m;
@@ -622,72 +595,6 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         check(accB[0][1], accB[1][1], xC.y, colC + 16, 0, stale);
         check(accB[2][1], accB[3][1], xC.y, colC + 16, 1, stale);
     };
-#else
-    // candidate test of 8 accumulator registers (16 rows x 32 columns of the wave's tile)
-    auto check = [&](const f32x16 &acc, int g0, float x, int tile, int rb, unsigned stale) {
-#if LR_PB_EXP & 2
-        if (g0 == 0) asm volatile("" :: "v"(acc));
-        return;
-#endif
-        float m;
-        asm("v_max3_f32 %0, %1, %2, %3\n\tv_max3_f32 %0, %0, %4, %5\n\tv_max3_f32 %0, %0, %6, %7\n\tv_max_f32 %0, %0, %8"
-            : "=&v"(m)
-            : "v"(acc[g0]), "v"(acc[g0 + 1]), "v"(acc[g0 + 2]), "v"(acc[g0 + 3]), "v"(acc[g0 + 4]), "v"(acc[g0 + 5]), "v"(acc[g0 + 6]),
-              "v"(acc[g0 + 7]));
-        const unsigned long long hit = __builtin_amdgcn_ballot_w64(m >= x);
-        if (__builtin_expect(hit != 0ull, 0)) {       // rare: keeps the common path a fall-through
-            if (m >= x) {
-                // which of the 8 registers: the sign of (acc - x) is shifted into the mask register by register (2 VALU ops
-                // each, no SGPR round trip).  Register g0 + g ends up in bit 7 - g; a set bit means acc < x.  A NaN accumulator
-                // (non-finite f16 operands) may read as a hit: rows with such operands are re-done by the exact full-row
-                // scan (nn16_exact_kernel tests the query row), columns only add candidates that the exact stage orders.
-                unsigned below = 0;
-#pragma unroll
-                for (int g = 0; g < 8; ++g) below = __builtin_amdgcn_alignbit(below, __float_as_uint(acc[g0 + g] - x), 31);
-                const unsigned mask = ~below & 0xffu;
-                const int pos = wcnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(hit >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hit, 0u));
-                if (pos < LR_PB_WLIST) {
-                    wlist[wave][pos] = make_uint2((unsigned)(tile * 32 + r), mask | (unsigned)((rb * 4 + (g0 >> 3) * 2 + h) << 8) | (stale << 31));
-                    whval[wave][pos] = m - x;
-                }
-            }
-            wcnt += __builtin_popcountll(hit);
-        }
-    };
-
-    f16x8 b0, b1;
-    float xN = LR_INF, xC = LR_INF;
-    f32x16 accA[2], accB[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int g = 0; g < 16; ++g) { accA[q][g] = -LR_INF; accB[q][g] = -LR_INF; }
-
-    // one pipeline step: MFMAs of tile (c, k) into accN, tests of the previous tile in accC, LDS read of the next tile
-    auto step = [&](int c, int k, f32x16 (&accN)[2], const f32x16 (&accC)[2], unsigned stale) {
-        f16x8 n0, n1; float nx;
-        if (k + 1 < CH) read_b(fo_cur, xo_cur, k + 1, n0, n1, nx);
-        else read_b(fo_oth, xo_oth, 0, n0, n1, nx);
-        const int tileC = t_begin + c * CH + k - 1;
-        accN[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][0], b0, y[0], 0, 0, 0);
-        check(accC[0], 0, xC, tileC, 0, stale);
-        accN[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][0], b0, y[1], 0, 0, 0);
-        check(accC[0], 8, xC, tileC, 0, stale);
-        accN[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][1], b1, accN[0], 0, 0, 0);
-        check(accC[1], 0, xC, tileC, 1, stale);
-        accN[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][1], b1, accN[1], 0, 0, 0);
-        check(accC[1], 8, xC, tileC, 1, stale);
-        b0 = n0; b1 = n1; xC = xN; xN = nx;
-    };
-
-    auto drain = [&](unsigned stale) {
-        const int tileC = t_begin + nchunks * CH - 1;
-        check(accB[0], 0, xC, tileC, 0, stale);
-        check(accB[0], 8, xC, tileC, 0, stale);
-        check(accB[1], 0, xC, tileC, 1, stale);
-        check(accB[1], 8, xC, tileC, 1, stale);
-    };
-#endif
     unsigned stale = 0u;     // 1: the accumulators awaiting their test were started from thresholds that have been reloaded since
     if (nchunks > 0) {
         load_chunk(0); store_chunk(0);
@@ -741,6 +648,9 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         cw[by] = seg_fill;                     // entries in this wave's segment (< 0: overflow)
         if (by == 0) cw[pg.gy] = my_strips;    // how the wave's store is divided (read by nn16_exact_kernel)
     }
+#if LR_PB_EXP & 8
+    if (threadIdx.x == 0 && logical < 4096) { lr_pb_clk[2 * logical] = __builtin_readcyclecounter() - clk0; lr_pb_clk[2 * logical + 1] = __builtin_amdgcn_s_memrealtime() - rt0; }
+#endif
     // the rows' final thresholds (wave-local: every wave writes its own 64 rows): nn16_exact_kernel drops the entries they exclude
     if (yfin) {
         const int rw = row0 + lane;

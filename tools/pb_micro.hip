@@ -3,6 +3,7 @@
 //   usage: pb_micro [n=30000] [P=32] [strips=1]
 #include "../lidarregistration_amd/csrc/lr_nn16.hip"
 #include <vector>
+#include <algorithm>
 #include <random>
 void lr_set_error(const char *, ...) {}
 template <class F> float timeit(F f, int reps = 8) {
@@ -57,6 +58,13 @@ int main(int argc, char **argv)
         float msp = timeit([&] { hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), 0, 0, H, n, (const int32_t*)nullptr, (const int32_t*)nullptr, H, nrm, n, tps, (const float*)tau, cnt, cand,
                                                     (const int32_t*)nullptr, (const float*)nullptr, (const uint32_t*)nullptr, (const int32_t*)nullptr, (const uint32_t*)nullptr, (float*)nullptr, 0, lr_thr_in{}, lr_pb_grid{ row_blocks, strips, total, 0 }, z); });
         printf("walk only, no candidates:       %8.3f ms  = %6.1f us/pair\n", msp, msp * 1e3 / P);
+#if LR_PB_EXP & 8
+        std::vector<unsigned long long> ck(8192); hipMemcpyFromSymbol(ck.data(), HIP_SYMBOL(lr_pb_clk), 65536);
+        std::vector<double> mhz, us;
+        for (int i = 0; i < 4096 && i < total; ++i) if (ck[2 * i + 1] > 100) { mhz.push_back((double)ck[2 * i] / ck[2 * i + 1] * 100.0); us.push_back(ck[2 * i + 1] / 100.0); }
+        std::sort(mhz.begin(), mhz.end()); std::sort(us.begin(), us.end());
+        if (!mhz.empty()) printf("  shader clock while a block runs: median %.0f MHz (p10 %.0f, p90 %.0f); block lifetime median %.1f us\n", mhz[mhz.size() / 2], mhz[mhz.size() / 10], mhz[mhz.size() * 9 / 10], us[us.size() / 2]);
+#endif
     }
     return 0;
 }
