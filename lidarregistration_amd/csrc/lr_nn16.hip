@@ -1,17 +1,17 @@
 // Fast exact nearest / second-nearest neighbour search: f16 matrix-core filter + exact fp32 verification.
 //
-// Same contract as lr_nn.hip (reference Experiments/algorithms/matching.py:22-65; arithmetic of oracle/oracle.c):
-// the RESULT is bit-identical to the fp32 fma-chain definition.  What changes is how the N0 x N1 candidates are
-// pruned.  On gfx950 the fp32-input MFMA runs at the fp32 VALU rate and (measured, profiles/) does not overlap
-// with VALU work, so the fp32 kernel pays 1024 + ~800 cycles per 32x32 tile.  Here:
+// Contract: reference Experiments/algorithms/matching.py:22-65 with the arithmetic of oracle/oracle.c -- the RESULT is
+// bit-identical to the fp32 fma-chain definition.  What is free is how the N0 x N1 candidates are pruned.  On gfx950 the
+// fp32-input MFMA runs at the fp32 VALU rate (round 1, profiles/r01a_*: 1024 + ~800 cycles per 32x32 tile), so the pruning
+// runs in f16:
 //
-//   pass A  f16 MFMA (32x32x16, the real matrix pipe) over every `stride`-th column tile; per query row the
-//           2nd smallest (1st for top-1) approximate value u' = n1[j] - 2 dot16(i,j) of that subset: U_i
+//   sample  f16 MFMA (v_mfma_f32_16x16x32_f16, the real matrix pipe) over every `sstride`-th column tile; per query row
+//           the 2nd smallest (1st for top-1) approximate value u' = n1[j] - 2 dot16(i,j) of that subset: U_i
 //   thresh  tau_i = U_i + 2 E_i (+ a sqrt-rounding band), E_i a rigorous bound on |d2_exact - (n0_i + u')|
-//           (computed in pass B's prologue for the block's own rows)
-//   pass B  f16 MFMA over ALL column tiles; a column is a candidate of row i iff u' <= tau_i.  The accumulator starts
+//   walk    f16 MFMA over ALL column tiles; a column is a candidate of row i iff u' <= tau_i.  The accumulator starts
 //           at tau_i/2, so the test is "largest of 8 accumulator registers >= n1[j]/2": 5 VALU ops per 512 elements,
-//           placed in the shadow of the next tile's MFMAs; candidates are ~3e-4 of the elements
+//           interleaved with the next tile's MFMAs; candidates are ~1e-4 of the elements; the thresholds tighten as the
+//           walk finds better neighbours (sample, thresholds and walk are ONE kernel, nn16_passb_kernel)
 //   reverse (mutual filter) thresholds from the forward result, rows / columns ordered by forward NN distance so that
 //           each row block walks only a prefix of the column tiles (lr_nn16_reverse)
 //   exact   per row, the fp32 fma-chain distance of its few candidates, ordered by (sqrt value, index) --
@@ -34,7 +34,6 @@
 #include <math.h>
 #include <stdlib.h>
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -45,7 +44,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // ------------------------------------------------------------------ prep: norms + f16 copy
 // Eight threads per row (coalesced 16-byte loads).  The norm is the sequential fp32 fma chain over k = 0..31 of the
 // arithmetic contract: thread t continues the chain over its four values from where thread t-1 stopped.
-// H[row] (64 B) = f16 of { k0..7, k16..23 | k8..15, k24..31 }: lane half h of an MFMA operand reads bytes [32h, 32h+32).
+// H[row] (64 B) = f16 of k0..31 in order: lane group kb of an MFMA operand reads bytes [16 kb, 16 kb + 16).
 __global__ void __launch_bounds__(256)
 nn16_prep_kernel(const float *__restrict__ Fa, int na, _Float16 *__restrict__ Ha, float *__restrict__ nrma, float *__restrict__ bmaxa,
                  const float *__restrict__ Fb, int nb, _Float16 *__restrict__ Hb, float *__restrict__ nrmb, float *__restrict__ bmaxb,
@@ -93,9 +92,7 @@ nn16_prep_kernel(const float *__restrict__ Fa, int na, _Float16 *__restrict__ Ha
             nrm[row] = norm;
             if (second && seed_b) { seed_b[row] = 0x7f7f7f7fu; seed64_b[row] = ~0ull; }      // "no query points at this row yet" (lr_nn16_reverse)
         }
-        // k = 4t..4t+3 sits in 8-element chunk c = t/2; chunks are stored in the order 0, 2, 1, 3
-        const int c = t >> 1;
-        const int pos = (c == 0 ? 0 : c == 1 ? 2 : c == 2 ? 1 : 3) * 8 + (t & 1) * 4;
+        const int pos = 4 * t;
         typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
         f16x4 hv = { (_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w };
         *reinterpret_cast<f16x4 *>(H + (size_t)row * 32 + pos) = hv;
@@ -113,48 +110,53 @@ nn16_prep_kernel(const float *__restrict__ Fa, int na, _Float16 *__restrict__ Ha
 // ------------------------------------------------------------------ filter pass: sample phase + candidate walk in one kernel
 // Block = 4 waves x 64 query rows = 256 rows of one column strip.  Column tiles (32 columns) are staged once per block through
 // LDS in chunks of LR_PB_CH tiles (register-staged, double-buffered, one barrier per chunk) and shared by the four waves.  LDS
-// image: one 80-byte row per column (64 B of f16 + 16 B pad): with that stride the two ds_read_b128 of a fragment are
-// bank-conflict-free for the b128 lane groups.
+// image: one 64-byte row per column, its four 16-byte pieces XOR-swizzled (lr_lds_off) so that the walk's ds_read_b128 are
+// bank-conflict-free for the instruction's lane groups.  Both phases use v_mfma_f32_16x16x32_f16: lane (c, kb) = (lane % 16,
+// lane / 16) supplies the 8 K values 8 kb.. of row / column c of a 16-block and receives rows 4 kb + 0..3 of column c.
 //
 // Phase 1 (forward direction; the reverse direction gets its thresholds from the forward result): the block walks every
 // `sstride`-th tile of its strip with the operand roles SWAPPED -- the column fragment is the MFMA's first operand, the query
-// rows the second, so a LANE holds one query row and its 16 accumulator registers are 16 different columns.  The accumulator
-// starts at zero and holds dot16 after the two MFMAs; the row's value of the tile is
-//     b = max_j dot16(i, j) - max_j n1[j]/2      (in-lane maximum tree: 7 v_max3 + 1 v_max per 16 values, one subtraction)
-// a LOWER bound of the tile's best g = dot16 - n1[j]/2, attained up to the spread of the column norms inside the tile (zero for
-// unit-norm descriptors such as FCGF's) -- no per-column operand is read.  Three more ops merge b into the running two largest
-// tile values of the row; they belong to different tiles, hence to different columns, so their second largest is a valid lower
-// bound of the row's 2nd largest g (u' = -2 g: an upper bound of the 2nd smallest u' -- any valid bound keeps the result exact, a
-// looser one only admits more candidates).  Round 2 ran this phase as a kernel of its own over every 4th tile (16 us per pair, 13 %
-// of the pair); here it shares the staging buffers and the row fragments with the walk, samples every 16th tile, and the thresholds
-// it yields are only the START of the walk:
+// rows the second, so a LANE holds one query row per 16-row block and its 4 + 4 accumulator registers of a tile are 8 different
+// columns.  The accumulator starts at zero and holds dot16; the lane's value of the tile is
+//     b = max_j dot16(i, j) - max_j n1[j]/2      (in-lane maximum tree over the 8 values, one subtraction)
+// a LOWER bound of the best g = dot16 - n1[j]/2 among those columns, attained up to the spread of the column norms inside the tile
+// (zero for unit-norm descriptors such as FCGF's) -- no per-column operand is read.  Three more ops merge b into the running two
+// largest values of the lane; they belong to different tiles, hence to different columns, and the four lanes that share a row see
+// disjoint columns, so the second largest after merging the four is a valid lower bound of the row's 2nd largest g (u' = -2 g: an
+// upper bound of the 2nd smallest u' -- any valid bound keeps the result exact, a looser one only admits more candidates).  Round 2
+// ran this phase as a kernel of its own over every 4th tile (16 us per pair, 13 % of the pair); here it shares the staging buffers
+// and the row fragments with the walk, samples every 16th tile (~3 us), and the thresholds it yields are only the START of the walk:
 //
 // Phase 2: f16 MFMA over ALL tiles of the strip, columns on the lanes.  The accumulator is started at y_i = tau_i / 2 instead of 0,
 // so the candidate test u' <= tau_i  <=>  dot16 + y_i >= n1[j]/2 needs no per-element arithmetic: the lane's largest of 8
-// accumulator registers is compared with x_j = n1[j]/2 once.  A 32x32x16 MFMA occupies the matrix pipe for 32 cycles but holds the
-// SIMD's vector issue for only 8 of them, so the candidate test of tile t-1 (3 v_max3 + 1 v_max + 1 v_cmp + 1 scalar branch per 8
-// accumulator registers) is placed in the shadow of the MFMAs of tile t: every test group follows one MFMA in program order and
-// its branch ends the basic block, so the compiler cannot pull the pieces apart again.  The column fragments of tile t+1 are read
-// from LDS one step ahead, which moves the chunk barrier one step forward.  Hits are parked in a wave-private LDS list whose fill
-// count lives in a scalar register: no atomics and no LDS round trip in the loop.
+// accumulator registers (two 16-row blocks of one 16-column block) is compared with x_j = n1[j]/2 once -- 3 v_max3 + 1 v_max +
+// 1 v_cmp + 1 scalar branch per 8 registers.  There is ONE set of 32 accumulator registers: a group of 8 is tested (it holds the
+// previous tile) and then handed to the two MFMAs that overwrite it with the current tile, so every test reads its registers six
+// MFMAs after they were issued (the hardware does not interlock a vector read of an MFMA result) and its branch ends the basic
+// block, so the compiler cannot pull the pieces apart.  The vector ops of one wave run while the matrix pipe works on another's
+// MFMAs: measured on the idealised mix (tools/coissue_micro.hip: 8 MFMA + 20 v_max3 per iteration, 3 waves per SIMD) 79 ns per
+// tile and wave against 71-74 for the MFMAs alone and 41 for the vector ops alone; the walk takes 104 ns per tile and wave
+// (LDS reads, branches, staging, barrier), at a shader clock of 2.1 GHz -- the board's power limit, not the 2.4 GHz peak clock,
+// is what the kernel runs against, and a fourth wave per SIMD only lowers the clock (measured: 43.2 instead of 44.5 us per pair
+// without candidates, no gain with them).  The column fragments of tile t+1 are read from LDS one step ahead, which moves the chunk
+// barrier one step forward.  Hits are parked in a wave-private LDS list whose fill count lives in a scalar register: no atomics
+// and no LDS round trip in the loop.
 //
 // Thresholds tighten while the walk runs.  A hit entry also keeps h = (largest register) - x_j.  Whenever LR_PB_TIGHTEN new
 // entries have gathered, the wave goes through them ONE LANE PER ENTRY: an entry whose mask has a single bit names its row, and
 // g = h - y_row is that row's filter value of that column; the two largest g of every row (of the walk: distinct columns) are kept
-// in LDS with two float atomics per entry, y_row <- min(y_row, E_row - g2 + ...), and the lanes reload their 32 threshold
-// registers with 8 ds_read_b128.  All of it is wave-local (a wave owns its 64 rows for the whole strip) and costs ~60 instructions
+// in LDS with two float atomics per entry, y_row <- min(y_row, E_row - g2 + ...), and the lanes reload their 16 threshold
+// registers with 4 ds_read_b128.  All of it is wave-local (a wave owns its 64 rows for the whole strip) and costs ~60 instructions
 // per 48 hits.  The number of hits of a row then grows like 2 + 2 ln(tiles / sampled tiles) instead of 2 tiles / sampled tiles,
 // which is what lets the sample be small.  (The test of a tile lags one tile behind its MFMAs: hits of the one tile whose
 // accumulators were started with the thresholds of before a reload are flagged and not used for tightening.)
-#define LR_CH 4
 #define LR_LDS_ROW 64
 // byte offset of 16-byte piece p (K 8p..8p+7) of staged column j of a chunk: rows of 64 bytes, the piece index XOR-swizzled with bits
 // 1..2 of the column.  ds_read_b128 is served in four fixed groups of 16 lanes ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ...); with
 // the walk's lane map (column = lane % 16, piece = lane / 16) every group then reads 16 different 16-byte slots of the 256-byte bank
 // row -- conflict-free (unswizzled 64- or 80-byte rows: 2-way).  The sample phase's reads (column = lane % 32) are 2-way.
 __device__ __forceinline__ int lr_lds_off(int j, int p) { return j * LR_LDS_ROW + ((p ^ ((j >> 1) & 3)) << 4); }
-#define LR_RB 2                  // 32-row MFMA blocks per wave (rows per wave = 64, rows per block = 256)
-#define LR_BLOCK_ROWS (128 * LR_RB)
+#define LR_BLOCK_ROWS 256        // rows per block: 4 waves x 64 rows (four 16-row MFMA blocks per wave)
 #ifndef LR_PB_CH
 #define LR_PB_CH 4
 #endif
@@ -237,7 +239,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     __shared__ __attribute__((aligned(16))) float s_Y[LR_BLOCK_ROWS];
     __shared__ float s_D[LR_BLOCK_ROWS], s_N1[LR_BLOCK_ROWS], s_N2[LR_BLOCK_ROWS];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int r = lane & 31, h = lane >> 5;
+    const int c16 = lane & 15, kb = lane >> 4;
     const int row0 = bx * LR_BLOCK_ROWS + wave * 64;
     int ntiles = (nb + 31) >> 5;
     int my_strips = pg.gy;           // strips this row block really uses (the ordered reverse pass: as many as its column prefix is worth)
@@ -264,15 +266,16 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     const int t_end = min(ntiles, t_begin + tiles_per_strip);
     const int nchunks = t_end > t_begin ? (t_end - t_begin + CH - 1) / CH : 0;
 
-    // row fragments: lane (r, h) holds K half h of rows r and 32 + r of the wave -- the same registers serve as the MFMA's first
-    // operand (phase 2: rows x columns) and as its second (phase 1: columns x rows)
-    f16x8 a[2][2];
+    // Both phases run on v_mfma_f32_16x16x32_f16 (all 32 K in one instruction; under the board's power limit it sustains ~20 % more
+    // flops than 32x32x16, tools/mfma_clock.hip): lane (c, kb) = (lane % 16, lane / 16) supplies K bytes 16 kb.. of row / column c of
+    // a 16-block and receives rows 4 kb + 0..3, column c of the 16 x 16 result.  Row fragments of the wave's four 16-row blocks -- the
+    // same registers serve as the MFMA's first operand (phase 2: rows x columns) and as its second (phase 1: columns x rows):
+    f16x8 a16[4];
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
-        int row = min(row0 + 32 * rb + r, na - 1);
+    for (int rbk = 0; rbk < 4; ++rbk) {
+        int row = min(row0 + 16 * rbk + c16, na - 1);
         if (rowmap) row = rowmap[row];
-        const f16x8 *p = reinterpret_cast<const f16x8 *>(Hq + (size_t)row * 32 + 16 * h);
-        a[rb][0] = p[0]; a[rb][1] = p[1];
+        a16[rbk] = *reinterpret_cast<const f16x8 *>(Hq + (size_t)row * 32 + 8 * kb);
     }
 
     f32x4 stage[CH / 2];
@@ -330,23 +333,21 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
                 for (int k = 16; k >= 1; k >>= 1) xm = fmaxf(xm, __shfl_xor(xm, k));
                 if (tid < CH * 32 && (tid & 31) == 0) *reinterpret_cast<float *>(&lds[buf * BUF + XOFF + (tid >> 5) * 4]) = xm;
             };
-            float m1[2] = { -LR_INF, -LR_INF }, m2[2] = { -LR_INF, -LR_INF };     // running two largest tile maxima of the lane's row
+            float m1[4], m2[4];           // running two largest (lane, tile) maxima of the lane's four rows (one per 16-row block)
+#pragma unroll
+            for (int rbk = 0; rbk < 4; ++rbk) { m1[rbk] = -LR_INF; m2[rbk] = -LR_INF; }
             // plain fmaxf (not inline asm): the compiler must see these reads of the MFMA results to place the wait states
             // the hardware requires between an MFMA and a VALU read of its destination
-            auto fold = [&](const f32x16 &acc, int rb, float xmax) {
-                float t = fmaxf(fmaxf(acc[0], acc[1]), acc[2]);
-                float u = fmaxf(fmaxf(acc[3], acc[4]), acc[5]);
-                float v = fmaxf(fmaxf(acc[6], acc[7]), acc[8]);
-                float w = fmaxf(fmaxf(acc[9], acc[10]), acc[11]);
-                float zz = fmaxf(fmaxf(acc[12], acc[13]), acc[14]);
-                t = fmaxf(fmaxf(t, u), acc[15]);
-                v = fmaxf(fmaxf(v, w), zz);
-                t = fmaxf(t, v) - xmax;
-                const float lo = fminf(m1[rb], t);
-                m1[rb] = fmaxf(m1[rb], t);
-                m2[rb] = fmaxf(m2[rb], lo);
+            auto fold = [&](const f32x4 &lo4, const f32x4 &hi4, int rbk, float xmax) {
+                float t = fmaxf(fmaxf(lo4[0], lo4[1]), lo4[2]);
+                float u = fmaxf(fmaxf(lo4[3], hi4[0]), hi4[1]);
+                t = fmaxf(fmaxf(t, u), fmaxf(hi4[2], hi4[3])) - xmax;
+                const float lo = fminf(m1[rbk], t);
+                m1[rbk] = fmaxf(m1[rbk], t);
+                m2[rbk] = fmaxf(m2[rbk], lo);
             };
-            const f32x16 zero16 = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+            const f32x4 zero4 = { 0, 0, 0, 0 };
+            const int frag16s = lr_lds_off(c16, kb);
             if (nsch > 0) {
                 load_s(0); store_s(0);
                 __syncthreads();
@@ -355,37 +356,47 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
                     if (c + 1 < nsch) load_s(c + 1);
 #pragma unroll
                     for (int k = 0; k < CH; ++k) {
-                        // fragment of tile k (lane = column r, K half h); accumulator register g <-> column (g&3) + 8 (g>>2) + 4 h of the tile
-                        const unsigned char *bp = &lds[buf * BUF + k * 32 * LR_LDS_ROW];
-                        const f16x8 b0 = *reinterpret_cast<const f16x8 *>(bp + lr_lds_off(r, 2 * h)), b1 = *reinterpret_cast<const f16x8 *>(bp + lr_lds_off(r, 2 * h + 1));
+                        // fragments of tile k: lane (c, kb) reads piece kb of columns c and 16 + c; in the result the lane holds query row c
+                        // of a row block and registers g <-> columns 4 kb + g of the column block
+                        const unsigned char *bp = &lds[buf * BUF + frag16s + k * 32 * LR_LDS_ROW];
+                        const f16x8 b0 = *reinterpret_cast<const f16x8 *>(bp), b1 = *reinterpret_cast<const f16x8 *>(bp + 16 * LR_LDS_ROW);
                         const float xmax = *reinterpret_cast<const float *>(&lds[buf * BUF + XOFF + k * 4]);
-                        f32x16 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0, a[0][0], zero16, 0, 0, 0);
-                        f32x16 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b0, a[1][0], zero16, 0, 0, 0);
-                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b1, a[0][1], acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b1, a[1][1], acc1, 0, 0, 0);
+                        f32x4 d0[4], d1[4];
+#pragma unroll
+                        for (int rbk = 0; rbk < 4; ++rbk) {
+                            d0[rbk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b0, a16[rbk], zero4, 0, 0, 0);
+                            d1[rbk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1, a16[rbk], zero4, 0, 0, 0);
+                        }
                         // Tiles past the end of the strip (the last chunk may reach beyond it) are not counted -- and neither is a
-                        // PARTIAL last tile: its staged image repeats the cloud's last column in the padding, in BOTH 16-column halves
-                        // of the tile, so a row whose best column is that one would get the same column as its best and its
-                        // second best from the two lanes that share the row (the merge below relies on the two lanes seeing
-                        // disjoint columns) -- a threshold one neighbour too tight (found by tools/soak_fr.py, round 3; the walk
-                        // of phase 2 still visits that tile).
-                        if (tile_s(c, k) < t_end && (tile_s(c, k) + 1) * 32 <= nb) { fold(acc0, 0, xmax); fold(acc1, 1, xmax); }
+                        // PARTIAL last tile: its staged image repeats the cloud's last column in the padding, so a row whose best
+                        // column is that one would get the same column as its best and its second best from two of the four lanes
+                        // that share the row (the merge below relies on the lanes seeing disjoint columns) -- a threshold one
+                        // neighbour too tight (found by tools/soak_fr.py, round 3; the walk of phase 2 still visits that tile).
+                        if (tile_s(c, k) < t_end && (tile_s(c, k) + 1) * 32 <= nb) {
+#pragma unroll
+                            for (int rbk = 0; rbk < 4; ++rbk) fold(d0[rbk], d1[rbk], rbk, xmax);
+                        }
                     }
                     if (c + 1 < nsch) store_s(buf ^ 1);
                     __syncthreads();
                 }
             }
-            // the two lanes of a row (h = 0, 1: different columns) merge their pairs; lane h = 0 writes the row's start value
+            // the four lanes of a row (kb = 0..3: disjoint columns) merge their pairs in two exchange rounds; lane kb = 0 writes the row's
+            // start value
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb) {
-                const float c1 = __shfl_xor(m1[rb], 32), c2 = __shfl_xor(m2[rb], 32);
-                const float hi = fmaxf(m1[rb], c1), lo = fminf(m1[rb], c1);
-                const float second = fmaxf(lo, fmaxf(m2[rb], c2));
-                const int rl = wave * 64 + 32 * rb + r, row = bx * LR_BLOCK_ROWS + rl;
-                if (h == 0) {
+            for (int rbk = 0; rbk < 4; ++rbk) {
+#pragma unroll
+                for (int o = 16; o <= 32; o <<= 1) {
+                    const float c1 = __shfl_xor(m1[rbk], o), c2 = __shfl_xor(m2[rbk], o);
+                    const float hi = fmaxf(m1[rbk], c1), lo = fminf(m1[rbk], c1);
+                    m2[rbk] = fmaxf(lo, fmaxf(m2[rbk], c2));
+                    m1[rbk] = hi;
+                }
+                const int rl = wave * 64 + 16 * rbk + c16, row = bx * LR_BLOCK_ROWS + rl;
+                if (kb == 0) {
                     float yv = -LR_INF;
                     if (row < na) {
-                        const float U = -2.0f * (thr.need >= 2 ? second : hi);
+                        const float U = -2.0f * (thr.need >= 2 ? m2[rbk] : m1[rbk]);
                         const float scale = thr.nQ[rowmap ? rowmap[row] : row] + max_nc;
                         const float E = 1.05e-3f * scale + 4e-7f;
                         yv = 0.5f * (U + 2.0f * E + 6e-6f * scale + 2e-6f * fabsf(U));
@@ -397,17 +408,6 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         __syncthreads();
     }
 
-    // The walk runs on v_mfma_f32_16x16x32_f16 (all 32 K in one instruction; under the board's power limit it sustains ~20 % more
-    // flops than 32x32x16, tools/mfma_clock.hip): lane (c, kb) = (lane % 16, lane / 16) supplies K bytes 16 kb.. of row / column c of
-    // a 16-block and receives rows 4 kb + 0..3, column c of the 16 x 16 result.  Row fragments of the wave's four 16-row blocks:
-    const int c16 = lane & 15, kb = lane >> 4;
-    f16x8 a16[4];
-#pragma unroll
-    for (int rbk = 0; rbk < 4; ++rbk) {
-        int row = min(row0 + 16 * rbk + c16, na - 1);
-        if (rowmap) row = rowmap[row];
-        a16[rbk] = *reinterpret_cast<const f16x8 *>(Hq + (size_t)row * 32 + 8 * kb);
-    }
     // the lane's 4 x 4 threshold registers: register g of row block rbk <-> row 16 rbk + 4 kb + g of the wave
     f32x4 y4[4];
     auto load_y = [&]() {
@@ -560,40 +560,42 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
 
     f16x8 b0, b1;
     f32x2 xN = { LR_INF, LR_INF }, xC = { LR_INF, LR_INF };
-    f32x4 accA[4][2], accB[4][2];
+    // ONE set of accumulators (32 registers): a group of 8 is tested -- it holds the previous tile -- and then handed to the two MFMAs
+    // that overwrite it with the current tile, so every test reads its registers six MFMAs after they were issued and nothing is
+    // double-buffered (the 32 registers this saves are what lets a fourth wave onto the SIMD)
+    f32x4 acc[4][2];
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) { accA[q][cb][g] = -LR_INF; accB[q][cb][g] = -LR_INF; }
+            for (int g = 0; g < 4; ++g) acc[q][cb][g] = -LR_INF;
 
-    // one pipeline step: MFMAs of tile (c, k) into accN, tests of the previous tile in accC, LDS read of the next tile
-    auto step = [&](int c, int k, f32x4 (&accN)[4][2], const f32x4 (&accC)[4][2], unsigned stale) {
+    // one pipeline step: tests of the previous tile group by group, each followed by the MFMAs of tile (c, k) into the registers just
+    // tested; LDS read of the next tile
+    auto step = [&](int c, int k, unsigned stale) {
         f16x8 n0, n1; f32x2 nx;
         if (k + 1 < CH) read_b(fo_cur, xo_cur, k + 1, n0, n1, nx);
         else read_b(fo_oth, xo_oth, 0, n0, n1, nx);
         const int colC = (t_begin + c * CH + k - 1) * 32 + c16;
-        accN[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[0], b0, y4[0], 0, 0, 0);
-        accN[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[1], b0, y4[1], 0, 0, 0);
-        check(accC[0][0], accC[1][0], xC.x, colC, 0, stale);
-        accN[2][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[2], b0, y4[2], 0, 0, 0);
-        accN[3][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[3], b0, y4[3], 0, 0, 0);
-        check(accC[2][0], accC[3][0], xC.x, colC, 1, stale);
-        accN[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[0], b1, y4[0], 0, 0, 0);
-        accN[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[1], b1, y4[1], 0, 0, 0);
-        check(accC[0][1], accC[1][1], xC.y, colC + 16, 0, stale);
-        accN[2][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[2], b1, y4[2], 0, 0, 0);
-        accN[3][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[3], b1, y4[3], 0, 0, 0);
-        check(accC[2][1], accC[3][1], xC.y, colC + 16, 1, stale);
+#define MF(rbk, cb, b) acc[rbk][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[rbk], b, y4[rbk], 0, 0, 0)
+        check(acc[0][0], acc[1][0], xC.x, colC, 0, stale);
+        MF(0, 0, b0); MF(1, 0, b0);
+        check(acc[2][0], acc[3][0], xC.x, colC, 1, stale);
+        MF(2, 0, b0); MF(3, 0, b0);
+        check(acc[0][1], acc[1][1], xC.y, colC + 16, 0, stale);
+        MF(0, 1, b1); MF(1, 1, b1);
+        check(acc[2][1], acc[3][1], xC.y, colC + 16, 1, stale);
+        MF(2, 1, b1); MF(3, 1, b1);
+#undef MF
         b0 = n0; b1 = n1; xC = xN; xN = nx;
     };
     auto drain = [&](unsigned stale) {
         const int colC = (t_begin + nchunks * CH - 1) * 32 + c16;
-        check(accB[0][0], accB[1][0], xC.x, colC, 0, stale);
-        check(accB[2][0], accB[3][0], xC.x, colC, 1, stale);
-        check(accB[0][1], accB[1][1], xC.y, colC + 16, 0, stale);
-        check(accB[2][1], accB[3][1], xC.y, colC + 16, 1, stale);
+        check(acc[0][0], acc[1][0], xC.x, colC, 0, stale);
+        check(acc[2][0], acc[3][0], xC.x, colC, 1, stale);
+        check(acc[0][1], acc[1][1], xC.y, colC + 16, 0, stale);
+        check(acc[2][1], acc[3][1], xC.y, colC + 16, 1, stale);
     };
     unsigned stale = 0u;     // 1: the accumulators awaiting their test were started from thresholds that have been reloaded since
     if (nchunks > 0) {
@@ -611,10 +613,8 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
             bool attention = false;
             for (; c < nchunks && !attention; ++c) {
 #pragma unroll
-                for (int k = 0; k < CH; k += 2) {
-                    step(c, k, accA, accB, k == 0 ? stale : 0u);
-                    if (k == 0) stale = 0u;
-                    if (k == CH - 2) {
+                for (int k = 0; k < CH; ++k) {
+                    if (k == CH - 1) {
                         // the last step of a chunk reads the first fragment of the next one: make that chunk visible now.  All
                         // reads of the buffer it goes to were issued before the previous barrier (the step above read this
                         // chunk's own last tile), so one barrier per chunk still orders everything.
@@ -624,7 +624,8 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
                         if (c + 2 < nchunks) load_chunk(c + 2);
 #endif
                     }
-                    step(c, k + 1, accB, accA, 0u);
+                    step(c, k, k == 0 ? stale : 0u);
+                    if (k == 0) stale = 0u;
                 }
                 { const int t0 = fo_cur; fo_cur = fo_oth; fo_oth = t0; const int t1 = xo_cur; xo_cur = xo_oth; xo_oth = t1; }
                 attention = wcnt >= LR_PB_WLIST / 2 || (tightening && wcnt - wdone >= LR_PB_TIGHTEN);
@@ -634,7 +635,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
                 stale = tightening ? 1u : 0u;
             }
         }
-        // drain: the last tile of the last chunk sits in accB.  The inline-asm maxima below read MFMA results the
+        // drain: the last tile of the last chunk sits in the accumulators.  The inline-asm maxima below read MFMA results the
         // compiler cannot see them read (no automatic wait states): inside the loop every such read is at least two
         // MFMAs behind its producer; here an explicit wait covers the 8-pass MFMA write latency.
         {
