@@ -48,7 +48,7 @@ void carve(lr_workspace *ws, Carver &c)
     ws->bmax0 = c.take<float>(n0 / 32 + 2); ws->bmax1 = c.take<float>(n1 / 32 + 2);
     ws->rev_seed = c.take<uint32_t>(n1); ws->rev_rows = c.take<int32_t>(n1);
     ws->rev_seed64 = c.take<unsigned long long>(n1);
-    ws->rev_cols = c.take<int32_t>(n0); ws->rev_s1 = c.take<float>(n0);
+    ws->rev_cols = c.take<int32_t>(n0); ws->rev_s1 = c.take<float>(n0); ws->rev_pos = c.take<int32_t>(n0);
     ws->rev_tmin = c.take<float>(n0 / 32 + 2); ws->rev_hist = c.take<int32_t>(2 * 4096);
     ws->Hs = c.take<_Float16>(n0 * 32); ws->nrms = c.take<float>(n0);
     ws->nn_idx1 = c.take<int32_t>(n0); ws->nn_idx2 = c.take<int32_t>(n0);

@@ -104,6 +104,7 @@ struct lr_workspace {
     unsigned long long *rev_seed64;  // [max_n1] ... and who: (distance bits << 32) | smallest cloud-0 index at that distance
     int32_t *rev_rows;           // [max_n1] the cloud-1 rows that have one, by descending seed
     int32_t *rev_cols;           // [max_n0] cloud-0 points by ascending NN distance (columns of the reverse pass)
+    int32_t *rev_pos;            // [max_n0] position of every cloud-0 point in rev_cols order (scratch between the rank and the copy kernel)
     float *rev_s1;               // [max_n0] column key of the reverse pass per cloud-0 point: its 2nd-NN distance (NN distance when no 2nd was asked for)
     float *rev_tmin;             // [max_n0/32+1] smallest key of each column tile
     int32_t *rev_hist;           // [2][4096] counting-sort offsets

@@ -247,13 +247,14 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         // Ordered reverse pass (lr_nn16_reverse): a column can only win a row if its key (a lower bound of its distance to every row
         // it does not point at) is <= the row's bound.  Rows lie by descending bucket of their bound, columns by ascending bucket of
         // their key (one monotone map, nn16_rev_scan / _scatter), so the block's FIRST row has its largest bucket b and the columns
-        // that can matter to the block are the first offs[b] of the order (after the scatter offs[b] is the end of bucket b): three
+        // that can matter to the block are the first offs[b + 1] of the order (the end of bucket b): three
         // dependent loads by one thread instead of 256 bounds + all tile minima reduced by the block -- most of the (row block, strip)
         // blocks of this launch only find out here that they are not needed.
         if (tid == 0) {
             const float lo = __uint_as_float(rev_range[0]), scale = rs_scale(lo, __uint_as_float(rev_range[1]));
             const float sv = __uint_as_float(row_bound[rowmap[bx * LR_BLOCK_ROWS]]);
-            s_limit[0] = (rev_offs[rs_bucket(sv, lo, scale)] + 31) >> 5;
+            const int b = rs_bucket(sv, lo, scale);        // (bucket b of the column order ends where bucket b + 1 starts)
+            s_limit[0] = ((b + 1 < LR_RS_BUCKETS ? rev_offs[b + 1] : nb) + 31) >> 5;
         }
         __syncthreads();
         ntiles = min(ntiles, s_limit[0]);
@@ -1010,58 +1011,103 @@ nn16_rev_scan_kernel(int n0, int n1, const float *__restrict__ s1, const uint32_
     }
 }
 
-// pass 3: scatter.  Cloud-0 points: position in ascending-s1 order -> colmap, and the f16 row /
-// norm copied there (pass B streams the permuted copy, no indirection in its loop).  Cloud-1 points with a seed: position in descending-s* order -> rowmap, threshold and empty
-// candidate list at that position; the others get rev = -1.
-__global__ void __launch_bounds__(256)
-nn16_rev_scatter_kernel(int n0, int n1, const float *__restrict__ s1, const uint32_t *__restrict__ seed_bits,
-                        const uint32_t *__restrict__ range, int32_t *__restrict__ offs,
-                        const _Float16 *__restrict__ H0, const float *__restrict__ nrm0, const float *__restrict__ block_max_c, int nblk_c,
-                        const float *__restrict__ nrm1,
-                        int32_t *__restrict__ colmap, _Float16 *__restrict__ H0s, float *__restrict__ nrm0s, uint32_t *__restrict__ tile_min_bits,
-                        int32_t *__restrict__ rowmap, float *__restrict__ tau, int32_t *__restrict__ cand_cnt, int32_t *__restrict__ rev_out,
-                        int seg_counters, lr_zargs z)
+// pass 3: ranks.  Cloud-0 points: position in ascending-key order -> pos0 (nn16_rev_copy_kernel moves the f16 rows there).  Cloud-1
+// points with a seed: position in descending-s* order -> rowmap, threshold and empty candidate list at that position; the others get
+// rev = -1.
+// LR_RS_PARTS blocks per pair: every block reads ALL keys (cheap: 4 bytes each) and owns the buckets whose first position falls into
+// its share of the order; the rank of an element inside its bucket is an LDS atomic of the one block that owns the bucket.  (Round 2-3
+// took the ranks with one device-scope atomic per element on the bucket offsets and copied the row in the same thread: 60 000
+// returning atomics per pair, 3.7 us per pair -- 0.5 TB/s for a kernel that only moves 4 MB.)  The offsets stay what the scan
+// wrote: bucket b ends where bucket b + 1 starts.
+#define LR_RS_PARTS 8
+__global__ void __launch_bounds__(1024)
+nn16_rev_rank_kernel(int n0, int n1, const float *__restrict__ s1, const uint32_t *__restrict__ seed_bits,
+                     const uint32_t *__restrict__ range, const int32_t *__restrict__ offs, const int32_t *__restrict__ n_rows,
+                     const float *__restrict__ block_max_c, int nblk_c, const float *__restrict__ nrm1, int32_t *__restrict__ pos0,
+                     int32_t *__restrict__ rowmap, float *__restrict__ tau, int32_t *__restrict__ cand_cnt, int32_t *__restrict__ rev_out,
+                     int seg_counters, lr_zargs z)
 {
-    __shared__ float s_m[4];
+    __shared__ float s_m[16];
+    __shared__ int s_cnt[2 * LR_RS_BUCKETS];
     if (z.descs) { n0 = z.descs[blockIdx.z].n0; n1 = z.descs[blockIdx.z].n1; nblk_c = (n0 + 31) >> 5; }
-    lr_z(s1, z, blockIdx.z); lr_z(seed_bits, z, blockIdx.z); lr_z(range, z, blockIdx.z); lr_z(offs, z, blockIdx.z); lr_z(H0, z, blockIdx.z);
-    lr_z(nrm0, z, blockIdx.z); lr_z(block_max_c, z, blockIdx.z); lr_z(nrm1, z, blockIdx.z); lr_z(colmap, z, blockIdx.z); lr_z(H0s, z, blockIdx.z);
-    lr_z(nrm0s, z, blockIdx.z); lr_z(tile_min_bits, z, blockIdx.z); lr_z(rowmap, z, blockIdx.z); lr_z(tau, z, blockIdx.z);
+    lr_z(s1, z, blockIdx.z); lr_z(seed_bits, z, blockIdx.z); lr_z(range, z, blockIdx.z); lr_z(offs, z, blockIdx.z); lr_z(n_rows, z, blockIdx.z);
+    lr_z(block_max_c, z, blockIdx.z); lr_z(nrm1, z, blockIdx.z); lr_z(pos0, z, blockIdx.z); lr_z(rowmap, z, blockIdx.z); lr_z(tau, z, blockIdx.z);
     lr_z(cand_cnt, z, blockIdx.z); lr_z(rev_out, z, blockIdx.z);
-    const int t = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+    const int tid = threadIdx.x, lane = tid & 63, part = blockIdx.x;
     // the segment counters of the reverse pass B start from zero (row blocks that use fewer strips than offered leave the
     // others untouched)
-    for (int k = t; k < seg_counters; k += (int)gridDim.x * 256) cand_cnt[k] = 0;
+    for (int k = part * 1024 + tid; k < seg_counters; k += LR_RS_PARTS * 1024) cand_cnt[k] = 0;
+    for (int k = tid; k < 2 * LR_RS_BUCKETS; k += 1024) s_cnt[k] = 0;
     float mx = 0.0f;
-    for (int b = threadIdx.x; b < nblk_c; b += 256) mx = fmaxf(mx, block_max_c[b]);
+    for (int b = tid; b < nblk_c; b += 1024) mx = fmaxf(mx, block_max_c[b]);
 #pragma unroll
     for (int k = 32; k >= 1; k >>= 1) mx = fmaxf(mx, __shfl_xor(mx, k));
-    if (lane == 0) s_m[threadIdx.x >> 6] = mx;
+    if (lane == 0) s_m[tid >> 6] = mx;
     __syncthreads();
-    const float max_nc = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));      // largest norm of cloud 0 (the columns)
+    float max_nc = 0.0f;                                        // largest norm of cloud 0 (the columns)
+#pragma unroll
+    for (int w = 0; w < 16; ++w) max_nc = fmaxf(max_nc, s_m[w]);
     const float lo = __uint_as_float(range[0]), scale = rs_scale(lo, __uint_as_float(range[1]));
-    if (t < n0) {
-        const float sv = s1[t];
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(H0 + (size_t)t * 32);
-        const f32x4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
-        const float nt = nrm0[t];
-        const int pos = atomicAdd(&offs[rs_bucket(sv, lo, scale)], 1);
-        f32x4 *dst = reinterpret_cast<f32x4 *>(H0s + (size_t)pos * 32);
-        dst[0] = v0; dst[1] = v1; dst[2] = v2; dst[3] = v3;
-        colmap[pos] = t;
-        nrm0s[pos] = nt;
-    } else if (t < n0 + n1) {
-        const int row = t - n0;
-        const float sv = __uint_as_float(seed_bits[row]);
-        if (!(sv <= 3.0e38f)) { rev_out[row] = -1; return; }      // still the 0x7f7f7f7f fill: no query points at this row
-        const int pos = atomicAdd(&offs[LR_RS_BUCKETS + (LR_RS_BUCKETS - 1 - rs_bucket(sv, lo, scale))], 1);
-        const float scl = nrm1[row] + max_nc;
-        const float E = 1.05e-3f * scl + 4e-7f;
-        const float d2hi = sv * sv * (1.0f + 6e-7f);               // every d2 whose sqrt rounds to <= sv lies below this
-        rowmap[pos] = row;
-        tau[pos] = (d2hi - nrm1[row]) + E + 6e-6f * scl + 2e-6f * d2hi;
+    // the part that owns a bucket: the one whose share [part, part + 1) * n / LR_RS_PARTS of the order holds the bucket's first position
+    // (products compared, no division in the loops)
+    const long long nrows = *n_rows;
+    const long long c_lo = (long long)part * n0, c_hi = (long long)(part + 1) * n0, r_lo = (long long)part * nrows, r_hi = (long long)(part + 1) * nrows;
+    // cloud 0: eight keys in flight per thread
+    for (int i0 = tid; i0 < n0; i0 += 8 * 1024) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = s1[min(i0 + 1024 * k, n0 - 1)];
+        int start[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) start[k] = offs[rs_bucket(v[k], lo, scale)];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const long long sp = (long long)start[k] * LR_RS_PARTS;
+            if (i0 + 1024 * k < n0 && sp >= c_lo && sp < c_hi) pos0[i0 + 1024 * k] = start[k] + atomicAdd(&s_cnt[rs_bucket(v[k], lo, scale)], 1);
+        }
     }
+    // cloud 1
+    for (int j0 = tid; j0 < n1; j0 += 8 * 1024) {
+        uint32_t v[8];
+        float nj[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { v[k] = seed_bits[min(j0 + 1024 * k, n1 - 1)]; nj[k] = nrm1[min(j0 + 1024 * k, n1 - 1)]; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int row = j0 + 1024 * k;
+            if (row >= n1) continue;
+            const float sv = __uint_as_float(v[k]);
+            if (!(sv <= 3.0e38f)) {      // still the 0x7f7f7f7f fill: no query points at this row
+                if ((row & (LR_RS_PARTS - 1)) == part) rev_out[row] = -1;
+                continue;
+            }
+            const int b = LR_RS_BUCKETS + (LR_RS_BUCKETS - 1 - rs_bucket(sv, lo, scale));
+            const int start = offs[b];
+            const long long sp = (long long)start * LR_RS_PARTS;
+            if (sp < r_lo || sp >= r_hi) continue;
+            const int p = start + atomicAdd(&s_cnt[b], 1);
+            const float scl = nj[k] + max_nc;
+            const float E = 1.05e-3f * scl + 4e-7f;
+            const float d2hi = sv * sv * (1.0f + 6e-7f);               // every d2 whose sqrt rounds to <= sv lies below this
+            rowmap[p] = row;
+            tau[p] = (d2hi - nj[k]) + E + 6e-6f * scl + 2e-6f * d2hi;
+        }
+    }
+}
 
+// pass 4: the f16 rows and norms of cloud 0 -> their positions (pass B streams the permuted copy, no indirection in its loop).  Four
+// threads per row, 16 bytes each: coalesced reads, whole 64-byte segments written.
+__global__ void __launch_bounds__(256)
+nn16_rev_copy_kernel(int n0, const int32_t *__restrict__ pos0, const _Float16 *__restrict__ H0, const float *__restrict__ nrm0,
+                     int32_t *__restrict__ colmap, _Float16 *__restrict__ H0s, float *__restrict__ nrm0s, lr_zargs z)
+{
+    if (z.descs) n0 = z.descs[blockIdx.z].n0;
+    lr_z(pos0, z, blockIdx.z); lr_z(H0, z, blockIdx.z); lr_z(nrm0, z, blockIdx.z); lr_z(colmap, z, blockIdx.z); lr_z(H0s, z, blockIdx.z); lr_z(nrm0s, z, blockIdx.z);
+    const int t = blockIdx.x * 256 + threadIdx.x, i = t >> 2, piece = t & 3;
+    if (i >= n0) return;
+    const int p = pos0[i];
+    reinterpret_cast<f32x4 *>(H0s + (size_t)p * 32)[piece] = reinterpret_cast<const f32x4 *>(H0 + (size_t)i * 32)[piece];
+    if (piece == 0) { colmap[p] = i; nrm0s[p] = nrm0[i]; }
 }
 
 int lr_nn16_reverse(lr_workspace *ws, const float *F0, const _Float16 *H0, const float *nrm0, const float *bmax0, int n0,
@@ -1090,9 +1136,11 @@ int lr_nn16_reverse(lr_workspace *ws, const float *F0, const _Float16 *H0, const
         hipLaunchKernelGGL(nn16_rev_seed_kernel, dim3(lr_cdiv(n0, 256)), dim3(256), 0, st, F0, nrm0, n0, F1, nrm1, fwd_idx1, seed, ws->rev_s1, range);
     hipLaunchKernelGGL(nn16_rev_scan_kernel, dim3(1, 1, ws->zP), dim3(1024), 0, st, n0, n1, (const float *)ws->rev_s1, (const uint32_t *)seed,
                        (const uint32_t *)range, ws->rev_hist, n_rows, tmin, ws->z);
-    hipLaunchKernelGGL(nn16_rev_scatter_kernel, dim3(lr_cdiv(n0 + n1, 256), 1, ws->zP), dim3(256), 0, st, n0, n1, (const float *)ws->rev_s1,
-                       (const uint32_t *)seed, (const uint32_t *)range, ws->rev_hist, H0, nrm0, bmax0, lr_cdiv(nb, 32), nrm1,
-                       ws->rev_cols, ws->Hs, ws->nrms, tmin, ws->rev_rows, ws->tau, ws->cand_cnt, rev, row_blocks * 4 * (strips + 1), ws->z);
+    hipLaunchKernelGGL(nn16_rev_rank_kernel, dim3(LR_RS_PARTS, 1, ws->zP), dim3(1024), 0, st, n0, n1, (const float *)ws->rev_s1,
+                       (const uint32_t *)seed, (const uint32_t *)range, (const int32_t *)ws->rev_hist, (const int32_t *)n_rows, bmax0, lr_cdiv(nb, 32), nrm1,
+                       ws->rev_pos, ws->rev_rows, ws->tau, ws->cand_cnt, rev, row_blocks * 4 * (strips + 1), ws->z);
+    hipLaunchKernelGGL(nn16_rev_copy_kernel, dim3(lr_cdiv(4 * n0, 256), 1, ws->zP), dim3(256), 0, st, n0, (const int32_t *)ws->rev_pos, H0, nrm0,
+                       ws->rev_cols, ws->Hs, ws->nrms, ws->z);
     // grids are sized for all rows; blocks past the compacted count (or past their row block's strips) leave at once.
     // The column-prefix pruning (flagged by a non-null tile_min) rests on the keys being true lower bounds: that holds when
     // the list comes from this library's own forward pass (`seeded`, lr_register_pair).  A caller-supplied list (lr_nn_to_mutual,
