@@ -136,11 +136,14 @@ __device__ __forceinline__ bool hypothesis_sample(const float *__restrict__ corr
         uint32_t s = __umulhi(c[k], (uint32_t)m);
         if (n_top) s = k < NS - 1 ? __umulhi(c[k], (uint32_t)(n_top - 1)) : (uint32_t)(n_top - 1);
         sidx[k] = s;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            P[k][a] = (double)corr8[lr_corr_at((int)s, a)];
-            Q[k][a] = (double)corr8[lr_corr_at((int)s, 3 + a)];
-        }
+        // the correspondence's six floats sit at every second place of the first 48 bytes of its pair's record (lr_corr_at): three 16-byte
+        // gathers and a selection by parity instead of six 4-byte gathers -- a gather costs the memory pipe a cache line per lane whatever
+        // its width, and the gathers are what this kernel waits for
+        const f32x4 *rec = reinterpret_cast<const f32x4 *>(corr8 + (size_t)(s >> 1) * 16);
+        const f32x4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+        const bool odd = (s & 1u) != 0u;
+        P[k][0] = (double)(odd ? r0.y : r0.x); P[k][1] = (double)(odd ? r0.w : r0.z); P[k][2] = (double)(odd ? r1.y : r1.x);
+        Q[k][0] = (double)(odd ? r1.w : r1.z); Q[k][1] = (double)(odd ? r2.y : r2.x); Q[k][2] = (double)(odd ? r2.w : r2.z);
     }
     bool ok = true;
     if (unique) {       // GC-RANSAC's samplers draw distinct indices: a repeated index rejects the draw
@@ -156,9 +159,18 @@ __device__ __forceinline__ bool hypothesis_sample(const float *__restrict__ corr
         for (int j = i + 1; j < NS; ++j) {
             double sx = P[j][0] - P[i][0], sy = P[j][1] - P[i][1], sz = P[j][2] - P[i][2];
             double tx = Q[j][0] - Q[i][0], ty = Q[j][1] - Q[i][1], tz = Q[j][2] - Q[i][2];
-            double ds = sqrt((sx * sx + sy * sy) + sz * sz);
-            double dt = sqrt((tx * tx + ty * ty) + tz * tz);
-            if (ds < dt * 0.9 || dt < ds * 0.9) ok = false;
+            // the contract compares the LENGTHS (oracle.c: ds < dt * 0.9 || dt < ds * 0.9, sqrt and products rounded in fp64).  The
+            // roundings move either side by < 4 ulp, so away from equality the squares decide the same way, and the six fp64 square
+            // roots per draw -- a third of this kernel -- are only taken inside a relative band of 1e-13 around it (or when a square is
+            // zero or not finite: every comparison below is then false)
+            const double a2 = (sx * sx + sy * sy) + sz * sz, b2 = (tx * tx + ty * ty) + tz * tz;
+            const double band = 1e-13 * (a2 + b2);
+            if (fabs(a2 - 0.81 * b2) > band && fabs(b2 - 0.81 * a2) > band) {
+                if (a2 < 0.81 * b2 || b2 < 0.81 * a2) ok = false;
+            } else {
+                const double ds = sqrt(a2), dt = sqrt(b2);
+                if (ds < dt * 0.9 || dt < ds * 0.9) ok = false;
+            }
         }
     return ok;
 }
@@ -201,23 +213,28 @@ __device__ __forceinline__ void lr_score_info_reset(lr_score_info *info)      //
 template <int NS>
 __global__ void __launch_bounds__(256)
 ransac_gen_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__restrict__ m_dev, lr_ransac_params p,
-                  int h_begin, int h_end, float *__restrict__ models, double *__restrict__ models64, int32_t *__restrict__ model_h,
+                  int h_begin, int h_end, int32_t *__restrict__ model_h,
                   uint32_t *__restrict__ score_cnt, unsigned long long *__restrict__ score_ssq,
-                  int32_t *__restrict__ counters, const int32_t *__restrict__ G, int TN, int model_stride,
+                  int32_t *__restrict__ counters, const int32_t *__restrict__ G, int TN,
                   lr_score_info *__restrict__ info, lr_zargs z)
 {
-    __shared__ int s_pass[256];
+    // ids that passed the pre-check -> dense list model_h[0 .. NVALID) (appended by whole groups: one device atomic per block and
+    // FIT_AT ids); ransac_fit_kernel estimates their models.  The fit (fp64 Kabsch, a dependent chain of ~14 us for a wave) used to
+    // run here, on the 18 of 256 ids of a group that pass the edge-length check: a quarter of ONE wave per block for the full length
+    // of the fit, 1.25 such waves per SIMD -- 61 of the kernel's 111 us per 32-pair launch were that wait.
+    constexpr int FIT_AT = 192;
+    __shared__ int s_pass[FIT_AT + 256];
     __shared__ int s_np, s_base;
     lr_z(info, z, blockIdx.z);
     if (blockIdx.x == 0) lr_score_info_reset(info);       // the scoring passes of this batch elect their pilot model afresh
-    lr_z(corr8, z, blockIdx.z); lr_z(m_dev, z, blockIdx.z); lr_z(models, z, blockIdx.z); lr_z(models64, z, blockIdx.z); lr_z(model_h, z, blockIdx.z); lr_z(score_cnt, z, blockIdx.z); lr_z(score_ssq, z, blockIdx.z); lr_z(counters, z, blockIdx.z); lr_z(G, z, blockIdx.z);
+    lr_z(corr8, z, blockIdx.z); lr_z(m_dev, z, blockIdx.z); lr_z(model_h, z, blockIdx.z); lr_z(score_cnt, z, blockIdx.z); lr_z(score_ssq, z, blockIdx.z); lr_z(counters, z, blockIdx.z); lr_z(G, z, blockIdx.z);
     const int m = m_dev ? min(*m_dev, m_max) : m_max;
     if (m <= 0 || reinterpret_cast<const lr_ransac_state *>(counters + LR_CNT_COUNT)->done) return;
+    if (threadIdx.x == 0) s_np = 0;
+    __syncthreads();
     // (a capped grid strides over the 256-id groups: the launches of the batches behind an early exit then cost a few hundred
     // idle blocks instead of tens of thousands)
     for (int blk = blockIdx.x; blk * 256 < h_end - h_begin; blk += gridDim.x) {
-        if (threadIdx.x == 0) s_np = 0;
-        __syncthreads();
         const int h = h_begin + blk * 256 + threadIdx.x;
         {
             double P[NS][3], Q[NS][3];
@@ -225,23 +242,46 @@ ransac_gen_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__r
         }
         __syncthreads();
         const int np = s_np;
-        if (threadIdx.x == 0 && np > 0) s_base = atomicAdd(&counters[LR_CNT_NVALID], np);
-        __syncthreads();
-        if ((int)threadIdx.x < np) {
-            const int hh = s_pass[threadIdx.x];
-            double P[NS][3], Q[NS][3], T[16];
-            hypothesis_sample<NS>(corr8, m, p.seed, (uint64_t)hh, 0, P, Q, G, TN);
-            kabsch_sample<NS>(P, Q, T);
-            const int slot = s_base + threadIdx.x;
-#pragma unroll
-            // fp32 models component-major ([12][model_stride]: the scoring kernel's 64 lanes read 64 consecutive floats per
-            // component), fp64 models row-major (only the winner is ever read back)
-            for (int k = 0; k < 12; ++k) { models[(size_t)k * model_stride + slot] = (float)T[k]; models64[(size_t)slot * 12 + k] = T[k]; }
-            model_h[slot] = hh;
+        const bool last = (blk + (int)gridDim.x) * 256 >= h_end - h_begin;
+        if (threadIdx.x == 0 && np > 0 && (np >= FIT_AT || last)) s_base = atomicAdd(&counters[LR_CNT_NVALID], np);
+        __syncthreads();                             // (every thread has read np before the next group's ids are appended)
+        if (np < FIT_AT && !last) continue;          // (block-uniform: np and last are the same for every thread)
+        for (int e = threadIdx.x; e < np; e += 256) {
+            const int slot = s_base + e;
+            model_h[slot] = s_pass[e];
             score_cnt[slot] = 0u;
             score_ssq[slot] = 0ull;
         }
-        if ((blk + (int)gridDim.x) * 256 < h_end - h_begin) __syncthreads();      // (only when the block takes another group)
+        if (!last) {
+            __syncthreads();
+            if (threadIdx.x == 0) s_np = 0;
+            __syncthreads();
+        }
+    }
+}
+
+// the models of the ids ransac_gen_kernel listed: a thread per list slot re-draws its sample (same Philox counter) and fits it
+template <int NS>
+__global__ void __launch_bounds__(64)
+ransac_fit_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__restrict__ m_dev, lr_ransac_params p,
+                  float *__restrict__ models, double *__restrict__ models64, const int32_t *__restrict__ model_h,
+                  const int32_t *__restrict__ counters, const int32_t *__restrict__ G, int TN, int model_stride, lr_zargs z)
+{
+    lr_z(corr8, z, blockIdx.z); lr_z(m_dev, z, blockIdx.z); lr_z(models, z, blockIdx.z); lr_z(models64, z, blockIdx.z); lr_z(model_h, z, blockIdx.z); lr_z(counters, z, blockIdx.z); lr_z(G, z, blockIdx.z);
+    const int m = m_dev ? min(*m_dev, m_max) : m_max;
+    if (m <= 0 || reinterpret_cast<const lr_ransac_state *>(counters + LR_CNT_COUNT)->done) return;
+    const int V = counters[LR_CNT_NVALID];
+    // (a capped grid strides over the list: with the pre-check the list is a fraction of the batch, and tens of thousands of blocks
+    // that only find that out cost more than the fits)
+    for (int slot = blockIdx.x * 64 + threadIdx.x; slot < V; slot += gridDim.x * 64) {
+        const int hh = model_h[slot];
+        double P[NS][3], Q[NS][3], T[16];
+        hypothesis_sample<NS>(corr8, m, p.seed, (uint64_t)hh, 0, P, Q, G, TN);
+        kabsch_sample<NS>(P, Q, T);
+        // fp32 models component-major ([12][model_stride]: the scoring kernel's 64 lanes read 64 consecutive floats per
+        // component), fp64 models row-major (only the winner is ever read back)
+#pragma unroll
+        for (int k = 0; k < 12; ++k) { models[(size_t)k * model_stride + slot] = (float)T[k]; models64[(size_t)slot * 12 + k] = T[k]; }
     }
 }
 
@@ -1411,12 +1451,20 @@ int lr_ransac_run(lr_workspace *ws, const float *corr8, int m_max, const int32_t
         const int gb_all = lr_cdiv(h1 - h0 > 0 ? h1 - h0 : 1, 256);      // 256-id groups of the batch
         const int gb = gb_all < 1024 ? gb_all : 1024;                       // blocks per pair (they stride over the groups)
         lr_score_info *info = reinterpret_cast<lr_score_info *>(ws->sc_info);
-        if (p->sample_size == 3)
-            hipLaunchKernelGGL(ransac_gen_kernel<3>, dim3(gb, 1, ws->zP), dim3(256), 0, st, corr8, m_max, m_dev, *p, h0, h1, ws->models, ws->models64,
-                               ws->model_h, ws->score_cnt, ws->score_ssq, ws->counters, G, TN, ws->max_iters, info, ws->z);
-        else
-            hipLaunchKernelGGL(ransac_gen_kernel<4>, dim3(gb, 1, ws->zP), dim3(256), 0, st, corr8, m_max, m_dev, *p, h0, h1, ws->models, ws->models64,
-                               ws->model_h, ws->score_cnt, ws->score_ssq, ws->counters, G, TN, ws->max_iters, info, ws->z);
+        // fit: a wave per 64 list slots, at most 4096 waves in the launch (four per SIMD; they stride over longer lists)
+        const int fb_all = lr_cdiv(h1 - h0 > 0 ? h1 - h0 : 1, 64), fb_cap = 4096 / ws->zP > 16 ? 4096 / ws->zP : 16;
+        const int fb = fb_all < fb_cap ? fb_all : fb_cap;
+        if (p->sample_size == 3) {
+            hipLaunchKernelGGL(ransac_gen_kernel<3>, dim3(gb, 1, ws->zP), dim3(256), 0, st, corr8, m_max, m_dev, *p, h0, h1, ws->model_h, ws->score_cnt, ws->score_ssq,
+                               ws->counters, G, TN, info, ws->z);
+            hipLaunchKernelGGL(ransac_fit_kernel<3>, dim3(fb, 1, ws->zP), dim3(64), 0, st, corr8, m_max, m_dev, *p, ws->models, ws->models64, (const int32_t *)ws->model_h,
+                               (const int32_t *)ws->counters, G, TN, ws->max_iters, ws->z);
+        } else {
+            hipLaunchKernelGGL(ransac_gen_kernel<4>, dim3(gb, 1, ws->zP), dim3(256), 0, st, corr8, m_max, m_dev, *p, h0, h1, ws->model_h, ws->score_cnt, ws->score_ssq,
+                               ws->counters, G, TN, info, ws->z);
+            hipLaunchKernelGGL(ransac_fit_kernel<4>, dim3(fb, 1, ws->zP), dim3(64), 0, st, corr8, m_max, m_dev, *p, ws->models, ws->models64, (const int32_t *)ws->model_h,
+                               (const int32_t *)ws->counters, G, TN, ws->max_iters, ws->z);
+        }
         const bool sprt = p->use_elc == 2;
         if (sprt)       // every estimated model is pre-verified; the survivors form a second dense list that is scored in full
             hipLaunchKernelGGL(ransac_sprt_kernel, dim3(gb_all, 1, ws->zP), dim3(256), 0, st, corr8, m_max, m_dev, p->thr2,
