@@ -2,8 +2,9 @@
 # GPU box: SQ counters per kernel of the batched bench workload, one --pmc pass per group -> gpurun_out/pmc_bench/summary.txt
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/pmc_bench
-mkdir -p $O
+O=/tmp/pmc_bench_csv            # raw counter CSVs (10 MB per pass) stay on the box; only the summary is merged back
+S=$R/gpurun_out/pmc_bench
+rm -rf $O; mkdir -p $O $S
 cd /tmp
 k=0
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_VALU_MFMA_BUSY_CYCLES" \
@@ -14,7 +15,7 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_ACTI
   f=$(find /tmp/pb_$k -name '*counter_collection.csv' | head -1)
   if [ -n "$f" ]; then cp "$f" $O/g$k.csv; else echo "group $k FAILED"; tail -3 /tmp/pb_$k.log; fi
 done
-python3 - $O <<'PY' | tee $O/summary.txt
+python3 - $O <<'PY' | tee $S/summary.txt
 import csv, glob, sys, collections, re
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 def short(n):

@@ -2,8 +2,9 @@
 # GPU box: more SQ counters for the filter pass (co-execution of the vector and matrix pipes, LDS, waits, scalar / branch issue)
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/pmc_passb
-mkdir -p $O
+O=/tmp/pmc_passb_csv            # raw counter CSVs (10 MB per pass) stay on the box; only the summary is merged back
+S=$R/gpurun_out/pmc_passb
+rm -rf $O; mkdir -p $O $S
 cd /tmp
 k=0
 for grp in "SQ_VALU_MFMA_COEXEC_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS" \
@@ -14,7 +15,7 @@ for grp in "SQ_VALU_MFMA_COEXEC_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_V
   f=$(find /tmp/pp_$k -name '*counter_collection.csv' | head -1)
   if [ -n "$f" ]; then cp "$f" $O/g$k.csv; else echo "group $k FAILED"; tail -3 /tmp/pp_$k.log; fi
 done
-python3 - $O <<'PY' | tee $O/summary.txt
+python3 - $O <<'PY' | tee $S/summary.txt
 import csv, glob, sys, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob(sys.argv[1] + "/g*.csv")):

@@ -26,7 +26,10 @@ prof bench_gc_streams1 --codebase GC --streams 1 --pairs 64 --steps 3 --warmup 1
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/p_$c
   rocprofv3 --pmc $c --output-format csv -d /tmp/p_$c -o c -- python3 $R/bench.py --steps 2 --warmup 1 --streams 1 --pairs 32 --no-cpu-baseline > /tmp/p_$c.log 2>&1
-  cp "$(find /tmp/p_$c -name '*counter_collection.csv' | head -1)" $O/pmc_$c.csv
+  cp "$(find /tmp/p_$c -name '*counter_collection.csv' | head -1)" /tmp/pmc_$c.csv
 done
+python3 $R/tools/pmc_to_json.py /tmp/pmc_FETCH_SIZE.csv /tmp/pmc_WRITE_SIZE.csv $O/pmc_traffic.json > $O/pmc_traffic.txt
 bash $R/tools/pmc_bench.sh > $O/pmc_sq_summary.txt 2>&1
+bash $R/tools/pmc_passb.sh > $O/pmc_passb_summary.txt 2>&1
+for l in A B; do python $R/bench.py --list $l --no-cpu-baseline > $O/list_${l}_bench_line.json 2>> $O/bench_stderr.log; done
 ls -la $O
