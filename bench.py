@@ -36,7 +36,7 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=128, help="distinct resident pairs per step per GPU")
+    ap.add_argument("--pairs", type=int, default=192, help="distinct resident pairs per step per GPU")
     ap.add_argument("--n", "--points", dest="n", type=int, default=30000, help="points per cloud")
     ap.add_argument("--iters", type=int, default=50000)
     ap.add_argument("--mode", default="MNN")
@@ -45,7 +45,7 @@ def parse(argv=None):
                          "(the headline workload); GC: the reference CLI's defaults (test.py:301-313: PROSAC, ELC, MSAC, confidence 0.999 "
                          "early exit, local optimisation + final least squares) -- an additional, lighter workload, never the headline")
     ap.add_argument("--batch", type=int, default=0, help="pairs per batched call (0: 32, or 8 for clouds above 60k points)")
-    ap.add_argument("--streams", type=int, default=0, help="batched calls in flight per GPU (0: 2, or 4 with --codebase GC whose one-block-per-pair "
+    ap.add_argument("--streams", type=int, default=0, help="batched calls in flight per GPU (0: 3, or 4 with --codebase GC whose one-block-per-pair "
                                                             "local optimisation leaves most CUs to the other calls)")
     ap.add_argument("--include-h2d", action="store_true", help="copy each pair from pinned host memory inside the timed region (PCIe-inclusive rate; not the headline value)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -258,7 +258,7 @@ def main():
 
     B = args.batch if args.batch > 0 else (32 if args.n <= 60000 else 8)
     B = max(1, min(B, args.pairs, 64))
-    nstreams = args.streams if args.streams > 0 else (4 if args.codebase == "GC" else 2)
+    nstreams = args.streams if args.streams > 0 else (4 if args.codebase == "GC" else 3)
     res_bytes = 496
     pairs, T_gt = [], []
     if not dry:

@@ -19,7 +19,7 @@ prof() {   # tag, then bench args
   cp "$(find /tmp/p_$tag -name '*kernel_stats.csv' | head -1)" $O/${tag}_kernel_stats.csv
 }
 prof bench_streams1 --streams 1 --pairs 64 --steps 3 --warmup 1
-prof bench_default --steps 3 --warmup 1
+prof bench_default --steps 3 --warmup 1          # (3 streams x 192 pairs since the end of round 3)
 prof bench_gpf_streams1 --mode GPF --streams 1 --pairs 64 --steps 3 --warmup 1
 prof bench_n100k_streams1 --n 100000 --streams 1 --pairs 16 --batch 8 --steps 3 --warmup 1
 prof bench_gc_streams1 --codebase GC --streams 1 --pairs 64 --steps 3 --warmup 1
