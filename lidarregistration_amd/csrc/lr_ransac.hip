@@ -416,31 +416,62 @@ __device__ __forceinline__ float lr_model_d2(const lr_model12 &M, const float *_
 __device__ __forceinline__ void lr_score_stream(const float *__restrict__ corr8, int begin, int end, int sub, float thr2,
                                                 const lr_model12 &M, uint32_t &cnt, unsigned long long &ssq)
 {
-    // two correspondences per iteration: the record of a pair is wave-uniform (scalar load) and its halves feed
+    // two correspondences per packed instruction: the record of a pair is wave-uniform (scalar load) and its halves feed
     // packed fp32 instructions directly; every component keeps the fma order of the arithmetic contract.
     // The error sum runs in 32 bits over sub-blocks short enough not to overflow (sub * thr2 * 2^20 < 2^32).
-    const f32x2 *rec = reinterpret_cast<const f32x2 *>(corr8);
+    // Scalar loads return out of order, so every wait for one drains all of them: the stream is read TWO records (four
+    // correspondences) per wait, the loads of the next two issued before the arithmetic of these two -- one wait per ~50 vector
+    // instructions with a full iteration of lookahead (a record per wait had the next record's loads and their wait ~25 instructions apart).
     const f32x2 R00 = { M.r00, M.r00 }, R01 = { M.r01, M.r01 }, R02 = { M.r02, M.r02 }, TX = { M.tx, M.tx };
     const f32x2 R10 = { M.r10, M.r10 }, R11 = { M.r11, M.r11 }, R12 = { M.r12, M.r12 }, TY = { M.ty, M.ty };
     const f32x2 R20 = { M.r20, M.r20 }, R21 = { M.r21, M.r21 }, R22 = { M.r22, M.r22 }, TZ = { M.tz, M.tz };
     const f32x2 SC = { 1048576.0f, 1048576.0f };
+    uint32_t q32 = 0;
+    auto pair_of = [&](const f32x2 px, const f32x2 py, const f32x2 pz, const f32x2 qx, const f32x2 qy, const f32x2 qz) {
+        const f32x2 x = __builtin_elementwise_fma(R00, px, __builtin_elementwise_fma(R01, py, __builtin_elementwise_fma(R02, pz, TX)));
+        const f32x2 y = __builtin_elementwise_fma(R10, px, __builtin_elementwise_fma(R11, py, __builtin_elementwise_fma(R12, pz, TY)));
+        const f32x2 z = __builtin_elementwise_fma(R20, px, __builtin_elementwise_fma(R21, py, __builtin_elementwise_fma(R22, pz, TZ)));
+        const f32x2 dx = x - qx, dy = y - qy, dz = z - qz;
+        const f32x2 d2 = __builtin_elementwise_fma(dx, dx, __builtin_elementwise_fma(dy, dy, dz * dz));
+        const f32x2 fx = d2 * SC;
+        const bool in0 = d2.x < thr2, in1 = d2.y < thr2;
+        cnt += (in0 ? 1u : 0u) + (in1 ? 1u : 0u);
+        q32 += (in0 ? (uint32_t)fx.x : 0u) + (in1 ? (uint32_t)fx.y : 0u);
+    };
     const int pend = end & ~1;
     for (int b0 = begin; b0 < pend; b0 += sub) {
         const int b1 = min(pend, b0 + sub);
-        uint32_t q32 = 0;
-#pragma unroll 4
-        for (int i = b0; i < b1; i += 2) {
+        q32 = 0;
+        int i = b0;
+        const f32x2 *rec = reinterpret_cast<const f32x2 *>(corr8);
+        if (i + 4 <= b1) {
+            f32x2 c0[6], c1[6], n0[6], n1[6];
+            auto load2 = [&](int at, f32x2 (&r0)[6], f32x2 (&r1)[6]) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) { r0[k] = rec[(size_t)(at >> 1) * 8 + k]; r1[k] = rec[(size_t)(at >> 1) * 8 + 8 + k]; }
+                __builtin_amdgcn_sched_barrier(0);       // (the loads stay ahead of the arithmetic that follows: left alone the scheduler sinks them to their use)
+            };
+            load2(i, c0, c1);
+            // ping-pong between two register sets (no copies); the last load of a sub-block re-reads its own records: no read past the stream
+            while (i + 4 <= b1) {
+                // (wait for the records in hand BEFORE the next loads are issued: scalar loads return out of order, a wait placed after
+                // them -- where the compiler would put it, at the first use -- drains the prefetch as well)
+                __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0)
+                load2(i + 8 <= b1 ? i + 4 : i, n0, n1);
+                pair_of(c0[0], c0[1], c0[2], c0[3], c0[4], c0[5]);
+                pair_of(c1[0], c1[1], c1[2], c1[3], c1[4], c1[5]);
+                i += 4;
+                if (i + 4 > b1) break;
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                load2(i + 8 <= b1 ? i + 4 : i, c0, c1);
+                pair_of(n0[0], n0[1], n0[2], n0[3], n0[4], n0[5]);
+                pair_of(n1[0], n1[1], n1[2], n1[3], n1[4], n1[5]);
+                i += 4;
+            }
+        }
+        if (i < b1) {        // one record left in the sub-block
             const f32x2 *q = rec + (size_t)(i >> 1) * 8;
-            const f32x2 px = q[0], py = q[1], pz = q[2], qx = q[3], qy = q[4], qz = q[5];
-            const f32x2 x = __builtin_elementwise_fma(R00, px, __builtin_elementwise_fma(R01, py, __builtin_elementwise_fma(R02, pz, TX)));
-            const f32x2 y = __builtin_elementwise_fma(R10, px, __builtin_elementwise_fma(R11, py, __builtin_elementwise_fma(R12, pz, TY)));
-            const f32x2 z = __builtin_elementwise_fma(R20, px, __builtin_elementwise_fma(R21, py, __builtin_elementwise_fma(R22, pz, TZ)));
-            const f32x2 dx = x - qx, dy = y - qy, dz = z - qz;
-            const f32x2 d2 = __builtin_elementwise_fma(dx, dx, __builtin_elementwise_fma(dy, dy, dz * dz));
-            const f32x2 fx = d2 * SC;
-            const bool in0 = d2.x < thr2, in1 = d2.y < thr2;
-            cnt += (in0 ? 1u : 0u) + (in1 ? 1u : 0u);
-            q32 += (in0 ? (uint32_t)fx.x : 0u) + (in1 ? (uint32_t)fx.y : 0u);
+            pair_of(q[0], q[1], q[2], q[3], q[4], q[5]);
         }
         ssq += q32;
     }
