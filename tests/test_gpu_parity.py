@@ -112,7 +112,8 @@ def test_nn_to_mutual_golden_and_arity(lr, filt):
     assert np.array_equal(is_bb, g["is_bb"]) and int(num_bb) == int(g["num_bb"])
 
 
-@pytest.mark.parametrize("n0,n1,seed", [(1000, 3000, 31), (3000, 1000, 32), (257, 255, 33)])
+@pytest.mark.parametrize("n0,n1,seed", [(1000, 3000, 31), (3000, 1000, 32), (257, 255, 33),
+                                       (8200, 8193, 34), (1023, 8195, 35)])      # (around the 1024 x 8 elements of a rank-kernel round)
 def test_nn_to_mutual_ragged_vs_oracle(lr, oracle, n0, n1, seed):
     F0, F1 = synth.make_features(n0, n1, 32, 0.5, 0.8, seed)
     i0, i1, i2, _ = oracle.find_2nn(F0, F1)
