@@ -1014,12 +1014,11 @@ nn16_rev_scan_kernel(int n0, int n1, const float *__restrict__ s1, const uint32_
 // pass 3: ranks.  Cloud-0 points: position in ascending-key order -> pos0 (nn16_rev_copy_kernel moves the f16 rows there).  Cloud-1
 // points with a seed: position in descending-s* order -> rowmap, threshold and empty candidate list at that position; the others get
 // rev = -1.
-// LR_RS_PARTS blocks per pair: every block reads ALL keys (cheap: 4 bytes each) and owns the buckets whose first position falls into
+// Several blocks per pair (8 in a full batch, up to 32 for a single pair: lr_nn16_reverse): every block reads ALL keys (cheap: 4 bytes each) and owns the buckets whose first position falls into
 // its share of the order; the rank of an element inside its bucket is an LDS atomic of the one block that owns the bucket.  (Round 2-3
 // took the ranks with one device-scope atomic per element on the bucket offsets and copied the row in the same thread: 60 000
 // returning atomics per pair, 3.7 us per pair -- 0.5 TB/s for a kernel that only moves 4 MB.)  The offsets stay what the scan
 // wrote: bucket b ends where bucket b + 1 starts.
-#define LR_RS_PARTS 8
 __global__ void __launch_bounds__(1024)
 nn16_rev_rank_kernel(int n0, int n1, const float *__restrict__ s1, const uint32_t *__restrict__ seed_bits,
                      const uint32_t *__restrict__ range, const int32_t *__restrict__ offs, const int32_t *__restrict__ n_rows,
@@ -1028,16 +1027,19 @@ nn16_rev_rank_kernel(int n0, int n1, const float *__restrict__ s1, const uint32_
                      int seg_counters, lr_zargs z)
 {
     __shared__ float s_m[16];
-    __shared__ int s_cnt[2 * LR_RS_BUCKETS];
+    // next free position of every bucket, starting from the scan's offsets.  Every key of the pair looks its bucket up in every block:
+    // from global memory that is 64 different cache lines per wave instruction (most of the kernel's time when it was tried)
+    __shared__ int s_pos[2 * LR_RS_BUCKETS];
+    __shared__ int s_own[4];                     // the block's bucket ranges [lo, hi) of the two sides
     if (z.descs) { n0 = z.descs[blockIdx.z].n0; n1 = z.descs[blockIdx.z].n1; nblk_c = (n0 + 31) >> 5; }
     lr_z(s1, z, blockIdx.z); lr_z(seed_bits, z, blockIdx.z); lr_z(range, z, blockIdx.z); lr_z(offs, z, blockIdx.z); lr_z(n_rows, z, blockIdx.z);
     lr_z(block_max_c, z, blockIdx.z); lr_z(nrm1, z, blockIdx.z); lr_z(pos0, z, blockIdx.z); lr_z(rowmap, z, blockIdx.z); lr_z(tau, z, blockIdx.z);
     lr_z(cand_cnt, z, blockIdx.z); lr_z(rev_out, z, blockIdx.z);
-    const int tid = threadIdx.x, lane = tid & 63, part = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, part = blockIdx.x, parts = gridDim.x;      // (parts: a power of two)
     // the segment counters of the reverse pass B start from zero (row blocks that use fewer strips than offered leave the
     // others untouched)
-    for (int k = part * 1024 + tid; k < seg_counters; k += LR_RS_PARTS * 1024) cand_cnt[k] = 0;
-    for (int k = tid; k < 2 * LR_RS_BUCKETS; k += 1024) s_cnt[k] = 0;
+    for (int k = part * 1024 + tid; k < seg_counters; k += parts * 1024) cand_cnt[k] = 0;
+    if (tid < 4) s_own[tid] = (tid & 1) ? 0 : 0x7fffffff;
     float mx = 0.0f;
     for (int b = tid; b < nblk_c; b += 1024) mx = fmaxf(mx, block_max_c[b]);
 #pragma unroll
@@ -1048,49 +1050,61 @@ nn16_rev_rank_kernel(int n0, int n1, const float *__restrict__ s1, const uint32_
 #pragma unroll
     for (int w = 0; w < 16; ++w) max_nc = fmaxf(max_nc, s_m[w]);
     const float lo = __uint_as_float(range[0]), scale = rs_scale(lo, __uint_as_float(range[1]));
-    // the part that owns a bucket: the one whose share [part, part + 1) * n / LR_RS_PARTS of the order holds the bucket's first position
-    // (products compared, no division in the loops)
-    const long long nrows = *n_rows;
-    const long long c_lo = (long long)part * n0, c_hi = (long long)(part + 1) * n0, r_lo = (long long)part * nrows, r_hi = (long long)(part + 1) * nrows;
-    // cloud 0: eight keys in flight per thread
-    for (int i0 = tid; i0 < n0; i0 += 8 * 1024) {
-        float v[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = s1[min(i0 + 1024 * k, n0 - 1)];
-        int start[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) start[k] = offs[rs_bucket(v[k], lo, scale)];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const long long sp = (long long)start[k] * LR_RS_PARTS;
-            if (i0 + 1024 * k < n0 && sp >= c_lo && sp < c_hi) pos0[i0 + 1024 * k] = start[k] + atomicAdd(&s_cnt[rs_bucket(v[k], lo, scale)], 1);
+    // the part that owns a bucket: the one whose share [part, part + 1) * n / parts of the order holds the bucket's first position -- a
+    // contiguous range of buckets per side, found here once (products compared, no division), so that the loops below only compare
+    // a key's bucket with the range
+    for (int k = tid; k < 2 * LR_RS_BUCKETS; k += 1024) s_pos[k] = offs[k];
+    __syncthreads();
+    {
+        // (the owned buckets of a side are contiguous: the two threads that sit on the range's ends write them -- no atomics)
+        const long long nrows = *n_rows;
+        for (int k = tid; k < 2 * LR_RS_BUCKETS; k += 1024) {
+            const int side = k >= LR_RS_BUCKETS, kb = k & (LR_RS_BUCKETS - 1);
+            const long long n = side ? nrows : (long long)n0, lo_p = (long long)part * n, hi_p = (long long)(part + 1) * n;
+            auto own = [&](int idx) { const long long sp = (long long)s_pos[idx] * parts; return sp >= lo_p && sp < hi_p; };
+            if (own(k)) {
+                if (kb == 0 || !own(k - 1)) s_own[2 * side] = k;
+                if (kb == LR_RS_BUCKETS - 1 || !own(k + 1)) s_own[2 * side + 1] = k + 1;
+            }
         }
     }
-    // cloud 1
-    for (int j0 = tid; j0 < n1; j0 += 8 * 1024) {
-        uint32_t v[8];
-        float nj[8];
+    __syncthreads();
+    const int c_lo = s_own[0], c_len = max(s_own[1] - s_own[0], 0), r_lo = s_own[2], r_len = max(s_own[3] - s_own[2], 0);
+    // cloud 0, then cloud 1: sixteen keys in flight per thread.  (What the kernel costs is the number of its sparsely populated memory
+    // instructions: every block walks all keys and stores under the ownership mask.  Measured for a single pair, 32 blocks: 17 us, of which
+    // 7.5 before the loops; neither requesting the keys at the top of the kernel nor dropping the LDS atomics changes that.)
+    constexpr int U = 16;
+    for (int i0 = tid; i0 < n0; i0 += U * 1024) {
+        float v[U];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { v[k] = seed_bits[min(j0 + 1024 * k, n1 - 1)]; nj[k] = nrm1[min(j0 + 1024 * k, n1 - 1)]; }
+        for (int k = 0; k < U; ++k) v[k] = s1[min(i0 + 1024 * k, n0 - 1)];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < U; ++k) {
+            const int b = rs_bucket(v[k], lo, scale);
+            if (i0 + 1024 * k < n0 && (unsigned)(b - c_lo) < (unsigned)c_len) pos0[i0 + 1024 * k] = atomicAdd(&s_pos[b], 1);
+        }
+    }
+    for (int j0 = tid; j0 < n1; j0 += U * 1024) {
+        uint32_t v[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) v[k] = seed_bits[min(j0 + 1024 * k, n1 - 1)];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
             const int row = j0 + 1024 * k;
             if (row >= n1) continue;
             const float sv = __uint_as_float(v[k]);
             if (!(sv <= 3.0e38f)) {      // still the 0x7f7f7f7f fill: no query points at this row
-                if ((row & (LR_RS_PARTS - 1)) == part) rev_out[row] = -1;
+                if ((row & (parts - 1)) == part) rev_out[row] = -1;
                 continue;
             }
             const int b = LR_RS_BUCKETS + (LR_RS_BUCKETS - 1 - rs_bucket(sv, lo, scale));
-            const int start = offs[b];
-            const long long sp = (long long)start * LR_RS_PARTS;
-            if (sp < r_lo || sp >= r_hi) continue;
-            const int p = start + atomicAdd(&s_cnt[b], 1);
-            const float scl = nj[k] + max_nc;
+            if ((unsigned)(b - r_lo) >= (unsigned)r_len) continue;
+            const int p = atomicAdd(&s_pos[b], 1);
+            const float nj = nrm1[row], scl = nj + max_nc;
             const float E = 1.05e-3f * scl + 4e-7f;
             const float d2hi = sv * sv * (1.0f + 6e-7f);               // every d2 whose sqrt rounds to <= sv lies below this
             rowmap[p] = row;
-            tau[p] = (d2hi - nj[k]) + E + 6e-6f * scl + 2e-6f * d2hi;
+            tau[p] = (d2hi - nj) + E + 6e-6f * scl + 2e-6f * d2hi;
         }
     }
 }
@@ -1136,7 +1150,8 @@ int lr_nn16_reverse(lr_workspace *ws, const float *F0, const _Float16 *H0, const
         hipLaunchKernelGGL(nn16_rev_seed_kernel, dim3(lr_cdiv(n0, 256)), dim3(256), 0, st, F0, nrm0, n0, F1, nrm1, fwd_idx1, seed, ws->rev_s1, range);
     hipLaunchKernelGGL(nn16_rev_scan_kernel, dim3(1, 1, ws->zP), dim3(1024), 0, st, n0, n1, (const float *)ws->rev_s1, (const uint32_t *)seed,
                        (const uint32_t *)range, ws->rev_hist, n_rows, tmin, ws->z);
-    hipLaunchKernelGGL(nn16_rev_rank_kernel, dim3(LR_RS_PARTS, 1, ws->zP), dim3(1024), 0, st, n0, n1, (const float *)ws->rev_s1,
+    const int rank_parts = ws->zP >= 16 ? 8 : ws->zP >= 4 ? 16 : 32;      // (a power of two; few pairs: more, smaller shares)
+    hipLaunchKernelGGL(nn16_rev_rank_kernel, dim3(rank_parts, 1, ws->zP), dim3(1024), 0, st, n0, n1, (const float *)ws->rev_s1,
                        (const uint32_t *)seed, (const uint32_t *)range, (const int32_t *)ws->rev_hist, (const int32_t *)n_rows, bmax0, lr_cdiv(nb, 32), nrm1,
                        ws->rev_pos, ws->rev_rows, ws->tau, ws->cand_cnt, rev, row_blocks * 4 * (strips + 1), ws->z);
     hipLaunchKernelGGL(nn16_rev_copy_kernel, dim3(lr_cdiv(4 * n0, 256), 1, ws->zP), dim3(256), 0, st, n0, (const int32_t *)ws->rev_pos, H0, nrm0,
