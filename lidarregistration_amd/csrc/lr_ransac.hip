@@ -501,7 +501,7 @@ ransac_score_kernel(const float *__restrict__ corr8, const float *__restrict__ c
                     const float *__restrict__ models, const float *__restrict__ models_s, uint32_t *__restrict__ score_cnt,
                     unsigned long long *__restrict__ score_ssq, const int32_t *__restrict__ counters, lr_score_info *__restrict__ info,
                     const int32_t *__restrict__ perm, const int32_t *__restrict__ glen, int sub, int model_stride, int vslot,
-                    int gx, int total, lr_zargs z)
+                    int gx, int total, int allow_prune, lr_zargs z)
 {
     // 1-D XCD-aware grid -> (block of the pair, pair): the blocks of one pair run on one XCD, whose L2 then serves the pair's
     // record stream (0.5 MB, read by every wave) and its models
@@ -514,7 +514,7 @@ ransac_score_kernel(const float *__restrict__ corr8, const float *__restrict__ c
     const int V = counters[vslot];           // LR_CNT_NVALID, or LR_CNT_NVALID2 behind the SPRT pre-verification
     const int hb = (V + 63) >> 6;
     if (hb == 0 || m <= 0 || reinterpret_cast<const lr_ransac_state *>(counters + LR_CNT_COUNT)->done) return;
-    const int K0 = lr_sc_head(m, V);
+    const int K0 = allow_prune ? lr_sc_head(m, V) : 0;     // (the host leaves the ordering passes out for short batches: same decision here)
     const int lane = threadIdx.x & 63;
     const size_t ms = (size_t)model_stride;
     // a block is four independent waves (one-wave blocks cap the CU at half its wave slots); wave w of the pair's gx blocks takes
@@ -1521,12 +1521,14 @@ int lr_ransac_run(lr_workspace *ws, const float *corr8, int m_max, const int32_t
             // (main: LR_SCORE_BLOCKS / 4 blocks for EVERY pair of a batched call: 64 per pair -- the GPU filled exactly once -- measured
             // 32 % slower, the few large work items of a pair do not balance)
             const float *mdl = sprt ? (const float *)ws->models2 : (const float *)ws->models;
-            const bool may_prune = m_max >= LR_SC_MIN_M && h1 - h0 >= LR_SC_MIN_V;      // (the device decides from the live counts)
+            // (the device decides from the live counts; a batch of up to 1 024 ids is scored in full -- its four ordering launches cost
+            // more than they save, and with the pre-check fewer than LR_SC_MIN_V of its ids survive anyway)
+            const bool may_prune = m_max >= LR_SC_MIN_M && h1 - h0 >= 2048;
             if (may_prune) {
                 const int hgx = 64, htotal = hgx * ws->zP;
                 hipLaunchKernelGGL(ransac_score_kernel<1>, dim3(8 * lr_cdiv(htotal, 8)), dim3(256), 0, st, corr8, (const float *)ws->corr8s, m_max, m_dev, p->thr2,
                                    mdl, (const float *)ws->models_s, ws->score_cnt, ws->score_ssq, ws->counters, info, (const int32_t *)ws->sc_perm, (const int32_t *)ws->sc_glen, sub,
-                                   ws->max_iters, vslot, hgx, htotal, ws->z);
+                                   ws->max_iters, vslot, hgx, htotal, 1, ws->z);
                 const dim3 cgrid(lr_cdiv(m_max, 256), 1, ws->zP);
                 hipLaunchKernelGGL(ransac_resid_kernel, cgrid, dim3(256), 0, st, corr8, m_max, m_dev, mdl, (const int32_t *)ws->counters, info, ws->sc_cb,
                                    ws->max_iters, vslot, ws->z);
@@ -1538,7 +1540,7 @@ int lr_ransac_run(lr_workspace *ws, const float *corr8, int m_max, const int32_t
             const int sgx = LR_SCORE_BLOCKS / 4, stotal = sgx * ws->zP;
             hipLaunchKernelGGL(ransac_score_kernel<0>, dim3(8 * lr_cdiv(stotal, 8)), dim3(256), 0, st, corr8, (const float *)ws->corr8s, m_max, m_dev, p->thr2,
                                mdl, (const float *)ws->models_s, ws->score_cnt, ws->score_ssq, ws->counters, info, (const int32_t *)ws->sc_perm, (const int32_t *)ws->sc_glen, sub,
-                               ws->max_iters, vslot, sgx, stotal, ws->z);
+                               ws->max_iters, vslot, sgx, stotal, may_prune ? 1 : 0, ws->z);
         }
         if (h0 == 0 && ws->timing && ws->ev_pending == 1) { LR_HIP(hipEventRecord(ws->ev[3], st)); ws->ev_pending = 2; }
         hipLaunchKernelGGL(ransac_final_kernel, dim3(1, 1, ws->zP), dim3(1024), 0, st, ws->score_cnt, ws->score_ssq,
