@@ -154,7 +154,7 @@ nn16_prep_kernel(const float *__restrict__ Fa, int na, _Float16 *__restrict__ Ha
 // byte offset of 16-byte piece p (K 8p..8p+7) of staged column j of a chunk: rows of 64 bytes, the piece index XOR-swizzled with bits
 // 1..2 of the column.  ds_read_b128 is served in four fixed groups of 16 lanes ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ...); with
 // the walk's lane map (column = lane % 16, piece = lane / 16) every group then reads 16 different 16-byte slots of the 256-byte bank
-// row -- conflict-free (unswizzled 64- or 80-byte rows: 2-way).  The sample phase's reads (column = lane % 32) are 2-way.
+// row -- conflict-free (unswizzled 64- or 80-byte rows: 2-way).  Both phases read with that lane map.
 __device__ __forceinline__ int lr_lds_off(int j, int p) { return j * LR_LDS_ROW + ((p ^ ((j >> 1) & 3)) << 4); }
 #define LR_BLOCK_ROWS 256        // rows per block: 4 waves x 64 rows (four 16-row MFMA blocks per wave)
 #ifndef LR_PB_CH
