@@ -199,6 +199,9 @@ struct lr_pb_grid { int gx, gy, total, dir; };
 #if LR_PB_EXP & 8
 __device__ unsigned long long lr_pb_clk[4096 * 2];      // development probe: shader clocks / 100 MHz ticks a block spent
 #endif
+#if LR_PB_EXP & 16
+__device__ unsigned long long lr_pb_stat[16];             // development probe: waves, tests, slow-path visits, hits, derive() rounds, 16-entry groups
+#endif
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *__restrict__ rowmap, const int32_t *__restrict__ na_dev,
                   const _Float16 *__restrict__ Hc, const float *__restrict__ nC, int nb,
@@ -233,14 +236,19 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     constexpr int XOFF = CH * 32 * LR_LDS_ROW;
     constexpr int BUF = XOFF + CH * 32 * 4;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
-    __shared__ uint2 wlist[4][LR_PB_WLIST];   // per wave: { column, (stale << 31) | (code << 8) | register mask }, code = rb*4 + (g0/8)*2 + h
-    __shared__ float whval[4][LR_PB_WLIST];   //           largest register - x_j of the entry
+    __shared__ uint2 wlist[4][LR_PB_WLIST];   // per wave: { column, (code << 8) | register mask (0 until derive() has seen the entry) }, code = (row-block pair q) * 4 + lane / 16
+    __shared__ float whval[4][LR_PB_WLIST];   //           filter value g of a single-row entry (LR_PB_HASG)
     // per row of the block: y = tau/2 (what the accumulators start from), the row's error term, the two largest g of the walk
     __shared__ __attribute__((aligned(16))) float s_Y[LR_BLOCK_ROWS];
     __shared__ float s_D[LR_BLOCK_ROWS], s_N1[LR_BLOCK_ROWS], s_N2[LR_BLOCK_ROWS];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int c16 = lane & 15, kb = lane >> 4;
     const int row0 = bx * LR_BLOCK_ROWS + wave * 64;
+#if LR_PB_EXP & 16
+    int n_visits = 0, n_hits = 0, n_rounds = 0, n_groups = 0, n_tk_derive = 0, n_tk_flush = 0;      // development probe: slow-path visits, hits, derive() rounds, 16-entry groups, 10 ns ticks
+    const unsigned long long tk_start = __builtin_amdgcn_s_memrealtime();
+    unsigned long long tk_walk = 0;
+#endif
     int ntiles = (nb + 31) >> 5;
     int my_strips = pg.gy;           // strips this row block really uses (the ordered reverse pass: as many as its column prefix is worth)
     if (tile_min) {
@@ -337,49 +345,74 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
             float m1[4], m2[4];           // running two largest (lane, tile) maxima of the lane's four rows (one per 16-row block)
 #pragma unroll
             for (int rbk = 0; rbk < 4; ++rbk) { m1[rbk] = -LR_INF; m2[rbk] = -LR_INF; }
-            // plain fmaxf (not inline asm): the compiler must see these reads of the MFMA results to place the wait states
-            // the hardware requires between an MFMA and a VALU read of its destination
+            // The phase is software-pipelined like the walk: two accumulator sets, the MFMAs of tile k are issued into one while tile k - 1
+            // is folded out of the other (the fold is inline asm -- no canonicalising v_max x, x, x -- and reads its registers at least
+            // eight MFMAs after they were issued: the hardware does not interlock a vector read of an MFMA result and the compiler does
+            // not see inside the asm, so scheduling barriers pin the order); the LDS fragments of tile k + 1 are requested before the
+            // MFMAs of tile k.  Unpipelined (round 3) the phase took 1.75x the walk's time per tile: 9 % of a block's lifetime.
             auto fold = [&](const f32x4 &lo4, const f32x4 &hi4, int rbk, float xmax) {
-                float t = fmaxf(fmaxf(lo4[0], lo4[1]), lo4[2]);
-                float u = fmaxf(fmaxf(lo4[3], hi4[0]), hi4[1]);
-                t = fmaxf(fmaxf(t, u), fmaxf(hi4[2], hi4[3])) - xmax;
-                const float lo = fminf(m1[rbk], t);
-                m1[rbk] = fmaxf(m1[rbk], t);
-                m2[rbk] = fmaxf(m2[rbk], lo);
+                float t, lo;
+                asm("v_max3_f32 %0, %2, %3, %4\n\tv_max3_f32 %0, %0, %5, %6\n\tv_max3_f32 %0, %0, %7, %8\n\tv_max_f32 %0, %0, %9\n\t"
+                    "v_sub_f32 %0, %0, %10\n\tv_min_f32 %1, %11, %0"
+                    : "=&v"(t), "=&v"(lo)
+                    : "v"(lo4[0]), "v"(lo4[1]), "v"(lo4[2]), "v"(lo4[3]), "v"(hi4[0]), "v"(hi4[1]), "v"(hi4[2]), "v"(hi4[3]), "v"(xmax), "v"(m1[rbk]));
+                asm("v_max_f32 %0, %0, %1" : "+v"(m1[rbk]) : "v"(t));
+                asm("v_max_f32 %0, %0, %1" : "+v"(m2[rbk]) : "v"(lo));
             };
             const f32x4 zero4 = { 0, 0, 0, 0 };
             const int frag16s = lr_lds_off(c16, kb);
+            f32x4 sA[8], sB[8];           // [rbk]: columns 0..15 of the tile, [4 + rbk]: columns 16..31
+            bool pend = false;            // the set that was filled last awaits its fold (false: its tile does not count)
+            float pend_x = 0.0f;
             if (nsch > 0) {
                 load_s(0); store_s(0);
                 __syncthreads();
                 for (int c = 0; c < nsch; ++c) {
                     const int buf = c & 1;
                     if (c + 1 < nsch) load_s(c + 1);
+                    // fragments of tile k: lane (c, kb) reads piece kb of columns c and 16 + c; in the result the lane holds query row c
+                    // of a row block and registers g <-> columns 4 kb + g of the column block
+                    const unsigned char *bp = &lds[buf * BUF + frag16s];
+                    f16x8 b0 = *reinterpret_cast<const f16x8 *>(bp), b1 = *reinterpret_cast<const f16x8 *>(bp + 16 * LR_LDS_ROW);
+                    float xmax = *reinterpret_cast<const float *>(&lds[buf * BUF + XOFF]);
 #pragma unroll
                     for (int k = 0; k < CH; ++k) {
-                        // fragments of tile k: lane (c, kb) reads piece kb of columns c and 16 + c; in the result the lane holds query row c
-                        // of a row block and registers g <-> columns 4 kb + g of the column block
-                        const unsigned char *bp = &lds[buf * BUF + frag16s + k * 32 * LR_LDS_ROW];
-                        const f16x8 b0 = *reinterpret_cast<const f16x8 *>(bp), b1 = *reinterpret_cast<const f16x8 *>(bp + 16 * LR_LDS_ROW);
-                        const float xmax = *reinterpret_cast<const float *>(&lds[buf * BUF + XOFF + k * 4]);
-                        f32x4 d0[4], d1[4];
+                        f16x8 n0 = b0, n1 = b1; float nx = xmax;
+                        if (k + 1 < CH) {
+                            n0 = *reinterpret_cast<const f16x8 *>(bp + (k + 1) * 32 * LR_LDS_ROW);
+                            n1 = *reinterpret_cast<const f16x8 *>(bp + (k + 1) * 32 * LR_LDS_ROW + 16 * LR_LDS_ROW);
+                            nx = *reinterpret_cast<const float *>(&lds[buf * BUF + XOFF + (k + 1) * 4]);
+                        }
+                        f32x4 (&cur)[8] = (k & 1) ? sB : sA;
+                        const f32x4 (&prev)[8] = (k & 1) ? sA : sB;
+                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int rbk = 0; rbk < 4; ++rbk) {
-                            d0[rbk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b0, a16[rbk], zero4, 0, 0, 0);
-                            d1[rbk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1, a16[rbk], zero4, 0, 0, 0);
+                            cur[rbk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b0, a16[rbk], zero4, 0, 0, 0);
+                            cur[4 + rbk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1, a16[rbk], zero4, 0, 0, 0);
                         }
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (pend) {
+#pragma unroll
+                            for (int rbk = 0; rbk < 4; ++rbk) fold(prev[rbk], prev[4 + rbk], rbk, pend_x);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
                         // Tiles past the end of the strip (the last chunk may reach beyond it) are not counted -- and neither is a
                         // PARTIAL last tile: its staged image repeats the cloud's last column in the padding, so a row whose best
                         // column is that one would get the same column as its best and its second best from two of the four lanes
                         // that share the row (the merge below relies on the lanes seeing disjoint columns) -- a threshold one
                         // neighbour too tight (found by tools/soak_fr.py, round 3; the walk of phase 2 still visits that tile).
-                        if (tile_s(c, k) < t_end && (tile_s(c, k) + 1) * 32 <= nb) {
-#pragma unroll
-                            for (int rbk = 0; rbk < 4; ++rbk) fold(d0[rbk], d1[rbk], rbk, xmax);
-                        }
+                        pend = tile_s(c, k) < t_end && (tile_s(c, k) + 1) * 32 <= nb;
+                        pend_x = xmax;
+                        b0 = n0; b1 = n1; xmax = nx;
                     }
                     if (c + 1 < nsch) store_s(buf ^ 1);
                     __syncthreads();
+                }
+                if (pend) {      // the last tile sits in set B (CH is even); an explicit wait covers the MFMA write latency
+                    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+                    for (int rbk = 0; rbk < 4; ++rbk) fold(sB[rbk], sB[4 + rbk], rbk, pend_x);
                 }
             }
             // the four lanes of a row (kb = 0..3: disjoint columns) merge their pairs in two exchange rounds; lane kb = 0 writes the row's
@@ -416,6 +449,9 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         for (int rbk = 0; rbk < 4; ++rbk) y4[rbk] = *reinterpret_cast<const f32x4 *>(&s_Y[wave * 64 + 16 * rbk + 4 * kb]);
     };
     load_y();
+#if LR_PB_EXP & 16
+    tk_walk = __builtin_amdgcn_s_memrealtime();
+#endif
     // staging of the walk: buffer loads -- the chunk's position is a scalar offset, the thread's place in it a constant vector
     // offset (no address arithmetic on the vector pipe), and rows past the end of the cloud read as zeros (range check of the
     // buffer descriptor) instead of being clamped: their x_j is +inf below, so they never pass the test.  Thread t moves the two
@@ -450,6 +486,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         xj.y = *reinterpret_cast<const float *>(&lds[xo + k * 32 * 4 + 64]);
     };
     int wcnt = 0;            // entries in this wave's list (wave-uniform: lives in a scalar register)
+    const unsigned code_kb = (unsigned)kb << 8;
     int wdone = 0;           // ... of which the tightening has seen this many
     // The wave owns one segment of the candidate store: seg[(row block, wave, strip)][seg_cap] entries { column, code | mask }
     // exactly as they lie in its LDS list.  Emptying the list is a compacting copy with plain stores -- no atomics, nothing
@@ -460,41 +497,91 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     uint2 *__restrict__ seg = reinterpret_cast<uint2 *>(cand) + (size_t)(bx * 4 + wave) * LR_NN16_SEG + (size_t)by * seg_cap;
     int seg_fill = 0;
     const bool tightening = thr.nQ != nullptr && !(LR_PB_EXP & 4);
-    // one tightening round (wave-local): entries [wdone, wcnt) -> the rows' two largest g -> y -> threshold registers.
-    // Returns with every lane's registers reloaded; the accumulators in flight were started from the OLD values (see `stale`).
-    auto tighten = [&]() {
+    // One round over the new entries [wdone, wcnt) of the wave's list (wave-local).  The slow path of the walk only parks { column,
+    // register group } of a hit; WHICH of the group's 8 rows passed, and with what filter value, is worked out here, 16 entries at a
+    // time, by the matrix pipe itself: lane (c, kb) fetches K slice kb of the column of entry e0 + c (one 16-byte gather), four
+    // v_mfma_f32_16x16x32_f16 with the row fragments and the thresholds of NOW give it y_i + dot16 of that column against rows
+    // 16 rbk + 4 kb + 0..3 -- the same instruction on the same operands as the walk, so the same bits -- and the lane whose kb is the
+    // entry's compares the group's 8 registers with x_j: 2 vector instructions per entry and register instead of 16 per hit and wave.
+    // Thresholds only ever decrease, so a mask taken against the thresholds of now is a subset of the one the walk saw and still a
+    // superset of what the final thresholds admit; an entry that no longer passes any row is dropped on the spot.
+    // update: (forward direction, and the reverse one when it is given the rows' error terms) the two largest g of every row ->
+    // y -> threshold registers.  An entry with a single row keeps its g = dot16 - x_j for the drop tests of flush() and
+    // nn16_exact_kernel.
+    auto derive = [&](bool update) {
         const int nlist = min(wcnt, LR_PB_WLIST);
+#if LR_PB_EXP & 16
+        ++n_rounds; n_groups += (nlist - wdone + 15) >> 4;
+        const unsigned long long tk0 = __builtin_amdgcn_s_memrealtime();
+#endif
         for (int e0 = wdone; e0 < nlist; e0 += 64) {
-            const int e = e0 + lane;
-            if (e < nlist) {
-                const uint2 v = wlist[wave][e];
-                const unsigned mask = v.y & 0xffu;
-                if ((mask & (mask - 1u)) == 0u && !(v.y >> 31)) {       // exactly one register (the mask of a hit is never empty)
-                    const int rl = wave * 64 + lr_pb_row((int)(v.y >> 8) & 0xf, 7 - __builtin_ctz(mask));
-                    // the register held y_row + dot16 and h = register - x_j, so g = dot16 - x_j = h - y_row (the y of now: entries
-                    // made before the last reload have been seen by the round that did it, the tile in between is flagged stale)
-                    const float gv = whval[wave][e] - s_Y[rl];
-                    const float old = atomicMax(&s_N1[rl], gv);
-                    atomicMax(&s_N2[rl], fminf(old, gv));
-                    // the entry keeps its g: an entry admitted by an early, loose threshold is dropped again -- when the list is
-                    // emptied, or by nn16_exact_kernel -- once the row's threshold has moved past it (no gather, no distance)
-                    whval[wave][e] = gv;
-                    wlist[wave][e].y = v.y | LR_PB_HASG;
+            // up to four groups of 16 entries per pass: all their gathers are in flight before the first MFMA (one L2 latency per pass)
+            uint2 v[4]; f16x8 bf[4]; float xn[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                v[g] = wlist[wave][min(e0 + 16 * g + c16, LR_PB_WLIST - 1)];
+                const int col = (int)v[g].x;
+                bf[g] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrcH, col * 64 + kb * 16, 0, 0));
+                xn[g] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrcN, col * 4, 0, 0));
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (e0 + 16 * g >= nlist) break;              // (wave-uniform)
+                const int e = e0 + 16 * g + c16;
+                const bool valid = e < nlist;
+                const int col = (int)v[g].x;
+                // padding columns (past the end of the cloud or of the strip) pass the walk's test only when the threshold is +inf
+                const float x = (valid && col < nb && (col >> 5) < t_end) ? 0.5f * xn[g] : LR_INF;
+                f32x4 d[4];
+#pragma unroll
+                for (int rbk = 0; rbk < 4; ++rbk) d[rbk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[rbk], bf[g], y4[rbk], 0, 0, 0);
+                const int code = (int)(v[g].y >> 8) & 0xf;
+                if (valid && (code & 3) == kb) {
+                    const bool q1 = (code >> 2) != 0;
+                    float r8[8];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { r8[k] = q1 ? d[2][k] : d[0][k]; r8[4 + k] = q1 ? d[3][k] : d[1][k]; }
+                    // register i <-> bit 7 - i; set unless acc < x (a NaN accumulator -- non-finite f16 operands -- stays a candidate: rows
+                    // with such operands are re-done by the exact full-row scan, columns only add candidates the exact stage orders)
+                    unsigned mask = 0u;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) mask |= (r8[i] < x) ? 0u : (0x80u >> i);
+                    unsigned y = (unsigned)(code << 8) | mask;       // mask 0: the entry is dropped when the list is emptied
+                    if (update && mask != 0u && (mask & (mask - 1u)) == 0u) {
+                        const int i = 7 - __builtin_ctz(mask);
+                        const int rl = wave * 64 + lr_pb_row(code, i);
+                        float m = r8[0];
+#pragma unroll
+                        for (int k = 1; k < 8; ++k) m = (mask >> (7 - k)) & 1u ? r8[k] : m;
+                        // the register holds y_row + dot16, so g = dot16 - x_j = (register - x_j) - y_row
+                        const float gv = (m - x) - s_Y[rl];
+                        const float old = atomicMax(&s_N1[rl], gv);
+                        atomicMax(&s_N2[rl], fminf(old, gv));
+                        whval[wave][e] = gv;
+                        y |= LR_PB_HASG;
+                    }
+                    wlist[wave][e].y = y;
                 }
             }
         }
         wdone = nlist;
-        // lane = row: y <- min(y, E' - g_need + 2e-6 |g_need|)   (g_need: the need-th largest g of the walk so far; -inf: no change)
-        {
+        if (update) {
+            // lane = row: y <- min(y, E' - g_need + 2e-6 |g_need|)   (g_need: the need-th largest g of the walk so far; -inf: no change)
             const int rl = wave * 64 + lane;
             const float gn = thr.need >= 2 ? s_N2[rl] : s_N1[rl];
             const float yn = (s_D[rl] - gn) + 2e-6f * fabsf(gn);
             if (yn < s_Y[rl]) s_Y[rl] = yn;                 // (NaN compares false: the row keeps its threshold)
+            load_y();
         }
-        load_y();
+#if LR_PB_EXP & 16
+        n_tk_derive += (int)(__builtin_amdgcn_s_memrealtime() - tk0);
+#endif
     };
     auto flush = [&]() {
-        if (tightening && wdone < wcnt) tighten();
+        if (wdone < wcnt) derive(tightening);
+#if LR_PB_EXP & 16
+        const unsigned long long tkf = __builtin_amdgcn_s_memrealtime();
+#endif
         if (wcnt > LR_PB_WLIST) seg_fill = -1;       // more hits between two chunk boundaries than the list holds
         else if (seg_fill >= 0) {
             for (int e0 = 0; e0 < wcnt; e0 += 64) {
@@ -503,7 +590,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
                 if (e < wcnt) v = wlist[wave][e];
                 v.y &= 0x7fffffffu;
                 // padding columns pass the test only when tau is +inf
-                bool keep = e < wcnt && (int)v.x < nb && ((int)v.x >> 5) < t_end;
+                bool keep = e < wcnt && (v.y & 0xffu) != 0u && (int)v.x < nb && ((int)v.x >> 5) < t_end;
                 if (v.y & LR_PB_HASG) {
                     // g of the entry against the row's threshold of NOW (candidate <=> g >= -y): what an earlier, looser threshold let
                     // in is dropped here; what stays carries g rounded UP to 16 bits for the same test against the final threshold
@@ -525,9 +612,14 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
             }
         }
         wcnt = 0; wdone = 0;
+#if LR_PB_EXP & 16
+        n_tk_flush += (int)(__builtin_amdgcn_s_memrealtime() - tkf);
+#endif
     };
-    // candidate test of 8 accumulator registers: row blocks 2q, 2q + 1 (32 rows) x column block cb (16 columns) of the wave's tile
-    auto check = [&](const f32x4 &lo4, const f32x4 &hi4, float x, int col, int q, unsigned stale) {
+    // candidate test of 8 accumulator registers: row blocks 2q, 2q + 1 (32 rows) x column block cb (16 columns) of the wave's tile.
+    // A hit only parks { column, register group } -- 2 + 4 vector instructions and one LDS write; everything else about it is worked
+    // out later, 16 entries per instruction group (derive()).
+    auto check = [&](const f32x4 &lo4, const f32x4 &hi4, float x, int col, int q) {
 #if LR_PB_EXP & 2
         asm volatile("" :: "v"(lo4), "v"(hi4));
         return;
@@ -539,23 +631,13 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         const unsigned long long hit = __builtin_amdgcn_ballot_w64(m >= x);
         if (__builtin_expect(hit != 0ull, 0)) {       // rare: keeps the common path a fall-through
             if (m >= x) {
-                // which of the 8 registers: the sign of (acc - x) is shifted into the mask register by register (2 VALU ops
-                // each, no SGPR round trip).  Register i ends up in bit 7 - i; a set bit means acc < x.  A NaN accumulator
-                // (non-finite f16 operands) may read as a hit: rows with such operands are re-done by the exact full-row
-                // scan (nn16_exact_kernel tests the query row), columns only add candidates that the exact stage orders.
-                unsigned below = 0;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) below = __builtin_amdgcn_alignbit(below, __float_as_uint(lo4[g] - x), 31);
-#pragma unroll
-                for (int g = 0; g < 4; ++g) below = __builtin_amdgcn_alignbit(below, __float_as_uint(hi4[g] - x), 31);
-                const unsigned mask = ~below & 0xffu;
                 const int pos = wcnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(hit >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hit, 0u));
-                if (pos < LR_PB_WLIST) {
-                    wlist[wave][pos] = make_uint2((unsigned)col, mask | (unsigned)((q * 4 + kb) << 8) | (stale << 31));
-                    whval[wave][pos] = m - x;
-                }
+                if (pos < LR_PB_WLIST) wlist[wave][pos] = make_uint2((unsigned)col, (unsigned)(q << 10) | code_kb);
             }
             wcnt += __builtin_popcountll(hit);
+#if LR_PB_EXP & 16
+            ++n_visits; n_hits += __builtin_popcountll(hit);
+#endif
         }
     };
 
@@ -574,31 +656,30 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
 
     // one pipeline step: tests of the previous tile group by group, each followed by the MFMAs of tile (c, k) into the registers just
     // tested; LDS read of the next tile
-    auto step = [&](int c, int k, unsigned stale) {
+    auto step = [&](int c, int k) {
         f16x8 n0, n1; f32x2 nx;
         if (k + 1 < CH) read_b(fo_cur, xo_cur, k + 1, n0, n1, nx);
         else read_b(fo_oth, xo_oth, 0, n0, n1, nx);
         const int colC = (t_begin + c * CH + k - 1) * 32 + c16;
 #define MF(rbk, cb, b) acc[rbk][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[rbk], b, y4[rbk], 0, 0, 0)
-        check(acc[0][0], acc[1][0], xC.x, colC, 0, stale);
+        check(acc[0][0], acc[1][0], xC.x, colC, 0);
         MF(0, 0, b0); MF(1, 0, b0);
-        check(acc[2][0], acc[3][0], xC.x, colC, 1, stale);
+        check(acc[2][0], acc[3][0], xC.x, colC, 1);
         MF(2, 0, b0); MF(3, 0, b0);
-        check(acc[0][1], acc[1][1], xC.y, colC + 16, 0, stale);
+        check(acc[0][1], acc[1][1], xC.y, colC + 16, 0);
         MF(0, 1, b1); MF(1, 1, b1);
-        check(acc[2][1], acc[3][1], xC.y, colC + 16, 1, stale);
+        check(acc[2][1], acc[3][1], xC.y, colC + 16, 1);
         MF(2, 1, b1); MF(3, 1, b1);
 #undef MF
         b0 = n0; b1 = n1; xC = xN; xN = nx;
     };
-    auto drain = [&](unsigned stale) {
+    auto drain = [&]() {
         const int colC = (t_begin + nchunks * CH - 1) * 32 + c16;
-        check(acc[0][0], acc[1][0], xC.x, colC, 0, stale);
-        check(acc[2][0], acc[3][0], xC.x, colC, 1, stale);
-        check(acc[0][1], acc[1][1], xC.y, colC + 16, 0, stale);
-        check(acc[2][1], acc[3][1], xC.y, colC + 16, 1, stale);
+        check(acc[0][0], acc[1][0], xC.x, colC, 0);
+        check(acc[2][0], acc[3][0], xC.x, colC, 1);
+        check(acc[0][1], acc[1][1], xC.y, colC + 16, 0);
+        check(acc[2][1], acc[3][1], xC.y, colC + 16, 1);
     };
-    unsigned stale = 0u;     // 1: the accumulators awaiting their test were started from thresholds that have been reloaded since
     if (nchunks > 0) {
         load_chunk(0); store_chunk(0);
         __syncthreads();
@@ -625,15 +706,13 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
                         if (c + 2 < nchunks) load_chunk(c + 2);
 #endif
                     }
-                    step(c, k, k == 0 ? stale : 0u);
-                    if (k == 0) stale = 0u;
+                    step(c, k);
                 }
                 { const int t0 = fo_cur; fo_cur = fo_oth; fo_oth = t0; const int t1 = xo_cur; xo_cur = xo_oth; xo_oth = t1; }
                 attention = wcnt >= LR_PB_WLIST / 2 || (tightening && wcnt - wdone >= LR_PB_TIGHTEN);
             }
             if (attention) {
-                if (wcnt >= LR_PB_WLIST / 2) flush(); else tighten();
-                stale = tightening ? 1u : 0u;
+                if (wcnt >= LR_PB_WLIST / 2) flush(); else derive(true);
             }
         }
         // drain: the last tile of the last chunk sits in the accumulators.  The inline-asm maxima below read MFMA results the
@@ -641,7 +720,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         // MFMAs behind its producer; here an explicit wait covers the 8-pass MFMA write latency.
         {
             asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-            drain(stale);
+            drain();
         }
         flush();           // (with a last tightening round: the entries get their g, the rows their final thresholds)
     }
@@ -652,6 +731,15 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     }
 #if LR_PB_EXP & 8
     if (threadIdx.x == 0 && logical < 4096) { lr_pb_clk[2 * logical] = __builtin_readcyclecounter() - clk0; lr_pb_clk[2 * logical + 1] = __builtin_amdgcn_s_memrealtime() - rt0; }
+#endif
+#if LR_PB_EXP & 16
+    if (lane == 0) {
+        atomicAdd(&lr_pb_stat[0], 1ull); atomicAdd(&lr_pb_stat[1], (unsigned long long)nchunks * CH * 4); atomicAdd(&lr_pb_stat[2], (unsigned long long)n_visits);
+        atomicAdd(&lr_pb_stat[3], (unsigned long long)n_hits); atomicAdd(&lr_pb_stat[4], (unsigned long long)n_rounds); atomicAdd(&lr_pb_stat[5], (unsigned long long)n_groups);
+        const unsigned long long tk_end = __builtin_amdgcn_s_memrealtime();
+        atomicAdd(&lr_pb_stat[6], (unsigned long long)n_tk_derive); atomicAdd(&lr_pb_stat[7], (unsigned long long)n_tk_flush);
+        atomicAdd(&lr_pb_stat[8], tk_walk - tk_start); atomicAdd(&lr_pb_stat[9], tk_end - tk_start);
+    }
 #endif
     // the rows' final thresholds (wave-local: every wave writes its own 64 rows): nn16_exact_kernel drops the entries they exclude
     if (yfin) {

@@ -1,7 +1,10 @@
 // Timing harness for the batched filter pass (nn16_passb_kernel: sample phase + walk) (development tool): P identical pairs in P arenas.
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form=1 [-DLR_PB_EXP=k] tools/pb_micro.hip -o tools/bin/pb_micro_k
 //   usage: pb_micro [n=30000] [P=32] [strips=1]
-#include "../lidarregistration_amd/csrc/lr_nn16.hip"
+#ifndef PB_SRC
+#define PB_SRC "../lidarregistration_amd/csrc/lr_nn16.hip"
+#endif
+#include PB_SRC
 #include <vector>
 #include <algorithm>
 #include <random>
@@ -14,6 +17,16 @@ template <class F> float timeit(F f, int reps = 8) {
     for (int r = 0; r < reps; ++r) { hipEventRecord(e0, 0); f(); hipEventRecord(e1, 0); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); best = ms < best ? ms : best; }
     return best;
 }
+static void print_clk(int total)
+{
+#if LR_PB_EXP & 8
+    std::vector<unsigned long long> ck(8192); hipMemcpyFromSymbol(ck.data(), HIP_SYMBOL(lr_pb_clk), 65536);
+    std::vector<double> mhz, us;
+    for (int i = 0; i < 4096 && i < total; ++i) if (ck[2 * i + 1] > 100) { mhz.push_back((double)ck[2 * i] / ck[2 * i + 1] * 100.0); us.push_back(ck[2 * i + 1] / 100.0); }
+    std::sort(mhz.begin(), mhz.end()); std::sort(us.begin(), us.end());
+    if (!mhz.empty()) printf("  shader clock while a block runs: median %.0f MHz (p10 %.0f, p90 %.0f); block lifetime median %.1f us\n", mhz[mhz.size() / 2], mhz[mhz.size() / 10], mhz[mhz.size() * 9 / 10], us[us.size() / 2]);
+#endif
+}
 int main(int argc, char **argv)
 {
     const int n = argc > 1 ? atoi(argv[1]) : 30000, P = argc > 2 ? atoi(argv[2]) : 32, strips = argc > 3 ? atoi(argv[3]) : 1;
@@ -23,7 +36,7 @@ int main(int argc, char **argv)
     // arena layout (bytes): H | nrm | bmax | pu1 | pu2 | tau | cnt | cand
     size_t off = 0; auto take = [&](size_t b) { size_t o = off; off = (off + b + 255) & ~size_t(255); return o; };
     const size_t oH = take((size_t)n * 64), oN = take((size_t)n * 4), oB = take((size_t)(n / 32 + 2) * 4), o1 = take((size_t)n * 4 * 8), o2 = take((size_t)n * 4 * 8),
-                 oT = take((size_t)n * 4), oC = take(LR_NN16_CNT_INTS(n) * 4), oD = take(LR_NN16_SEG_INTS(n) * 4);
+                 oT = take((size_t)n * 4), oY = take((size_t)n * 4 * 8), oC = take(LR_NN16_CNT_INTS(n) * 4), oD = take(LR_NN16_SEG_INTS(n) * 4);
     const size_t stride = off;
     char *base; hipMalloc(&base, stride * P); hipMemset(base, 0, stride * P);
     float *F; hipMalloc(&F, (size_t)n * 128); hipMemcpy(F, h.data(), (size_t)n * 128, hipMemcpyHostToDevice);
@@ -51,6 +64,45 @@ int main(int argc, char **argv)
         std::vector<int32_t> c1(nseg); hipMemcpy(c1.data(), cnt, (size_t)nseg * 4, hipMemcpyDeviceToHost);
         double tot = 0; int over = 0; for (int i = 0; i < nseg; ++i) if (i % (strips + 1) != strips) { if (c1[i] < 0) over++; else tot += c1[i]; }
         printf("filter pass need=%d sample stride %2d: %8.3f ms  = %6.1f us/pair   list entries/row %.2f  overflowed segments %d\n", need, sstride, msp, msp * 1e3 / P, tot / n, over);
+        print_clk(total);
+#if LR_PB_EXP & 16
+        {
+            unsigned long long z8[16] = {0}, st[16];
+            hipMemcpyToSymbol(HIP_SYMBOL(lr_pb_stat), z8, sizeof z8); run(); hipDeviceSynchronize();
+            hipMemcpyFromSymbol(st, HIP_SYMBOL(lr_pb_stat), sizeof st);
+            printf("    per wave: tests %.0f  slow-path visits %.1f (one per %.1f tests)  hits %.1f (%.2f per row)  derive rounds %.1f  16-entry groups %.1f\n",
+                   (double)st[1] / st[0], (double)st[2] / st[0], (double)st[1] / (double)(st[2] ? st[2] : 1), (double)st[3] / st[0], (double)st[3] / st[0] / 64.0, (double)st[4] / st[0], (double)st[5] / st[0]);
+            printf("    per wave, us: lifetime %.1f  before the walk (thresholds / sample phase) %.1f  derive rounds %.1f  list flushes %.1f\n",
+                   (double)st[9] / st[0] / 100.0, (double)st[8] / st[0] / 100.0, (double)st[6] / st[0] / 100.0, (double)st[7] / st[0] / 100.0);
+        }
+#endif
+    }
+    {
+        // the walk alone on REAL thresholds: the final thresholds of a tightening run (stride 16) given as tau -> no sample phase, no
+        // tightening, only the true candidates hit (accumulators hold real values, unlike the -1e30 run below)
+        float *yf = (float *)(base + oY);
+        lr_thr_in thr = { nrm, bmax, (n+31)/32, 2, 16 };
+        hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), 0, 0, H, n, (const int32_t*)nullptr, (const int32_t*)nullptr, H, nrm, n, tps, (const float*)nullptr, cnt, cand,
+                           (const int32_t*)nullptr, (const float*)nullptr, (const uint32_t*)nullptr, (const int32_t*)nullptr, (const uint32_t*)nullptr, yf, n, thr, lr_pb_grid{ row_blocks, strips, total, 0 }, z);
+        hipDeviceSynchronize();
+        std::vector<float> y((size_t)n * strips), t(n);
+        hipMemcpy(y.data(), yf, (size_t)n * strips * 4, hipMemcpyDeviceToHost);
+        for (int i = 0; i < n; ++i) { float m = y[i]; for (int sidx = 1; sidx < strips; ++sidx) m = std::min(m, y[(size_t)sidx * n + i]); t[i] = 2.0f * m; }
+        for (int p = 0; p < P; ++p) hipMemcpy((char *)tau + p * stride, t.data(), (size_t)n * 4, hipMemcpyHostToDevice);
+        auto run = [&] { hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), 0, 0, H, n, (const int32_t*)nullptr, (const int32_t*)nullptr, H, nrm, n, tps, (const float*)tau, cnt, cand,
+                                            (const int32_t*)nullptr, (const float*)nullptr, (const uint32_t*)nullptr, (const int32_t*)nullptr, (const uint32_t*)nullptr, (float*)nullptr, 0, lr_thr_in{}, lr_pb_grid{ row_blocks, strips, total, 0 }, z); };
+        float msp = timeit([&] { run(); });
+        const int nseg = row_blocks * 4 * (strips + 1);
+        std::vector<int32_t> c1(nseg); hipMemcpy(c1.data(), cnt, (size_t)nseg * 4, hipMemcpyDeviceToHost);
+        double tot = 0; for (int i = 0; i < nseg; ++i) if (i % (strips + 1) != strips && c1[i] > 0) tot += c1[i];
+        printf("walk only, final thresholds given: %8.3f ms  = %6.1f us/pair   list entries/row %.2f\n", msp, msp * 1e3 / P, tot / n);
+        print_clk(total);
+        // the same thresholds moved out of reach (tau - 0.5: accumulators of the same magnitude, nothing passes)
+        for (int i = 0; i < n; ++i) t[i] -= 0.5f;
+        for (int p = 0; p < P; ++p) hipMemcpy((char *)tau + p * stride, t.data(), (size_t)n * 4, hipMemcpyHostToDevice);
+        msp = timeit([&] { run(); });
+        printf("walk only, final thresholds - 0.5 (no hits, real accumulators): %8.3f ms  = %6.1f us/pair\n", msp, msp * 1e3 / P);
+        print_clk(total);
     }
     {
         std::vector<float> t(n, -1e30f);
@@ -58,13 +110,7 @@ int main(int argc, char **argv)
         float msp = timeit([&] { hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), 0, 0, H, n, (const int32_t*)nullptr, (const int32_t*)nullptr, H, nrm, n, tps, (const float*)tau, cnt, cand,
                                                     (const int32_t*)nullptr, (const float*)nullptr, (const uint32_t*)nullptr, (const int32_t*)nullptr, (const uint32_t*)nullptr, (float*)nullptr, 0, lr_thr_in{}, lr_pb_grid{ row_blocks, strips, total, 0 }, z); });
         printf("walk only, no candidates:       %8.3f ms  = %6.1f us/pair\n", msp, msp * 1e3 / P);
-#if LR_PB_EXP & 8
-        std::vector<unsigned long long> ck(8192); hipMemcpyFromSymbol(ck.data(), HIP_SYMBOL(lr_pb_clk), 65536);
-        std::vector<double> mhz, us;
-        for (int i = 0; i < 4096 && i < total; ++i) if (ck[2 * i + 1] > 100) { mhz.push_back((double)ck[2 * i] / ck[2 * i + 1] * 100.0); us.push_back(ck[2 * i + 1] / 100.0); }
-        std::sort(mhz.begin(), mhz.end()); std::sort(us.begin(), us.end());
-        if (!mhz.empty()) printf("  shader clock while a block runs: median %.0f MHz (p10 %.0f, p90 %.0f); block lifetime median %.1f us\n", mhz[mhz.size() / 2], mhz[mhz.size() / 10], mhz[mhz.size() * 9 / 10], us[us.size() / 2]);
-#endif
+        print_clk(total);
     }
     return 0;
 }
