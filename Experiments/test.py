@@ -9,7 +9,8 @@ FCGF_FAST/test.py:86-106).  Datasets and FCGF weights are not part of this repo;
   0. the reference's cloud cache (env LIDARREG_CLOUD_CACHE=<dir with <session>_<idx>.npy>, voxel-deduplicated on the GPU like the
      reference's loader) + a feature cache for the same voxelisation + LIDARREG_BALANCED_SETS,
   1. a feature cache  (env LIDARREG_FEATURE_CACHE=<dir> + LIDARREG_BALANCED_SETS=<dir with <set>/<phase>.txt>),
-  2. the list-driven synthetic surrogate (LIDARREG_BALANCED_SETS only: GT motion + overlap from the list rows),
+  2. the list-driven synthetic surrogate (GT motion + overlap from the list rows: LIDARREG_BALANCED_SETS, or for --dataset A / B
+     the full test lists committed under tests/golden/lists),
   3. plain synthetic pairs (--dataset synthetic --num_pairs P).
 """
 import argparse
@@ -18,6 +19,7 @@ import logging
 import os
 import sys
 import tempfile
+import time
 from glob import glob
 
 import numpy as np
@@ -62,7 +64,9 @@ def get_args(argv=None):
     p.add_argument("--num_pairs", type=int, default=32, help="synthetic: number of pairs")
     p.add_argument("--synthetic_n", type=int, default=30000, help="synthetic: points per cloud")
     p.add_argument("--seed", type=int, default=51)
-    p.add_argument("--in_flight", type=int, default=4, help="pairs in flight per GPU")
+    p.add_argument("--batch", type=int, default=32, help="list rows per batched call (lr_register_batch: every kernel launched once for all of them)")
+    p.add_argument("--in_flight", type=int, default=6, help="batched calls per window (each on its own workspace, round-robin over 3 streams); with --serial: pairs in flight")
+    p.add_argument("--serial", type=str2bool, default=False, help="one lr_register_pair per list row, like the reference harness (cross-check / latency)")
     p.add_argument("--icp", type=str2bool, default=True, help="refine by point-to-point ICP and fill stats columns 11-14 (test.py:183-193)")
     p.add_argument("--o3d_conf", type=float, default=0.9995, help="confidence of the open3D codebase (FR.py:136)")
     args = p.parse_args(argv)
@@ -86,6 +90,11 @@ def make_source(args):
         if cache:
             return harness.CacheSource(lst, os.path.join(cache, args.dataset_name, args.phase))
         return harness.SyntheticSource(len(lst["session"]), n=args.synthetic_n, seed=args.seed, pair_list=lst)
+    if args.dataset in ("A", "B") and args.phase == "test":
+        # no list directory given: the reference's FULL balanced test lists as committed fixtures (tests/golden/lists, made from
+        # balanced_sets/<set>/test.txt) drive the synthetic surrogate -- 7008 / 2592 rows
+        lst = harness.load_list_fixture(args.dataset)
+        return harness.SyntheticSource(len(lst["session"]), n=args.synthetic_n, seed=args.seed, pair_list=lst)
     return harness.SyntheticSource(args.num_pairs, n=args.synthetic_n, seed=args.seed)
 
 
@@ -96,7 +105,20 @@ def test_subset(args):
     P = len(source) if args.max_samples is None else min(len(source), args.max_samples)
     idx = shard.shard_indices(P, args.world_size, args.rank)
     print("process %d, GPU: cuda:%d, %d pairs" % (args.rank, torch.cuda.current_device(), len(idx)))
-    stats, T = harness.eval_pairs(source, idx, args, in_flight=args.in_flight, verbose=args.rank == 0)
+    t0 = time.time()
+    if args.serial:
+        stats, T = harness.eval_pairs_serial(source, idx, args, in_flight=min(args.in_flight, 4), verbose=args.rank == 0)
+    else:
+        stats, T = harness.eval_pairs(source, idx, args, batch=args.batch, in_flight=args.in_flight, verbose=False)
+    wall = time.time() - t0
+    msg = "process %d: %d pairs in %.2f s end to end (data source + registration + ICP + statistics): %.1f pairs/s" % (args.rank, len(idx), wall, len(idx) / max(wall, 1e-9))
+    if not args.serial:
+        r = harness.LAST_RUN
+        msg += "; registration region %.3f s = %.1f pairs/s (data %.2f s, ICP %.2f s, statistics %.2f s)" % (
+            r["registration_s"], len(idx) / max(r["registration_s"], 1e-9), r["data_s"], r["icp_s"], r["stats_s"])
+    print(msg, flush=True)
+    with open(f"{args.tmp_file_base}_throughput_{args.world_size}_{args.rank}.txt", "w") as fid:
+        fid.write(msg + "\n")
     np.save(f"{args.tmp_file_base}_res_{args.world_size}_{args.rank}.npy",
             np.concatenate([stats, T.reshape(-1, 16), harness.LAST_WHOLE_PATH[:, None], np.asarray(idx, np.float64)[:, None]], 1))
 
@@ -119,6 +141,8 @@ def analyze_stats(args):
         for k, v in args.__dict__.items():
             fid.write(f"{k} = {v}\n")
         fid.write("\n" + s)
+        for f in sorted(glob(args.tmp_file_base + "_throughput_*")):
+            fid.write("\n" + open(f).read().strip())
     io_lists.write_coarse_motions(args.outdir + "coarse_motions.txt", stats[:, 19], stats[:, 20], stats[:, 21], T)
     return stats
 
@@ -130,7 +154,7 @@ def main(argv=None):
         test_subset(args)
     if args.do_analysis:
         stats = analyze_stats(args)
-        for f in glob(args.tmp_file_base + "_res_*"):
+        for f in glob(args.tmp_file_base + "_res_*") + glob(args.tmp_file_base + "_throughput_*"):
             os.remove(f)
         return stats
 

@@ -153,10 +153,15 @@ def list_run(args):
     from lidarregistration_amd import harness, shard, metrics
     world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = "WORLD_SIZE" in os.environ
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank if not args.devices else int(args.devices.split(",")[local_rank])
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    host_coll = use_dist and args.dist_backend == "gloo"
     if use_dist:
-        dist.init_process_group("nccl", device_id=dev)
+        if host_coll:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     class A:      # Experiments/test.py:294-313 defaults + the README's flags
         codebase = "GC"; prosac = True; fast_rejection = "ELC"; GC_LO = True; GPF_factor = 2.0; GPF_grid_wid = 10
@@ -176,10 +181,10 @@ def list_run(args):
     local[:, 1] = res["re_deg"]; local[:, 2] = res["te_m"] * 100; local[:, 17] = res["n_corr"]; local[:, 22:38] = res["T"].reshape(-1, 16)
     if use_dist:
         dist.barrier()
-        sec = torch.tensor([res["seconds"]], dtype=torch.float64, device=dev)
+        sec = torch.tensor([res["seconds"]], dtype=torch.float64, device="cpu" if host_coll else dev)
         dist.all_reduce(sec, op=dist.ReduceOp.MAX)
         seconds = float(sec.item())
-        table = shard.gather_rows(local, len(rows_all), world, rank, device=dev)
+        table = shard.gather_rows(local, len(rows_all), world, rank, device=None if host_coll else dev)
     else:
         seconds, table = res["seconds"], local[:len(rows_all)]
     if rank == 0:

@@ -128,7 +128,7 @@ typedef struct lr_pair_params {
 } lr_pair_params;
 
 /* ---- library ------------------------------------------------------------------------------- */
-LR_API int         lr_version(void);
+LR_API int         lr_version(void);    /* 100 * major + minor; 101: lr_ransac_params 64 bytes / lr_pair_params 96 bytes (round 3), lr_icp_batch */
 LR_API const char *lr_last_error(void);
 
 /* Scratch for clouds up to (max_n0, max_n1) points x dim and up to max_iters hypotheses. */
@@ -216,6 +216,13 @@ LR_API int lr_icp(lr_workspace *ws, const float *xyz0, int n0, const float *xyz1
                   double max_dist, int max_iter, double rel_fitness, double rel_rmse,
                   double *T_out, lr_icp_result *res, void *stream);
 
+/* The same refinement for EVERY pair of the last lr_register_batch call on this workspace, as one set of launches: the
+ * harness runs ICP after the timed registration and times it on its own (Experiments/test.py:183-193, stats columns 11-14).
+ * Starts from that call's final transforms (still in the arenas), over the clouds that call was given (they must still be
+ * alive); fills T_icp / icp of out[k], k < npairs of that call (out = the result blocks of that call, or a copy).       */
+LR_API int lr_icp_batch(lr_workspace *ws, double max_dist, int max_iter, double rel_fitness, double rel_rmse,
+                        lr_pair_result *out, void *stream);
+
 /* ---- a13: least-squares rigid fit of n point pairs  (models/common.py:7-45) -------------------------
  * P, Q [n,3] float64, optional weights w [n]; T_out[16].                                           */
 LR_API int lr_kabsch(const double *P, const double *Q, const double *w, int n, double *T_out, void *stream);
@@ -246,6 +253,10 @@ LR_API int lr_workspace_lists(lr_workspace *ws, int n0, int32_t *nn_idx1, int32_
 /* ... and of pair `pair` of the last lr_register_batch */
 LR_API int lr_workspace_lists_at(lr_workspace *ws, int pair, int n0, int32_t *nn_idx1, int32_t *nn_idx2,
                                  int32_t *corr_idx0, int32_t *corr_idx1, void *stream);
+/* ... and of its first `npairs` pairs at once: buffers [npairs][width] int32, row k = pair k (what the harness reads for the
+ * statistics of Experiments/test.py:200-208 after a batched call: one strided copy per list)                             */
+LR_API int lr_workspace_lists_batch(lr_workspace *ws, int npairs, int width, int32_t *nn_idx1, int32_t *nn_idx2,
+                                    int32_t *corr_idx0, int32_t *corr_idx1, void *stream);
 
 /* ---- f2: voxel de-duplication of a raw cloud -- ME.utils.sparse_quantize(xyz / voxel_size, return_index=True) as the
  * reference's loaders call it (Experiments/dataloader/generic_balanced_loader.py:62-63; voxel_size 0.3).

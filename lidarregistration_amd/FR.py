@@ -126,7 +126,11 @@ def pair_lists(ws, n0, n_corr, dev):
     return nn1.cpu().numpy(), c0[:n_corr].cpu().numpy(), c1[:n_corr].cpu().numpy()
 
 
-_SHARE = {}          # (n0, n1) rounded up to 1024 -> the second neighbour's share of the forward NN time
+_SHARE = {}          # (n0, n1 rounded up to 1024, device index) -> the second neighbour's share of the forward NN time
+
+
+def share_key(n0, n1, device):
+    return ((int(n0) + 1023) // 1024, (int(n1) + 1023) // 1024, torch.device(device).index)
 last_timing = {}     # of the last FR() call: whole_path_s, forward_nn_s, second_nn_share, reference_style_s (= the returned elapsed_time)
 
 
@@ -135,7 +139,7 @@ def second_nn_share(f0, f1, ws, reps=3):
     (FR.py:117).  Here the forward NN runs once per call; its second-neighbour share is measured once per cloud-size class with the
     same two calls (device events) and applied to the forward-NN time of each call."""
     n0, n1 = int(f0.shape[0]), int(f1.shape[0])
-    key = ((n0 + 1023) // 1024, (n1 + 1023) // 1024)
+    key = share_key(n0, n1, f0.device)
     if key not in _SHARE:
         i1 = torch.empty(n0, dtype=torch.int32, device=f0.device); i2 = torch.empty_like(i1)
         st = torch.cuda.current_stream(f0.device)

@@ -18,7 +18,7 @@ SYMBOLS = [
     "lr_nn_top2", "lr_nn_to_mutual", "lr_feat_ratio", "lr_gpf", "lr_gpf_bb_first", "lr_ransac", "lr_refit", "lr_icp", "lr_kabsch",
     "lr_register_pair", "lr_workspace_lists", "lr_workspace_timing", "lr_workspace_timing_read",
     "lr_workspace_create_batch", "lr_register_batch", "lr_workspace_lists_at", "lr_inlier_mask", "lr_workspace_mask_at",
-    "lr_voxel_dedup_scratch_bytes", "lr_voxel_dedup", "lr_workspace_option", "lr_workspace_stage_times",
+    "lr_voxel_dedup_scratch_bytes", "lr_voxel_dedup", "lr_workspace_option", "lr_workspace_stage_times", "lr_icp_batch", "lr_workspace_lists_batch",
 ]
 
 # lr_workspace_option ids (include/lidarreg.h).  DEFAULT_OPTIONS is applied to every Workspace this module creates (a hook for
@@ -111,9 +111,11 @@ def lib():
         L.lr_refit.argtypes = [vp, vp, ci, vp, vp, vp, ctypes.c_double, vp, vp, vp]
         L.lr_icp.argtypes = [vp, vp, ci, vp, ci, vp, ctypes.c_double, ci, ctypes.c_double, ctypes.c_double, vp, vp, vp]
         L.lr_kabsch.argtypes = [vp, vp, vp, ci, vp, vp]
+        L.lr_icp_batch.argtypes = [vp, ctypes.c_double, ci, ctypes.c_double, ctypes.c_double, vp, vp]
         L.lr_register_pair.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ctypes.POINTER(PairParams), vp, vp]
         L.lr_workspace_lists.argtypes = [vp, ci, vp, vp, vp, vp, vp]
         L.lr_workspace_lists_at.argtypes = [vp, ci, ci, vp, vp, vp, vp, vp]
+        L.lr_workspace_lists_batch.argtypes = [vp, ci, ci, vp, vp, vp, vp, vp]
         L.lr_inlier_mask.argtypes = [vp, vp, vp, ci, vp, ctypes.c_float, vp, vp, vp]
         L.lr_workspace_mask_at.argtypes = [vp, ci, vp, vp, ci, ctypes.c_float, vp, vp, vp]
         L.lr_voxel_dedup_scratch_bytes.restype = ctypes.c_size_t

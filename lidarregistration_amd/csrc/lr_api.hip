@@ -19,7 +19,7 @@ void lr_set_error(const char *fmt, ...)
 static_assert(sizeof(lr_ransac_params) == 64 && sizeof(lr_pair_params) == 96 && sizeof(lr_pair_result) == 496,
               "ABI structs changed: update include/lidarreg.h, _ext.py, INTEGRATION.md and tests/test_abi_cpu.py together");
 
-extern "C" int lr_version(void) { return 100; }
+extern "C" int lr_version(void) { return 101; }
 extern "C" const char *lr_last_error(void) { return g_err; }
 
 // ------------------------------------------------------------------ workspace
@@ -150,7 +150,7 @@ extern "C" int lr_workspace_option(lr_workspace *ws, int option, int value)
     switch (option) {
     case LR_OPT_NN_BLOCKS: ws->nn_blocks_target = value > 0 ? value : 512; break;
     case LR_OPT_NN_BLOCKS_BATCH: ws->nn_blocks_batch = value > 0 ? value : 3072; break;
-    case LR_OPT_NN_SAMPLE_STRIDE: ws->nn_sample_stride = value; break;
+    case LR_OPT_NN_SAMPLE_STRIDE: ws->nn_sample_stride = value > 4096 ? 4096 : value; break;      // (lr_nn16_run clamps it to the strip length)
     case LR_OPT_REV_STRIPS: ws->rev_strips = value > 64 ? 64 : value; break;
     case LR_OPT_NN_SECOND_AUTO: ws->nn_second_auto = value ? 1 : 0; break;
     default: lr_set_error("lr_workspace_option: unknown option %d", option); return LR_EINVAL;
@@ -187,6 +187,25 @@ extern "C" int lr_workspace_lists_at(lr_workspace *ws, int pair, int n0, int32_t
     if (nn_idx2) LR_HIP(hipMemcpyAsync(nn_idx2, at(ws->nn_idx2), nb, hipMemcpyDeviceToDevice, st));
     if (corr_idx0) LR_HIP(hipMemcpyAsync(corr_idx0, at(ws->corr_idx0), nb, hipMemcpyDeviceToDevice, st));
     if (corr_idx1) LR_HIP(hipMemcpyAsync(corr_idx1, at(ws->corr_idx1), nb, hipMemcpyDeviceToDevice, st));
+    return LR_OK;
+}
+
+// the same lists for the first `npairs` pairs of the last call at once: out[k * width + i], one strided copy per list
+extern "C" int lr_workspace_lists_batch(lr_workspace *ws, int npairs, int width, int32_t *nn_idx1, int32_t *nn_idx2,
+                                        int32_t *corr_idx0, int32_t *corr_idx1, void *stream)
+{
+    LR_REQUIRE(ws, LR_EINVAL, "lr_workspace_lists_batch: null workspace");
+    LR_REQUIRE(npairs >= 1 && npairs <= ws->last_npairs, LR_EINVAL, "lr_workspace_lists_batch: the last registration call on this workspace had fewer pairs");
+    LR_REQUIRE(width > 0 && width <= ws->max_n0, LR_ESIZE, "lr_workspace_lists_batch: width exceeds the workspace");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t wb = sizeof(int32_t) * (size_t)width;
+    auto copy = [&](int32_t *dst, const int32_t *src) -> int {
+        if (!dst) return LR_OK;
+        LR_HIP(hipMemcpy2DAsync(dst, wb, src, ws->stride, wb, (size_t)npairs, hipMemcpyDeviceToDevice, st));
+        return LR_OK;
+    };
+    LR_TRY_HIP(copy(nn_idx1, ws->nn_idx1)); LR_TRY_HIP(copy(nn_idx2, ws->nn_idx2));
+    LR_TRY_HIP(copy(corr_idx0, ws->corr_idx0)); LR_TRY_HIP(copy(corr_idx1, ws->corr_idx1));
     return LR_OK;
 }
 
@@ -396,6 +415,28 @@ extern "C" int lr_icp(lr_workspace *ws, const float *xyz0, int n0, const float *
     return lr_icp_run(ws, xyz0, n0, xyz1, n1, T_init, nullptr, max_dist, max_iter, rel_fitness, rel_rmse, T_out, res, (hipStream_t)stream);
 }
 
+__global__ void pair_icp_kernel(const double *__restrict__ T_icp, const lr_icp_result *__restrict__ r, lr_pair_result *__restrict__ out, int have, lr_zargs z);
+
+// The harness' ICP stage for every pair of the last lr_register_batch call (test.py:183-193 times it on its own, after the
+// registration): starts from that call's final transforms, which are still in the arenas, over the clouds its descriptor table
+// names; fills T_icp / icp of out[k].  One set of launches for all pairs, like every other stage.
+extern "C" int lr_icp_batch(lr_workspace *ws, double max_dist, int max_iter, double rel_fitness, double rel_rmse, lr_pair_result *out, void *stream)
+{
+    LR_REQUIRE(ws && out, LR_EINVAL, "lr_icp_batch: null pointer");
+    LR_REQUIRE(ws->last_batch && ws->last_npairs >= 1 && ws->last_T_final, LR_EINVAL, "lr_icp_batch: the last registration call on this workspace was not lr_register_batch");
+    hipStream_t st = (hipStream_t)stream;
+    ws->zP = ws->last_npairs; ws->z = lr_zargs{ ws->stride, ws->descs };
+    lr_icp_result *icp_res = reinterpret_cast<lr_icp_result *>(ws->icp_state + 24);
+    int rc = lr_icp_run(ws, nullptr, ws->last_mx0, nullptr, ws->last_mx1, ws->last_T_final, ws->res_tmp, max_dist, max_iter, rel_fitness, rel_rmse,
+                        ws->T_tmp + 32, icp_res, st);
+    if (rc == LR_OK) {
+        hipLaunchKernelGGL(pair_icp_kernel, dim3(1, 1, ws->zP), dim3(64), 0, st, ws->T_tmp + 32, icp_res, out, 1, ws->z);
+        if (hipGetLastError() != hipSuccess) { lr_set_error("lr_icp_batch: launch failed"); rc = LR_EHIP; }
+    }
+    ws->zP = 1; ws->z = lr_zargs{ 0, nullptr };
+    return rc;
+}
+
 __global__ void pair_icp_kernel(const double *__restrict__ T_icp, const lr_icp_result *__restrict__ r, lr_pair_result *__restrict__ out, int have,
                                 lr_zargs z)
 {
@@ -489,6 +530,7 @@ static int register_stages(lr_workspace *ws, const float *xyz0, const float *xyz
     } else
     hipLaunchKernelGGL(pair_result_kernel, dim3(1, 1, ws->zP), dim3(64), 0, st, ws->T_tmp, T_final, ws->res_tmp, ws->counters,
                        p->refit ? n_refit : (const int32_t *)nullptr, out, ws->z);
+    ws->last_T_final = T_final; ws->last_mx0 = n0; ws->last_mx1 = n1;
     // 5. ICP refinement (test.py:183-189): max distance 2*voxel, Open3D's default criteria
     lr_icp_result *icp_res = reinterpret_cast<lr_icp_result *>(ws->icp_state + 24);
     if (p->icp)
@@ -507,7 +549,7 @@ extern "C" int lr_register_pair(lr_workspace *ws, const float *xyz0, const float
     LR_REQUIRE(p->mode == LR_MODE_NO_FILTER || p->mode == LR_MODE_MNN || p->mode == LR_MODE_GPF, LR_EINVAL,
                "lr_register_pair: unknown mode");
     ws->zP = 1; ws->z = lr_zargs{ 0, nullptr };
-    ws->last_npairs = 1;
+    ws->last_npairs = 1; ws->last_batch = 0;
     return register_stages(ws, xyz0, xyz1, F0, F1, n0, n1, dim, p, out, (hipStream_t)stream);
 }
 
@@ -538,7 +580,7 @@ extern "C" int lr_register_batch(lr_workspace *ws, int npairs, const float *cons
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(batch_setup_kernel, dim3(1), dim3(64), 0, st, t, ws->descs, npairs);
     ws->zP = npairs; ws->z = lr_zargs{ ws->stride, ws->descs };
-    ws->last_npairs = npairs;
+    ws->last_npairs = npairs; ws->last_batch = 1;
     const int rc = register_stages(ws, xyz0[0], xyz1[0], F0[0], F1[0], mx0, mx1, dim, p, out, st);
     ws->zP = 1; ws->z = lr_zargs{ 0, nullptr };
     return rc;

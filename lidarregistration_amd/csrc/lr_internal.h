@@ -86,6 +86,9 @@ struct lr_workspace {
     int max_n0, max_n1, max_n, dim, max_iters;
     int max_pairs;               // arenas in this workspace
     int last_npairs;             // pairs of the last lr_register_pair / _batch call (0: none yet): what the *_at accessors may read
+    int last_batch;              // 1: that call was lr_register_batch (descs[] still describes its pairs: lr_icp_batch)
+    int last_mx0, last_mx1;      // largest cloud sizes of that call (they size the grids of a follow-up stage)
+    const double *last_T_final;  // arena-0 pointer of that call's final transform (T_tmp or T_tmp + 16)
     size_t stride;               // bytes per arena
     size_t bytes;
     char *base;                  // one hipMalloc

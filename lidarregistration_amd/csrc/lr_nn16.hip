@@ -972,6 +972,7 @@ int lr_nn16_run(lr_workspace *ws, const float *Fq, const _Float16 *Hq, const flo
     int sstride = ws->nn_sample_stride > 0 ? ws->nn_sample_stride : tps / 32;
     if (ws->nn_sample_stride <= 0) { const int cap = tps > 2048 ? 32 : 16; if (sstride > cap) sstride = cap; }
     if (sstride < 1) sstride = 1;
+    if (sstride > tps) sstride = tps;          // (one sampled tile per strip at least; keeps phase 1's column index in range)
     // 1-D XCD-aware grid over (row block, strip, pair), padded to a multiple of 8
     const int total = row_blocks * strips * ws->zP;
     dim3 grid(8 * lr_cdiv(total, 8));

@@ -42,6 +42,22 @@ class SyntheticSource:
             p["T_gt"] = T_new
         return p
 
+    def get_dev(self, k, device):
+        """The same recipe drawn on the device (synth.make_pair_dev: milliseconds instead of a quarter second per 30k-point pair;
+        same distributions, different numbers than get()): dict of float32 device tensors + T_gt."""
+        rho = self.rho
+        T_gt = None
+        if self.pair_list is not None:
+            if self.pair_list["overlap"] is not None:
+                rho = float(np.clip(self.pair_list["overlap"][k], 0.05, 0.95))
+            T_gt = self.pair_list["T_gt"][k]
+        return synth.make_pair_dev(N=self.n, rho=rho, s=self.s, seed=self.seed + int(k), device=device, T_gt=T_gt)
+
+
+def _upload(p, device):
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(device, non_blocking=True)
+    return dict(xyz0=t(p["xyz0"]), xyz1=t(p["xyz1"]), feats0=t(p["feats0"]), feats1=t(p["feats1"]), T_gt=p["T_gt"])
+
 
 class CacheSource:
     """Real clouds + FCGF features from a feature cache (io_lists.save_cloud) for the pairs of a balanced list."""
@@ -60,6 +76,9 @@ class CacheSource:
         xyz0, f0 = io_lists.load_cloud(self.cache_dir, s, i)
         xyz1, f1 = io_lists.load_cloud(self.cache_dir, s, j)
         return dict(xyz0=xyz0, xyz1=xyz1, feats0=f0, feats1=f1, T_gt=self.pair_list["T_gt"][k])
+
+    def get_dev(self, k, device):
+        return _upload(self.get(k), device)
 
 
 class RefCloudSource:
@@ -93,6 +112,9 @@ class RefCloudSource:
         xyz0, f0 = self._cloud(s, i)
         xyz1, f1 = self._cloud(s, j)
         return dict(xyz0=xyz0, xyz1=xyz1, feats0=f0, feats1=f1, T_gt=self.pair_list["T_gt"][k])
+
+    def get_dev(self, k, device):
+        return _upload(self.get(k), device)
 
 
 def load_list_fixture(dataset):
@@ -199,8 +221,200 @@ def registration_params(args):
     return params
 
 
-def eval_pairs(source, indices, args, device=None, in_flight=4, verbose=False):
-    """Register source[k] for k in indices.  Returns (stats [n,22] float64, T [n,4,4] float64)."""
+def inlier_ratios_dev(xyz0, xyz1, nn1, c0, c1, n0, n_corr, T_gt):
+    """measure_inlier_ratio (matching.py:241-249) of a batch of pairs on the device, in float64 with a fixed elementwise
+    operation order (so a pair's value does not depend on the batch it was in): returns (ratio over the n0[k] NN pairs
+    (i, nn1[k, i]), ratio over the first n_corr[k] filtered pairs (c0[k, c], c1[k, c])) as two [B] float64 device tensors.
+    xyz0 / xyz1: lists of [n,3] float32 device tensors; nn1 / c0 / c1: [B, W] int32; n0 / n_corr: [B] device int tensors;
+    T_gt: [B,4,4] float64 on the host."""
+    B, W = nn1.shape
+    dev = nn1.device
+    thr2 = (2 * fr.VOXEL_SIZE) ** 2
+
+    def padded(xs):
+        w = max(int(x.shape[0]) for x in xs)
+        if all(int(x.shape[0]) == w for x in xs):
+            return torch.stack(xs).to(torch.float64)
+        out = torch.zeros((len(xs), w, 3), dtype=torch.float64, device=dev)
+        for k, x in enumerate(xs):
+            out[k, :x.shape[0]] = x
+        return out
+
+    X0, X1 = padded(xyz0), padded(xyz1)
+    T = torch.from_numpy(np.ascontiguousarray(T_gt, np.float64)).to(dev)
+    # R p + t, component by component (no BLAS: one fixed order of operations)
+    P = [X0[..., 0] * T[:, r, 0, None] + X0[..., 1] * T[:, r, 1, None] + X0[..., 2] * T[:, r, 2, None] + T[:, r, 3, None] for r in range(3)]
+    ar = torch.arange(W, device=dev)[None, :]
+
+    def ratio(i0, i1, count):
+        i0 = i0.long().clamp(0, X0.shape[1] - 1); i1 = i1.long().clamp(0, X1.shape[1] - 1)
+        d2 = torch.zeros(i0.shape, dtype=torch.float64, device=dev)
+        for r in range(3):
+            d = torch.gather(P[r], 1, i0) - torch.gather(X1[..., r], 1, i1)
+            d2 += d * d
+        live = ar < count[:, None]
+        hits = ((d2 < thr2) & live).sum(1).to(torch.float64)
+        return torch.where(count > 0, hits / count.clamp(min=1).to(torch.float64), torch.zeros_like(hits))
+
+    init = ratio(ar.expand(B, W), nn1, n0)
+    filt = ratio(c0, c1, n_corr)
+    return init, filt
+
+
+_NCORR_OFF = _ext.PairResult.n_corr.offset
+
+
+def eval_pairs(source, indices, args, device=None, batch=32, in_flight=6, nstreams=3, verbose=False):
+    """Register source[k] for k in indices through the BATCHED engine -- what Experiments/test.py:108-234 does pair by pair.
+    The list is taken in windows of `in_flight` batches of `batch` rows; per window:
+      A  data: source.get_dev for every row (device synthesis / upload), synchronised                       -> column 10
+      B  registration: one lr_register_batch per batch (every kernel of the path launched once for all its pairs), batch i on
+         workspace i and stream i % nstreams, + the strided copies of the lists; nothing else is in the region; synchronised;
+         its wall time is the window's registration time                                                        -> column 9
+      C  ICP (args.icp): one lr_icp_batch per batch on the same workspaces, timed the same way (test.py:183-193) -> column 11
+      D  statistics: ground-truth inlier ratios on the device, RE / TE on the host                               -> the rest
+    Returns (stats [n,22] float64, T [n,4,4] float64) in the reference's 22-column layout (test.py:98-100).  Time columns are
+    per-pair SHARES of a window: column 9 = (registration wall of the window / its pairs) x the part FR.py:117 bills -- the
+    library's own stage events give the forward-NN fraction f of the window's calls, the first neighbour's part of it,
+    f (1 - second_nn_share), is what the reference treats as given (matching.py:7-11); the share is calibrated once per
+    cloud-size class (FR.second_nn_share), so column 9 is an estimate of the reference-style figure, the whole path is kept in
+    LAST_WHOLE_PATH.  LAST_RUN holds the run's totals (seconds in A, B, C, D; pairs).
+    Results are bit-identical to the one-pair-at-a-time path (eval_pairs_serial; tests/test_gpu_cli.py)."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    params = registration_params(args)
+    n = len(indices)
+    stats = np.full((n, 22), np.nan)
+    Ts = np.tile(np.eye(4), (n, 1, 1))
+    whole_path = np.full(n, np.nan)
+    batch = max(1, min(int(batch), 64))
+    in_flight = max(1, int(in_flight))
+    nstreams = max(1, min(int(nstreams), in_flight))
+    streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
+    wss = [None] * in_flight
+    seen = [None] * in_flight
+    size = ctypes.sizeof(_ext.PairResult)
+    want_icp = bool(getattr(args, "icp", False))
+    lib = _ext.lib()
+    totals = dict(data_s=0.0, registration_s=0.0, icp_s=0.0, stats_s=0.0, pairs=n, batch=batch, in_flight=in_flight, nstreams=nstreams)
+    window = batch * in_flight
+    cur = torch.cuda.current_stream(dev)
+    for w0 in range(0, n, window):
+        rows_w = list(range(w0, min(w0 + window, n)))
+        # ---- A: data
+        t0 = time.time()
+        ps = [source.get_dev(indices[row], dev) for row in rows_w]
+        torch.cuda.synchronize(dev)
+        t_data = time.time() - t0
+        totals["data_s"] += t_data
+        groups = []
+        for i, g0 in enumerate(range(0, len(rows_w), batch)):
+            sl = slice(g0, min(g0 + batch, len(rows_w)))
+            gp = ps[sl]
+            n0s = [int(p["feats0"].shape[0]) for p in gp]; n1s = [int(p["feats1"].shape[0]) for p in gp]
+            d = int(gp[0]["feats0"].shape[1])
+            if wss[i] is None or not wss[i].fits(max(n0s), max(n1s), params.ransac.iters):
+                if wss[i] is not None:
+                    wss[i].close()
+                ragged = len(set(n0s + n1s)) > 1          # real data: leave headroom for the next windows
+                wss[i] = _ext.Workspace(int(max(n0s) * (1.25 if ragged else 1)), int(max(n1s) * (1.25 if ragged else 1)), d, params.ransac.iters, max_pairs=batch)
+                seen[i] = None
+            k_big = int(np.argmax(n0s))
+            fresh = fr.share_key(n0s[k_big], n1s[k_big], dev) not in fr._SHARE
+            share = fr.second_nn_share(gp[k_big]["feats0"], gp[k_big]["feats1"], wss[i])      # (the GPU is idle here: calibrated once per size class)
+            if fresh or seen[i] is None:
+                torch.cuda.synchronize(dev)
+                wss[i].timing(True); seen[i] = [0.0] * 6
+            groups.append(dict(rows=rows_w[sl], ps=gp, n0=n0s, n1=n1s, share=share, slot=i,
+                               out=torch.empty((len(gp), size), dtype=torch.uint8, device=dev)))
+        torch.cuda.synchronize(dev)
+        for st in streams:
+            st.wait_stream(cur)
+        # ---- B: registration
+        t0 = time.time()
+        for g in groups:
+            st = streams[g["slot"] % nstreams]
+            chunk = [(p["xyz0"], p["xyz1"], p["feats0"], p["feats1"]) for p in g["ps"]]
+            fr.register_batch_dev(chunk, params, out=g["out"], ws=wss[g["slot"]], stream=st.cuda_stream)
+            W = max(g["n0"]); B = len(chunk)
+            with torch.cuda.stream(st):
+                g["nn1"] = torch.empty((B, W), dtype=torch.int32, device=dev); g["c0"] = torch.empty_like(g["nn1"]); g["c1"] = torch.empty_like(g["nn1"])
+            _ext.check(lib.lr_workspace_lists_batch(wss[g["slot"]].handle, B, W, g["nn1"].data_ptr(), None, g["c0"].data_ptr(), g["c1"].data_ptr(), st.cuda_stream))
+        for st in streams:
+            st.synchronize()
+        t_reg = time.time() - t0
+        totals["registration_s"] += t_reg
+        # ---- C: ICP
+        t_icp = 0.0
+        if want_icp:
+            t0 = time.time()
+            for g in groups:
+                _ext.check(lib.lr_icp_batch(wss[g["slot"]].handle, 2 * fr.VOXEL_SIZE, 30, 1e-6, 1e-6, g["out"].data_ptr(), streams[g["slot"] % nstreams].cuda_stream))
+            for st in streams:
+                st.synchronize()
+            t_icp = time.time() - t0
+            totals["icp_s"] += t_icp
+        # ---- D: statistics
+        t0 = time.time()
+        d_call = d_fwd = 0.0
+        share_w = 0.0
+        for g in groups:
+            ms, _ = wss[g["slot"]].stage_times()
+            d_call += ms[0] - seen[g["slot"]][0]; d_fwd += ms[1] - seen[g["slot"]][1]
+            share_w += g["share"] * len(g["rows"])
+            seen[g["slot"]] = ms
+        share_w /= len(rows_w)
+        f_fwd = d_fwd / d_call if d_call > 0 else 0.0
+        per_pair = t_reg / len(rows_w)
+        billed = per_pair * (1.0 - f_fwd * (1.0 - share_w))
+        for g in groups:
+            gp = g["ps"]
+            with torch.cuda.stream(streams[g["slot"] % nstreams]):
+                n_corr = g["out"][:, _NCORR_OFF:_NCORR_OFF + 4].contiguous().view(torch.int32).view(-1)
+                T_gt = np.stack([np.asarray(p["T_gt"], np.float64) for p in gp])
+                ri, rf = inlier_ratios_dev([p["xyz0"] for p in gp], [p["xyz1"] for p in gp], g["nn1"], g["c0"], g["c1"],
+                                           torch.tensor(g["n0"], dtype=torch.int32, device=dev), n_corr, T_gt)
+                hb = g["out"].cpu().numpy(); ri = ri.cpu().numpy(); rf = rf.cpu().numpy()
+            for j, row in enumerate(g["rows"]):
+                r = _ext.PairResult.from_buffer_copy(hb[j].tobytes())
+                T = np.array(r.T[:], np.float64).reshape(4, 4) if r.status == 0 else np.eye(4)
+                gt = T_gt[j]
+                re, te = metrics.rotation_error_deg(T, gt), metrics.translation_error_cm(T, gt)
+                sess, si, ti = source.ids(indices[row])
+                stats[row, 0] = float(re < metrics.RE_THRE_DEG and te < metrics.TE_THRE_CM)
+                stats[row, 1], stats[row, 2] = re, te
+                stats[row, 9] = billed
+                whole_path[row] = per_pair
+                stats[row, 10], stats[row, 11] = t_data / len(rows_w), 0.0
+                if want_icp:
+                    T_icp = np.array(r.T_icp[:], np.float64).reshape(4, 4) if r.status == 0 else np.eye(4)
+                    re_i, te_i = metrics.rotation_error_deg(T_icp, gt), metrics.translation_error_cm(T_icp, gt)
+                    stats[row, 11] = t_icp / len(rows_w)
+                    stats[row, 12] = float(re_i < metrics.RE_THRE_DEG and te_i < metrics.TE_THRE_CM)
+                    stats[row, 13], stats[row, 14] = re_i, te_i
+                stats[row, 15] = g["n0"][j]
+                stats[row, 16] = ri[j]
+                stats[row, 17] = int(r.n_corr)
+                stats[row, 18] = rf[j]
+                stats[row, 19], stats[row, 20], stats[row, 21] = sess, si, ti
+                Ts[row] = T
+        totals["stats_s"] += time.time() - t0
+        if verbose:
+            print(f"{time.strftime('%m/%d %H:%M:%S')} Finished pair:{rows_w[-1]}/{n}  ({len(rows_w) / max(t_reg, 1e-9):.0f} pairs/s in the registration region)", flush=True)
+        del ps, groups
+    torch.cuda.synchronize(dev)
+    for w in wss:
+        if w is not None:
+            w.close()
+    global LAST_WHOLE_PATH, LAST_RUN
+    LAST_WHOLE_PATH = whole_path
+    LAST_RUN = totals
+    return stats, Ts
+
+
+def eval_pairs_serial(source, indices, args, device=None, in_flight=4, verbose=False):
+    """The one-pair-at-a-time call pattern of the reference harness (one lr_register_pair per list row, `in_flight` pairs on
+    separate streams): kept as the cross-check of eval_pairs (same data source, same statistics code) and for latency
+    measurements.  Returns (stats [n,22] float64, T [n,4,4] float64)."""
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
     params = registration_params(args)
     n = len(indices)
@@ -214,11 +428,10 @@ def eval_pairs(source, indices, args, device=None, in_flight=4, verbose=False):
 
     def retire(s):
         row, out, ev0, ev1, p, t_data, n0, icp_buf, ev2 = slots[s]
-        (ev2 or ev1).synchronize()
+        p["_end"].synchronize()
         r = fr.read_result(out)
         T = np.array(r.T[:], np.float64).reshape(4, 4) if r.status == 0 else np.eye(4)
-        idx1, ci0, ci1 = fr.pair_lists(wss[s], n0, int(r.n_corr), dev)
-        pcd0, pcd1 = fr.PointCloud(p["xyz0"]), fr.PointCloud(p["xyz1"])
+        ri, rf = (float(v.cpu()[0]) for v in p["_ratios"])
         re, te = metrics.rotation_error_deg(T, p["T_gt"]), metrics.translation_error_cm(T, p["T_gt"])
         sess, si, ti = source.ids(indices[row])
         stats[row, 0] = float(re < metrics.RE_THRE_DEG and te < metrics.TE_THRE_CM)
@@ -238,9 +451,9 @@ def eval_pairs(source, indices, args, device=None, in_flight=4, verbose=False):
             stats[row, 12] = float(re_i < metrics.RE_THRE_DEG and te_i < metrics.TE_THRE_CM)
             stats[row, 13], stats[row, 14] = re_i, te_i
         stats[row, 15] = n0
-        stats[row, 16] = fr.measure_inlier_ratio(np.arange(n0), idx1, pcd0, pcd1, p["T_gt"], fr.VOXEL_SIZE)
+        stats[row, 16] = ri
         stats[row, 17] = int(r.n_corr)
-        stats[row, 18] = fr.measure_inlier_ratio(ci0, ci1, pcd0, pcd1, p["T_gt"], fr.VOXEL_SIZE)
+        stats[row, 18] = rf
         stats[row, 19], stats[row, 20], stats[row, 21] = sess, si, ti
         Ts[row] = T
         slots[s] = None
@@ -252,7 +465,8 @@ def eval_pairs(source, indices, args, device=None, in_flight=4, verbose=False):
         if slots[s] is not None:
             retire(s)
         t0 = time.time()
-        p = source.get(k)
+        with torch.cuda.stream(streams[s]):
+            p = source.get_dev(k, dev)
         t_data = time.time() - t0
         n0, n1, d = p["feats0"].shape[0], p["feats1"].shape[0], p["feats0"].shape[1]
         if wss[s] is None or not wss[s].fits(n0, n1, params.ransac.iters):
@@ -262,11 +476,12 @@ def eval_pairs(source, indices, args, device=None, in_flight=4, verbose=False):
             wss[s] = _ext.Workspace(int(n0 * 1.25), int(n1 * 1.25), d, params.ransac.iters)
             seen[s] = None
         with torch.cuda.stream(streams[s]):
-            x0 = torch.from_numpy(p["xyz0"]).to(dev, non_blocking=True); x1 = torch.from_numpy(p["xyz1"]).to(dev, non_blocking=True)
-            f0 = torch.from_numpy(p["feats0"]).to(dev, non_blocking=True); f1 = torch.from_numpy(p["feats1"]).to(dev, non_blocking=True)
+            x0, x1, f0, f1 = p["xyz0"], p["xyz1"], p["feats0"], p["feats1"]
             # the second neighbour's share of the forward NN for clouds of this size (measured once per size class with a few
             # timed NN calls on this workspace, which is idle here); the stage events are (re)armed afterwards
-            fresh = ((n0 + 1023) // 1024, (n1 + 1023) // 1024) not in fr._SHARE
+            fresh = fr.share_key(n0, n1, dev) not in fr._SHARE
+            if fresh:
+                torch.cuda.synchronize(dev)               # calibrate on an idle GPU
             share = fr.second_nn_share(f0, f1, wss[s])
             if fresh or seen[s] is None:
                 wss[s].timing(True); seen[s] = [0.0] * 6
@@ -285,7 +500,13 @@ def eval_pairs(source, indices, args, device=None, in_flight=4, verbose=False):
                 ev2 = torch.cuda.Event(enable_timing=True)
                 ev2.record(streams[s])
                 icp_buf = (T_icp, res_icp)
-        slots[s] = (row, out, ev0, ev1, dict(p, _keep=(x0, x1, f0, f1), _share=share), t_data, n0, icp_buf, ev2)
+            nn1 = torch.empty((1, n0), dtype=torch.int32, device=dev); c0 = torch.empty_like(nn1); c1 = torch.empty_like(nn1)
+            _ext.check(_ext.lib().lr_workspace_lists_at(wss[s].handle, 0, n0, nn1.data_ptr(), None, c0.data_ptr(), c1.data_ptr(), streams[s].cuda_stream))
+            n_corr = out[_NCORR_OFF:_NCORR_OFF + 4].view(torch.int32)
+            ratios = inlier_ratios_dev([x0], [x1], nn1, c0, c1, torch.tensor([n0], dtype=torch.int32, device=dev), n_corr,
+                                       np.asarray(p["T_gt"], np.float64)[None])
+            ev3 = torch.cuda.Event(); ev3.record(streams[s])
+        slots[s] = (row, out, ev0, ev1, dict(p, _keep=(x0, x1, f0, f1), _share=share, _ratios=ratios, _end=ev3), t_data, n0, icp_buf, ev2)
     for s in range(in_flight):
         if slots[s] is not None:
             retire(s)
@@ -298,3 +519,4 @@ def eval_pairs(source, indices, args, device=None, in_flight=4, verbose=False):
 
 
 LAST_WHOLE_PATH = None      # eval_pairs: whole-call device seconds per row of its last run
+LAST_RUN = None             # eval_pairs: totals of its last run (seconds in the data / registration / ICP / statistics phases, pairs)

@@ -38,6 +38,8 @@ def summarize(all_stats, algo="RANSAC"):
     out += (f"{algo}+ICP | recall: {100*avg[12]:.2f}%, #failed/#total: {int((s[:,12]==0).sum())}/{n}, TE(cm): {icpavg[14]:.3f}, "
             f"RE(deg): {icpavg[13]:.3f}, ICP time(s): {avg[11]:.3f}, Total time(s) {avg[9]+avg[11]:.3f}\n")
     # (not in the reference's block) what "reg time" covers here, so that the two are not compared line by line
-    out += ("note: reg time = device time of the whole path incl. the forward NN (the reference bills the 2nd-NN surcharge + filter + "
-            "RANSAC only, FR.py:117); ICP is timed on its own\n")
+    out += ("note: reg time = what FR.py:117 bills (filter incl. the reverse NN + RANSAC + the 2nd neighbour's surcharge) as an ESTIMATE: "
+            "a pair's share of its window's registration time (batched calls) or its call's device time (--serial), minus the first "
+            "neighbour's part of the forward NN from the library's stage events and a share calibrated once per cloud size; "
+            "ICP is timed on its own\n")
     return out
