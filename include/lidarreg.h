@@ -83,7 +83,7 @@ typedef struct lr_ransac_params {
 typedef struct lr_ransac_result {
     int64_t  best_h;        /* winning hypothesis id, -1 when none had an inlier                     */
     uint32_t best_count;    /* its inlier count over the M correspondences                            */
-    uint32_t pad0;
+    uint32_t pad0;          /* diagnostic: see lr_pair_result.reserved[1] (0 unless a hand-off wait of the local optimisation timed out) */
     uint64_t best_ssq;      /* sum over its inliers of (uint32)(d^2 * 2^20)                           */
     int64_t  n_valid;       /* hypotheses that passed the pre-check and were scored                   */
     int64_t  n_ids;         /* hypothesis ids examined before the run stopped (== iters without early exit) */
@@ -108,7 +108,10 @@ typedef struct lr_pair_result {
     int32_t  status;        /* 0 ok, 1 = no valid hypothesis (T = identity, GC_RANSAC.py:51-52)       */
     int32_t  reserved[8];   /* [0]: diagnostic, like n_nn_fixed -- (model, correspondence) evaluations of the scoring passes in ppm of
                                scanning every list in full (0: not recorded); may differ between runs (the pilot among models with
-                               equal head counts depends on scheduling), no result does.  [1..7]: 0                              */
+                               equal head counts depends on scheduling), no result does.  [1]: diagnostic -- waits of the local optimisation's
+                               helper-block hand-off that hit their 0.2 s bound (low 16 bits: the master block recomputed a scoring job alone;
+                               high 16 bits: a helper block left without a job); integer sums make the result the same either way, a non-zero
+                               value means time was lost (also in lr_ransac_result.pad0).  [2..7]: 0                              */
     double   T_icp[16];     /* T refined by point-to-point ICP (test.py:183-189) when icp != 0, else = T */
     lr_icp_result icp;
 } lr_pair_result;

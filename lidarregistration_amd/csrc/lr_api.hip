@@ -466,6 +466,7 @@ __global__ void pair_result_kernel(const double *__restrict__ T_ransac, const do
         out->n_nn_fixed = counters[LR_CNT_FIX_TOTAL];
         out->status = rr->best_h < 0 ? 1 : 0;
         for (int q = 0; q < 8; ++q) out->reserved[q] = 0;
+        out->reserved[1] = reinterpret_cast<const lr_ransac_state *>(counters + LR_CNT_COUNT)->lo_timeouts;
         out->icp.fitness = 0.0; out->icp.inlier_rmse = 0.0; out->icp.n_corr = 0; out->icp.iterations = 0;
     }
     if (k < 16) out->T_icp[k] = T_final[k];      // overwritten by pair_icp_kernel when the ICP stage runs

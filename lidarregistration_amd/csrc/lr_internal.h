@@ -201,7 +201,8 @@ struct lr_ransac_state {
     int32_t done;                 // set when the confidence test says stop: later batches return immediately
     int32_t lo_pending;           // the best model changed in the batch just merged: the local optimisation has to run on it
     int32_t lo_calls;             // local optimisations run so far (part of the key of their sample stream)
-    int32_t pad;
+    int32_t lo_timeouts;          // diagnostic: waits of the local optimisation's hand-off protocol that hit their 0.2 s bound (low 16 bits: the master
+                                  // recomputed a job alone; high 16 bits: a helper block left after 0.2 s without a job) -- 0 in every run seen
     // SPRT pre-verification (use_elc == 2): design of the current batch (0 = not designed yet: eps 0.1, delta 0.01) and the
     // statistics of the models rejected so far
     double sprt_eps, sprt_delta;

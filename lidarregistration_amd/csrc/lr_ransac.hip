@@ -857,7 +857,7 @@ ransac_final_kernel(const uint32_t *__restrict__ score_cnt, const unsigned long 
             if ((double)h_end >= kk && h_end >= p.min_iters) state->done = 1;
         }
         lr_ransac_result r;
-        r.best_h = nc > 0 ? nh : -1; r.best_count = nc; r.pad0 = 0; r.best_ssq = nc > 0 ? nq : 0;
+        r.best_h = nc > 0 ? nh : -1; r.best_count = nc; r.pad0 = (uint32_t)state->lo_timeouts; r.best_ssq = nc > 0 ? nq : 0;
         r.n_valid = state->n_valid; r.n_ids = h_end;
         *res = r;
     }
@@ -1169,7 +1169,7 @@ __device__ void lo_job_work(lo_shared &sh, lr_lo_job *jb, const float *__restric
 }
 
 // master: score sh.Rt[0 .. LO_TRIALS) over all correspondences with whoever helps -> sh.cnt / sh.ssq
-__device__ void lo_score_shared(lo_shared &sh, lr_lo_ctl *ctl, int job, const float *__restrict__ corr8, int m, float thr2)
+__device__ void lo_score_shared(lo_shared &sh, lr_lo_ctl *ctl, int job, const float *__restrict__ corr8, int m, float thr2, int32_t *timeouts)
 {
     const int tid = threadIdx.x;
     lr_lo_job *jb = &ctl->job[job];
@@ -1199,7 +1199,11 @@ __device__ void lo_score_shared(lo_shared &sh, lr_lo_ctl *ctl, int job, const fl
     __syncthreads();
     const int ok = sh.flag;
     __syncthreads();
-    if (!ok) { lo_score_lanes(sh, corr8, m, thr2); return; }          // (never observed; the sums of the job are abandoned)
+    if (!ok) {          // (never observed; the sums of the job are abandoned, the event is counted: lr_ransac_result.pad0)
+        if (tid == 0 && timeouts) __hip_atomic_fetch_add(timeouts, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        lo_score_lanes(sh, corr8, m, thr2);
+        return;
+    }
     if (tid < LO_TRIALS) {
         sh.cnt[tid] = __hip_atomic_load(&jb->cnt[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         sh.ssq[tid] = __hip_atomic_load(&jb->ssq[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1208,7 +1212,7 @@ __device__ void lo_score_shared(lo_shared &sh, lr_lo_ctl *ctl, int job, const fl
 }
 
 // helper block: serves the jobs the master publishes until it says it is done (or nothing happens for 0.2 s)
-__device__ void lo_helper_loop(lo_shared &sh, lr_lo_ctl *ctl, const float *__restrict__ corr8, int m, float thr2)
+__device__ void lo_helper_loop(lo_shared &sh, lr_lo_ctl *ctl, const float *__restrict__ corr8, int m, float thr2, int32_t *timeouts)
 {
     const int tid = threadIdx.x;
     int seen = 0;
@@ -1218,7 +1222,7 @@ __device__ void lo_helper_loop(lo_shared &sh, lr_lo_ctl *ctl, const float *__res
             int p;
             while ((p = __hip_atomic_load(&ctl->phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == seen) {
                 __builtin_amdgcn_s_sleep(8);
-                if (__builtin_amdgcn_s_memrealtime() - t0 > 20000000ull) { p = -1; break; }
+                if (__builtin_amdgcn_s_memrealtime() - t0 > 20000000ull) { p = -1; __hip_atomic_fetch_add(timeouts, 0x10000, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             sh.flag = p;
@@ -1259,11 +1263,12 @@ __device__ void lo_score_wide(lo_shared &sh, const float *__restrict__ corr8, in
     __syncthreads();
 }
 
-__device__ __forceinline__ void lo_score(lo_shared &sh, const float *__restrict__ corr8, int m, float thr2, int ntrial, lr_lo_ctl *ctl = nullptr, int job = -1)
+__device__ __forceinline__ void lo_score(lo_shared &sh, const float *__restrict__ corr8, int m, float thr2, int ntrial, lr_lo_ctl *ctl = nullptr, int job = -1,
+                                         int32_t *timeouts = nullptr)
 {
     // 32-bit per-thread error sums hold when (correspondences per thread) * thr2 * 2^20 < 2^32
     if (ntrial > 1) {      // (lanes of trials >= ntrial score stale models nobody reads)
-        if (ctl && job >= 0 && job < LO_JOBS) lo_score_shared(sh, ctl, job, corr8, m, thr2);
+        if (ctl && job >= 0 && job < LO_JOBS) lo_score_shared(sh, ctl, job, corr8, m, thr2, timeouts);
         else lo_score_lanes(sh, corr8, m, thr2);
         return;
     }
@@ -1285,7 +1290,7 @@ ransac_lo_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__re
     const int tid = threadIdx.x;
     const bool helpers = gridDim.x > 1 && mode == 0;              // blocks 1.. of the pair's group serve the master's scoring jobs
     if (blockIdx.x > 0) {
-        if (helpers && m > 0) lo_helper_loop(sh, ctl, corr8, m, p.thr2);
+        if (helpers && m > 0) lo_helper_loop(sh, ctl, corr8, m, p.thr2, &state->lo_timeouts);
         return;
     }
     // (every way out of the master tells the helpers: they must not wait for jobs that never come)
@@ -1358,7 +1363,7 @@ ransac_lo_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__re
                 }
                 __syncthreads();
             } else if (!lo_fit_all(sh, corr8, list, nI)) break;
-            lo_score(sh, corr8, m, p.thr2, ntrial, helpers ? ctl : nullptr, round);
+            lo_score(sh, corr8, m, p.thr2, ntrial, helpers ? ctl : nullptr, round, &state->lo_timeouts);
             if (tid == 0) {
                 int bt = -1; unsigned bc = 0; unsigned long long bq = 0;
                 for (int t = 0; t < ntrial; ++t) {
@@ -1410,7 +1415,7 @@ ransac_lo_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__re
             }
         }
         lr_ransac_result r;
-        r.best_h = state->h; r.best_count = sh.curc; r.pad0 = 0; r.best_ssq = sh.curq;
+        r.best_h = state->h; r.best_count = sh.curc; r.pad0 = (uint32_t)state->lo_timeouts; r.best_ssq = sh.curq;
         r.n_valid = state->n_valid; r.n_ids = state->n_ids;
         *res = r;
     }
@@ -1606,6 +1611,7 @@ __device__ void refit_solve_body(const double *__restrict__ partial, int nblocks
         {   // reserved[0]: (model, correspondence) evaluations of the scoring passes, in ppm of scanning every list in full (0: not recorded)
             const lr_ransac_state *state = reinterpret_cast<const lr_ransac_state *>(counters + LR_CNT_COUNT);
             if (state->evals_full > 0) pair_out->reserved[0] = (int32_t)((double)state->evals / (double)state->evals_full * 1e6);
+            pair_out->reserved[1] = state->lo_timeouts;       // hand-off waits of the local optimisation that hit their bound (lr_ransac_state)
         }
         for (int k = 0; k < 16; ++k) pair_out->T_icp[k] = T[k];      // overwritten by pair_icp_kernel when the ICP stage runs
         pair_out->icp.fitness = 0.0; pair_out->icp.inlier_rmse = 0.0; pair_out->icp.n_corr = 0; pair_out->icp.iterations = 0;

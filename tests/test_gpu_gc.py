@@ -292,3 +292,162 @@ def test_gc_soak_cases(lr, oracle, case):
     T, info = lr.ransac.ransac_dev(src, tgt, iters, **kw)
     Te, einfo = oracle.ransac(src, tgt, iters, **kw)
     assert info == einfo and np.array_equal(T, Te), (kw, iters, info, einfo)
+
+
+def _reference_call(A, B, distance_threshold, num_iterations, args, match_quality, pygcransac):
+    """The CALL of the reference's Experiments/algorithms/GC_RANSAC.py:12-55 -- the parameter dict, the flag overrides with their
+    sentinel overloading, the PROSAC pre-sort, ``findRigidTransform(x1, x2, **params)``, ``None -> eye``, the transpose -- with
+    its TabError at :29-30 fixed.  Parameters only: nothing of the estimator is restated here."""
+    x1y1z1_ = np.ascontiguousarray(A); x2y2z2_ = np.ascontiguousarray(B)
+    params = {'threshold': distance_threshold, 'conf': 0.999, 'spatial_coherence_weight': 0.0, 'max_iters': num_iterations, 'use_sprt': True,
+              'min_inlier_ratio_for_sprt': 0.1, 'sampler': 0, 'neighborhood': 0, 'neighborhood_size': 20}
+    params['spatial_coherence_weight'] = args.spatial_coherence_weight
+    params['sampler'] = args.prosac
+    params['conf'] = args.GC_conf
+    params['use_sprt'] = args.fast_rejection != "NONE"           # "actually means: perform fast rejection"
+    if args.fast_rejection == "ELC":
+        params['min_inlier_ratio_for_sprt'] = -1                  # negative value: the C++ side uses ELC instead of SPRT
+    if not args.GC_LO:
+        params['neighborhood'] = 1                                # non-zero value: the C++ side does not run the local optimisation
+    if args.prosac:
+        order = np.argsort(-match_quality)
+        x1y1z1_ = x1y1z1_[order, :]; x2y2z2_ = x2y2z2_[order, :]
+    pose_T, mask = pygcransac.findRigidTransform(x1y1z1_, x2y2z2_, **params)
+    if pose_T is None:
+        pose_T = np.eye(4, dtype=np.float32)
+    return pose_T.T, mask
+
+
+@pytest.mark.parametrize("fast_rejection", ["ELC", "SPRT", "NONE"])
+@pytest.mark.parametrize("GC_LO", [True, False])
+@pytest.mark.parametrize("prosac", [True, False])
+def test_pygcransac_call_shape(lr, fast_rejection, GC_LO, prosac):
+    """`import pygcransac` as the reference does, its own call transcribed above: the pose is GC_RANSAC()'s bit for bit, in
+    pygcransac's row-vector convention until the caller transposes it; the mask covers the caller's (sorted) pairs."""
+    import os
+    import sys
+    exp = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "Experiments")
+    sys.path.insert(0, exp)
+    try:
+        sys.modules.pop("pygcransac", None)
+        import pygcransac
+    finally:
+        sys.path.remove(exp)
+    src, tgt, T_gt = _planted(n=5000, inlier=0.3, seed=31)
+    q = np.random.default_rng(5).random(len(src)).astype(np.float32)        # distinct finite qualities: one sort order
+    a = Args(codebase="GC", prosac=prosac, fast_rejection=fast_rejection, GC_LO=GC_LO, GC_conf=0.999)
+    T_ref, mask = _reference_call(src, tgt, 0.6, 20000, a, q, pygcransac)
+    T, _, mask2 = lr.ransac.GC_RANSAC(src, tgt, 0.6, 20000, a, q, return_mask=True)
+    assert np.array_equal(T_ref, T) and T_ref.dtype == np.float64
+    order = np.argsort(-q) if prosac else np.arange(len(src))
+    assert mask.dtype == bool and np.array_equal(mask, mask2[order]) and mask.sum() > 1000
+    from lidarregistration_amd import metrics
+    assert metrics.rotation_error_deg(T_ref, T_gt) < 0.5
+
+
+def test_pygcransac_sentinels_and_errors(lr, capsys):
+    from lidarregistration_amd import pygcransac
+    src, tgt, _ = _planted(n=2000, inlier=0.4, seed=8)
+    pose, mask = pygcransac.findRigidTransform(src, tgt, threshold=0.6, spatial_coherence_weight=0.0, sampler=7)      # gcransac_python.cpp:473-479
+    assert pose is None and mask.shape == (2000,) and not mask.any() and "Unknown sampler identifier: 7" in capsys.readouterr().err
+    with pytest.raises(NotImplementedError):
+        pygcransac.findRigidTransform(src, tgt, threshold=0.6)                                                          # upstream default weight 0.975
+    # nothing to find: no pose, empty mask (the reference maps None to the identity, GC_RANSAC.py:51-52)
+    rng = np.random.default_rng(1)
+    pose, mask = pygcransac.findRigidTransform(rng.uniform(-50, 50, (3, 3)), rng.uniform(-50, 50, (3, 3)) * 1e3, threshold=1e-6, spatial_coherence_weight=0.0,
+                                               sampler=0, use_sprt=False, max_iters=50)
+    assert (pose is None and not mask.any()) or mask.sum() >= 3
+    # the neighbourhood sentinel is ignored without a pre-verification (gcransac_python.cpp:571-591)
+    a = pygcransac.findRigidTransform(src, tgt, threshold=0.6, conf=0.999, spatial_coherence_weight=0.0, max_iters=5000, use_sprt=False, sampler=0, neighborhood=1)
+    b = pygcransac.findRigidTransform(src, tgt, threshold=0.6, conf=0.999, spatial_coherence_weight=0.0, max_iters=5000, use_sprt=False, sampler=0, neighborhood=0)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_lo_helper_protocol_under_contention(lr):
+    """The local optimisation's helper blocks (calls of <= 4 pairs) hand scoring jobs over through device memory with bounded spins
+    and a "master recomputes alone" fallback.  Here the protocol runs while the CUs are NOT idle: 4 host threads, each with 4 streams
+    of single-pair --codebase GC lr_register_pair calls, and a 32-pair batched call looping on a fifth stream.  Results must be
+    bit-identical to the one-call-at-a-time run, no wait may hit its 0.2 s bound (lr_pair_result.reserved[1] == 0 == ransac.pad0),
+    and no call may take anywhere near that long."""
+    import ctypes
+    import threading
+    import time
+    torch, FR, ext = lr.torch, lr.FR, lr.ext
+    dev = torch.device("cuda", torch.cuda.current_device())
+    a = Args(mode="MNN", codebase="GC", iters=30000, prosac=True, GC_conf=0.999)
+    params = FR.pair_params(a)
+    n_small, per_thread, reps = 6000, 4, 6
+    small = [synth.make_pair_dev(N=n_small, seed=900 + k, device=dev) for k in range(4 * per_thread)]
+    size = ctypes.sizeof(ext.PairResult)
+
+    def run_one(p, ws, stream):
+        out = torch.empty(size, dtype=torch.uint8, device=dev)
+        FR.register_pair_dev(p["xyz0"], p["xyz1"], p["feats0"], p["feats1"], params, out=out, ws=ws, stream=stream.cuda_stream)
+        return out
+
+    # reference: one call at a time on an idle GPU
+    ws0 = ext.Workspace(n_small, n_small, 32, a.iters)
+    s0 = torch.cuda.Stream(device=dev)
+    ref = []
+    for p in small:
+        o = run_one(p, ws0, s0); s0.synchronize()
+        ref.append(ext.PairResult.from_buffer_copy(o.cpu().numpy().tobytes()))
+    ws0.close()
+    assert all(r.status == 0 and r.ransac.best_count > 500 for r in ref)
+
+    big = [synth.make_pair_dev(N=30000, seed=700 + k, device=dev) for k in range(32)]
+    chunk = [(p["xyz0"], p["xyz1"], p["feats0"], p["feats1"]) for p in big]
+    pb = FR.pair_params(Args(mode="MNN", codebase="open3D", iters=50000, ransac_n=3, o3d_conf=1.0))
+    wsb = ext.Workspace(30000, 30000, 32, 50000, max_pairs=32)
+    sb = torch.cuda.Stream(device=dev)
+    outb = torch.empty((32, size), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize(dev)
+
+    results = [[None] * reps for _ in small]
+    latency = []
+    errors = []
+
+    def worker(t):
+        try:
+            torch.cuda.set_device(dev)
+            wss = [ext.Workspace(n_small, n_small, 32, a.iters) for _ in range(per_thread)]
+            sts = [torch.cuda.Stream(device=dev) for _ in range(per_thread)]
+            for rep in range(reps):
+                evs, outs = [], []
+                for j in range(per_thread):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(sts[j]); outs.append(run_one(small[t * per_thread + j], wss[j], sts[j])); e1.record(sts[j])
+                    evs.append((e0, e1))
+                for j in range(per_thread):
+                    sts[j].synchronize()
+                    latency.append(evs[j][0].elapsed_time(evs[j][1]) * 1e-3)
+                    results[t * per_thread + j][rep] = ext.PairResult.from_buffer_copy(outs[j].cpu().numpy().tobytes())
+            for w in wss:
+                w.close()
+        except Exception as e:      # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    t0 = time.time()
+    for th in threads:
+        th.start()
+    nb = 0
+    while any(th.is_alive() for th in threads):
+        FR.register_batch_dev(chunk, pb, out=outb, ws=wsb, stream=sb.cuda_stream)      # keeps every CU busy with filter passes / scoring
+        sb.synchronize(); nb += 1
+    for th in threads:
+        th.join()
+    wall = time.time() - t0
+    wsb.close()
+    assert not errors, errors
+    assert nb >= 2, "the batched call did not overlap the single-pair calls"
+    for k, r0 in enumerate(ref):
+        for rep in range(reps):
+            r = results[k][rep]
+            assert r.reserved[1] == 0 and r.ransac.pad0 == 0, (k, rep, hex(r.reserved[1]))          # no hand-off wait hit its bound
+            assert bytes(r.T) == bytes(r0.T) and bytes(r.T_ransac) == bytes(r0.T_ransac), (k, rep)
+            assert (r.ransac.best_h, r.ransac.best_count, r.ransac.best_ssq, r.ransac.n_ids, r.n_corr, r.status) == \
+                   (r0.ransac.best_h, r0.ransac.best_count, r0.ransac.best_ssq, r0.ransac.n_ids, r0.n_corr, r0.status), (k, rep)
+    assert max(latency) < 0.15, max(latency)           # (a timed-out wait alone is 0.2 s)
+    print(f"contention: {len(latency)} single-pair GC calls next to {nb} batched calls in {wall:.2f} s; single-pair latency median "
+          f"{np.median(latency) * 1e3:.2f} ms, max {max(latency) * 1e3:.2f} ms")

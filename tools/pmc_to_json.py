@@ -1,6 +1,6 @@
 """Per-kernel HBM bytes per launch from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) -> profiles/pmc_traffic.json.
 
-    python tools/pmc_to_json.py gpurun_out/round/pmc_fetch.csv gpurun_out/round/pmc_write.csv profiles/pmc_traffic.json
+    python tools/pmc_to_json.py gpurun_out/round/pmc_fetch.csv gpurun_out/round/pmc_write.csv profiles/pmc_traffic.json [commit]
 
 hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: both counters are KiB, and on gfx950 FETCH_SIZE reports half of a wide
 coalesced read (/opt/skills/guides/MI355X_MICROARCH.md, HBM / rocprofv3 section).
@@ -31,31 +31,34 @@ def per_kernel(path, counter):
     return {k: v[0] / v[1] for k, v in acc.items()}, {k: v[1] for k, v in acc.items()}
 
 
-def main(fetch_csv, write_csv, out):
+def main(fetch_csv, write_csv, out, commit="commit unrecorded"):
     (f, nf), (w, _) = per_kernel(fetch_csv, "FETCH_SIZE"), per_kernel(write_csv, "WRITE_SIZE")
-    res = {"_how": "rocprofv3 --pmc FETCH_SIZE (and, in a separate run, --pmc WRITE_SIZE) --output-format csv -- python3 bench.py "
+    res = {"_meta": {"commit": commit, "note": "source tree the counters were collected on (passed to the profiling script from `git rev-parse`: the GPU box has no .git)"},
+           "_how": "rocprofv3 --pmc FETCH_SIZE (and, in a separate run, --pmc WRITE_SIZE) --output-format csv -- python3 bench.py "
                    "--steps 2 --warmup 1 --streams 1 --pairs 32 --no-cpu-baseline ; per-launch averages over all launches of the run "
                    "(a launch of the batched path covers the 32 pairs of one lr_register_batch call); "
                    "FETCH_SIZE/WRITE_SIZE are KiB; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE reports half of a "
                    "wide coalesced read, MI355X_MICROARCH.md section HBM); tools/prof_round2.sh + tools/pmc_to_json.py"}
     for k in sorted(set(f) | set(w)):
+        if not k.strip():
+            continue
         fk, wk = f.get(k, 0.0), w.get(k, 0.0)
         res[k] = {"FETCH_SIZE_KiB": round(fk, 1), "WRITE_SIZE_KiB": round(wk, 1), "hbm_bytes_per_launch": int((2 * fk + wk) * 1024),
                   "launches": nf.get(k, 0)}
     # whole pair: every launch of the library's own kernels (not the input generation, torch / rocprim / rocBLAS / runtime fills),
     # over the pairs the profiled run registered: one batched call of 32 pairs per two pass-B launches (warm-up, timed steps and the
     # repetitions bench.py adds for the roofline events)
-    own = [k for k in res if k != "_how" and not k.startswith(("at::", "rocprim::", "Cijk_", "__amd_rocclr", "void at::")) and k.strip()]
+    own = [k for k in res if not k.startswith("_") and not k.startswith(("at::", "rocprim::", "Cijk_", "__amd_rocclr", "void at::")) and k.strip()]
     pairs = res["nn16_passb_kernel"]["launches"] // 2 * 32
     total = sum(res[k]["hbm_bytes_per_launch"] * res[k]["launches"] for k in own)
     res["_pair"] = {"hbm_bytes_per_pair": int(total / pairs), "pairs_in_run": pairs,
                     "kernels": {k: int(res[k]["hbm_bytes_per_launch"] * res[k]["launches"] / pairs) for k in sorted(own, key=lambda k: -res[k]["hbm_bytes_per_launch"] * res[k]["launches"])[:12]}}
     json.dump(res, open(out, "w"), indent=1)
     for k, v in res.items():
-        if k not in ("_how", "_pair"):
+        if not k.startswith("_"):
             print(f"{k:36s} {v['hbm_bytes_per_launch'] / 1e6:9.2f} MB")
     print("per pair:", res["_pair"]["hbm_bytes_per_pair"] / 1e6, "MB")
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:4])
+    main(*sys.argv[1:5])
