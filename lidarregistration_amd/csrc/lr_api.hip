@@ -43,9 +43,12 @@ void carve(lr_workspace *ws, Carver &c)
     ws->H0 = c.take<_Float16>(n0 * 32); ws->H1 = c.take<_Float16>(n1 * 32);
     ws->tau = c.take<float>(n);
     ws->yfin = c.take<float>(n * LR_NN_MAX_STRIPS);
+    ws->yshare = c.take<uint32_t>(n);
     ws->cand_cnt = c.take<int32_t>(LR_NN16_CNT_INTS(n)); ws->cand = c.take<int32_t>(LR_NN16_SEG_INTS(n));
     ws->counters = c.take<int32_t>(LR_CNT_TOTAL);
     ws->bmax0 = c.take<float>(n0 / 32 + 2); ws->bmax1 = c.take<float>(n1 / 32 + 2);
+    ws->bmin0 = c.take<float>(n0 / 32 + 2); ws->bmin1 = c.take<float>(n1 / 32 + 2);
+    ws->nn_range = c.take<float>(8);
     ws->rev_seed = c.take<uint32_t>(n1); ws->rev_rows = c.take<int32_t>(n1);
     ws->rev_seed64 = c.take<unsigned long long>(n1);
     ws->rev_cols = c.take<int32_t>(n0); ws->rev_s1 = c.take<float>(n0); ws->rev_pos = c.take<int32_t>(n0);
@@ -107,7 +110,7 @@ extern "C" int lr_workspace_create_batch(lr_workspace **out, int max_pairs, int 
     ws->dim = dim; ws->max_iters = max_iters > 0 ? max_iters : 1;
     ws->max_pairs = max_pairs; ws->zP = 1; ws->z = lr_zargs{ 0, nullptr };
     // tuning defaults (lr_workspace_option changes them; no environment variable is read anywhere in this library)
-    ws->nn_blocks_target = 512;          // 2 blocks per CU: measured best with many single-pair calls in flight
+    ws->nn_blocks_target = 768;          // 3 blocks per CU = every block of a single pair's filter pass resident at once
     ws->nn_blocks_batch = 3072;
     ws->nn_sample_stride = 0; ws->rev_strips = 0; ws->nn_second_auto = 0;
     Carver sizing;
@@ -148,7 +151,7 @@ extern "C" int lr_workspace_option(lr_workspace *ws, int option, int value)
     LR_REQUIRE(ws, LR_EINVAL, "lr_workspace_option: null workspace");
     LR_REQUIRE(value >= 0, LR_EINVAL, "lr_workspace_option: value must be >= 0");
     switch (option) {
-    case LR_OPT_NN_BLOCKS: ws->nn_blocks_target = value > 0 ? value : 512; break;
+    case LR_OPT_NN_BLOCKS: ws->nn_blocks_target = value > 0 ? value : 768; break;
     case LR_OPT_NN_BLOCKS_BATCH: ws->nn_blocks_batch = value > 0 ? value : 3072; break;
     case LR_OPT_NN_SAMPLE_STRIDE: ws->nn_sample_stride = value > 4096 ? 4096 : value; break;      // (lr_nn16_run clamps it to the strip length)
     case LR_OPT_REV_STRIPS: ws->rev_strips = value > 64 ? 64 : value; break;
@@ -294,7 +297,7 @@ static int prep_both(lr_workspace *ws, const float *F0, int n0, const float *F1,
 static int nn_forward(lr_workspace *ws, const float *F0, int n0, const float *F1, int n1,
                       int32_t *idx1, int32_t *idx2, float *s1, float *s2, hipStream_t st, bool seed_reverse = false)
 {
-    return lr_nn16_run(ws, F0, ws->H0, ws->nrm0, n0, F1, ws->H1, ws->nrm1, ws->bmax1, n1,
+    return lr_nn16_run(ws, F0, ws->H0, ws->nrm0, n0, F1, ws->H1, ws->nrm1, ws->nn_range + 2, n1,
                        idx2 ? 2 : 1, idx1, idx2, s1, idx2 ? s2 : nullptr, st, seed_reverse);
 }
 

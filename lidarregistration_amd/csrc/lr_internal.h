@@ -100,9 +100,13 @@ struct lr_workspace {
     float *nrm0, *nrm1;          // row norms
     _Float16 *H0, *H1;           // [n,32] f16 copies for the matrix-core filter passes
     float *tau;                  // [max_n] per-row candidate threshold
+    uint32_t *yshare;            // [max_n] the rows' tightest threshold so far over all column strips of the filter pass in flight (order-preserving
+                                 // integer image of y, lowered with atomicMin): how the strips of one row block learn from each other
     float *yfin;                 // [LR_NN_MAX_STRIPS][max_n] the rows' final thresholds (y = tau/2) of the forward filter pass, per strip
     int32_t *cand_cnt, *cand;    // segment counters [row blocks][4 waves][strips] and the candidate store (LR_NN16_SEG_INTS)
     float *bmax0, *bmax1;        // per-32-row maxima of the norms (f16 filter error bound)
+    float *bmin0, *bmin1;        // ... and minima
+    float *nn_range;             // [4] largest / smallest squared norm of cloud 0, of cloud 1 (are the norms all alike?  then the walk's candidate test is a sign test)
     uint32_t *rev_seed;          // [max_n1] best forward distance pointing at each cloud-1 row (bit pattern)
     unsigned long long *rev_seed64;  // [max_n1] ... and who: (distance bits << 32) | smallest cloud-0 index at that distance
     int32_t *rev_rows;           // [max_n1] the cloud-1 rows that have one, by descending seed
@@ -218,7 +222,7 @@ int lr_zero_scratch(lr_workspace *ws, void *p, size_t bytes, hipStream_t st);
 // lr_nn16.hip
 int lr_nn16_prep(lr_workspace *ws, const float *F0, int n0, const float *F1, int n1, hipStream_t st, bool zero_counters = false);
 int lr_nn16_run(lr_workspace *ws, const float *Fq, const _Float16 *Hq, const float *nQ, int na,
-                const float *Fc, const _Float16 *Hc, const float *nC, const float *block_max_c, int nb,
+                const float *Fc, const _Float16 *Hc, const float *nC, const float *range_c, int nb,
                 int need, int32_t *idx1, int32_t *idx2, float *s1, float *s2, hipStream_t st, bool seed_reverse = false);
 int lr_nn16_reverse(lr_workspace *ws, const float *F0, const _Float16 *H0, const float *nrm0, const float *bmax0, int n0,
                     const float *F1, const _Float16 *H1, const float *nrm1, int n1, const int32_t *fwd_idx1,

@@ -41,19 +41,26 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define LR_INF __builtin_huge_valf()
 #define LR_IMAX 0x7fffffff
 
+// order-preserving image of a float in an unsigned integer (smaller float <=> smaller integer; NaN never travels)
+__device__ __forceinline__ uint32_t lr_ord_enc(float v) { const uint32_t b = __float_as_uint(v); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+__device__ __forceinline__ float lr_ord_dec(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
+#define LR_ORD_INF 0xff800000u      // lr_ord_enc(+inf)
+
 // ------------------------------------------------------------------ prep: norms + f16 copy
 // Eight threads per row (coalesced 16-byte loads).  The norm is the sequential fp32 fma chain over k = 0..31 of the
 // arithmetic contract: thread t continues the chain over its four values from where thread t-1 stopped.
 // H[row] (64 B) = f16 of k0..31 in order: lane group kb of an MFMA operand reads bytes [16 kb, 16 kb + 16).
 __global__ void __launch_bounds__(256)
-nn16_prep_kernel(const float *__restrict__ Fa, int na, _Float16 *__restrict__ Ha, float *__restrict__ nrma, float *__restrict__ bmaxa,
-                 const float *__restrict__ Fb, int nb, _Float16 *__restrict__ Hb, float *__restrict__ nrmb, float *__restrict__ bmaxb,
-                 uint32_t *__restrict__ seed_b, unsigned long long *__restrict__ seed64_b, int32_t *__restrict__ counters, int zero_counters, int nblk_a, lr_zargs z)
+nn16_prep_kernel(const float *__restrict__ Fa, int na, _Float16 *__restrict__ Ha, float *__restrict__ nrma, float *__restrict__ bmaxa, float *__restrict__ bmina,
+                 const float *__restrict__ Fb, int nb, _Float16 *__restrict__ Hb, float *__restrict__ nrmb, float *__restrict__ bmaxb, float *__restrict__ bminb,
+                 uint32_t *__restrict__ seed_b, unsigned long long *__restrict__ seed64_b, int32_t *__restrict__ counters, int zero_counters, int nblk_a,
+                 uint32_t *__restrict__ yshare_a, lr_zargs z)
 {
-    __shared__ float s_m[4];
+    __shared__ float s_m[4], s_n[4];
     if (z.descs) { const lr_pair_desc d = z.descs[blockIdx.z]; Fa = d.F0; na = d.n0; Fb = d.F1; nb = d.n1; }
+    lr_z(bmina, z, blockIdx.z); lr_z(bminb, z, blockIdx.z);
     lr_z(Ha, z, blockIdx.z); lr_z(nrma, z, blockIdx.z); lr_z(bmaxa, z, blockIdx.z); lr_z(Hb, z, blockIdx.z); lr_z(nrmb, z, blockIdx.z);
-    lr_z(bmaxb, z, blockIdx.z); lr_z(seed_b, z, blockIdx.z); lr_z(seed64_b, z, blockIdx.z); lr_z(counters, z, blockIdx.z);
+    lr_z(bmaxb, z, blockIdx.z); lr_z(seed_b, z, blockIdx.z); lr_z(seed64_b, z, blockIdx.z); lr_z(counters, z, blockIdx.z); lr_z(yshare_a, z, blockIdx.z);
     // first kernel of a pair: the counter block starts from zero (lr_register_pair) and the distance range of
     // lr_nn16_reverse from { 0x7f7f7f7f, 0 }
     if (counters && blockIdx.x == 0 && (int)threadIdx.x < LR_CNT_TOTAL) {
@@ -68,6 +75,7 @@ nn16_prep_kernel(const float *__restrict__ Fa, int na, _Float16 *__restrict__ Ha
     _Float16 *__restrict__ H = second ? Hb : Ha;
     float *__restrict__ nrm = second ? nrmb : nrma;
     float *__restrict__ block_max = second ? bmaxb : bmaxa;
+    float *__restrict__ block_min = second ? bminb : bmina;
     const int n = second ? nb : na;
     const int blk = second ? blockIdx.x - nblk_a : blockIdx.x;
     const int gid = blk * 256 + threadIdx.x;
@@ -90,6 +98,7 @@ nn16_prep_kernel(const float *__restrict__ Fa, int na, _Float16 *__restrict__ Ha
     if (live) {
         if (t == 0) {
             nrm[row] = norm;
+            if (!second && yshare_a) yshare_a[row] = LR_ORD_INF;      // "no strip of the forward filter pass has a threshold for this row yet"
             if (second && seed_b) { seed_b[row] = 0x7f7f7f7fu; seed64_b[row] = ~0ull; }      // "no query points at this row yet" (lr_nn16_reverse)
         }
         const int pos = 4 * t;
@@ -99,12 +108,39 @@ nn16_prep_kernel(const float *__restrict__ Fa, int na, _Float16 *__restrict__ Ha
     }
     // largest norm of the block (32 rows) -> block_max[blockIdx.x]; the threshold kernel reduces that short array
     // (no same-address atomics: thousands of them serialise at ~12 ns each)
-    float m = live ? norm : 0.0f;
+    float m = live ? norm : 0.0f, mn = live ? norm : LR_INF;      // (a NaN norm drops out of fmaxf / fminf: such rows are re-done exactly anyway)
 #pragma unroll
-    for (int k = 32; k >= 1; k >>= 1) m = fmaxf(m, __shfl_xor(m, k));
-    if (lane == 0) s_m[threadIdx.x >> 6] = m;
+    for (int k = 32; k >= 1; k >>= 1) { m = fmaxf(m, __shfl_xor(m, k)); mn = fminf(mn, __shfl_xor(mn, k)); }
+    if (lane == 0) { s_m[threadIdx.x >> 6] = m; s_n[threadIdx.x >> 6] = mn; }
     __syncthreads();
-    if (threadIdx.x == 0) block_max[blk] = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+    if (threadIdx.x == 0) {
+        block_max[blk] = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+        if (block_min) block_min[blk] = fminf(fminf(s_n[0], s_n[1]), fminf(s_n[2], s_n[3]));
+    }
+}
+
+// largest / smallest squared norm of both clouds from the per-32-row values of the prep kernel: range[0..1] cloud a, range[2..3] cloud b
+// (one block per cloud and pair; the filter-pass blocks then read two floats instead of reducing ~1000 each)
+__global__ void __launch_bounds__(256)
+nn16_range_kernel(int na, const float *__restrict__ bmaxa, const float *__restrict__ bmina, int nb, const float *__restrict__ bmaxb,
+                  const float *__restrict__ bminb, float *__restrict__ range, lr_zargs z)
+{
+    __shared__ float s_m[4], s_n[4];
+    if (z.descs) { na = z.descs[blockIdx.z].n0; nb = z.descs[blockIdx.z].n1; }
+    lr_z(bmaxa, z, blockIdx.z); lr_z(bmina, z, blockIdx.z); lr_z(bmaxb, z, blockIdx.z); lr_z(bminb, z, blockIdx.z); lr_z(range, z, blockIdx.z);
+    const bool second = blockIdx.x == 1;
+    const float *__restrict__ bmax = second ? bmaxb : bmaxa, *__restrict__ bmin = second ? bminb : bmina;
+    const int nblk = ((second ? nb : na) + 31) >> 5;
+    float mx = 0.0f, mn = LR_INF;
+    for (int b = threadIdx.x; b < nblk; b += 256) { mx = fmaxf(mx, bmax[b]); mn = fminf(mn, bmin[b]); }
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) { mx = fmaxf(mx, __shfl_xor(mx, k)); mn = fminf(mn, __shfl_xor(mn, k)); }
+    if ((threadIdx.x & 63) == 0) { s_m[threadIdx.x >> 6] = mx; s_n[threadIdx.x >> 6] = mn; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        range[2 * second] = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+        range[2 * second + 1] = fminf(fminf(s_n[0], s_n[1]), fminf(s_n[2], s_n[3]));
+    }
 }
 
 // ------------------------------------------------------------------ filter pass: sample phase + candidate walk in one kernel
@@ -190,8 +226,8 @@ __device__ __forceinline__ float rs_scale(float lo, float hi) { return hi > lo ?
 // norms, how many neighbours are wanted, and the sampling stride of phase 1 (forward direction)
 struct lr_thr_in {
     const float *nQ;
-    const float *block_max_c;
-    int nblk_c, need, sstride;
+    const float *range_c;          // { largest, smallest } squared norm of the column cloud (nn16_range_kernel), or nullptr
+    int need, sstride;
 };
 // grid shape of a 1-D XCD-aware launch + direction (0: rows = cloud 0, columns = cloud 1; 1: the reverse pass)
 struct lr_pb_grid { int gx, gy, total, dir; };
@@ -202,13 +238,14 @@ __device__ unsigned long long lr_pb_clk[4096 * 2];      // development probe: sh
 #if LR_PB_EXP & 16
 __device__ unsigned long long lr_pb_stat[16];             // development probe: waves, tests, slow-path visits, hits, derive() rounds, 16-entry groups
 #endif
+template <bool SIGN>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *__restrict__ rowmap, const int32_t *__restrict__ na_dev,
                   const _Float16 *__restrict__ Hc, const float *__restrict__ nC, int nb,
                   int tiles_per_strip, const float *__restrict__ tau, int32_t *__restrict__ cand_cnt, int32_t *__restrict__ cand,
                   const int32_t *__restrict__ colmap, const float *__restrict__ tile_min, const uint32_t *__restrict__ row_bound,
                   const int32_t *__restrict__ rev_offs, const uint32_t *__restrict__ rev_range, float *__restrict__ yfin, int yfin_stride,
-                  lr_thr_in thr, lr_pb_grid pg, lr_zargs z)
+                  uint32_t *__restrict__ yshare, lr_thr_in thr, lr_pb_grid pg, lr_zargs z)
 {
     // 1-D XCD-aware grid -> (row block, strip, pair): the blocks one XCD receives are consecutive row blocks of the same
     // (strip, pair), i.e. they stream the same columns through that XCD's L2
@@ -221,16 +258,28 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     if (z.descs) {
         const lr_pair_desc d = z.descs[pair];
         na_host = pg.dir ? d.n1 : d.n0; nb = pg.dir ? d.n0 : d.n1;
-        thr.nblk_c = (nb + 31) >> 5;
     }
     lr_z(Hq, z, pair); lr_z(rowmap, z, pair); lr_z(na_dev, z, pair); lr_z(Hc, z, pair); lr_z(nC, z, pair); lr_z(tau, z, pair);
     lr_z(cand_cnt, z, pair); lr_z(cand, z, pair); lr_z(colmap, z, pair); lr_z(tile_min, z, pair); lr_z(row_bound, z, pair); lr_z(rev_offs, z, pair); lr_z(rev_range, z, pair);
-    lr_z(thr.nQ, z, pair); lr_z(thr.block_max_c, z, pair); lr_z(yfin, z, pair);
+    lr_z(thr.nQ, z, pair); lr_z(thr.range_c, z, pair); lr_z(yfin, z, pair); lr_z(yshare, z, pair);
     // rows: either 0..na_host-1, or (reverse direction) the ordered list rowmap[0..*na_dev-1]; tau, cand_cnt and cand
     // are indexed by the position in that list.  Columns: Hc/nC as they lie; with colmap they are a permuted copy and
     // a candidate's column id is colmap[position].
     const int na = na_dev ? *na_dev : na_host;
     if (bx * LR_BLOCK_ROWS >= na) return;
+    // The candidate test of the walk, "some accumulator y_i + dot16 >= x_j", takes two forms -- two instantiations of this kernel, both
+    // launched, of which the one the pair's column norms do not ask for returns here.  When the norms are (nearly) all the same -- FCGF
+    // descriptors are L2-normalised -- the smallest column term xhat = min_j x_j is folded into the accumulators' start values:
+    // y_i - xhat + dot16 >= 0 is then NECESSARY for a hit (x_j >= xhat), a sign test: the AND of 8 sign bits, three v_bitop3_b32 + one
+    // v_and_b32 at the full vector rate instead of three v_max3_f32 + one v_max_f32 at half rate, and no per-column operand.  It admits
+    // a few pairs more (those between xhat and x_j); derive() applies the exact x_j to every hit anyway.  With spread-out norms that
+    // slack would flood the hit lists, so SIGN = false compares with x_j itself (xhat = 0).  (NaN or non-positive norms compare
+    // false: the plain test.)
+    float max_nc = 0.0f, min_nc = 0.0f;
+    if (thr.range_c) { max_nc = thr.range_c[0]; min_nc = thr.range_c[1]; }
+    const bool sign_ok = thr.range_c != nullptr && min_nc > 0.0f && max_nc - min_nc <= 1e-4f * max_nc && !(LR_PB_EXP & 128);
+    if (sign_ok != SIGN) return;
+    const float xhat = SIGN ? 0.5f * min_nc : 0.0f;
     __shared__ int s_limit[4];
     constexpr int CH = LR_PB_CH;
     constexpr int XOFF = CH * 32 * LR_LDS_ROW;
@@ -296,14 +345,6 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     // given (reverse direction), or made here by phase 1: U = need-th smallest sampled u' = -2 * (need-th largest g);
     // tau = U + 2E + sqrt band 2^-21 (n0 + U + E) + rounding slop; y = tau/2; +inf when fewer than `need` tiles were sampled
     {
-        __shared__ float s_m[4];
-        float mx = 0.0f;       // max_j n1_j of the column cloud from the per-block maxima of its prep kernel
-        if (thr.block_max_c) for (int b = tid; b < thr.nblk_c; b += 256) mx = fmaxf(mx, thr.block_max_c[b]);
-#pragma unroll
-        for (int k = 32; k >= 1; k >>= 1) mx = fmaxf(mx, __shfl_xor(mx, k));
-        if (lane == 0) s_m[wave] = mx;
-        __syncthreads();
-        const float max_nc = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
         const int rw = bx * LR_BLOCK_ROWS + tid;
         // error term of the row for thresholds made from a filter value found during the walk: y = E' - g (+ 2e-6 |g|)
         float Dv = LR_INF;
@@ -441,12 +482,29 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         }
         __syncthreads();
     }
+    // Several column strips per row block (single-pair and small-batch calls): the strips' blocks run at the same time and each finds
+    // thresholds for the same rows from its own columns.  A threshold is a property of the ROW -- any valid upper bound of its need-th
+    // smallest u' holds for every column -- so the strips pool them: one atomicMin per row on an order-preserving integer image of y
+    // (yshare, set to +inf by the prep kernel), here after the sample phase and then once per tightening round.  The returned value
+    // is what the other strips had found by then.  (A rendezvous of the strips after the sample phase -- a bounded spin on an arrival
+    // counter -- was measured and dropped: the strips of a row block are dispatched too far apart, 127 against 110 us for one pair.)
+    const bool pooled = yshare != nullptr && thr.nQ != nullptr && my_strips > 1 && !(LR_PB_EXP & 4);
+    if (pooled) {
+        const int rw = bx * LR_BLOCK_ROWS + tid;
+        if (rw < na) {
+            const float yv = s_Y[tid];
+            if (yv == yv) { const float other = lr_ord_dec(atomicMin(&yshare[rw], lr_ord_enc(yv))); if (other < yv) s_Y[tid] = other; }
+        }
+        __syncthreads();
+    }
 
     // the lane's 4 x 4 threshold registers: register g of row block rbk <-> row 16 rbk + 4 kb + g of the wave
     f32x4 y4[4];
     auto load_y = [&]() {
 #pragma unroll
         for (int rbk = 0; rbk < 4; ++rbk) y4[rbk] = *reinterpret_cast<const f32x4 *>(&s_Y[wave * 64 + 16 * rbk + 4 * kb]);
+#pragma unroll
+        for (int rbk = 0; rbk < 4; ++rbk) y4[rbk] -= xhat;          // (xhat = 0 unless SIGN: x - 0 is x)
     };
     load_y();
 #if LR_PB_EXP & 16
@@ -531,7 +589,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
                 const bool valid = e < nlist;
                 const int col = (int)v[g].x;
                 // padding columns (past the end of the cloud or of the strip) pass the walk's test only when the threshold is +inf
-                const float x = (valid && col < nb && (col >> 5) < t_end) ? 0.5f * xn[g] : LR_INF;
+                const float x = (valid && col < nb && (col >> 5) < t_end) ? 0.5f * xn[g] - xhat : LR_INF;      // (xhat = 0 unless SIGN)
                 f32x4 d[4];
 #pragma unroll
                 for (int rbk = 0; rbk < 4; ++rbk) d[rbk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[rbk], bf[g], y4[rbk], 0, 0, 0);
@@ -570,7 +628,13 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
             const int rl = wave * 64 + lane;
             const float gn = thr.need >= 2 ? s_N2[rl] : s_N1[rl];
             const float yn = (s_D[rl] - gn) + 2e-6f * fabsf(gn);
-            if (yn < s_Y[rl]) s_Y[rl] = yn;                 // (NaN compares false: the row keeps its threshold)
+            float yv = s_Y[rl];
+            if (yn < yv) yv = yn;                           // (NaN compares false: the row keeps its threshold)
+            if (pooled && row0 + lane < na && yv == yv) {   // pool with the row block's other strips
+                const float other = lr_ord_dec(atomicMin(&yshare[row0 + lane], lr_ord_enc(yv)));
+                if (other < yv) yv = other;
+            }
+            s_Y[rl] = yv;
             load_y();
         }
 #if LR_PB_EXP & 16
@@ -624,13 +688,23 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         asm volatile("" :: "v"(lo4), "v"(hi4));
         return;
 #endif
-        float m;
-        asm("v_max3_f32 %0, %1, %2, %3\n\tv_max3_f32 %0, %0, %4, %5\n\tv_max3_f32 %0, %0, %6, %7\n\tv_max_f32 %0, %0, %8"
-            : "=&v"(m)
-            : "v"(lo4[0]), "v"(lo4[1]), "v"(lo4[2]), "v"(lo4[3]), "v"(hi4[0]), "v"(hi4[1]), "v"(hi4[2]), "v"(hi4[3]));
-        const unsigned long long hit = __builtin_amdgcn_ballot_w64(m >= x);
+        bool mine_hit;
+        if constexpr (SIGN) {
+            int sg;
+            asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x80\n\tv_bitop3_b32 %0, %0, %4, %5 bitop3:0x80\n\tv_bitop3_b32 %0, %0, %6, %7 bitop3:0x80\n\tv_and_b32 %0, %0, %8"
+                : "=&v"(sg)
+                : "v"(lo4[0]), "v"(lo4[1]), "v"(lo4[2]), "v"(lo4[3]), "v"(hi4[0]), "v"(hi4[1]), "v"(hi4[2]), "v"(hi4[3]));
+            mine_hit = sg >= 0;                        // the AND of the sign bits is clear: some register is not negative
+        } else {
+            float m;
+            asm("v_max3_f32 %0, %1, %2, %3\n\tv_max3_f32 %0, %0, %4, %5\n\tv_max3_f32 %0, %0, %6, %7\n\tv_max_f32 %0, %0, %8"
+                : "=&v"(m)
+                : "v"(lo4[0]), "v"(lo4[1]), "v"(lo4[2]), "v"(lo4[3]), "v"(hi4[0]), "v"(hi4[1]), "v"(hi4[2]), "v"(hi4[3]));
+            mine_hit = m >= x;
+        }
+        const unsigned long long hit = __builtin_amdgcn_ballot_w64(mine_hit);
         if (__builtin_expect(hit != 0ull, 0)) {       // rare: keeps the common path a fall-through
-            if (m >= x) {
+            if (mine_hit) {
                 const int pos = wcnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(hit >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hit, 0u));
                 if (pos < LR_PB_WLIST) wlist[wave][pos] = make_uint2((unsigned)col, (unsigned)(q << 10) | code_kb);
             }
@@ -715,13 +789,11 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
                 if (wcnt >= LR_PB_WLIST / 2) flush(); else derive(true);
             }
         }
-        // drain: the last tile of the last chunk sits in the accumulators.  The inline-asm maxima below read MFMA results the
+        // drain: the last tile of the last chunk sits in the accumulators.  The inline-asm tests below read MFMA results the
         // compiler cannot see them read (no automatic wait states): inside the loop every such read is at least two
         // MFMAs behind its producer; here an explicit wait covers the 8-pass MFMA write latency.
-        {
-            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-            drain();
-        }
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+        drain();
         flush();           // (with a last tightening round: the entries get their g, the rows their final thresholds)
     }
     if (lane == 0) {
@@ -947,20 +1019,24 @@ nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, in
 // ------------------------------------------------------------------ host side
 int lr_nn16_prep(lr_workspace *ws, const float *F0, int n0, const float *F1, int n1, hipStream_t st, bool zero_counters)
 {
-    hipLaunchKernelGGL(nn16_prep_kernel, dim3(lr_cdiv(n0, 32) + lr_cdiv(n1, 32), 1, ws->zP), dim3(256), 0, st, F0, n0, ws->H0, ws->nrm0, ws->bmax0,
-                       F1, n1, ws->H1, ws->nrm1, ws->bmax1, ws->rev_seed, ws->rev_seed64, ws->counters, zero_counters ? 1 : 0, lr_cdiv(n0, 32), ws->z);
+    hipLaunchKernelGGL(nn16_prep_kernel, dim3(lr_cdiv(n0, 32) + lr_cdiv(n1, 32), 1, ws->zP), dim3(256), 0, st, F0, n0, ws->H0, ws->nrm0, ws->bmax0, ws->bmin0,
+                       F1, n1, ws->H1, ws->nrm1, ws->bmax1, ws->bmin1, ws->rev_seed, ws->rev_seed64, ws->counters, zero_counters ? 1 : 0, lr_cdiv(n0, 32), ws->yshare, ws->z);
+    hipLaunchKernelGGL(nn16_range_kernel, dim3(2, 1, ws->zP), dim3(256), 0, st, n0, (const float *)ws->bmax0, (const float *)ws->bmin0, n1, (const float *)ws->bmax1,
+                       (const float *)ws->bmin1, ws->nn_range, ws->z);
     LR_LAUNCH_CHECK();
     return LR_OK;
 }
 
 int lr_nn16_run(lr_workspace *ws, const float *Fq, const _Float16 *Hq, const float *nQ, int na,
-                const float *Fc, const _Float16 *Hc, const float *nC, const float *block_max_c, int nb,
+                const float *Fc, const _Float16 *Hc, const float *nC, const float *range_c, int nb,
                 int need, int32_t *idx1, int32_t *idx2, float *s1, float *s2, hipStream_t st, bool seed_reverse)
 {
     const int ntiles = lr_cdiv(nb, 32);
     const int row_blocks = lr_cdiv(na, LR_BLOCK_ROWS);
     // strips: enough blocks (over all pairs of a batched call) to fill 256 CUs a few times over, at least 64 tiles per strip
-    int strips = lr_cdiv(ws->zP > 1 ? ws->nn_blocks_batch : ws->nn_blocks_target, row_blocks * ws->zP);
+    // (a single pair: as many strips as keep ALL blocks resident at once -- the strips of a row block pool their thresholds, see the
+    // kernel, so a shorter strip no longer means a looser one, and a second round of blocks would be a tail)
+    int strips = ws->zP > 1 ? lr_cdiv(ws->nn_blocks_batch, row_blocks * ws->zP) : ws->nn_blocks_target / row_blocks;
     int smax = ntiles / 64;
     if (strips > smax) strips = smax;
     if (strips > LR_NN_MAX_STRIPS) strips = LR_NN_MAX_STRIPS;
@@ -969,7 +1045,8 @@ int lr_nn16_run(lr_workspace *ws, const float *Fq, const _Float16 *Hq, const flo
     // phase 1 of the filter pass samples every `sstride`-th tile of a strip (any subset gives a valid, if looser, start; the walk
     // tightens it).  Its cost is ~ tiles / stride per row, the extra hits of a looser start ~ 2 ln(stride) per row: about 32
     // sampled tiles per strip, a stride of at most 16 (32 for very long strips).
-    int sstride = ws->nn_sample_stride > 0 ? ws->nn_sample_stride : tps / 32;
+    // With several strips per row block the start thresholds are pooled, so the budget is per ROW: about 64 sampled tiles over all strips.
+    int sstride = ws->nn_sample_stride > 0 ? ws->nn_sample_stride : (strips > 1 ? ntiles / 64 : tps / 32);
     if (ws->nn_sample_stride <= 0) { const int cap = tps > 2048 ? 32 : 16; if (sstride > cap) sstride = cap; }
     if (sstride < 1) sstride = 1;
     if (sstride > tps) sstride = tps;          // (one sampled tile per strip at least; keeps phase 1's column index in range)
@@ -977,11 +1054,20 @@ int lr_nn16_run(lr_workspace *ws, const float *Fq, const _Float16 *Hq, const flo
     const int total = row_blocks * strips * ws->zP;
     dim3 grid(8 * lr_cdiv(total, 8));
     if (ws->timing && !ws->ev_pending) { LR_HIP(hipEventRecord(ws->ev[0], st)); }
-    lr_thr_in thr = { nQ, block_max_c, lr_cdiv(nb, 32), need, sstride };
-    hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), 0, st, Hq, na, (const int32_t *)nullptr, (const int32_t *)nullptr, Hc, nC, nb,
+    lr_thr_in thr = { nQ, range_c, need, sstride };
+    // both forms of the walk's candidate test; the blocks of the one the column norms do not ask for return at once
+#define SIGN_ true
+    hipLaunchKernelGGL(nn16_passb_kernel<SIGN_>, grid, dim3(256), 0, st, Hq, na, (const int32_t *)nullptr, (const int32_t *)nullptr, Hc, nC, nb,
                        tps, (const float *)nullptr, ws->cand_cnt, ws->cand, (const int32_t *)nullptr, (const float *)nullptr,
-                       (const uint32_t *)nullptr, (const int32_t *)nullptr, (const uint32_t *)nullptr, ws->yfin, ws->max_n, thr,
+                       (const uint32_t *)nullptr, (const int32_t *)nullptr, (const uint32_t *)nullptr, ws->yfin, ws->max_n, ws->yshare, thr,
                        lr_pb_grid{ row_blocks, strips, total, 0 }, ws->z);
+#undef SIGN_
+#define SIGN_ false
+    hipLaunchKernelGGL(nn16_passb_kernel<SIGN_>, grid, dim3(256), 0, st, Hq, na, (const int32_t *)nullptr, (const int32_t *)nullptr, Hc, nC, nb,
+                       tps, (const float *)nullptr, ws->cand_cnt, ws->cand, (const int32_t *)nullptr, (const float *)nullptr,
+                       (const uint32_t *)nullptr, (const int32_t *)nullptr, (const uint32_t *)nullptr, ws->yfin, ws->max_n, ws->yshare, thr,
+                       lr_pb_grid{ row_blocks, strips, total, 0 }, ws->z);
+#undef SIGN_
     if (ws->timing && !ws->ev_pending) { LR_HIP(hipEventRecord(ws->ev[1], st)); ws->ev_pending = 1; }
     const int ex_gx = lr_cdiv(na, LR_EX_ROWS), ex_total = ex_gx * ws->zP;
     hipLaunchKernelGGL(nn16_exact_kernel, dim3(8 * lr_cdiv(ex_total, 8)), dim3(256), 0, st, Fq, nQ, na, Fc, nC, nb, ws->cand_cnt, ws->cand,
@@ -1254,11 +1340,22 @@ int lr_nn16_reverse(lr_workspace *ws, const float *F0, const _Float16 *H0, const
     dim3 grid(8 * lr_cdiv(total, 8));
     const bool timed = ws->timing && ws->ev_pending == 1 && !ws->rev_recorded;
     if (timed) { LR_HIP(hipEventRecord(ws->ev[4], st)); }
-    hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), 0, st, H1, na, (const int32_t *)ws->rev_rows, (const int32_t *)n_rows,
+#define SIGN_ true
+    hipLaunchKernelGGL(nn16_passb_kernel<SIGN_>, grid, dim3(256), 0, st, H1, na, (const int32_t *)ws->rev_rows, (const int32_t *)n_rows,
                        (const _Float16 *)ws->Hs, (const float *)ws->nrms, nb, tps, ws->tau, ws->cand_cnt, ws->cand,
                        (const int32_t *)ws->rev_cols, seeded ? (const float *)ws->rev_tmin : (const float *)nullptr, (const uint32_t *)seed,
-                       (const int32_t *)ws->rev_hist, (const uint32_t *)range, (float *)nullptr, 0, lr_thr_in{},
+                       (const int32_t *)ws->rev_hist, (const uint32_t *)range, (float *)nullptr, 0, (uint32_t *)nullptr,
+                       lr_thr_in{ nullptr, (const float *)ws->nn_range, 1, 0 },      // (no tightening: the column norms' range selects the form of the walk's test)
                        lr_pb_grid{ row_blocks, strips, total, 1 }, ws->z);
+#undef SIGN_
+#define SIGN_ false
+    hipLaunchKernelGGL(nn16_passb_kernel<SIGN_>, grid, dim3(256), 0, st, H1, na, (const int32_t *)ws->rev_rows, (const int32_t *)n_rows,
+                       (const _Float16 *)ws->Hs, (const float *)ws->nrms, nb, tps, ws->tau, ws->cand_cnt, ws->cand,
+                       (const int32_t *)ws->rev_cols, seeded ? (const float *)ws->rev_tmin : (const float *)nullptr, (const uint32_t *)seed,
+                       (const int32_t *)ws->rev_hist, (const uint32_t *)range, (float *)nullptr, 0, (uint32_t *)nullptr,
+                       lr_thr_in{ nullptr, (const float *)ws->nn_range, 1, 0 },      // (no tightening: the column norms' range selects the form of the walk's test)
+                       lr_pb_grid{ row_blocks, strips, total, 1 }, ws->z);
+#undef SIGN_
     if (timed) { LR_HIP(hipEventRecord(ws->ev[5], st)); ws->rev_recorded = 1; }
     const int ex_gx = lr_cdiv(na, LR_EX_ROWS), ex_total = ex_gx * ws->zP;
     hipLaunchKernelGGL(nn16_exact_kernel, dim3(8 * lr_cdiv(ex_total, 8)), dim3(256), 0, st, F1, nrm1, na, F0, nrm0, nb, ws->cand_cnt, ws->cand,

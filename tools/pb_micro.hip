@@ -5,16 +5,28 @@
 #define PB_SRC "../lidarregistration_amd/csrc/lr_nn16.hip"
 #endif
 #include PB_SRC
+#ifdef PB_OLD_ABI      // kernels of round 3: no pooled-threshold argument
+#define PB_YS
+#define PB_YS_ARG
+#define PB_BMIN_ARG(p)
+#define PB_NEW_ABI 0
+#else
+#define PB_YS ysh,
+#define PB_YS_ARG (uint32_t*)nullptr,
+#define PB_BMIN_ARG(p) (float *)((char *)bmin + (p) * stride),
+#define PB_NEW_ABI 1
+#endif
 #include <vector>
 #include <algorithm>
 #include <random>
 void lr_set_error(const char *, ...) {}
+static void (*g_pre)() = nullptr;      // untimed set-up before every timed call (resets of what the prep kernel initialises in the library)
 template <class F> float timeit(F f, int reps = 8) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int w = 0; w < 2; ++w) f();
+    for (int w = 0; w < 2; ++w) { if (g_pre) g_pre(); f(); }
     hipDeviceSynchronize();
     float best = 1e9;
-    for (int r = 0; r < reps; ++r) { hipEventRecord(e0, 0); f(); hipEventRecord(e1, 0); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); best = ms < best ? ms : best; }
+    for (int r = 0; r < reps; ++r) { if (g_pre) { g_pre(); hipDeviceSynchronize(); } hipEventRecord(e0, 0); f(); hipEventRecord(e1, 0); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); best = ms < best ? ms : best; }
     return best;
 }
 static void print_clk(int total)
@@ -27,6 +39,13 @@ static void print_clk(int total)
     if (!mhz.empty()) printf("  shader clock while a block runs: median %.0f MHz (p10 %.0f, p90 %.0f); block lifetime median %.1f us\n", mhz[mhz.size() / 2], mhz[mhz.size() / 10], mhz[mhz.size() * 9 / 10], us[us.size() / 2]);
 #endif
 }
+#if PB_NEW_ABI
+#define PB_THR(name, nq, need, ss) lr_thr_in name = { nq, nrange, need, ss }
+#define PB_LAUNCH(...) do { hipLaunchKernelGGL(nn16_passb_kernel<true>, __VA_ARGS__); hipLaunchKernelGGL(nn16_passb_kernel<false>, __VA_ARGS__); } while (0)
+#else
+#define PB_THR(name, nq, need, ss) lr_thr_in name = { nq, bmax, (n+31)/32, need, ss }
+#define PB_LAUNCH(...) hipLaunchKernelGGL(nn16_passb_kernel, __VA_ARGS__)
+#endif
 int main(int argc, char **argv)
 {
     const int n = argc > 1 ? atoi(argv[1]) : 30000, P = argc > 2 ? atoi(argv[2]) : 32, strips = argc > 3 ? atoi(argv[3]) : 1;
@@ -35,19 +54,28 @@ int main(int argc, char **argv)
     for (size_t r = 0; r < (size_t)n; ++r) { double s = 0; for (int k = 0; k < 32; ++k) { h[r*32+k] = nd(rng); s += h[r*32+k]*h[r*32+k]; } for (int k = 0; k < 32; ++k) h[r*32+k] /= (float)sqrt(s); }
     // arena layout (bytes): H | nrm | bmax | pu1 | pu2 | tau | cnt | cand
     size_t off = 0; auto take = [&](size_t b) { size_t o = off; off = (off + b + 255) & ~size_t(255); return o; };
-    const size_t oH = take((size_t)n * 64), oN = take((size_t)n * 4), oB = take((size_t)(n / 32 + 2) * 4), o1 = take((size_t)n * 4 * 8), o2 = take((size_t)n * 4 * 8),
-                 oT = take((size_t)n * 4), oY = take((size_t)n * 4 * 8), oC = take(LR_NN16_CNT_INTS(n) * 4), oD = take(LR_NN16_SEG_INTS(n) * 4);
+    const size_t oH = take((size_t)n * 64), oN = take((size_t)n * 4), oB = take((size_t)(n / 32 + 2) * 4), oBm = take((size_t)(n / 32 + 2) * 4), oR = take(64), o1 = take((size_t)n * 4 * 8), o2 = take((size_t)n * 4 * 8),
+                 oT = take((size_t)n * 4), oY = take((size_t)n * 4 * 8), oS = take((size_t)n * 4), oA = take((size_t)(n / 256 + 2) * 4), oC = take(LR_NN16_CNT_INTS(n) * 4), oD = take(LR_NN16_SEG_INTS(n) * 4);
     const size_t stride = off;
     char *base; hipMalloc(&base, stride * P); hipMemset(base, 0, stride * P);
     float *F; hipMalloc(&F, (size_t)n * 128); hipMemcpy(F, h.data(), (size_t)n * 128, hipMemcpyHostToDevice);
-    _Float16 *H = (_Float16 *)(base + oH); float *nrm = (float *)(base + oN), *bmax = (float *)(base + oB), *pu1 = (float *)(base + o1), *pu2 = (float *)(base + o2), *tau = (float *)(base + oT);
+    _Float16 *H = (_Float16 *)(base + oH); float *nrm = (float *)(base + oN), *bmax = (float *)(base + oB), *bmin = (float *)(base + oBm), *nrange = (float *)(base + oR), *pu1 = (float *)(base + o1), *pu2 = (float *)(base + o2), *tau = (float *)(base + oT);
     int32_t *cnt = (int32_t *)(base + oC), *cand = (int32_t *)(base + oD);
+    uint32_t *ysh = (uint32_t *)(base + oS); (void)ysh;
+    int32_t *arr = (int32_t *)(base + oA); (void)arr;
     lr_zargs z0 = { 0, nullptr };
     for (int p = 0; p < P; ++p)
-        hipLaunchKernelGGL(nn16_prep_kernel, dim3((n+31)/32), dim3(256), 0, 0, F, n, (_Float16 *)((char *)H + p * stride), (float *)((char *)nrm + p * stride), (float *)((char *)bmax + p * stride),
-                           F, 0, H, nrm, bmax, (uint32_t*)nullptr, (unsigned long long*)nullptr, (int32_t*)nullptr, 0, (n + 31) / 32, z0);
+        hipLaunchKernelGGL(nn16_prep_kernel, dim3((n+31)/32), dim3(256), 0, 0, F, n, (_Float16 *)((char *)H + p * stride), (float *)((char *)nrm + p * stride), (float *)((char *)bmax + p * stride), PB_BMIN_ARG(p)
+                           F, 0, H, nrm, bmax, PB_BMIN_ARG(0) (uint32_t*)nullptr, (unsigned long long*)nullptr, (int32_t*)nullptr, 0, (n + 31) / 32, PB_YS_ARG z0);
+#if PB_NEW_ABI
+    for (int p = 0; p < P; ++p)
+        hipLaunchKernelGGL(nn16_range_kernel, dim3(1), dim3(256), 0, 0, n, (const float *)((char *)bmax + p * stride), (const float *)((char *)bmin + p * stride), 0, (const float *)bmax,
+                           (const float *)bmin, (float *)((char *)nrange + p * stride), z0);
+#endif
+    (void)bmin; (void)nrange;
     hipDeviceSynchronize();
     lr_zargs z = { stride, nullptr };
+    PB_THR(thr0, nullptr, 2, 16);
     const int ntiles = (n + 31) / 32, row_blocks = (n + LR_BLOCK_ROWS - 1) / LR_BLOCK_ROWS;
     const int total = row_blocks * strips * P;
     dim3 grid(8 * ((total + 7) / 8));
@@ -55,11 +83,13 @@ int main(int argc, char **argv)
     printf("EXP=%d TIGHTEN=%d n=%d P=%d strips=%d blocks=%d\n", LR_PB_EXP, LR_PB_TIGHTEN, n, P, strips, total);
     for (int need : {2, 1})
     for (int sstride : {2, 4, 8, 16, 32, 64}) {
-        lr_thr_in thr = { nrm, bmax, (n+31)/32, need, sstride };
-        auto run = [&] { hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), 0, 0, H, n, (const int32_t*)nullptr, (const int32_t*)nullptr, H, nrm, n, tps, (const float*)nullptr, cnt, cand,
-                                            (const int32_t*)nullptr, (const float*)nullptr, (const uint32_t*)nullptr, (const int32_t*)nullptr, (const uint32_t*)nullptr, (float*)nullptr, 0, thr, lr_pb_grid{ row_blocks, strips, total, 0 }, z); };
+        PB_THR(thr, nrm, need, sstride);
+        static char *s_ysh, *s_arr; static size_t s_stride; static int s_P, s_n; s_ysh = (char *)ysh; s_arr = (char *)arr; s_stride = stride; s_P = P; s_n = n;
+        g_pre = [] { for (int p = 0; p < s_P; ++p) { hipMemsetD32Async((hipDeviceptr_t)(s_ysh + p * s_stride), 0xff800000u, s_n, 0); hipMemsetD32Async((hipDeviceptr_t)(s_arr + p * s_stride), 0, s_n / 256 + 2, 0); } };
+        auto run = [&] { PB_LAUNCH(grid, dim3(256), 0, 0, H, n, (const int32_t*)nullptr, (const int32_t*)nullptr, H, nrm, n, tps, (const float*)nullptr, cnt, cand,
+                                            (const int32_t*)nullptr, (const float*)nullptr, (const uint32_t*)nullptr, (const int32_t*)nullptr, (const uint32_t*)nullptr, (float*)nullptr, 0, PB_YS thr, lr_pb_grid{ row_blocks, strips, total, 0 }, z); };
         float msp = timeit([&] { run(); });
-        run();
+        g_pre(); run();
         const int nseg = row_blocks * 4 * (strips + 1);
         std::vector<int32_t> c1(nseg); hipMemcpy(c1.data(), cnt, (size_t)nseg * 4, hipMemcpyDeviceToHost);
         double tot = 0; int over = 0; for (int i = 0; i < nseg; ++i) if (i % (strips + 1) != strips) { if (c1[i] < 0) over++; else tot += c1[i]; }
@@ -81,16 +111,16 @@ int main(int argc, char **argv)
         // the walk alone on REAL thresholds: the final thresholds of a tightening run (stride 16) given as tau -> no sample phase, no
         // tightening, only the true candidates hit (accumulators hold real values, unlike the -1e30 run below)
         float *yf = (float *)(base + oY);
-        lr_thr_in thr = { nrm, bmax, (n+31)/32, 2, 16 };
-        hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), 0, 0, H, n, (const int32_t*)nullptr, (const int32_t*)nullptr, H, nrm, n, tps, (const float*)nullptr, cnt, cand,
-                           (const int32_t*)nullptr, (const float*)nullptr, (const uint32_t*)nullptr, (const int32_t*)nullptr, (const uint32_t*)nullptr, yf, n, thr, lr_pb_grid{ row_blocks, strips, total, 0 }, z);
+        PB_THR(thr, nrm, 2, 16);
+        PB_LAUNCH(grid, dim3(256), 0, 0, H, n, (const int32_t*)nullptr, (const int32_t*)nullptr, H, nrm, n, tps, (const float*)nullptr, cnt, cand,
+                           (const int32_t*)nullptr, (const float*)nullptr, (const uint32_t*)nullptr, (const int32_t*)nullptr, (const uint32_t*)nullptr, yf, n, PB_YS thr, lr_pb_grid{ row_blocks, strips, total, 0 }, z);
         hipDeviceSynchronize();
         std::vector<float> y((size_t)n * strips), t(n);
         hipMemcpy(y.data(), yf, (size_t)n * strips * 4, hipMemcpyDeviceToHost);
         for (int i = 0; i < n; ++i) { float m = y[i]; for (int sidx = 1; sidx < strips; ++sidx) m = std::min(m, y[(size_t)sidx * n + i]); t[i] = 2.0f * m; }
         for (int p = 0; p < P; ++p) hipMemcpy((char *)tau + p * stride, t.data(), (size_t)n * 4, hipMemcpyHostToDevice);
-        auto run = [&] { hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), 0, 0, H, n, (const int32_t*)nullptr, (const int32_t*)nullptr, H, nrm, n, tps, (const float*)tau, cnt, cand,
-                                            (const int32_t*)nullptr, (const float*)nullptr, (const uint32_t*)nullptr, (const int32_t*)nullptr, (const uint32_t*)nullptr, (float*)nullptr, 0, lr_thr_in{}, lr_pb_grid{ row_blocks, strips, total, 0 }, z); };
+        auto run = [&] { PB_LAUNCH(grid, dim3(256), 0, 0, H, n, (const int32_t*)nullptr, (const int32_t*)nullptr, H, nrm, n, tps, (const float*)tau, cnt, cand,
+                                            (const int32_t*)nullptr, (const float*)nullptr, (const uint32_t*)nullptr, (const int32_t*)nullptr, (const uint32_t*)nullptr, (float*)nullptr, 0, PB_YS thr0, lr_pb_grid{ row_blocks, strips, total, 0 }, z); };
         float msp = timeit([&] { run(); });
         const int nseg = row_blocks * 4 * (strips + 1);
         std::vector<int32_t> c1(nseg); hipMemcpy(c1.data(), cnt, (size_t)nseg * 4, hipMemcpyDeviceToHost);
@@ -107,8 +137,8 @@ int main(int argc, char **argv)
     {
         std::vector<float> t(n, -1e30f);
         for (int p = 0; p < P; ++p) hipMemcpy((char *)tau + p * stride, t.data(), (size_t)n * 4, hipMemcpyHostToDevice);
-        float msp = timeit([&] { hipLaunchKernelGGL(nn16_passb_kernel, grid, dim3(256), 0, 0, H, n, (const int32_t*)nullptr, (const int32_t*)nullptr, H, nrm, n, tps, (const float*)tau, cnt, cand,
-                                                    (const int32_t*)nullptr, (const float*)nullptr, (const uint32_t*)nullptr, (const int32_t*)nullptr, (const uint32_t*)nullptr, (float*)nullptr, 0, lr_thr_in{}, lr_pb_grid{ row_blocks, strips, total, 0 }, z); });
+        float msp = timeit([&] { PB_LAUNCH(grid, dim3(256), 0, 0, H, n, (const int32_t*)nullptr, (const int32_t*)nullptr, H, nrm, n, tps, (const float*)tau, cnt, cand,
+                                                    (const int32_t*)nullptr, (const float*)nullptr, (const uint32_t*)nullptr, (const int32_t*)nullptr, (const uint32_t*)nullptr, (float*)nullptr, 0, PB_YS thr0, lr_pb_grid{ row_blocks, strips, total, 0 }, z); });
         printf("walk only, no candidates:       %8.3f ms  = %6.1f us/pair\n", msp, msp * 1e3 / P);
         print_clk(total);
     }

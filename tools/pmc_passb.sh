@@ -19,7 +19,8 @@ python3 - $O <<'PY' | tee $S/summary.txt
 import csv, glob, sys, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob(sys.argv[1] + "/g*.csv")):
-    rows = [r for r in csv.DictReader(open(f)) if "nn16_passb" in r["Kernel_Name"]]
+    # (the kernel has two instantiations, both launched; on the bench's unit-norm descriptors the blocks of <false> return at once)
+    rows = [r for r in csv.DictReader(open(f)) if "nn16_passb" in r["Kernel_Name"] and ("ILb1E" in r["Kernel_Name"] or "<true>" in r["Kernel_Name"])]
     # launches alternate forward, reverse
     by = collections.defaultdict(list)
     for r in rows: by[r["Counter_Name"]].append(float(r["Counter_Value"]))
