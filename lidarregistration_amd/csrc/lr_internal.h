@@ -24,7 +24,7 @@ void lr_set_error(const char *fmt, ...);
     } while (0)
 
 // Candidate store of the f16 filter: every wave of a pass-B block (64 query rows x one column strip) owns a private segment
-// of { column, code | register mask } entries; the segments of one wave's rows over all strips hold at most
+// of { column | lane group, row mask | filter value } entries (lr_nn16.hip, LR_PB_*); the segments of one wave's rows over all strips hold at most
 // LR_NN16_SEG entries (8 bytes each).  Columns must be < 2^22.
 #define LR_NN16_SEG 4096
 #define LR_NN16_SEG_INTS(n) ((size_t)((n) / 256 + 1) * 4 * LR_NN16_SEG * 2)      // int32 words of the store for n query rows

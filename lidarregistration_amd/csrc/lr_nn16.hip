@@ -200,16 +200,21 @@ __device__ __forceinline__ int lr_lds_off(int j, int p) { return j * LR_LDS_ROW 
 #define LR_PB_EXP 0     // development switches (tools/pb_micro.hip): 1 no staging, 2 no tests, 4 no tightening
 #endif
 #define LR_PB_WLIST 512          // entries per wave (12 bytes each)
-#define LR_PB_HASG 0x1000u       // entry flag: whval holds the entry's filter value g (single-row entries seen by a tightening round)
+// Entry of a hit list / of the candidate store (8 bytes): x = column (22 bits) | kb << 22 | LR_PB_HASG; y = 16-bit row mask | g16 << 16.
+// kb = lane / 16 of the lane that saw the hit: bit b = 4 rbk + g of the mask <-> row 16 rbk + 4 kb + g of the wave (the lane's 16
+// accumulator registers of one 16-column block).  The walk parks entries with an empty mask; derive() fills it in.
+#define LR_PB_COLMASK 0x3fffffu
+#define LR_PB_HASG 0x1000000u    // entry flag (in x): exactly one row, and y carries its filter value g rounded up to 16 bits
+#ifndef LR_PB_DGROUPS
+#define LR_PB_DGROUPS 3          // groups of 16 entries derive() has in flight at once (registers: 9 per group)
+#endif
 #ifndef LR_PB_TIGHTEN
 #define LR_PB_TIGHTEN 48         // new entries of a wave that trigger a tightening round
 #endif
 
-// row (0..63 of the wave) of register i (0..7: mask bit 7 - i) of an entry with the given code
-__device__ __forceinline__ int lr_pb_row(int code, int i)
-{
-    return 32 * (code >> 2) + 16 * (i >> 2) + 4 * (code & 3) + (i & 3);       // code = (row-block pair q) * 4 + (lane / 16)
-}
+// row (0..63 of the wave) of mask bit b (0..15) of an entry of lane group kb
+__device__ __forceinline__ int lr_pb_row(int kb, int b) { return 16 * (b >> 2) + 4 * kb + (b & 3); }
+__device__ __forceinline__ int lr_pb_kb(unsigned x) { return (int)(x >> 22) & 3; }
 
 #define LR_RS_BUCKETS 4096
 
@@ -285,7 +290,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     constexpr int XOFF = CH * 32 * LR_LDS_ROW;
     constexpr int BUF = XOFF + CH * 32 * 4;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
-    __shared__ uint2 wlist[4][LR_PB_WLIST];   // per wave: { column, (code << 8) | register mask (0 until derive() has seen the entry) }, code = (row-block pair q) * 4 + lane / 16
+    __shared__ uint2 wlist[4][LR_PB_WLIST];   // per wave: entries as above (mask empty until derive() has seen the entry)
     __shared__ float whval[4][LR_PB_WLIST];   //           filter value g of a single-row entry (LR_PB_HASG)
     // per row of the block: y = tau/2 (what the accumulators start from), the row's error term, the two largest g of the walk
     __shared__ __attribute__((aligned(16))) float s_Y[LR_BLOCK_ROWS];
@@ -523,7 +528,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         const int col0 = (t_begin + c * CH) * 32;       // wave-uniform
         stage[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcH, st_voff, col0 * 64, 0));
         stage[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcH, st_voff + 16, col0 * 64, 0));
-        stage_n = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrcN, st_noff, col0 * 4, 0));
+        if constexpr (!SIGN) stage_n = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrcN, st_noff, col0 * 4, 0));
         const int col = col0 + (tid & (CH * 32 - 1));
         stage_ok = col < nb && (col >> 5) < t_end;
     };
@@ -531,7 +536,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         *reinterpret_cast<f32x4 *>(&lds[buf * BUF + st_lds0]) = stage[0];
         *reinterpret_cast<f32x4 *>(&lds[buf * BUF + st_lds1]) = stage[1];
         // x_j = n1[j]/2 ; +inf masks columns past the end of the cloud or of the strip
-        if (tid < CH * 32) *reinterpret_cast<float *>(&lds[buf * BUF + XOFF + tid * 4]) = stage_ok ? 0.5f * stage_n : LR_INF;
+        if constexpr (!SIGN) { if (tid < CH * 32) *reinterpret_cast<float *>(&lds[buf * BUF + XOFF + tid * 4]) = stage_ok ? 0.5f * stage_n : LR_INF; }
     };
     // per-lane byte offsets of the fragment / x_j of tile 0 of the current and the other buffer; tile k adds a constant.  The lane
     // reads piece kb of columns c and 16 + c of the tile, and their x_j
@@ -540,11 +545,13 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     auto read_b = [&](int fo, int xo, int k, f16x8 &b0, f16x8 &b1, f32x2 &xj) {
         b0 = *reinterpret_cast<const f16x8 *>(&lds[fo + k * 32 * LR_LDS_ROW]);
         b1 = *reinterpret_cast<const f16x8 *>(&lds[fo + k * 32 * LR_LDS_ROW + 16 * LR_LDS_ROW]);
-        xj.x = *reinterpret_cast<const float *>(&lds[xo + k * 32 * 4]);
-        xj.y = *reinterpret_cast<const float *>(&lds[xo + k * 32 * 4 + 64]);
+        if constexpr (!SIGN) {      // (the sign form of the test reads no per-column operand)
+            xj.x = *reinterpret_cast<const float *>(&lds[xo + k * 32 * 4]);
+            xj.y = *reinterpret_cast<const float *>(&lds[xo + k * 32 * 4 + 64]);
+        }
     };
     int wcnt = 0;            // entries in this wave's list (wave-uniform: lives in a scalar register)
-    const unsigned code_kb = (unsigned)kb << 8;
+    const unsigned code_kb = (unsigned)kb << 22;
     int wdone = 0;           // ... of which the tightening has seen this many
     // The wave owns one segment of the candidate store: seg[(row block, wave, strip)][seg_cap] entries { column, code | mask }
     // exactly as they lie in its LDS list.  Emptying the list is a compacting copy with plain stores -- no atomics, nothing
@@ -572,53 +579,51 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         ++n_rounds; n_groups += (nlist - wdone + 15) >> 4;
         const unsigned long long tk0 = __builtin_amdgcn_s_memrealtime();
 #endif
-        for (int e0 = wdone; e0 < nlist; e0 += 64) {
-            // up to four groups of 16 entries per pass: all their gathers are in flight before the first MFMA (one L2 latency per pass)
-            uint2 v[4]; f16x8 bf[4]; float xn[4];
+        for (int e0 = wdone; e0 < nlist; e0 += 16 * LR_PB_DGROUPS) {
+            // a few groups of 16 entries per pass: all their gathers are in flight before the first MFMA (one L2 latency per pass)
+            uint2 v[LR_PB_DGROUPS]; f16x8 bf[LR_PB_DGROUPS]; float xn[LR_PB_DGROUPS];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
+            for (int g = 0; g < LR_PB_DGROUPS; ++g) {
                 v[g] = wlist[wave][min(e0 + 16 * g + c16, LR_PB_WLIST - 1)];
-                const int col = (int)v[g].x;
+                const int col = (int)(v[g].x & LR_PB_COLMASK);
                 bf[g] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrcH, col * 64 + kb * 16, 0, 0));
                 xn[g] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrcN, col * 4, 0, 0));
             }
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
+            for (int g = 0; g < LR_PB_DGROUPS; ++g) {
                 if (e0 + 16 * g >= nlist) break;              // (wave-uniform)
                 const int e = e0 + 16 * g + c16;
                 const bool valid = e < nlist;
-                const int col = (int)v[g].x;
+                const int col = (int)(v[g].x & LR_PB_COLMASK);
                 // padding columns (past the end of the cloud or of the strip) pass the walk's test only when the threshold is +inf
                 const float x = (valid && col < nb && (col >> 5) < t_end) ? 0.5f * xn[g] - xhat : LR_INF;      // (xhat = 0 unless SIGN)
                 f32x4 d[4];
 #pragma unroll
                 for (int rbk = 0; rbk < 4; ++rbk) d[rbk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[rbk], bf[g], y4[rbk], 0, 0, 0);
-                const int code = (int)(v[g].y >> 8) & 0xf;
-                if (valid && (code & 3) == kb) {
-                    const bool q1 = (code >> 2) != 0;
-                    float r8[8];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) { r8[k] = q1 ? d[2][k] : d[0][k]; r8[4 + k] = q1 ? d[3][k] : d[1][k]; }
-                    // register i <-> bit 7 - i; set unless acc < x (a NaN accumulator -- non-finite f16 operands -- stays a candidate: rows
-                    // with such operands are re-done by the exact full-row scan, columns only add candidates the exact stage orders)
+                if (valid && lr_pb_kb(v[g].x) == kb) {
+                    // bit 4 rbk + k <-> register k of row block rbk; set unless acc < x (a NaN accumulator -- non-finite f16 operands --
+                    // stays a candidate: rows with such operands are re-done by the exact full-row scan, columns only add candidates
+                    // the exact stage orders)
                     unsigned mask = 0u;
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) mask |= (r8[i] < x) ? 0u : (0x80u >> i);
-                    unsigned y = (unsigned)(code << 8) | mask;       // mask 0: the entry is dropped when the list is emptied
-                    if (update && mask != 0u && (mask & (mask - 1u)) == 0u) {
-                        const int i = 7 - __builtin_ctz(mask);
-                        const int rl = wave * 64 + lr_pb_row(code, i);
-                        float m = r8[0];
+                    for (int rbk = 0; rbk < 4; ++rbk)
 #pragma unroll
-                        for (int k = 1; k < 8; ++k) m = (mask >> (7 - k)) & 1u ? r8[k] : m;
+                        for (int k = 0; k < 4; ++k) mask |= (d[rbk][k] < x) ? 0u : (1u << (4 * rbk + k));
+                    uint2 w = make_uint2(v[g].x, mask);              // mask 0: the entry is dropped when the list is emptied
+                    if (update && mask != 0u && (mask & (mask - 1u)) == 0u) {
+                        const int b = __builtin_ctz(mask);
+                        const int rl = wave * 64 + lr_pb_row(kb, b);
+                        // (the one register that passed is the largest of the 16)
+                        float m = fmaxf(fmaxf(fmaxf(d[0][0], d[0][1]), fmaxf(d[0][2], d[0][3])), fmaxf(fmaxf(d[1][0], d[1][1]), fmaxf(d[1][2], d[1][3])));
+                        m = fmaxf(m, fmaxf(fmaxf(fmaxf(d[2][0], d[2][1]), fmaxf(d[2][2], d[2][3])), fmaxf(fmaxf(d[3][0], d[3][1]), fmaxf(d[3][2], d[3][3]))));
                         // the register holds y_row + dot16, so g = dot16 - x_j = (register - x_j) - y_row
                         const float gv = (m - x) - s_Y[rl];
                         const float old = atomicMax(&s_N1[rl], gv);
                         atomicMax(&s_N2[rl], fminf(old, gv));
                         whval[wave][e] = gv;
-                        y |= LR_PB_HASG;
+                        w.x |= LR_PB_HASG;
                     }
-                    wlist[wave][e].y = y;
+                    wlist[wave][e] = w;
                 }
             }
         }
@@ -652,26 +657,25 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
                 const int e = e0 + lane;
                 uint2 v = make_uint2(0u, 0u);
                 if (e < wcnt) v = wlist[wave][e];
-                v.y &= 0x7fffffffu;
+                const int col = (int)(v.x & LR_PB_COLMASK);
                 // padding columns pass the test only when tau is +inf
-                bool keep = e < wcnt && (v.y & 0xffu) != 0u && (int)v.x < nb && ((int)v.x >> 5) < t_end;
-                if (v.y & LR_PB_HASG) {
+                bool keep = e < wcnt && (v.y & 0xffffu) != 0u && col < nb && (col >> 5) < t_end;
+                if (v.x & LR_PB_HASG) {
                     // g of the entry against the row's threshold of NOW (candidate <=> g >= -y): what an earlier, looser threshold let
                     // in is dropped here; what stays carries g rounded UP to 16 bits for the same test against the final threshold
                     const float gv = whval[wave][min(e, LR_PB_WLIST - 1)];
-                    const unsigned mask = v.y & 0xffu;
-                    const int rl = wave * 64 + lr_pb_row((int)(v.y >> 8) & 0xf, 7 - __builtin_ctz((mask & 0xffu) | 0x80u));
+                    const int rl = wave * 64 + lr_pb_row(lr_pb_kb(v.x), __builtin_ctz((v.y & 0xffffu) | 0x8000u));
                     const float yr = s_Y[rl];
                     if (gv + 1e-5f * (fabsf(gv) + fabsf(yr)) < -yr) keep = false;
                     const unsigned gb = __float_as_uint(gv);
                     const unsigned up16 = (gb & 0x80000000u) ? (gb >> 16) : ((gb + 0xffffu) >> 16);      // towards +inf
-                    v.y = (v.y & 0x1fffu) | (up16 << 15);
+                    v.y = (v.y & 0xffffu) | (up16 << 16);
                 }
                 const unsigned long long kb = __builtin_amdgcn_ballot_w64(keep);
                 const int pos = seg_fill + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(kb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)kb, 0u));
                 const int nk = __builtin_popcountll(kb);
                 if (seg_fill + nk > seg_cap) { seg_fill = -1; break; }
-                if (keep) { if (colmap) v.x = (unsigned)colmap[v.x]; seg[pos] = v; }
+                if (keep) { if (colmap) v.x = (unsigned)colmap[col] | (v.x & ~LR_PB_COLMASK); seg[pos] = v; }
                 seg_fill += nk;
             }
         }
@@ -680,33 +684,37 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         n_tk_flush += (int)(__builtin_amdgcn_s_memrealtime() - tkf);
 #endif
     };
-    // candidate test of 8 accumulator registers: row blocks 2q, 2q + 1 (32 rows) x column block cb (16 columns) of the wave's tile.
-    // A hit only parks { column, register group } -- 2 + 4 vector instructions and one LDS write; everything else about it is worked
+    // candidate test of the lane's 16 accumulator registers of column block cb (16 columns x the wave's 64 rows).
+    // A hit only parks { column, lane group } -- a handful of vector instructions and one LDS write; everything else about it is worked
     // out later, 16 entries per instruction group (derive()).
-    auto check = [&](const f32x4 &lo4, const f32x4 &hi4, float x, int col, int q) {
+    auto check = [&](const f32x4 &r0, const f32x4 &r1, const f32x4 &r2, const f32x4 &r3, float x, int tile, int cb) {
 #if LR_PB_EXP & 2
-        asm volatile("" :: "v"(lo4), "v"(hi4));
+        asm volatile("" :: "v"(r0), "v"(r1), "v"(r2), "v"(r3));
         return;
 #endif
         bool mine_hit;
         if constexpr (SIGN) {
-            int sg;
+            // two chains of three-input ANDs over the 16 sign bits
+            int sa, sb;
             asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x80\n\tv_bitop3_b32 %0, %0, %4, %5 bitop3:0x80\n\tv_bitop3_b32 %0, %0, %6, %7 bitop3:0x80\n\tv_and_b32 %0, %0, %8"
-                : "=&v"(sg)
-                : "v"(lo4[0]), "v"(lo4[1]), "v"(lo4[2]), "v"(lo4[3]), "v"(hi4[0]), "v"(hi4[1]), "v"(hi4[2]), "v"(hi4[3]));
-            mine_hit = sg >= 0;                        // the AND of the sign bits is clear: some register is not negative
+                : "=&v"(sa) : "v"(r0[0]), "v"(r0[1]), "v"(r0[2]), "v"(r0[3]), "v"(r1[0]), "v"(r1[1]), "v"(r1[2]), "v"(r1[3]));
+            asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x80\n\tv_bitop3_b32 %0, %0, %4, %5 bitop3:0x80\n\tv_bitop3_b32 %0, %0, %6, %7 bitop3:0x80\n\tv_bitop3_b32 %0, %0, %8, %9 bitop3:0x80"
+                : "=&v"(sb) : "v"(r2[0]), "v"(r2[1]), "v"(r2[2]), "v"(r2[3]), "v"(r3[0]), "v"(r3[1]), "v"(r3[2]), "v"(r3[3]), "v"(sa));
+            mine_hit = sb >= 0;                        // the AND of the sign bits is clear: some register is not negative
         } else {
-            float m;
+            float ma, mb;
             asm("v_max3_f32 %0, %1, %2, %3\n\tv_max3_f32 %0, %0, %4, %5\n\tv_max3_f32 %0, %0, %6, %7\n\tv_max_f32 %0, %0, %8"
-                : "=&v"(m)
-                : "v"(lo4[0]), "v"(lo4[1]), "v"(lo4[2]), "v"(lo4[3]), "v"(hi4[0]), "v"(hi4[1]), "v"(hi4[2]), "v"(hi4[3]));
-            mine_hit = m >= x;
+                : "=&v"(ma) : "v"(r0[0]), "v"(r0[1]), "v"(r0[2]), "v"(r0[3]), "v"(r1[0]), "v"(r1[1]), "v"(r1[2]), "v"(r1[3]));
+            asm("v_max3_f32 %0, %1, %2, %3\n\tv_max3_f32 %0, %0, %4, %5\n\tv_max3_f32 %0, %0, %6, %7\n\tv_max3_f32 %0, %0, %8, %9"
+                : "=&v"(mb) : "v"(r2[0]), "v"(r2[1]), "v"(r2[2]), "v"(r2[3]), "v"(r3[0]), "v"(r3[1]), "v"(r3[2]), "v"(r3[3]), "v"(ma));
+            mine_hit = mb >= x;
         }
         const unsigned long long hit = __builtin_amdgcn_ballot_w64(mine_hit);
         if (__builtin_expect(hit != 0ull, 0)) {       // rare: keeps the common path a fall-through
             if (mine_hit) {
                 const int pos = wcnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(hit >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hit, 0u));
-                if (pos < LR_PB_WLIST) wlist[wave][pos] = make_uint2((unsigned)col, (unsigned)(q << 10) | code_kb);
+                // (the column is worked out here, not on the fast path: tile is wave-uniform)
+                if (pos < LR_PB_WLIST) wlist[wave][pos] = make_uint2((unsigned)(tile * 32 + cb * 16 + c16) | code_kb, 0u);
             }
             wcnt += __builtin_popcountll(hit);
 #if LR_PB_EXP & 16
@@ -734,25 +742,25 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         f16x8 n0, n1; f32x2 nx;
         if (k + 1 < CH) read_b(fo_cur, xo_cur, k + 1, n0, n1, nx);
         else read_b(fo_oth, xo_oth, 0, n0, n1, nx);
-        const int colC = (t_begin + c * CH + k - 1) * 32 + c16;
+        const int tileC = t_begin + c * CH + k - 1;
 #define MF(rbk, cb, b) acc[rbk][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[rbk], b, y4[rbk], 0, 0, 0)
-        check(acc[0][0], acc[1][0], xC.x, colC, 0);
-        MF(0, 0, b0); MF(1, 0, b0);
-        check(acc[2][0], acc[3][0], xC.x, colC, 1);
-        MF(2, 0, b0); MF(3, 0, b0);
-        check(acc[0][1], acc[1][1], xC.y, colC + 16, 0);
-        MF(0, 1, b1); MF(1, 1, b1);
-        check(acc[2][1], acc[3][1], xC.y, colC + 16, 1);
-        MF(2, 1, b1); MF(3, 1, b1);
+        // (the scheduling barriers keep the MFMAs behind the test of the registers they overwrite: hoisted above it they would need
+        // a second set of accumulators -- and the kernel its row fragments from scratch memory)
+        check(acc[0][0], acc[1][0], acc[2][0], acc[3][0], xC.x, tileC, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        MF(0, 0, b0); MF(1, 0, b0); MF(2, 0, b0); MF(3, 0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        check(acc[0][1], acc[1][1], acc[2][1], acc[3][1], xC.y, tileC, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        MF(0, 1, b1); MF(1, 1, b1); MF(2, 1, b1); MF(3, 1, b1);
+        __builtin_amdgcn_sched_barrier(0);
 #undef MF
         b0 = n0; b1 = n1; xC = xN; xN = nx;
     };
     auto drain = [&]() {
-        const int colC = (t_begin + nchunks * CH - 1) * 32 + c16;
-        check(acc[0][0], acc[1][0], xC.x, colC, 0);
-        check(acc[2][0], acc[3][0], xC.x, colC, 1);
-        check(acc[0][1], acc[1][1], xC.y, colC + 16, 0);
-        check(acc[2][1], acc[3][1], xC.y, colC + 16, 1);
+        const int tileC = t_begin + nchunks * CH - 1;
+        check(acc[0][0], acc[1][0], acc[2][0], acc[3][0], xC.x, tileC, 0);
+        check(acc[0][1], acc[1][1], acc[2][1], acc[3][1], xC.y, tileC, 1);
     };
     if (nchunks > 0) {
         load_chunk(0); store_chunk(0);
@@ -911,8 +919,7 @@ nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, in
         const float d2 = __builtin_fmaf(-2.0f, acc, s_nq[rl] + ncj);
         return __builtin_sqrtf(fmaxf(d2, 1e-30f));
     };
-    // ---- the candidates: entry { column, (code << 8) | mask }, code = rb*4 + (g0/8)*2 + h of the pass-B wave tile, mask bit
-    //      7-k <-> register g0 + k; row of register g: 32 rb + 4 h + (g & 3) + 8 (g >> 2)
+    // ---- the candidates: entries { column | kb << 22 | LR_PB_HASG, 16-bit row mask | g16 << 16 } of the filter-pass wave (LR_PB_* above)
     {
         const int32_t *cw = cand_cnt + bxi * (nstrips + 1);
         const int used = min(max(cw[nstrips], 1), nstrips);        // strips the pass-B row block really used
@@ -933,10 +940,10 @@ nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, in
             // (two entries in flight per thread measured slower: 118 VGPRs, 4 instead of 6 waves per SIMD)
             for (int e = tid; e < c; e += 256) {
                 const uint2 v = segs[(size_t)sidx * seg_cap + e];
-                const int j = (int)v.x;
-                if (v.y & LR_PB_HASG) {       // (single-row entry with its g, rounded up to 16 bits)
-                    const int rl = lr_pb_row((int)(v.y >> 8) & 0xf, 7 - __builtin_ctz((v.y & 0xffu) | 0x80u));
-                    const float gv = __uint_as_float((v.y >> 15) << 16), yr = s_yf[rl];
+                const int j = (int)(v.x & LR_PB_COLMASK), ekb = lr_pb_kb(v.x);
+                if (v.x & LR_PB_HASG) {       // (single-row entry with its g, rounded up to 16 bits)
+                    const int rl = lr_pb_row(ekb, __builtin_ctz((v.y & 0xffffu) | 0x8000u));
+                    const float gv = __uint_as_float(v.y & 0xffff0000u), yr = s_yf[rl];
                     if (gv + 1e-5f * (fabsf(gv) + fabsf(yr)) < -yr) continue;
                 }
                 f32x4 t[8];
@@ -944,12 +951,11 @@ nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, in
 #pragma unroll
                 for (int k = 0; k < 8; ++k) t[k] = pb[k];
                 const float ncj = nC[j];
-                const int code = (int)(v.y >> 8) & 0xf;
-                unsigned m = v.y & 0xffu;
+                unsigned m = v.y & 0xffffu;
                 while (m) {
                     const int bit = __builtin_ctz(m);
                     m &= m - 1;
-                    const int rl = lr_pb_row(code, 7 - bit);
+                    const int rl = lr_pb_row(ekb, bit);
                     ex_offer(&s_best[rl], &s_second[rl], dist(rl, t, ncj), j);
                     atomicAdd(&s_cnt[rl], 1);
                 }

@@ -11,7 +11,7 @@ for grp in "SQ_VALU_MFMA_COEXEC_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_V
            "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES" "SQ_INST_CYCLES_SALU SQ_INSTS_BRANCH SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA" "GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU"; do
   k=$((k+1))
   rm -rf /tmp/pp_$k
-  rocprofv3 --pmc $grp --output-format csv -d /tmp/pp_$k -o m -- python3 $R/bench.py --streams 1 --pairs 32 --steps 2 --warmup 1 --no-cpu-baseline > /tmp/pp_$k.log 2>&1
+  rocprofv3 --pmc $grp --output-format csv -d /tmp/pp_$k -o m -- python3 $R/bench.py --streams 1 --pairs 32 --steps 2 --warmup 1 --no-cpu-baseline --sustain-s 0 > /tmp/pp_$k.log 2>&1
   f=$(find /tmp/pp_$k -name '*counter_collection.csv' | head -1)
   if [ -n "$f" ]; then cp "$f" $O/g$k.csv; else echo "group $k FAILED"; tail -3 /tmp/pp_$k.log; fi
 done
