@@ -128,7 +128,12 @@ extern "C" int lr_workspace_create_batch(lr_workspace **out, int max_pairs, int 
     real.base = ws->base;
     carve(ws, real);
     ws->descs = reinterpret_cast<lr_pair_desc *>(ws->base + desc_off);
-    if (hipMemset(ws->base, 0, ws->bytes) != hipSuccess) { (void)hipFree(ws->base); delete ws; lr_set_error("lr_workspace_create: hipMemset failed"); return LR_EHIP; }
+    // The fill runs on the null stream; the caller's streams may be non-blocking ones (torch's are), which do not wait for it: without
+    // the synchronisation the first call on the new workspace can overtake the fill, which then wipes what that call wrote (found by
+    // tests/test_gpu_gc.py::test_lo_helper_protocol_under_contention, round 4: workspaces created while other streams keep the GPU busy)
+    if (hipMemset(ws->base, 0, ws->bytes) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) {
+        (void)hipFree(ws->base); delete ws; lr_set_error("lr_workspace_create: hipMemset failed"); return LR_EHIP;
+    }
     for (int k = 0; k < LR_NEV; ++k)
         if (hipEventCreate(&ws->ev[k]) != hipSuccess) { (void)hipFree(ws->base); delete ws; lr_set_error("lr_workspace_create: hipEventCreate failed"); return LR_EHIP; }
     *out = ws;

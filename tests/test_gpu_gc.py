@@ -445,7 +445,8 @@ def test_lo_helper_protocol_under_contention(lr):
         for rep in range(reps):
             r = results[k][rep]
             assert r.reserved[1] == 0 and r.ransac.pad0 == 0, (k, rep, hex(r.reserved[1]))          # no hand-off wait hit its bound
-            assert bytes(r.T) == bytes(r0.T) and bytes(r.T_ransac) == bytes(r0.T_ransac), (k, rep)
+            desc = lambda q: (q.status, q.n_corr, q.ransac.best_h, q.ransac.best_count, q.ransac.n_ids, q.ransac.n_valid, q.n_nn_fixed, list(q.T[:4]))
+            assert bytes(r.T) == bytes(r0.T) and bytes(r.T_ransac) == bytes(r0.T_ransac), (k, rep, desc(r), desc(r0))
             assert (r.ransac.best_h, r.ransac.best_count, r.ransac.best_ssq, r.ransac.n_ids, r.n_corr, r.status) == \
                    (r0.ransac.best_h, r0.ransac.best_count, r0.ransac.best_ssq, r0.ransac.n_ids, r0.n_corr, r0.status), (k, rep)
     assert max(latency) < 0.15, max(latency)           # (a timed-out wait alone is 0.2 s)
