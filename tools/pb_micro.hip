@@ -98,6 +98,7 @@ int main(int argc, char **argv)
 #if LR_PB_EXP & 16
         {
             unsigned long long z8[16] = {0}, st[16];
+            if (g_pre) g_pre();
             hipMemcpyToSymbol(HIP_SYMBOL(lr_pb_stat), z8, sizeof z8); run(); hipDeviceSynchronize();
             hipMemcpyFromSymbol(st, HIP_SYMBOL(lr_pb_stat), sizeof st);
             printf("    per wave: tests %.0f  slow-path visits %.1f (one per %.1f tests)  hits %.1f (%.2f per row)  derive rounds %.1f  16-entry groups %.1f\n",
