@@ -15,7 +15,10 @@ from collections import defaultdict
 def short(name):
     m = re.match(r"^_Z(\d+)", name)          # rocprofv3 leaves some names mangled: _Z<len><name>...
     if m:
-        return name[m.end():m.end() + int(m.group(1))]
+        base = name[m.end():m.end() + int(m.group(1))]
+        rest = name[m.end() + int(m.group(1)):]
+        t = re.match(r"^ILb([01])EE", rest)   # a bool template argument: the two instantiations of the filter pass are different kernels
+        return base + ("<true>" if t.group(1) == "1" else "<false>") if t else base
     name = re.sub(r"^void ", "", name)
     name = name.split("(")[0]
     return re.sub(r"<.*$", "", name) if name.startswith("at::") else name
@@ -46,10 +49,10 @@ def main(fetch_csv, write_csv, out, commit="commit unrecorded"):
         res[k] = {"FETCH_SIZE_KiB": round(fk, 1), "WRITE_SIZE_KiB": round(wk, 1), "hbm_bytes_per_launch": int((2 * fk + wk) * 1024),
                   "launches": nf.get(k, 0)}
     # whole pair: every launch of the library's own kernels (not the input generation, torch / rocprim / rocBLAS / runtime fills),
-    # over the pairs the profiled run registered: one batched call of 32 pairs per two pass-B launches (warm-up, timed steps and the
+    # over the pairs the profiled run registered: one batched call of 32 pairs per prep launch (warm-up, timed steps and the
     # repetitions bench.py adds for the roofline events)
     own = [k for k in res if not k.startswith("_") and not k.startswith(("at::", "rocprim::", "Cijk_", "__amd_rocclr", "void at::")) and k.strip()]
-    pairs = res["nn16_passb_kernel"]["launches"] // 2 * 32
+    pairs = res["nn16_prep_kernel"]["launches"] * 32          # one prep launch per batched call of 32 pairs
     total = sum(res[k]["hbm_bytes_per_launch"] * res[k]["launches"] for k in own)
     res["_pair"] = {"hbm_bytes_per_pair": int(total / pairs), "pairs_in_run": pairs,
                     "kernels": {k: int(res[k]["hbm_bytes_per_launch"] * res[k]["launches"] / pairs) for k in sorted(own, key=lambda k: -res[k]["hbm_bytes_per_launch"] * res[k]["launches"])[:12]}}
