@@ -205,6 +205,15 @@ __device__ __forceinline__ int lr_lds_off(int j, int p) { return j * LR_LDS_ROW 
 // accumulator registers of one 16-column block).  The walk parks entries with an empty mask; derive() fills it in.
 #define LR_PB_COLMASK 0x3fffffu
 #define LR_PB_HASG 0x1000000u    // entry flag (in x): exactly one row, and y carries its filter value g rounded up to 16 bits
+#ifndef LR_PB_JOINT
+#define LR_PB_JOINT 1
+#endif
+#ifndef LR_PB_JOINT_EVERY
+#define LR_PB_JOINT_EVERY 1    // the wishes are exchanged at every this-many-th chunk barrier (a power of two)
+#endif
+#ifndef LR_PB_PRIO
+#define LR_PB_PRIO 1          // a wave inside derive() runs at raised priority: its siblings wait for it at the next chunk barrier (60.1 -> 59.3 us per pair)
+#endif
 #ifndef LR_PB_DGROUPS
 #define LR_PB_DGROUPS 3          // groups of 16 entries derive() has in flight at once (registers: 9 per group)
 #endif
@@ -295,6 +304,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     // per row of the block: y = tau/2 (what the accumulators start from), the row's error term, the two largest g of the walk
     __shared__ __attribute__((aligned(16))) float s_Y[LR_BLOCK_ROWS];
     __shared__ float s_D[LR_BLOCK_ROWS], s_N1[LR_BLOCK_ROWS], s_N2[LR_BLOCK_ROWS];
+    __shared__ __attribute__((aligned(16))) int s_att[2][4];      // what the four waves' hit lists want, per chunk parity (LR_PB_JOINT)
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int c16 = lane & 15, kb = lane >> 4;
     const int row0 = bx * LR_BLOCK_ROWS + wave * 64;
@@ -575,6 +585,9 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     // nn16_exact_kernel.
     auto derive = [&](bool update) {
         const int nlist = min(wcnt, LR_PB_WLIST);
+#if LR_PB_PRIO
+        __builtin_amdgcn_s_setprio(3);      // the wave's three siblings wait for it at the next chunk barrier
+#endif
 #if LR_PB_EXP & 16
         ++n_rounds; n_groups += (nlist - wdone + 15) >> 4;
         const unsigned long long tk0 = __builtin_amdgcn_s_memrealtime();
@@ -644,6 +657,9 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         }
 #if LR_PB_EXP & 16
         n_tk_derive += (int)(__builtin_amdgcn_s_memrealtime() - tk0);
+#endif
+#if LR_PB_PRIO
+        __builtin_amdgcn_s_setprio(0);
 #endif
     };
     auto flush = [&]() {
@@ -771,11 +787,15 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         if (nchunks > 1) load_chunk(1);
         read_b(fo_cur, xo_cur, 0, b0, b1, xN);
         // The walk is a loop nest: the inner loop is the hot one and contains no tightening code (the compiler then keeps the threshold
-        // registers loop-invariant and its wait counts exact); it is left whenever the hit list wants attention.
+        // registers loop-invariant and its wait counts exact); it is left whenever a hit list wants attention.
+        // The four waves of a block attend to their lists TOGETHER (LR_PB_JOINT): a wave in derive() keeps its three siblings waiting
+        // at the next chunk barrier, so 4 x ~11 rounds per block, one wave at a time, stall the block four times as often as ~12 rounds
+        // that all four take at once.  Every wave posts what its list wants (bit 0: a tightening round, bit 1: to be emptied) before the
+        // chunk barrier, reads all four wishes behind it -- the decision is block-uniform -- and acts at the end of the chunk.
         int c = 0;
         while (c < nchunks) {
-            bool attention = false;
-            for (; c < nchunks && !attention; ++c) {
+            int wish = 0;
+            for (; c < nchunks && !wish; ++c) {
 #pragma unroll
                 for (int k = 0; k < CH; ++k) {
                     if (k == CH - 1) {
@@ -784,18 +804,25 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
                         // chunk's own last tile), so one barrier per chunk still orders everything.
 #if !(LR_PB_EXP & 1)
                         if (c + 1 < nchunks) store_chunk((c & 1) ^ 1);
+#if LR_PB_JOINT
+                        if (LR_PB_JOINT_EVERY == 1 || (c & (LR_PB_JOINT_EVERY - 1)) == 0) { if (lane == 0) s_att[(c / LR_PB_JOINT_EVERY) & 1][wave] = (wcnt >= LR_PB_WLIST / 2 ? 2 : 0) | ((tightening && wcnt - wdone >= LR_PB_TIGHTEN) ? 1 : 0); }
+#endif
                         __syncthreads();
+#if LR_PB_JOINT
+                        if (LR_PB_JOINT_EVERY == 1 || (c & (LR_PB_JOINT_EVERY - 1)) == 0) { const int4 f = *reinterpret_cast<const int4 *>(s_att[(c / LR_PB_JOINT_EVERY) & 1]); wish = __builtin_amdgcn_readfirstlane(f.x | f.y | f.z | f.w); }
+#endif
                         if (c + 2 < nchunks) load_chunk(c + 2);
 #endif
                     }
                     step(c, k);
                 }
                 { const int t0 = fo_cur; fo_cur = fo_oth; fo_oth = t0; const int t1 = xo_cur; xo_cur = xo_oth; xo_oth = t1; }
-                attention = wcnt >= LR_PB_WLIST / 2 || (tightening && wcnt - wdone >= LR_PB_TIGHTEN);
+#if !LR_PB_JOINT
+                wish = (wcnt >= LR_PB_WLIST / 2 ? 2 : 0) | ((tightening && wcnt - wdone >= LR_PB_TIGHTEN) ? 1 : 0);
+#endif
             }
-            if (attention) {
-                if (wcnt >= LR_PB_WLIST / 2) flush(); else derive(true);
-            }
+            if (wish & 2) flush();
+            else if (wish) { if (wdone < wcnt) derive(true); }
         }
         // drain: the last tile of the last chunk sits in the accumulators.  The inline-asm tests below read MFMA results the
         // compiler cannot see them read (no automatic wait states): inside the loop every such read is at least two
