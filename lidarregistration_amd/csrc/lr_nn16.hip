@@ -206,10 +206,7 @@ __device__ __forceinline__ int lr_lds_off(int j, int p) { return j * LR_LDS_ROW 
 #define LR_PB_COLMASK 0x3fffffu
 #define LR_PB_HASG 0x1000000u    // entry flag (in x): exactly one row, and y carries its filter value g rounded up to 16 bits
 #ifndef LR_PB_JOINT
-#define LR_PB_JOINT 1
-#endif
-#ifndef LR_PB_JOINT_EVERY
-#define LR_PB_JOINT_EVERY 1    // the wishes are exchanged at every this-many-th chunk barrier (a power of two)
+#define LR_PB_JOINT 1          // 0: development switch, no launch uses the joint form
 #endif
 #ifndef LR_PB_PRIO
 #define LR_PB_PRIO 1          // a wave inside derive() runs at raised priority: its siblings wait for it at the next chunk barrier (60.1 -> 59.3 us per pair)
@@ -252,7 +249,7 @@ __device__ unsigned long long lr_pb_clk[4096 * 2];      // development probe: sh
 #if LR_PB_EXP & 16
 __device__ unsigned long long lr_pb_stat[16];             // development probe: waves, tests, slow-path visits, hits, derive() rounds, 16-entry groups
 #endif
-template <bool SIGN>
+template <bool SIGN, bool JOINT>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *__restrict__ rowmap, const int32_t *__restrict__ na_dev,
                   const _Float16 *__restrict__ Hc, const float *__restrict__ nC, int nb,
@@ -304,7 +301,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     // per row of the block: y = tau/2 (what the accumulators start from), the row's error term, the two largest g of the walk
     __shared__ __attribute__((aligned(16))) float s_Y[LR_BLOCK_ROWS];
     __shared__ float s_D[LR_BLOCK_ROWS], s_N1[LR_BLOCK_ROWS], s_N2[LR_BLOCK_ROWS];
-    __shared__ __attribute__((aligned(16))) int s_att[2][4];      // what the four waves' hit lists want, per chunk parity (LR_PB_JOINT)
+    __shared__ __attribute__((aligned(16))) int s_att[2][4];      // what the four waves' hit lists want, per chunk parity 
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int c16 = lane & 15, kb = lane >> 4;
     const int row0 = bx * LR_BLOCK_ROWS + wave * 64;
@@ -788,7 +785,8 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         read_b(fo_cur, xo_cur, 0, b0, b1, xN);
         // The walk is a loop nest: the inner loop is the hot one and contains no tightening code (the compiler then keeps the threshold
         // registers loop-invariant and its wait counts exact); it is left whenever a hit list wants attention.
-        // The four waves of a block attend to their lists TOGETHER (LR_PB_JOINT): a wave in derive() keeps its three siblings waiting
+        // The four waves of a block attend to their lists TOGETHER (JOINT: the forward launch; the reverse launch does not tighten, its
+        // lists only ever want to be emptied, and the exchange would be 2 % for nothing): a wave in derive() keeps its three siblings waiting
         // at the next chunk barrier, so 4 x ~11 rounds per block, one wave at a time, stall the block four times as often as ~12 rounds
         // that all four take at once.  Every wave posts what its list wants (bit 0: a tightening round, bit 1: to be emptied) before the
         // chunk barrier, reads all four wishes behind it -- the decision is block-uniform -- and acts at the end of the chunk.
@@ -796,6 +794,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         while (c < nchunks) {
             int wish = 0;
             for (; c < nchunks && !wish; ++c) {
+                int4 wishes = { 0, 0, 0, 0 };
 #pragma unroll
                 for (int k = 0; k < CH; ++k) {
                     if (k == CH - 1) {
@@ -804,22 +803,18 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
                         // chunk's own last tile), so one barrier per chunk still orders everything.
 #if !(LR_PB_EXP & 1)
                         if (c + 1 < nchunks) store_chunk((c & 1) ^ 1);
-#if LR_PB_JOINT
-                        if (LR_PB_JOINT_EVERY == 1 || (c & (LR_PB_JOINT_EVERY - 1)) == 0) { if (lane == 0) s_att[(c / LR_PB_JOINT_EVERY) & 1][wave] = (wcnt >= LR_PB_WLIST / 2 ? 2 : 0) | ((tightening && wcnt - wdone >= LR_PB_TIGHTEN) ? 1 : 0); }
-#endif
+                        if constexpr (JOINT) { if (lane == 0) s_att[c & 1][wave] = (wcnt >= LR_PB_WLIST / 2 ? 2 : 0) | ((tightening && wcnt - wdone >= LR_PB_TIGHTEN) ? 1 : 0); }
                         __syncthreads();
-#if LR_PB_JOINT
-                        if (LR_PB_JOINT_EVERY == 1 || (c & (LR_PB_JOINT_EVERY - 1)) == 0) { const int4 f = *reinterpret_cast<const int4 *>(s_att[(c / LR_PB_JOINT_EVERY) & 1]); wish = __builtin_amdgcn_readfirstlane(f.x | f.y | f.z | f.w); }
-#endif
+                        // (requested here, looked at behind the chunk's last step)
+                        if constexpr (JOINT) wishes = *reinterpret_cast<const int4 *>(s_att[c & 1]);
                         if (c + 2 < nchunks) load_chunk(c + 2);
 #endif
                     }
                     step(c, k);
                 }
                 { const int t0 = fo_cur; fo_cur = fo_oth; fo_oth = t0; const int t1 = xo_cur; xo_cur = xo_oth; xo_oth = t1; }
-#if !LR_PB_JOINT
-                wish = (wcnt >= LR_PB_WLIST / 2 ? 2 : 0) | ((tightening && wcnt - wdone >= LR_PB_TIGHTEN) ? 1 : 0);
-#endif
+                if constexpr (JOINT) wish = __builtin_amdgcn_readfirstlane(wishes.x | wishes.y | wishes.z | wishes.w);
+                else wish = (wcnt >= LR_PB_WLIST / 2 ? 2 : 0) | ((tightening && wcnt - wdone >= LR_PB_TIGHTEN) ? 1 : 0);
             }
             if (wish & 2) flush();
             else if (wish) { if (wdone < wcnt) derive(true); }
@@ -1090,13 +1085,13 @@ int lr_nn16_run(lr_workspace *ws, const float *Fq, const _Float16 *Hq, const flo
     lr_thr_in thr = { nQ, range_c, need, sstride };
     // both forms of the walk's candidate test; the blocks of the one the column norms do not ask for return at once
 #define SIGN_ true
-    hipLaunchKernelGGL(nn16_passb_kernel<SIGN_>, grid, dim3(256), 0, st, Hq, na, (const int32_t *)nullptr, (const int32_t *)nullptr, Hc, nC, nb,
+    hipLaunchKernelGGL((nn16_passb_kernel<SIGN_, LR_PB_JOINT != 0>), grid, dim3(256), 0, st, Hq, na, (const int32_t *)nullptr, (const int32_t *)nullptr, Hc, nC, nb,
                        tps, (const float *)nullptr, ws->cand_cnt, ws->cand, (const int32_t *)nullptr, (const float *)nullptr,
                        (const uint32_t *)nullptr, (const int32_t *)nullptr, (const uint32_t *)nullptr, ws->yfin, ws->max_n, ws->yshare, thr,
                        lr_pb_grid{ row_blocks, strips, total, 0 }, ws->z);
 #undef SIGN_
 #define SIGN_ false
-    hipLaunchKernelGGL(nn16_passb_kernel<SIGN_>, grid, dim3(256), 0, st, Hq, na, (const int32_t *)nullptr, (const int32_t *)nullptr, Hc, nC, nb,
+    hipLaunchKernelGGL((nn16_passb_kernel<SIGN_, LR_PB_JOINT != 0>), grid, dim3(256), 0, st, Hq, na, (const int32_t *)nullptr, (const int32_t *)nullptr, Hc, nC, nb,
                        tps, (const float *)nullptr, ws->cand_cnt, ws->cand, (const int32_t *)nullptr, (const float *)nullptr,
                        (const uint32_t *)nullptr, (const int32_t *)nullptr, (const uint32_t *)nullptr, ws->yfin, ws->max_n, ws->yshare, thr,
                        lr_pb_grid{ row_blocks, strips, total, 0 }, ws->z);
@@ -1374,7 +1369,7 @@ int lr_nn16_reverse(lr_workspace *ws, const float *F0, const _Float16 *H0, const
     const bool timed = ws->timing && ws->ev_pending == 1 && !ws->rev_recorded;
     if (timed) { LR_HIP(hipEventRecord(ws->ev[4], st)); }
 #define SIGN_ true
-    hipLaunchKernelGGL(nn16_passb_kernel<SIGN_>, grid, dim3(256), 0, st, H1, na, (const int32_t *)ws->rev_rows, (const int32_t *)n_rows,
+    hipLaunchKernelGGL((nn16_passb_kernel<SIGN_, false>), grid, dim3(256), 0, st, H1, na, (const int32_t *)ws->rev_rows, (const int32_t *)n_rows,
                        (const _Float16 *)ws->Hs, (const float *)ws->nrms, nb, tps, ws->tau, ws->cand_cnt, ws->cand,
                        (const int32_t *)ws->rev_cols, seeded ? (const float *)ws->rev_tmin : (const float *)nullptr, (const uint32_t *)seed,
                        (const int32_t *)ws->rev_hist, (const uint32_t *)range, (float *)nullptr, 0, (uint32_t *)nullptr,
@@ -1382,7 +1377,7 @@ int lr_nn16_reverse(lr_workspace *ws, const float *F0, const _Float16 *H0, const
                        lr_pb_grid{ row_blocks, strips, total, 1 }, ws->z);
 #undef SIGN_
 #define SIGN_ false
-    hipLaunchKernelGGL(nn16_passb_kernel<SIGN_>, grid, dim3(256), 0, st, H1, na, (const int32_t *)ws->rev_rows, (const int32_t *)n_rows,
+    hipLaunchKernelGGL((nn16_passb_kernel<SIGN_, false>), grid, dim3(256), 0, st, H1, na, (const int32_t *)ws->rev_rows, (const int32_t *)n_rows,
                        (const _Float16 *)ws->Hs, (const float *)ws->nrms, nb, tps, ws->tau, ws->cand_cnt, ws->cand,
                        (const int32_t *)ws->rev_cols, seeded ? (const float *)ws->rev_tmin : (const float *)nullptr, (const uint32_t *)seed,
                        (const int32_t *)ws->rev_hist, (const uint32_t *)range, (float *)nullptr, 0, (uint32_t *)nullptr,
