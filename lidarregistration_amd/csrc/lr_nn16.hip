@@ -9,9 +9,12 @@
 //           the 2nd smallest (1st for top-1) approximate value u' = n1[j] - 2 dot16(i,j) of that subset: U_i
 //   thresh  tau_i = U_i + 2 E_i (+ a sqrt-rounding band), E_i a rigorous bound on |d2_exact - (n0_i + u')|
 //   walk    f16 MFMA over ALL column tiles; a column is a candidate of row i iff u' <= tau_i.  The accumulator starts
-//           at tau_i/2, so the test is "largest of 8 accumulator registers >= n1[j]/2": 5 VALU ops per 512 elements,
-//           interleaved with the next tile's MFMAs; candidates are ~1e-4 of the elements; the thresholds tighten as the
-//           walk finds better neighbours (sample, thresholds and walk are ONE kernel, nn16_passb_kernel)
+//           at tau_i/2 (minus the smallest column term when all column norms are alike), so the test of a lane's 16
+//           accumulator registers is the AND of their sign bits (or, with spread-out norms, their maximum against n1[j]/2):
+//           9 VALU ops per 1024 elements, interleaved with the next tile's MFMAs; candidates are ~1e-4 of the elements;
+//           a hit only parks { column, lane group }, the rows and filter values are re-derived later by the same MFMA on
+//           the gathered columns, and the thresholds tighten as the walk finds better neighbours (sample, thresholds and
+//           walk are ONE kernel, nn16_passb_kernel)
 //   reverse (mutual filter) thresholds from the forward result, rows / columns ordered by forward NN distance so that
 //           each row block walks only a prefix of the column tiles (lr_nn16_reverse)
 //   exact   per row, the fp32 fma-chain distance of its few candidates, ordered by (sqrt value, index) --
@@ -164,28 +167,29 @@ nn16_range_kernel(int na, const float *__restrict__ bmaxa, const float *__restri
 // and the row fragments with the walk, samples every 16th tile (~3 us), and the thresholds it yields are only the START of the walk:
 //
 // Phase 2: f16 MFMA over ALL tiles of the strip, columns on the lanes.  The accumulator is started at y_i = tau_i / 2 instead of 0,
-// so the candidate test u' <= tau_i  <=>  dot16 + y_i >= n1[j]/2 needs no per-element arithmetic: the lane's largest of 8
-// accumulator registers (two 16-row blocks of one 16-column block) is compared with x_j = n1[j]/2 once -- 3 v_max3 + 1 v_max +
-// 1 v_cmp + 1 scalar branch per 8 registers.  There is ONE set of 32 accumulator registers: a group of 8 is tested (it holds the
-// previous tile) and then handed to the two MFMAs that overwrite it with the current tile, so every test reads its registers six
-// MFMAs after they were issued (the hardware does not interlock a vector read of an MFMA result) and its branch ends the basic
-// block, so the compiler cannot pull the pieces apart.  The vector ops of one wave run while the matrix pipe works on another's
-// MFMAs: measured on the idealised mix (tools/coissue_micro.hip: 8 MFMA + 20 v_max3 per iteration, 3 waves per SIMD) 79 ns per
-// tile and wave against 71-74 for the MFMAs alone and 41 for the vector ops alone; the walk takes 104 ns per tile and wave
-// (LDS reads, branches, staging, barrier), at a shader clock of 2.1 GHz -- the board's power limit, not the 2.4 GHz peak clock,
-// is what the kernel runs against, and a fourth wave per SIMD only lowers the clock (measured: 43.2 instead of 44.5 us per pair
-// without candidates, no gain with them).  The column fragments of tile t+1 are read from LDS one step ahead, which moves the chunk
-// barrier one step forward.  Hits are parked in a wave-private LDS list whose fill count lives in a scalar register: no atomics
-// and no LDS round trip in the loop.
+// so the candidate test u' <= tau_i  <=>  dot16 + y_i >= n1[j]/2 needs no per-element arithmetic: the lane's 16 accumulator
+// registers of one 16-column block (the wave's 64 rows) are tested at once.  Two forms, two instantiations (SIGN; both are launched,
+// the blocks of the one the pair's column norms do not ask for return at their first branch): with all column norms alike the
+// smallest column term is folded into the start values and the test is the AND of 16 sign bits -- 7 v_bitop3_b32 + 1 v_and_b32,
+// full rate, no per-column operand --, otherwise the largest of the 16 registers against x_j = n1[j]/2 (7 v_max3 + 1 v_max, half
+// rate); + 1 v_cmp + 1 scalar branch.  There is ONE set of 32 accumulator registers: a group of 16 is tested (it holds the previous
+// tile) and then handed to the four MFMAs that overwrite it with the current tile, so every test reads its registers four MFMAs
+// after they were issued (the hardware does not interlock a vector read of an MFMA result; scheduling barriers keep the MFMAs
+// behind the test).  The vector ops of one wave run while the matrix pipe works on another's MFMAs.  What bounds the kernel is the
+// board's power limit: a stall that is removed comes back as a lower clock, an instruction that is removed from the fast path does
+// not.  The column fragments of tile t+1 are read from LDS one step ahead, which moves the chunk barrier one step
+// forward.  Hits are parked in a wave-private LDS list whose fill count lives in a scalar register: no atomics and no LDS round trip
+// in the loop.
 //
-// Thresholds tighten while the walk runs.  A hit entry also keeps h = (largest register) - x_j.  Whenever LR_PB_TIGHTEN new
-// entries have gathered, the wave goes through them ONE LANE PER ENTRY: an entry whose mask has a single bit names its row, and
-// g = h - y_row is that row's filter value of that column; the two largest g of every row (of the walk: distinct columns) are kept
-// in LDS with two float atomics per entry, y_row <- min(y_row, E_row - g2 + ...), and the lanes reload their 16 threshold
-// registers with 4 ds_read_b128.  All of it is wave-local (a wave owns its 64 rows for the whole strip) and costs ~60 instructions
-// per 48 hits.  The number of hits of a row then grows like 2 + 2 ln(tiles / sampled tiles) instead of 2 tiles / sampled tiles,
-// which is what lets the sample be small.  (The test of a tile lags one tile behind its MFMAs: hits of the one tile whose
-// accumulators were started with the thresholds of before a reload are flagged and not used for tightening.)
+// Thresholds tighten while the walk runs (derive(), below): whenever LR_PB_TIGHTEN new entries have gathered in a list, the four
+// waves of the block go through their new entries TOGETHER (JOINT: they exchange what their lists want at the chunk barrier -- a wave
+// in a round keeps its siblings waiting there, so the rounds are taken at the same time), 16 entries per instruction group: the
+// entries' columns are gathered and the walk's own MFMA repeated on them with the thresholds of now -- same instruction, same
+// operands, same bits --, which yields each entry's row mask and, for single-row entries, the filter value g = dot16 - x_j; the two
+// largest g of every row (of the walk: distinct columns) are kept in LDS with two float atomics per entry, y_row <- min(y_row,
+// E_row - g2 + ...), and the lanes reload their 16 threshold registers.  The number of hits of a row then grows like
+// 2 + 2 ln(tiles / sampled tiles) instead of 2 tiles / sampled tiles, which is what lets the sample be small.  Several strips of one
+// row block (single-pair calls) pool their thresholds through atomicMin on an order-preserving integer image (yshare).
 #define LR_LDS_ROW 64
 // byte offset of 16-byte piece p (K 8p..8p+7) of staged column j of a chunk: rows of 64 bytes, the piece index XOR-swizzled with bits
 // 1..2 of the column.  ds_read_b128 is served in four fixed groups of 16 lanes ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ...); with
@@ -197,7 +201,7 @@ __device__ __forceinline__ int lr_lds_off(int j, int p) { return j * LR_LDS_ROW 
 #define LR_PB_CH 4
 #endif
 #ifndef LR_PB_EXP
-#define LR_PB_EXP 0     // development switches (tools/pb_micro.hip): 1 no staging, 2 no tests, 4 no tightening
+#define LR_PB_EXP 0     // development switches (tools/pb_micro.hip): 1 no staging, 2 no tests, 4 no tightening, 8 clock probe, 16 hit statistics, 128 plain test only
 #endif
 #define LR_PB_WLIST 512          // entries per wave (12 bytes each)
 // Entry of a hit list / of the candidate store (8 bytes): x = column (22 bits) | kb << 22 | LR_PB_HASG; y = 16-bit row mask | g16 << 16.
