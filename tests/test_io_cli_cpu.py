@@ -98,3 +98,33 @@ def test_coarse_motion_writer_reproduces_the_reference_files_byte_for_byte():
         # and the ground-truth list of the same rows pairs up with it
         lst = io_lists.read_pair_list(os.path.join(GOLDEN, "balanced_sets_excerpt", name, "test.txt"))
         assert np.array_equal(np.stack([lst["session"], lst["src"], lst["tgt"]], 1), ids)
+
+
+def test_device_inlier_ratios_equal_the_reference_statistic():
+    """harness.inlier_ratios_dev (the batched harness' statistics of test.py:200-208, written for device tensors) against
+    matching.measure_inlier_ratio (matching.py:241-249, numpy) on ragged pairs -- run here on CPU tensors."""
+    import torch
+    from lidarregistration_amd import harness, matching, synth
+    from lidarregistration_amd.FR import PointCloud, VOXEL_SIZE
+    rng = np.random.default_rng(3)
+    xs0, xs1, T, nn, c0, c1, n0s, ncs = [], [], [], [], [], [], [], []
+    W = 900
+    for k, (n0, n1) in enumerate([(900, 700), (500, 900), (640, 640)]):
+        x0, x1, Tg = synth.make_clouds(n0, n1, rho=0.6, seed=20 + k, noise=0.2)
+        nmin = min(n0, n1)                                  # planted pairs i <-> i with 0.35 m noise: a good share lies near the 0.6 m bound
+        x1[:nmin] = (x0[:nmin].astype(np.float64) @ Tg[:3, :3].T + Tg[:3, 3] + rng.normal(0, 0.35, (nmin, 3))).astype(np.float32)
+        xs0.append(torch.from_numpy(x0)); xs1.append(torch.from_numpy(x1)); T.append(Tg)
+        a = rng.integers(0, n1, W).astype(np.int32); a[:nmin:2] = np.arange(0, nmin, 2); nn.append(a)
+        m = int(rng.integers(n0 // 2, n0))
+        b0 = rng.integers(0, n0, W).astype(np.int32); b1 = rng.integers(0, n1, W).astype(np.int32)
+        b0[:m:3] = np.arange(0, m, 3) % nmin; b1[:m:3] = b0[:m:3]
+        b0[m:] = 2 ** 30; b1[m:] = -5                       # (entries past the live count are garbage in the library's buffers)
+        c0.append(b0); c1.append(b1); n0s.append(n0); ncs.append(m)
+    ri, rf = harness.inlier_ratios_dev(xs0, xs1, torch.from_numpy(np.stack(nn)), torch.from_numpy(np.stack(c0)), torch.from_numpy(np.stack(c1)),
+                                       torch.tensor(n0s, dtype=torch.int32), torch.tensor(ncs, dtype=torch.int32), np.stack(T))
+    for k in range(3):
+        p0, p1 = PointCloud(xs0[k].numpy()), PointCloud(xs1[k].numpy())
+        e_i = matching.measure_inlier_ratio(np.arange(n0s[k]), nn[k][:n0s[k]], p0, p1, T[k], VOXEL_SIZE)
+        e_f = matching.measure_inlier_ratio(c0[k][:ncs[k]], c1[k][:ncs[k]], p0, p1, T[k], VOXEL_SIZE)
+        assert abs(float(ri[k]) - e_i) < 1e-12 and abs(float(rf[k]) - e_f) < 1e-12, (k, float(ri[k]), e_i, float(rf[k]), e_f)
+    assert 0.1 < float(ri.min()) < 0.6 and 0.05 < float(rf.min()) < 0.5          # (the planted pairs make the statistic non-trivial)

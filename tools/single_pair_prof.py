@@ -1,7 +1,9 @@
 """One pair at a time (lr_register_pair, the reference harness' call pattern): run under rocprofv3 --kernel-trace --stats."""
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from lidarregistration_amd import FR, synth
+from lidarregistration_amd import FR, synth, _ext
+for kv in os.environ.get("LIDARREG_OPTS", "").split():      # e.g. LIDARREG_OPTS="rev_strips=16 nn_blocks=768"
+    k, v = kv.split("="); _ext.DEFAULT_OPTIONS[k] = int(v)
 from tests.conftest import Args
 cb = sys.argv[1] if len(sys.argv) > 1 else "open3D"
 mode = sys.argv[2] if len(sys.argv) > 2 else "MNN"
