@@ -300,6 +300,9 @@ def philox(seed, h):
 
 def _params(sample_size, use_elc, thr, iters, seed, confidence=1.0, batch=0, sampler=0, prosac_growth=0, scoring=0, local_opt=0,
             lo_rounds=0, lo_trials=0, lo_max_calls=0, min_iters=0):
+    # (the library rejects these with LR_EINVAL, lr_ransac.hip: the checker refuses them too instead of clamping silently)
+    if not (0 <= int(lo_trials) <= 20 and int(lo_rounds) >= 0 and int(lo_max_calls) >= 0 and int(min_iters) >= 0):
+        raise ValueError("lo_rounds, lo_trials (<= 20), lo_max_calls and min_iters must be >= 0 (0 = default)")
     return RansacParams(sample_size, int(use_elc), np.float32(float(thr) * float(thr)), iters, seed, confidence, batch,
                         int(sampler), int(prosac_growth), int(scoring), int(local_opt), int(lo_rounds), int(lo_trials), int(lo_max_calls),
                         int(min_iters))
