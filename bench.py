@@ -436,7 +436,9 @@ def main():
         tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         tdoc = json.load(open(tj)) if os.path.exists(tj) else {}
         # (the filter pass has two instantiations, both launched; the one the data asks for does the work)
-        traffic = (tdoc.get("nn16_passb_kernel<true>") or tdoc.get("nn16_passb_kernel", {})).get("hbm_bytes_per_launch")
+        live = [v for k, v in tdoc.items() if k.startswith("nn16_passb_kernel<true") and isinstance(v, dict)]
+        traffic = int(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in live) / max(1, sum(v["launches"] for v in live))) if live else \
+            tdoc.get("nn16_passb_kernel", {}).get("hbm_bytes_per_launch")
         traffic_source = None if traffic is None else ("NOT measured in this run: profiles/pmc_traffic.json, the builder's separate rocprofv3 --pmc passes of this "
                                                        "command (" + str(tdoc.get("_meta", {}).get("commit", "commit unrecorded")) + "), per launch")
         nn_stage_s = (fwd_nn_ms + rev_nn_ms) * 1e-3

@@ -210,7 +210,7 @@ __device__ __forceinline__ int lr_lds_off(int j, int p) { return j * LR_LDS_ROW 
 #define LR_PB_COLMASK 0x3fffffu
 #define LR_PB_HASG 0x1000000u    // entry flag (in x): exactly one row, and y carries its filter value g rounded up to 16 bits
 #ifndef LR_PB_JOINT
-#define LR_PB_JOINT 1          // 0: development switch, no launch uses the joint form
+#define LR_PB_JOINT 1          // 0: development switch, every wave attends to its list on its own
 #endif
 #ifndef LR_PB_PRIO
 #define LR_PB_PRIO 1          // a wave inside derive() runs at raised priority: its siblings wait for it at the next chunk barrier (60.1 -> 59.3 us per pair)
@@ -253,7 +253,7 @@ __device__ unsigned long long lr_pb_clk[4096 * 2];      // development probe: sh
 #if LR_PB_EXP & 16
 __device__ unsigned long long lr_pb_stat[16];             // development probe: waves, tests, slow-path visits, hits, derive() rounds, 16-entry groups
 #endif
-template <bool SIGN, bool JOINT>
+template <bool SIGN>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *__restrict__ rowmap, const int32_t *__restrict__ na_dev,
                   const _Float16 *__restrict__ Hc, const float *__restrict__ nC, int nb,
@@ -277,6 +277,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     lr_z(Hq, z, pair); lr_z(rowmap, z, pair); lr_z(na_dev, z, pair); lr_z(Hc, z, pair); lr_z(nC, z, pair); lr_z(tau, z, pair);
     lr_z(cand_cnt, z, pair); lr_z(cand, z, pair); lr_z(colmap, z, pair); lr_z(tile_min, z, pair); lr_z(row_bound, z, pair); lr_z(rev_offs, z, pair); lr_z(rev_range, z, pair);
     lr_z(thr.nQ, z, pair); lr_z(thr.range_c, z, pair); lr_z(yfin, z, pair); lr_z(yshare, z, pair);
+    constexpr bool JOINT = LR_PB_JOINT != 0;      // (one instantiation serves the forward and the reverse launch: the reverse one pays ~2 % for the exchange it does not need)
     // rows: either 0..na_host-1, or (reverse direction) the ordered list rowmap[0..*na_dev-1]; tau, cand_cnt and cand
     // are indexed by the position in that list.  Columns: Hc/nC as they lie; with colmap they are a permuted copy and
     // a candidate's column id is colmap[position].
@@ -789,8 +790,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         read_b(fo_cur, xo_cur, 0, b0, b1, xN);
         // The walk is a loop nest: the inner loop is the hot one and contains no tightening code (the compiler then keeps the threshold
         // registers loop-invariant and its wait counts exact); it is left whenever a hit list wants attention.
-        // The four waves of a block attend to their lists TOGETHER (JOINT: the forward launch; the reverse launch does not tighten, its
-        // lists only ever want to be emptied, and the exchange would be 2 % for nothing): a wave in derive() keeps its three siblings waiting
+        // The four waves of a block attend to their lists TOGETHER (JOINT): a wave in derive() keeps its three siblings waiting
         // at the next chunk barrier, so 4 x ~11 rounds per block, one wave at a time, stall the block four times as often as ~12 rounds
         // that all four take at once.  Every wave posts what its list wants (bit 0: a tightening round, bit 1: to be emptied) before the
         // chunk barrier, reads all four wishes behind it -- the decision is block-uniform -- and acts at the end of the chunk.
@@ -1089,13 +1089,13 @@ int lr_nn16_run(lr_workspace *ws, const float *Fq, const _Float16 *Hq, const flo
     lr_thr_in thr = { nQ, range_c, need, sstride };
     // both forms of the walk's candidate test; the blocks of the one the column norms do not ask for return at once
 #define SIGN_ true
-    hipLaunchKernelGGL((nn16_passb_kernel<SIGN_, LR_PB_JOINT != 0>), grid, dim3(256), 0, st, Hq, na, (const int32_t *)nullptr, (const int32_t *)nullptr, Hc, nC, nb,
+    hipLaunchKernelGGL(nn16_passb_kernel<SIGN_>, grid, dim3(256), 0, st, Hq, na, (const int32_t *)nullptr, (const int32_t *)nullptr, Hc, nC, nb,
                        tps, (const float *)nullptr, ws->cand_cnt, ws->cand, (const int32_t *)nullptr, (const float *)nullptr,
                        (const uint32_t *)nullptr, (const int32_t *)nullptr, (const uint32_t *)nullptr, ws->yfin, ws->max_n, ws->yshare, thr,
                        lr_pb_grid{ row_blocks, strips, total, 0 }, ws->z);
 #undef SIGN_
 #define SIGN_ false
-    hipLaunchKernelGGL((nn16_passb_kernel<SIGN_, LR_PB_JOINT != 0>), grid, dim3(256), 0, st, Hq, na, (const int32_t *)nullptr, (const int32_t *)nullptr, Hc, nC, nb,
+    hipLaunchKernelGGL(nn16_passb_kernel<SIGN_>, grid, dim3(256), 0, st, Hq, na, (const int32_t *)nullptr, (const int32_t *)nullptr, Hc, nC, nb,
                        tps, (const float *)nullptr, ws->cand_cnt, ws->cand, (const int32_t *)nullptr, (const float *)nullptr,
                        (const uint32_t *)nullptr, (const int32_t *)nullptr, (const uint32_t *)nullptr, ws->yfin, ws->max_n, ws->yshare, thr,
                        lr_pb_grid{ row_blocks, strips, total, 0 }, ws->z);
@@ -1373,7 +1373,7 @@ int lr_nn16_reverse(lr_workspace *ws, const float *F0, const _Float16 *H0, const
     const bool timed = ws->timing && ws->ev_pending == 1 && !ws->rev_recorded;
     if (timed) { LR_HIP(hipEventRecord(ws->ev[4], st)); }
 #define SIGN_ true
-    hipLaunchKernelGGL((nn16_passb_kernel<SIGN_, false>), grid, dim3(256), 0, st, H1, na, (const int32_t *)ws->rev_rows, (const int32_t *)n_rows,
+    hipLaunchKernelGGL(nn16_passb_kernel<SIGN_>, grid, dim3(256), 0, st, H1, na, (const int32_t *)ws->rev_rows, (const int32_t *)n_rows,
                        (const _Float16 *)ws->Hs, (const float *)ws->nrms, nb, tps, ws->tau, ws->cand_cnt, ws->cand,
                        (const int32_t *)ws->rev_cols, seeded ? (const float *)ws->rev_tmin : (const float *)nullptr, (const uint32_t *)seed,
                        (const int32_t *)ws->rev_hist, (const uint32_t *)range, (float *)nullptr, 0, (uint32_t *)nullptr,
@@ -1381,7 +1381,7 @@ int lr_nn16_reverse(lr_workspace *ws, const float *F0, const _Float16 *H0, const
                        lr_pb_grid{ row_blocks, strips, total, 1 }, ws->z);
 #undef SIGN_
 #define SIGN_ false
-    hipLaunchKernelGGL((nn16_passb_kernel<SIGN_, false>), grid, dim3(256), 0, st, H1, na, (const int32_t *)ws->rev_rows, (const int32_t *)n_rows,
+    hipLaunchKernelGGL(nn16_passb_kernel<SIGN_>, grid, dim3(256), 0, st, H1, na, (const int32_t *)ws->rev_rows, (const int32_t *)n_rows,
                        (const _Float16 *)ws->Hs, (const float *)ws->nrms, nb, tps, ws->tau, ws->cand_cnt, ws->cand,
                        (const int32_t *)ws->rev_cols, seeded ? (const float *)ws->rev_tmin : (const float *)nullptr, (const uint32_t *)seed,
                        (const int32_t *)ws->rev_hist, (const uint32_t *)range, (float *)nullptr, 0, (uint32_t *)nullptr,

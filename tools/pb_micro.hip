@@ -41,7 +41,7 @@ static void print_clk(int total)
 }
 #if PB_NEW_ABI
 #define PB_THR(name, nq, need, ss) lr_thr_in name = { nq, nrange, need, ss }
-#define PB_LAUNCH(...) do { hipLaunchKernelGGL((nn16_passb_kernel<true, LR_PB_JOINT != 0>), __VA_ARGS__); hipLaunchKernelGGL((nn16_passb_kernel<false, LR_PB_JOINT != 0>), __VA_ARGS__); } while (0)
+#define PB_LAUNCH(...) do { hipLaunchKernelGGL(nn16_passb_kernel<true>, __VA_ARGS__); hipLaunchKernelGGL(nn16_passb_kernel<false>, __VA_ARGS__); } while (0)
 #else
 #define PB_THR(name, nq, need, ss) lr_thr_in name = { nq, bmax, (n+31)/32, need, ss }
 #define PB_LAUNCH(...) hipLaunchKernelGGL(nn16_passb_kernel, __VA_ARGS__)

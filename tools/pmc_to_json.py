@@ -17,8 +17,8 @@ def short(name):
     if m:
         base = name[m.end():m.end() + int(m.group(1))]
         rest = name[m.end() + int(m.group(1)):]
-        t = re.match(r"^ILb([01])EE", rest)   # a bool template argument: the two instantiations of the filter pass are different kernels
-        return base + ("<true>" if t.group(1) == "1" else "<false>") if t else base
+        t = re.match(r"^I((?:Lb[01]E)+)E", rest)   # bool template arguments: the instantiations of the filter pass are different kernels
+        return base + "<" + ",".join("true" if b == "1" else "false" for b in re.findall(r"Lb([01])E", t.group(1))) + ">" if t else base
     name = re.sub(r"^void ", "", name)
     name = name.split("(")[0]
     return re.sub(r"<.*$", "", name) if name.startswith("at::") else name
