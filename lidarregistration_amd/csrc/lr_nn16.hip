@@ -306,7 +306,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     // per row of the block: y = tau/2 (what the accumulators start from), the row's error term, the two largest g of the walk
     __shared__ __attribute__((aligned(16))) float s_Y[LR_BLOCK_ROWS];
     __shared__ float s_D[LR_BLOCK_ROWS], s_N1[LR_BLOCK_ROWS], s_N2[LR_BLOCK_ROWS];
-    __shared__ __attribute__((aligned(16))) int s_att[2][4];      // what the four waves' hit lists want, per chunk parity 
+    __shared__ unsigned s_att[2];      // what the four waves' hit lists want (one byte per wave), per chunk parity 
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int c16 = lane & 15, kb = lane >> 4;
     const int row0 = bx * LR_BLOCK_ROWS + wave * 64;
@@ -712,20 +712,26 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
 #endif
         bool mine_hit;
         if constexpr (SIGN) {
-            // two chains of three-input ANDs over the 16 sign bits
+            // two interleaved chains of three-input ANDs over the 16 sign bits (one asm block: no hazard padding between the halves)
             int sa, sb;
-            asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x80\n\tv_bitop3_b32 %0, %0, %4, %5 bitop3:0x80\n\tv_bitop3_b32 %0, %0, %6, %7 bitop3:0x80\n\tv_and_b32 %0, %0, %8"
-                : "=&v"(sa) : "v"(r0[0]), "v"(r0[1]), "v"(r0[2]), "v"(r0[3]), "v"(r1[0]), "v"(r1[1]), "v"(r1[2]), "v"(r1[3]));
-            asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x80\n\tv_bitop3_b32 %0, %0, %4, %5 bitop3:0x80\n\tv_bitop3_b32 %0, %0, %6, %7 bitop3:0x80\n\tv_bitop3_b32 %0, %0, %8, %9 bitop3:0x80"
-                : "=&v"(sb) : "v"(r2[0]), "v"(r2[1]), "v"(r2[2]), "v"(r2[3]), "v"(r3[0]), "v"(r3[1]), "v"(r3[2]), "v"(r3[3]), "v"(sa));
-            mine_hit = sb >= 0;                        // the AND of the sign bits is clear: some register is not negative
+            asm("v_bitop3_b32 %0, %2, %3, %4 bitop3:0x80\n\tv_bitop3_b32 %1, %10, %11, %12 bitop3:0x80\n\t"
+                "v_bitop3_b32 %0, %0, %5, %6 bitop3:0x80\n\tv_bitop3_b32 %1, %1, %13, %14 bitop3:0x80\n\t"
+                "v_bitop3_b32 %0, %0, %7, %8 bitop3:0x80\n\tv_bitop3_b32 %1, %1, %15, %16 bitop3:0x80\n\t"
+                "v_bitop3_b32 %0, %0, %1, %9 bitop3:0x80\n\tv_and_b32 %0, %0, %17"
+                : "=&v"(sa), "=&v"(sb)
+                : "v"(r0[0]), "v"(r0[1]), "v"(r0[2]), "v"(r0[3]), "v"(r1[0]), "v"(r1[1]), "v"(r1[2]), "v"(r1[3]),
+                  "v"(r2[0]), "v"(r2[1]), "v"(r2[2]), "v"(r2[3]), "v"(r3[0]), "v"(r3[1]), "v"(r3[2]), "v"(r3[3]));
+            mine_hit = sa >= 0;                        // the AND of the sign bits is clear: some register is not negative
         } else {
             float ma, mb;
-            asm("v_max3_f32 %0, %1, %2, %3\n\tv_max3_f32 %0, %0, %4, %5\n\tv_max3_f32 %0, %0, %6, %7\n\tv_max_f32 %0, %0, %8"
-                : "=&v"(ma) : "v"(r0[0]), "v"(r0[1]), "v"(r0[2]), "v"(r0[3]), "v"(r1[0]), "v"(r1[1]), "v"(r1[2]), "v"(r1[3]));
-            asm("v_max3_f32 %0, %1, %2, %3\n\tv_max3_f32 %0, %0, %4, %5\n\tv_max3_f32 %0, %0, %6, %7\n\tv_max3_f32 %0, %0, %8, %9"
-                : "=&v"(mb) : "v"(r2[0]), "v"(r2[1]), "v"(r2[2]), "v"(r2[3]), "v"(r3[0]), "v"(r3[1]), "v"(r3[2]), "v"(r3[3]), "v"(ma));
-            mine_hit = mb >= x;
+            asm("v_max3_f32 %0, %2, %3, %4\n\tv_max3_f32 %1, %10, %11, %12\n\t"
+                "v_max3_f32 %0, %0, %5, %6\n\tv_max3_f32 %1, %1, %13, %14\n\t"
+                "v_max3_f32 %0, %0, %7, %8\n\tv_max3_f32 %1, %1, %15, %16\n\t"
+                "v_max3_f32 %0, %0, %1, %9\n\tv_max_f32 %0, %0, %17"
+                : "=&v"(ma), "=&v"(mb)
+                : "v"(r0[0]), "v"(r0[1]), "v"(r0[2]), "v"(r0[3]), "v"(r1[0]), "v"(r1[1]), "v"(r1[2]), "v"(r1[3]),
+                  "v"(r2[0]), "v"(r2[1]), "v"(r2[2]), "v"(r2[3]), "v"(r3[0]), "v"(r3[1]), "v"(r3[2]), "v"(r3[3]));
+            mine_hit = ma >= x;
         }
         const unsigned long long hit = __builtin_amdgcn_ballot_w64(mine_hit);
         if (__builtin_expect(hit != 0ull, 0)) {       // rare: keeps the common path a fall-through
@@ -798,7 +804,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         while (c < nchunks) {
             int wish = 0;
             for (; c < nchunks && !wish; ++c) {
-                int4 wishes = { 0, 0, 0, 0 };
+                unsigned wishes = 0u;
 #pragma unroll
                 for (int k = 0; k < CH; ++k) {
                     if (k == CH - 1) {
@@ -807,17 +813,17 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
                         // chunk's own last tile), so one barrier per chunk still orders everything.
 #if !(LR_PB_EXP & 1)
                         if (c + 1 < nchunks) store_chunk((c & 1) ^ 1);
-                        if constexpr (JOINT) { if (lane == 0) s_att[c & 1][wave] = (wcnt >= LR_PB_WLIST / 2 ? 2 : 0) | ((tightening && wcnt - wdone >= LR_PB_TIGHTEN) ? 1 : 0); }
+                        if constexpr (JOINT) { if (lane == 0) reinterpret_cast<unsigned char *>(&s_att[c & 1])[wave] = (unsigned char)((wcnt >= LR_PB_WLIST / 2 ? 2 : 0) | ((tightening && wcnt - wdone >= LR_PB_TIGHTEN) ? 1 : 0)); }
                         __syncthreads();
                         // (requested here, looked at behind the chunk's last step)
-                        if constexpr (JOINT) wishes = *reinterpret_cast<const int4 *>(s_att[c & 1]);
+                        if constexpr (JOINT) wishes = s_att[c & 1];
                         if (c + 2 < nchunks) load_chunk(c + 2);
 #endif
                     }
                     step(c, k);
                 }
                 { const int t0 = fo_cur; fo_cur = fo_oth; fo_oth = t0; const int t1 = xo_cur; xo_cur = xo_oth; xo_oth = t1; }
-                if constexpr (JOINT) wish = __builtin_amdgcn_readfirstlane(wishes.x | wishes.y | wishes.z | wishes.w);
+                if constexpr (JOINT) { const unsigned w = __builtin_amdgcn_readfirstlane(wishes); wish = (w & 0x02020202u) ? 2 : (w ? 1 : 0); }
                 else wish = (wcnt >= LR_PB_WLIST / 2 ? 2 : 0) | ((tightening && wcnt - wdone >= LR_PB_TIGHTEN) ? 1 : 0);
             }
             if (wish & 2) flush();
