@@ -1082,10 +1082,10 @@ int lr_nn16_run(lr_workspace *ws, const float *Fq, const _Float16 *Hq, const flo
     const int tps = lr_cdiv(ntiles, strips);
     // phase 1 of the filter pass samples every `sstride`-th tile of a strip (any subset gives a valid, if looser, start; the walk
     // tightens it).  Its cost is ~ tiles / stride per row, the extra hits of a looser start ~ 2 ln(stride) per row: about 32
-    // sampled tiles per strip, a stride of at most 16 (32 for very long strips).
+    // sampled tiles per strip, a stride of at most 32.
     // With several strips per row block the start thresholds are pooled, so the budget is per ROW: about 64 sampled tiles over all strips.
     int sstride = ws->nn_sample_stride > 0 ? ws->nn_sample_stride : (strips > 1 ? ntiles / 64 : tps / 32);
-    if (ws->nn_sample_stride <= 0) { const int cap = tps > 2048 ? 32 : 16; if (sstride > cap) sstride = cap; }
+    if (ws->nn_sample_stride <= 0) { const int cap = strips > 1 ? 16 : 32; if (sstride > cap) sstride = cap; }      // (pipeline, 30k points: 16 / 24 / 32 / 48 / 64 -> 11 750 / 11 820 / 11 910 / 11 880 / 11 920 pairs/s)
     if (sstride < 1) sstride = 1;
     if (sstride > tps) sstride = tps;          // (one sampled tile per strip at least; keeps phase 1's column index in range)
     // 1-D XCD-aware grid over (row block, strip, pair), padded to a multiple of 8

@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: the bench under different workspace options (same box, same library)
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r4_opts; mkdir -p $O; cd $R
-for rep in 1 2; do for o in "${@}"; do
+for rep in 1 2 3; do for o in "${@}"; do
   python bench.py --no-cpu-baseline --sustain-s 0 $o > $O/line.json 2>/dev/null
   python - $O/line.json "$o" <<'PY'
 import json, sys
