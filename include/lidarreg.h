@@ -148,7 +148,7 @@ LR_API int    lr_workspace_poison(lr_workspace *ws, int byte, void *stream);
 enum {
     LR_OPT_NN_BLOCKS        = 1,  /* a single-pair filter pass is cut into column strips so that it launches about this many blocks (512) */
     LR_OPT_NN_BLOCKS_BATCH  = 2,  /* the same for a batched call, over all its pairs (3072)                                  */
-    LR_OPT_NN_SAMPLE_STRIDE = 3,  /* the filter pass samples every k-th column tile for its start thresholds (default: strip tiles / 32, at most 16) */
+    LR_OPT_NN_SAMPLE_STRIDE = 3,  /* the filter pass samples every k-th column tile for its start thresholds (default: strip tiles / 32, at most 32) */
     LR_OPT_REV_STRIPS       = 4,  /* column strips offered to each row block of the reverse NN pass (default 48 / pairs, within 2..8) */
     LR_OPT_NN_SECOND_AUTO   = 5   /* 1: lr_register_pair / _batch compute the second neighbour only when a stage of the call reads it */
 };
