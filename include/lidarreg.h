@@ -8,7 +8,9 @@
  *     row-major; the library allocates nothing behind the caller's back except inside an explicit
  *     lr_workspace;
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all calls are asynchronous on
- *     it and do not synchronise with the host;
+ *     it and do not synchronise with the host; the data-path entry points only launch kernels (and
+ *     1-D memsets) on that stream, so a caller may capture them in a HIP graph and replay it on new
+ *     data in the same buffers (timing off: lr_workspace_timing records events);
  *   - return value 0 = LR_OK, negative = error (lr_last_error() gives the text); nothing throws;
  *   - 4x4 transforms are row-major float64, column-vector convention, cloud 0 -> cloud 1
  *     (the reference's pygcransac binding returns the transpose, GC_RANSAC.py:55 -- not here);

@@ -217,11 +217,21 @@ extern "C" int lr_workspace_lists_batch(lr_workspace *ws, int npairs, int width,
     return LR_OK;
 }
 
-// zero `bytes` of scratch at p (an arena-0 pointer) in the arena of every pair of the call in flight
+// zero `bytes` (a multiple of 4) of scratch at p (an arena-0 pointer) in the arena of every pair of the call in flight.  A kernel, not
+// hipMemset2DAsync: one launch whatever the number of pairs, and a plain kernel node when the caller captures the call in a HIP graph
+// (the 2-D memset node faulted on replay with the arena stride as its pitch: tests/test_gpu_batch.py, round 4).
+__global__ void __launch_bounds__(256) zero_scratch_kernel(uint32_t *__restrict__ p, size_t words, lr_zargs z)
+{
+    lr_z(p, z, blockIdx.z);
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < words; k += (size_t)gridDim.x * 256) p[k] = 0u;
+}
 int lr_zero_scratch(lr_workspace *ws, void *p, size_t bytes, hipStream_t st)
 {
-    if (ws->zP <= 1) LR_HIP(hipMemsetAsync(p, 0, bytes, st));
-    else LR_HIP(hipMemset2DAsync(p, ws->stride, 0, bytes, (size_t)ws->zP, st));
+    const size_t words = (bytes + 3) / 4;
+    int blocks = (int)((words + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(zero_scratch_kernel, dim3(blocks < 1 ? 1 : blocks, 1, ws->zP), dim3(256), 0, st, reinterpret_cast<uint32_t *>(p), words, ws->z);
+    LR_LAUNCH_CHECK();
     return LR_OK;
 }
 

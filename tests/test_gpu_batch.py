@@ -142,3 +142,50 @@ def test_batch_with_tiny_and_degenerate_pairs(lr):
         assert np.array_equal(outb[k], out1), (k, sizes[k])
     r = lr.ext.PairResult.from_buffer_copy(outb[0].tobytes())
     assert r.status in (0, 1) and r.n_corr <= 1
+
+
+@pytest.mark.parametrize("kw", [dict(mode="MNN", codebase="open3D", ransac_n=3, o3d_conf=1.0), dict(mode="GPF", codebase="GC", prosac=True, GC_conf=0.999)])
+def test_entry_points_can_be_captured_in_a_hip_graph(lr, kw):
+    """The data-path entry points launch on the given stream only, allocate nothing and never synchronise -- so a caller may capture
+    them in a HIP graph once and replay the graph on new data copied into the same buffers.  One pair and a 3-pair batched call:
+    replays are bit-identical to eager calls."""
+    torch, FR, ext = lr.torch, lr.FR, lr.ext
+    dev = torch.device("cuda", 0)
+    a = Args(iters=3000, **kw)
+    params = FR.pair_params(a)
+    n = 4000
+    data = [synth.make_pair_dev(N=n, seed=300 + k, device=dev) for k in range(6)]
+    keys = ("xyz0", "xyz1", "feats0", "feats1")
+    size = ctypes.sizeof(ext.PairResult)
+    s = torch.cuda.Stream(device=dev)
+    for P in (1, 3):
+        bufs = [tuple(torch.empty_like(data[0][k]) for k in keys) for _ in range(P)]
+        out = torch.empty((P, size), dtype=torch.uint8, device=dev)
+        ws = ext.Workspace(n, n, 32, a.iters, max_pairs=P)
+
+        def call():
+            if P == 1:
+                FR.register_pair_dev(*bufs[0], params, out=out[0], ws=ws, stream=s.cuda_stream)
+            else:
+                FR.register_batch_dev(bufs, params, out=out, ws=ws, stream=s.cuda_stream)
+
+        def load(j):
+            for q in range(P):
+                for dst, k in zip(bufs[q], keys):
+                    dst.copy_(data[(j + q) % len(data)][k])
+            torch.cuda.synchronize(dev)
+
+        load(0); call(); s.synchronize()                      # warm-up outside the capture
+        eager = []
+        for j in range(4):
+            load(j); call(); s.synchronize(); eager.append(out.cpu().numpy().copy())
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            call()
+        for j in range(4):
+            load(j); g.replay(); torch.cuda.synchronize(dev)
+            got = out.cpu().numpy()
+            assert np.array_equal(got[:, :256], eager[j][:, :256]), (P, j)           # T and T_ransac of every pair, bit for bit
+            r = ext.PairResult.from_buffer_copy(got[0].tobytes()); e = ext.PairResult.from_buffer_copy(eager[j][0].tobytes())
+            assert (r.n_corr, r.ransac.best_h, r.ransac.best_count, r.status) == (e.n_corr, e.ransac.best_h, e.ransac.best_count, e.status) and r.status == 0
+        ws.close()
