@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _bench(extra):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--n", "4000", "--iters", "3000", "--pairs", "12", "--batch", "4",
-                        "--steps", "2", "--warmup", "1"] + extra, capture_output=True, text=True, timeout=900, env=env)
+                        "--steps", "2", "--warmup", "1", "--sustain-s", "0.5"] + extra, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -26,6 +26,8 @@ def test_bench_line_small_workload():
     assert line["n_gpus"] == 1 and line["unit"] == "pairs/s" and line["value"] > 0 and line["scaling"] == "weak" and line["dtype"] == "f32"
     assert line["recall_2deg_0.6m"] == 1.0 and line["nn_rows_redone_by_full_scan_per_pair"] == 0.0
     assert line["config"]["pairs_per_batched_call"] == 4 and "workload" in line["config"]
+    sus = line["sustained"]          # the same step loop run on for --sustain-s seconds, reported next to `value`
+    assert sus["seconds"] >= 0.5 and sus["steps"] >= 2 and sus["pairs_per_s"] > 0 and 0.3 < sus["ratio_to_value"] < 3.0
     roof = line["roofline"]
     assert roof["bound"] == "mfma" and roof["kernel"] == "nn16_passb_kernel" and roof["unit"] == "TFLOP/s" and roof["peak"] == 2500.0
     assert 0 < roof["frac"] < 1 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and roof["launch_ms"] > 0
@@ -85,3 +87,19 @@ def test_a_dying_rank_ends_the_self_launched_run_quickly():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--devices", "0,7", "--n", "4000",
                         "--iters", "3000", "--pairs", "4", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode != 0 and time.time() - t0 < 120          # rank 1 has no device 7 on this box
+
+
+def test_list_mode_with_two_ranks_on_this_gpu():
+    """`bench.py --list B` through the self-launcher with two ranks on one GPU (gloo, host tensors): the list rows shard round-robin
+    over the ranks (DistributedSampler order), the merged table covers every row once, the sustained leg belongs to the headline
+    workload only."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--devices", "0,0", "--list", "B",
+                        "--list-stride", "216", "--batch", "4", "--streams", "2", "--n", "8000", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["pairs"] == 12 and d["recall_5deg_0.6m"] == 1.0 and d["config"]["parallelism"] == "pair-sharded x2"
+    assert 0.0 <= d["hard"]["recall_5deg_0.6m"] <= 1.0
