@@ -695,3 +695,43 @@ def test_tuning_options_do_not_change_results(lr):
     matching._WS.clear()
     with pytest.raises(lr.ext.LidarRegError):
         lr.ext.Workspace(100, 100, 32, 10).set_option("nn_blocks", -1)
+
+
+@pytest.mark.parametrize("spread0,spread1", [(0.0, 0.0), (6e-5, 0.0), (0.0, 6e-5), (9e-5, 1.1e-4), (3e-4, 0.0), (0.0, 3e-4), (0.3, 2e-5), (0.5, 0.5)])
+def test_nn_both_forms_of_the_walk_test_by_norm_spread(lr, oracle, spread0, spread1):
+    """The filter pass tests candidates with a sign test when all column norms lie within 1e-4 of each other and with a comparison
+    against the per-column term otherwise (nn16_passb_kernel<SIGN>; both are launched, the norm range decides on the device).  The
+    forward pass looks at cloud 1's norms, the reverse pass at cloud 0's: spreads on either side of the switch, in every combination,
+    single pair (several strips, pooled thresholds) and a 3-pair batched call -- NN lists, distances and mutual lists bit-exact."""
+    rng = np.random.default_rng(int(1e6 * (spread0 + 2 * spread1)) + 5)
+    n0, n1 = 6100, 5900
+    F0, F1 = synth.make_features(n0, n1, 32, 0.5, 1.0, 77)
+    F0 = (F0 * np.sqrt(1.0 + spread0 * rng.random((n0, 1)))).astype(np.float32)      # squared norms in [1, 1 + spread]
+    F1 = (F1 * np.sqrt(1.0 + spread1 * rng.random((n1, 1)))).astype(np.float32)
+    i1, i2, s1, s2 = lr.matching.nn_top2_dev(F0, F1, want_2nd=True, want_dist=True)
+    o1, o2, os1, os2 = oracle.nn_top2(F0, F1)
+    assert np.array_equal(i1.cpu().numpy(), o1) and np.array_equal(i2.cpu().numpy(), o2)
+    assert np.array_equal(_bits(s1.cpu().numpy()), _bits(os1)) and np.array_equal(_bits(s2.cpu().numpy()), _bits(os2))
+    t = lr.torch.from_numpy
+    m = oracle.nn_to_mutual(F0, F1, np.arange(n0), o1, o2)
+    g = lr.matching.nn_to_mutual(t(F0), t(F1), t(np.arange(n0)), t(o1), t(o2))
+    assert all(np.array_equal(a.numpy(), b) for a, b in zip(g, m))
+    # the same pair next to two others in one batched call (one strip per row block, joint rounds): its lists again
+    from tests.conftest import Args
+    import ctypes
+    dev = lr.torch.device("cuda", 0)
+    params = lr.FR.pair_params(Args(mode="MNN", codebase="open3D", iters=500, ransac_n=3, o3d_conf=1.0))
+    others = [synth.make_features(3000 + 500 * k, 4000, 32, 0.5, 1.0, 90 + k) for k in range(2)]
+    pairs = []
+    for A, B in [(F0, F1)] + others:
+        pairs.append((lr.torch.rand(A.shape[0], 3, device=dev), lr.torch.rand(B.shape[0], 3, device=dev), t(A).to(dev), t(B).to(dev)))
+    ws = lr.ext.Workspace(7000, 7000, 32, 500, max_pairs=3)
+    ws.poison(0xA5)
+    out = lr.FR.register_batch_dev(pairs, params, ws=ws).cpu().numpy()
+    bufs = [lr.torch.empty(n0, dtype=lr.torch.int32, device=dev) for _ in range(4)]
+    lr.ext.check(lr.ext.lib().lr_workspace_lists_at(ws.handle, 0, n0, *[b.data_ptr() for b in bufs], None))
+    r = lr.ext.PairResult.from_buffer_copy(out[0].tobytes())
+    nn1, nn2, c0, c1 = [b.cpu().numpy() for b in bufs]
+    assert np.array_equal(nn1, o1) and np.array_equal(nn2, o2) and r.n_nn_fixed == 0
+    assert r.n_corr == len(m[0]) and np.array_equal(c0[:r.n_corr], m[0]) and np.array_equal(c1[:r.n_corr], m[1])
+    ws.close()
