@@ -27,7 +27,7 @@ def test_bench_line_small_workload():
     assert line["recall_2deg_0.6m"] == 1.0 and line["nn_rows_redone_by_full_scan_per_pair"] == 0.0
     assert line["config"]["pairs_per_batched_call"] == 4 and "workload" in line["config"]
     sus = line["sustained"]          # the same step loop run on for --sustain-s seconds, reported next to `value`
-    assert sus["seconds"] >= 0.5 and sus["steps"] >= 2 and sus["pairs_per_s"] > 0 and 0.3 < sus["ratio_to_value"] < 3.0
+    assert sus["seconds"] > 0.05 and sus["steps"] >= 2 and sus["pairs_per_s"] > 0 and 0.3 < sus["ratio_to_value"] < 3.0
     roof = line["roofline"]
     assert roof["bound"] == "mfma" and roof["kernel"] == "nn16_passb_kernel" and roof["unit"] == "TFLOP/s" and roof["peak"] == 2500.0
     assert 0 < roof["frac"] < 1 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and roof["launch_ms"] > 0
