@@ -306,31 +306,66 @@ ratio_kernel(const float *__restrict__ F0, const float *__restrict__ F1, int dim
     if (m_dev) m = min(m, *m_dev);
     float v[3] = { 0.0f, 0.0f, 0.0f };
     const bool live = c < m;
-    if (live) {
+    if (dim == 32) {
+        // FCGF's 32 dimensions (block-uniform branch): EIGHT lanes per pair, lane t holding elements 4 t .. 4 t + 3 of the three rows,
+        // so a load instruction of the wave fetches 8 whole 128-byte rows instead of 16 bytes of 64 different ones (the
+        // one-thread-per-pair form spent its time in the texture addresser: 110 us per 32 x 30k pairs).  The sums still run over
+        // k = 0, 1, 2, ... in order: the running sums are handed from lane t to lane t + 1, four additions per hop.  The block's 256
+        // pairs are taken in 8 rounds of 32; lane 7 of a group leaves the round's ratio in LDS, thread i picks up pair i's.
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        __shared__ int s_i[3][256];
+        __shared__ float s_ratio[256];
+        const int tid = threadIdx.x, g = tid >> 3, t = tid & 7;
+        s_i[0][tid] = live ? (i0 ? i0[c] : c) : 0; s_i[1][tid] = live ? i1[c] : 0; s_i[2][tid] = live ? i2[c] : 0;
+        __syncthreads();
+#pragma unroll 2
+        for (int r = 0; r < 8; r += 4) {
+            f32x4 av[4], pv[4], qv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int row = (r + u) * 32 + g;
+                av[u] = reinterpret_cast<const f32x4 *>(F0 + (size_t)s_i[0][row] * 32)[t];
+                pv[u] = reinterpret_cast<const f32x4 *>(F1 + (size_t)s_i[1][row] * 32)[t];
+                qv[u] = reinterpret_cast<const f32x4 *>(F1 + (size_t)s_i[2][row] * 32)[t];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float q1[4], q2[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float e1 = av[u][e] - pv[u][e], e2 = av[u][e] - qv[u][e];
+                    q1[e] = e1 * e1; q2[e] = e2 * e2;
+                }
+                float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+                for (int hop = 0; hop < 8; ++hop) {
+                    const float in1 = __shfl_up(s1, 1, 8), in2 = __shfl_up(s2, 1, 8);
+                    float c1 = t ? in1 : 0.0f, c2 = t ? in2 : 0.0f;
+                    c1 = c1 + q1[0]; c2 = c2 + q2[0];
+                    c1 = c1 + q1[1]; c2 = c2 + q2[1];
+                    c1 = c1 + q1[2]; c2 = c2 + q2[2];
+                    c1 = c1 + q1[3]; c2 = c2 + q2[3];
+                    if (t == hop) { s1 = c1; s2 = c2; }
+                }
+                if (t == 7) {
+                    float d1 = __builtin_sqrtf(s1), d2 = __builtin_sqrtf(s2);
+                    s_ratio[(r + u) * 32 + g] = ((d1) / (d2 + 1e-6f));
+                }
+            }
+        }
+        __syncthreads();
+        if (live) {
+            v[0] = s_ratio[tid];
+            out[c] = v[0];
+            if (mm) { const int pa = s_i[0][tid]; v[1] = xyz0[3 * pa]; v[2] = xyz0[3 * pa + 1]; }
+        }
+    } else if (live) {
         const int pa = i0 ? i0[c] : c;
         const float *a = F0 + (size_t)pa * dim;
         const float *b1 = F1 + (size_t)i1[c] * dim;
         const float *b2 = F1 + (size_t)i2[c] * dim;
         float s1 = 0.0f, s2 = 0.0f;
-        if (dim == 32) {
-            // FCGF's 32 dimensions: all 24 16-byte loads of the three rows are in flight before the first subtraction (the
-            // generic loop below pays one memory round trip per iteration); the sums still run over k = 0, 1, 2, ... in order
-            typedef float f32x4 __attribute__((ext_vector_type(4)));
-            const f32x4 *a4 = reinterpret_cast<const f32x4 *>(a), *p4 = reinterpret_cast<const f32x4 *>(b1), *q4 = reinterpret_cast<const f32x4 *>(b2);
-            f32x4 av[8], pv[8], qv[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { av[k] = a4[k]; pv[k] = p4[k]; qv[k] = q4[k]; }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    float e1 = av[k][t] - pv[k][t], e2 = av[k][t] - qv[k][t];
-                    float q1 = e1 * e1, q2 = e2 * e2;
-                    s1 = s1 + q1;
-                    s2 = s2 + q2;
-                }
-            }
-        } else if ((dim & 3) == 0) {
+        if ((dim & 3) == 0) {
             // 16-byte loads; the sums still run over k = 0, 1, 2, ... in order (rows of a [n, dim] float array with
             // dim % 4 == 0 are 16-byte aligned whenever the array is, and torch / hipMalloc allocations are)
             typedef float f32x4 __attribute__((ext_vector_type(4)));

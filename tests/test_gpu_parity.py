@@ -164,6 +164,21 @@ def test_ratio_bit_exact(lr, oracle, filt):
     np.testing.assert_allclose(r.cpu().numpy(), filt["g"]["ratio_nn"], rtol=2e-6)
 
 
+@pytest.mark.parametrize("m", [1, 7, 31, 33, 255, 256, 257, 1000, 5003])
+@pytest.mark.parametrize("dim", [32, 16, 5])
+def test_ratio_ragged_counts_bit_exact(lr, oracle, m, dim):
+    """Every count around the kernel's 32-pair rounds and 256-pair blocks (dim 32: eight lanes per pair, running sums handed from lane
+    to lane), repeated and scattered rows, and the generic widths: the bits of matching.py:77's ratio as the oracle computes it."""
+    rng = np.random.default_rng(1000 * dim + m)
+    F0 = rng.standard_normal((3000, dim)).astype(np.float32); F1 = rng.standard_normal((2500, dim)).astype(np.float32)
+    i0 = rng.integers(0, 3000, m).astype(np.int64); i1 = rng.integers(0, 2500, m).astype(np.int64); i2 = rng.integers(0, 2500, m).astype(np.int64)
+    if m > 3:
+        i2[1] = i1[1]; F1[i1[2]] = F0[i0[2]]          # ratio exactly 1, and a zero numerator
+    r = lr.matching.calc_distance_ratio_in_feature_space(F0, F1, i0, i1, i2)
+    e = oracle.calc_distance_ratio_in_feature_space(F0, F1, i0, i1, i2)
+    assert np.array_equal(_bits(r.cpu().numpy()), _bits(e))
+
+
 @pytest.mark.parametrize("k", [0, 1, 2, 3, 4, 5, 6])
 def test_gpf_golden(lr, oracle, filt, k):
     g = filt["g"]
