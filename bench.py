@@ -46,7 +46,7 @@ def parse(argv=None):
                          "early exit, local optimisation + final least squares) -- an additional, lighter workload, never the headline")
     ap.add_argument("--batch", type=int, default=0, help="pairs per batched call (0: 32, or 8 for clouds above 60k points)")
     ap.add_argument("--streams", type=int, default=0, help="batched calls in flight per GPU (0: 3, or 4 with --codebase GC whose one-block-per-pair "
-                                                            "local optimisation leaves most CUs to the other calls)")
+                                                            "local optimisation leaves most CUs to the other calls; 6 with --list)")
     ap.add_argument("--sustain-s", type=float, default=10.0, help="after the K timed steps, run the same step loop for at least this many seconds and report it as "
                                                                   "`sustained` (outside `value`; 0: skip) -- the timed region of the contract is a fraction of a second")
     ap.add_argument("--include-h2d", action="store_true", help="copy each pair from pinned host memory inside the timed region (PCIe-inclusive rate; not the headline value)")
@@ -177,7 +177,7 @@ def list_run(args):
     rows_all = list(range(0, len(L["session"]), max(1, args.list_stride)))
     mine = [rows_all[i] for i in shard.shard_indices(len(rows_all), world, rank)]      # rank r: rows r, r+W, ... (DistributedSampler order)
     B = args.batch if args.batch > 0 else 32
-    nstreams = args.streams if args.streams > 0 else 4
+    nstreams = args.streams if args.streams > 0 else 6      # (4 -> 6 calls in flight: +8 % on list A, +6 % on list B; 8 and 12 fall back, round 4)
     t0 = time.perf_counter()
     res = harness.eval_list_batched(L, mine, A, n=args.n, batch=B, nstreams=nstreams, device=dev)
     wall = time.perf_counter() - t0

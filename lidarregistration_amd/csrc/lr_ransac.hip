@@ -1488,7 +1488,8 @@ int lr_ransac_run(lr_workspace *ws, const float *corr8, int m_max, const int32_t
     const int TN = p->prosac_growth > 0 ? p->prosac_growth : 100000;
     const int32_t *G = nullptr;
     // blocks per pair of the local-optimisation launches: with one or a few pairs in the call the GPU is idle next to the one block
-    // that optimises a pair's model, so helper blocks take shares of its scoring jobs (lo_score_shared); a full batch fills the GPU anyway
+    // that optimises a pair's model, so helper blocks take shares of its scoring jobs (lo_score_shared); with a full batch the calls of the
+    // other streams fill the GPU (2 / 4 / 8 helper groups per pair of a 32-pair call: +1 ... -3 % over the list runs, round 4)
     const int lo_groups = (p->local_opt == 1 && m_max >= 4 * LO_CHUNK_REC) ? (ws->zP <= 2 ? 16 : ws->zP <= 4 ? 8 : 1) : 1;
     if (ws->timing && ws->ev_pending == 1) { LR_HIP(hipEventRecord(ws->ev[2], st)); }
     if (p->sampler == 1) {
