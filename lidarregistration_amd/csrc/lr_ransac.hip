@@ -1033,33 +1033,35 @@ __device__ bool lo_fit_all(lo_shared &sh, const float *__restrict__ corr8, const
 }
 
 // score sh.Rt[0 .. ntrial) over all m correspondences -> sh.cnt / sh.ssq (integer atomics in LDS): three forms.
-// One model (the polish, or a round with at most LO_SAMPLE inliers): one thread per correspondence, four of them per step (24
-// independent loads in flight), 32-bit sums per thread (the caller guarantees that a thread's share of the correspondences
-// cannot overflow them), one wave reduction and one LDS atomic per wave at the end.
+// One model (the polish, or a round with at most LO_SAMPLE inliers): one thread per 64-byte record (two correspondences), 32-bit sums
+// per thread (the caller guarantees that a thread's share of the correspondences cannot overflow them), one wave reduction and one
+// LDS atomic per wave at the end.
 __device__ void lo_score_one(lo_shared &sh, const float *__restrict__ corr8, int m, float thr2)
 {
     const int tid = threadIdx.x, lane = tid & 63;
     if (tid < LO_TRIALS) { sh.cnt[tid] = 0u; sh.ssq[tid] = 0ull; }
     __syncthreads();
-    float Rt[12];
-#pragma unroll
-    for (int k = 0; k < 12; ++k) Rt[k] = sh.Rt[0][k];
+    const float *Rt = sh.Rt[0];
+    const f32x2 R00 = { Rt[0], Rt[0] }, R01 = { Rt[1], Rt[1] }, R02 = { Rt[2], Rt[2] }, TX = { Rt[3], Rt[3] };
+    const f32x2 R10 = { Rt[4], Rt[4] }, R11 = { Rt[5], Rt[5] }, R12 = { Rt[6], Rt[6] }, TY = { Rt[7], Rt[7] };
+    const f32x2 R20 = { Rt[8], Rt[8] }, R21 = { Rt[9], Rt[9] }, R22 = { Rt[10], Rt[10] }, TZ = { Rt[11], Rt[11] };
+    const int nrec = (m + 1) >> 1;
     uint32_t c = 0u, q = 0u;
-    for (int i0 = tid; i0 < m; i0 += 4 * LO_THREADS) {
-        float P[4][6];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = min(i0 + u * LO_THREADS, m - 1);
-#pragma unroll
-            for (int k = 0; k < 6; ++k) P[u][k] = corr8[lr_corr_at(i, k)];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const float d2 = lo_d2(Rt, P[u][0], P[u][1], P[u][2], P[u][3], P[u][4], P[u][5]);
-            const bool in = i0 + u * LO_THREADS < m && d2 < thr2;
-            c += in ? 1u : 0u;
-            q += in ? (uint32_t)(d2 * 1048576.0f) : 0u;
-        }
+    // the record walk of lo_build_list (three 16-byte loads per 64-byte record, both correspondences in one packed chain; the scalar
+    // form -- 24 strided 4-byte loads per step -- kept the texture addresser busy for 76 us per call at 30k correspondences)
+#pragma unroll 4
+    for (int r = tid; r < nrec; r += LO_THREADS) {
+        const f32x4 *rec = reinterpret_cast<const f32x4 *>(corr8) + (size_t)r * 4;
+        const f32x4 A = rec[0], B = rec[1], C = rec[2];
+        const f32x2 px = { A.x, A.y }, py = { A.z, A.w }, pz = { B.x, B.y }, qx = { B.z, B.w }, qy = { C.x, C.y }, qz = { C.z, C.w };
+        const f32x2 x = __builtin_elementwise_fma(R00, px, __builtin_elementwise_fma(R01, py, __builtin_elementwise_fma(R02, pz, TX)));
+        const f32x2 y = __builtin_elementwise_fma(R10, px, __builtin_elementwise_fma(R11, py, __builtin_elementwise_fma(R12, pz, TY)));
+        const f32x2 z = __builtin_elementwise_fma(R20, px, __builtin_elementwise_fma(R21, py, __builtin_elementwise_fma(R22, pz, TZ)));
+        const f32x2 dx = x - qx, dy = y - qy, dz = z - qz;
+        const f32x2 d2 = __builtin_elementwise_fma(dx, dx, __builtin_elementwise_fma(dy, dy, dz * dz));
+        const bool in0 = d2.x < thr2, in1 = 2 * r + 1 < m && d2.y < thr2;
+        c += (in0 ? 1u : 0u) + (in1 ? 1u : 0u);
+        q += (in0 ? (uint32_t)(d2.x * 1048576.0f) : 0u) + (in1 ? (uint32_t)(d2.y * 1048576.0f) : 0u);
     }
     unsigned long long qq = q;
 #pragma unroll
@@ -1272,10 +1274,25 @@ __device__ __forceinline__ void lo_score(lo_shared &sh, const float *__restrict_
         else lo_score_lanes(sh, corr8, m, thr2);
         return;
     }
-    const bool narrow = ((double)(m / LO_THREADS + 1)) * (double)thr2 * 1048576.0 < 4.0e9;
+    const bool narrow = ((double)(m / LO_THREADS + 2)) * (double)thr2 * 1048576.0 < 4.0e9;      // (a thread's correspondences x the largest term)
     if (!narrow) lo_score_wide(sh, corr8, m, thr2, ntrial);
     else lo_score_one(sh, corr8, m, thr2);
 }
+
+#ifdef LR_LO_PROBE      // development build (tools/r4_loprobe.sh): 10 ns ticks the master block spends per phase, summed over all launches
+__device__ unsigned long long g_lo_probe[16];
+extern "C" __attribute__((visibility("default"))) int lr_debug_lo_probe(unsigned long long *out, int reset)
+{
+    if (out) hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lo_probe), sizeof(unsigned long long) * 16);
+    if (reset) { unsigned long long z[16] = { 0 }; hipMemcpyToSymbol(HIP_SYMBOL(g_lo_probe), z, sizeof(z)); }
+    return 0;
+}
+#define LO_TICK(slot) do { if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); atomicAdd(&g_lo_probe[slot], now_ - tk_); tk_ = now_; } } while (0)
+#define LO_COUNT(slot) do { if (threadIdx.x == 0) atomicAdd(&g_lo_probe[slot], 1ull); } while (0)
+#else
+#define LO_TICK(slot) do { } while (0)
+#define LO_COUNT(slot) do { } while (0)
+#endif
 
 __global__ void __launch_bounds__(LO_THREADS)
 ransac_lo_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__restrict__ m_dev, lr_ransac_params p, int h_end, int mode,
@@ -1297,6 +1314,11 @@ ransac_lo_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__re
     auto release_helpers = [&]() { if (helpers && tid == 0) __hip_atomic_store(&ctl->phase, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     if (state->cnt == 0 || m <= 0) { release_helpers(); return; }                         // no model
     if (mode == 0 && !state->lo_pending) { release_helpers(); return; }                  // best model unchanged by the batch just merged
+#ifdef LR_LO_PROBE
+    unsigned long long tk_ = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long tk0_ = tk_;
+#endif
+    LO_COUNT(mode == 0 ? 9 : 10);
     const uint32_t msac_T = p.scoring == 1 ? (uint32_t)(p.thr2 * 1048576.0f) : 0u;
     if (tid < 12) sh.curT[tid] = state->T[tid];
     if (tid == 0) { sh.curc = state->cnt; sh.curq = state->ssq; }
@@ -1304,7 +1326,9 @@ ransac_lo_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__re
     __syncthreads();
     if (mode == 0) {
         for (int round = 0; round < p.lo_rounds; ++round) {
+            LO_COUNT(8);
             lo_build_list(sh, corr8, m, p.thr2, list);
+            LO_TICK(0);
             const int nI = sh.nI;
             if (nI <= p.sample_size) break;
             const int ntrial = nI > LO_SAMPLE ? p.lo_trials : 1;
@@ -1363,7 +1387,9 @@ ransac_lo_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__re
                 }
                 __syncthreads();
             } else if (!lo_fit_all(sh, corr8, list, nI)) break;
+            LO_TICK(1);
             lo_score(sh, corr8, m, p.thr2, ntrial, helpers ? ctl : nullptr, round, &state->lo_timeouts);
+            LO_TICK(2);
             if (tid == 0) {
                 int bt = -1; unsigned bc = 0; unsigned long long bq = 0;
                 for (int t = 0; t < ntrial; ++t) {
@@ -1375,14 +1401,19 @@ ransac_lo_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__re
                 if (sh.flag >= 0) { sh.curc = bc; sh.curq = bq; for (int k = 0; k < 12; ++k) sh.curT[k] = sh.T[bt][k]; }
             }
             __syncthreads();
+            LO_TICK(3);
             if (sh.flag < 0) break;
         }
     } else {
         for (int it = 0; it < LO_POLISH; ++it) {
+            LO_COUNT(11);
             lo_build_list(sh, corr8, m, p.thr2, list);
+            LO_TICK(4);
             const int nI = sh.nI;
             if (nI <= p.sample_size || !lo_fit_all(sh, corr8, list, nI)) break;
+            LO_TICK(5);
             lo_score(sh, corr8, m, p.thr2, 1);
+            LO_TICK(6);
             if (tid == 0) {
                 // a fit that loses inliers is discarded; an equal count is kept and ends the iteration; more: again
                 const unsigned tc = sh.cnt[0];
@@ -1419,6 +1450,9 @@ ransac_lo_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__re
         r.n_valid = state->n_valid; r.n_ids = state->n_ids;
         *res = r;
     }
+#ifdef LR_LO_PROBE
+    if (tid == 0) atomicAdd(&g_lo_probe[7], __builtin_amdgcn_s_memrealtime() - tk0_);
+#endif
 }
 
 // ------------------------------------------------------------------ inlier mask (what findRigidTransform returns next to the pose)
