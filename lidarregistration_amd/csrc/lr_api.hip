@@ -64,7 +64,7 @@ void carve(lr_workspace *ws, Carver &c)
     ws->ratio = c.take<float>(n0);
     ws->cell = c.take<int32_t>(n0); ws->cell_sorted = c.take<int32_t>(n0);
     ws->gpf_quota = c.take<double>(LR_GPF_MAX_CELLS);
-    ws->gpf_cells = c.take<int32_t>(3 * (LR_GPF_MAX_CELLS + 8));
+    ws->gpf_cells = c.take<int32_t>(3 * (LR_GPF_MAX_CELLS + 8) > 2 * (LR_PR_BUCKETS + 8) + 8 ? 3 * (LR_GPF_MAX_CELLS + 8) : 2 * (LR_PR_BUCKETS + 8) + 8);
     ws->gpf_keep = c.take<uint8_t>(n0);
     ws->gpf_f = c.take<float>(8);
     ws->corr8 = c.take<float>((n0 + 2) * 8);

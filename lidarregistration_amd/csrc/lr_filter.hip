@@ -171,9 +171,8 @@ int lr_pack_corr(lr_workspace *ws, const float *xyz0, const float *xyz1, const i
 // ------------------------------------------------------------------ PROSAC order (GC_RANSAC.py:39-43)
 // rank[c] = position of pair c when the pairs are sorted by ascending feature distance (= descending match quality,
 // FR.py:74-80), ties by c (numpy's argsort leaves ties unspecified; a stable order keeps the result reproducible), NaN
-// last.  Bucket sort: 4096 linear buckets over the value range, then the exact rank inside the bucket by comparing with
+// last.  Bucket sort: LR_PR_BUCKETS (8192) linear buckets over the value range, then the exact rank inside the bucket by comparing with
 // its members -- O(M x bucket size) instead of the O(M^2) of a plain counting rank (M can be all N pairs under GPF).
-#define LR_PR_BUCKETS 4096
 __device__ __forceinline__ float pr_key(float v) { return v == v ? v : __builtin_huge_valf(); }
 __device__ __forceinline__ int pr_bucket(float v, float lo, float scale)
 {
@@ -231,20 +230,24 @@ prosac_scan_kernel(const float *__restrict__ q, int m_max, const int32_t *__rest
 
 __global__ void __launch_bounds__(256)
 prosac_scatter_kernel(const float *__restrict__ q, int m_max, const int32_t *__restrict__ m_dev, const float *__restrict__ range,
-                      int32_t *__restrict__ fill, int32_t *__restrict__ members, lr_zargs z)
+                      int32_t *__restrict__ fill, int32_t *__restrict__ members, float *__restrict__ mkeys, lr_zargs z)
 {
-    lr_z(q, z, blockIdx.z); lr_z(m_dev, z, blockIdx.z); lr_z(range, z, blockIdx.z); lr_z(fill, z, blockIdx.z); lr_z(members, z, blockIdx.z);
+    lr_z(q, z, blockIdx.z); lr_z(m_dev, z, blockIdx.z); lr_z(range, z, blockIdx.z); lr_z(fill, z, blockIdx.z); lr_z(members, z, blockIdx.z); lr_z(mkeys, z, blockIdx.z);
     const int m = m_dev ? min(*m_dev, m_max) : m_max;
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= m) return;
-    members[atomicAdd(&fill[pr_bucket(pr_key(q[c]), range[0], range[1])], 1)] = c;
+    const float v = pr_key(q[c]);
+    const int pos = atomicAdd(&fill[pr_bucket(v, range[0], range[1])], 1);
+    members[pos] = c; mkeys[pos] = v;          // the key travels with the member: the ranking loop has no dependent loads
 }
 
 __global__ void __launch_bounds__(256)
 prosac_rank_kernel(const float *__restrict__ q, int m_max, const int32_t *__restrict__ m_dev, const float *__restrict__ range,
-                   const int32_t *__restrict__ offs, const int32_t *__restrict__ members, int32_t *__restrict__ rank, lr_zargs z)
+                   const int32_t *__restrict__ offs, const int32_t *__restrict__ members, const float *__restrict__ mkeys,
+                   int32_t *__restrict__ rank, lr_zargs z)
 {
-    lr_z(q, z, blockIdx.z); lr_z(m_dev, z, blockIdx.z); lr_z(range, z, blockIdx.z); lr_z(offs, z, blockIdx.z); lr_z(members, z, blockIdx.z); lr_z(rank, z, blockIdx.z);
+    lr_z(q, z, blockIdx.z); lr_z(m_dev, z, blockIdx.z); lr_z(range, z, blockIdx.z); lr_z(offs, z, blockIdx.z); lr_z(members, z, blockIdx.z); lr_z(mkeys, z, blockIdx.z);
+    lr_z(rank, z, blockIdx.z);
     const int m = m_dev ? min(*m_dev, m_max) : m_max;
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= m) return;
@@ -252,10 +255,15 @@ prosac_rank_kernel(const float *__restrict__ q, int m_max, const int32_t *__rest
     const int b = pr_bucket(v, range[0], range[1]);
     const int e = offs[b + 1];
     int r = offs[b];
-    for (int t = offs[b]; t < e; ++t) {
-        const int j = members[t];
-        const float w = pr_key(q[j]);
-        r += (w < v || (w == v && j < c)) ? 1 : 0;
+    // four members per step, their eight loads independent (the quality distribution decides the bucket sizes: GPF's normalised distance
+    // piles a tenth of the pairs up just below 1 -- 33 members per pair's bucket on average with 4096 buckets, where a dependent
+    // q[members[t]] per step cost 218 us per 32 x 30k pairs)
+    for (int t = offs[b]; t < e; t += 4) {
+        int j[4]; float w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int tt = min(t + u, e - 1); j[u] = members[tt]; w[u] = mkeys[tt]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) r += (t + u < e && (w[u] < v || (w[u] == v && j[u] < c))) ? 1 : 0;
     }
     rank[c] = r;
 }
@@ -276,12 +284,13 @@ int lr_prosac_order(lr_workspace *ws, const float *F0, const float *F1, int dim,
         quality = ws->ratio;
     }
     // GPF's scratch is free by now: offsets | fill | range in its cell arrays, bucket members in its sort buffer
-    int32_t *offs = ws->gpf_cells, *fill = offs + LR_GPF_MAX_CELLS + 8;
-    float *range = reinterpret_cast<float *>(fill + LR_GPF_MAX_CELLS + 8);
+    int32_t *offs = ws->gpf_cells, *fill = offs + LR_PR_BUCKETS + 8;
+    float *range = reinterpret_cast<float *>(fill + LR_PR_BUCKETS + 8);
     hipLaunchKernelGGL(prosac_scan_kernel, dim3(1, 1, ws->zP), dim3(1024), 0, st, quality, m_max, m_dev, offs, fill, range, ws->z);
-    hipLaunchKernelGGL(prosac_scatter_kernel, dim3(nb, 1, ws->zP), dim3(256), 0, st, quality, m_max, m_dev, (const float *)range, fill, ws->cell_sorted, ws->z);
+    float *mkeys = reinterpret_cast<float *>(ws->cell);       // (GPF's cell ids: free by now, like the rest of its scratch)
+    hipLaunchKernelGGL(prosac_scatter_kernel, dim3(nb, 1, ws->zP), dim3(256), 0, st, quality, m_max, m_dev, (const float *)range, fill, ws->cell_sorted, mkeys, ws->z);
     hipLaunchKernelGGL(prosac_rank_kernel, dim3(nb, 1, ws->zP), dim3(256), 0, st, quality, m_max, m_dev, (const float *)range, (const int32_t *)offs,
-                       (const int32_t *)ws->cell_sorted, ws->prosac_rank, ws->z);
+                       (const int32_t *)ws->cell_sorted, (const float *)mkeys, ws->prosac_rank, ws->z);
     LR_LAUNCH_CHECK();
     return LR_OK;
 }

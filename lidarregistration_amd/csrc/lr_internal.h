@@ -45,6 +45,7 @@ __host__ __device__ static inline int lr_seg_cap(int strips) { const int c = (LR
 #define LR_SCORE_BLOCKS 2048      // 512 blocks per pair (8192: one work item per wave, +4 % time: measured round 3)
 #endif
 #define LR_GPF_MAX_CELLS 4096
+#define LR_PR_BUCKETS 8192        // PROSAC ordering: linear buckets over the quality range (lr_filter.hip); its offsets / fill / range reuse gpf_cells
 #define LR_SC_INFO_BYTES 2048
 #define LR_LO_CTL_BYTES 20480      // lr_lo_ctl: control block of the local optimisation's helper blocks
 #define LR_NEV 10
@@ -135,7 +136,7 @@ struct lr_workspace {
     int32_t *cell;               // GPF: cell id per pair
     int32_t *cell_sorted;        // GPF: pair ids bucketed by cell
     double *gpf_quota;           // GPF: per-cell quota [LR_GPF_MAX_CELLS]
-    int32_t *gpf_cells;          // GPF: cell_count | cell_fill | cell_off, each [LR_GPF_MAX_CELLS + 8]
+    int32_t *gpf_cells;          // GPF: cell_count | cell_fill | cell_off, each [LR_GPF_MAX_CELLS + 8]; PROSAC: offsets | fill [LR_PR_BUCKETS + 8] | range
     uint8_t *gpf_keep;           // GPF: keep mask [max_n0]
     float *gpf_f;                // GPF: min/max scratch
     int32_t *prosac_G;           // [max_n0+2] PROSAC growth function G[n], n = sample_size..M
