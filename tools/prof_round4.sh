@@ -36,6 +36,8 @@ python3 $R/tools/pmc_to_json.py /tmp/pmc_FETCH_SIZE.csv /tmp/pmc_WRITE_SIZE.csv 
 bash $R/tools/pmc_bench.sh --sustain-s 0 > $O/pmc_sq_summary.txt 2>&1
 bash $R/tools/pmc_passb.sh > $O/pmc_passb_summary.txt 2>&1
 for l in A B; do python $R/bench.py --list $l --no-cpu-baseline > $O/list_${l}_bench_line.json 2>> $O/bench_stderr.log; done
+( cd $R && STREAMS=1 LISTS="A B" STRIDE=8 tools/r4_listprof.sh > /dev/null 2>&1; cp gpurun_out/r4_listprof/list_A_s1_kernel_stats.csv $O/list_A_streams1_kernel_stats.csv; cp gpurun_out/r4_listprof/list_B_s1_kernel_stats.csv $O/list_B_streams1_kernel_stats.csv )
+( cd $R && [ -f tools/bin/liblidarreg_probe.so ] && STRIDE=8 tools/r4_loprobe.sh run > /dev/null 2>&1 && cp gpurun_out/r4_loprobe/probe.txt $O/lo_probe.txt )
 bash $R/tools/single_pair_prof.sh > $O/single_pair_kernels.txt 2>&1
 python $R/tools/fr_latency.py 2>/dev/null > $O/fr_latency.txt
 ( cd $R && tools/bin/pb_micro_new 30000 32 1 > $O/pb_micro.txt 2>&1; tools/bin/pb_micro_new 30000 1 6 > $O/pb_micro_single.txt 2>&1 )
