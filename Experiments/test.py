@@ -65,6 +65,7 @@ def get_args(argv=None):
     p.add_argument("--synthetic_n", type=int, default=30000, help="synthetic: points per cloud")
     p.add_argument("--seed", type=int, default=51)
     p.add_argument("--batch", type=int, default=32, help="list rows per batched call (lr_register_batch: every kernel launched once for all of them)")
+    p.add_argument("--num_workers", type=int, default=8, help="threads that read the NEXT window's files (feature cache / cloud cache) while this window registers; 0: read on the main thread, as the reference's DataLoader(num_workers=0) does")
     p.add_argument("--streams", type=int, default=0, help="HIP streams the window's batched calls are spread over (0: 3; 6 measured the same over both lists -- the calls in flight count, not the streams)")
     p.add_argument("--in_flight", type=int, default=6, help="batched calls per window (each on its own workspace, round-robin over 3 streams); with --serial: pairs in flight")
     p.add_argument("--serial", type=str2bool, default=False, help="one lr_register_pair per list row, like the reference harness (cross-check / latency)")
@@ -110,7 +111,7 @@ def test_subset(args):
     if args.serial:
         stats, T = harness.eval_pairs_serial(source, idx, args, in_flight=min(args.in_flight, 4), verbose=args.rank == 0)
     else:
-        stats, T = harness.eval_pairs(source, idx, args, batch=args.batch, in_flight=args.in_flight, nstreams=args.streams or 3, verbose=False)
+        stats, T = harness.eval_pairs(source, idx, args, batch=args.batch, in_flight=args.in_flight, nstreams=args.streams or 3, verbose=False, workers=args.num_workers)
     wall = time.time() - t0
     msg = "process %d: %d pairs in %.2f s end to end (data source + registration + ICP + statistics): %.1f pairs/s" % (args.rank, len(idx), wall, len(idx) / max(wall, 1e-9))
     if not args.serial:

@@ -81,6 +81,12 @@ class CacheSource:
     def get_dev(self, k, device):
         return _upload(self.get(k), device)
 
+    # host half / device half of get_dev: eval_pairs reads the files of the NEXT window on worker threads while this one registers
+    load_host = get
+
+    def finish(self, host, device):
+        return _upload(host, device)
+
 
 class RefCloudSource:
     """Pairs of a balanced list from the REFERENCE's cloud cache (io_lists.load_ref_cloud: raw scans, [N,3] float64): every
@@ -98,24 +104,33 @@ class RefCloudSource:
     def ids(self, k):
         return int(self.pair_list["session"][k]), int(self.pair_list["src"][k]), int(self.pair_list["tgt"][k])
 
-    def _cloud(self, s, i):
+    def _files(self, s, i):
+        return io_lists.load_ref_cloud(self.cloud_dir, s, i), io_lists.load_cloud(self.feat_dir, s, i)
+
+    def _cloud(self, s, i, files=None):
         from . import voxel
-        raw = io_lists.load_ref_cloud(self.cloud_dir, s, i)
+        raw, (cx, feats) = files if files is not None else self._files(s, i)
         xyz, sel = voxel.voxel_downsample(raw, self.voxel_size)
         xyz = xyz.cpu().numpy()
-        cx, feats = io_lists.load_cloud(self.feat_dir, s, i)
         if feats.shape[0] != xyz.shape[0] or not np.allclose(cx, xyz, atol=1e-4):
             raise ValueError(f"feature cache entry {s}_{i} was not computed for this voxelisation ({feats.shape[0]} vs {xyz.shape[0]} points)")
         return xyz, feats
 
-    def get(self, k):
+    def get(self, k, files=None):
         s, i, j = self.ids(k)
-        xyz0, f0 = self._cloud(s, i)
-        xyz1, f1 = self._cloud(s, j)
+        xyz0, f0 = self._cloud(s, i, files and files[0])
+        xyz1, f1 = self._cloud(s, j, files and files[1])
         return dict(xyz0=xyz0, xyz1=xyz1, feats0=f0, feats1=f1, T_gt=self.pair_list["T_gt"][k])
 
     def get_dev(self, k, device):
         return _upload(self.get(k), device)
+
+    def load_host(self, k):          # the file reads (worker threads); the voxel de-duplication stays on the caller's thread and device
+        s, i, j = self.ids(k)
+        return k, (self._files(s, i), self._files(s, j))
+
+    def finish(self, host, device):
+        return _upload(self.get(host[0], host[1]), device)
 
 
 def load_list_fixture(dataset):
@@ -272,10 +287,12 @@ def inlier_ratios_dev(xyz0, xyz1, nn1, c0, c1, n0, n_corr, T_gt):
 _NCORR_OFF = _ext.PairResult.n_corr.offset
 
 
-def eval_pairs(source, indices, args, device=None, batch=32, in_flight=6, nstreams=3, verbose=False):
+def eval_pairs(source, indices, args, device=None, batch=32, in_flight=6, nstreams=3, verbose=False, workers=8):
     """Register source[k] for k in indices through the BATCHED engine -- what Experiments/test.py:108-234 does pair by pair.
     The list is taken in windows of `in_flight` batches of `batch` rows; per window:
       A  data: source.get_dev for every row (device synthesis / upload), synchronised                       -> column 10
+         (a source with load_host / finish -- the file-backed ones -- has the files of the NEXT window read by `workers` threads while
+         this window registers; column 10 is then the wait for them + the device half)
       B  registration: one lr_register_batch per batch (every kernel of the path launched once for all its pairs), batch i on
          workspace i and stream i % nstreams, + the strided copies of the lists; nothing else is in the region; synchronised;
          its wall time is the window's registration time                                                        -> column 9
@@ -306,11 +323,20 @@ def eval_pairs(source, indices, args, device=None, batch=32, in_flight=6, nstrea
     totals = dict(data_s=0.0, registration_s=0.0, icp_s=0.0, stats_s=0.0, pairs=n, batch=batch, in_flight=in_flight, nstreams=nstreams)
     window = batch * in_flight
     cur = torch.cuda.current_stream(dev)
+    pool = None
+    if workers > 1 and hasattr(source, "load_host"):
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=int(workers))
+    ahead = [pool.submit(source.load_host, indices[row]) for row in range(0, min(window, n))] if pool else None
     for w0 in range(0, n, window):
         rows_w = list(range(w0, min(w0 + window, n)))
         # ---- A: data
         t0 = time.time()
-        ps = [source.get_dev(indices[row], dev) for row in rows_w]
+        if pool:
+            mine, ahead = ahead, [pool.submit(source.load_host, indices[row]) for row in range(w0 + window, min(w0 + 2 * window, n))]
+            ps = [source.finish(f.result(), dev) for f in mine]
+        else:
+            ps = [source.get_dev(indices[row], dev) for row in rows_w]
         torch.cuda.synchronize(dev)
         t_data = time.time() - t0
         totals["data_s"] += t_data
@@ -410,6 +436,8 @@ def eval_pairs(source, indices, args, device=None, batch=32, in_flight=6, nstrea
             print(f"{time.strftime('%m/%d %H:%M:%S')} Finished pair:{rows_w[-1]}/{n}  ({len(rows_w) / max(t_reg, 1e-9):.0f} pairs/s in the registration region)", flush=True)
         del ps, groups
     torch.cuda.synchronize(dev)
+    if pool:
+        pool.shutdown(wait=True)
     for w in wss:
         if w is not None:
             w.close()

@@ -144,3 +144,24 @@ def test_batched_harness_on_ragged_clouds_equals_the_serial_one():
             assert np.array_equal(sb[:, c], ss[:, c], equal_nan=True), (a.mode, c, sb[:, c], ss[:, c])
         assert np.array_equal(Tb, Ts)
         assert sb[:, 15].tolist() == [s[0] for s in src.sizes] and (sb[[0, 1, 2, 4, 5], 0] == 1).all()
+
+
+def test_file_backed_source_is_read_ahead_by_worker_threads(tmp_path):
+    """A feature cache on disk (io_lists.save_cloud) through harness.CacheSource: eval_pairs reads the next window's files on worker
+    threads while the current window registers -- same rows as with the reads on the caller's thread, in list order, over several windows."""
+    from lidarregistration_amd import harness, io_lists, synth
+    from tests.conftest import Args
+    n_pairs = 9
+    lst = dict(session=np.full(n_pairs, 3), src=np.arange(n_pairs) * 2, tgt=np.arange(n_pairs) * 2 + 1, T_gt=[None] * n_pairs, overlap=None)
+    for k in range(n_pairs):
+        p = synth.make_pair(N=1500 + 100 * k, N1=1400 + 50 * k, rho=0.5, s=0.8, seed=900 + k)
+        io_lists.save_cloud(str(tmp_path), 3, 2 * k, p["xyz0"], p["feats0"]); io_lists.save_cloud(str(tmp_path), 3, 2 * k + 1, p["xyz1"], p["feats1"])
+        lst["T_gt"][k] = p["T_gt"]
+    src = harness.CacheSource(lst, str(tmp_path))
+    order = [4, 0, 8, 2, 6, 1, 7, 3, 5]
+    a = Args(mode="MNN", codebase="GC", iters=4000, prosac=True, icp=False)
+    s1, T1 = harness.eval_pairs(src, order, a, batch=2, in_flight=2, workers=4)      # windows of 4 rows: 4 + 4 + 1
+    s0, T0 = harness.eval_pairs(src, order, a, batch=2, in_flight=2, workers=0)
+    for c in (0, 1, 2, 15, 16, 17, 18, 19, 20, 21):
+        assert np.array_equal(s1[:, c], s0[:, c], equal_nan=True), c
+    assert np.array_equal(T1, T0) and s1[:, 20].tolist() == [2 * k for k in order] and (s1[:, 0] == 1).all()
