@@ -71,8 +71,10 @@ struct lr_desc_table { lr_pair_desc d[LR_MAX_BATCH]; };
 // __restrict__-qualified, which a `T *&` template parameter does not bind to.  The offset is applied as pointer arithmetic on
 // the parameter itself (never through an integer): the compiler then still knows that the address is global memory, uniform
 // and not clobbered by the kernel's own stores -- which is what lets wave-uniform streams stay on scalar loads.
+// Branch-free (a select on the offset): with an `if` per pointer the compiler fetched every kernel argument in its own basic block --
+// up to twenty dependent s_load / s_waitcnt pairs at the head of every block of every kernel.
 #define lr_z(p, z, pair) \
-    do { if (p) p = (decltype(p))((const char *)(p) + (size_t)(pair) * (z).stride); } while (0)
+    do { const size_t lr_zo_ = (size_t)(pair) * (z).stride; p = (decltype(p))((const char *)(p) + (lr_zo_ & ((size_t)0 - (size_t)((p) != nullptr)))); } while (0)
 // 1-D grid of 8 * ceil(total / 8) blocks -> logical block id such that the blocks an XCD receives (hardware ids congruent
 // mod 8) form one contiguous range of logical ids (cdna_hip_programming.md T1).  false: padding block.
 __device__ __forceinline__ bool lr_xcd_block(int total, int &logical)
