@@ -452,3 +452,21 @@ def test_lo_helper_protocol_under_contention(lr):
     assert max(latency) < 0.15, max(latency)           # (a timed-out wait alone is 0.2 s)
     print(f"contention: {len(latency)} single-pair GC calls next to {nb} batched calls in {wall:.2f} s; single-pair latency median "
           f"{np.median(latency) * 1e3:.2f} ms, max {max(latency) * 1e3:.2f} ms")
+
+
+@pytest.mark.parametrize("mode", ["GPF", "MNN"])
+def test_prosac_order_with_tied_qualities(lr, oracle, mode):
+    """PROSAC's order on the device (bucket scatter with the keys, rank inside the bucket four members per step) when the quality ties
+    massively: every descriptor of cloud 0 occurs four times, so four pairs share each feature-distance ratio / GPF score and only the pair
+    index orders them -- the oracle's stable argsort.  Same model, same counts."""
+    rng = np.random.default_rng(3)
+    p = synth.make_pair(N=1500, rho=0.6, s=0.7, seed=91)
+    perm = rng.permutation(6000)
+    p["feats0"] = np.ascontiguousarray(np.repeat(p["feats0"], 4, axis=0)[perm])
+    p["xyz0"] = np.ascontiguousarray((np.repeat(p["xyz0"], 4, axis=0) + rng.normal(0, 0.02, (6000, 3)).astype(np.float32))[perm])
+    a = Args(mode=mode, codebase="GC", iters=3000, prosac=True, GPF_factor=2.0)
+    t = lr.torch.from_numpy
+    out = lr.FR.FR(t(p["xyz0"]), t(p["xyz1"]), t(p["feats0"]), t(p["feats1"]), a, p["T_gt"])
+    e = oracle.register_pair(p["xyz0"], p["xyz1"], p["feats0"], p["feats1"], mode=mode, iters=3000, seed=51, args=a, **gc_oracle_kwargs(a))
+    np.testing.assert_allclose(out[0], e["T"], rtol=0, atol=1e-9)
+    assert oracle.rotation_error_deg(out[0], p["T_gt"]) < 1.0
