@@ -334,7 +334,13 @@ def eval_pairs(source, indices, args, device=None, batch=32, in_flight=6, nstrea
         t0 = time.time()
         if pool:
             mine, ahead = ahead, [pool.submit(source.load_host, indices[row]) for row in range(w0 + window, min(w0 + 2 * window, n))]
-            ps = [source.finish(f.result(), dev) for f in mine]
+            try:
+                ps = [source.finish(f.result(), dev) for f in mine]
+            except BaseException:          # a missing / mismatching file: stop the readers of the next window before the error leaves
+                for f in ahead:
+                    f.cancel()
+                pool.shutdown(wait=True)
+                raise
         else:
             ps = [source.get_dev(indices[row], dev) for row in rows_w]
         torch.cuda.synchronize(dev)
