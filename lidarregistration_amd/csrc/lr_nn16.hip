@@ -36,6 +36,7 @@
 #include "lr_internal.h"
 #include <math.h>
 #include <stdlib.h>
+#include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -203,7 +204,9 @@ __device__ __forceinline__ int lr_lds_off(int j, int p) { return j * LR_LDS_ROW 
 #ifndef LR_PB_EXP
 #define LR_PB_EXP 0     // development switches (tools/pb_micro.hip): 1 no staging, 2 no tests, 4 no tightening, 8 clock probe, 16 hit statistics, 128 plain test only
 #endif
+#ifndef LR_PB_WLIST
 #define LR_PB_WLIST 512          // entries per wave (12 bytes each)
+#endif
 // Entry of a hit list / of the candidate store (8 bytes): x = column (22 bits) | kb << 22 | LR_PB_HASG; y = 16-bit row mask | g16 << 16.
 // kb = lane / 16 of the lane that saw the hit: bit b = 4 rbk + g of the mask <-> row 16 rbk + 4 kb + g of the wave (the lane's 16
 // accumulator registers of one 16-column block).  The walk parks entries with an empty mask; derive() fills it in.
@@ -220,6 +223,15 @@ __device__ __forceinline__ int lr_lds_off(int j, int p) { return j * LR_LDS_ROW 
 #endif
 #ifndef LR_PB_TIGHTEN
 #define LR_PB_TIGHTEN 48         // new entries of a wave that trigger a tightening round
+#endif
+#ifndef LR_PB_GEO
+#define LR_PB_GEO 0              // > 0: geometric schedule -- the first round after LR_PB_GEO new entries, every later one after twice as many (capped at LR_PB_GEO_CAP)
+#endif
+#ifndef LR_PB_GEO_CAP
+#define LR_PB_GEO_CAP 192
+#endif
+#ifndef LR_PB_P1FOLD
+#define LR_PB_P1FOLD 0           // 1: phase 1 (SIGN form) keeps elementwise running maxima of the accumulators (16 v_max3 per tile instead of 32 half-rate ops)
 #endif
 
 // row (0..63 of the wave) of mask bit b (0..15) of an entry of lane group kb
@@ -306,7 +318,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     // per row of the block: y = tau/2 (what the accumulators start from), the row's error term, the two largest g of the walk
     __shared__ __attribute__((aligned(16))) float s_Y[LR_BLOCK_ROWS];
     __shared__ float s_D[LR_BLOCK_ROWS], s_N1[LR_BLOCK_ROWS], s_N2[LR_BLOCK_ROWS];
-    __shared__ unsigned s_att[2];      // what the four waves' hit lists want (one byte per wave), per chunk parity 
+    __shared__ unsigned s_att[2];      // [0]: what the four waves' hit lists want (one byte per wave)
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int c16 = lane & 15, kb = lane >> 4;
     const int row0 = bx * LR_BLOCK_ROWS + wave * 64;
@@ -356,7 +368,6 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     f32x4 stage[CH / 2];
     float stage_n = 0.0f;        // raw norm of the staged column: NOT touched until store_chunk, so that the compiler's
                                  // s_waitcnt for it lands after the tile loop instead of right behind the prefetch
-    bool stage_ok = false;
 
     // ---------------------------------------------------------------- thresholds of the block's 256 rows -> LDS
     // given (reverse direction), or made here by phase 1: U = need-th smallest sampled u' = -2 * (need-th largest g);
@@ -376,6 +387,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
             const int sstride = thr.sstride;
             const int nsamp = t_end > t_begin ? (t_end - t_begin + sstride - 1) / sstride : 0;     // tiles this block samples
             const int nsch = (nsamp + CH - 1) / CH;
+            constexpr bool P1E = SIGN && (LR_PB_P1FOLD != 0);      // (see fold() below)
             auto tile_s = [&](int c, int k) { return t_begin + (c * CH + k) * sstride; };
             auto load_s = [&](int c) {
 #pragma unroll
@@ -386,7 +398,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
                 }
                 const int lc = tid & (CH * 32 - 1);
                 const int col = tile_s(c, lc >> 5) * 32 + (lc & 31);
-                stage_n = nC[min(col, nb - 1)];      // (columns past the end repeat the last one: same tile, same norm)
+                if constexpr (!P1E) stage_n = nC[min(col, nb - 1)];      // (columns past the end repeat the last one: same tile, same norm)
             };
             auto store_s = [&](int buf) {
 #pragma unroll
@@ -394,6 +406,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
                     const int p = tid + 256 * q;
                     *reinterpret_cast<f32x4 *>(&lds[buf * BUF + lr_lds_off(p >> 2, p & 3)]) = stage[q];
                 }
+                if constexpr (P1E) return;
                 // largest x_j = n1[j]/2 of every tile of the chunk: the threads tid < CH*32 hold one column each, 32 per tile
                 float xm = 0.5f * stage_n;
 #pragma unroll
@@ -408,7 +421,20 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
             // eight MFMAs after they were issued: the hardware does not interlock a vector read of an MFMA result and the compiler does
             // not see inside the asm, so scheduling barriers pin the order); the LDS fragments of tile k + 1 are requested before the
             // MFMAs of tile k.  Unpipelined (round 3) the phase took 1.75x the walk's time per tile: 9 % of a block's lifetime.
+            // P1E (all column norms alike, LR_PB_P1FOLD): the lane keeps ELEMENTWISE running maxima of its accumulators instead -- register
+            // g of row block rbk collects columns 4 kb + g and 16 + 4 kb + g of every sampled tile, one v_max3 per register and tile (16
+            // per tile instead of 32 half-rate ops); the 4 registers x 4 lanes of a row are 16 disjoint column classes, so the two largest
+            // class maxima belong to different columns, and g >= dot16 - max_nc / 2 bounds the filter value from below
+            f32x4 runm[4];
+#pragma unroll
+            for (int rbk = 0; rbk < 4; ++rbk) runm[rbk] = f32x4{ -LR_INF, -LR_INF, -LR_INF, -LR_INF };
             auto fold = [&](const f32x4 &lo4, const f32x4 &hi4, int rbk, float xmax) {
+                if constexpr (P1E) {
+                    asm("v_max3_f32 %0, %0, %4, %8\n\tv_max3_f32 %1, %1, %5, %9\n\tv_max3_f32 %2, %2, %6, %10\n\tv_max3_f32 %3, %3, %7, %11"
+                        : "+v"(runm[rbk][0]), "+v"(runm[rbk][1]), "+v"(runm[rbk][2]), "+v"(runm[rbk][3])
+                        : "v"(lo4[0]), "v"(lo4[1]), "v"(lo4[2]), "v"(lo4[3]), "v"(hi4[0]), "v"(hi4[1]), "v"(hi4[2]), "v"(hi4[3]));
+                    return;
+                }
                 float t, lo;
                 asm("v_max3_f32 %0, %2, %3, %4\n\tv_max3_f32 %0, %0, %5, %6\n\tv_max3_f32 %0, %0, %7, %8\n\tv_max_f32 %0, %0, %9\n\t"
                     "v_sub_f32 %0, %0, %10\n\tv_min_f32 %1, %11, %0"
@@ -473,6 +499,17 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
                     for (int rbk = 0; rbk < 4; ++rbk) fold(sB[rbk], sB[4 + rbk], rbk, pend_x);
                 }
             }
+            if constexpr (P1E) {
+                // the two largest of the lane's four class maxima per row block; x_j <= max_nc / 2 for every column
+                const float xg = 0.5f * max_nc;
+#pragma unroll
+                for (int rbk = 0; rbk < 4; ++rbk) {
+                    const float a = fmaxf(runm[rbk][0], runm[rbk][1]), b = fminf(runm[rbk][0], runm[rbk][1]);
+                    const float c = fmaxf(runm[rbk][2], runm[rbk][3]), d = fminf(runm[rbk][2], runm[rbk][3]);
+                    m1[rbk] = fmaxf(a, c) - xg;
+                    m2[rbk] = fmaxf(fminf(a, c), fmaxf(b, d)) - xg;
+                }
+            }
             // the four lanes of a row (kb = 0..3: disjoint columns) merge their pairs in two exchange rounds; lane kb = 0 writes the row's
             // start value
 #pragma unroll
@@ -531,40 +568,59 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     // offset (no address arithmetic on the vector pipe), and rows past the end of the cloud read as zeros (range check of the
     // buffer descriptor) instead of being clamped: their x_j is +inf below, so they never pass the test.  Thread t moves the two
     // adjacent 16-byte pieces 2 (t & 1), 2 (t & 1) + 1 of column t >> 1 of the chunk.
-    static_assert(CH == 4, "the staging maps 256 threads onto 128 columns x 2 halves");
+    static_assert(CH % 4 == 0, "the staging maps 256 threads onto groups of 128 columns x 2 halves");
     const __amdgpu_buffer_rsrc_t rsrcH = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(Hc), 0, nb * 64, 0x27000);
     const __amdgpu_buffer_rsrc_t rsrcN = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(nC), 0, nb * 4, 0x27000);
     const int st_voff = tid * 32, st_noff = (tid & (CH * 32 - 1)) * 4;
     const int st_lds0 = lr_lds_off(tid >> 1, 2 * (tid & 1)), st_lds1 = lr_lds_off(tid >> 1, 2 * (tid & 1) + 1);
     auto load_chunk = [&](int c) {
         const int col0 = (t_begin + c * CH) * 32;       // wave-uniform
-        stage[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcH, st_voff, col0 * 64, 0));
-        stage[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcH, st_voff + 16, col0 * 64, 0));
+#pragma unroll
+        for (int q = 0; q < CH / 4; ++q) {      // (groups of 128 columns)
+            stage[2 * q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcH, st_voff + q * 128 * 64, col0 * 64, 0));
+            stage[2 * q + 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcH, st_voff + q * 128 * 64 + 16, col0 * 64, 0));
+        }
         if constexpr (!SIGN) stage_n = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrcN, st_noff, col0 * 4, 0));
-        const int col = col0 + (tid & (CH * 32 - 1));
-        stage_ok = col < nb && (col >> 5) < t_end;
     };
-    auto store_chunk = [&](int buf) {
-        *reinterpret_cast<f32x4 *>(&lds[buf * BUF + st_lds0]) = stage[0];
-        *reinterpret_cast<f32x4 *>(&lds[buf * BUF + st_lds1]) = stage[1];
+    // (the buffer is a compile-time choice: its offset travels in the instruction, not through the vector pipe)
+    auto store_chunk = [&](auto bufc, int c) {
+        constexpr int buf = decltype(bufc)::value;
+#pragma unroll
+        for (int q = 0; q < CH / 4; ++q) {
+            *reinterpret_cast<f32x4 *>(&lds[buf * BUF + st_lds0 + q * 128 * LR_LDS_ROW]) = stage[2 * q];
+            *reinterpret_cast<f32x4 *>(&lds[buf * BUF + st_lds1 + q * 128 * LR_LDS_ROW]) = stage[2 * q + 1];
+        }
         // x_j = n1[j]/2 ; +inf masks columns past the end of the cloud or of the strip
-        if constexpr (!SIGN) { if (tid < CH * 32) *reinterpret_cast<float *>(&lds[buf * BUF + XOFF + tid * 4]) = stage_ok ? 0.5f * stage_n : LR_INF; }
+        if constexpr (!SIGN) {
+            const int col = (t_begin + c * CH) * 32 + (tid & (CH * 32 - 1));
+            const bool ok = col < nb && (col >> 5) < t_end;
+            if (tid < CH * 32) *reinterpret_cast<float *>(&lds[buf * BUF + XOFF + tid * 4]) = ok ? 0.5f * stage_n : LR_INF;
+        }
     };
+    typedef std::integral_constant<int, 0> c0_t;
+    typedef std::integral_constant<int, 1> c1_t;
     // per-lane byte offsets of the fragment / x_j of tile 0 of the current and the other buffer; tile k adds a constant.  The lane
     // reads piece kb of columns c and 16 + c of the tile, and their x_j
     const int frag16 = lr_lds_off(c16, kb), x_lane = XOFF + c16 * 4;
-    int fo_cur = frag16, fo_oth = frag16 + BUF, xo_cur = x_lane, xo_oth = x_lane + BUF;
-    auto read_b = [&](int fo, int xo, int k, f16x8 &b0, f16x8 &b1, f32x2 &xj) {
-        b0 = *reinterpret_cast<const f16x8 *>(&lds[fo + k * 32 * LR_LDS_ROW]);
-        b1 = *reinterpret_cast<const f16x8 *>(&lds[fo + k * 32 * LR_LDS_ROW + 16 * LR_LDS_ROW]);
+    auto read_b = [&](auto bufc, int k, f16x8 &b0, f16x8 &b1, f32x2 &xj) {
+        constexpr int buf = decltype(bufc)::value;
+        b0 = *reinterpret_cast<const f16x8 *>(&lds[frag16 + buf * BUF + k * 32 * LR_LDS_ROW]);
+        b1 = *reinterpret_cast<const f16x8 *>(&lds[frag16 + buf * BUF + k * 32 * LR_LDS_ROW + 16 * LR_LDS_ROW]);
         if constexpr (!SIGN) {      // (the sign form of the test reads no per-column operand)
-            xj.x = *reinterpret_cast<const float *>(&lds[xo + k * 32 * 4]);
-            xj.y = *reinterpret_cast<const float *>(&lds[xo + k * 32 * 4 + 64]);
+            xj.x = *reinterpret_cast<const float *>(&lds[x_lane + buf * BUF + k * 32 * 4]);
+            xj.y = *reinterpret_cast<const float *>(&lds[x_lane + buf * BUF + k * 32 * 4 + 64]);
         }
     };
     int wcnt = 0;            // entries in this wave's list (wave-uniform: lives in a scalar register)
-    const unsigned code_kb = (unsigned)kb << 22;
+    const unsigned lanecode = (unsigned)c16 | ((unsigned)kb << 22);      // the lane's part of an entry: column within the 16-block | lane group
+    // The slow paths (derive(), flush(); a hit in the plain form) work out the lane's coordinates afresh: values that only they use would
+    // otherwise be kept in registers across the hot loop (or spilled to scratch memory and fetched back on every visit: +4 us per pair)
+    auto cold_lane = [&]() { int l; asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l)); return l; };
     int wdone = 0;           // ... of which the tightening has seen this many
+    int trig = LR_PB_GEO > 0 ? LR_PB_GEO : LR_PB_TIGHTEN;      // new entries that make the wave ask for a tightening round
+    // what the wave's list wants (bit 0: a tightening round, bit 1: to be emptied): recomputed where wcnt / wdone change (the slow path of
+    // a hit, derive(), flush()) -- not at every chunk -- and posted to the block only when it differs from what was posted last
+    int wposted = 0, wnext = 0;      // the wish posted last; the fill count from which the list wants something
     // The wave owns one segment of the candidate store: seg[(row block, wave, strip)][seg_cap] entries { column, code | mask }
     // exactly as they lie in its LDS list.  Emptying the list is a compacting copy with plain stores -- no atomics, nothing
     // to wait for; nn16_exact_kernel expands the masks and bins the entries by row.  seg_fill < 0: the segment overflowed
@@ -574,6 +630,9 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     uint2 *__restrict__ seg = reinterpret_cast<uint2 *>(cand) + (size_t)(bx * 4 + wave) * LR_NN16_SEG + (size_t)by * seg_cap;
     int seg_fill = 0;
     const bool tightening = thr.nQ != nullptr && !(LR_PB_EXP & 4);
+    auto my_wish = [&]() { return (wcnt >= LR_PB_WLIST / 2 ? 2 : 0) | ((tightening && wcnt - wdone >= trig) ? 1 : 0); };
+    auto set_next = [&]() { wnext = tightening ? min(wdone + trig, LR_PB_WLIST / 2) : LR_PB_WLIST / 2; };      // (my_wish() != 0 <=> wcnt >= wnext)
+    set_next();
     // One round over the new entries [wdone, wcnt) of the wave's list (wave-local).  The slow path of the walk only parks { column,
     // register group } of a hit; WHICH of the group's 8 rows passed, and with what filter value, is worked out here, 16 entries at a
     // time, by the matrix pipe itself: lane (c, kb) fetches K slice kb of the column of entry e0 + c (one 16-byte gather), four
@@ -586,6 +645,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     // y -> threshold registers.  An entry with a single row keeps its g = dot16 - x_j for the drop tests of flush() and
     // nn16_exact_kernel.
     auto derive = [&](bool update) {
+        const int lane = cold_lane(), c16 = lane & 15, kb = lane >> 4;      // (shadow the kernel's)
         const int nlist = min(wcnt, LR_PB_WLIST);
 #if LR_PB_PRIO
         __builtin_amdgcn_s_setprio(3);      // the wave's three siblings wait for it at the next chunk barrier
@@ -594,18 +654,19 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         ++n_rounds; n_groups += (nlist - wdone + 15) >> 4;
         const unsigned long long tk0 = __builtin_amdgcn_s_memrealtime();
 #endif
-        for (int e0 = wdone; e0 < nlist; e0 += 16 * LR_PB_DGROUPS) {
+        constexpr int DG = SIGN ? LR_PB_DGROUPS : (LR_PB_DGROUPS > 2 ? 2 : LR_PB_DGROUPS);      // (the plain form holds the x_j operands too: a third group would spill)
+        for (int e0 = wdone; e0 < nlist; e0 += 16 * DG) {
             // a few groups of 16 entries per pass: all their gathers are in flight before the first MFMA (one L2 latency per pass)
-            uint2 v[LR_PB_DGROUPS]; f16x8 bf[LR_PB_DGROUPS]; float xn[LR_PB_DGROUPS];
+            uint2 v[DG]; f16x8 bf[DG]; float xn[DG];
 #pragma unroll
-            for (int g = 0; g < LR_PB_DGROUPS; ++g) {
+            for (int g = 0; g < DG; ++g) {
                 v[g] = wlist[wave][min(e0 + 16 * g + c16, LR_PB_WLIST - 1)];
                 const int col = (int)(v[g].x & LR_PB_COLMASK);
                 bf[g] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrcH, col * 64 + kb * 16, 0, 0));
                 xn[g] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrcN, col * 4, 0, 0));
             }
 #pragma unroll
-            for (int g = 0; g < LR_PB_DGROUPS; ++g) {
+            for (int g = 0; g < DG; ++g) {
                 if (e0 + 16 * g >= nlist) break;              // (wave-uniform)
                 const int e = e0 + 16 * g + c16;
                 const bool valid = e < nlist;
@@ -643,6 +704,8 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
             }
         }
         wdone = nlist;
+        if (LR_PB_GEO > 0 && update) trig = min(2 * trig, LR_PB_GEO_CAP);
+        set_next();
         if (update) {
             // lane = row: y <- min(y, E' - g_need + 2e-6 |g_need|)   (g_need: the need-th largest g of the walk so far; -inf: no change)
             const int rl = wave * 64 + lane;
@@ -666,6 +729,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     };
     auto flush = [&]() {
         if (wdone < wcnt) derive(tightening);
+        const int lane = cold_lane();
 #if LR_PB_EXP & 16
         const unsigned long long tkf = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -697,7 +761,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
                 seg_fill += nk;
             }
         }
-        wcnt = 0; wdone = 0;
+        wcnt = 0; wdone = 0; set_next();
 #if LR_PB_EXP & 16
         n_tk_flush += (int)(__builtin_amdgcn_s_memrealtime() - tkf);
 #endif
@@ -738,7 +802,9 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
             if (mine_hit) {
                 const int pos = wcnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(hit >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hit, 0u));
                 // (the column is worked out here, not on the fast path: tile is wave-uniform)
-                if (pos < LR_PB_WLIST) wlist[wave][pos] = make_uint2((unsigned)(tile * 32 + cb * 16 + c16) | code_kb, 0u);
+                unsigned lc = lanecode;
+                if constexpr (!SIGN) { const int ln = cold_lane(); lc = (unsigned)(ln & 15) | ((unsigned)(ln >> 4) << 22); }      // (the plain form has no register to spare for it)
+                if (pos < LR_PB_WLIST) wlist[wave][pos] = make_uint2((unsigned)(tile * 32 + cb * 16) | lc, 0u);
             }
             wcnt += __builtin_popcountll(hit);
 #if LR_PB_EXP & 16
@@ -761,11 +827,13 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
             for (int g = 0; g < 4; ++g) acc[q][cb][g] = -LR_INF;
 
     // one pipeline step: tests of the previous tile group by group, each followed by the MFMAs of tile (c, k) into the registers just
-    // tested; LDS read of the next tile
-    auto step = [&](int c, int k) {
+    // tested; LDS read of the next tile (par = c & 1: the buffer chunk c lies in -- a compile-time value, the loop below is unrolled by
+    // two chunks so that no buffer offset is computed, swapped or selected at run time)
+    auto step = [&](int c, int k, auto parc) {
+        constexpr int par = decltype(parc)::value;
         f16x8 n0, n1; f32x2 nx;
-        if (k + 1 < CH) read_b(fo_cur, xo_cur, k + 1, n0, n1, nx);
-        else read_b(fo_oth, xo_oth, 0, n0, n1, nx);
+        if (k + 1 < CH) read_b(std::integral_constant<int, par>{}, k + 1, n0, n1, nx);
+        else read_b(std::integral_constant<int, par ^ 1>{}, 0, n0, n1, nx);
         const int tileC = t_begin + c * CH + k - 1;
 #define MF(rbk, cb, b) acc[rbk][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[rbk], b, y4[rbk], 0, 0, 0)
         // (the scheduling barriers keep the MFMAs behind the test of the registers they overwrite: hoisted above it they would need
@@ -787,45 +855,81 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         check(acc[0][1], acc[1][1], acc[2][1], acc[3][1], xC.y, tileC, 1);
     };
     if (nchunks > 0) {
-        load_chunk(0); store_chunk(0);
+        load_chunk(0); store_chunk(c0_t{}, 0);
+        if (tid == 0) s_att[0] = 0u;
         __syncthreads();
         // everything older than the prefetch below (row fragments, thresholds) is complete from here on: the loop's
         // counted waits then only ever refer to the prefetch itself
         __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
         if (nchunks > 1) load_chunk(1);
-        read_b(fo_cur, xo_cur, 0, b0, b1, xN);
+        read_b(c0_t{}, 0, b0, b1, xN);
         // The walk is a loop nest: the inner loop is the hot one and contains no tightening code (the compiler then keeps the threshold
         // registers loop-invariant and its wait counts exact); it is left whenever a hit list wants attention.
         // The four waves of a block attend to their lists TOGETHER (JOINT): a wave in derive() keeps its three siblings waiting
         // at the next chunk barrier, so 4 x ~11 rounds per block, one wave at a time, stall the block four times as often as ~12 rounds
-        // that all four take at once.  Every wave posts what its list wants (bit 0: a tightening round, bit 1: to be emptied) before the
-        // chunk barrier, reads all four wishes behind it -- the decision is block-uniform -- and acts at the end of the chunk.
+        // that all four take at once.  Every wave keeps what its list wants in one byte of an LDS word (written only when it changes),
+        // reads all four wishes behind the chunk barrier and acts at the end of the chunk.  (The decision need not be block-uniform: a wave
+        // acts on its own list only, and neither derive() nor flush() contains a barrier.)
+        // What a chunk boundary costs is the wave's own instruction stream (round 5, tools/r5_pmc_micro.sh: a wave issues one instruction
+        // per ~5 cycles whatever its class, and at three waves per SIMD it has 48 cycles per MFMA): per 32 MFMAs the boundary used to
+        // be 34 scalar + 12 vector instructions -- bounds tests, buffer parity, exec save / restore around the one-lane write, materialised
+        // booleans.  Now: the two chunks of a buffer pair are separate code (offsets are immediates), the last two chunks of the strip
+        // run as a tail with the bounds tests, and a wish is posted only when it changes.
         int c = 0;
-        while (c < nchunks) {
-            int wish = 0;
-            for (; c < nchunks && !wish; ++c) {
-                unsigned wishes = 0u;
+        int wish = 0;
+        auto chunk = [&](auto parc, auto tailc) {
+            constexpr int par = decltype(parc)::value;
+            constexpr bool tail = decltype(tailc)::value != 0;
+            unsigned wishes = 0u;
 #pragma unroll
-                for (int k = 0; k < CH; ++k) {
-                    if (k == CH - 1) {
-                        // the last step of a chunk reads the first fragment of the next one: make that chunk visible now.  All
-                        // reads of the buffer it goes to were issued before the previous barrier (the step above read this
-                        // chunk's own last tile), so one barrier per chunk still orders everything.
+            for (int k = 0; k < CH; ++k) {
+                if (k == CH - 1) {
+                    // the last step of a chunk reads the first fragment of the next one: make that chunk visible now.  All
+                    // reads of the buffer it goes to were issued before the previous barrier (the step above read this
+                    // chunk's own last tile), so one barrier per chunk still orders everything.
 #if !(LR_PB_EXP & 1)
-                        if (c + 1 < nchunks) store_chunk((c & 1) ^ 1);
-                        if constexpr (JOINT) { if (lane == 0) reinterpret_cast<unsigned char *>(&s_att[c & 1])[wave] = (unsigned char)((wcnt >= LR_PB_WLIST / 2 ? 2 : 0) | ((tightening && wcnt - wdone >= LR_PB_TIGHTEN) ? 1 : 0)); }
-                        __syncthreads();
-                        // (requested here, looked at behind the chunk's last step)
-                        if constexpr (JOINT) wishes = s_att[c & 1];
-                        if (c + 2 < nchunks) load_chunk(c + 2);
+#if !(LR_PB_EXP & 32)
+                    if (!tail || c + 1 < nchunks) store_chunk(std::integral_constant<int, par ^ 1>{}, c + 1);
 #endif
+                    if constexpr (JOINT) {
+                        // (one scalar comparison per chunk; the wish is worked out and written when the list reaches the mark; a round
+                        // follows at the end of this very chunk -- the wave reads its own byte behind the barrier -- and takes it back)
+                        if (__builtin_expect(wcnt >= wnext, 0)) {
+                            const int wm = my_wish();
+                            if (lane == 0) reinterpret_cast<unsigned char *>(&s_att[0])[wave] = (unsigned char)wm;
+                            wposted = wm; wnext = 0x7fffffff;
+                        }
                     }
-                    step(c, k);
+#if !(LR_PB_EXP & 64)
+                    __syncthreads();
+#endif
+                    // (requested here, looked at behind the chunk's last step)
+                    if constexpr (JOINT) wishes = s_att[0];
+#if !(LR_PB_EXP & 32)
+                    if (!tail || c + 2 < nchunks) load_chunk(c + 2);
+#endif
+#endif
                 }
-                { const int t0 = fo_cur; fo_cur = fo_oth; fo_oth = t0; const int t1 = xo_cur; xo_cur = xo_oth; xo_oth = t1; }
-                if constexpr (JOINT) { const unsigned w = __builtin_amdgcn_readfirstlane(wishes); wish = (w & 0x02020202u) ? 2 : (w ? 1 : 0); }
-                else wish = (wcnt >= LR_PB_WLIST / 2 ? 2 : 0) | ((tightening && wcnt - wdone >= LR_PB_TIGHTEN) ? 1 : 0);
+                step(c, k, parc);
             }
+            // (the four bytes as they are: which bit is set is looked at outside the loop)
+            if constexpr (JOINT) wish = (int)__builtin_amdgcn_readfirstlane(wishes);
+            else wish = wcnt >= wnext ? my_wish() : 0;
+            ++c;
+        };
+        typedef std::integral_constant<int, 0> body_t;
+        typedef std::integral_constant<int, 1> tail_t;
+        while (c < nchunks) {
+            wish = 0;
+            // The hot loop takes two chunks per iteration, buffer 0 then buffer 1, as straight-line code (`body`: chunks c + 1 and c + 2
+            // exist, nothing is tested).  An odd chunk on its own -- the walk resumes at one after a round, or it is the strip's last --
+            // and the last two chunks of the strip run through the `tail` form with the bounds tests.
+            if (c & 1) chunk(c1_t{}, tail_t{});
+            else if (c + 3 < nchunks) {
+                do { chunk(c0_t{}, body_t{}); if (wish) break; chunk(c1_t{}, body_t{}); } while (!wish && c + 3 < nchunks);
+            } else chunk(c0_t{}, tail_t{});
+            if constexpr (JOINT) wish = (wish & 0x02020202) ? 2 : (wish ? 1 : 0);
+            if constexpr (JOINT) { if (wish && wposted) { if (lane == 0) reinterpret_cast<unsigned char *>(&s_att[0])[wave] = 0; wposted = 0; } }
             if (wish & 2) flush();
             else if (wish) { if (wdone < wcnt) derive(true); }
         }

@@ -83,6 +83,9 @@ def test_config4_100k_point_clouds(lr, oracle):
     o1, o2, os1, os2 = oracle.nn_top2(p["feats0"][rows], p["feats1"])
     assert np.array_equal(i1[rows], o1) and np.array_equal(i2[rows], o2)
     assert np.array_equal(s1[rows].view(np.uint32), os1.view(np.uint32)) and np.array_equal(s2[rows].view(np.uint32), os2.view(np.uint32))
+    # ... and against the REFERENCE's find_nn on a fixed 1 800-row slice of this pair (tests/golden/make_golden_full.py)
+    g = golden("g13_slice_100k.npz")
+    assert np.array_equal(i1[g["rows"]], g["idx1"]) and np.array_equal(i2[g["rows"]], g["idx2"])
     a = Args(mode="MNN", codebase="open3D", iters=50000, ransac_n=3, o3d_conf=1.0)
     t = lr.torch.from_numpy
     T, _, _, _, n_init, ir_init, n_filt, ir_filt = lr.FR.FR(t(p["xyz0"]), t(p["xyz1"]), t(p["feats0"]), t(p["feats1"]), a, p["T_gt"])
@@ -100,3 +103,6 @@ def test_config4_100k_point_clouds(lr, oracle):
             assert member.get(j) == i
         else:
             assert j not in member
+    # the reference's reverse neighbours of 800 fixed cloud-1 points decide their membership the same way
+    for j, i in zip(g["cols"].tolist(), g["rev_idx1"].tolist()):
+        assert (member.get(j) == i) if i1[i] == j else (j not in member)

@@ -86,6 +86,23 @@ def test_nn_full_size_30k(lr, oracle):
     o1, o2, os1, os2 = oracle.nn_top2(p["feats0"], p["feats1"])
     assert np.array_equal(i1.cpu().numpy(), o1) and np.array_equal(i2.cpu().numpy(), o2)
     assert np.array_equal(_bits(s1.cpu().numpy()), _bits(os1))
+    # ... and against the REFERENCE itself at this size (tests/golden/make_golden_full.py: matching.py find_2nn / nn_to_mutual /
+    # calc_distance_ratio_in_feature_space / Grid_Prioritized_Filter run on this very pair)
+    g = golden("g12_full_30k.npz")
+    assert np.array_equal(i1.cpu().numpy(), g["idx1"]) and np.array_equal(i2.cpu().numpy(), g["idx2"])
+    t = lr.torch.from_numpy
+    F0, F1 = t(p["feats0"]), t(p["feats1"])
+    i0 = lr.torch.arange(30000)
+    m0, m1, m2 = lr.matching.nn_to_mutual(F0, F1, i0, i1.cpu().long(), i2.cpu().long())
+    assert len(m0) == 15794
+    assert np.array_equal(m0.numpy(), g["mnn_idx0"]) and np.array_equal(m1.numpy(), g["mnn_idx1"]) and np.array_equal(m2.numpy(), g["mnn_idx2"])
+    r = lr.matching.calc_distance_ratio_in_feature_space(F0, F1, m0, m1, m2).cpu().numpy()
+    np.testing.assert_allclose(r, g["mnn_ratio"], rtol=2e-6, atol=0)
+    from tests.test_oracle_golden import prosac_order_consistent
+    assert prosac_order_consistent(oracle.prosac_order(r), g["mnn_ratio"], g["mnn_prosac_order"])
+    for tag, factor in (("gpf20", 2.0), ("gpf05", 0.5)):
+        k = lr.matching.Grid_Prioritized_Filter(F0, F1, i0, i1.cpu().long(), i2.cpu().long(), t(p["xyz0"]), Args(GPF_factor=factor))
+        assert np.array_equal(k[0].numpy(), g[f"{tag}_idx0"]) and np.array_equal(k[1].numpy(), g[f"{tag}_idx1"])
 
 
 # ----------------------------------------------------------------------------- mutual / ratio / GPF (a3-a7)
@@ -529,6 +546,13 @@ def test_FR_gpf_full_size(lr, oracle):
     e = oracle.register_pair(p["xyz0"], p["xyz1"], p["feats0"], p["feats1"], mode="GPF", iters=20000, seed=51, args=a, **gc_oracle_kwargs(a))
     assert n_filt == len(e["idx0"]) and n_filt < n_init
     assert np.radians(oracle.rotation_error_deg(T, e["T"])) <= 1e-4 and oracle.translation_error_cm(T, e["T"]) / 100 <= 1e-3
+    # the reference's own GPF list of this pair (tests/golden/make_golden_full.py): what FR() filtered down to, and the standalone call
+    g = golden("g12_full_30k.npz")
+    assert n_filt == len(g["c52_gpf05_idx0"]) and np.array_equal(e["idx0"], g["c52_gpf05_idx0"]) and np.array_equal(e["idx1"], g["c52_gpf05_idx1"])
+    i0, i1, i2, _ = lr.matching.find_2nn(t(p["feats0"]), t(p["feats1"]))
+    assert np.array_equal(i1.numpy(), g["c52_idx1"])
+    k = lr.matching.Grid_Prioritized_Filter(t(p["feats0"]), t(p["feats1"]), i0, i1, i2, t(p["xyz0"]), a)
+    assert np.array_equal(k[0].numpy(), g["c52_gpf05_idx0"]) and np.array_equal(k[1].numpy(), g["c52_gpf05_idx1"])
 
 
 @pytest.mark.parametrize("conf,batch", [(0.999, 0), (0.999, 1024), (0.9, 512), (0.999999, 2048)])

@@ -168,3 +168,62 @@ def test_sparse_quantize_restatement_properties(oracle):
         seen.setdefault(k, i)
     assert sorted(seen.values()) == sel.tolist()
     assert not np.isin(np.arange(5000, 5200), sel).any() or (np.floor(xyz[5000:5200] / 0.3) != np.floor(xyz[100:300] / 0.3)).any()
+
+
+# ------------------------------------------------------------------ full size: the configurations BASELINE.json names
+# (tests/golden/make_golden_full.py: the reference's own functions run on configs[1]'s 30 000-point pair and on a slice of
+# configs[4]'s 100 000-point pair)
+def prosac_order_consistent(order, ref_ratio, ref_order, rtol=4e-6):
+    """`order` (ascending argsort of OUR ratio) against the reference's: a permutation that sorts the reference's ratios up to the
+    2e-6 relative difference between the two ratio computations, and identical wherever the neighbouring values are further apart."""
+    order = np.asarray(order).astype(np.int64); ref_order = np.asarray(ref_order).astype(np.int64)
+    if not np.array_equal(np.sort(order), np.arange(len(ref_order))):
+        return False
+    v = ref_ratio[order].astype(np.float64)
+    if not np.all(v[1:] >= v[:-1] * (1 - rtol)):
+        return False
+    diff = np.nonzero(order != ref_order)[0]
+    vs = ref_ratio[ref_order].astype(np.float64)
+    near = np.zeros(len(vs), bool)
+    gap = vs[1:] - vs[:-1] <= rtol * vs[1:]
+    near[1:] |= gap; near[:-1] |= gap
+    return bool(np.all(near[diff]))
+
+
+def test_g12_full_size_30k_pair_matches_reference(oracle):
+    g = golden("g12_full_30k.npz")
+    N, seed = [int(v) for v in g["shape"]]
+    p = synth.make_pair(N=N, seed=seed)
+    i0, i1, i2, _ = oracle.find_2nn(p["feats0"], p["feats1"])
+    assert np.array_equal(i1, g["idx1"]) and np.array_equal(i2, g["idx2"])          # all 30 000 first and second neighbours
+    m0, m1, m2 = oracle.nn_to_mutual(p["feats0"], p["feats1"], i0, i1, i2)
+    assert len(m0) == 15794
+    assert np.array_equal(m0, g["mnn_idx0"]) and np.array_equal(m1, g["mnn_idx1"]) and np.array_equal(m2, g["mnn_idx2"])
+    r = oracle.calc_distance_ratio_in_feature_space(p["feats0"], p["feats1"], m0, m1, m2)
+    np.testing.assert_allclose(r, g["mnn_ratio"], rtol=2e-6, atol=0)
+    assert prosac_order_consistent(oracle.prosac_order(r), g["mnn_ratio"], g["mnn_prosac_order"])
+    for tag, factor in (("gpf20", 2.0), ("gpf05", 0.5)):
+        a = Args(GPF_factor=factor)
+        k = oracle.Grid_Prioritized_Filter(p["feats0"], p["feats1"], i0, i1, i2, p["xyz0"], a)
+        assert np.array_equal(k[0], g[f"{tag}_idx0"]) and np.array_equal(k[1], g[f"{tag}_idx1"])
+    assert len(g["gpf05_idx0"]) < len(g["gpf20_idx0"]) == N
+
+
+def test_g12_clustered_30k_gpf_matches_reference(oracle):
+    g = golden("g12_full_30k.npz")
+    N, seed = [int(v) for v in g["c52_shape"]]
+    p = synth.make_pair(N=N, seed=seed, clustered=True)
+    i0, i1, i2, _ = oracle.find_2nn(p["feats0"], p["feats1"])
+    assert np.array_equal(i1, g["c52_idx1"])
+    k = oracle.Grid_Prioritized_Filter(p["feats0"], p["feats1"], i0, i1, i2, p["xyz0"], Args(GPF_factor=0.5))
+    assert np.array_equal(k[0], g["c52_gpf05_idx0"]) and np.array_equal(k[1], g["c52_gpf05_idx1"])
+
+
+def test_g13_100k_slice_matches_reference(oracle):
+    g = golden("g13_slice_100k.npz")
+    N, seed = [int(v) for v in g["shape"]]
+    p = synth.make_pair(N=N, seed=seed)
+    o1, o2, _, _ = oracle.nn_top2(p["feats0"][g["rows"]], p["feats1"])
+    assert np.array_equal(o1, g["idx1"]) and np.array_equal(o2, g["idx2"])
+    r1, _, _, _ = oracle.nn_top2(p["feats1"][g["cols"]], p["feats0"])
+    assert np.array_equal(r1, g["rev_idx1"])

@@ -16,6 +16,7 @@
 #define PB_BMIN_ARG(p) (float *)((char *)bmin + (p) * stride),
 #define PB_NEW_ABI 1
 #endif
+#include <string.h>
 #include <vector>
 #include <algorithm>
 #include <random>
@@ -81,8 +82,10 @@ int main(int argc, char **argv)
     dim3 grid(8 * ((total + 7) / 8));
     const int tps = (ntiles + strips - 1) / strips;
     printf("EXP=%d TIGHTEN=%d n=%d P=%d strips=%d blocks=%d\n", LR_PB_EXP, LR_PB_TIGHTEN, n, P, strips, total);
+    const bool only_nohit = getenv("PB_ONLY") && !strcmp(getenv("PB_ONLY"), "nohit");      // (counter runs: only the candidate-free walk on real accumulators is repeated)
     for (int need : {2, 1})
     for (int sstride : {2, 4, 8, 16, 32, 64}) {
+        if (only_nohit) break;
         PB_THR(thr, nrm, need, sstride);
         static char *s_ysh, *s_arr; static size_t s_stride; static int s_P, s_n; s_ysh = (char *)ysh; s_arr = (char *)arr; s_stride = stride; s_P = P; s_n = n;
         g_pre = [] { for (int p = 0; p < s_P; ++p) { hipMemsetD32Async((hipDeviceptr_t)(s_ysh + p * s_stride), 0xff800000u, s_n, 0); hipMemsetD32Async((hipDeviceptr_t)(s_arr + p * s_stride), 0, s_n / 256 + 2, 0); } };
@@ -122,7 +125,7 @@ int main(int argc, char **argv)
         for (int p = 0; p < P; ++p) hipMemcpy((char *)tau + p * stride, t.data(), (size_t)n * 4, hipMemcpyHostToDevice);
         auto run = [&] { PB_LAUNCH(grid, dim3(256), 0, 0, H, n, (const int32_t*)nullptr, (const int32_t*)nullptr, H, nrm, n, tps, (const float*)tau, cnt, cand,
                                             (const int32_t*)nullptr, (const float*)nullptr, (const uint32_t*)nullptr, (const int32_t*)nullptr, (const uint32_t*)nullptr, (float*)nullptr, 0, PB_YS thr0, lr_pb_grid{ row_blocks, strips, total, 0 }, z); };
-        float msp = timeit([&] { run(); });
+        float msp = only_nohit ? 0.0f : timeit([&] { run(); });
         const int nseg = row_blocks * 4 * (strips + 1);
         std::vector<int32_t> c1(nseg); hipMemcpy(c1.data(), cnt, (size_t)nseg * 4, hipMemcpyDeviceToHost);
         double tot = 0; for (int i = 0; i < nseg; ++i) if (i % (strips + 1) != strips && c1[i] > 0) tot += c1[i];
@@ -135,7 +138,7 @@ int main(int argc, char **argv)
         printf("walk only, final thresholds - 0.5 (no hits, real accumulators): %8.3f ms  = %6.1f us/pair\n", msp, msp * 1e3 / P);
         print_clk(total);
     }
-    {
+    if (!only_nohit) {
         std::vector<float> t(n, -1e30f);
         for (int p = 0; p < P; ++p) hipMemcpy((char *)tau + p * stride, t.data(), (size_t)n * 4, hipMemcpyHostToDevice);
         float msp = timeit([&] { PB_LAUNCH(grid, dim3(256), 0, 0, H, n, (const int32_t*)nullptr, (const int32_t*)nullptr, H, nrm, n, tps, (const float*)tau, cnt, cand,
