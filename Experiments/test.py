@@ -1,7 +1,7 @@
 """CLI with the reference's surface (Experiments/test.py:273-353): run from this directory as
 
     python -m test --dataset A --algo RANSAC --mode GPF --iters 50000
-    ./test_parallel.sh --dataset B --algo RANSAC --mode MNN --iters 1000000 --GC_conf 0.9995
+    ./test_parallel.sh --dataset B --algo RANSAC --mode MNN --iters 1000000 --GC_conf 0.9995      (= python -m test launch ...)
 
 Same flags and defaults for the RANSAC path, same `test_parallel <start_time> <tmp_base> <world> <rank|analysis>` protocol,
 same outputs (`outputs/<dataset>.Test.<time>/{raw_stats.npy,log.txt}`) plus `coarse_motions.txt` (format of
@@ -149,7 +149,37 @@ def analyze_stats(args):
     return stats
 
 
+def launch(argv):
+    """`python -m test launch <flags>` (= ./test_parallel.sh <flags>): one rank per GPU over the positional protocol
+    `test_parallel <start_time> <tmp_base> <world> <rank>` (Experiments/test.py:275-285 of the reference), then the analysis pass in
+    this process.  All ranks are watched (lidarregistration_amd.launch.run_ranks): when one dies the others are stopped, the partial
+    files are removed and NO analysis is run -- the exit code is the failed rank's."""
+    from lidarregistration_amd import launch as L
+    gpus = L.gpu_list()
+    if not gpus:
+        sys.exit("no GPU visible (set LIDARREG_GPUS to choose devices)")
+    world = len(gpus)
+    start_time = datetime.datetime.now().strftime("%Y%m%d_%H_%M_%S")
+    fd, base = tempfile.mkstemp(prefix="lidarreg_ranks_")
+    os.close(fd)
+    here = os.path.dirname(os.path.abspath(__file__))
+    cmds = [[sys.executable, "-m", "test", "test_parallel", start_time, base, str(world), str(r)] + list(argv) for r in range(world)]
+    pp = here + (os.pathsep + os.environ["PYTHONPATH"] if os.environ.get("PYTHONPATH") else "")
+    rc = L.run_ranks(cmds, [dict(HIP_VISIBLE_DEVICES=str(g), PYTHONPATH=pp) for g in gpus])
+    try:
+        if rc != 0:
+            logging.error("a rank failed (exit code %d): the other ranks were stopped, no analysis", rc)
+            sys.exit(rc)
+        return main(["test_parallel", start_time, base, str(world), "analysis"] + list(argv))
+    finally:
+        for f in glob(base + "*"):
+            os.remove(f)
+
+
 def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    if argv and argv[0] == "launch":
+        return launch(argv[1:])
     args = get_args(argv)
     logging.info("Starting")
     if args.rank is not None:

@@ -1,21 +1,4 @@
-#! /bin/bash
-# One process per GPU, pairs sharded round-robin, results merged by the analysis pass
-# (same protocol as the reference's Experiments/test_parallel.sh; GPUs are enumerated through torch instead of nvidia-smi).
-if [ -n "$LIDARREG_GPUS" ]; then
-	gpu_inds=( $LIDARREG_GPUS )
-else
-	n_gpus_in_system=$(python -c "import torch; print(torch.cuda.device_count())")
-	let max_gpu_ind=$n_gpus_in_system-1
-	gpu_inds=($(seq 0 $max_gpu_ind))
-fi
-n_gpus=${#gpu_inds[@]}
-
-file_base=$(mktemp)
-start_time=$(date '+%Y%m%d_%H_%M_%S')
-for i in ${!gpu_inds[@]}; do
-  HIP_VISIBLE_DEVICES=${gpu_inds[$i]} python -m test test_parallel $start_time $file_base $n_gpus ${i} "$@" &
-done
-
-wait < <(jobs -p)
-
-python -m test test_parallel $start_time $file_base $n_gpus analysis "$@"
+#!/bin/bash
+# Kept under the reference's name for its README command (`./test_parallel.sh --dataset B ...`); everything happens in
+# `python -m test launch`: one rank per GPU (LIDARREG_GPUS="0 1 ..." picks devices), every rank watched, analysis only if all succeed.
+PYTHONPATH="$(cd "$(dirname "$0")" && pwd)${PYTHONPATH:+:$PYTHONPATH}" exec python -m test launch "$@"

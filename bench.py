@@ -74,36 +74,14 @@ def parse(argv=None):
 # ----------------------------------------------------------------------------- self-launch (no torch.distributed.run)
 def spawn_ranks(args):
     """`python bench.py --gpus N` with no rendezvous environment: start one child per GPU (the launch shape of the
-    reference's test_parallel.sh:18-24) and wait.  The parent never touches HIP (no torch.cuda call, no exec after init)."""
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    rc = 0
-    try:
-        # poll ALL children: a rank that dies during init would otherwise leave the parent waiting on rank 0 until the collective's
-        # timeout; the first non-zero exit ends the run and the remaining ranks are killed
-        live = list(procs)
-        while live and rc == 0:
-            for p in list(live):
-                r = p.poll()
-                if r is not None:
-                    live.remove(p)
-                    rc = max(rc, abs(r))
-            if live and rc == 0:
-                time.sleep(0.05)
-    finally:
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
-        for p in procs:
-            try:
-                p.wait(timeout=10)
-            except Exception:
-                pass
-    return rc
+    reference's test_parallel.sh:18-24) and wait.  The parent never touches HIP (no torch.cuda call, no exec after init);
+    lidarregistration_amd.launch.run_ranks polls ALL children: a rank that dies during init would otherwise leave the parent waiting
+    on rank 0 until the collective's timeout; the first non-zero exit ends the run and the remaining ranks are killed."""
+    from lidarregistration_amd import launch
+    port = launch.free_port()
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    envs = [dict(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)) for r in range(args.gpus)]
+    return launch.run_ranks([cmd] * args.gpus, envs)
 
 
 # ----------------------------------------------------------------------------- helpers

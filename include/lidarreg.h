@@ -38,6 +38,8 @@ typedef struct lr_workspace lr_workspace;
 /* RANSAC knobs.  Replaces the parameter dict of GC_RANSAC.py:12-37 and the keyword arguments of
  * FR.py:128-137, with explicit flags instead of the reference's sentinel overloading.            */
 typedef struct lr_ransac_params {
+    uint32_t struct_size;   /* = sizeof(lr_ransac_params) of the header the caller was built against; every entry point that
+                               takes the struct checks it first and returns LR_EINVAL on a mismatch (lr_version 102)   */
     int32_t  sample_size;   /* 3 = GC-RANSAC minimal solver, 4 = FR.py:134 ransac_n                  */
     int32_t  use_elc;       /* pre-verification (--fast_rejection, GC_RANSAC.py:29-34): 0 none; 1 edge-length check of the
                                sample, similarity 0.9 (preemption_edge_length.h:82); 2 SPRT on the estimated model
@@ -119,6 +121,7 @@ typedef struct lr_pair_result {
 } lr_pair_result;
 
 typedef struct lr_pair_params {
+    uint32_t struct_size;   /* = sizeof(lr_pair_params), checked like lr_ransac_params.struct_size (which must be set too) */
     int32_t  mode;          /* LR_MODE_*                                                             */
     int32_t  refit;         /* 0 none; 1: LS refit on the ORIGINAL NN pairs within thr (FR.py:99-111, codebase open3D);
                                2: on the FILTERED pairs RANSAC ran on (GC-RANSAC's final least squares over its inliers);
@@ -133,10 +136,10 @@ typedef struct lr_pair_params {
 } lr_pair_params;
 
 /* ---- library ------------------------------------------------------------------------------- */
-LR_API int         lr_version(void);    /* 100 * major + minor; 101: lr_ransac_params 64 bytes / lr_pair_params 96 bytes (round 3), lr_icp_batch */
+LR_API int         lr_version(void);    /* 100 * major + minor; 102: params structs start with struct_size (72 / 112 bytes), descriptors of 1..32 dimensions; 101: lr_ransac_params 64 bytes / lr_pair_params 96 bytes (round 3), lr_icp_batch */
 LR_API const char *lr_last_error(void);
 
-/* Scratch for clouds up to (max_n0, max_n1) points x dim and up to max_iters hypotheses. */
+/* Scratch for clouds up to (max_n0, max_n1) points x dim (1 <= dim <= 32; matching.py:22-65 takes any width) and up to max_iters hypotheses. */
 LR_API int    lr_workspace_create(lr_workspace **ws, int max_n0, int max_n1, int dim, int max_iters);
 /* The same for up to max_pairs (<= 64) pairs registered by ONE call of lr_register_batch: max_pairs arenas of identical
  * layout in one allocation.  The single-pair entry points below work on such a workspace too (they use arena 0).        */

@@ -32,10 +32,14 @@ class LidarRegError(RuntimeError):
 
 
 class RansacParams(ctypes.Structure):
-    _fields_ = [("sample_size", ctypes.c_int32), ("use_elc", ctypes.c_int32), ("thr2", ctypes.c_float),
+    """lr_ransac_params.  Positional arguments start at sample_size: struct_size (the first field of the C struct) is filled in."""
+    _fields_ = [("struct_size", ctypes.c_uint32), ("sample_size", ctypes.c_int32), ("use_elc", ctypes.c_int32), ("thr2", ctypes.c_float),
                 ("iters", ctypes.c_int32), ("seed", ctypes.c_uint64), ("confidence", ctypes.c_float), ("batch", ctypes.c_int32),
                 ("sampler", ctypes.c_int32), ("prosac_growth", ctypes.c_int32), ("scoring", ctypes.c_int32), ("local_opt", ctypes.c_int32),
                 ("lo_rounds", ctypes.c_int32), ("lo_trials", ctypes.c_int32), ("lo_max_calls", ctypes.c_int32), ("min_iters", ctypes.c_int32)]
+
+    def __init__(self, *args, **kw):
+        super().__init__(ctypes.sizeof(type(self)), *args, **kw)
 
     def effective_thr2(self):
         """The squared threshold the estimator really tests inliers against: scoring 2 (MSAC as GC-RANSAC runs it) uses the
@@ -60,12 +64,18 @@ class PairResult(ctypes.Structure):
 
 
 class PairParams(ctypes.Structure):
-    _fields_ = [("mode", ctypes.c_int32), ("refit", ctypes.c_int32), ("ransac", RansacParams),
+    """lr_pair_params.  struct_size (here and in the nested lr_ransac_params) is filled in."""
+    _fields_ = [("struct_size", ctypes.c_uint32), ("mode", ctypes.c_int32), ("refit", ctypes.c_int32), ("ransac", RansacParams),
                 ("gpf_grid_wid", ctypes.c_int32), ("icp", ctypes.c_int32), ("gpf_factor", ctypes.c_double),
                 ("refit_thr2", ctypes.c_double)]
 
+    def __init__(self, *args, **kw):
+        super().__init__(ctypes.sizeof(type(self)), *args, **kw)
+        if self.ransac.struct_size == 0:
+            self.ransac.struct_size = ctypes.sizeof(RansacParams)
 
-assert ctypes.sizeof(PairResult) == 496, ctypes.sizeof(PairResult)
+
+assert ctypes.sizeof(PairResult) == 496 and ctypes.sizeof(RansacParams) == 72 and ctypes.sizeof(PairParams) == 112
 
 _lib = None
 

@@ -16,10 +16,10 @@ void lr_set_error(const char *fmt, ...)
     va_end(ap);
 }
 
-static_assert(sizeof(lr_ransac_params) == 64 && sizeof(lr_pair_params) == 96 && sizeof(lr_pair_result) == 496,
+static_assert(sizeof(lr_ransac_params) == 72 && sizeof(lr_pair_params) == 112 && sizeof(lr_pair_result) == 496,
               "ABI structs changed: update include/lidarreg.h, _ext.py, INTEGRATION.md and tests/test_abi_cpu.py together");
 
-extern "C" int lr_version(void) { return 101; }
+extern "C" int lr_version(void) { return 102; }
 extern "C" const char *lr_last_error(void) { return g_err; }
 
 // ------------------------------------------------------------------ workspace
@@ -41,6 +41,7 @@ void carve(lr_workspace *ws, Carver &c)
     const size_t n0 = ws->max_n0, n1 = ws->max_n1, n = ws->max_n, it = ws->max_iters;
     ws->nrm0 = c.take<float>(n0); ws->nrm1 = c.take<float>(n1);
     ws->H0 = c.take<_Float16>(n0 * 32); ws->H1 = c.take<_Float16>(n1 * 32);
+    if (ws->dim != LR_FEAT_DIM) { ws->P0 = c.take<float>(n0 * 32); ws->P1 = c.take<float>(n1 * 32); }
     ws->tau = c.take<float>(n);
     ws->yfin = c.take<float>(n * LR_NN_MAX_STRIPS);
     ws->yshare = c.take<uint32_t>(n);
@@ -101,7 +102,7 @@ extern "C" int lr_workspace_create_batch(lr_workspace **out, int max_pairs, int 
     LR_REQUIRE(out, LR_EINVAL, "lr_workspace_create: null output");
     LR_REQUIRE(max_pairs >= 1 && max_pairs <= LR_MAX_BATCH, LR_EINVAL, "lr_workspace_create_batch: max_pairs must be in [1, 64]");
     LR_REQUIRE(max_n0 > 0 && max_n1 > 0 && max_iters >= 0, LR_EINVAL, "lr_workspace_create: sizes must be positive");
-    LR_REQUIRE(dim == LR_FEAT_DIM, LR_EINVAL, "lr_workspace_create: only 32-d descriptors (FCGF) are supported");
+    LR_REQUIRE(dim >= 1 && dim <= LR_FEAT_DIM, LR_EINVAL, "lr_workspace_create: descriptors of 1 to 32 dimensions are supported");
     LR_REQUIRE(max_n0 < (1 << 22) && max_n1 < (1 << 22), LR_ESIZE, "lr_workspace_create: clouds are limited to 2^22 points");
     lr_workspace *ws = new (std::nothrow) lr_workspace();
     LR_REQUIRE(ws, LR_ENOMEM, "lr_workspace_create: host allocation failed");
@@ -302,6 +303,64 @@ static int check_nn_args(const lr_workspace *ws, const void *F0, int n0, const v
 
 #define LR_TRY(x) do { int rc_ = (x); if (rc_ != LR_OK) return rc_; } while (0)
 
+// The params structs start with their own size: a caller built against another version of include/lidarreg.h is turned away instead
+// of having a shorter struct read past its end (lr_version 102)
+static int check_ransac_params(const lr_ransac_params *p, const char *who)
+{
+    if (!p) { lr_set_error("%s: null params", who); return LR_EINVAL; }
+    if (p->struct_size != sizeof(lr_ransac_params)) {
+        lr_set_error("%s: lr_ransac_params.struct_size is %u, this library (lr_version %d) expects %zu -- set it to sizeof(lr_ransac_params) / rebuild against include/lidarreg.h",
+                     who, p->struct_size, lr_version(), sizeof(lr_ransac_params));
+        return LR_EINVAL;
+    }
+    return LR_OK;
+}
+static int check_pair_params(const lr_pair_params *p, const char *who)
+{
+    if (!p) { lr_set_error("%s: null params", who); return LR_EINVAL; }
+    if (p->struct_size != sizeof(lr_pair_params)) {
+        lr_set_error("%s: lr_pair_params.struct_size is %u, this library (lr_version %d) expects %zu -- set it to sizeof(lr_pair_params) / rebuild against include/lidarreg.h",
+                     who, p->struct_size, lr_version(), sizeof(lr_pair_params));
+        return LR_EINVAL;
+    }
+    return check_ransac_params(&p->ransac, who);
+}
+
+// Descriptors narrower than 32 (matching.py:22-65 is dimension-agnostic; FCGF_FAST/net/BBR_F.py:148-176 calls it with D = 3): zero-padded
+// fp32 copies in the workspace, and everything downstream runs 32 wide on them.  A zero term changes neither the fma chains of the
+// arithmetic contract (fma(0, 0, acc) == acc) nor the ratio's sum of squared differences: results are bit-identical to the dim-wide
+// definitions (the oracle's).  One thread per element, rows of the input `dim` floats apart (no alignment assumed).
+__global__ void __launch_bounds__(256)
+pad_feats_kernel(const float *__restrict__ Fa, int na, float *__restrict__ Pa, const float *__restrict__ Fb, int nb, float *__restrict__ Pb,
+                 int dim, int nblk_a, lr_zargs z)
+{
+    if (z.descs) { const lr_pair_desc d = z.descs[blockIdx.z]; Fa = d.F0; na = d.n0; Fb = d.F1; nb = d.n1; }
+    lr_z(Pa, z, blockIdx.z); lr_z(Pb, z, blockIdx.z);
+    const bool second = (int)blockIdx.x >= nblk_a;
+    const float *__restrict__ F = second ? Fb : Fa;
+    float *__restrict__ P = second ? Pb : Pa;
+    const int n = second ? nb : na;
+    const int row = (second ? blockIdx.x - nblk_a : blockIdx.x) * 8 + (threadIdx.x >> 5), k = threadIdx.x & 31;
+    if (row < n) P[(size_t)row * 32 + k] = k < dim ? F[(size_t)row * dim + k] : 0.0f;
+}
+// (a batched call's descriptor table then names the padded copies: every later kernel reads its inputs through it)
+__global__ void pad_patch_descs_kernel(lr_pair_desc *__restrict__ descs, int npairs, float *P0, float *P1, size_t stride)
+{
+    const int k = threadIdx.x;
+    if (k < npairs) {
+        descs[k].F0 = reinterpret_cast<const float *>(reinterpret_cast<const char *>(P0) + (size_t)k * stride);
+        descs[k].F1 = reinterpret_cast<const float *>(reinterpret_cast<const char *>(P1) + (size_t)k * stride);
+    }
+}
+static void pad_if_narrow(lr_workspace *ws, const float *&F0, int n0, const float *&F1, int n1, int &dim, hipStream_t st)
+{
+    if (dim == LR_FEAT_DIM) return;
+    const int nblk_a = lr_cdiv(n0, 8);
+    hipLaunchKernelGGL(pad_feats_kernel, dim3(nblk_a + lr_cdiv(n1, 8), 1, ws->zP), dim3(256), 0, st, F0, n0, ws->P0, F1, n1, ws->P1, dim, nblk_a, ws->z);
+    if (ws->z.descs) hipLaunchKernelGGL(pad_patch_descs_kernel, dim3(1), dim3(64), 0, st, ws->descs, ws->zP, ws->P0, ws->P1, ws->stride);
+    F0 = ws->P0; F1 = ws->P1; dim = LR_FEAT_DIM;
+}
+
 // norms + f16 operand copies of both clouds
 static int prep_both(lr_workspace *ws, const float *F0, int n0, const float *F1, int n1, hipStream_t st, bool zero_counters = false)
 {
@@ -332,6 +391,7 @@ extern "C" int lr_nn_top2(lr_workspace *ws, const float *F0, int n0, const float
     LR_TRY(check_nn_args(ws, F0, n0, F1, n1, dim, "lr_nn_top2"));
     LR_REQUIRE(idx1, LR_EINVAL, "lr_nn_top2: idx1 is required");
     hipStream_t st = (hipStream_t)stream;
+    pad_if_narrow(ws, F0, n0, F1, n1, dim, st);
     LR_TRY(prep_both(ws, F0, n0, F1, n1, st));
     return nn_forward(ws, F0, n0, F1, n1, idx1, idx2, s1, s2, st);
 }
@@ -344,6 +404,7 @@ extern "C" int lr_nn_to_mutual(lr_workspace *ws, const float *F0, int n0, const 
     LR_TRY(check_nn_args(ws, F0, n0, F1, n1, dim, "lr_nn_to_mutual"));
     LR_REQUIRE(idx1, LR_EINVAL, "lr_nn_to_mutual: idx1 is required");
     hipStream_t st = (hipStream_t)stream;
+    pad_if_narrow(ws, F0, n0, F1, n1, dim, st);
     LR_TRY(prep_both(ws, F0, n0, F1, n1, st));
     LR_TRY(nn_reverse(ws, F0, n0, F1, n1, idx1, ws->rev_idx1, st));
     return lr_mutual_run(ws, n0, idx1, idx2, ws->rev_idx1, is_bb, o0, o1, o2, n_out, st);
@@ -357,6 +418,7 @@ extern "C" int lr_gpf(lr_workspace *ws, const float *F0, int n0, const float *F1
     LR_TRY(check_nn_args(ws, F0, n0, F1, n1, dim, "lr_gpf"));
     LR_REQUIRE(idx1 && idx2 && xyz0 && o0 && o1, LR_EINVAL, "lr_gpf: null pointer");
     hipStream_t st = (hipStream_t)stream;
+    pad_if_narrow(ws, F0, n0, F1, n1, dim, st);
     LR_TRY(prep_both(ws, F0, n0, F1, n1, st));
     LR_TRY(nn_reverse(ws, F0, n0, F1, n1, idx1, ws->rev_idx1, st));
     LR_TRY(lr_mutual_run(ws, n0, idx1, nullptr, ws->rev_idx1, ws->is_bb, nullptr, nullptr, nullptr, nullptr, st));
@@ -372,6 +434,7 @@ extern "C" int lr_gpf_bb_first(lr_workspace *ws, const float *F0, int n0, const 
     LR_TRY(check_nn_args(ws, F0, n0, F1, n1, dim, "lr_gpf_bb_first"));
     LR_REQUIRE(idx1 && idx2 && xyz0 && o0 && o1 && o2 && n_out && has_score, LR_EINVAL, "lr_gpf_bb_first: null pointer");
     hipStream_t st = (hipStream_t)stream;
+    pad_if_narrow(ws, F0, n0, F1, n1, dim, st);
     int32_t *mb_dev = ws->counters + LR_CNT_NCORR;
     LR_TRY(prep_both(ws, F0, n0, F1, n1, st));
     LR_TRY(nn_reverse(ws, F0, n0, F1, n1, idx1, ws->rev_idx1, st));
@@ -385,6 +448,7 @@ extern "C" int lr_ransac(lr_workspace *ws, const float *src, const float *tgt, i
                          const lr_ransac_params *p, double *T_out, lr_ransac_result *res, void *stream)
 {
     LR_REQUIRE(ws && src && tgt && p && T_out && res, LR_EINVAL, "lr_ransac: null pointer");
+    LR_TRY(check_ransac_params(p, "lr_ransac"));
     LR_REQUIRE(m >= 0 && m <= ws->max_n0, LR_ESIZE, "lr_ransac: m exceeds the workspace");
     hipStream_t st = (hipStream_t)stream;
     LR_TRY(lr_pack_corr(ws, src, tgt, nullptr, nullptr, m, m_dev, ws->corr8, st));
@@ -497,6 +561,7 @@ static int register_stages(lr_workspace *ws, const float *xyz0, const float *xyz
 {
     int32_t *m_dev = ws->counters + LR_CNT_NCORR;
     int32_t *n_refit = ws->counters + LR_CNT_COUNT - 2;
+    pad_if_narrow(ws, F0, n0, F1, n1, dim, st);
     // 1. coarse correspondences (FR.py:38): first + second NN of every cloud-0 descriptor
     LR_TRY(prep_both(ws, F0, n0, F1, n1, st, true));
     const bool fuse_seed = p->mode != LR_MODE_NO_FILTER;   // the forward exact kernel seeds the reverse pass
@@ -563,8 +628,9 @@ static int register_stages(lr_workspace *ws, const float *xyz0, const float *xyz
 extern "C" int lr_register_pair(lr_workspace *ws, const float *xyz0, const float *xyz1, const float *F0, const float *F1,
                                 int n0, int n1, int dim, const lr_pair_params *p, lr_pair_result *out, void *stream)
 {
+    LR_REQUIRE(ws && xyz0 && xyz1 && p && out, LR_EINVAL, "lr_register_pair: null pointer");
+    LR_TRY(check_pair_params(p, "lr_register_pair"));
     LR_TRY(check_nn_args(ws, F0, n0, F1, n1, dim, "lr_register_pair"));
-    LR_REQUIRE(xyz0 && xyz1 && p && out, LR_EINVAL, "lr_register_pair: null pointer");
     LR_REQUIRE(p->mode == LR_MODE_NO_FILTER || p->mode == LR_MODE_MNN || p->mode == LR_MODE_GPF, LR_EINVAL,
                "lr_register_pair: unknown mode");
     ws->zP = 1; ws->z = lr_zargs{ 0, nullptr };
@@ -584,6 +650,7 @@ extern "C" int lr_register_batch(lr_workspace *ws, int npairs, const float *cons
                                  const lr_pair_params *p, lr_pair_result *out, void *stream)
 {
     LR_REQUIRE(ws && xyz0 && xyz1 && F0 && F1 && n0 && n1 && p && out, LR_EINVAL, "lr_register_batch: null pointer");
+    LR_TRY(check_pair_params(p, "lr_register_batch"));
     LR_REQUIRE(npairs >= 1 && npairs <= ws->max_pairs, LR_ESIZE, "lr_register_batch: npairs exceeds the workspace (lr_workspace_create_batch)");
     LR_REQUIRE(p->mode == LR_MODE_NO_FILTER || p->mode == LR_MODE_MNN || p->mode == LR_MODE_GPF, LR_EINVAL,
                "lr_register_batch: unknown mode");

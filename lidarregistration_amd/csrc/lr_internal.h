@@ -102,6 +102,7 @@ struct lr_workspace {
     // --- NN (both directions share these) ---
     float *nrm0, *nrm1;          // row norms
     _Float16 *H0, *H1;           // [n,32] f16 copies for the matrix-core filter passes
+    float *P0, *P1;              // [n,32] zero-padded fp32 copies of descriptors narrower than 32 (nullptr at dim 32)
     float *tau;                  // [max_n] per-row candidate threshold
     uint32_t *yshare;            // [max_n] the rows' tightest threshold so far over all column strips of the filter pass in flight (order-preserving
                                  // integer image of y, lowered with atomicMin): how the strips of one row block learn from each other

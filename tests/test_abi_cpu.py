@@ -33,13 +33,39 @@ def test_version_and_error_string(libpath):
 
 
 def test_struct_layouts_match_header():
-    # sizes the C side static-asserts implicitly through its field order (include/lidarreg.h)
-    assert ctypes.sizeof(_ext.RansacParams) == 64 and _ext.RansacParams.sampler.offset == 32 and _ext.RansacParams.scoring.offset == 40
-    assert _ext.RansacParams.local_opt.offset == 44 and _ext.RansacParams.lo_rounds.offset == 48 and _ext.RansacParams.min_iters.offset == 60
+    # sizes the C side static-asserts implicitly through its field order (include/lidarreg.h); both params structs start with struct_size
+    R, P = _ext.RansacParams, _ext.PairParams
+    assert ctypes.sizeof(R) == 72 and R.struct_size.offset == 0 and R.sample_size.offset == 4 and R.seed.offset == 24
+    assert R.sampler.offset == 40 and R.scoring.offset == 48 and R.local_opt.offset == 52 and R.lo_rounds.offset == 56 and R.min_iters.offset == 68
     assert ctypes.sizeof(_ext.RansacResult) == 40
     assert ctypes.sizeof(_ext.PairResult) == 496
-    assert ctypes.sizeof(_ext.PairParams) == 96
-    assert _ext.PairParams.ransac.offset == 8 and _ext.PairParams.gpf_factor.offset == 80
+    assert ctypes.sizeof(P) == 112 and P.struct_size.offset == 0 and P.mode.offset == 4 and P.ransac.offset == 16 and P.gpf_factor.offset == 96
+    # the Python mirror fills the sizes in (positional arguments start at sample_size, as before)
+    r = R(3, 1, 0.36, 50000, 51)
+    assert (r.struct_size, r.sample_size, r.use_elc, r.iters, r.seed) == (72, 3, 1, 50000, 51)
+    p = P()
+    assert p.struct_size == 112 and p.ransac.struct_size == 72
+    p.ransac = r
+    assert p.ransac.struct_size == 72 and p.ransac.iters == 50000
+
+
+def test_params_from_another_header_version_are_rejected():
+    """A caller built against lr_version 101 (no struct_size: the struct started with sample_size = 3 or 4; 64 / 96 bytes) is turned
+    away before anything is read past the end of its shorter struct.  Checked before any HIP call: safe without a device."""
+    L = _ext.lib()
+    assert L.lr_version() == 102
+    r = _ext.RansacParams(3, 1, 0.36, 1000, 51)
+    r.struct_size = 3                                   # what an old caller's first field would hold
+    one = ctypes.c_void_p(1)                            # non-null dummies: the size check comes before any dereference of them
+    assert L.lr_ransac(one, one, one, 10, None, ctypes.byref(r), one, one, None) == -1
+    assert b"struct_size" in L.lr_last_error() and b"lr_version 102" in L.lr_last_error()
+    p = _ext.PairParams()
+    p.mode = 1
+    p.struct_size = 96
+    pp = (ctypes.c_void_p * 1)(1)
+    ip = (ctypes.c_int32 * 1)(10)
+    assert L.lr_register_batch(one, 1, pp, pp, pp, pp, ip, ip, 32, ctypes.byref(p), one, None) == -1 and b"lr_pair_params.struct_size is 96" in L.lr_last_error()
+    assert L.lr_register_pair(one, one, one, one, one, 10, 10, 32, ctypes.byref(p), one, None) == -1 and b"struct_size" in L.lr_last_error()
 
 
 def test_bad_arguments_are_reported_not_crashed(libpath):
@@ -48,8 +74,8 @@ def test_bad_arguments_are_reported_not_crashed(libpath):
     # argument validation happens before any HIP call, so this is safe without a device
     assert L.lr_workspace_create(ctypes.byref(h), 0, 10, 32, 10) == -1
     assert b"positive" in L.lr_last_error()
-    assert L.lr_workspace_create(ctypes.byref(h), 10, 10, 16, 10) == -1
-    assert b"32-d" in L.lr_last_error()
+    assert L.lr_workspace_create(ctypes.byref(h), 10, 10, 33, 10) == -1 and b"1 to 32" in L.lr_last_error()      # wider than FCGF's 32: refused
+    assert L.lr_workspace_create(ctypes.byref(h), 10, 10, 0, 10) == -1
     assert L.lr_feat_ratio(None, None, 32, 4, None, None, None, None, None) == -1
 
 

@@ -103,3 +103,32 @@ def test_list_mode_with_two_ranks_on_this_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["pairs"] == 12 and d["recall_5deg_0.6m"] == 1.0 and d["config"]["parallelism"] == "pair-sharded x2"
     assert 0.0 <= d["hard"]["recall_5deg_0.6m"] <= 1.0
+
+
+# ------------------------------------------------------------------ world size 8 -- on ONE GPU: no scaling number comes out of these
+# (DESIGN.md section 7); they make sure that eight ranks rendezvous, shard, gather and time together before an 8-GPU node is the first to try
+def test_eight_ranks_share_this_gpu_through_the_self_launcher():
+    line = _bench(["--gpus", "8", "--dist-backend", "gloo", "--devices", "0,0,0,0,0,0,0,0", "--no-cpu-baseline", "--pairs", "16", "--steps", "3", "--warmup", "1"])
+    assert line["n_gpus"] == 8 and line["steps"] == 3 and line["value"] > 0 and line["recall_2deg_0.6m"] == 1.0 and line["scaling"] == "weak"
+    assert line["config"]["parallelism"] == "pair-sharded x8"
+
+
+def test_list_mode_with_eight_ranks_on_this_gpu():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dist-backend", "gloo", "--devices", "0,0,0,0,0,0,0,0", "--list", "B",
+                        "--list-stride", "64", "--batch", "4", "--streams", "2", "--n", "8000", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=1500, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["pairs"] == 41 and d["recall_5deg_0.6m"] == 1.0 and d["config"]["parallelism"] == "pair-sharded x8"      # ceil(2592 / 64) rows
+
+
+def test_a_dying_rank_ends_the_eight_rank_run_quickly():
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dist-backend", "gloo", "--devices", "0,0,0,0,0,7,0,0", "--n", "4000",
+                        "--iters", "3000", "--pairs", "8", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0 and time.time() - t0 < 180          # rank 5 has no device 7 on this box

@@ -167,3 +167,50 @@ def test_pygcransac_sentinel_decoding_without_a_gpu(monkeypatch, capsys):
     monkeypatch.setattr(ransac, "ransac_dev", nothing)
     pose, mask = pygcransac.findRigidTransform(P, P, **kw)
     assert pose is None and mask.shape == (10,) and not mask.any()
+
+
+# ------------------------------------------------------------------ the rank launcher (bench.py --gpus N, python -m test launch)
+def test_run_ranks_stops_everything_when_one_rank_fails():
+    import sys
+    import time
+    from lidarregistration_amd import launch
+    t0 = time.time()
+    rc = launch.run_ranks([[sys.executable, "-c", "import time; time.sleep(60)"], [sys.executable, "-c", "import sys, time; time.sleep(0.3); sys.exit(3)"],
+                           [sys.executable, "-c", "import time; time.sleep(60)"]])
+    assert rc == 3 and time.time() - t0 < 20
+    assert launch.run_ranks([[sys.executable, "-c", "import os, sys; sys.exit(0 if os.environ['RANKX'] == str(i) else 1)".replace("str(i)", repr(str(i)))] for i in range(8)],
+                            [dict(RANKX=str(i)) for i in range(8)]) == 0
+
+
+def test_gpu_list_from_the_environment(monkeypatch):
+    from lidarregistration_amd import launch
+    monkeypatch.setenv("LIDARREG_GPUS", "0 0 3,1")
+    assert launch.gpu_list() == [0, 0, 3, 1]
+
+
+def test_cli_launcher_builds_the_positional_protocol_and_skips_the_analysis_on_failure(monkeypatch, tmp_path):
+    import glob
+    import importlib
+    import tempfile
+    from lidarregistration_amd import launch
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.syspath_prepend(os.path.join(ROOT, "Experiments"))
+    cli = importlib.import_module("test")
+    monkeypatch.setenv("LIDARREG_GPUS", "0 0 0 0 0 0 0 0")
+    monkeypatch.setattr(tempfile, "tempdir", str(tmp_path))
+    seen = {}
+
+    def fake(cmds, envs=None, **kw):
+        seen["cmds"], seen["envs"] = cmds, envs
+        return 7
+    monkeypatch.setattr(launch, "run_ranks", fake)
+    with pytest.raises(SystemExit) as e:
+        cli.main(["launch", "--dataset", "B", "--mode", "MNN", "--iters", "1000000", "--GC_conf", "0.9995"])
+    assert e.value.code == 7
+    assert len(seen["cmds"]) == 8 and all(env["HIP_VISIBLE_DEVICES"] == "0" for env in seen["envs"])
+    for r, c in enumerate(seen["cmds"]):
+        k = c.index("test_parallel")
+        assert c[k - 2:k] == ["-m", "test"] and c[k + 3:k + 5] == ["8", str(r)] and c[k + 5:] == ["--dataset", "B", "--mode", "MNN", "--iters", "1000000", "--GC_conf", "0.9995"]
+        assert c[k + 1] == seen["cmds"][0][k + 1] and c[k + 2] == seen["cmds"][0][k + 2]          # one start time, one file base
+    assert not glob.glob(str(tmp_path / "lidarreg_ranks_*"))                                      # partial files removed, no analysis ran
+    assert not (tmp_path / "outputs").exists()
