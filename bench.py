@@ -67,6 +67,7 @@ def parse(argv=None):
     ap.add_argument("--list-stride", type=int, default=1, help="with --list: every k-th row only")
     ap.add_argument("--hard", type=int, default=1, help="with --list: also run the rows under the HARD surrogate settings (harness.HARD: a fraction of the listed overlap, "
                                                         "noisier descriptors / coordinates; recall near 90 %%) and report that recall next to the plain one (0: skip)")
+    ap.add_argument("--traffic-key", action="store_true", help="print the key this command's PMC traffic is filed under in profiles/pmc_traffic.json and exit (tools/pmc_traffic.sh)")
     ap.add_argument("--dry-run", action="store_true", help="test hook: no GPU work, gloo collectives, fake result rows (exercises the launcher, the gather and the JSON line on CPU)")
     return ap.parse_args(argv)
 
@@ -85,6 +86,35 @@ def spawn_ranks(args):
 
 
 # ----------------------------------------------------------------------------- helpers
+def traffic_key(n, mode, codebase, iters, pairs_per_launch):
+    """The workload a set of PMC traffic figures belongs to (profiles/pmc_traffic.json is keyed by it: the counters of the default
+    workload say nothing about 100k-point clouds, another filter mode, another estimator or another batch size)."""
+    mode = "MNN" if mode == "MMN" else mode
+    return f"n={int(n)},mode={mode},codebase={codebase},iters={int(iters)},pairs_per_launch={int(pairs_per_launch)}"
+
+
+DEFAULT_TRAFFIC_KEY = traffic_key(30000, "MNN", "open3D", 50000, 32)
+
+
+def lookup_traffic(tdoc, key):
+    """(filter-pass HBM bytes per launch, all kernels' HBM bytes per pair, source note) for workload `key`, or (None, None, None) when
+    no PMC pass was taken for it.  Files written before round 5 hold one unkeyed workload: the default one."""
+    if not tdoc:
+        return None, None, None
+    w = tdoc.get("workloads", {}).get(key)
+    if w is None and "workloads" not in tdoc and key == DEFAULT_TRAFFIC_KEY:
+        w = tdoc
+    if w is None:
+        return None, None, None
+    # (the filter pass has two instantiations, both launched; the one the data asks for does the work)
+    live = [v for k, v in w.items() if k.startswith("nn16_passb_kernel<true") and isinstance(v, dict)]
+    traffic = int(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in live) / max(1, sum(v["launches"] for v in live))) if live else \
+        w.get("nn16_passb_kernel", {}).get("hbm_bytes_per_launch")
+    src = ("NOT measured in this run: profiles/pmc_traffic.json[" + key + "], the builder's separate rocprofv3 --pmc passes of this command ("
+           + str(w.get("_meta", {}).get("commit", "commit unrecorded")) + "), per launch")
+    return traffic, w.get("_pair", {}).get("hbm_bytes_per_pair"), (None if traffic is None else src)
+
+
 def transform_errors(T, G):
     re = np.degrees(np.arccos(np.clip((np.trace(T[:3, :3].T @ G[:3, :3]) - 1) / 2, -1, 1)))
     return re, np.linalg.norm(T[:3, 3] - G[:3, 3])
@@ -99,6 +129,21 @@ def cpu_baseline(args, seed0):
     orc.build()
     w = synth.make_pair(N=2000, seed=1)
     torch_cpu.register_pair(w["xyz0"], w["xyz1"], w["feats0"], w["feats1"], mode=args.mode, iters=1000)     # page-in / thread pools: untimed
+    # How many threads does the reference's chunked NN want?  Its GEMMs are 250 rows tall (nn_max_n): on a 128-thread host torch's default
+    # (all of them) thrashes -- BENCH_r04 timed 5.0 s per NN pass on 128 threads where 8 vCPUs take 1.2 s.  One NN pass of one pair per
+    # candidate count, the fastest is used for the sample (and reported as `cores`).
+    max_threads = int(torch.get_num_threads())
+    sweep = {}
+    p0 = synth.make_pair(N=args.n, seed=seed0)
+    for nt in sorted({t for t in (8, 16, 32, 64, 128) if t <= max_threads} | {max_threads}):
+        torch.set_num_threads(nt)
+        t1 = time.perf_counter()
+        torch_cpu.find_nn(p0["feats0"], p0["feats1"], return_2nd=True)
+        sweep[nt] = round(time.perf_counter() - t1, 3)
+        if sum(sweep.values()) > 0.6 * args.cpu_budget_s:
+            break
+    best_threads = min(sweep, key=sweep.get)
+    torch.set_num_threads(best_threads)
     t_reg = 0.0; done = 0; parts = np.zeros(3)
     for k in range(args.cpu_pairs):
         p = synth.make_pair(N=args.n, seed=seed0 + k)
@@ -119,7 +164,9 @@ def cpu_baseline(args, seed0):
         model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
     except Exception:
         pass
-    return {"value": round(done / t_reg, 4), "unit": "pairs/s", "cores": int(torch.get_num_threads()), "kind": "port",
+    torch.set_num_threads(max_threads)
+    return {"value": round(done / t_reg, 4), "unit": "pairs/s", "cores": int(best_threads), "kind": "port",
+            "torch_threads_sweep_s_per_nn_pass": {str(k): v for k, v in sweep.items()},
             "impl": "restatement of the reference's Python path: torch-CPU chunked einsum NN (nn_max_n=250, matching.py:22-65) x2 directions + "
                     "numpy mutual filter + OpenMP RANSAC/refit (oracle.c) -- oracle/torch_cpu.py",
             "sample": f"{done} pairs of the same workload (N={args.n}, {args.mode}, {args.iters} iters); seconds per pair: NN {parts[0] / done:.2f}, "
@@ -218,6 +265,10 @@ def list_run(args):
 
 def main():
     args = parse()
+    if args.traffic_key:
+        B = args.batch if args.batch > 0 else (32 if args.n <= 60000 else 8)
+        print(traffic_key(args.n, args.mode, args.codebase, args.iters, max(1, min(B, args.pairs, 64))))
+        return
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args))
     if args.opt:
@@ -413,15 +464,12 @@ def main():
         achieved = flop_launch / t_launch / 1e12
         tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         tdoc = json.load(open(tj)) if os.path.exists(tj) else {}
-        # (the filter pass has two instantiations, both launched; the one the data asks for does the work)
-        live = [v for k, v in tdoc.items() if k.startswith("nn16_passb_kernel<true") and isinstance(v, dict)]
-        traffic = int(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in live) / max(1, sum(v["launches"] for v in live))) if live else \
-            tdoc.get("nn16_passb_kernel", {}).get("hbm_bytes_per_launch")
-        traffic_source = None if traffic is None else ("NOT measured in this run: profiles/pmc_traffic.json, the builder's separate rocprofv3 --pmc passes of this "
-                                                       "command (" + str(tdoc.get("_meta", {}).get("commit", "commit unrecorded")) + "), per launch")
+        # traffic figures only for the workload they were collected on (else null: say nothing rather than the wrong launch's bytes)
+        tkey = traffic_key(args.n, args.mode, args.codebase, args.iters, len(chunk))
+        traffic, hbm_pair_doc, traffic_source = lookup_traffic(tdoc, tkey)
         nn_stage_s = (fwd_nn_ms + rev_nn_ms) * 1e-3
         roof = {"bound": "mfma", "kernel": "nn16_passb_kernel", "achieved": round(achieved, 3), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source, "launch_ms": round(t_launch * 1e3, 4),
+                "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source, "traffic_key": tkey, "launch_ms": round(t_launch * 1e3, 4),
                 "forward_launch_ms": round(fwd_filter_ms, 4), "reverse_launch_ms": round(rev_filter_ms, 4),
                 "pairs_per_launch": len(chunk), "launches_per_call": launches_per_call,
                 # the ladder from the kernel to the step, all from this run's events (one batched call at a time):
@@ -438,9 +486,7 @@ def main():
         # whole pair against the blended floor: one NN pass on the matrix pipe + V*M*27 flop of scoring on the vector pipe
         t_min = flop_pass / (MFMA_F16_PEAK_TFLOPS * 1e12) + n_valid_mean * n_corr_mean * 27.0 / (VALU_F32_PEAK_TFLOPS * 1e12)
         t_pair = dt / (args.pairs * args.steps)
-        hbm_pair = None      # HBM bytes of ALL the library's kernels per pair (PMC passes of the default workload, profiles/pmc_traffic.json)
-        if tdoc and args.n == 30000 and args.mode in ("MNN", "MMN") and args.codebase == "open3D" and args.iters == 50000:
-            hbm_pair = tdoc.get("_pair", {}).get("hbm_bytes_per_pair")
+        hbm_pair = hbm_pair_doc      # HBM bytes of ALL the library's kernels per pair (PMC passes of THIS workload, profiles/pmc_traffic.json; else null)
         pair_roof = {"t_min_us": round(t_min * 1e6, 2), "t_pair_us": round(t_pair * 1e6, 2), "frac": round(t_min / t_pair, 4),
                      "hbm_bytes_per_pair": hbm_pair, "hbm_GBps": None if hbm_pair is None else round(hbm_pair / t_pair / 1e9, 1),
                      "hbm_frac_of_8TBps": None if hbm_pair is None else round(hbm_pair / t_pair / 8.0e12, 4),
@@ -474,7 +520,7 @@ def main():
         if cpu:
             # against BOTH host implementations, the headline ratio against the FASTER one (the OpenMP port of the oracle, not the
             # reference-style torch path whose 250-row einsum chunks leave most of the cores idle)
-            line["speedup_vs_reference_python_path"] = round(value / cpu["value"], 1)
+            line["speedup_vs_reference_style_path"] = round(value / cpu["value"], 1)      # (at the thread count the reference-style NN runs fastest with: cpu_baseline.cores)
             line["speedup_vs_openmp_port"] = round(value / cpu["oracle_port_pairs_per_s"], 1)
             line["speedup_vs_cpu_baseline"] = round(value / max(cpu["value"], cpu["oracle_port_pairs_per_s"]), 1)
         print(json.dumps(line), flush=True)

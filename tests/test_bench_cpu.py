@@ -41,3 +41,23 @@ def test_under_an_external_launcher_environment():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     line = _run(["--gpus", "1"], dict(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)))
     assert line["n_gpus"] == 1
+
+
+def test_traffic_figures_belong_to_one_workload():
+    """profiles/pmc_traffic.json is keyed by workload: bench.py reports `traffic` / `hbm_bytes_per_pair` only for the workload the
+    counters were collected on, and null for everything else (round 4 reported the 30k launch's bytes for a launch of 8 x 100k points)."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+    doc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    t, pair, src = b.lookup_traffic(doc, b.DEFAULT_TRAFFIC_KEY)
+    assert t and t > 1e8 and pair and pair > 3e7 and b.DEFAULT_TRAFFIC_KEY in src
+    for key in (b.traffic_key(100000, "MNN", "open3D", 50000, 8), b.traffic_key(30000, "MNN", "open3D", 50000, 16), b.traffic_key(30000, "no_filter", "open3D", 50000, 32),
+                b.traffic_key(30000, "MNN", "open3D", 1000, 32), b.traffic_key(12345, "GPF", "GC", 50000, 32)):
+        if key not in doc.get("workloads", {}):
+            assert b.lookup_traffic(doc, key) == (None, None, None), key
+    assert b.traffic_key(30000, "MMN", "open3D", 50000, 32) == b.DEFAULT_TRAFFIC_KEY          # the reference's alias
+    fake = {"workloads": {"k1": {"nn16_passb_kernel<true>": {"hbm_bytes_per_launch": 100, "launches": 2}, "_pair": {"hbm_bytes_per_pair": 7}, "_meta": {"commit": "abc"}}}}
+    assert b.lookup_traffic(fake, "k1")[:2] == (100, 7) and "abc" in b.lookup_traffic(fake, "k1")[2] and b.lookup_traffic(fake, "k2") == (None, None, None)
+    assert b.lookup_traffic({}, "k1") == (None, None, None)

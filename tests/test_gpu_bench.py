@@ -35,7 +35,7 @@ def test_bench_line_small_workload():
     assert 0 < pr["frac"] < 1 and pr["t_min_us"] < pr["t_pair_us"]
     cpu = line["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["unit"] == "pairs/s" and cpu["value"] > 0 and cpu["cores"] >= 1 and "einsum" in cpu["impl"]
-    assert line["speedup_vs_cpu_baseline"] > 1 and line["speedup_vs_cpu_baseline"] == min(line["speedup_vs_reference_python_path"], line["speedup_vs_openmp_port"])
+    assert line["speedup_vs_cpu_baseline"] > 1 and line["speedup_vs_cpu_baseline"] == min(line["speedup_vs_reference_style_path"], line["speedup_vs_openmp_port"])
     assert 0 < roof["whole_call_frac"] <= roof["nn_stage_frac"] <= roof["forward_launch_frac"] < 1 and roof["forward_launch_ms"] > roof["reverse_launch_ms"] > 0
 
 

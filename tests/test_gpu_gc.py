@@ -294,38 +294,24 @@ def test_gc_soak_cases(lr, oracle, case):
     assert info == einfo and np.array_equal(T, Te), (kw, iters, info, einfo)
 
 
-def _reference_call(A, B, distance_threshold, num_iterations, args, match_quality, pygcransac):
-    """The CALL of the reference's Experiments/algorithms/GC_RANSAC.py:12-55 -- the parameter dict, the flag overrides with their
-    sentinel overloading, the PROSAC pre-sort, ``findRigidTransform(x1, x2, **params)``, ``None -> eye``, the transpose -- with
-    its TabError at :29-30 fixed.  Parameters only: nothing of the estimator is restated here."""
-    x1y1z1_ = np.ascontiguousarray(A); x2y2z2_ = np.ascontiguousarray(B)
-    params = {'threshold': distance_threshold, 'conf': 0.999, 'spatial_coherence_weight': 0.0, 'max_iters': num_iterations, 'use_sprt': True,
-              'min_inlier_ratio_for_sprt': 0.1, 'sampler': 0, 'neighborhood': 0, 'neighborhood_size': 20}
-    params['spatial_coherence_weight'] = args.spatial_coherence_weight
-    params['sampler'] = args.prosac
-    params['conf'] = args.GC_conf
-    params['use_sprt'] = args.fast_rejection != "NONE"           # "actually means: perform fast rejection"
-    if args.fast_rejection == "ELC":
-        params['min_inlier_ratio_for_sprt'] = -1                  # negative value: the C++ side uses ELC instead of SPRT
-    if not args.GC_LO:
-        params['neighborhood'] = 1                                # non-zero value: the C++ side does not run the local optimisation
-    if args.prosac:
-        order = np.argsort(-match_quality)
-        x1y1z1_ = x1y1z1_[order, :]; x2y2z2_ = x2y2z2_[order, :]
-    pose_T, mask = pygcransac.findRigidTransform(x1y1z1_, x2y2z2_, **params)
-    if pose_T is None:
-        pose_T = np.eye(4, dtype=np.float32)
-    return pose_T.T, mask
+def _recorded_calls():
+    """What the reference's Experiments/algorithms/GC_RANSAC.py:12-55 hands to ``pygcransac.findRigidTransform`` for every combination of
+    its CLI flags -- recorded from the reference itself by tests/golden/make_golden_gc_call.py (a stand-in module captured the call), not
+    restated here: keyword arguments with their sentinel overloading, whether the points arrive sorted by descending quality, and that
+    the caller transposes the pose."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g14_gc_call.json")) as f:
+        return json.load(f)
 
 
-@pytest.mark.parametrize("fast_rejection", ["ELC", "SPRT", "NONE"])
-@pytest.mark.parametrize("GC_LO", [True, False])
-@pytest.mark.parametrize("prosac", [True, False])
-def test_pygcransac_call_shape(lr, fast_rejection, GC_LO, prosac):
-    """`import pygcransac` as the reference does, its own call transcribed above: the pose is GC_RANSAC()'s bit for bit, in
-    pygcransac's row-vector convention until the caller transposes it; the mask covers the caller's (sorted) pairs."""
+@pytest.mark.parametrize("row", range(12))
+def test_pygcransac_call_shape(lr, row):
+    """`import pygcransac` as the reference does, called with the reference's own recorded arguments: the pose is GC_RANSAC()'s bit for
+    bit, in pygcransac's row-vector convention until the caller transposes it; the mask covers the caller's (sorted) pairs."""
     import os
     import sys
+    rec = _recorded_calls()[row]
     exp = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "Experiments")
     sys.path.insert(0, exp)
     try:
@@ -335,11 +321,14 @@ def test_pygcransac_call_shape(lr, fast_rejection, GC_LO, prosac):
         sys.path.remove(exp)
     src, tgt, T_gt = _planted(n=5000, inlier=0.3, seed=31)
     q = np.random.default_rng(5).random(len(src)).astype(np.float32)        # distinct finite qualities: one sort order
-    a = Args(codebase="GC", prosac=prosac, fast_rejection=fast_rejection, GC_LO=GC_LO, GC_conf=0.999)
-    T_ref, mask = _reference_call(src, tgt, 0.6, 20000, a, q, pygcransac)
-    T, _, mask2 = lr.ransac.GC_RANSAC(src, tgt, 0.6, 20000, a, q, return_mask=True)
+    f = rec["flags"]
+    a = Args(codebase="GC", prosac=f["prosac"], fast_rejection=f["fast_rejection"], GC_LO=f["GC_LO"], GC_conf=f["GC_conf"])
+    order = np.argsort(-q) if rec["presorted_by_descending_quality"] else np.arange(len(src))
+    assert rec["presorted_by_descending_quality"] == f["prosac"] and rec["pose_is_transposed"]
+    pose, mask = pygcransac.findRigidTransform(np.ascontiguousarray(src[order]), np.ascontiguousarray(tgt[order]), **rec["kwargs"])
+    T_ref = pose.T
+    T, _, mask2 = lr.ransac.GC_RANSAC(src, tgt, rec["threshold_arg"], rec["iterations_arg"], a, q, return_mask=True)
     assert np.array_equal(T_ref, T) and T_ref.dtype == np.float64
-    order = np.argsort(-q) if prosac else np.arange(len(src))
     assert mask.dtype == bool and np.array_equal(mask, mask2[order]) and mask.sum() > 1000
     from lidarregistration_amd import metrics
     assert metrics.rotation_error_deg(T_ref, T_gt) < 0.5

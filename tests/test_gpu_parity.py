@@ -666,6 +666,12 @@ def test_fcgf_fast_and_dgr_callers(lr, oracle):
                              confidence=0.9999, refit_on_orig=3)
     np.testing.assert_allclose(r["base"], e["T"], rtol=0, atol=1e-9)
     assert oracle.rotation_error_deg(r["base"], p["T_gt"]) < 0.5
+    # 'w_icp' = 'base' refined by ICP at 2 * voxel_size (deep_global_registration.py:556-563), as the oracle's ICP does it; off: = 'base'
+    Ti, _ = oracle.icp(p["xyz0"], p["xyz1"], e["T"], max_dist=0.6)
+    np.testing.assert_allclose(r["w_icp"], Ti, rtol=0, atol=1e-9)
+    assert np.abs(r["w_icp"] - r["base"]).max() > 1e-9
+    r0 = callers.DGR_register_FCGF(t(p["xyz0"]), t(p["xyz1"]), t(p["feats0"]), t(p["feats1"]), iters=20000, T_gt=p["T_gt"], use_icp=False)
+    assert np.array_equal(r0["base"], r["base"]) and np.array_equal(r0["w_icp"], r0["base"])
     # the weighted refit is really different from the unweighted one
     e1 = oracle.register_pair(p["xyz0"], p["xyz1"], p["feats0"], p["feats1"], mode="no_filter", iters=20000, sample_size=4, seed=51,
                               confidence=0.9999, refit_on_orig=1)

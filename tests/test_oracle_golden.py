@@ -227,3 +227,17 @@ def test_g13_100k_slice_matches_reference(oracle):
     assert np.array_equal(o1, g["idx1"]) and np.array_equal(o2, g["idx2"])
     r1, _, _, _ = oracle.nn_top2(p["feats1"][g["cols"]], p["feats0"])
     assert np.array_equal(r1, g["rev_idx1"])
+
+
+def test_g14_recorded_reference_call_table_is_complete():
+    """tests/golden/g14_gc_call.json (the reference's own findRigidTransform arguments, recorded): one row per flag combination,
+    the sentinels of GC_RANSAC.py:29-37 as the reference sets them."""
+    import json
+    import os
+    from tests.conftest import GOLDEN
+    rows = json.load(open(os.path.join(GOLDEN, "g14_gc_call.json")))
+    assert len(rows) == 12 and len({(r["flags"]["fast_rejection"], r["flags"]["GC_LO"], r["flags"]["prosac"]) for r in rows}) == 12
+    for r in rows:
+        f, k = r["flags"], r["kwargs"]
+        assert k["use_sprt"] == (f["fast_rejection"] != "NONE") and (k["min_inlier_ratio_for_sprt"] < 0) == (f["fast_rejection"] == "ELC")
+        assert (k["neighborhood"] != 0) == (not f["GC_LO"]) and bool(k["sampler"]) == f["prosac"] and k["max_iters"] == 20000
