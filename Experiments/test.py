@@ -133,6 +133,9 @@ def analyze_stats(args):
     allrows = allrows[first]
     stats, T, whole = allrows[:, :22], allrows[:, 22:38].reshape(-1, 4, 4), allrows[:, 38]
     np.save(args.outdir + "raw_stats.npy", stats)
+    from lidarregistration_amd import harness
+    with open(args.outdir + "raw_stats.columns.txt", "w") as fid:      # (the batched engine's time columns are window shares: say so next to the file)
+        fid.write(harness.stats_columns(args.serial))
     s = metrics.summarize(stats, args.algo)
     # the reference bills filter + RANSAC + the second neighbour's surcharge (FR.py:117; column 9 above); the whole device path of a
     # call additionally contains the first nearest-neighbour search

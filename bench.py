@@ -47,8 +47,10 @@ def parse(argv=None):
     ap.add_argument("--batch", type=int, default=0, help="pairs per batched call (0: 32, or 8 for clouds above 60k points)")
     ap.add_argument("--streams", type=int, default=0, help="batched calls in flight per GPU (0: 3, or 4 with --codebase GC whose one-block-per-pair "
                                                             "local optimisation leaves most CUs to the other calls; 6 with --list)")
-    ap.add_argument("--sustain-s", type=float, default=10.0, help="after the K timed steps, run the same step loop for at least this many seconds and report it as "
-                                                                  "`sustained` (outside `value`; 0: skip) -- the timed region of the contract is a fraction of a second")
+    ap.add_argument("--sustain-s", type=float, default=None, help="after the K timed steps, run the same step loop for at least this many seconds and report it as "
+                                                                  "`sustained` (outside `value`; 0: skip) -- the timed region of the contract is a fraction of a second.  "
+                                                                  "Default 10, or 0 under rocprofv3 (ROCPROF* in the environment): ~600 untimed steps would otherwise dominate "
+                                                                  "every counter pass and kernel summary")
     ap.add_argument("--include-h2d", action="store_true", help="copy each pair from pinned host memory inside the timed region (PCIe-inclusive rate; not the headline value)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=8)
@@ -69,7 +71,10 @@ def parse(argv=None):
                                                         "noisier descriptors / coordinates; recall near 90 %%) and report that recall next to the plain one (0: skip)")
     ap.add_argument("--traffic-key", action="store_true", help="print the key this command's PMC traffic is filed under in profiles/pmc_traffic.json and exit (tools/pmc_traffic.sh)")
     ap.add_argument("--dry-run", action="store_true", help="test hook: no GPU work, gloo collectives, fake result rows (exercises the launcher, the gather and the JSON line on CPU)")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    if args.sustain_s is None:
+        args.sustain_s = 0.0 if any(k.startswith("ROCPROF") for k in os.environ) else 10.0
+    return args
 
 
 # ----------------------------------------------------------------------------- self-launch (no torch.distributed.run)

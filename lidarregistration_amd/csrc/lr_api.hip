@@ -303,6 +303,10 @@ static int check_nn_args(const lr_workspace *ws, const void *F0, int n0, const v
 
 #define LR_TRY(x) do { int rc_ = (x); if (rc_ != LR_OK) return rc_; } while (0)
 
+// Every entry point that writes arena state (scratch, counters, result temporaries) makes lr_icp_batch forget the last batched
+// registration: its transforms / descriptor table would otherwise be read back stale (only lr_register_batch, on success, re-arms it)
+static inline void forget_last_batch(lr_workspace *ws) { if (ws) { ws->last_batch = 0; ws->last_T_final = nullptr; } }
+
 // The params structs start with their own size: a caller built against another version of include/lidarreg.h is turned away instead
 // of having a shorter struct read past its end (lr_version 102)
 static int check_ransac_params(const lr_ransac_params *p, const char *who)
@@ -389,6 +393,7 @@ extern "C" int lr_nn_top2(lr_workspace *ws, const float *F0, int n0, const float
                           int32_t *idx1, int32_t *idx2, float *s1, float *s2, void *stream)
 {
     LR_TRY(check_nn_args(ws, F0, n0, F1, n1, dim, "lr_nn_top2"));
+    forget_last_batch(ws);
     LR_REQUIRE(idx1, LR_EINVAL, "lr_nn_top2: idx1 is required");
     hipStream_t st = (hipStream_t)stream;
     pad_if_narrow(ws, F0, n0, F1, n1, dim, st);
@@ -402,6 +407,7 @@ extern "C" int lr_nn_to_mutual(lr_workspace *ws, const float *F0, int n0, const 
                                int32_t *o0, int32_t *o1, int32_t *o2, int32_t *n_out, void *stream)
 {
     LR_TRY(check_nn_args(ws, F0, n0, F1, n1, dim, "lr_nn_to_mutual"));
+    forget_last_batch(ws);
     LR_REQUIRE(idx1, LR_EINVAL, "lr_nn_to_mutual: idx1 is required");
     hipStream_t st = (hipStream_t)stream;
     pad_if_narrow(ws, F0, n0, F1, n1, dim, st);
@@ -416,6 +422,7 @@ extern "C" int lr_gpf(lr_workspace *ws, const float *F0, int n0, const float *F1
                       int32_t *o0, int32_t *o1, int32_t *o2, float *oscore, int32_t *n_out, void *stream)
 {
     LR_TRY(check_nn_args(ws, F0, n0, F1, n1, dim, "lr_gpf"));
+    forget_last_batch(ws);
     LR_REQUIRE(idx1 && idx2 && xyz0 && o0 && o1, LR_EINVAL, "lr_gpf: null pointer");
     hipStream_t st = (hipStream_t)stream;
     pad_if_narrow(ws, F0, n0, F1, n1, dim, st);
@@ -432,6 +439,7 @@ extern "C" int lr_gpf_bb_first(lr_workspace *ws, const float *F0, int n0, const 
                                void *stream)
 {
     LR_TRY(check_nn_args(ws, F0, n0, F1, n1, dim, "lr_gpf_bb_first"));
+    forget_last_batch(ws);
     LR_REQUIRE(idx1 && idx2 && xyz0 && o0 && o1 && o2 && n_out && has_score, LR_EINVAL, "lr_gpf_bb_first: null pointer");
     hipStream_t st = (hipStream_t)stream;
     pad_if_narrow(ws, F0, n0, F1, n1, dim, st);
@@ -449,6 +457,7 @@ extern "C" int lr_ransac(lr_workspace *ws, const float *src, const float *tgt, i
 {
     LR_REQUIRE(ws && src && tgt && p && T_out && res, LR_EINVAL, "lr_ransac: null pointer");
     LR_TRY(check_ransac_params(p, "lr_ransac"));
+    forget_last_batch(ws);
     LR_REQUIRE(m >= 0 && m <= ws->max_n0, LR_ESIZE, "lr_ransac: m exceeds the workspace");
     hipStream_t st = (hipStream_t)stream;
     LR_TRY(lr_pack_corr(ws, src, tgt, nullptr, nullptr, m, m_dev, ws->corr8, st));
@@ -494,6 +503,7 @@ extern "C" int lr_icp(lr_workspace *ws, const float *xyz0, int n0, const float *
 {
     LR_REQUIRE(ws && xyz0 && xyz1 && T_init && T_out, LR_EINVAL, "lr_icp: null pointer");
     LR_REQUIRE(n0 > 0 && n0 <= ws->max_n0 && n1 > 0 && n1 <= ws->max_n1, LR_ESIZE, "lr_icp: cloud exceeds the workspace");
+    forget_last_batch(ws);          // (the ICP scratch and the result temporaries are overwritten)
     return lr_icp_run(ws, xyz0, n0, xyz1, n1, T_init, nullptr, max_dist, max_iter, rel_fitness, rel_rmse, T_out, res, (hipStream_t)stream);
 }
 
@@ -505,8 +515,11 @@ __global__ void pair_icp_kernel(const double *__restrict__ T_icp, const lr_icp_r
 extern "C" int lr_icp_batch(lr_workspace *ws, double max_dist, int max_iter, double rel_fitness, double rel_rmse, lr_pair_result *out, void *stream)
 {
     LR_REQUIRE(ws && out, LR_EINVAL, "lr_icp_batch: null pointer");
-    LR_REQUIRE(ws->last_batch && ws->last_npairs >= 1 && ws->last_T_final, LR_EINVAL, "lr_icp_batch: the last registration call on this workspace was not lr_register_batch");
+    LR_REQUIRE(ws->last_batch && ws->last_npairs >= 1 && ws->last_T_final, LR_EINVAL,
+               "lr_icp_batch: no successful lr_register_batch on this workspace since the last call that touched its scratch");
     hipStream_t st = (hipStream_t)stream;
+    // the transforms it starts from are written by the registration call's stream: the ICP must be ordered behind it
+    LR_REQUIRE(st == ws->last_stream, LR_EINVAL, "lr_icp_batch: must be enqueued on the stream of the lr_register_batch call it continues");
     ws->zP = ws->last_npairs; ws->z = lr_zargs{ ws->stride, ws->descs };
     lr_icp_result *icp_res = reinterpret_cast<lr_icp_result *>(ws->icp_state + 24);
     int rc = lr_icp_run(ws, nullptr, ws->last_mx0, nullptr, ws->last_mx1, ws->last_T_final, ws->res_tmp, max_dist, max_iter, rel_fitness, rel_rmse,
@@ -666,8 +679,9 @@ extern "C" int lr_register_batch(lr_workspace *ws, int npairs, const float *cons
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(batch_setup_kernel, dim3(1), dim3(64), 0, st, t, ws->descs, npairs);
     ws->zP = npairs; ws->z = lr_zargs{ ws->stride, ws->descs };
-    ws->last_npairs = npairs; ws->last_batch = 1;
+    ws->last_npairs = npairs; forget_last_batch(ws);
     const int rc = register_stages(ws, xyz0[0], xyz1[0], F0[0], F1[0], mx0, mx1, dim, p, out, st);
     ws->zP = 1; ws->z = lr_zargs{ 0, nullptr };
+    if (rc == LR_OK) { ws->last_batch = 1; ws->last_stream = st; } else ws->last_T_final = nullptr;      // (lr_icp_batch: only after a call that went through)
     return rc;
 }

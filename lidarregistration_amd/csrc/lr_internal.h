@@ -92,6 +92,7 @@ struct lr_workspace {
     int last_batch;              // 1: that call was lr_register_batch (descs[] still describes its pairs: lr_icp_batch)
     int last_mx0, last_mx1;      // largest cloud sizes of that call (they size the grids of a follow-up stage)
     const double *last_T_final;  // arena-0 pointer of that call's final transform (T_tmp or T_tmp + 16)
+    hipStream_t last_stream;     // the stream that call ran on (lr_icp_batch must follow on the same one)
     size_t stride;               // bytes per arena
     size_t bytes;
     char *base;                  // one hipMalloc

@@ -112,7 +112,9 @@ nn16_prep_kernel(const float *__restrict__ Fa, int na, _Float16 *__restrict__ Ha
     }
     // largest norm of the block (32 rows) -> block_max[blockIdx.x]; the threshold kernel reduces that short array
     // (no same-address atomics: thousands of them serialise at ~12 ns each)
-    float m = live ? norm : 0.0f, mn = live ? norm : LR_INF;      // (a NaN norm drops out of fmaxf / fminf: such rows are re-done exactly anyway)
+    // (a NaN norm drops out of fmaxf: such rows are re-done exactly anyway.  For the minimum a norm that is not finite -- NaN, or an
+    // overflowing sum -- counts as 0: the sign form of the walk's test, which needs all norms alike, is then not selected)
+    float m = live ? norm : 0.0f, mn = live ? ((norm - norm == 0.0f) ? norm : 0.0f) : LR_INF;
 #pragma unroll
     for (int k = 32; k >= 1; k >>= 1) { m = fmaxf(m, __shfl_xor(m, k)); mn = fminf(mn, __shfl_xor(mn, k)); }
     if (lane == 0) { s_m[threadIdx.x >> 6] = m; s_n[threadIdx.x >> 6] = mn; }
@@ -301,11 +303,12 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     // y_i - xhat + dot16 >= 0 is then NECESSARY for a hit (x_j >= xhat), a sign test: the AND of 8 sign bits, three v_bitop3_b32 + one
     // v_and_b32 at the full vector rate instead of three v_max3_f32 + one v_max_f32 at half rate, and no per-column operand.  It admits
     // a few pairs more (those between xhat and x_j); derive() applies the exact x_j to every hit anyway.  With spread-out norms that
-    // slack would flood the hit lists, so SIGN = false compares with x_j itself (xhat = 0).  (NaN or non-positive norms compare
-    // false: the plain test.)
+    // slack would flood the hit lists, so SIGN = false compares with x_j itself (xhat = 0).  (A NaN, infinite, overflowing or
+    // non-positive norm anywhere in the column cloud: the plain test -- the prep kernel reports such a norm as a minimum of 0, and
+    // an infinite maximum fails `max_nc < inf`; with `inf - min <= 1e-4 inf` alone one overflowing column selected the sign form.)
     float max_nc = 0.0f, min_nc = 0.0f;
     if (thr.range_c) { max_nc = thr.range_c[0]; min_nc = thr.range_c[1]; }
-    const bool sign_ok = thr.range_c != nullptr && min_nc > 0.0f && max_nc - min_nc <= 1e-4f * max_nc && !(LR_PB_EXP & 128);
+    const bool sign_ok = thr.range_c != nullptr && min_nc > 0.0f && max_nc < LR_INF && max_nc - min_nc <= 1e-4f * max_nc && !(LR_PB_EXP & 128);
     if (sign_ok != SIGN) return;
     const float xhat = SIGN ? 0.5f * min_nc : 0.0f;
     __shared__ int s_limit[4];

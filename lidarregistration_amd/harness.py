@@ -328,129 +328,143 @@ def eval_pairs(source, indices, args, device=None, batch=32, in_flight=6, nstrea
         from concurrent.futures import ThreadPoolExecutor
         pool = ThreadPoolExecutor(max_workers=int(workers))
     ahead = [pool.submit(source.load_host, indices[row]) for row in range(0, min(window, n))] if pool else None
-    for w0 in range(0, n, window):
-        rows_w = list(range(w0, min(w0 + window, n)))
-        # ---- A: data
-        t0 = time.time()
-        if pool:
-            mine, ahead = ahead, [pool.submit(source.load_host, indices[row]) for row in range(w0 + window, min(w0 + 2 * window, n))]
-            try:
-                ps = [source.finish(f.result(), dev) for f in mine]
-            except BaseException:          # a missing / mismatching file: stop the readers of the next window before the error leaves
-                for f in ahead:
-                    f.cancel()
-                pool.shutdown(wait=True)
-                raise
-        else:
-            ps = [source.get_dev(indices[row], dev) for row in rows_w]
-        torch.cuda.synchronize(dev)
-        t_data = time.time() - t0
-        totals["data_s"] += t_data
-        groups = []
-        for i, g0 in enumerate(range(0, len(rows_w), batch)):
-            sl = slice(g0, min(g0 + batch, len(rows_w)))
-            gp = ps[sl]
-            n0s = [int(p["feats0"].shape[0]) for p in gp]; n1s = [int(p["feats1"].shape[0]) for p in gp]
-            d = int(gp[0]["feats0"].shape[1])
-            if wss[i] is None or not wss[i].fits(max(n0s), max(n1s), params.ransac.iters):
-                if wss[i] is not None:
-                    wss[i].close()
-                ragged = len(set(n0s + n1s)) > 1          # real data: leave headroom for the next windows
-                wss[i] = _ext.Workspace(int(max(n0s) * (1.25 if ragged else 1)), int(max(n1s) * (1.25 if ragged else 1)), d, params.ransac.iters, max_pairs=batch)
-                seen[i] = None
-            k_big = int(np.argmax(n0s))
-            fresh = fr.share_key(n0s[k_big], n1s[k_big], dev) not in fr._SHARE
-            share = fr.second_nn_share(gp[k_big]["feats0"], gp[k_big]["feats1"], wss[i])      # (the GPU is idle here: calibrated once per size class)
-            if fresh or seen[i] is None:
-                torch.cuda.synchronize(dev)
-                wss[i].timing(True); seen[i] = [0.0] * 6
-            groups.append(dict(rows=rows_w[sl], ps=gp, n0=n0s, n1=n1s, share=share, slot=i,
-                               out=torch.empty((len(gp), size), dtype=torch.uint8, device=dev)))
-        torch.cuda.synchronize(dev)
-        for st in streams:
-            st.wait_stream(cur)
-        # ---- B: registration
-        t0 = time.time()
-        for g in groups:
-            st = streams[g["slot"] % nstreams]
-            chunk = [(p["xyz0"], p["xyz1"], p["feats0"], p["feats1"]) for p in g["ps"]]
-            fr.register_batch_dev(chunk, params, out=g["out"], ws=wss[g["slot"]], stream=st.cuda_stream)
-            W = max(g["n0"]); B = len(chunk)
-            with torch.cuda.stream(st):
-                g["nn1"] = torch.empty((B, W), dtype=torch.int32, device=dev); g["c0"] = torch.empty_like(g["nn1"]); g["c1"] = torch.empty_like(g["nn1"])
-            _ext.check(lib.lr_workspace_lists_batch(wss[g["slot"]].handle, B, W, g["nn1"].data_ptr(), None, g["c0"].data_ptr(), g["c1"].data_ptr(), st.cuda_stream))
-        for st in streams:
-            st.synchronize()
-        t_reg = time.time() - t0
-        totals["registration_s"] += t_reg
-        # ---- C: ICP
-        t_icp = 0.0
-        if want_icp:
+    # Whatever ends the loop -- a file that cannot be read, a failing library call, out of memory, Ctrl-C -- the readers of the next
+    # window are stopped and every workspace is released on the way out (they would otherwise keep reading files and holding device
+    # memory until the interpreter exits)
+    try:
+        for w0 in range(0, n, window):
+            rows_w = list(range(w0, min(w0 + window, n)))
+            # ---- A: data
+            t0 = time.time()
+            if pool:
+                mine, ahead = ahead, [pool.submit(source.load_host, indices[row]) for row in range(w0 + window, min(w0 + 2 * window, n))]
+                ps = [source.finish(f.result(), dev) for f in mine]      # (a missing / mismatching file raises here: the finally below stops the readers)
+            else:
+                ps = [source.get_dev(indices[row], dev) for row in rows_w]
+            torch.cuda.synchronize(dev)
+            t_data = time.time() - t0
+            totals["data_s"] += t_data
+            groups = []
+            for i, g0 in enumerate(range(0, len(rows_w), batch)):
+                sl = slice(g0, min(g0 + batch, len(rows_w)))
+                gp = ps[sl]
+                n0s = [int(p["feats0"].shape[0]) for p in gp]; n1s = [int(p["feats1"].shape[0]) for p in gp]
+                d = int(gp[0]["feats0"].shape[1])
+                if wss[i] is None or not wss[i].fits(max(n0s), max(n1s), params.ransac.iters):
+                    if wss[i] is not None:
+                        wss[i].close()
+                    ragged = len(set(n0s + n1s)) > 1          # real data: leave headroom for the next windows
+                    wss[i] = _ext.Workspace(int(max(n0s) * (1.25 if ragged else 1)), int(max(n1s) * (1.25 if ragged else 1)), d, params.ransac.iters, max_pairs=batch)
+                    seen[i] = None
+                k_big = int(np.argmax(n0s))
+                fresh = fr.share_key(n0s[k_big], n1s[k_big], dev) not in fr._SHARE
+                share = fr.second_nn_share(gp[k_big]["feats0"], gp[k_big]["feats1"], wss[i])      # (the GPU is idle here: calibrated once per size class)
+                if fresh or seen[i] is None:
+                    torch.cuda.synchronize(dev)
+                    wss[i].timing(True); seen[i] = [0.0] * 6
+                groups.append(dict(rows=rows_w[sl], ps=gp, n0=n0s, n1=n1s, share=share, slot=i,
+                                   out=torch.empty((len(gp), size), dtype=torch.uint8, device=dev)))
+            torch.cuda.synchronize(dev)
+            for st in streams:
+                st.wait_stream(cur)
+            # ---- B: registration
             t0 = time.time()
             for g in groups:
-                _ext.check(lib.lr_icp_batch(wss[g["slot"]].handle, 2 * fr.VOXEL_SIZE, 30, 1e-6, 1e-6, g["out"].data_ptr(), streams[g["slot"] % nstreams].cuda_stream))
+                st = streams[g["slot"] % nstreams]
+                chunk = [(p["xyz0"], p["xyz1"], p["feats0"], p["feats1"]) for p in g["ps"]]
+                fr.register_batch_dev(chunk, params, out=g["out"], ws=wss[g["slot"]], stream=st.cuda_stream)
+                W = max(g["n0"]); B = len(chunk)
+                with torch.cuda.stream(st):
+                    g["nn1"] = torch.empty((B, W), dtype=torch.int32, device=dev); g["c0"] = torch.empty_like(g["nn1"]); g["c1"] = torch.empty_like(g["nn1"])
+                _ext.check(lib.lr_workspace_lists_batch(wss[g["slot"]].handle, B, W, g["nn1"].data_ptr(), None, g["c0"].data_ptr(), g["c1"].data_ptr(), st.cuda_stream))
             for st in streams:
                 st.synchronize()
-            t_icp = time.time() - t0
-            totals["icp_s"] += t_icp
-        # ---- D: statistics
-        t0 = time.time()
-        d_call = d_fwd = 0.0
-        share_w = 0.0
-        for g in groups:
-            ms, _ = wss[g["slot"]].stage_times()
-            d_call += ms[0] - seen[g["slot"]][0]; d_fwd += ms[1] - seen[g["slot"]][1]
-            share_w += g["share"] * len(g["rows"])
-            seen[g["slot"]] = ms
-        share_w /= len(rows_w)
-        f_fwd = d_fwd / d_call if d_call > 0 else 0.0
-        per_pair = t_reg / len(rows_w)
-        billed = per_pair * (1.0 - f_fwd * (1.0 - share_w))
-        for g in groups:
-            gp = g["ps"]
-            with torch.cuda.stream(streams[g["slot"] % nstreams]):
-                n_corr = g["out"][:, _NCORR_OFF:_NCORR_OFF + 4].contiguous().view(torch.int32).view(-1)
-                T_gt = np.stack([np.asarray(p["T_gt"], np.float64) for p in gp])
-                ri, rf = inlier_ratios_dev([p["xyz0"] for p in gp], [p["xyz1"] for p in gp], g["nn1"], g["c0"], g["c1"],
-                                           torch.tensor(g["n0"], dtype=torch.int32, device=dev), n_corr, T_gt)
-                hb = g["out"].cpu().numpy(); ri = ri.cpu().numpy(); rf = rf.cpu().numpy()
-            for j, row in enumerate(g["rows"]):
-                r = _ext.PairResult.from_buffer_copy(hb[j].tobytes())
-                T = np.array(r.T[:], np.float64).reshape(4, 4) if r.status == 0 else np.eye(4)
-                gt = T_gt[j]
-                re, te = metrics.rotation_error_deg(T, gt), metrics.translation_error_cm(T, gt)
-                sess, si, ti = source.ids(indices[row])
-                stats[row, 0] = float(re < metrics.RE_THRE_DEG and te < metrics.TE_THRE_CM)
-                stats[row, 1], stats[row, 2] = re, te
-                stats[row, 9] = billed
-                whole_path[row] = per_pair
-                stats[row, 10], stats[row, 11] = t_data / len(rows_w), 0.0
-                if want_icp:
-                    T_icp = np.array(r.T_icp[:], np.float64).reshape(4, 4) if r.status == 0 else np.eye(4)
-                    re_i, te_i = metrics.rotation_error_deg(T_icp, gt), metrics.translation_error_cm(T_icp, gt)
-                    stats[row, 11] = t_icp / len(rows_w)
-                    stats[row, 12] = float(re_i < metrics.RE_THRE_DEG and te_i < metrics.TE_THRE_CM)
-                    stats[row, 13], stats[row, 14] = re_i, te_i
-                stats[row, 15] = g["n0"][j]
-                stats[row, 16] = ri[j]
-                stats[row, 17] = int(r.n_corr)
-                stats[row, 18] = rf[j]
-                stats[row, 19], stats[row, 20], stats[row, 21] = sess, si, ti
-                Ts[row] = T
-        totals["stats_s"] += time.time() - t0
-        if verbose:
-            print(f"{time.strftime('%m/%d %H:%M:%S')} Finished pair:{rows_w[-1]}/{n}  ({len(rows_w) / max(t_reg, 1e-9):.0f} pairs/s in the registration region)", flush=True)
-        del ps, groups
-    torch.cuda.synchronize(dev)
-    if pool:
-        pool.shutdown(wait=True)
-    for w in wss:
-        if w is not None:
-            w.close()
+            t_reg = time.time() - t0
+            totals["registration_s"] += t_reg
+            # ---- C: ICP
+            t_icp = 0.0
+            if want_icp:
+                t0 = time.time()
+                for g in groups:
+                    _ext.check(lib.lr_icp_batch(wss[g["slot"]].handle, 2 * fr.VOXEL_SIZE, 30, 1e-6, 1e-6, g["out"].data_ptr(), streams[g["slot"] % nstreams].cuda_stream))
+                for st in streams:
+                    st.synchronize()
+                t_icp = time.time() - t0
+                totals["icp_s"] += t_icp
+            # ---- D: statistics
+            t0 = time.time()
+            d_call = d_fwd = 0.0
+            share_w = 0.0
+            for g in groups:
+                ms, _ = wss[g["slot"]].stage_times()
+                d_call += ms[0] - seen[g["slot"]][0]; d_fwd += ms[1] - seen[g["slot"]][1]
+                share_w += g["share"] * len(g["rows"])
+                seen[g["slot"]] = ms
+            share_w /= len(rows_w)
+            f_fwd = d_fwd / d_call if d_call > 0 else 0.0
+            per_pair = t_reg / len(rows_w)
+            billed = per_pair * (1.0 - f_fwd * (1.0 - share_w))
+            for g in groups:
+                gp = g["ps"]
+                with torch.cuda.stream(streams[g["slot"] % nstreams]):
+                    n_corr = g["out"][:, _NCORR_OFF:_NCORR_OFF + 4].contiguous().view(torch.int32).view(-1)
+                    T_gt = np.stack([np.asarray(p["T_gt"], np.float64) for p in gp])
+                    ri, rf = inlier_ratios_dev([p["xyz0"] for p in gp], [p["xyz1"] for p in gp], g["nn1"], g["c0"], g["c1"],
+                                               torch.tensor(g["n0"], dtype=torch.int32, device=dev), n_corr, T_gt)
+                    hb = g["out"].cpu().numpy(); ri = ri.cpu().numpy(); rf = rf.cpu().numpy()
+                for j, row in enumerate(g["rows"]):
+                    r = _ext.PairResult.from_buffer_copy(hb[j].tobytes())
+                    T = np.array(r.T[:], np.float64).reshape(4, 4) if r.status == 0 else np.eye(4)
+                    gt = T_gt[j]
+                    re, te = metrics.rotation_error_deg(T, gt), metrics.translation_error_cm(T, gt)
+                    sess, si, ti = source.ids(indices[row])
+                    stats[row, 0] = float(re < metrics.RE_THRE_DEG and te < metrics.TE_THRE_CM)
+                    stats[row, 1], stats[row, 2] = re, te
+                    stats[row, 9] = billed
+                    whole_path[row] = per_pair
+                    stats[row, 10], stats[row, 11] = t_data / len(rows_w), 0.0
+                    if want_icp:
+                        T_icp = np.array(r.T_icp[:], np.float64).reshape(4, 4) if r.status == 0 else np.eye(4)
+                        re_i, te_i = metrics.rotation_error_deg(T_icp, gt), metrics.translation_error_cm(T_icp, gt)
+                        stats[row, 11] = t_icp / len(rows_w)
+                        stats[row, 12] = float(re_i < metrics.RE_THRE_DEG and te_i < metrics.TE_THRE_CM)
+                        stats[row, 13], stats[row, 14] = re_i, te_i
+                    stats[row, 15] = g["n0"][j]
+                    stats[row, 16] = ri[j]
+                    stats[row, 17] = int(r.n_corr)
+                    stats[row, 18] = rf[j]
+                    stats[row, 19], stats[row, 20], stats[row, 21] = sess, si, ti
+                    Ts[row] = T
+            totals["stats_s"] += time.time() - t0
+            if verbose:
+                print(f"{time.strftime('%m/%d %H:%M:%S')} Finished pair:{rows_w[-1]}/{n}  ({len(rows_w) / max(t_reg, 1e-9):.0f} pairs/s in the registration region)", flush=True)
+            del ps, groups
+        torch.cuda.synchronize(dev)
+    finally:
+        if pool:
+            for f in (ahead or []):
+                f.cancel()
+            pool.shutdown(wait=True, cancel_futures=True)
+        for w in wss:
+            if w is not None:
+                w.close()
     global LAST_WHOLE_PATH, LAST_RUN
     LAST_WHOLE_PATH = whole_path
     LAST_RUN = totals
     return stats, Ts
+
+
+def stats_columns(serial):
+    """What the 22 columns of raw_stats.npy hold (layout of the reference's Experiments/test.py:96-100), written next to the file: the
+    time columns of the batched engine are per-pair SHARES of a window, not per-pair measurements."""
+    t = ("measured per pair (device events of the call, billed as FR.py:117)" if serial else
+         "ESTIMATE, identical for all rows of a window: registration wall time of the window / its pairs x the part FR.py:117 bills; depends on "
+         "--batch / --in_flight; run with --serial True for per-pair measurements comparable with the reference's column")
+    names = ["success", "RE (deg)", "TE (cm)", "(unused here) input inlier number", "(unused) input inlier ratio", "(unused) output inlier number",
+             "(unused) output inlier precision", "(unused) output inlier recall", "(unused) output inlier F1", "model_time / reg time (s): " + t,
+             "data_time (s)" + ("" if serial else ": window share"), "icp_time (s)" + ("" if serial else ": window share"), "recall_icp", "RE_icp (deg)", "TE_icp (cm)",
+             "num_pairs_init", "inlier_ratio_init", "num_pairs_filtered", "inlier_ratio_filtered", "drive / session", "t0 / source index", "t1 / target index"]
+    return "".join(f"{k}: {v}\n" for k, v in enumerate(names))
 
 
 def eval_pairs_serial(source, indices, args, device=None, in_flight=4, verbose=False):

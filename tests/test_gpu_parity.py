@@ -678,6 +678,29 @@ def test_fcgf_fast_and_dgr_callers(lr, oracle):
     assert np.abs(e1["T"] - e["T"]).max() > 1e-7
 
 
+@pytest.mark.parametrize("kind", ["inf_norm_column", "nan_column", "overflowing_row_and_column"])
+def test_nn_one_nonfinite_norm_among_unit_norm_descriptors(lr, oracle, kind):
+    """with `inf - min <= 1e-4 inf` one column whose squared norm overflows selected the SIGN form of the walk's test for a
+    cloud whose norms are not alike at all (results stayed right, the hit lists flooded).  The form is now chosen from finite norms only;
+    here: the results with such a column present."""
+    n0, n1 = 1500, 2300
+    F0, F1 = synth.make_features(n0, n1, 32, 0.5, 1.0, 91)
+    F1 = F1.copy(); F0 = F0.copy()
+    if kind == "inf_norm_column":
+        F1[777] *= np.float32(3e19)              # squared norm 9e38 > FLT_MAX: inf in fp32 (and in the f16 copy)
+    elif kind == "nan_column":
+        F1[777, 5] = np.nan
+    else:
+        F1[12] *= np.float32(3e19); F0[40] *= np.float32(3e19)
+    i1, i2, s1, s2 = lr.matching.nn_top2_dev(F0, F1, want_2nd=True, want_dist=True)
+    o1, o2, os1, os2 = oracle.nn_top2(F0, F1)
+    ok = np.ones(n0, bool)
+    if kind == "overflowing_row_and_column":
+        ok[40] = False                           # every distance of that row is inf or NaN: its order is not defined by the contract
+    assert np.array_equal(i1.cpu().numpy()[ok], o1[ok]) and np.array_equal(i2.cpu().numpy()[ok], o2[ok])
+    assert np.array_equal(_bits(s1.cpu().numpy())[ok], _bits(os1)[ok])
+
+
 def test_nn_candidate_store_overflow_falls_back_to_the_exact_scan(lr, oracle):
     """Every column identical (and many near-identical): each query row has thousands of candidates, far beyond a wave's list
     and segment -- the rows must come out of the exact full-column scan with torch.min's first-index order intact."""
