@@ -894,6 +894,13 @@ struct lo_shared {
     int wcnt[LO_MAXIT][LO_THREADS / 64];    // inliers per (step, wave) of a list-builder pass, then their offsets in the list
     int wsum[16];
     int nI, flag;
+    // near-inlier bound of a round (see lo_build_list): bounding box of the source points, how many correspondences lie within
+    // thr + LO_NEAR_CAP of the model under optimisation, whether the round's trial models may be scored over those alone
+    float box[6];
+    int box_state;                   // 0: not computed yet; 1: valid; -1: a non-finite coordinate (no bound)
+    int nNear, near_ok;
+    double eps[LO_TRIALS];
+    double baseT[12];                // the model near8 was copied around
 };
 
 __device__ __forceinline__ float lo_d2(const float *Rt, float px, float py, float pz, float qx, float qy, float qz)
@@ -910,9 +917,27 @@ __device__ __forceinline__ float lo_d2(const float *Rt, float px, float py, floa
 // scoring kernel: same fma order per component).  A pass covers LO_MAXIT * LO_THREADS records: every thread runs its LO_MAXIT steps
 // back to back (independent loads, no barrier in between), keeping the outcomes as a bit mask; the per-(step, wave) counts go to
 // LDS, one block-wide exclusive scan turns them into list offsets, and the threads write their inliers.  Four barriers per pass.
-__device__ void lo_build_list(lo_shared &sh, const float *__restrict__ corr8, int m, float thr2, int32_t *__restrict__ list)
+//
+// NEAR (OUT = 1; the rounds of mode 0): the trial models of a round are least-squares fits over subsets of the current model's inliers, i.e.
+// close to it.  For two models t, b and a correspondence (p, q):  |T_t p - q| >= |T_b p - q| - |T_t p - T_b p| >= r_b - eps_t,
+//     eps_t = |R_t - R_b|_F rho + |(R_t - R_b) c + t_t - t_b|          (c, rho: centre and half diagonal of the source points' bounding box)
+// so (p, q) can be an inlier of t only if r_b < thr + eps_t -- the bound of the pilot-ordered scoring (ransac_order_kernel) with the model
+// the optimisation started from as the pilot.  With OUT = 1 the pass copies the correspondences with r_b < (1 + LO_NEAR_CAP) thr, IN INDEX
+// ORDER, to `near8` (corr8's record layout) instead of listing the inliers, and reduces the bounding box.  Everything a round does then
+// runs over near8 alone -- about a quarter of the list on the balanced-set surrogates -- as long as every model involved stays within
+// eps + slack <= LO_NEAR_CAP thr of the base model (checked in fp64 after the fits; otherwise the round scores everything and the next
+// one starts from a fresh copy): the inlier list (the same call with OUT = 0 over near8: the same correspondences in the same order, so
+// the samples of the trials are the oracle's), the 21-point fits, and the scoring of the 20 trials (113 -> ~30 us per round).  Counts and
+// error sums are integer sums over inliers, which all lie in near8: the same integers as a scan of everything (tests/test_gpu_gc.py,
+// tools/soak_gc.py against the oracle, which scores all).
+#define LO_NEAR_CAP 0.5f
+template <int OUT>
+__device__ void lo_build_list(lo_shared &sh, const float *__restrict__ corr8, int m, float thr2, int32_t *__restrict__ list, float *__restrict__ near8 = nullptr)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool want_box = OUT == 1 && sh.box_state == 0;
+    float bmn[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, bmx[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
+    bool bad = false;
     const f32x2 R00 = { (float)sh.curT[0], (float)sh.curT[0] }, R01 = { (float)sh.curT[1], (float)sh.curT[1] }, R02 = { (float)sh.curT[2], (float)sh.curT[2] },
                 TX = { (float)sh.curT[3], (float)sh.curT[3] };
     const f32x2 R10 = { (float)sh.curT[4], (float)sh.curT[4] }, R11 = { (float)sh.curT[5], (float)sh.curT[5] }, R12 = { (float)sh.curT[6], (float)sh.curT[6] },
@@ -938,6 +963,18 @@ __device__ void lo_build_list(lo_shared &sh, const float *__restrict__ corr8, in
             const f32x2 d2 = __builtin_elementwise_fma(dx, dx, __builtin_elementwise_fma(dy, dy, dz * dz));
             const bool in0 = r < nrec && d2.x < thr2, in1 = r < nrec && 2 * r + 1 < m && d2.y < thr2;
             bits |= (unsigned long long)((in0 ? 1u : 0u) | (in1 ? 2u : 0u)) << (2 * it);
+            if (want_box && r < nrec) {
+                bmn[0] = fminf(bmn[0], A.x); bmx[0] = fmaxf(bmx[0], A.x); bmn[1] = fminf(bmn[1], A.z); bmx[1] = fmaxf(bmx[1], A.z);
+                bmn[2] = fminf(bmn[2], B.x); bmx[2] = fmaxf(bmx[2], B.x);
+                const float s0 = A.x + A.z + B.x;
+                bad = bad || !(s0 - s0 == 0.0f);
+                if (2 * r + 1 < m) {
+                    bmn[0] = fminf(bmn[0], A.y); bmx[0] = fmaxf(bmx[0], A.y); bmn[1] = fminf(bmn[1], A.w); bmx[1] = fmaxf(bmx[1], A.w);
+                    bmn[2] = fminf(bmn[2], B.y); bmx[2] = fmaxf(bmx[2], B.y);
+                    const float s1 = A.y + A.w + B.y;
+                    bad = bad || !(s1 - s1 == 0.0f);
+                }
+            }
         }
         for (int it = 0; it < nit; ++it) {
             const unsigned long long b0 = __ballot((bits >> (2 * it)) & 1ull), b1 = __ballot((bits >> (2 * it + 1)) & 1ull);
@@ -962,14 +999,47 @@ __device__ void lo_build_list(lo_shared &sh, const float *__restrict__ corr8, in
             const bool in0 = (bits >> (2 * it)) & 1ull, in1 = (bits >> (2 * it + 1)) & 1ull;
             const unsigned long long b0 = __ballot(in0), b1 = __ballot(in1);
             const int pos = sh.wcnt[it][wave] + (int)__popcll(b0 & lt) + (int)__popcll(b1 & lt);
-            const int i = 2 * (sbase + it * LO_THREADS + tid);
-            if (in0) list[pos] = i;
-            if (in1) list[pos + (in0 ? 1 : 0)] = i + 1;
+            const int r = sbase + it * LO_THREADS + tid;
+            if constexpr (OUT == 0) {
+                if (in0) list[pos] = 2 * r;
+                if (in1) list[pos + (in0 ? 1 : 0)] = 2 * r + 1;
+            } else if (in0 || in1) {
+                // (the record again: it is in L2; keeping LO_MAXIT records in registers across the scan is not an option)
+                const f32x4 *rec = reinterpret_cast<const f32x4 *>(corr8) + (size_t)r * 4;
+                const f32x4 A = rec[0], B = rec[1], C = rec[2];
+                if (in0) { const float w0[6] = { A.x, A.z, B.x, B.z, C.x, C.z };
+#pragma unroll
+                           for (int k = 0; k < 6; ++k) near8[lr_corr_at(pos, k)] = w0[k]; }
+                if (in1) { const float w1[6] = { A.y, A.w, B.y, B.w, C.y, C.w }; const int p1 = pos + (in0 ? 1 : 0);
+#pragma unroll
+                           for (int k = 0; k < 6; ++k) near8[lr_corr_at(p1, k)] = w1[k]; }
+            }
         }
         total += all;
         __syncthreads();          // (the next pass rewrites wcnt / wsum)
     }
-    if (tid == 0) sh.nI = total;
+    if (tid == 0) { if (OUT == 0) sh.nI = total; else sh.nNear = total; }
+    if (want_box) {
+        // bounding box of the source points (and "all finite"): wave shuffles, then one thread per component over the waves
+        float *scr = reinterpret_cast<float *>(&sh.red[0][0]);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { bmn[k] = fminf(bmn[k], __shfl_xor(bmn[k], o)); bmx[k] = fmaxf(bmx[k], __shfl_xor(bmx[k], o)); }
+        }
+        const bool wbad = __ballot(bad) != 0ull;
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { scr[wave * 8 + k] = bmn[k]; scr[wave * 8 + 3 + k] = bmx[k]; }
+            scr[wave * 8 + 6] = wbad ? 1.0f : 0.0f;
+        }
+        __syncthreads();
+        if (tid < 7) {
+            float v = scr[tid];
+            for (int w = 1; w < LO_THREADS / 64; ++w) v = tid < 3 ? fminf(v, scr[w * 8 + tid]) : fmaxf(v, scr[w * 8 + tid]);
+            if (tid < 6) sh.box[tid] = v; else sh.box_state = v > 0.0f ? -1 : 1;
+        }
+    }
     __syncthreads();
 }
 
@@ -1133,7 +1203,8 @@ __device__ void lo_score_lanes(lo_shared &sh, const float *__restrict__ corr8, i
 // recomputes the job alone.
 #define LO_CHUNK_REC 384
 #define LO_JOBS 16
-struct lr_lo_job { int32_t next_chunk, done_chunks, nchunks, pad; float Rt[LO_TRIALS][12]; unsigned cnt[LO_TRIALS]; unsigned long long ssq[LO_TRIALS]; };
+struct lr_lo_job { int32_t next_chunk, done_chunks, nchunks, m_near;      // m_near > 0: the job runs over that many records' worth of the near list
+                   float Rt[LO_TRIALS][12]; unsigned cnt[LO_TRIALS]; unsigned long long ssq[LO_TRIALS]; };
 struct lr_lo_ctl { int32_t phase, pad[3]; lr_lo_job job[LO_JOBS]; };      // phase: 0 nothing yet; k > 0: job k - 1 is published; -1: the master is done
 static_assert(sizeof(lr_lo_ctl) <= LR_LO_CTL_BYTES, "lr_lo_ctl does not fit its scratch block");
 
@@ -1171,14 +1242,15 @@ __device__ void lo_job_work(lo_shared &sh, lr_lo_job *jb, const float *__restric
 }
 
 // master: score sh.Rt[0 .. LO_TRIALS) over all correspondences with whoever helps -> sh.cnt / sh.ssq
-__device__ void lo_score_shared(lo_shared &sh, lr_lo_ctl *ctl, int job, const float *__restrict__ corr8, int m, float thr2, int32_t *timeouts)
+// (near_m > 0: `corr8` is the near list of the round and m = near_m its length -- the helpers are told through the job)
+__device__ void lo_score_shared(lo_shared &sh, lr_lo_ctl *ctl, int job, const float *__restrict__ corr8, int m, float thr2, int32_t *timeouts, int near_m = 0)
 {
     const int tid = threadIdx.x;
     lr_lo_job *jb = &ctl->job[job];
     const int nrec = (m + 1) >> 1;
     const int nchunks = (nrec + LO_CHUNK_REC - 1) / LO_CHUNK_REC;
     for (int k = tid; k < LO_TRIALS * 12; k += LO_THREADS) jb->Rt[k / 12][k % 12] = sh.Rt[k / 12][k % 12];
-    if (tid == 0) jb->nchunks = nchunks;
+    if (tid == 0) { jb->nchunks = nchunks; jb->m_near = near_m; }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
@@ -1214,7 +1286,7 @@ __device__ void lo_score_shared(lo_shared &sh, lr_lo_ctl *ctl, int job, const fl
 }
 
 // helper block: serves the jobs the master publishes until it says it is done (or nothing happens for 0.2 s)
-__device__ void lo_helper_loop(lo_shared &sh, lr_lo_ctl *ctl, const float *__restrict__ corr8, int m, float thr2, int32_t *timeouts)
+__device__ void lo_helper_loop(lo_shared &sh, lr_lo_ctl *ctl, const float *__restrict__ corr8, const float *__restrict__ near8, int m, float thr2, int32_t *timeouts)
 {
     const int tid = threadIdx.x;
     int seen = 0;
@@ -1238,7 +1310,9 @@ __device__ void lo_helper_loop(lo_shared &sh, lr_lo_ctl *ctl, const float *__res
         lr_lo_job *jb = &ctl->job[p - 1];
         for (int k = tid; k < LO_TRIALS * 12; k += LO_THREADS) sh.Rt[k / 12][k % 12] = jb->Rt[k / 12][k % 12];
         __syncthreads();
-        lo_job_work(sh, jb, corr8, m, thr2);
+        const int mj = jb->m_near;           // (written before the job was published)
+        if (mj > 0) lo_job_work(sh, jb, near8, mj, thr2);
+        else lo_job_work(sh, jb, corr8, m, thr2);
     }
 }
 
@@ -1266,11 +1340,11 @@ __device__ void lo_score_wide(lo_shared &sh, const float *__restrict__ corr8, in
 }
 
 __device__ __forceinline__ void lo_score(lo_shared &sh, const float *__restrict__ corr8, int m, float thr2, int ntrial, lr_lo_ctl *ctl = nullptr, int job = -1,
-                                         int32_t *timeouts = nullptr)
+                                         int32_t *timeouts = nullptr, int near_m = 0)
 {
     // 32-bit per-thread error sums hold when (correspondences per thread) * thr2 * 2^20 < 2^32
     if (ntrial > 1) {      // (lanes of trials >= ntrial score stale models nobody reads)
-        if (ctl && job >= 0 && job < LO_JOBS) lo_score_shared(sh, ctl, job, corr8, m, thr2, timeouts);
+        if (ctl && job >= 0 && job < LO_JOBS) lo_score_shared(sh, ctl, job, corr8, m, thr2, timeouts, near_m);
         else lo_score_lanes(sh, corr8, m, thr2);
         return;
     }
@@ -1297,17 +1371,17 @@ extern "C" __attribute__((visibility("default"))) int lr_debug_lo_probe(unsigned
 __global__ void __launch_bounds__(LO_THREADS)
 ransac_lo_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__restrict__ m_dev, lr_ransac_params p, int h_end, int mode,
                  int32_t *__restrict__ counters, int32_t *__restrict__ list, double *__restrict__ T_out, lr_ransac_result *__restrict__ res,
-                 lr_lo_ctl *__restrict__ ctl, lr_zargs z)
+                 lr_lo_ctl *__restrict__ ctl, float *__restrict__ near8, lr_zargs z)
 {
     lr_z(corr8, z, blockIdx.z); lr_z(m_dev, z, blockIdx.z); lr_z(counters, z, blockIdx.z); lr_z(list, z, blockIdx.z); lr_z(T_out, z, blockIdx.z);
-    lr_z(res, z, blockIdx.z); lr_z(ctl, z, blockIdx.z);
+    lr_z(res, z, blockIdx.z); lr_z(ctl, z, blockIdx.z); lr_z(near8, z, blockIdx.z);
     __shared__ lo_shared sh;
     lr_ransac_state *state = reinterpret_cast<lr_ransac_state *>(counters + LR_CNT_COUNT);
     const int m = m_dev ? min(*m_dev, m_max) : m_max;
     const int tid = threadIdx.x;
     const bool helpers = gridDim.x > 1 && mode == 0;              // blocks 1.. of the pair's group serve the master's scoring jobs
     if (blockIdx.x > 0) {
-        if (helpers && m > 0) lo_helper_loop(sh, ctl, corr8, m, p.thr2, &state->lo_timeouts);
+        if (helpers && m > 0) lo_helper_loop(sh, ctl, corr8, near8, m, p.thr2, &state->lo_timeouts);
         return;
     }
     // (every way out of the master tells the helpers: they must not wait for jobs that never come)
@@ -1325,9 +1399,27 @@ ransac_lo_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__re
     const int call = state->lo_calls;
     __syncthreads();
     if (mode == 0) {
+        // near8: the correspondences within (1 + LO_NEAR_CAP) thr of the base model, in index order (lo_build_list<1>); while every
+        // model involved stays within the cap of the base, a round runs over near8 alone
+        const float thr = sqrtf(p.thr2);
+        const float thr_near = thr * (1.0f + LO_NEAR_CAP), thr2_near = thr_near * thr_near * 1.000001f;
+        const bool near_on = near8 != nullptr && m >= 4096;          // (short lists: nothing to gain)
+        if (tid == 0) { sh.box_state = 0; sh.near_ok = 0; sh.nNear = 0; }
+        __syncthreads();
+        bool have_near = false;
         for (int round = 0; round < p.lo_rounds; ++round) {
             LO_COUNT(8);
-            lo_build_list(sh, corr8, m, p.thr2, list);
+            const float *cc = corr8; int mm = m;          // what this round's list, fits (and, eps permitting, scoring) run over
+            if (near_on) {
+                if (!have_near) {
+                    if (tid < 12) sh.baseT[tid] = sh.curT[tid];
+                    lo_build_list<1>(sh, corr8, m, thr2_near, nullptr, near8);
+                    have_near = sh.box_state == 1 && sh.nNear > 0;
+                    LO_COUNT(13);
+                }
+                if (have_near) { cc = near8; mm = sh.nNear; }
+            }
+            lo_build_list<0>(sh, cc, mm, p.thr2, list);
             LO_TICK(0);
             const int nI = sh.nI;
             if (nI <= p.sample_size) break;
@@ -1359,7 +1451,7 @@ ransac_lo_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__re
                         if (j < LO_SAMPLE) {
                             const int i = list[mine];
 #pragma unroll
-                            for (int a = 0; a < 6; ++a) sh.pts[t][j][a] = corr8[lr_corr_at(i, a)];
+                            for (int a = 0; a < 6; ++a) sh.pts[t][j][a] = cc[lr_corr_at(i, a)];
                         }
                     }
                 }
@@ -1384,11 +1476,38 @@ ransac_lo_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__re
                     double T[16];
                     lr_rt_from_cov(H, cp, cq, T);
                     for (int k = 0; k < 12; ++k) { sh.T[tid][k] = T[k]; sh.Rt[tid][k] = (float)T[k]; }
+                    // how far this trial can move a source point away from where the model under optimisation puts it (fp64; see lo_build_list)
+                    double e = 1.0e300;
+                    if (have_near) {
+                        const double cx = 0.5 * ((double)sh.box[0] + (double)sh.box[3]), cy = 0.5 * ((double)sh.box[1] + (double)sh.box[4]), cz = 0.5 * ((double)sh.box[2] + (double)sh.box[5]);
+                        const double ex = (double)sh.box[3] - (double)sh.box[0], ey = (double)sh.box[4] - (double)sh.box[1], ez = (double)sh.box[5] - (double)sh.box[2];
+                        const double rho = 0.5 * sqrt(ex * ex + ey * ey + ez * ez) * 1.0001 + 1e-6;
+                        double d[12], F2 = 0.0;
+                        for (int k = 0; k < 12; ++k) d[k] = T[k] - sh.baseT[k];
+                        for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) F2 += d[4 * a + b] * d[4 * a + b];
+                        const double ux = d[0] * cx + d[1] * cy + d[2] * cz + d[3], uy = d[4] * cx + d[5] * cy + d[6] * cz + d[7], uz = d[8] * cx + d[9] * cy + d[10] * cz + d[11];
+                        const double amax = fmax(fmax(fmax(fabs((double)sh.box[0]), fabs((double)sh.box[3])), fmax(fabs((double)sh.box[1]), fabs((double)sh.box[4]))),
+                                                 fmax(fabs((double)sh.box[2]), fabs((double)sh.box[5])));
+                        // (the slack of the pilot-ordered scoring: 1 cm + 4e-6 of the coordinate magnitude, two orders above the fp32 rounding of both residuals)
+                        const double slack = 0.01 + 4e-6 * (3.0 * amax + fabs(T[3]) + fabs(T[7]) + fabs(T[11]) + fabs(sh.baseT[3]) + fabs(sh.baseT[7]) + fabs(sh.baseT[11]));
+                        e = (sqrt(F2) * rho + sqrt(ux * ux + uy * uy + uz * uz)) * 1.001 + slack;
+                    }
+                    sh.eps[tid] = e;          // (NaN from a degenerate fit fails the comparison below: the round scores everything)
                 }
                 __syncthreads();
-            } else if (!lo_fit_all(sh, corr8, list, nI)) break;
+                if (tid == 0) {
+                    bool ok = have_near;
+                    for (int t = 0; t < ntrial && ok; ++t) ok = sh.eps[t] <= (double)(LO_NEAR_CAP * thr);
+                    sh.near_ok = ok ? 1 : 0;
+                }
+                __syncthreads();
+            } else {
+                if (tid == 0) { sh.near_ok = 0; sh.eps[0] = 1.0e300; }      // (one fit over all inliers: not bounded, scored over everything)
+                if (!lo_fit_all(sh, cc, list, nI)) break;
+            }
             LO_TICK(1);
-            lo_score(sh, corr8, m, p.thr2, ntrial, helpers ? ctl : nullptr, round, &state->lo_timeouts);
+            if (sh.near_ok) { LO_COUNT(12); lo_score(sh, near8, sh.nNear, p.thr2, ntrial, helpers ? ctl : nullptr, round, &state->lo_timeouts, sh.nNear); }
+            else lo_score(sh, corr8, m, p.thr2, ntrial, helpers ? ctl : nullptr, round, &state->lo_timeouts);
             LO_TICK(2);
             if (tid == 0) {
                 int bt = -1; unsigned bc = 0; unsigned long long bq = 0;
@@ -1403,11 +1522,14 @@ ransac_lo_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__re
             __syncthreads();
             LO_TICK(3);
             if (sh.flag < 0) break;
+            // the next round may keep running over near8 only if the model it optimises lies within the cap of the base model
+            // (its inliers are then all in near8); else it starts from a fresh copy around that model
+            have_near = have_near && sh.eps[sh.flag] <= (double)(LO_NEAR_CAP * thr);
         }
     } else {
         for (int it = 0; it < LO_POLISH; ++it) {
             LO_COUNT(11);
-            lo_build_list(sh, corr8, m, p.thr2, list);
+            lo_build_list<false>(sh, corr8, m, p.thr2, list);
             LO_TICK(4);
             const int nI = sh.nI;
             if (nI <= p.sample_size || !lo_fit_all(sh, corr8, list, nI)) break;
@@ -1587,12 +1709,13 @@ int lr_ransac_run(lr_workspace *ws, const float *corr8, int m_max, const int32_t
                            sprt ? (const int32_t *)ws->model_h2 : (const int32_t *)ws->model_h, sprt ? (const double *)ws->models64_2 : (const double *)ws->models64,
                            ws->counters, m_max, m_dev, *p, h1, T_out, res, vslot, lo_groups > 1 ? reinterpret_cast<int32_t *>(ws->lo_ctl) : (int32_t *)nullptr, ws->z);
         if (p->local_opt == 1)
+            // (near8 = the scratch of the pilot-ordered scoring: this batch's scoring is over, the next batch's scatter pass rewrites it before it is read)
             hipLaunchKernelGGL(ransac_lo_kernel, dim3(lo_groups, 1, ws->zP), dim3(LO_THREADS), 0, st, corr8, m_max, m_dev, *p, h1, 0, ws->counters, ws->lo_list,
-                               T_out, res, reinterpret_cast<lr_lo_ctl *>(ws->lo_ctl), ws->z);
+                               T_out, res, reinterpret_cast<lr_lo_ctl *>(ws->lo_ctl), ws->corr8s, ws->z);
     }
     if (p->local_opt)          // final iterated least squares over the inliers
         hipLaunchKernelGGL(ransac_lo_kernel, dim3(1, 1, ws->zP), dim3(LO_THREADS), 0, st, corr8, m_max, m_dev, *p, p->iters, 1, ws->counters, ws->lo_list,
-                           T_out, res, reinterpret_cast<lr_lo_ctl *>(ws->lo_ctl), ws->z);
+                           T_out, res, reinterpret_cast<lr_lo_ctl *>(ws->lo_ctl), (float *)nullptr, ws->z);
     LR_LAUNCH_CHECK();
     return LR_OK;
 }

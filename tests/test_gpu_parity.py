@@ -434,7 +434,7 @@ def test_FR_prosac_matches_oracle_pipeline(lr, oracle, mode, N, iters):
 
 def test_errors_are_loud(lr):
     with pytest.raises(lr.ext.LidarRegError):
-        lr.matching.nn_top2_dev(np.zeros((10, 16), np.float32), np.zeros((10, 16), np.float32))
+        lr.matching.nn_top2_dev(np.zeros((10, 33), np.float32), np.zeros((10, 33), np.float32))      # wider than 32: refused (1..32 are served, tests/test_gpu_dims.py)
 
 
 # ----------------------------------------------------------------------------- f16 filter robustness (error bound, fallbacks)

@@ -32,7 +32,7 @@ for serial in (1, 6):
     v = [int(x) for x in buf]
     n = len(rows)
     us = lambda t: t / 100.0
-    print(f"list {which}: {n} pairs, {serial} call(s) in flight; LO launches mode0 {v[9]} (pair-blocks), final {v[10]}; rounds {v[8]}, polish iterations {v[11]}")
+    print(f"list {which}: {n} pairs, {serial} call(s) in flight; LO launches mode0 {v[9]} (pair-blocks), final {v[10]}; rounds {v[8]} ({v[12]} scored over the near list only, {v[13]} near-list copies), polish iterations {v[11]}")
     names = ["build list", "sample + fit", "score 20", "select", "polish: build list", "polish: fit all", "polish: score 1"]
     for k, nm in enumerate(names):
         cnt = v[8] if k < 4 else v[11]
