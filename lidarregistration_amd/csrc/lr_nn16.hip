@@ -113,8 +113,11 @@ nn16_prep_kernel(const float *__restrict__ Fa, int na, _Float16 *__restrict__ Ha
     // largest norm of the block (32 rows) -> block_max[blockIdx.x]; the threshold kernel reduces that short array
     // (no same-address atomics: thousands of them serialise at ~12 ns each)
     // (a NaN norm drops out of fmaxf: such rows are re-done exactly anyway.  For the minimum a norm that is not finite -- NaN, or an
-    // overflowing sum -- counts as 0: the sign form of the walk's test, which needs all norms alike, is then not selected)
-    float m = live ? norm : 0.0f, mn = live ? ((norm - norm == 0.0f) ? norm : 0.0f) : LR_INF;
+    // overflowing sum -- counts as -1: the range kernel's minimum is then negative, which tells the filter pass not to select the sign
+    // form of its test (it needs all norms alike) and the exact kernel to re-do EVERY row of the other cloud by the full scan: a NaN
+    // column is every row's nearest neighbour under the contract -- fmaxf(NaN, 1e-30) is 1e-30, torch.min returns the NaN -- and no
+    // filter value says so)
+    float m = live ? norm : 0.0f, mn = live ? ((norm - norm == 0.0f) ? norm : -1.0f) : LR_INF;
 #pragma unroll
     for (int k = 32; k >= 1; k >>= 1) { m = fmaxf(m, __shfl_xor(m, k)); mn = fminf(mn, __shfl_xor(mn, k)); }
     if (lane == 0) { s_m[threadIdx.x >> 6] = m; s_n[threadIdx.x >> 6] = mn; }
@@ -207,7 +210,7 @@ __device__ __forceinline__ int lr_lds_off(int j, int p) { return j * LR_LDS_ROW 
 #define LR_PB_EXP 0     // development switches (tools/pb_micro.hip): 1 no staging, 2 no tests, 4 no tightening, 8 clock probe, 16 hit statistics, 128 plain test only
 #endif
 #ifndef LR_PB_WLIST
-#define LR_PB_WLIST 512          // entries per wave (12 bytes each)
+#define LR_PB_WLIST 512          // entries per wave (8 bytes each)
 #endif
 // Entry of a hit list / of the candidate store (8 bytes): x = column (22 bits) | kb << 22 | LR_PB_HASG; y = 16-bit row mask | g16 << 16.
 // kb = lane / 16 of the lane that saw the hit: bit b = 4 rbk + g of the mask <-> row 16 rbk + 4 kb + g of the wave (the lane's 16
@@ -233,7 +236,8 @@ __device__ __forceinline__ int lr_lds_off(int j, int p) { return j * LR_LDS_ROW 
 #define LR_PB_GEO_CAP 192
 #endif
 #ifndef LR_PB_P1FOLD
-#define LR_PB_P1FOLD 0           // 1: phase 1 (SIGN form) keeps elementwise running maxima of the accumulators (16 v_max3 per tile instead of 32 half-rate ops)
+#define LR_PB_P1FOLD 1           // 1: phase 1 (SIGN form) keeps elementwise running maxima of the accumulators (16 v_max3 per tile instead of 32 half-rate ops, no
+                                 // per-tile column operand in LDS); same time as the per-tile fold (round 5, profiles/r05_pb_ablation.txt), 1 % more entries per row
 #endif
 
 // row (0..63 of the wave) of mask bit b (0..15) of an entry of lane group kb
@@ -314,10 +318,11 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     __shared__ int s_limit[4];
     constexpr int CH = LR_PB_CH;
     constexpr int XOFF = CH * 32 * LR_LDS_ROW;
-    constexpr int BUF = XOFF + CH * 32 * 4;
+    constexpr int BUF = XOFF + ((SIGN && LR_PB_P1FOLD) ? 0 : CH * 32 * 4);      // (the sign form stages no per-column operand, in either phase)
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
-    __shared__ uint2 wlist[4][LR_PB_WLIST];   // per wave: entries as above (mask empty until derive() has seen the entry)
-    __shared__ float whval[4][LR_PB_WLIST];   //           filter value g of a single-row entry (LR_PB_HASG)
+    // (with 8-tile chunks the plain form, which also stages x_j, gives up an eighth of its list to stay at three blocks per CU)
+    constexpr int WL = (LR_PB_CH >= 8 && !SIGN) ? (LR_PB_WLIST * 7) / 8 : LR_PB_WLIST;
+    __shared__ uint2 wlist[4][WL];   // per wave: entries as above (mask empty until derive() has seen the entry)
     // per row of the block: y = tau/2 (what the accumulators start from), the row's error term, the two largest g of the walk
     __shared__ __attribute__((aligned(16))) float s_Y[LR_BLOCK_ROWS];
     __shared__ float s_D[LR_BLOCK_ROWS], s_N1[LR_BLOCK_ROWS], s_N2[LR_BLOCK_ROWS];
@@ -567,33 +572,37 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
 #if LR_PB_EXP & 16
     tk_walk = __builtin_amdgcn_s_memrealtime();
 #endif
-    // staging of the walk: buffer loads -- the chunk's position is a scalar offset, the thread's place in it a constant vector
-    // offset (no address arithmetic on the vector pipe), and rows past the end of the cloud read as zeros (range check of the
-    // buffer descriptor) instead of being clamped: their x_j is +inf below, so they never pass the test.  Thread t moves the two
-    // adjacent 16-byte pieces 2 (t & 1), 2 (t & 1) + 1 of column t >> 1 of the chunk.
-    static_assert(CH % 4 == 0, "the staging maps 256 threads onto groups of 128 columns x 2 halves");
+    // Staging of the walk: buffer loads STRAIGHT INTO LDS (buffer_load_dwordx4 ... lds: no staging registers, no ds_write; the chunk's
+    // position is a scalar offset; rows past the end of the cloud read as zeros through the range check of the buffer descriptor, and
+    // whatever such a column -- or a column past the end of the strip -- makes of the test is masked by derive() and flush()).
+    // A wave instruction of 64 lanes x 16 bytes fills 1 KB of LDS from M0 onwards in lane order = 16 columns; the XOR swizzle of the
+    // LDS image is folded into the lane's GLOBAL address: lane L fetches piece (L & 3) ^ ((L >> 3) & 3) of column L >> 2 of its group.
+    // Wave w owns the groups w NQ .. w NQ + NQ - 1 of a chunk; consecutive groups are 1 KB apart in both address spaces (the
+    // instruction's offset field applies to both).  The loads of chunk c + 2 are issued right behind the barrier of chunk c (every read
+    // of the buffer they go to was complete before that barrier) and awaited -- vmcnt(0) -- before the barrier of chunk c + 1.
+    static_assert(CH % 4 == 0, "the staging maps 4 waves onto groups of 16 columns");
+    constexpr int NQ = CH * 2 / 4;          // 1 KB groups per wave and chunk
     const __amdgpu_buffer_rsrc_t rsrcH = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(Hc), 0, nb * 64, 0x27000);
     const __amdgpu_buffer_rsrc_t rsrcN = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(nC), 0, nb * 4, 0x27000);
-    const int st_voff = tid * 32, st_noff = (tid & (CH * 32 - 1)) * 4;
-    const int st_lds0 = lr_lds_off(tid >> 1, 2 * (tid & 1)), st_lds1 = lr_lds_off(tid >> 1, 2 * (tid & 1) + 1);
-    auto load_chunk = [&](int c) {
+    const int ld_voff = wave * NQ * 1024 + (lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 3) & 3)) << 4);
+    const int st_noff = (tid & (CH * 32 - 1)) * 4;
+    auto load_chunk = [&](auto bufc, int c) {
+        constexpr int buf = decltype(bufc)::value;
         const int col0 = (t_begin + c * CH) * 32;       // wave-uniform
-#pragma unroll
-        for (int q = 0; q < CH / 4; ++q) {      // (groups of 128 columns)
-            stage[2 * q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcH, st_voff + q * 128 * 64, col0 * 64, 0));
-            stage[2 * q + 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcH, st_voff + q * 128 * 64 + 16, col0 * 64, 0));
+        __attribute__((address_space(3))) void *dst = (__attribute__((address_space(3))) void *)(lds + buf * BUF + wave * NQ * 1024);
+        static_assert(NQ == 2 || NQ == 4, "chunks of 4 or 8 tiles");      // (the offset field must be a literal)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcH, dst, 16, ld_voff, col0 * 64, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcH, dst, 16, ld_voff, col0 * 64, 1024, 0);
+        if constexpr (NQ == 4) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcH, dst, 16, ld_voff, col0 * 64, 2048, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcH, dst, 16, ld_voff, col0 * 64, 3072, 0);
         }
         if constexpr (!SIGN) stage_n = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrcN, st_noff, col0 * 4, 0));
     };
-    // (the buffer is a compile-time choice: its offset travels in the instruction, not through the vector pipe)
-    auto store_chunk = [&](auto bufc, int c) {
+    // the chunk's loads have landed (caller: vmcnt(0)); what is left is the plain form's x_j = n1[j]/2 (+inf masks columns past the end
+    // of the cloud or of the strip)
+    auto finish_chunk = [&](auto bufc, int c) {
         constexpr int buf = decltype(bufc)::value;
-#pragma unroll
-        for (int q = 0; q < CH / 4; ++q) {
-            *reinterpret_cast<f32x4 *>(&lds[buf * BUF + st_lds0 + q * 128 * LR_LDS_ROW]) = stage[2 * q];
-            *reinterpret_cast<f32x4 *>(&lds[buf * BUF + st_lds1 + q * 128 * LR_LDS_ROW]) = stage[2 * q + 1];
-        }
-        // x_j = n1[j]/2 ; +inf masks columns past the end of the cloud or of the strip
         if constexpr (!SIGN) {
             const int col = (t_begin + c * CH) * 32 + (tid & (CH * 32 - 1));
             const bool ok = col < nb && (col >> 5) < t_end;
@@ -633,8 +642,8 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     uint2 *__restrict__ seg = reinterpret_cast<uint2 *>(cand) + (size_t)(bx * 4 + wave) * LR_NN16_SEG + (size_t)by * seg_cap;
     int seg_fill = 0;
     const bool tightening = thr.nQ != nullptr && !(LR_PB_EXP & 4);
-    auto my_wish = [&]() { return (wcnt >= LR_PB_WLIST / 2 ? 2 : 0) | ((tightening && wcnt - wdone >= trig) ? 1 : 0); };
-    auto set_next = [&]() { wnext = tightening ? min(wdone + trig, LR_PB_WLIST / 2) : LR_PB_WLIST / 2; };      // (my_wish() != 0 <=> wcnt >= wnext)
+    auto my_wish = [&]() { return (wcnt >= WL / 2 ? 2 : 0) | ((tightening && wcnt - wdone >= trig) ? 1 : 0); };
+    auto set_next = [&]() { wnext = tightening ? min(wdone + trig, WL / 2) : WL / 2; };      // (my_wish() != 0 <=> wcnt >= wnext)
     set_next();
     // One round over the new entries [wdone, wcnt) of the wave's list (wave-local).  The slow path of the walk only parks { column,
     // register group } of a hit; WHICH of the group's 8 rows passed, and with what filter value, is worked out here, 16 entries at a
@@ -649,7 +658,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     // nn16_exact_kernel.
     auto derive = [&](bool update) {
         const int lane = cold_lane(), c16 = lane & 15, kb = lane >> 4;      // (shadow the kernel's)
-        const int nlist = min(wcnt, LR_PB_WLIST);
+        const int nlist = min(wcnt, WL);
 #if LR_PB_PRIO
         __builtin_amdgcn_s_setprio(3);      // the wave's three siblings wait for it at the next chunk barrier
 #endif
@@ -663,7 +672,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
             uint2 v[DG]; f16x8 bf[DG]; float xn[DG];
 #pragma unroll
             for (int g = 0; g < DG; ++g) {
-                v[g] = wlist[wave][min(e0 + 16 * g + c16, LR_PB_WLIST - 1)];
+                v[g] = wlist[wave][min(e0 + 16 * g + c16, WL - 1)];
                 const int col = (int)(v[g].x & LR_PB_COLMASK);
                 bf[g] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrcH, col * 64 + kb * 16, 0, 0));
                 xn[g] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrcN, col * 4, 0, 0));
@@ -699,7 +708,11 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
                         const float gv = (m - x) - s_Y[rl];
                         const float old = atomicMax(&s_N1[rl], gv);
                         atomicMax(&s_N2[rl], fminf(old, gv));
-                        whval[wave][e] = gv;
+                        // (kept rounded UP to 16 bits next to the mask: the form the candidate store carries; the drop tests -- flush() now, the
+                        // exact kernel against the final threshold -- then only ever keep more than the exact value would)
+                        const unsigned gb = __float_as_uint(gv);
+                        const unsigned up16 = (gb & 0x80000000u) ? (gb >> 16) : ((gb + 0xffffu) >> 16);      // towards +inf
+                        w.y |= up16 << 16;
                         w.x |= LR_PB_HASG;
                     }
                     wlist[wave][e] = w;
@@ -736,7 +749,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
 #if LR_PB_EXP & 16
         const unsigned long long tkf = __builtin_amdgcn_s_memrealtime();
 #endif
-        if (wcnt > LR_PB_WLIST) seg_fill = -1;       // more hits between two chunk boundaries than the list holds
+        if (wcnt > WL) seg_fill = -1;       // more hits between two chunk boundaries than the list holds
         else if (seg_fill >= 0) {
             for (int e0 = 0; e0 < wcnt; e0 += 64) {
                 const int e = e0 + lane;
@@ -747,14 +760,11 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
                 bool keep = e < wcnt && (v.y & 0xffffu) != 0u && col < nb && (col >> 5) < t_end;
                 if (v.x & LR_PB_HASG) {
                     // g of the entry against the row's threshold of NOW (candidate <=> g >= -y): what an earlier, looser threshold let
-                    // in is dropped here; what stays carries g rounded UP to 16 bits for the same test against the final threshold
-                    const float gv = whval[wave][min(e, LR_PB_WLIST - 1)];
+                    // in is dropped here (g as derive() left it: rounded UP to 16 bits); the exact kernel repeats the test against the final threshold
+                    const float gv = __uint_as_float(v.y & 0xffff0000u);
                     const int rl = wave * 64 + lr_pb_row(lr_pb_kb(v.x), __builtin_ctz((v.y & 0xffffu) | 0x8000u));
                     const float yr = s_Y[rl];
                     if (gv + 1e-5f * (fabsf(gv) + fabsf(yr)) < -yr) keep = false;
-                    const unsigned gb = __float_as_uint(gv);
-                    const unsigned up16 = (gb & 0x80000000u) ? (gb >> 16) : ((gb + 0xffffu) >> 16);      // towards +inf
-                    v.y = (v.y & 0xffffu) | (up16 << 16);
                 }
                 const unsigned long long kb = __builtin_amdgcn_ballot_w64(keep);
                 const int pos = seg_fill + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(kb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)kb, 0u));
@@ -807,7 +817,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
                 // (the column is worked out here, not on the fast path: tile is wave-uniform)
                 unsigned lc = lanecode;
                 if constexpr (!SIGN) { const int ln = cold_lane(); lc = (unsigned)(ln & 15) | ((unsigned)(ln >> 4) << 22); }      // (the plain form has no register to spare for it)
-                if (pos < LR_PB_WLIST) wlist[wave][pos] = make_uint2((unsigned)(tile * 32 + cb * 16) | lc, 0u);
+                if (pos < WL) wlist[wave][pos] = make_uint2((unsigned)(tile * 32 + cb * 16) | lc, 0u);
             }
             wcnt += __builtin_popcountll(hit);
 #if LR_PB_EXP & 16
@@ -858,13 +868,12 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         check(acc[0][1], acc[1][1], acc[2][1], acc[3][1], xC.y, tileC, 1);
     };
     if (nchunks > 0) {
-        load_chunk(0); store_chunk(c0_t{}, 0);
+        load_chunk(c0_t{}, 0);
+        __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): chunk 0 has landed (and everything older: row fragments, thresholds)
+        finish_chunk(c0_t{}, 0);
+        if (nchunks > 1) load_chunk(c1_t{}, 1);
         if (tid == 0) s_att[0] = 0u;
         __syncthreads();
-        // everything older than the prefetch below (row fragments, thresholds) is complete from here on: the loop's
-        // counted waits then only ever refer to the prefetch itself
-        __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
-        if (nchunks > 1) load_chunk(1);
         read_b(c0_t{}, 0, b0, b1, xN);
         // The walk is a loop nest: the inner loop is the hot one and contains no tightening code (the compiler then keeps the threshold
         // registers loop-invariant and its wait counts exact); it is left whenever a hit list wants attention.
@@ -892,7 +901,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
                     // chunk's own last tile), so one barrier per chunk still orders everything.
 #if !(LR_PB_EXP & 1)
 #if !(LR_PB_EXP & 32)
-                    if (!tail || c + 1 < nchunks) store_chunk(std::integral_constant<int, par ^ 1>{}, c + 1);
+                    if (!tail || c + 1 < nchunks) { __builtin_amdgcn_s_waitcnt(0x0F70); finish_chunk(std::integral_constant<int, par ^ 1>{}, c + 1); }      // vmcnt(0): chunk c + 1 has landed
 #endif
                     if constexpr (JOINT) {
                         // (one scalar comparison per chunk; the wish is worked out and written when the list reaches the mark; a round
@@ -909,7 +918,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
                     // (requested here, looked at behind the chunk's last step)
                     if constexpr (JOINT) wishes = s_att[0];
 #if !(LR_PB_EXP & 32)
-                    if (!tail || c + 2 < nchunks) load_chunk(c + 2);
+                    if (!tail || c + 2 < nchunks) load_chunk(std::integral_constant<int, par>{}, c + 2);      // (into the buffer chunk c has just been read out of)
 #endif
 #endif
                 }
@@ -999,7 +1008,7 @@ nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, in
                   int32_t *__restrict__ idx1, int32_t *__restrict__ idx2, float *__restrict__ s1o, float *__restrict__ s2o,
                   int32_t *__restrict__ counters,
                   uint32_t *__restrict__ seed_out, float *__restrict__ seed_s1, uint32_t *__restrict__ seed_range,
-                  unsigned long long *__restrict__ seed64, int dir, int gx, int total, lr_zargs z)
+                  unsigned long long *__restrict__ seed64, const float *__restrict__ range_c, int dir, int gx, int total, lr_zargs z)
 {
     // 1-D XCD-aware grid -> (row block, pair): the blocks one XCD receives are consecutive row blocks of the same pairs, so the
     // column cloud they gather from (3.84 MB of fp32 rows at 30k points) stays in that XCD's L2
@@ -1017,7 +1026,7 @@ nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, in
     }
     lr_z(nQ, z, pair); lr_z(nC, z, pair); lr_z(cand_cnt, z, pair); lr_z(cand, z, pair); lr_z(rowmap, z, pair); lr_z(yfin, z, pair);
     lr_z(na_dev, z, pair); lr_z(idx1, z, pair); lr_z(idx2, z, pair); lr_z(s1o, z, pair); lr_z(s2o, z, pair);
-    lr_z(counters, z, pair); lr_z(seed_out, z, pair); lr_z(seed_s1, z, pair); lr_z(seed_range, z, pair); lr_z(seed64, z, pair);
+    lr_z(counters, z, pair); lr_z(seed_out, z, pair); lr_z(seed_s1, z, pair); lr_z(seed_range, z, pair); lr_z(seed64, z, pair); lr_z(range_c, z, pair);
     if (na_dev) na = *na_dev;                  // compacted row list (reverse direction): lists by position, data by rowmap[]
     const int row0 = bxi * LR_EX_ROWS;
     if (row0 >= na) return;
@@ -1035,7 +1044,8 @@ nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, in
         const float big = fmaxf(fmaxf(fmaxf(fabsf(u.x), fabsf(u.y)), fmaxf(fabsf(u.z), fabsf(u.w))), fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
         const bool bad = !(big <= 65504.0f) || u.x != u.x || u.y != u.y || u.z != u.z || u.w != u.w || v.x != v.x || v.y != v.y || v.z != v.z || v.w != v.w;
         if (tid < LR_EX_ROWS) { s_best[tid] = LR_EX_EMPTY; s_second[tid] = LR_EX_EMPTY; s_cnt[tid] = 0; s_badrow[tid] = 0; }
-        if (tid == 0) { s_bad = 0; s_nredo = 0; }
+        // (a column cloud with a norm that is not finite -- the prep kernel's minimum is negative then --: every row by the full scan)
+        if (tid == 0) { s_bad = (range_c != nullptr && range_c[1] < 0.0f) ? 1 : 0; s_nredo = 0; }
         if (part == 0) { s_nq[rl] = nQ[rowd]; s_rowd[rl] = rowd; }
         __syncthreads();
         if (bad) s_badrow[rl] = 1;
@@ -1218,7 +1228,7 @@ int lr_nn16_run(lr_workspace *ws, const float *Fq, const _Float16 *Hq, const flo
     hipLaunchKernelGGL(nn16_exact_kernel, dim3(8 * lr_cdiv(ex_total, 8)), dim3(256), 0, st, Fq, nQ, na, Fc, nC, nb, ws->cand_cnt, ws->cand,
                        strips, need, (const float *)ws->yfin, ws->max_n, (const int32_t *)nullptr, (const int32_t *)nullptr, idx1, idx2, s1, s2, ws->counters,
                        seed_reverse ? ws->rev_seed : (uint32_t *)nullptr, ws->rev_s1, reinterpret_cast<uint32_t *>(ws->counters + LR_CNT_RLO),
-                       ws->rev_seed64, 0, ex_gx, ex_total, ws->z);
+                       ws->rev_seed64, range_c, 0, ex_gx, ex_total, ws->z);
     LR_LAUNCH_CHECK();
     return LR_OK;
 }
@@ -1506,7 +1516,7 @@ int lr_nn16_reverse(lr_workspace *ws, const float *F0, const _Float16 *H0, const
     hipLaunchKernelGGL(nn16_exact_kernel, dim3(8 * lr_cdiv(ex_total, 8)), dim3(256), 0, st, F1, nrm1, na, F0, nrm0, nb, ws->cand_cnt, ws->cand,
                        strips, 1, (const float *)nullptr, 0, (const int32_t *)ws->rev_rows, (const int32_t *)n_rows, rev, (int32_t *)nullptr, (float *)nullptr, (float *)nullptr,
                        ws->counters, (uint32_t *)nullptr, (float *)nullptr, (uint32_t *)nullptr,
-                       seeded ? ws->rev_seed64 : (unsigned long long *)nullptr, 1, ex_gx, ex_total, ws->z);
+                       seeded ? ws->rev_seed64 : (unsigned long long *)nullptr, (const float *)ws->nn_range, 1, ex_gx, ex_total, ws->z);
     LR_LAUNCH_CHECK();
     return LR_OK;
 }

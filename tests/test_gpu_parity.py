@@ -699,6 +699,15 @@ def test_nn_one_nonfinite_norm_among_unit_norm_descriptors(lr, oracle, kind):
         ok[40] = False                           # every distance of that row is inf or NaN: its order is not defined by the contract
     assert np.array_equal(i1.cpu().numpy()[ok], o1[ok]) and np.array_equal(i2.cpu().numpy()[ok], o2[ok])
     assert np.array_equal(_bits(s1.cpu().numpy())[ok], _bits(os1)[ok])
+    if kind == "nan_column":
+        # under the contract (fmaxf(NaN, 1e-30) = 1e-30; torch.min returns the NaN) the NaN column is EVERY row's nearest neighbour: no
+        # filter value can say so, the exact kernel re-does every row by the full scan when a column norm is not finite
+        assert (o1 == 777).all() and (i1.cpu().numpy() == 777).all()
+        t = lr.torch.from_numpy
+        m = lr.matching.nn_to_mutual(t(F0), t(F1), lr.torch.arange(n0), t(o1.astype(np.int64)), t(o2.astype(np.int64)))
+        em = oracle.nn_to_mutual(F0, F1, np.arange(n0), o1, o2)
+        for a, b in zip(m, em):
+            assert np.array_equal(a.numpy(), b)
 
 
 def test_nn_candidate_store_overflow_falls_back_to_the_exact_scan(lr, oracle):

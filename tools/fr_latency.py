@@ -8,10 +8,11 @@ t = torch.from_numpy
 A, B, FA, FB = (t(p[k]).cuda() for k in ("xyz0", "xyz1", "feats0", "feats1"))
 for mode, cb in (("MNN", "open3D"), ("GPF", "GC")):
     a = Args(mode=mode, codebase=cb, iters=50000, ransac_n=3, o3d_conf=1.0, GC_conf=1.0, prosac=(cb == "GC"))
-    ts = []
+    ts, wh = [], []
     for _ in range(30):
-        ts.append(FR.FR(A, B, FA, FB, a, p["T_gt"])[1])
-    print(mode, cb, "FR elapsed us: median %.0f min %.0f" % (1e6 * np.median(ts[5:]), 1e6 * min(ts)))
+        ts.append(FR.FR(A, B, FA, FB, a, p["T_gt"])[1]); wh.append(FR.last_timing["whole_path_s"])
+    print(mode, cb, "FR elapsed us: median %.0f min %.0f   (whole device path of the call incl. the forward NN and the result read-back: median %.0f min %.0f)" % (
+        1e6 * np.median(ts[5:]), 1e6 * min(ts), 1e6 * np.median(wh[5:]), 1e6 * min(wh)))
 # the reference CLI's defaults: --codebase GC --prosac True --GC_conf 0.999, iters = 500k (FR.py:65-67)
 for mode in ("MNN", "GPF"):
     a = Args(mode=mode, codebase="GC", iters=None, prosac=True)

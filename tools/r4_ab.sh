@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: the same bench with the shipped library and with a build whose filter pass always uses the plain (v_max3) test
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r4_ab; mkdir -p $O; cd $R
-for rep in 1 2; do
+for rep in ${REPS:-1 2}; do
 for lib in ${LIBS:-plain shipped}; do
   if [ $lib = shipped ]; then unset LIDARREG_LIB; else export LIDARREG_LIB=$R/tools/bin/liblidarreg_$lib.so; fi
   python bench.py --no-cpu-baseline --sustain-s 0 "$@" > $O/line_$lib.json 2>/dev/null
