@@ -271,8 +271,11 @@ __device__ unsigned long long lr_pb_clk[4096 * 2];      // development probe: sh
 #if LR_PB_EXP & 16
 __device__ unsigned long long lr_pb_stat[16];             // development probe: waves, tests, slow-path visits, hits, derive() rounds, 16-entry groups
 #endif
+#ifndef LR_PB_WAVES
+#define LR_PB_WAVES 3            // waves per SIMD the filter pass is compiled for (4: 128 registers -- development switch)
+#endif
 template <bool SIGN>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LR_PB_WAVES, LR_PB_WAVES)))
 nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *__restrict__ rowmap, const int32_t *__restrict__ na_dev,
                   const _Float16 *__restrict__ Hc, const float *__restrict__ nC, int nb,
                   int tiles_per_strip, const float *__restrict__ tau, int32_t *__restrict__ cand_cnt, int32_t *__restrict__ cand,
