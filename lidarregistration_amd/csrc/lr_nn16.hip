@@ -322,7 +322,11 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     constexpr int CH = LR_PB_CH;
     constexpr int XOFF = CH * 32 * LR_LDS_ROW;
     constexpr int BUF = XOFF + ((SIGN && LR_PB_P1FOLD) ? 0 : CH * 32 * 4);      // (the sign form stages no per-column operand, in either phase)
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
+    // The two chunk buffers are SEPARATE arrays on purpose: the walk fills one by LDS-direct loads while it reads the other, and the
+    // compiler's wait-count pass puts a vmcnt(0) in front of every LDS read that MAY alias a pending LDS-direct load -- with one array
+    // that was every fragment read behind the loads, i.e. the prefetch became synchronous (round 5: found in the ISA).
+    __shared__ __attribute__((aligned(16))) unsigned char lds_a[BUF];
+    __shared__ __attribute__((aligned(16))) unsigned char lds_b[BUF];
     // (with 8-tile chunks the plain form, which also stages x_j, gives up an eighth of its list to stay at three blocks per CU)
     constexpr int WL = (LR_PB_CH >= 8 && !SIGN) ? (LR_PB_WLIST * 7) / 8 : LR_PB_WLIST;
     __shared__ uint2 wlist[4][WL];   // per wave: entries as above (mask empty until derive() has seen the entry)
@@ -415,14 +419,14 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
 #pragma unroll
                 for (int q = 0; q < CH / 2; ++q) {
                     const int p = tid + 256 * q;
-                    *reinterpret_cast<f32x4 *>(&lds[buf * BUF + lr_lds_off(p >> 2, p & 3)]) = stage[q];
+                    *reinterpret_cast<f32x4 *>(&(buf ? lds_b : lds_a)[lr_lds_off(p >> 2, p & 3)]) = stage[q];
                 }
                 if constexpr (P1E) return;
                 // largest x_j = n1[j]/2 of every tile of the chunk: the threads tid < CH*32 hold one column each, 32 per tile
                 float xm = 0.5f * stage_n;
 #pragma unroll
                 for (int k = 16; k >= 1; k >>= 1) xm = fmaxf(xm, __shfl_xor(xm, k));
-                if (tid < CH * 32 && (tid & 31) == 0) *reinterpret_cast<float *>(&lds[buf * BUF + XOFF + (tid >> 5) * 4]) = xm;
+                if (tid < CH * 32 && (tid & 31) == 0) *reinterpret_cast<float *>(&(buf ? lds_b : lds_a)[XOFF + (tid >> 5) * 4]) = xm;
             };
             float m1[4], m2[4];           // running two largest (lane, tile) maxima of the lane's four rows (one per 16-row block)
 #pragma unroll
@@ -467,16 +471,17 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
                     if (c + 1 < nsch) load_s(c + 1);
                     // fragments of tile k: lane (c, kb) reads piece kb of columns c and 16 + c; in the result the lane holds query row c
                     // of a row block and registers g <-> columns 4 kb + g of the column block
-                    const unsigned char *bp = &lds[buf * BUF + frag16s];
+                    const unsigned char *lbuf = buf ? lds_b : lds_a;
+                    const unsigned char *bp = &lbuf[frag16s];
                     f16x8 b0 = *reinterpret_cast<const f16x8 *>(bp), b1 = *reinterpret_cast<const f16x8 *>(bp + 16 * LR_LDS_ROW);
-                    float xmax = *reinterpret_cast<const float *>(&lds[buf * BUF + XOFF]);
+                    float xmax = *reinterpret_cast<const float *>(&lbuf[XOFF]);
 #pragma unroll
                     for (int k = 0; k < CH; ++k) {
                         f16x8 n0 = b0, n1 = b1; float nx = xmax;
                         if (k + 1 < CH) {
                             n0 = *reinterpret_cast<const f16x8 *>(bp + (k + 1) * 32 * LR_LDS_ROW);
                             n1 = *reinterpret_cast<const f16x8 *>(bp + (k + 1) * 32 * LR_LDS_ROW + 16 * LR_LDS_ROW);
-                            nx = *reinterpret_cast<const float *>(&lds[buf * BUF + XOFF + (k + 1) * 4]);
+                            nx = *reinterpret_cast<const float *>(&lbuf[XOFF + (k + 1) * 4]);
                         }
                         f32x4 (&cur)[8] = (k & 1) ? sB : sA;
                         const f32x4 (&prev)[8] = (k & 1) ? sA : sB;
@@ -592,7 +597,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     auto load_chunk = [&](auto bufc, int c) {
         constexpr int buf = decltype(bufc)::value;
         const int col0 = (t_begin + c * CH) * 32;       // wave-uniform
-        __attribute__((address_space(3))) void *dst = (__attribute__((address_space(3))) void *)(lds + buf * BUF + wave * NQ * 1024);
+        __attribute__((address_space(3))) void *dst = (__attribute__((address_space(3))) void *)((buf ? lds_b : lds_a) + wave * NQ * 1024);
         static_assert(NQ == 2 || NQ == 4, "chunks of 4 or 8 tiles");      // (the offset field must be a literal)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcH, dst, 16, ld_voff, col0 * 64, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcH, dst, 16, ld_voff, col0 * 64, 1024, 0);
@@ -609,7 +614,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         if constexpr (!SIGN) {
             const int col = (t_begin + c * CH) * 32 + (tid & (CH * 32 - 1));
             const bool ok = col < nb && (col >> 5) < t_end;
-            if (tid < CH * 32) *reinterpret_cast<float *>(&lds[buf * BUF + XOFF + tid * 4]) = ok ? 0.5f * stage_n : LR_INF;
+            if (tid < CH * 32) *reinterpret_cast<float *>(&(buf ? lds_b : lds_a)[XOFF + tid * 4]) = ok ? 0.5f * stage_n : LR_INF;
         }
     };
     typedef std::integral_constant<int, 0> c0_t;
@@ -619,11 +624,12 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     const int frag16 = lr_lds_off(c16, kb), x_lane = XOFF + c16 * 4;
     auto read_b = [&](auto bufc, int k, f16x8 &b0, f16x8 &b1, f32x2 &xj) {
         constexpr int buf = decltype(bufc)::value;
-        b0 = *reinterpret_cast<const f16x8 *>(&lds[frag16 + buf * BUF + k * 32 * LR_LDS_ROW]);
-        b1 = *reinterpret_cast<const f16x8 *>(&lds[frag16 + buf * BUF + k * 32 * LR_LDS_ROW + 16 * LR_LDS_ROW]);
+        const unsigned char *lbuf = buf ? lds_b : lds_a;          // (buf is a compile-time value)
+        b0 = *reinterpret_cast<const f16x8 *>(&lbuf[frag16 + k * 32 * LR_LDS_ROW]);
+        b1 = *reinterpret_cast<const f16x8 *>(&lbuf[frag16 + k * 32 * LR_LDS_ROW + 16 * LR_LDS_ROW]);
         if constexpr (!SIGN) {      // (the sign form of the test reads no per-column operand)
-            xj.x = *reinterpret_cast<const float *>(&lds[x_lane + buf * BUF + k * 32 * 4]);
-            xj.y = *reinterpret_cast<const float *>(&lds[x_lane + buf * BUF + k * 32 * 4 + 64]);
+            xj.x = *reinterpret_cast<const float *>(&lbuf[x_lane + k * 32 * 4]);
+            xj.y = *reinterpret_cast<const float *>(&lbuf[x_lane + k * 32 * 4 + 64]);
         }
     };
     int wcnt = 0;            // entries in this wave's list (wave-uniform: lives in a scalar register)
