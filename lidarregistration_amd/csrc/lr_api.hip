@@ -129,6 +129,11 @@ extern "C" int lr_workspace_create_batch(lr_workspace **out, int max_pairs, int 
     real.base = ws->base;
     carve(ws, real);
     ws->descs = reinterpret_cast<lr_pair_desc *>(ws->base + desc_off);
+    // (optional: without it every call launches both forms of the filter pass, as batched calls always do)
+    if (hipHostMalloc(reinterpret_cast<void **>(&ws->form_host), 2 * sizeof(int32_t), hipHostMallocMapped) == hipSuccess) {
+        ws->form_host[0] = ws->form_host[1] = 0;
+        if (hipHostGetDevicePointer(reinterpret_cast<void **>(&ws->form_dev), ws->form_host, 0) != hipSuccess) { (void)hipHostFree(ws->form_host); ws->form_host = ws->form_dev = nullptr; }
+    } else { (void)hipGetLastError(); ws->form_host = ws->form_dev = nullptr; }
     // The fill runs on the null stream; the caller's streams may be non-blocking ones (torch's are), which do not wait for it: without
     // the synchronisation the first call on the new workspace can overtake the fill, which then wipes what that call wrote (found by
     // tests/test_gpu_gc.py::test_lo_helper_protocol_under_contention, round 4: workspaces created while other streams keep the GPU busy)
@@ -144,6 +149,7 @@ extern "C" int lr_workspace_create_batch(lr_workspace **out, int max_pairs, int 
 extern "C" int lr_workspace_destroy(lr_workspace *ws)
 {
     if (!ws) return LR_OK;
+    if (ws->form_host) (void)hipHostFree(ws->form_host);
     for (int k = 0; k < LR_NEV; ++k) (void)hipEventDestroy(ws->ev[k]);
     (void)hipFree(ws->base);
     delete ws;

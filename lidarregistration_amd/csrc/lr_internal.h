@@ -112,6 +112,7 @@ struct lr_workspace {
     float *bmax0, *bmax1;        // per-32-row maxima of the norms (f16 filter error bound)
     float *bmin0, *bmin1;        // ... and minima
     float *nn_range;             // [4] largest / smallest squared norm of cloud 0, of cloud 1 (are the norms all alike?  then the walk's candidate test is a sign test)
+    int32_t *form_host, *form_dev;   // pinned, device-visible: [0] / [1] = the form the norms of cloud 0 / cloud 1 asked for in the last single-pair call (0 unknown, 1 sign, 2 plain)
     uint32_t *rev_seed;          // [max_n1] best forward distance pointing at each cloud-1 row (bit pattern)
     unsigned long long *rev_seed64;  // [max_n1] ... and who: (distance bits << 32) | smallest cloud-0 index at that distance
     int32_t *rev_rows;           // [max_n1] the cloud-1 rows that have one, by descending seed
@@ -191,6 +192,8 @@ enum {
     LR_CNT_RHI,
     LR_CNT_REFIT_TICKET, // blocks of the refit kernel that have finished (last-block-done; reset by the last block)
     LR_CNT_NVALID2,      // SPRT pre-verification: models that survived it (dense second list, scored in full)
+    LR_CNT_FORM_MISS_F,  // single-pair calls launch only the form of the filter pass the last call's norms asked for: set when THIS call's norms
+    LR_CNT_FORM_MISS_R,  //   ask for the other one (forward / reverse launch) -- the exact kernel then re-does every row by the full scan
     LR_CNT_COUNT = 16,
     LR_CNT_TOTAL = 64        // counters[16..63] hold lr_ransac_state
 };

@@ -70,7 +70,7 @@ nn16_prep_kernel(const float *__restrict__ Fa, int na, _Float16 *__restrict__ Ha
     if (counters && blockIdx.x == 0 && (int)threadIdx.x < LR_CNT_TOTAL) {
         const int k = threadIdx.x;
         if (k == LR_CNT_RLO) counters[k] = 0x7f7f7f7f;
-        else if (k == LR_CNT_RHI || zero_counters) counters[k] = 0;
+        else if (k == LR_CNT_RHI || k == LR_CNT_FORM_MISS_F || k == LR_CNT_FORM_MISS_R || zero_counters) counters[k] = 0;
     }
     // blocks [0, nblk_a) prepare cloud a, the rest cloud b (one launch for the pair; nblk_a = ceil(na/32) of the largest
     // cloud of a batch: blocks past a pair's own rows only write a zero maximum)
@@ -132,7 +132,7 @@ nn16_prep_kernel(const float *__restrict__ Fa, int na, _Float16 *__restrict__ Ha
 // (one block per cloud and pair; the filter-pass blocks then read two floats instead of reducing ~1000 each)
 __global__ void __launch_bounds__(256)
 nn16_range_kernel(int na, const float *__restrict__ bmaxa, const float *__restrict__ bmina, int nb, const float *__restrict__ bmaxb,
-                  const float *__restrict__ bminb, float *__restrict__ range, lr_zargs z)
+                  const float *__restrict__ bminb, float *__restrict__ range, int32_t *__restrict__ form_out, lr_zargs z)
 {
     __shared__ float s_m[4], s_n[4];
     if (z.descs) { na = z.descs[blockIdx.z].n0; nb = z.descs[blockIdx.z].n1; }
@@ -147,8 +147,12 @@ nn16_range_kernel(int na, const float *__restrict__ bmaxa, const float *__restri
     if ((threadIdx.x & 63) == 0) { s_m[threadIdx.x >> 6] = mx; s_n[threadIdx.x >> 6] = mn; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        range[2 * second] = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
-        range[2 * second + 1] = fminf(fminf(s_n[0], s_n[1]), fminf(s_n[2], s_n[3]));
+        const float hi = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3])), lo = fminf(fminf(s_n[0], s_n[1]), fminf(s_n[2], s_n[3]));
+        range[2 * second] = hi;
+        range[2 * second + 1] = lo;
+        // (single-pair calls: which form of the filter pass this cloud's norms ask for when it is the column cloud -- nn16_passb_kernel's
+        // own rule --, left in pinned host memory for the NEXT call on the workspace, which then launches that form alone)
+        if (form_out) form_out[second] = (lo > 0.0f && hi < LR_INF && hi - lo <= 1e-4f * hi) ? 1 : 2;
     }
 }
 
@@ -263,7 +267,7 @@ struct lr_thr_in {
     int need, sstride;
 };
 // grid shape of a 1-D XCD-aware launch + direction (0: rows = cloud 0, columns = cloud 1; 1: the reverse pass)
-struct lr_pb_grid { int gx, gy, total, dir; };
+struct lr_pb_grid { int gx, gy, total, dir, only; };      // only != 0: the other instantiation is not launched (single-pair calls, see lr_nn16_forms)
 
 #if LR_PB_EXP & 8
 __device__ unsigned long long lr_pb_clk[4096 * 2];      // development probe: shader clocks / 100 MHz ticks a block spent
@@ -281,7 +285,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
                   int tiles_per_strip, const float *__restrict__ tau, int32_t *__restrict__ cand_cnt, int32_t *__restrict__ cand,
                   const int32_t *__restrict__ colmap, const float *__restrict__ tile_min, const uint32_t *__restrict__ row_bound,
                   const int32_t *__restrict__ rev_offs, const uint32_t *__restrict__ rev_range, float *__restrict__ yfin, int yfin_stride,
-                  uint32_t *__restrict__ yshare, lr_thr_in thr, lr_pb_grid pg, lr_zargs z)
+                  uint32_t *__restrict__ yshare, int32_t *__restrict__ form_miss, lr_thr_in thr, lr_pb_grid pg, lr_zargs z)
 {
     // 1-D XCD-aware grid -> (row block, strip, pair): the blocks one XCD receives are consecutive row blocks of the same
     // (strip, pair), i.e. they stream the same columns through that XCD's L2
@@ -316,7 +320,12 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     float max_nc = 0.0f, min_nc = 0.0f;
     if (thr.range_c) { max_nc = thr.range_c[0]; min_nc = thr.range_c[1]; }
     const bool sign_ok = thr.range_c != nullptr && min_nc > 0.0f && max_nc < LR_INF && max_nc - min_nc <= 1e-4f * max_nc && !(LR_PB_EXP & 128);
-    if (sign_ok != SIGN) return;
+    if (sign_ok != SIGN) {
+        // (launched alone on the strength of the previous call's norms, and this call's ask for the other form: say so -- the exact
+        // kernel then re-does every row by the full scan, and the next call launches the right one)
+        if (pg.only && form_miss && bx == 0 && by == 0 && threadIdx.x == 0) { lr_z(form_miss, z, pair); *form_miss = 1; }
+        return;
+    }
     const float xhat = SIGN ? 0.5f * min_nc : 0.0f;
     __shared__ int s_limit[4];
     constexpr int CH = LR_PB_CH;
@@ -1054,7 +1063,8 @@ nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, in
         const bool bad = !(big <= 65504.0f) || u.x != u.x || u.y != u.y || u.z != u.z || u.w != u.w || v.x != v.x || v.y != v.y || v.z != v.z || v.w != v.w;
         if (tid < LR_EX_ROWS) { s_best[tid] = LR_EX_EMPTY; s_second[tid] = LR_EX_EMPTY; s_cnt[tid] = 0; s_badrow[tid] = 0; }
         // (a column cloud with a norm that is not finite -- the prep kernel's minimum is negative then --: every row by the full scan)
-        if (tid == 0) { s_bad = (range_c != nullptr && range_c[1] < 0.0f) ? 1 : 0; s_nredo = 0; }
+        // ... and so does a filter pass that was launched in one form only while this call's norms asked for the other (nothing was walked)
+        if (tid == 0) { s_bad = ((range_c != nullptr && range_c[1] < 0.0f) || counters[LR_CNT_FORM_MISS_F + (dir ? 1 : 0)] != 0) ? 1 : 0; s_nredo = 0; }
         if (part == 0) { s_nq[rl] = nQ[rowd]; s_rowd[rl] = rowd; }
         __syncthreads();
         if (bad) s_badrow[rl] = 1;
@@ -1186,9 +1196,18 @@ int lr_nn16_prep(lr_workspace *ws, const float *F0, int n0, const float *F1, int
     hipLaunchKernelGGL(nn16_prep_kernel, dim3(lr_cdiv(n0, 32) + lr_cdiv(n1, 32), 1, ws->zP), dim3(256), 0, st, F0, n0, ws->H0, ws->nrm0, ws->bmax0, ws->bmin0,
                        F1, n1, ws->H1, ws->nrm1, ws->bmax1, ws->bmin1, ws->rev_seed, ws->rev_seed64, ws->counters, zero_counters ? 1 : 0, lr_cdiv(n0, 32), ws->yshare, ws->z);
     hipLaunchKernelGGL(nn16_range_kernel, dim3(2, 1, ws->zP), dim3(256), 0, st, n0, (const float *)ws->bmax0, (const float *)ws->bmin0, n1, (const float *)ws->bmax1,
-                       (const float *)ws->bmin1, ws->nn_range, ws->z);
+                       (const float *)ws->bmin1, ws->nn_range, ws->zP == 1 ? ws->form_dev : (int32_t *)nullptr, ws->z);
     LR_LAUNCH_CHECK();
     return LR_OK;
+}
+
+// which form of the filter pass a single-pair call launches alone: what the range kernel of an earlier call on this workspace found
+// for the column cloud (0: cloud 0 = reverse pass, 1: cloud 1 = forward pass); 0 = unknown (first call, batched call): launch both
+static int lr_nn16_form_hint(const lr_workspace *ws, int col_cloud)
+{
+    if (ws->zP != 1 || !ws->form_host) return 0;
+    const int h = *reinterpret_cast<const volatile int32_t *>(&ws->form_host[col_cloud]);
+    return (h == 1 || h == 2) ? h : 0;
 }
 
 int lr_nn16_run(lr_workspace *ws, const float *Fq, const _Float16 *Hq, const float *nQ, int na,
@@ -1219,19 +1238,23 @@ int lr_nn16_run(lr_workspace *ws, const float *Fq, const _Float16 *Hq, const flo
     dim3 grid(8 * lr_cdiv(total, 8));
     if (ws->timing && !ws->ev_pending) { LR_HIP(hipEventRecord(ws->ev[0], st)); }
     lr_thr_in thr = { nQ, range_c, need, sstride };
-    // both forms of the walk's candidate test; the blocks of the one the column norms do not ask for return at once
-#define SIGN_ true
-    hipLaunchKernelGGL(nn16_passb_kernel<SIGN_>, grid, dim3(256), 0, st, Hq, na, (const int32_t *)nullptr, (const int32_t *)nullptr, Hc, nC, nb,
-                       tps, (const float *)nullptr, ws->cand_cnt, ws->cand, (const int32_t *)nullptr, (const float *)nullptr,
-                       (const uint32_t *)nullptr, (const int32_t *)nullptr, (const uint32_t *)nullptr, ws->yfin, ws->max_n, ws->yshare, thr,
-                       lr_pb_grid{ row_blocks, strips, total, 0 }, ws->z);
-#undef SIGN_
-#define SIGN_ false
-    hipLaunchKernelGGL(nn16_passb_kernel<SIGN_>, grid, dim3(256), 0, st, Hq, na, (const int32_t *)nullptr, (const int32_t *)nullptr, Hc, nC, nb,
-                       tps, (const float *)nullptr, ws->cand_cnt, ws->cand, (const int32_t *)nullptr, (const float *)nullptr,
-                       (const uint32_t *)nullptr, (const int32_t *)nullptr, (const uint32_t *)nullptr, ws->yfin, ws->max_n, ws->yshare, thr,
-                       lr_pb_grid{ row_blocks, strips, total, 0 }, ws->z);
-#undef SIGN_
+    // Both forms of the walk's candidate test; the blocks of the one the column norms do not ask for return at once.  A single-pair call
+    // launches only the form the column cloud's norms asked for in the PREVIOUS call on this workspace (lr_nn16_form_hint: a flag the range
+    // kernel leaves in pinned host memory; no synchronisation, any value is safe): if this call's norms ask for the other form, the
+    // launched kernel flags the miss and the exact kernel re-does every row by the full scan -- correct, slow once, and the next call
+    // launches the right form.  (An empty launch costs 4.7 us: 9.4 of a single pair's 346 us of kernels.)
+    const int only = lr_nn16_form_hint(ws, 1);
+    int32_t *miss = ws->counters + LR_CNT_FORM_MISS_F;
+    if (only != 2)
+        hipLaunchKernelGGL(nn16_passb_kernel<true>, grid, dim3(256), 0, st, Hq, na, (const int32_t *)nullptr, (const int32_t *)nullptr, Hc, nC, nb,
+                           tps, (const float *)nullptr, ws->cand_cnt, ws->cand, (const int32_t *)nullptr, (const float *)nullptr,
+                           (const uint32_t *)nullptr, (const int32_t *)nullptr, (const uint32_t *)nullptr, ws->yfin, ws->max_n, ws->yshare, miss, thr,
+                           lr_pb_grid{ row_blocks, strips, total, 0, only }, ws->z);
+    if (only != 1)
+        hipLaunchKernelGGL(nn16_passb_kernel<false>, grid, dim3(256), 0, st, Hq, na, (const int32_t *)nullptr, (const int32_t *)nullptr, Hc, nC, nb,
+                           tps, (const float *)nullptr, ws->cand_cnt, ws->cand, (const int32_t *)nullptr, (const float *)nullptr,
+                           (const uint32_t *)nullptr, (const int32_t *)nullptr, (const uint32_t *)nullptr, ws->yfin, ws->max_n, ws->yshare, miss, thr,
+                           lr_pb_grid{ row_blocks, strips, total, 0, only }, ws->z);
     if (ws->timing && !ws->ev_pending) { LR_HIP(hipEventRecord(ws->ev[1], st)); ws->ev_pending = 1; }
     const int ex_gx = lr_cdiv(na, LR_EX_ROWS), ex_total = ex_gx * ws->zP;
     hipLaunchKernelGGL(nn16_exact_kernel, dim3(8 * lr_cdiv(ex_total, 8)), dim3(256), 0, st, Fq, nQ, na, Fc, nC, nb, ws->cand_cnt, ws->cand,
@@ -1504,22 +1527,21 @@ int lr_nn16_reverse(lr_workspace *ws, const float *F0, const _Float16 *H0, const
     dim3 grid(8 * lr_cdiv(total, 8));
     const bool timed = ws->timing && ws->ev_pending == 1 && !ws->rev_recorded;
     if (timed) { LR_HIP(hipEventRecord(ws->ev[4], st)); }
-#define SIGN_ true
-    hipLaunchKernelGGL(nn16_passb_kernel<SIGN_>, grid, dim3(256), 0, st, H1, na, (const int32_t *)ws->rev_rows, (const int32_t *)n_rows,
-                       (const _Float16 *)ws->Hs, (const float *)ws->nrms, nb, tps, ws->tau, ws->cand_cnt, ws->cand,
-                       (const int32_t *)ws->rev_cols, seeded ? (const float *)ws->rev_tmin : (const float *)nullptr, (const uint32_t *)seed,
-                       (const int32_t *)ws->rev_hist, (const uint32_t *)range, (float *)nullptr, 0, (uint32_t *)nullptr,
-                       lr_thr_in{ nullptr, (const float *)ws->nn_range, 1, 0 },      // (no tightening: the column norms' range selects the form of the walk's test)
-                       lr_pb_grid{ row_blocks, strips, total, 1 }, ws->z);
-#undef SIGN_
-#define SIGN_ false
-    hipLaunchKernelGGL(nn16_passb_kernel<SIGN_>, grid, dim3(256), 0, st, H1, na, (const int32_t *)ws->rev_rows, (const int32_t *)n_rows,
-                       (const _Float16 *)ws->Hs, (const float *)ws->nrms, nb, tps, ws->tau, ws->cand_cnt, ws->cand,
-                       (const int32_t *)ws->rev_cols, seeded ? (const float *)ws->rev_tmin : (const float *)nullptr, (const uint32_t *)seed,
-                       (const int32_t *)ws->rev_hist, (const uint32_t *)range, (float *)nullptr, 0, (uint32_t *)nullptr,
-                       lr_thr_in{ nullptr, (const float *)ws->nn_range, 1, 0 },      // (no tightening: the column norms' range selects the form of the walk's test)
-                       lr_pb_grid{ row_blocks, strips, total, 1 }, ws->z);
-#undef SIGN_
+    const int only = lr_nn16_form_hint(ws, 0);          // (the columns of the reverse pass are cloud 0)
+    int32_t *miss = ws->counters + LR_CNT_FORM_MISS_R;
+    const lr_thr_in rthr = { nullptr, (const float *)ws->nn_range, 1, 0 };      // (no tightening: the column norms' range selects the form of the walk's test)
+    if (only != 2)
+        hipLaunchKernelGGL(nn16_passb_kernel<true>, grid, dim3(256), 0, st, H1, na, (const int32_t *)ws->rev_rows, (const int32_t *)n_rows,
+                           (const _Float16 *)ws->Hs, (const float *)ws->nrms, nb, tps, ws->tau, ws->cand_cnt, ws->cand,
+                           (const int32_t *)ws->rev_cols, seeded ? (const float *)ws->rev_tmin : (const float *)nullptr, (const uint32_t *)seed,
+                           (const int32_t *)ws->rev_hist, (const uint32_t *)range, (float *)nullptr, 0, (uint32_t *)nullptr, miss, rthr,
+                           lr_pb_grid{ row_blocks, strips, total, 1, only }, ws->z);
+    if (only != 1)
+        hipLaunchKernelGGL(nn16_passb_kernel<false>, grid, dim3(256), 0, st, H1, na, (const int32_t *)ws->rev_rows, (const int32_t *)n_rows,
+                           (const _Float16 *)ws->Hs, (const float *)ws->nrms, nb, tps, ws->tau, ws->cand_cnt, ws->cand,
+                           (const int32_t *)ws->rev_cols, seeded ? (const float *)ws->rev_tmin : (const float *)nullptr, (const uint32_t *)seed,
+                           (const int32_t *)ws->rev_hist, (const uint32_t *)range, (float *)nullptr, 0, (uint32_t *)nullptr, miss, rthr,
+                           lr_pb_grid{ row_blocks, strips, total, 1, only }, ws->z);
     if (timed) { LR_HIP(hipEventRecord(ws->ev[5], st)); ws->rev_recorded = 1; }
     const int ex_gx = lr_cdiv(na, LR_EX_ROWS), ex_total = ex_gx * ws->zP;
     hipLaunchKernelGGL(nn16_exact_kernel, dim3(8 * lr_cdiv(ex_total, 8)), dim3(256), 0, st, F1, nrm1, na, F0, nrm0, nb, ws->cand_cnt, ws->cand,

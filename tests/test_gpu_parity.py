@@ -812,3 +812,27 @@ def test_nn_both_forms_of_the_walk_test_by_norm_spread(lr, oracle, spread0, spre
     assert np.array_equal(nn1, o1) and np.array_equal(nn2, o2) and r.n_nn_fixed == 0
     assert r.n_corr == len(m[0]) and np.array_equal(c0[:r.n_corr], m[0]) and np.array_equal(c1[:r.n_corr], m[1])
     ws.close()
+
+
+def test_single_pair_calls_launch_one_form_of_the_filter_pass_and_survive_a_wrong_guess(lr, oracle):
+    """A single-pair call launches only the form of the filter pass (sign test / plain test) that the column cloud's norms asked for in
+    the PREVIOUS call on the workspace (a flag in pinned host memory).  When the data changes form between two calls the launched
+    kernel flags the miss and the exact kernel re-does every row by the full scan: the results stay the oracle's, call after call, in
+    every order of unit-norm and scaled clouds -- forward NN and the mutual list (whose reverse pass has cloud 0 as its columns)."""
+    n0, n1 = 1800, 2100
+    U0, U1 = synth.make_features(n0, n1, 32, 0.5, 1.0, 17)
+    rng = np.random.default_rng(3)
+    S0 = (U0 * rng.uniform(0.5, 2.0, (n0, 1))).astype(np.float32); S1 = (U1 * rng.uniform(0.5, 2.0, (n1, 1))).astype(np.float32)
+    ws_key = lr.matching.workspace(n0, n1, dim=32)          # (every call below lands on this cached workspace)
+    t = lr.torch.from_numpy
+    seq = [(U0, U1), (U0, U1), (S0, S1), (S0, S1), (U0, S1), (S0, U1), (U0, U1), (S0, S1), (U0, U1)]
+    for k, (F0, F1) in enumerate(seq):
+        i1, i2, s1, s2 = lr.matching.nn_top2_dev(F0, F1, want_2nd=True, want_dist=True)
+        o1, o2, os1, os2 = oracle.nn_top2(F0, F1)
+        assert np.array_equal(i1.cpu().numpy(), o1) and np.array_equal(i2.cpu().numpy(), o2), k
+        assert np.array_equal(_bits(s1.cpu().numpy()), _bits(os1)), k
+        m = lr.matching.nn_to_mutual(t(F0), t(F1), lr.torch.arange(n0), t(o1.astype(np.int64)), t(o2.astype(np.int64)))
+        em = oracle.nn_to_mutual(F0, F1, np.arange(n0), o1, o2)
+        for a, b in zip(m, em):
+            assert np.array_equal(a.numpy(), b), k
+    assert lr.matching.workspace(n0, n1, dim=32) is ws_key

@@ -11,7 +11,7 @@
 #define PB_BMIN_ARG(p)
 #define PB_NEW_ABI 0
 #else
-#define PB_YS ysh,
+#define PB_YS ysh, (int32_t *)nullptr,
 #define PB_YS_ARG (uint32_t*)nullptr,
 #define PB_BMIN_ARG(p) (float *)((char *)bmin + (p) * stride),
 #define PB_NEW_ABI 1
@@ -71,7 +71,7 @@ int main(int argc, char **argv)
 #if PB_NEW_ABI
     for (int p = 0; p < P; ++p)
         hipLaunchKernelGGL(nn16_range_kernel, dim3(1), dim3(256), 0, 0, n, (const float *)((char *)bmax + p * stride), (const float *)((char *)bmin + p * stride), 0, (const float *)bmax,
-                           (const float *)bmin, (float *)((char *)nrange + p * stride), z0);
+                           (const float *)bmin, (float *)((char *)nrange + p * stride), (int32_t *)nullptr, z0);
 #endif
     (void)bmin; (void)nrange;
     hipDeviceSynchronize();
@@ -90,7 +90,7 @@ int main(int argc, char **argv)
         static char *s_ysh, *s_arr; static size_t s_stride; static int s_P, s_n; s_ysh = (char *)ysh; s_arr = (char *)arr; s_stride = stride; s_P = P; s_n = n;
         g_pre = [] { for (int p = 0; p < s_P; ++p) { hipMemsetD32Async((hipDeviceptr_t)(s_ysh + p * s_stride), 0xff800000u, s_n, 0); hipMemsetD32Async((hipDeviceptr_t)(s_arr + p * s_stride), 0, s_n / 256 + 2, 0); } };
         auto run = [&] { PB_LAUNCH(grid, dim3(256), 0, 0, H, n, (const int32_t*)nullptr, (const int32_t*)nullptr, H, nrm, n, tps, (const float*)nullptr, cnt, cand,
-                                            (const int32_t*)nullptr, (const float*)nullptr, (const uint32_t*)nullptr, (const int32_t*)nullptr, (const uint32_t*)nullptr, (float*)nullptr, 0, PB_YS thr, lr_pb_grid{ row_blocks, strips, total, 0 }, z); };
+                                            (const int32_t*)nullptr, (const float*)nullptr, (const uint32_t*)nullptr, (const int32_t*)nullptr, (const uint32_t*)nullptr, (float*)nullptr, 0, PB_YS thr, lr_pb_grid{ row_blocks, strips, total, 0, 0 }, z); };
         float msp = timeit([&] { run(); });
         g_pre(); run();
         const int nseg = row_blocks * 4 * (strips + 1);
@@ -117,14 +117,14 @@ int main(int argc, char **argv)
         float *yf = (float *)(base + oY);
         PB_THR(thr, nrm, 2, 16);
         PB_LAUNCH(grid, dim3(256), 0, 0, H, n, (const int32_t*)nullptr, (const int32_t*)nullptr, H, nrm, n, tps, (const float*)nullptr, cnt, cand,
-                           (const int32_t*)nullptr, (const float*)nullptr, (const uint32_t*)nullptr, (const int32_t*)nullptr, (const uint32_t*)nullptr, yf, n, PB_YS thr, lr_pb_grid{ row_blocks, strips, total, 0 }, z);
+                           (const int32_t*)nullptr, (const float*)nullptr, (const uint32_t*)nullptr, (const int32_t*)nullptr, (const uint32_t*)nullptr, yf, n, PB_YS thr, lr_pb_grid{ row_blocks, strips, total, 0, 0 }, z);
         hipDeviceSynchronize();
         std::vector<float> y((size_t)n * strips), t(n);
         hipMemcpy(y.data(), yf, (size_t)n * strips * 4, hipMemcpyDeviceToHost);
         for (int i = 0; i < n; ++i) { float m = y[i]; for (int sidx = 1; sidx < strips; ++sidx) m = std::min(m, y[(size_t)sidx * n + i]); t[i] = 2.0f * m; }
         for (int p = 0; p < P; ++p) hipMemcpy((char *)tau + p * stride, t.data(), (size_t)n * 4, hipMemcpyHostToDevice);
         auto run = [&] { PB_LAUNCH(grid, dim3(256), 0, 0, H, n, (const int32_t*)nullptr, (const int32_t*)nullptr, H, nrm, n, tps, (const float*)tau, cnt, cand,
-                                            (const int32_t*)nullptr, (const float*)nullptr, (const uint32_t*)nullptr, (const int32_t*)nullptr, (const uint32_t*)nullptr, (float*)nullptr, 0, PB_YS thr0, lr_pb_grid{ row_blocks, strips, total, 0 }, z); };
+                                            (const int32_t*)nullptr, (const float*)nullptr, (const uint32_t*)nullptr, (const int32_t*)nullptr, (const uint32_t*)nullptr, (float*)nullptr, 0, PB_YS thr0, lr_pb_grid{ row_blocks, strips, total, 0, 0 }, z); };
         float msp = only_nohit ? 0.0f : timeit([&] { run(); });
         const int nseg = row_blocks * 4 * (strips + 1);
         std::vector<int32_t> c1(nseg); hipMemcpy(c1.data(), cnt, (size_t)nseg * 4, hipMemcpyDeviceToHost);
@@ -142,7 +142,7 @@ int main(int argc, char **argv)
         std::vector<float> t(n, -1e30f);
         for (int p = 0; p < P; ++p) hipMemcpy((char *)tau + p * stride, t.data(), (size_t)n * 4, hipMemcpyHostToDevice);
         float msp = timeit([&] { PB_LAUNCH(grid, dim3(256), 0, 0, H, n, (const int32_t*)nullptr, (const int32_t*)nullptr, H, nrm, n, tps, (const float*)tau, cnt, cand,
-                                                    (const int32_t*)nullptr, (const float*)nullptr, (const uint32_t*)nullptr, (const int32_t*)nullptr, (const uint32_t*)nullptr, (float*)nullptr, 0, PB_YS thr0, lr_pb_grid{ row_blocks, strips, total, 0 }, z); });
+                                                    (const int32_t*)nullptr, (const float*)nullptr, (const uint32_t*)nullptr, (const int32_t*)nullptr, (const uint32_t*)nullptr, (float*)nullptr, 0, PB_YS thr0, lr_pb_grid{ row_blocks, strips, total, 0, 0 }, z); });
         printf("walk only, no candidates:       %8.3f ms  = %6.1f us/pair\n", msp, msp * 1e3 / P);
         print_clk(total);
     }
