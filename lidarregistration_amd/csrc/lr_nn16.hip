@@ -1037,7 +1037,7 @@ nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, in
     __shared__ float s_nq[LR_EX_ROWS];
     __shared__ unsigned long long s_best[LR_EX_ROWS], s_second[LR_EX_ROWS];
     __shared__ int s_cnt[LR_EX_ROWS], s_rowd[LR_EX_ROWS], s_badrow[LR_EX_ROWS];
-    __shared__ int s_bad, s_nredo, s_redo[LR_EX_ROWS];
+    __shared__ int s_bad, s_skip, s_nredo, s_redo[LR_EX_ROWS];
     if (z.descs) {      // dir 0: rows = cloud 0 against cloud 1; 1: the reverse direction
         const lr_pair_desc d = z.descs[pair];
         Fq = dir ? d.F1 : d.F0; na = dir ? d.n1 : d.n0; Fc = dir ? d.F0 : d.F1; nb = dir ? d.n0 : d.n1;
@@ -1064,7 +1064,11 @@ nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, in
         if (tid < LR_EX_ROWS) { s_best[tid] = LR_EX_EMPTY; s_second[tid] = LR_EX_EMPTY; s_cnt[tid] = 0; s_badrow[tid] = 0; }
         // (a column cloud with a norm that is not finite -- the prep kernel's minimum is negative then --: every row by the full scan)
         // ... and so does a filter pass that was launched in one form only while this call's norms asked for the other (nothing was walked)
-        if (tid == 0) { s_bad = ((range_c != nullptr && range_c[1] < 0.0f) || counters[LR_CNT_FORM_MISS_F + (dir ? 1 : 0)] != 0) ? 1 : 0; s_nredo = 0; }
+        // -- and then NOBODY wrote this call's candidate counts: the store is not looked at (s_skip)
+        if (tid == 0) {
+            const int miss = counters[LR_CNT_FORM_MISS_F + (dir ? 1 : 0)] != 0 ? 1 : 0;
+            s_bad = ((range_c != nullptr && range_c[1] < 0.0f) || miss) ? 1 : 0; s_skip = miss; s_nredo = 0;
+        }
         if (part == 0) { s_nq[rl] = nQ[rowd]; s_rowd[rl] = rowd; }
         __syncthreads();
         if (bad) s_badrow[rl] = 1;
@@ -1088,7 +1092,7 @@ nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, in
         return __builtin_sqrtf(fmaxf(d2, 1e-30f));
     };
     // ---- the candidates: entries { column | kb << 22 | LR_PB_HASG, 16-bit row mask | g16 << 16 } of the filter-pass wave (LR_PB_* above)
-    {
+    if (!s_skip) {
         const int32_t *cw = cand_cnt + bxi * (nstrips + 1);
         const int used = min(max(cw[nstrips], 1), nstrips);        // strips the pass-B row block really used
         const int seg_cap = lr_seg_cap(used);

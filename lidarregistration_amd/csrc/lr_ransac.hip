@@ -195,6 +195,7 @@ __device__ __forceinline__ bool hypothesis_sample(const float *__restrict__ corr
 #define LR_SC_W 0.0625f
 #define LR_SC_MIN_M 2048
 #define LR_SC_MIN_V 128
+#define LR_SC_MIN_PAIRS 4       // calls of at most this many pairs score every model over every correspondence (no ordering passes)
 // what the head and order passes leave for the main pass (one per pair arena)
 struct lr_score_info {
     unsigned long long pilot_key;     // max over the models of (head inliers << 32 | ~slot): the pilot
@@ -1687,7 +1688,10 @@ int lr_ransac_run(lr_workspace *ws, const float *corr8, int m_max, const int32_t
             const float *mdl = sprt ? (const float *)ws->models2 : (const float *)ws->models;
             // (the device decides from the live counts; a batch of up to 1 024 ids is scored in full -- its four ordering launches cost
             // more than they save, and with the pre-check fewer than LR_SC_MIN_V of its ids survive anyway)
-            const bool may_prune = m_max >= LR_SC_MIN_M && h1 - h0 >= 2048;
+            // Nor with a few pairs in the call: the GPU is not full, the main pass over everything costs a lone 30k pair 37 us where the
+            // pruned pass costs 39 us AFTER 39 us of ordering launches (FR() 296 -> 254 us; one call of 2 / 4 / 8 / 16 pairs:
+            // 0.50 -> 0.46, 0.69 -> 0.65, 1.00 -> 1.03, 1.67 -> 1.76 ms).
+            const bool may_prune = m_max >= LR_SC_MIN_M && h1 - h0 >= 2048 && ws->zP > LR_SC_MIN_PAIRS;
             if (may_prune) {
                 const int hgx = 64, htotal = hgx * ws->zP;
                 hipLaunchKernelGGL(ransac_score_kernel<1>, dim3(8 * lr_cdiv(htotal, 8)), dim3(256), 0, st, corr8, (const float *)ws->corr8s, m_max, m_dev, p->thr2,
