@@ -347,7 +347,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     const int c16 = lane & 15, kb = lane >> 4;
     const int row0 = bx * LR_BLOCK_ROWS + wave * 64;
 #if LR_PB_EXP & 16
-    int n_visits = 0, n_hits = 0, n_rounds = 0, n_groups = 0, n_tk_derive = 0, n_tk_flush = 0;      // development probe: slow-path visits, hits, derive() rounds, 16-entry groups, 10 ns ticks
+    int n_visits = 0, n_hits = 0, n_rounds = 0, n_groups = 0, n_tk_derive = 0, n_tk_flush = 0, n_tk_a = 0, n_tk_b = 0;      // development probe: slow-path visits, hits, derive() rounds, 16-entry groups, 10 ns ticks
     const unsigned long long tk_start = __builtin_amdgcn_s_memrealtime();
     unsigned long long tk_walk = 0;
 #endif
@@ -695,6 +695,9 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
                 bf[g] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrcH, col * 64 + kb * 16, 0, 0));
                 xn[g] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrcN, col * 4, 0, 0));
             }
+#if LR_PB_EXP & 16
+            { const unsigned long long ta = __builtin_amdgcn_s_memrealtime(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); n_tk_a += (int)(__builtin_amdgcn_s_memrealtime() - ta); }
+#endif
 #pragma unroll
             for (int g = 0; g < DG; ++g) {
                 if (e0 + 16 * g >= nlist) break;              // (wave-uniform)
@@ -737,6 +740,9 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
                 }
             }
         }
+#if LR_PB_EXP & 16
+        const unsigned long long tb = __builtin_amdgcn_s_memrealtime();
+#endif
         wdone = nlist;
         if (LR_PB_GEO > 0 && update) trig = min(2 * trig, LR_PB_GEO_CAP);
         set_next();
@@ -747,6 +753,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
             const float yn = (s_D[rl] - gn) + 2e-6f * fabsf(gn);
             float yv = s_Y[rl];
             if (yn < yv) yv = yn;                           // (NaN compares false: the row keeps its threshold)
+            // (the exchange as a plain load at the start of the round + an atomic nobody waits for: no change, 96.4 us either way -- round 5)
             if (pooled && row0 + lane < na && yv == yv) {   // pool with the row block's other strips
                 const float other = lr_ord_dec(atomicMin(&yshare[row0 + lane], lr_ord_enc(yv)));
                 if (other < yv) yv = other;
@@ -755,6 +762,8 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
             load_y();
         }
 #if LR_PB_EXP & 16
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        n_tk_b += (int)(__builtin_amdgcn_s_memrealtime() - tb);
         n_tk_derive += (int)(__builtin_amdgcn_s_memrealtime() - tk0);
 #endif
 #if LR_PB_PRIO
@@ -985,6 +994,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         const unsigned long long tk_end = __builtin_amdgcn_s_memrealtime();
         atomicAdd(&lr_pb_stat[6], (unsigned long long)n_tk_derive); atomicAdd(&lr_pb_stat[7], (unsigned long long)n_tk_flush);
         atomicAdd(&lr_pb_stat[8], tk_walk - tk_start); atomicAdd(&lr_pb_stat[9], tk_end - tk_start);
+        atomicAdd(&lr_pb_stat[10], (unsigned long long)n_tk_a); atomicAdd(&lr_pb_stat[11], (unsigned long long)n_tk_b);
     }
 #endif
     // the rows' final thresholds (wave-local: every wave writes its own 64 rows): nn16_exact_kernel drops the entries they exclude

@@ -37,7 +37,7 @@ static void print_clk(int total)
     std::vector<double> mhz, us;
     for (int i = 0; i < 4096 && i < total; ++i) if (ck[2 * i + 1] > 100) { mhz.push_back((double)ck[2 * i] / ck[2 * i + 1] * 100.0); us.push_back(ck[2 * i + 1] / 100.0); }
     std::sort(mhz.begin(), mhz.end()); std::sort(us.begin(), us.end());
-    if (!mhz.empty()) printf("  shader clock while a block runs: median %.0f MHz (p10 %.0f, p90 %.0f); block lifetime median %.1f us\n", mhz[mhz.size() / 2], mhz[mhz.size() / 10], mhz[mhz.size() * 9 / 10], us[us.size() / 2]);
+    if (!mhz.empty()) printf("  shader clock while a block runs: median %.0f MHz (p10 %.0f, p90 %.0f); block lifetime median %.1f us (p10 %.1f, p90 %.1f, max %.1f)\n", mhz[mhz.size() / 2], mhz[mhz.size() / 10], mhz[mhz.size() * 9 / 10], us[us.size() / 2], us[us.size() / 10], us[us.size() * 9 / 10], us.back());
 #endif
 }
 #if PB_NEW_ABI
@@ -88,7 +88,10 @@ int main(int argc, char **argv)
         if (only_nohit) break;
         PB_THR(thr, nrm, need, sstride);
         static char *s_ysh, *s_arr; static size_t s_stride; static int s_P, s_n; s_ysh = (char *)ysh; s_arr = (char *)arr; s_stride = stride; s_P = P; s_n = n;
-        g_pre = [] { for (int p = 0; p < s_P; ++p) { hipMemsetD32Async((hipDeviceptr_t)(s_ysh + p * s_stride), 0xff800000u, s_n, 0); hipMemsetD32Async((hipDeviceptr_t)(s_arr + p * s_stride), 0, s_n / 256 + 2, 0); } };
+        static int s_pre_calls; s_pre_calls = 0;
+        // (PB_NOPRE=1: only the first reset happens, so every later run starts from the pooled FINAL thresholds of the run before it -- what a
+        // perfect start of the strips would buy)
+        g_pre = [] { if (getenv("PB_NOPRE") && s_pre_calls++ > 0) return; for (int p = 0; p < s_P; ++p) { hipMemsetD32Async((hipDeviceptr_t)(s_ysh + p * s_stride), 0xff800000u, s_n, 0); hipMemsetD32Async((hipDeviceptr_t)(s_arr + p * s_stride), 0, s_n / 256 + 2, 0); } };
         auto run = [&] { PB_LAUNCH(grid, dim3(256), 0, 0, H, n, (const int32_t*)nullptr, (const int32_t*)nullptr, H, nrm, n, tps, (const float*)nullptr, cnt, cand,
                                             (const int32_t*)nullptr, (const float*)nullptr, (const uint32_t*)nullptr, (const int32_t*)nullptr, (const uint32_t*)nullptr, (float*)nullptr, 0, PB_YS thr, lr_pb_grid{ row_blocks, strips, total, 0, 0 }, z); };
         float msp = timeit([&] { run(); });
@@ -108,6 +111,7 @@ int main(int argc, char **argv)
                    (double)st[1] / st[0], (double)st[2] / st[0], (double)st[1] / (double)(st[2] ? st[2] : 1), (double)st[3] / st[0], (double)st[3] / st[0] / 64.0, (double)st[4] / st[0], (double)st[5] / st[0]);
             printf("    per wave, us: lifetime %.1f  before the walk (thresholds / sample phase) %.1f  derive rounds %.1f  list flushes %.1f\n",
                    (double)st[9] / st[0] / 100.0, (double)st[8] / st[0] / 100.0, (double)st[6] / st[0] / 100.0, (double)st[7] / st[0] / 100.0);
+            printf("    per wave, us: of the derive rounds: waiting for the gathers %.1f  threshold update + exchange %.1f\n", (double)st[10] / st[0] / 100.0, (double)st[11] / st[0] / 100.0);
         }
 #endif
     }
