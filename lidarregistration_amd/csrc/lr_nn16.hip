@@ -211,7 +211,7 @@ __device__ __forceinline__ int lr_lds_off(int j, int p) { return j * LR_LDS_ROW 
 #define LR_PB_CH 4
 #endif
 #ifndef LR_PB_EXP
-#define LR_PB_EXP 0     // development switches (tools/pb_micro.hip): 1 no staging, 2 no tests, 4 no tightening, 8 clock probe, 16 hit statistics, 128 plain test only
+#define LR_PB_EXP 0     // development switches (tools/pb_micro.hip): 1 no staging, 2 no tests, 4 no tightening, 8 clock probe, 16 hit statistics, 128 plain test only, 2048 phase 1 compiled out
 #endif
 #ifndef LR_PB_WLIST
 #define LR_PB_WLIST 512          // entries per wave (8 bytes each)
@@ -406,6 +406,9 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         }
         s_D[tid] = Dv; s_N1[tid] = -LR_INF; s_N2[tid] = -LR_INF;
         if (tau) s_Y[tid] = rw < na ? 0.5f * tau[rw] : -LR_INF;          // rows past the end never pass the test
+#if LR_PB_EXP & 2048
+        else s_Y[tid] = LR_INF;      // (development switch: phase 1 compiled out -- only launches with given thresholds mean anything)
+#else
         else {
             // ---- phase 1: every sstride-th tile of the strip, rows on the lanes
             const int sstride = thr.sstride;
@@ -559,6 +562,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
                 }
             }
         }
+#endif
         __syncthreads();
     }
     // Several column strips per row block (single-pair and small-batch calls): the strips' blocks run at the same time and each finds
