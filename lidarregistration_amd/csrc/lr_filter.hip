@@ -181,12 +181,17 @@ __device__ __forceinline__ int pr_bucket(float v, float lo, float scale)
     return min(max(b, 0), LR_PR_BUCKETS - 1);
 }
 
-// one block: range of the finite values, bucket histogram in LDS, exclusive offsets -> offs[0..B], fill = copy of offs
+// one block per pair: range of the finite values, bucket histogram in LDS, exclusive offsets -> offs[0..B]; then the members of every bucket
+// with their keys, bucket by bucket (members / mkeys; the order inside a bucket is whatever the LDS position counters hand out -- the
+// ranks below compare (key, index), so it does not matter).  The scatter used to be a launch of its own with one returning device-scope
+// atomic per pair of the list (67 us per 32 x 30k pairs, on every CU); here the counters are LDS words of the block that has the
+// histogram anyway, and a one-block-per-pair kernel hides behind the other calls' filter passes.
+template <bool FUSED>
 __global__ void __launch_bounds__(1024)
-prosac_scan_kernel(const float *__restrict__ q, int m_max, const int32_t *__restrict__ m_dev, int32_t *__restrict__ offs,
-                   int32_t *__restrict__ fill, float *__restrict__ range, lr_zargs z)
+prosac_scan_kernel(const float *__restrict__ q, int m_max, const int32_t *__restrict__ m_dev, int32_t *__restrict__ offs, int32_t *__restrict__ fill,
+                   int32_t *__restrict__ members, float *__restrict__ mkeys, float *__restrict__ range, lr_zargs z)
 {
-    lr_z(q, z, blockIdx.z); lr_z(m_dev, z, blockIdx.z); lr_z(offs, z, blockIdx.z); lr_z(fill, z, blockIdx.z); lr_z(range, z, blockIdx.z);
+    lr_z(q, z, blockIdx.z); lr_z(m_dev, z, blockIdx.z); lr_z(offs, z, blockIdx.z); lr_z(fill, z, blockIdx.z); lr_z(members, z, blockIdx.z); lr_z(mkeys, z, blockIdx.z); lr_z(range, z, blockIdx.z);
     __shared__ int s_h[LR_PR_BUCKETS];
     __shared__ float s_lo[16], s_hi[16];
     __shared__ int s_w[16];
@@ -223,11 +228,29 @@ prosac_scan_kernel(const float *__restrict__ q, int m_max, const int32_t *__rest
 #pragma unroll
     for (int k = 0; k < LR_PR_BUCKETS / 1024; ++k) {
         const int b = threadIdx.x * (LR_PR_BUCKETS / 1024) + k;
-        offs[b] = run; fill[b] = run; run += v[k];
+        offs[b] = run;
+        if constexpr (FUSED) s_h[b] = run;          // (s_h: from here on the next free position of the bucket)
+        else fill[b] = run;                         // (calls of a few pairs: the scatter is a launch of its own, below)
+        run += v[k];
     }
     if (threadIdx.x == 1023) offs[LR_PR_BUCKETS] = run;
+    if constexpr (!FUSED) return;
+    __syncthreads();
+    for (int i0 = threadIdx.x; i0 < m; i0 += 8 * 1024) {
+        float w[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) w[k] = pr_key(q[min(i0 + 1024 * k, m - 1)]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (i0 + 1024 * k < m) {
+                const int pos = atomicAdd(&s_h[pr_bucket(w[k], lo, scale)], 1);
+                members[pos] = i0 + 1024 * k; mkeys[pos] = w[k];          // the key travels with the member: the ranking loop has no dependent loads
+            }
+    }
 }
 
+// the scatter as a launch of its own, for calls of a few pairs (the GPU is idle next to the one block per pair above: a lone 30k pair pays
+// 26 us for the fused form, 10 + 5 for scan + this)
 __global__ void __launch_bounds__(256)
 prosac_scatter_kernel(const float *__restrict__ q, int m_max, const int32_t *__restrict__ m_dev, const float *__restrict__ range,
                       int32_t *__restrict__ fill, int32_t *__restrict__ members, float *__restrict__ mkeys, lr_zargs z)
@@ -238,26 +261,28 @@ prosac_scatter_kernel(const float *__restrict__ q, int m_max, const int32_t *__r
     if (c >= m) return;
     const float v = pr_key(q[c]);
     const int pos = atomicAdd(&fill[pr_bucket(v, range[0], range[1])], 1);
-    members[pos] = c; mkeys[pos] = v;          // the key travels with the member: the ranking loop has no dependent loads
+    members[pos] = c; mkeys[pos] = v;
 }
 
+// thread = POSITION t of the bucket-ordered list (not pair c: the members of a pair's bucket lie around t, so the loads of a wave are
+// neighbours -- indexed by pair they were 2 x 30k scattered sectors per cloud, 95 us per 32 x 30k pairs)
 __global__ void __launch_bounds__(256)
-prosac_rank_kernel(const float *__restrict__ q, int m_max, const int32_t *__restrict__ m_dev, const float *__restrict__ range,
+prosac_rank_kernel(int m_max, const int32_t *__restrict__ m_dev, const float *__restrict__ range,
                    const int32_t *__restrict__ offs, const int32_t *__restrict__ members, const float *__restrict__ mkeys,
                    int32_t *__restrict__ rank, lr_zargs z)
 {
-    lr_z(q, z, blockIdx.z); lr_z(m_dev, z, blockIdx.z); lr_z(range, z, blockIdx.z); lr_z(offs, z, blockIdx.z); lr_z(members, z, blockIdx.z); lr_z(mkeys, z, blockIdx.z);
+    lr_z(m_dev, z, blockIdx.z); lr_z(range, z, blockIdx.z); lr_z(offs, z, blockIdx.z); lr_z(members, z, blockIdx.z); lr_z(mkeys, z, blockIdx.z);
     lr_z(rank, z, blockIdx.z);
     const int m = m_dev ? min(*m_dev, m_max) : m_max;
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= m) return;
-    const float v = pr_key(q[c]);
+    const int t0 = blockIdx.x * 256 + threadIdx.x;
+    if (t0 >= m) return;
+    const int c = members[t0];
+    const float v = mkeys[t0];
     const int b = pr_bucket(v, range[0], range[1]);
     const int e = offs[b + 1];
     int r = offs[b];
     // four members per step, their eight loads independent (the quality distribution decides the bucket sizes: GPF's normalised distance
-    // piles a tenth of the pairs up just below 1 -- 33 members per pair's bucket on average with 4096 buckets, where a dependent
-    // q[members[t]] per step cost 218 us per 32 x 30k pairs)
+    // piles a tenth of the pairs up just below 1)
     for (int t = offs[b]; t < e; t += 4) {
         int j[4]; float w[4];
 #pragma unroll
@@ -286,10 +311,15 @@ int lr_prosac_order(lr_workspace *ws, const float *F0, const float *F1, int dim,
     // GPF's scratch is free by now: offsets | fill | range in its cell arrays, bucket members in its sort buffer
     int32_t *offs = ws->gpf_cells, *fill = offs + LR_PR_BUCKETS + 8;
     float *range = reinterpret_cast<float *>(fill + LR_PR_BUCKETS + 8);
-    hipLaunchKernelGGL(prosac_scan_kernel, dim3(1, 1, ws->zP), dim3(1024), 0, st, quality, m_max, m_dev, offs, fill, range, ws->z);
     float *mkeys = reinterpret_cast<float *>(ws->cell);       // (GPF's cell ids: free by now, like the rest of its scratch)
-    hipLaunchKernelGGL(prosac_scatter_kernel, dim3(nb, 1, ws->zP), dim3(256), 0, st, quality, m_max, m_dev, (const float *)range, fill, ws->cell_sorted, mkeys, ws->z);
-    hipLaunchKernelGGL(prosac_rank_kernel, dim3(nb, 1, ws->zP), dim3(256), 0, st, quality, m_max, m_dev, (const float *)range, (const int32_t *)offs,
+    const bool fused = ws->zP > 4;      // (full batches: the scatter inside the one-block-per-pair scan, hidden behind the other calls' filter passes)
+    if (fused)
+        hipLaunchKernelGGL(prosac_scan_kernel<true>, dim3(1, 1, ws->zP), dim3(1024), 0, st, quality, m_max, m_dev, offs, fill, ws->cell_sorted, mkeys, range, ws->z);
+    else {
+        hipLaunchKernelGGL(prosac_scan_kernel<false>, dim3(1, 1, ws->zP), dim3(1024), 0, st, quality, m_max, m_dev, offs, fill, ws->cell_sorted, mkeys, range, ws->z);
+        hipLaunchKernelGGL(prosac_scatter_kernel, dim3(nb, 1, ws->zP), dim3(256), 0, st, quality, m_max, m_dev, (const float *)range, fill, ws->cell_sorted, mkeys, ws->z);
+    }
+    hipLaunchKernelGGL(prosac_rank_kernel, dim3(nb, 1, ws->zP), dim3(256), 0, st, m_max, m_dev, (const float *)range, (const int32_t *)offs,
                        (const int32_t *)ws->cell_sorted, (const float *)mkeys, ws->prosac_rank, ws->z);
     LR_LAUNCH_CHECK();
     return LR_OK;

@@ -459,3 +459,13 @@ def test_prosac_order_with_tied_qualities(lr, oracle, mode):
     e = oracle.register_pair(p["xyz0"], p["xyz1"], p["feats0"], p["feats1"], mode=mode, iters=3000, seed=51, args=a, **gc_oracle_kwargs(a))
     np.testing.assert_allclose(out[0], e["T"], rtol=0, atol=1e-9)
     assert oracle.rotation_error_deg(out[0], p["T_gt"]) < 1.0
+    # the same pair five times in ONE batched call: calls of more than four pairs scatter inside the one-block-per-pair scan kernel
+    # (LDS position counters) instead of a launch of its own -- same transform, pair for pair
+    params = lr.FR.pair_params(a)
+    dev = [tuple(t(p[k]).cuda() for k in ("xyz0", "xyz1", "feats0", "feats1")) for _ in range(5)]
+    ws = lr.ext.Workspace(6000, 1500, 32, a.iters, max_pairs=5)
+    ws.poison(0x5A)
+    outb = lr.FR.register_batch_dev(dev, params, ws=ws).cpu().numpy()
+    for k in range(5):
+        r = lr.ext.PairResult.from_buffer_copy(outb[k].tobytes())
+        np.testing.assert_allclose(np.array(r.T).reshape(4, 4), e["T"], rtol=0, atol=1e-9)
