@@ -192,7 +192,7 @@ nn16_range_kernel(int na, const float *__restrict__ bmaxa, const float *__restri
 // in the loop.
 //
 // Thresholds tighten while the walk runs (derive(), below): whenever LR_PB_TIGHTEN new entries have gathered in a list, the four
-// waves of the block go through their new entries TOGETHER (JOINT: they exchange what their lists want at the chunk barrier -- a wave
+// waves of the block go through their new entries TOGETHER (they exchange what their lists want at the chunk barrier -- a wave
 // in a round keeps its siblings waiting there, so the rounds are taken at the same time), 16 entries per instruction group: the
 // entries' columns are gathered and the walk's own MFMA repeated on them with the thresholds of now -- same instruction, same
 // operands, same bits --, which yields each entry's row mask and, for single-row entries, the filter value g = dot16 - x_j; the two
@@ -207,42 +207,18 @@ nn16_range_kernel(int na, const float *__restrict__ bmaxa, const float *__restri
 // row -- conflict-free (unswizzled 64- or 80-byte rows: 2-way).  Both phases read with that lane map.
 __device__ __forceinline__ int lr_lds_off(int j, int p) { return j * LR_LDS_ROW + ((p ^ ((j >> 1) & 3)) << 4); }
 #define LR_BLOCK_ROWS 256        // rows per block: 4 waves x 64 rows (four 16-row MFMA blocks per wave)
-#ifndef LR_PB_CH
-#define LR_PB_CH 4
-#endif
-#ifndef LR_PB_EXP
-#define LR_PB_EXP 0     // development switches (tools/pb_micro.hip): 1 no staging, 2 no tests, 4 no tightening, 8 clock probe, 16 hit statistics, 128 plain test only, 2048 phase 1 compiled out
-#endif
-#ifndef LR_PB_WLIST
+#define LR_PB_CH 4               // column tiles per staged chunk
 #define LR_PB_WLIST 512          // entries per wave (8 bytes each)
-#endif
 // Entry of a hit list / of the candidate store (8 bytes): x = column (22 bits) | kb << 22 | LR_PB_HASG; y = 16-bit row mask | g16 << 16.
 // kb = lane / 16 of the lane that saw the hit: bit b = 4 rbk + g of the mask <-> row 16 rbk + 4 kb + g of the wave (the lane's 16
 // accumulator registers of one 16-column block).  The walk parks entries with an empty mask; derive() fills it in.
 #define LR_PB_COLMASK 0x3fffffu
 #define LR_PB_HASG 0x1000000u    // entry flag (in x): exactly one row, and y carries its filter value g rounded up to 16 bits
-#ifndef LR_PB_JOINT
-#define LR_PB_JOINT 1          // 0: development switch, every wave attends to its list on its own
-#endif
-#ifndef LR_PB_PRIO
-#define LR_PB_PRIO 1          // a wave inside derive() runs at raised priority: its siblings wait for it at the next chunk barrier (60.1 -> 59.3 us per pair)
-#endif
-#ifndef LR_PB_DGROUPS
 #define LR_PB_DGROUPS 3          // groups of 16 entries derive() has in flight at once (registers: 9 per group)
-#endif
-#ifndef LR_PB_TIGHTEN
 #define LR_PB_TIGHTEN 48         // new entries of a wave that trigger a tightening round
-#endif
-#ifndef LR_PB_GEO
-#define LR_PB_GEO 0              // > 0: geometric schedule -- the first round after LR_PB_GEO new entries, every later one after twice as many (capped at LR_PB_GEO_CAP)
-#endif
-#ifndef LR_PB_GEO_CAP
-#define LR_PB_GEO_CAP 192
-#endif
-#ifndef LR_PB_P1FOLD
-#define LR_PB_P1FOLD 1           // 1: phase 1 (SIGN form) keeps elementwise running maxima of the accumulators (16 v_max3 per tile instead of 32 half-rate ops, no
-                                 // per-tile column operand in LDS); same time as the per-tile fold (round 5, profiles/r05_pb_ablation.txt), 1 % more entries per row
-#endif
+// (The variants measured against this kernel -- no staging / no tests / no tightening, geometric tightening schedule, per-wave rounds,
+// the per-tile fold of phase 1 for the sign form, four waves per SIMD, 8-tile chunks -- live in tools/pb_variants/ as patches applied to a
+// copy of this file by tools/pb_variant.sh; none of them is compiled into the library.  profiles/r05_pb_ablation.txt has their numbers.)
 
 // row (0..63 of the wave) of mask bit b (0..15) of an entry of lane group kb
 __device__ __forceinline__ int lr_pb_row(int kb, int b) { return 16 * (b >> 2) + 4 * kb + (b & 3); }
@@ -269,15 +245,15 @@ struct lr_thr_in {
 // grid shape of a 1-D XCD-aware launch + direction (0: rows = cloud 0, columns = cloud 1; 1: the reverse pass)
 struct lr_pb_grid { int gx, gy, total, dir, only; };      // only != 0: the other instantiation is not launched (single-pair calls, see lr_nn16_forms)
 
-#if LR_PB_EXP & 8
-__device__ unsigned long long lr_pb_clk[4096 * 2];      // development probe: shader clocks / 100 MHz ticks a block spent
+// The one development switch of this file: -DLR_PB_PROBE compiles the hit statistics of tools/pb_micro.hip into the filter pass (waves,
+// tests, slow-path visits, hits, derive() rounds, 16-entry groups, 10 ns ticks per phase).  Off in the library: LR_PROBE(...) is empty.
+#ifdef LR_PB_PROBE
+__device__ unsigned long long lr_pb_stat[16];
+#define LR_PROBE(...) __VA_ARGS__
+#else
+#define LR_PROBE(...)
 #endif
-#if LR_PB_EXP & 16
-__device__ unsigned long long lr_pb_stat[16];             // development probe: waves, tests, slow-path visits, hits, derive() rounds, 16-entry groups
-#endif
-#ifndef LR_PB_WAVES
-#define LR_PB_WAVES 3            // waves per SIMD the filter pass is compiled for (4: 128 registers -- development switch)
-#endif
+#define LR_PB_WAVES 3            // waves per SIMD the filter pass is compiled for
 template <bool SIGN>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LR_PB_WAVES, LR_PB_WAVES)))
 nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *__restrict__ rowmap, const int32_t *__restrict__ na_dev,
@@ -291,9 +267,6 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     // (strip, pair), i.e. they stream the same columns through that XCD's L2
     int logical;
     if (!lr_xcd_block(pg.total, logical)) return;
-#if LR_PB_EXP & 8
-    const unsigned long long clk0 = __builtin_readcyclecounter(), rt0 = __builtin_amdgcn_s_memrealtime();
-#endif
     const int bx = logical % pg.gx, by = (logical / pg.gx) % pg.gy, pair = logical / (pg.gx * pg.gy);
     if (z.descs) {
         const lr_pair_desc d = z.descs[pair];
@@ -302,7 +275,6 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     lr_z(Hq, z, pair); lr_z(rowmap, z, pair); lr_z(na_dev, z, pair); lr_z(Hc, z, pair); lr_z(nC, z, pair); lr_z(tau, z, pair);
     lr_z(cand_cnt, z, pair); lr_z(cand, z, pair); lr_z(colmap, z, pair); lr_z(tile_min, z, pair); lr_z(row_bound, z, pair); lr_z(rev_offs, z, pair); lr_z(rev_range, z, pair);
     lr_z(thr.nQ, z, pair); lr_z(thr.range_c, z, pair); lr_z(yfin, z, pair); lr_z(yshare, z, pair);
-    constexpr bool JOINT = LR_PB_JOINT != 0;      // (one instantiation serves the forward and the reverse launch: the reverse one pays ~2 % for the exchange it does not need)
     // rows: either 0..na_host-1, or (reverse direction) the ordered list rowmap[0..*na_dev-1]; tau, cand_cnt and cand
     // are indexed by the position in that list.  Columns: Hc/nC as they lie; with colmap they are a permuted copy and
     // a candidate's column id is colmap[position].
@@ -319,7 +291,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     // an infinite maximum fails `max_nc < inf`; with `inf - min <= 1e-4 inf` alone one overflowing column selected the sign form.)
     float max_nc = 0.0f, min_nc = 0.0f;
     if (thr.range_c) { max_nc = thr.range_c[0]; min_nc = thr.range_c[1]; }
-    const bool sign_ok = thr.range_c != nullptr && min_nc > 0.0f && max_nc < LR_INF && max_nc - min_nc <= 1e-4f * max_nc && !(LR_PB_EXP & 128);
+    const bool sign_ok = thr.range_c != nullptr && min_nc > 0.0f && max_nc < LR_INF && max_nc - min_nc <= 1e-4f * max_nc && true;
     if (sign_ok != SIGN) {
         // (launched alone on the strength of the previous call's norms, and this call's ask for the other form: say so -- the exact
         // kernel then re-does every row by the full scan, and the next call launches the right one)
@@ -330,7 +302,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     __shared__ int s_limit[4];
     constexpr int CH = LR_PB_CH;
     constexpr int XOFF = CH * 32 * LR_LDS_ROW;
-    constexpr int BUF = XOFF + ((SIGN && LR_PB_P1FOLD) ? 0 : CH * 32 * 4);      // (the sign form stages no per-column operand, in either phase)
+    constexpr int BUF = XOFF + (SIGN ? 0 : CH * 32 * 4);      // (the sign form stages no per-column operand, in either phase)
     // The two chunk buffers are SEPARATE arrays on purpose: the walk fills one by LDS-direct loads while it reads the other, and the
     // compiler's wait-count pass puts a vmcnt(0) in front of every LDS read that MAY alias a pending LDS-direct load -- with one array
     // that was every fragment read behind the loads, i.e. the prefetch became synchronous (round 5: found in the ISA).
@@ -346,11 +318,8 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int c16 = lane & 15, kb = lane >> 4;
     const int row0 = bx * LR_BLOCK_ROWS + wave * 64;
-#if LR_PB_EXP & 16
-    int n_visits = 0, n_hits = 0, n_rounds = 0, n_groups = 0, n_tk_derive = 0, n_tk_flush = 0, n_tk_a = 0, n_tk_b = 0;      // development probe: slow-path visits, hits, derive() rounds, 16-entry groups, 10 ns ticks
-    const unsigned long long tk_start = __builtin_amdgcn_s_memrealtime();
-    unsigned long long tk_walk = 0;
-#endif
+    LR_PROBE(int n_visits = 0, n_hits = 0, n_rounds = 0, n_groups = 0, n_tk_derive = 0, n_tk_flush = 0, n_tk_a = 0, n_tk_b = 0;
+             const unsigned long long tk_start = __builtin_amdgcn_s_memrealtime(); unsigned long long tk_walk = 0;)
     int ntiles = (nb + 31) >> 5;
     int my_strips = pg.gy;           // strips this row block really uses (the ordered reverse pass: as many as its column prefix is worth)
     if (tile_min) {
@@ -406,15 +375,12 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         }
         s_D[tid] = Dv; s_N1[tid] = -LR_INF; s_N2[tid] = -LR_INF;
         if (tau) s_Y[tid] = rw < na ? 0.5f * tau[rw] : -LR_INF;          // rows past the end never pass the test
-#if LR_PB_EXP & 2048
-        else s_Y[tid] = LR_INF;      // (development switch: phase 1 compiled out -- only launches with given thresholds mean anything)
-#else
         else {
             // ---- phase 1: every sstride-th tile of the strip, rows on the lanes
             const int sstride = thr.sstride;
             const int nsamp = t_end > t_begin ? (t_end - t_begin + sstride - 1) / sstride : 0;     // tiles this block samples
             const int nsch = (nsamp + CH - 1) / CH;
-            constexpr bool P1E = SIGN && (LR_PB_P1FOLD != 0);      // (see fold() below)
+            constexpr bool P1E = SIGN;      // (see fold() below)
             auto tile_s = [&](int c, int k) { return t_begin + (c * CH + k) * sstride; };
             auto load_s = [&](int c) {
 #pragma unroll
@@ -448,7 +414,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
             // eight MFMAs after they were issued: the hardware does not interlock a vector read of an MFMA result and the compiler does
             // not see inside the asm, so scheduling barriers pin the order); the LDS fragments of tile k + 1 are requested before the
             // MFMAs of tile k.  Unpipelined (round 3) the phase took 1.75x the walk's time per tile: 9 % of a block's lifetime.
-            // P1E (all column norms alike, LR_PB_P1FOLD): the lane keeps ELEMENTWISE running maxima of its accumulators instead -- register
+            // P1E (all column norms alike): the lane keeps ELEMENTWISE running maxima of its accumulators instead -- register
             // g of row block rbk collects columns 4 kb + g and 16 + 4 kb + g of every sampled tile, one v_max3 per register and tile (16
             // per tile instead of 32 half-rate ops); the 4 registers x 4 lanes of a row are 16 disjoint column classes, so the two largest
             // class maxima belong to different columns, and g >= dot16 - max_nc / 2 bounds the filter value from below
@@ -562,7 +528,6 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
                 }
             }
         }
-#endif
         __syncthreads();
     }
     // Several column strips per row block (single-pair and small-batch calls): the strips' blocks run at the same time and each finds
@@ -571,7 +536,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     // (yshare, set to +inf by the prep kernel), here after the sample phase and then once per tightening round.  The returned value
     // is what the other strips had found by then.  (A rendezvous of the strips after the sample phase -- a bounded spin on an arrival
     // counter -- was measured and dropped: the strips of a row block are dispatched too far apart, 127 against 110 us for one pair.)
-    const bool pooled = yshare != nullptr && thr.nQ != nullptr && my_strips > 1 && !(LR_PB_EXP & 4);
+    const bool pooled = yshare != nullptr && thr.nQ != nullptr && my_strips > 1;
     if (pooled) {
         const int rw = bx * LR_BLOCK_ROWS + tid;
         if (rw < na) {
@@ -590,9 +555,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         for (int rbk = 0; rbk < 4; ++rbk) y4[rbk] -= xhat;          // (xhat = 0 unless SIGN: x - 0 is x)
     };
     load_y();
-#if LR_PB_EXP & 16
-    tk_walk = __builtin_amdgcn_s_memrealtime();
-#endif
+    LR_PROBE(tk_walk = __builtin_amdgcn_s_memrealtime();)
     // Staging of the walk: buffer loads STRAIGHT INTO LDS (buffer_load_dwordx4 ... lds: no staging registers, no ds_write; the chunk's
     // position is a scalar offset; rows past the end of the cloud read as zeros through the range check of the buffer descriptor, and
     // whatever such a column -- or a column past the end of the strip -- makes of the test is masked by derive() and flush()).
@@ -651,7 +614,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     // otherwise be kept in registers across the hot loop (or spilled to scratch memory and fetched back on every visit: +4 us per pair)
     auto cold_lane = [&]() { int l; asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l)); return l; };
     int wdone = 0;           // ... of which the tightening has seen this many
-    int trig = LR_PB_GEO > 0 ? LR_PB_GEO : LR_PB_TIGHTEN;      // new entries that make the wave ask for a tightening round
+    int trig = LR_PB_TIGHTEN;      // new entries that make the wave ask for a tightening round
     // what the wave's list wants (bit 0: a tightening round, bit 1: to be emptied): recomputed where wcnt / wdone change (the slow path of
     // a hit, derive(), flush()) -- not at every chunk -- and posted to the block only when it differs from what was posted last
     int wposted = 0, wnext = 0;      // the wish posted last; the fill count from which the list wants something
@@ -663,7 +626,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     const int seg_cap = lr_seg_cap(my_strips);
     uint2 *__restrict__ seg = reinterpret_cast<uint2 *>(cand) + (size_t)(bx * 4 + wave) * LR_NN16_SEG + (size_t)by * seg_cap;
     int seg_fill = 0;
-    const bool tightening = thr.nQ != nullptr && !(LR_PB_EXP & 4);
+    const bool tightening = thr.nQ != nullptr;
     auto my_wish = [&]() { return (wcnt >= WL / 2 ? 2 : 0) | ((tightening && wcnt - wdone >= trig) ? 1 : 0); };
     auto set_next = [&]() { wnext = tightening ? min(wdone + trig, WL / 2) : WL / 2; };      // (my_wish() != 0 <=> wcnt >= wnext)
     set_next();
@@ -681,13 +644,8 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     auto derive = [&](bool update) {
         const int lane = cold_lane(), c16 = lane & 15, kb = lane >> 4;      // (shadow the kernel's)
         const int nlist = min(wcnt, WL);
-#if LR_PB_PRIO
-        __builtin_amdgcn_s_setprio(3);      // the wave's three siblings wait for it at the next chunk barrier
-#endif
-#if LR_PB_EXP & 16
-        ++n_rounds; n_groups += (nlist - wdone + 15) >> 4;
-        const unsigned long long tk0 = __builtin_amdgcn_s_memrealtime();
-#endif
+        __builtin_amdgcn_s_setprio(3);      // the wave's three siblings wait for it at the next chunk barrier (60.1 -> 59.3 us per pair)
+        LR_PROBE(++n_rounds; n_groups += (nlist - wdone + 15) >> 4; const unsigned long long tk0 = __builtin_amdgcn_s_memrealtime();)
         constexpr int DG = SIGN ? LR_PB_DGROUPS : (LR_PB_DGROUPS > 2 ? 2 : LR_PB_DGROUPS);      // (the plain form holds the x_j operands too: a third group would spill)
         for (int e0 = wdone; e0 < nlist; e0 += 16 * DG) {
             // a few groups of 16 entries per pass: all their gathers are in flight before the first MFMA (one L2 latency per pass)
@@ -699,9 +657,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
                 bf[g] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrcH, col * 64 + kb * 16, 0, 0));
                 xn[g] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrcN, col * 4, 0, 0));
             }
-#if LR_PB_EXP & 16
-            { const unsigned long long ta = __builtin_amdgcn_s_memrealtime(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); n_tk_a += (int)(__builtin_amdgcn_s_memrealtime() - ta); }
-#endif
+            LR_PROBE({ const unsigned long long ta = __builtin_amdgcn_s_memrealtime(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); n_tk_a += (int)(__builtin_amdgcn_s_memrealtime() - ta); })
 #pragma unroll
             for (int g = 0; g < DG; ++g) {
                 if (e0 + 16 * g >= nlist) break;              // (wave-uniform)
@@ -744,11 +700,9 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
                 }
             }
         }
-#if LR_PB_EXP & 16
-        const unsigned long long tb = __builtin_amdgcn_s_memrealtime();
-#endif
+        LR_PROBE(const unsigned long long tb = __builtin_amdgcn_s_memrealtime();)
         wdone = nlist;
-        if (LR_PB_GEO > 0 && update) trig = min(2 * trig, LR_PB_GEO_CAP);
+        if (false && update) trig = min(2 * trig, 192);
         set_next();
         if (update) {
             // lane = row: y <- min(y, E' - g_need + 2e-6 |g_need|)   (g_need: the need-th largest g of the walk so far; -inf: no change)
@@ -765,21 +719,13 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
             s_Y[rl] = yv;
             load_y();
         }
-#if LR_PB_EXP & 16
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        n_tk_b += (int)(__builtin_amdgcn_s_memrealtime() - tb);
-        n_tk_derive += (int)(__builtin_amdgcn_s_memrealtime() - tk0);
-#endif
-#if LR_PB_PRIO
+        LR_PROBE(asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); n_tk_b += (int)(__builtin_amdgcn_s_memrealtime() - tb); n_tk_derive += (int)(__builtin_amdgcn_s_memrealtime() - tk0);)
         __builtin_amdgcn_s_setprio(0);
-#endif
     };
     auto flush = [&]() {
         if (wdone < wcnt) derive(tightening);
         const int lane = cold_lane();
-#if LR_PB_EXP & 16
-        const unsigned long long tkf = __builtin_amdgcn_s_memrealtime();
-#endif
+        LR_PROBE(const unsigned long long tkf = __builtin_amdgcn_s_memrealtime();)
         if (wcnt > WL) seg_fill = -1;       // more hits between two chunk boundaries than the list holds
         else if (seg_fill >= 0) {
             for (int e0 = 0; e0 < wcnt; e0 += 64) {
@@ -806,18 +752,12 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
             }
         }
         wcnt = 0; wdone = 0; set_next();
-#if LR_PB_EXP & 16
-        n_tk_flush += (int)(__builtin_amdgcn_s_memrealtime() - tkf);
-#endif
+        LR_PROBE(n_tk_flush += (int)(__builtin_amdgcn_s_memrealtime() - tkf);)
     };
     // candidate test of the lane's 16 accumulator registers of column block cb (16 columns x the wave's 64 rows).
     // A hit only parks { column, lane group } -- a handful of vector instructions and one LDS write; everything else about it is worked
     // out later, 16 entries per instruction group (derive()).
     auto check = [&](const f32x4 &r0, const f32x4 &r1, const f32x4 &r2, const f32x4 &r3, float x, int tile, int cb) {
-#if LR_PB_EXP & 2
-        asm volatile("" :: "v"(r0), "v"(r1), "v"(r2), "v"(r3));
-        return;
-#endif
         bool mine_hit;
         if constexpr (SIGN) {
             // two interleaved chains of three-input ANDs over the 16 sign bits (one asm block: no hazard padding between the halves)
@@ -851,9 +791,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
                 if (pos < WL) wlist[wave][pos] = make_uint2((unsigned)(tile * 32 + cb * 16) | lc, 0u);
             }
             wcnt += __builtin_popcountll(hit);
-#if LR_PB_EXP & 16
-            ++n_visits; n_hits += __builtin_popcountll(hit);
-#endif
+            LR_PROBE(++n_visits; n_hits += __builtin_popcountll(hit);)
         }
     };
 
@@ -908,7 +846,7 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         read_b(c0_t{}, 0, b0, b1, xN);
         // The walk is a loop nest: the inner loop is the hot one and contains no tightening code (the compiler then keeps the threshold
         // registers loop-invariant and its wait counts exact); it is left whenever a hit list wants attention.
-        // The four waves of a block attend to their lists TOGETHER (JOINT): a wave in derive() keeps its three siblings waiting
+        // The four waves of a block attend to their lists TOGETHER: a wave in derive() keeps its three siblings waiting
         // at the next chunk barrier, so 4 x ~11 rounds per block, one wave at a time, stall the block four times as often as ~12 rounds
         // that all four take at once.  Every wave keeps what its list wants in one byte of an LDS word (written only when it changes),
         // reads all four wishes behind the chunk barrier and acts at the end of the chunk.  (The decision need not be block-uniform: a wave
@@ -930,34 +868,23 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
                     // the last step of a chunk reads the first fragment of the next one: make that chunk visible now.  All
                     // reads of the buffer it goes to were issued before the previous barrier (the step above read this
                     // chunk's own last tile), so one barrier per chunk still orders everything.
-#if !(LR_PB_EXP & 1)
-#if !(LR_PB_EXP & 32)
                     if (!tail || c + 1 < nchunks) { __builtin_amdgcn_s_waitcnt(0x0F70); finish_chunk(std::integral_constant<int, par ^ 1>{}, c + 1); }      // vmcnt(0): chunk c + 1 has landed
-#endif
-                    if constexpr (JOINT) {
-                        // (one scalar comparison per chunk; the wish is worked out and written when the list reaches the mark; a round
-                        // follows at the end of this very chunk -- the wave reads its own byte behind the barrier -- and takes it back)
-                        if (__builtin_expect(wcnt >= wnext, 0)) {
-                            const int wm = my_wish();
-                            if (lane == 0) reinterpret_cast<unsigned char *>(&s_att[0])[wave] = (unsigned char)wm;
-                            wposted = wm; wnext = 0x7fffffff;
-                        }
+                    // (one scalar comparison per chunk; the wish is worked out and written when the list reaches the mark; a round
+                    // follows at the end of this very chunk -- the wave reads its own byte behind the barrier -- and takes it back)
+                    if (__builtin_expect(wcnt >= wnext, 0)) {
+                        const int wm = my_wish();
+                        if (lane == 0) reinterpret_cast<unsigned char *>(&s_att[0])[wave] = (unsigned char)wm;
+                        wposted = wm; wnext = 0x7fffffff;
                     }
-#if !(LR_PB_EXP & 64)
                     __syncthreads();
-#endif
                     // (requested here, looked at behind the chunk's last step)
-                    if constexpr (JOINT) wishes = s_att[0];
-#if !(LR_PB_EXP & 32)
+                    wishes = s_att[0];
                     if (!tail || c + 2 < nchunks) load_chunk(std::integral_constant<int, par>{}, c + 2);      // (into the buffer chunk c has just been read out of)
-#endif
-#endif
                 }
                 step(c, k, parc);
             }
             // (the four bytes as they are: which bit is set is looked at outside the loop)
-            if constexpr (JOINT) wish = (int)__builtin_amdgcn_readfirstlane(wishes);
-            else wish = wcnt >= wnext ? my_wish() : 0;
+            wish = (int)__builtin_amdgcn_readfirstlane(wishes);
             ++c;
         };
         typedef std::integral_constant<int, 0> body_t;
@@ -971,8 +898,8 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
             else if (c + 3 < nchunks) {
                 do { chunk(c0_t{}, body_t{}); if (wish) break; chunk(c1_t{}, body_t{}); } while (!wish && c + 3 < nchunks);
             } else chunk(c0_t{}, tail_t{});
-            if constexpr (JOINT) wish = (wish & 0x02020202) ? 2 : (wish ? 1 : 0);
-            if constexpr (JOINT) { if (wish && wposted) { if (lane == 0) reinterpret_cast<unsigned char *>(&s_att[0])[wave] = 0; wposted = 0; } }
+            wish = (wish & 0x02020202) ? 2 : (wish ? 1 : 0);
+            if (wish && wposted) { if (lane == 0) reinterpret_cast<unsigned char *>(&s_att[0])[wave] = 0; wposted = 0; }
             if (wish & 2) flush();
             else if (wish) { if (wdone < wcnt) derive(true); }
         }
@@ -988,19 +915,14 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         cw[by] = seg_fill;                     // entries in this wave's segment (< 0: overflow)
         if (by == 0) cw[pg.gy] = my_strips;    // how the wave's store is divided (read by nn16_exact_kernel)
     }
-#if LR_PB_EXP & 8
-    if (threadIdx.x == 0 && logical < 4096) { lr_pb_clk[2 * logical] = __builtin_readcyclecounter() - clk0; lr_pb_clk[2 * logical + 1] = __builtin_amdgcn_s_memrealtime() - rt0; }
-#endif
-#if LR_PB_EXP & 16
-    if (lane == 0) {
+    LR_PROBE(if (lane == 0) {
         atomicAdd(&lr_pb_stat[0], 1ull); atomicAdd(&lr_pb_stat[1], (unsigned long long)nchunks * CH * 4); atomicAdd(&lr_pb_stat[2], (unsigned long long)n_visits);
         atomicAdd(&lr_pb_stat[3], (unsigned long long)n_hits); atomicAdd(&lr_pb_stat[4], (unsigned long long)n_rounds); atomicAdd(&lr_pb_stat[5], (unsigned long long)n_groups);
         const unsigned long long tk_end = __builtin_amdgcn_s_memrealtime();
         atomicAdd(&lr_pb_stat[6], (unsigned long long)n_tk_derive); atomicAdd(&lr_pb_stat[7], (unsigned long long)n_tk_flush);
         atomicAdd(&lr_pb_stat[8], tk_walk - tk_start); atomicAdd(&lr_pb_stat[9], tk_end - tk_start);
         atomicAdd(&lr_pb_stat[10], (unsigned long long)n_tk_a); atomicAdd(&lr_pb_stat[11], (unsigned long long)n_tk_b);
-    }
-#endif
+    })
     // the rows' final thresholds (wave-local: every wave writes its own 64 rows): nn16_exact_kernel drops the entries they exclude
     if (yfin) {
         const int rw = row0 + lane;

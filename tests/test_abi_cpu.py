@@ -135,3 +135,18 @@ def test_pair_params_follow_the_reference_flags():
         FR.pair_params(Args(mode="bogus"))
     with pytest.raises(AssertionError):
         FR.pair_params(Args(codebase="other"))
+
+
+def test_no_ablation_switches_in_the_shipped_kernels():
+    """The library's .hip files carry no development variants: the ablation switches of rounds 3-5 (LR_PB_EXP bits, geometric
+    schedule, per-wave rounds, ...) are rebuilt from history by tools/pb_variant.sh; lr_nn16.hip keeps ONE switch, the statistics probe."""
+    csrc = os.path.join(ROOT, "lidarregistration_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h")):
+            text = open(os.path.join(csrc, f)).read()
+            for word in ("LR_PB_EXP", "LR_PB_GEO", "LR_PB_JOINT", "LR_PB_P1FOLD", "LR_PB_PRIO"):
+                assert word not in text, f"{f} still carries the development switch {word}"
+    nn = open(os.path.join(csrc, "lr_nn16.hip")).read()
+    conds = re.findall(r"^\s*#\s*(?:if|ifdef|ifndef|elif)\b.*$", nn, flags=re.M)
+    assert len(conds) <= 6, conds
+    assert any("LR_PB_PROBE" in c for c in conds)

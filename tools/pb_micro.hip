@@ -1,5 +1,6 @@
 // Timing harness for the batched filter pass (nn16_passb_kernel: sample phase + walk) (development tool): P identical pairs in P arenas.
-//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form=1 [-DLR_PB_EXP=k] tools/pb_micro.hip -o tools/bin/pb_micro_k
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form=1 [-DLR_PB_PROBE] tools/pb_micro.hip -o tools/bin/pb_micro
+//   (-DLR_PB_PROBE: hit statistics.  The round-5 ablation variants -- -DLR_PB_EXP=... -- are built from that round's source: tools/pb_variant.sh)
 //   usage: pb_micro [n=30000] [P=32] [strips=1]
 #ifndef PB_SRC
 #define PB_SRC "../lidarregistration_amd/csrc/lr_nn16.hip"
@@ -30,16 +31,7 @@ template <class F> float timeit(F f, int reps = 8) {
     for (int r = 0; r < reps; ++r) { if (g_pre) { g_pre(); hipDeviceSynchronize(); } hipEventRecord(e0, 0); f(); hipEventRecord(e1, 0); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); best = ms < best ? ms : best; }
     return best;
 }
-static void print_clk(int total)
-{
-#if LR_PB_EXP & 8
-    std::vector<unsigned long long> ck(8192); hipMemcpyFromSymbol(ck.data(), HIP_SYMBOL(lr_pb_clk), 65536);
-    std::vector<double> mhz, us;
-    for (int i = 0; i < 4096 && i < total; ++i) if (ck[2 * i + 1] > 100) { mhz.push_back((double)ck[2 * i] / ck[2 * i + 1] * 100.0); us.push_back(ck[2 * i + 1] / 100.0); }
-    std::sort(mhz.begin(), mhz.end()); std::sort(us.begin(), us.end());
-    if (!mhz.empty()) printf("  shader clock while a block runs: median %.0f MHz (p10 %.0f, p90 %.0f); block lifetime median %.1f us (p10 %.1f, p90 %.1f, max %.1f)\n", mhz[mhz.size() / 2], mhz[mhz.size() / 10], mhz[mhz.size() * 9 / 10], us[us.size() / 2], us[us.size() / 10], us[us.size() * 9 / 10], us.back());
-#endif
-}
+static void print_clk(int) {}      // (round 5 printed the per-block shader clock of an -DLR_PB_EXP=8 build here; the library has lr_workspace_clock now)
 #if PB_NEW_ABI
 #define PB_THR(name, nq, need, ss) lr_thr_in name = { nq, nrange, need, ss }
 #define PB_LAUNCH(...) do { hipLaunchKernelGGL(nn16_passb_kernel<true>, __VA_ARGS__); hipLaunchKernelGGL(nn16_passb_kernel<false>, __VA_ARGS__); } while (0)
@@ -81,7 +73,7 @@ int main(int argc, char **argv)
     const int total = row_blocks * strips * P;
     dim3 grid(8 * ((total + 7) / 8));
     const int tps = (ntiles + strips - 1) / strips;
-    printf("EXP=%d TIGHTEN=%d n=%d P=%d strips=%d blocks=%d\n", LR_PB_EXP, LR_PB_TIGHTEN, n, P, strips, total);
+    printf("TIGHTEN=%d n=%d P=%d strips=%d blocks=%d\n", LR_PB_TIGHTEN, n, P, strips, total);
     const bool only_nohit = getenv("PB_ONLY") && !strcmp(getenv("PB_ONLY"), "nohit");      // (counter runs: only the candidate-free walk on real accumulators is repeated)
     for (int need : {2, 1})
     for (int sstride : {2, 4, 8, 16, 32, 64}) {
@@ -101,7 +93,7 @@ int main(int argc, char **argv)
         double tot = 0; int over = 0; for (int i = 0; i < nseg; ++i) if (i % (strips + 1) != strips) { if (c1[i] < 0) over++; else tot += c1[i]; }
         printf("filter pass need=%d sample stride %2d: %8.3f ms  = %6.1f us/pair   list entries/row %.2f  overflowed segments %d\n", need, sstride, msp, msp * 1e3 / P, tot / n, over);
         print_clk(total);
-#if LR_PB_EXP & 16
+#ifdef LR_PB_PROBE
         {
             unsigned long long z8[16] = {0}, st[16];
             if (g_pre) g_pre();
