@@ -136,7 +136,7 @@ typedef struct lr_pair_params {
 } lr_pair_params;
 
 /* ---- library ------------------------------------------------------------------------------- */
-LR_API int         lr_version(void);    /* 100 * major + minor; 102: params structs start with struct_size (72 / 112 bytes), descriptors of 1..32 dimensions; 101: lr_ransac_params 64 bytes / lr_pair_params 96 bytes (round 3), lr_icp_batch */
+LR_API int         lr_version(void);    /* 100 * major + minor; 103: lr_workspace_clock, options 6 / 7, fused verification; 102: params structs start with struct_size (72 / 112 bytes), descriptors of 1..32 dimensions; 101: lr_ransac_params 64 bytes / lr_pair_params 96 bytes (round 3), lr_icp_batch */
 LR_API const char *lr_last_error(void);
 
 /* Scratch for clouds up to (max_n0, max_n1) points x dim (1 <= dim <= 32; matching.py:22-65 takes any width) and up to max_iters hypotheses. */
@@ -155,9 +155,15 @@ enum {
     LR_OPT_NN_BLOCKS_BATCH  = 2,  /* the same for a batched call, over all its pairs (3072)                                  */
     LR_OPT_NN_SAMPLE_STRIDE = 3,  /* the filter pass samples every k-th column tile for its start thresholds (default: strip tiles / 32, at most 32) */
     LR_OPT_REV_STRIPS       = 4,  /* column strips offered to each row block of the reverse NN pass (default 48 / pairs, within 2..8) */
-    LR_OPT_NN_SECOND_AUTO   = 5   /* 1: lr_register_pair / _batch compute the second neighbour only when a stage of the call reads it */
+    LR_OPT_NN_SECOND_AUTO   = 5,  /* 1: lr_register_pair / _batch compute the second neighbour only when a stage of the call reads it */
+    LR_OPT_NN_VERIFY_SEPARATE = 6, /* 1: the exact fp32 verification always runs as its own kernel; default 0: a filter-pass wave that owns the complete
+                                      candidate lists of its rows (one column strip: every 32-pair batched call) verifies them itself        */
+    LR_OPT_CLOCK_PROBE      = 7   /* 1: the filter-pass blocks sum their shader cycles and 100 MHz ticks into the workspace (lr_workspace_clock) */
 };
 LR_API int    lr_workspace_option(lr_workspace *ws, int option, int value);
+/* Measurement hook (no reference counterpart): the shader clock the filter-pass blocks ran at since the last reset, *mhz = 100 * cycles / ticks
+ * (0 when nothing was recorded: LR_OPT_CLOCK_PROBE off).  The caller has synchronised the streams that used the workspace.  Any pointer may be NULL. */
+LR_API int    lr_workspace_clock(lr_workspace *ws, double *mhz, unsigned long long *cycles, unsigned long long *ticks, int reset);
 
 /* ---- a1/a2: find_nn / find_2nn  (Experiments/algorithms/matching.py:6-65) ------------------------
  * For every row of F0 [n0,dim] the nearest and second nearest row of F1 [n1,dim] under L2, first

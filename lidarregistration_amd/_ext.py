@@ -19,11 +19,12 @@ SYMBOLS = [
     "lr_register_pair", "lr_workspace_lists", "lr_workspace_timing", "lr_workspace_timing_read",
     "lr_workspace_create_batch", "lr_register_batch", "lr_workspace_lists_at", "lr_inlier_mask", "lr_workspace_mask_at",
     "lr_voxel_dedup_scratch_bytes", "lr_voxel_dedup", "lr_workspace_option", "lr_workspace_stage_times", "lr_icp_batch", "lr_workspace_lists_batch",
+    "lr_workspace_clock",
 ]
 
 # lr_workspace_option ids (include/lidarreg.h).  DEFAULT_OPTIONS is applied to every Workspace this module creates (a hook for
 # tuning experiments and for the test that no option changes a result; the library itself reads no environment variable).
-OPTIONS = {"nn_blocks": 1, "nn_blocks_batch": 2, "nn_sample_stride": 3, "rev_strips": 4, "nn_second_auto": 5}
+OPTIONS = {"nn_blocks": 1, "nn_blocks_batch": 2, "nn_sample_stride": 3, "rev_strips": 4, "nn_second_auto": 5, "nn_verify_separate": 6, "clock_probe": 7}
 DEFAULT_OPTIONS = {}
 
 
@@ -137,6 +138,8 @@ def lib():
         L.lr_workspace_option.argtypes = [vp, ci, ci]
         L.lr_workspace_stage_times.argtypes = [vp, ctypes.POINTER(ctypes.c_float * 8), ctypes.POINTER(ci)]
         L.lr_workspace_timing.argtypes = [vp, ci]
+        if hasattr(L, "lr_workspace_clock"):      # (absent only from older builds loaded through the LIDARREG_LIB development hook)
+            L.lr_workspace_clock.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(ctypes.c_ulonglong), ci]
         L.lr_workspace_timing_read.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ci)]
         _lib = L
     return _lib
@@ -172,6 +175,13 @@ class Workspace:
 
     def timing(self, enable):
         check(lib().lr_workspace_timing(self._h, int(bool(enable))))
+
+    def clock(self, reset=False):
+        """(MHz, shader cycles, 100 MHz ticks) of the filter-pass blocks since the last reset (option clock_probe); the streams that used the
+        workspace must be synchronised."""
+        mhz = ctypes.c_double(); cyc = ctypes.c_ulonglong(); tk = ctypes.c_ulonglong()
+        check(lib().lr_workspace_clock(self._h, ctypes.byref(mhz), ctypes.byref(cyc), ctypes.byref(tk), int(bool(reset))))
+        return mhz.value, cyc.value, tk.value
 
     @property
     def handle(self):

@@ -19,7 +19,7 @@ void lr_set_error(const char *fmt, ...)
 static_assert(sizeof(lr_ransac_params) == 72 && sizeof(lr_pair_params) == 112 && sizeof(lr_pair_result) == 496,
               "ABI structs changed: update include/lidarreg.h, _ext.py, INTEGRATION.md and tests/test_abi_cpu.py together");
 
-extern "C" int lr_version(void) { return 102; }
+extern "C" int lr_version(void) { return 103; }
 extern "C" const char *lr_last_error(void) { return g_err; }
 
 // ------------------------------------------------------------------ workspace
@@ -113,12 +113,13 @@ extern "C" int lr_workspace_create_batch(lr_workspace **out, int max_pairs, int 
     // tuning defaults (lr_workspace_option changes them; no environment variable is read anywhere in this library)
     ws->nn_blocks_target = 768;          // 3 blocks per CU = every block of a single pair's filter pass resident at once
     ws->nn_blocks_batch = 3072;
-    ws->nn_sample_stride = 0; ws->rev_strips = 0; ws->nn_second_auto = 0;
+    ws->nn_sample_stride = 0; ws->rev_strips = 0; ws->nn_second_auto = 0; ws->nn_verify_separate = 0; ws->clock_probe = 0;
     Carver sizing;
     carve(ws, sizing);
     ws->stride = (sizing.off + 511) & ~size_t(255);          // one arena per pair, identical layout
     const size_t desc_off = ws->stride * (size_t)max_pairs;
-    ws->bytes = desc_off + sizeof(lr_pair_desc) * LR_MAX_BATCH + 256;
+    const size_t clk_off = (desc_off + sizeof(lr_pair_desc) * LR_MAX_BATCH + 255) & ~size_t(255);
+    ws->bytes = clk_off + 256;
     hipError_t e = hipMalloc(&ws->base, ws->bytes);
     if (e != hipSuccess) {
         lr_set_error("lr_workspace_create: hipMalloc(%zu) -> %s", ws->bytes, hipGetErrorString(e));
@@ -129,6 +130,7 @@ extern "C" int lr_workspace_create_batch(lr_workspace **out, int max_pairs, int 
     real.base = ws->base;
     carve(ws, real);
     ws->descs = reinterpret_cast<lr_pair_desc *>(ws->base + desc_off);
+    ws->clk_dev = reinterpret_cast<unsigned long long *>(ws->base + clk_off);
     // (optional: without it every call launches both forms of the filter pass, as batched calls always do)
     if (hipHostMalloc(reinterpret_cast<void **>(&ws->form_host), 2 * sizeof(int32_t), hipHostMallocMapped) == hipSuccess) {
         ws->form_host[0] = ws->form_host[1] = 0;
@@ -168,6 +170,8 @@ extern "C" int lr_workspace_option(lr_workspace *ws, int option, int value)
     case LR_OPT_NN_SAMPLE_STRIDE: ws->nn_sample_stride = value > 4096 ? 4096 : value; break;      // (lr_nn16_run clamps it to the strip length)
     case LR_OPT_REV_STRIPS: ws->rev_strips = value > 64 ? 64 : value; break;
     case LR_OPT_NN_SECOND_AUTO: ws->nn_second_auto = value ? 1 : 0; break;
+    case LR_OPT_NN_VERIFY_SEPARATE: ws->nn_verify_separate = value ? 1 : 0; break;
+    case LR_OPT_CLOCK_PROBE: ws->clock_probe = value ? 1 : 0; break;
     default: lr_set_error("lr_workspace_option: unknown option %d", option); return LR_EINVAL;
     }
     return LR_OK;
@@ -239,6 +243,21 @@ int lr_zero_scratch(lr_workspace *ws, void *p, size_t bytes, hipStream_t st)
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(zero_scratch_kernel, dim3(blocks < 1 ? 1 : blocks, 1, ws->zP), dim3(256), 0, st, reinterpret_cast<uint32_t *>(p), words, ws->z);
     LR_LAUNCH_CHECK();
+    return LR_OK;
+}
+
+// Shader clock of the filter-pass blocks since the last reset (LR_OPT_CLOCK_PROBE): every block that walks adds its s_memtime cycles and its
+// s_memrealtime ticks (100 MHz) to two words of the workspace; MHz = 100 * cycles / ticks, weighted by block lifetime.  The caller has
+// synchronised the streams that used the workspace (blocking copies on the null stream).
+extern "C" int lr_workspace_clock(lr_workspace *ws, double *mhz, unsigned long long *cycles, unsigned long long *ticks, int reset)
+{
+    LR_REQUIRE(ws, LR_EINVAL, "lr_workspace_clock: null workspace");
+    unsigned long long h[2] = { 0ull, 0ull };
+    LR_HIP(hipMemcpy(h, ws->clk_dev, sizeof h, hipMemcpyDeviceToHost));
+    if (cycles) *cycles = h[0];
+    if (ticks) *ticks = h[1];
+    if (mhz) *mhz = h[1] ? 100.0 * (double)h[0] / (double)h[1] : 0.0;
+    if (reset) LR_HIP(hipMemset(ws->clk_dev, 0, sizeof h));
     return LR_OK;
 }
 

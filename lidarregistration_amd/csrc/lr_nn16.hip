@@ -244,6 +244,103 @@ struct lr_thr_in {
 };
 // grid shape of a 1-D XCD-aware launch + direction (0: rows = cloud 0, columns = cloud 1; 1: the reverse pass)
 struct lr_pb_grid { int gx, gy, total, dir, only; };      // only != 0: the other instantiation is not launched (single-pair calls, see lr_nn16_forms)
+// Where the exact stage leaves its results (nn16_exact_kernel -- and the filter pass itself, which verifies the rows of a wave that owns their
+// complete candidate list, see "fused verification" below): the two neighbours by data row, and (forward direction of a pair) the seeds of
+// the reverse pass
+struct lr_ex_out {
+    int32_t *idx1, *idx2;
+    float *s1o, *s2o;
+    uint32_t *seed_out;              // [columns] smallest forward distance pointing at each column (bit pattern), or nullptr
+    float *seed_s1;                  // [rows] column key of the reverse pass (2nd-NN distance, or the NN distance when need == 1)
+    uint32_t *seed_range;            // { smallest, largest } of the seeds and keys
+    unsigned long long *seed64;      // forward: [columns] (distance bits << 32) | smallest row at that distance; reverse: the seeds to start from
+};
+// what the filter pass needs to verify its own candidates: the fp32 descriptors and norms of both clouds (by DATA row / original column id)
+// This struct is the filter pass' FIRST kernel parameter and is only ever read at the END of the kernel, through the kernel-argument
+// segment pointer behind an opaque asm (lr_pb_tail_args): read as ordinary parameters its fifteen pointers are fetched at the top of the
+// kernel and held in scalar registers across the walk -- 17 scalar spills into a vector register, read back inside the slow paths.
+struct lr_pb_fuse {
+    const float *Fq, *Fc;            // Fq == nullptr: no fused verification (nn16_exact_kernel does all rows)
+    const float *nQ, *nCx;
+    lr_ex_out out;
+    unsigned long long *clk;         // { shader cycles, 100 MHz ticks } summed over the blocks of the launch (lr_workspace_clock), or nullptr
+    lr_zargs z;                      // copies of the kernel's z / grid shape for the tail (the originals are dead by then)
+    int gx, gy, dir, pad;
+};
+// the struct above as the kernel finds it at offset 0 of its argument segment; the asm keeps the compiler from hoisting the loads.  (Pointers
+// that arrive this way are generic to the compiler: the gathers of the tail go through explicitly global-qualified copies, lr_g4p / lr_gfp)
+typedef const __attribute__((address_space(1))) f32x4 *lr_g4p;
+typedef const __attribute__((address_space(1))) float *lr_gfp;
+typedef const __attribute__((address_space(1))) int32_t *lr_gip;
+__device__ __forceinline__ lr_pb_fuse lr_pb_tail_args()
+{
+    auto ka = __builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka) :: "memory");
+    typedef const unsigned long long __attribute__((opencl_constant)) *cw_t;
+    const cw_t w = (cw_t)ka;
+    static_assert(sizeof(lr_pb_fuse) % 8 == 0, "read as 64-bit words");
+    unsigned long long buf[sizeof(lr_pb_fuse) / 8];
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(lr_pb_fuse) / 8; ++i) buf[i] = w[i];
+    lr_pb_fuse f;
+    __builtin_memcpy(&f, buf, sizeof f);
+    return f;
+}
+
+// ------------------------------------------------------------------ exact stage: shared pieces
+#define LR_EX_EMPTY 0xffffffffffffffffull
+// The two best candidates of a row under the (sqrt value, index) order -- torch.min's "first minimal value" -- are kept as 64-bit keys (value
+// bits << 32 | index) with two LDS atomics per candidate:  old = atomicMin(best, key);  atomicMin(second, max(old, key)).  Whatever the
+// order of arrival, `best` ends as the smallest key and `second` as the second smallest (every loser max(old, key) is at least the second
+// smallest, and the second smallest itself loses exactly once).
+__device__ __forceinline__ void ex_offer(unsigned long long *best, unsigned long long *second, float sv, int j)
+{
+    const unsigned long long key = ((unsigned long long)__float_as_uint(sv) << 32) | (unsigned)j;       // sv > 0: bits order like values
+    const unsigned long long old = atomicMin(best, key);
+    atomicMin(second, old > key ? old : key);
+}
+// results of one row (the calling lane's): neighbours and distances by data row; forward direction of a pair: seed the reverse pass (what
+// nn16_rev_seed_kernel would recompute bit for bit): best forward distance per target, the row's own column key.  sv / key: the lane's
+// contribution to the range the ordering buckets of the reverse pass span (ex_range reduces them over the wave)
+__device__ __forceinline__ void ex_write_row(const lr_ex_out &o, int rowd, unsigned long long kb, unsigned long long ks, int nb, int need, float &sv, float &key)
+{
+    const int i1 = kb == LR_EX_EMPTY ? -1 : (int)(unsigned)kb;
+    const float b1 = kb == LR_EX_EMPTY ? LR_INF : __uint_as_float((unsigned)(kb >> 32));
+    o.idx1[rowd] = i1;
+    if (o.idx2) o.idx2[rowd] = ks == LR_EX_EMPTY ? (nb > 1 ? LR_IMAX : -1) : (int)(unsigned)ks;
+    if (o.s1o) o.s1o[rowd] = b1;
+    if (o.s2o) o.s2o[rowd] = ks == LR_EX_EMPTY ? LR_INF : __uint_as_float((unsigned)(ks >> 32));
+    if (o.seed_out) {
+        sv = b1;
+        if (!(sv < 3.0e38f)) sv = 3.0e38f;
+        if (i1 >= 0 && i1 < nb) {
+            atomicMin(&o.seed_out[i1], __float_as_uint(sv));
+            atomicMin(&o.seed64[i1], ((unsigned long long)__float_as_uint(sv) << 32) | (unsigned)rowd);
+        }
+        // column key of the reverse pass: a lower bound of the row's distance to every point it does NOT point at -- its exact
+        // second-smallest distance when the second neighbour was asked for (the thresholds then guarantee it), else the smallest
+        key = sv;
+        if (need >= 2) { key = ks == LR_EX_EMPTY ? 3.0e38f : __uint_as_float((unsigned)(ks >> 32)); if (!(key < 3.0e38f)) key = 3.0e38f; }
+        o.seed_s1[rowd] = key;
+    }
+}
+// (one wave, every lane: writer = the lane wrote a row) the range of the seeds and keys
+__device__ __forceinline__ void ex_range(const lr_ex_out &o, bool writer, float sv, float key, int lane)
+{
+    float lo = writer ? sv : 3.0e38f, hi = writer ? fmaxf(sv, key) : 0.0f;
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) { lo = fminf(lo, __shfl_xor(lo, k)); hi = fmaxf(hi, __shfl_xor(hi, k)); }
+    if (lane == 0) {
+        atomicMin(&o.seed_range[0], __float_as_uint(lo));
+        atomicMax(&o.seed_range[1], __float_as_uint(hi));
+    }
+}
+// a row whose f16 copy is not finite never produced a meaningful filter value (u, v: eight of its fp32 values)
+__device__ __forceinline__ bool ex_bad8(const f32x4 &u, const f32x4 &v)
+{
+    const float big = fmaxf(fmaxf(fmaxf(fabsf(u.x), fabsf(u.y)), fmaxf(fabsf(u.z), fabsf(u.w))), fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    return !(big <= 65504.0f) || u.x != u.x || u.y != u.y || u.z != u.z || u.w != u.w || v.x != v.x || v.y != v.y || v.z != v.z || v.w != v.w;
+}
 
 // The one development switch of this file: -DLR_PB_PROBE compiles the hit statistics of tools/pb_micro.hip into the filter pass (waves,
 // tests, slow-path visits, hits, derive() rounds, 16-entry groups, 10 ns ticks per phase).  Off in the library: LR_PROBE(...) is empty.
@@ -256,7 +353,8 @@ __device__ unsigned long long lr_pb_stat[16];
 #define LR_PB_WAVES 3            // waves per SIMD the filter pass is compiled for
 template <bool SIGN>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LR_PB_WAVES, LR_PB_WAVES)))
-nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *__restrict__ rowmap, const int32_t *__restrict__ na_dev,
+nn16_passb_kernel(lr_pb_fuse fz_first /* read at the end only, through lr_pb_tail_args() */, unsigned long long *clk_on,
+                  const _Float16 *__restrict__ Hq, int na_host, const int32_t *__restrict__ rowmap, const int32_t *__restrict__ na_dev,
                   const _Float16 *__restrict__ Hc, const float *__restrict__ nC, int nb,
                   int tiles_per_strip, const float *__restrict__ tau, int32_t *__restrict__ cand_cnt, int32_t *__restrict__ cand,
                   const int32_t *__restrict__ colmap, const float *__restrict__ tile_min, const uint32_t *__restrict__ row_bound,
@@ -300,6 +398,10 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
     }
     const float xhat = SIGN ? 0.5f * min_nc : 0.0f;
     __shared__ int s_limit[4];
+    // (LR_OPT_CLOCK_PROBE: shader cycles and 100 MHz ticks of every block that walks, summed per workspace -> lr_workspace_clock: the
+    // clock the power-limited walk really ran at, the one thing that tells a 3 % change of the kernel from a 3 % slower box)
+    __shared__ unsigned long long s_clk[2];
+    if (clk_on && threadIdx.x == 0) { s_clk[0] = __builtin_amdgcn_s_memtime(); s_clk[1] = __builtin_amdgcn_s_memrealtime(); }
     constexpr int CH = LR_PB_CH;
     constexpr int XOFF = CH * 32 * LR_LDS_ROW;
     constexpr int BUF = XOFF + (SIGN ? 0 : CH * 32 * 4);      // (the sign form stages no per-column operand, in either phase)
@@ -910,10 +1012,93 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         drain();
         flush();           // (with a last tightening round: the entries get their g, the rows their final thresholds)
     }
+    // ---------------------------------------------------------------- fused verification
+    // A row block with ONE column strip (every batched call of 32 pairs; the short-prefix row blocks of the reverse pass) owns the complete
+    // candidate lists of its rows: each wave verifies its 64 rows here, in the shadow of the other blocks' MFMAs, instead of leaving them to
+    // nn16_exact_kernel -- one launch per direction whose gathers nothing else hides (85 us per 32 pairs) becomes an empty one.  Same
+    // arithmetic, same order (ex_offer / ex_write_row): a lane takes ENTRIES of the wave's segment (read back coherently: the wave wrote them
+    // itself), drops what the rows' final thresholds exclude, gathers the entry's column row and the query row (fp32, 128 B each) and offers
+    // the fma-chain distance to the row's two 64-bit keys in LDS (the wave's hit list, empty by now, is the scratch).  All or nothing per
+    // wave: if any row needs the full scan (list too short, f16 copy not finite, a column norm that is not finite) or the segment
+    // overflowed, nothing is written and the exact kernel takes the 64 rows as before.  No block barrier: the four waves differ.
+    bool verified = false;
+    lr_pb_fuse fz = lr_pb_tail_args();
+    if (fz.Fq != nullptr && my_strips == 1 && seg_fill >= 0 && !(min_nc < 0.0f) && nchunks > 0) {
+        const int lane = cold_lane();
+        {   // the pair's own pointers (what the head of the kernel does for its arguments)
+            const int pr = logical / (fz.gx * fz.gy);
+            if (fz.z.descs) { const lr_pair_desc d = fz.z.descs[pr]; fz.Fq = fz.dir ? d.F1 : d.F0; fz.Fc = fz.dir ? d.F0 : d.F1; }
+            lr_z(fz.nQ, fz.z, pr); lr_z(fz.nCx, fz.z, pr); lr_z(fz.out.idx1, fz.z, pr); lr_z(fz.out.idx2, fz.z, pr); lr_z(fz.out.s1o, fz.z, pr); lr_z(fz.out.s2o, fz.z, pr);
+            lr_z(fz.out.seed_out, fz.z, pr); lr_z(fz.out.seed_s1, fz.z, pr); lr_z(fz.out.seed_range, fz.z, pr); lr_z(fz.out.seed64, fz.z, pr);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // flush()'s stores to the segment are out (it is read back below); and nothing of
+        __builtin_amdgcn_wave_barrier();                            // flush() moves behind the re-use of its list under another type
+        unsigned long long *t_best = reinterpret_cast<unsigned long long *>(&wlist[wave][0]), *t_second = t_best + 64;
+        int *t_cnt = reinterpret_cast<int *>(t_second + 64), *t_rowd = t_cnt + 64;
+        float *t_nq = reinterpret_cast<float *>(t_rowd + 64);
+        static_assert(WL * 8 >= 64 * (8 + 8 + 4 + 4 + 4), "the wave's hit list is the scratch of its verification");
+        const bool live = row0 + lane < na;
+        const int rowc = min(row0 + lane, na - 1);
+        const int rowd = rowmap ? rowmap[rowc] : rowc;
+        bool bad = false;
+        {
+            const lr_g4p pa = (lr_g4p)(fz.Fq + (size_t)rowd * 32);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const f32x4 u = pa[2 * k], v = pa[2 * k + 1]; bad |= ex_bad8(u, v); }
+        }
+        t_best[lane] = LR_EX_EMPTY; t_second[lane] = LR_EX_EMPTY; t_cnt[lane] = 0; t_rowd[lane] = rowd; t_nq[lane] = ((lr_gfp)fz.nQ)[rowd];
+        // reverse direction seeded by this library's forward pass: the best of the points that POINT AT the row is known
+        if (fz.dir == 1 && fz.out.seed64 && live) { t_best[lane] = fz.out.seed64[rowd]; t_cnt[lane] = 1; }
+        __builtin_amdgcn_wave_barrier();
+        for (int e0 = 0; e0 < seg_fill; e0 += 64) {
+            const int e = e0 + lane;
+            unsigned long long raw = 0ull;
+            if (e < seg_fill) raw = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(seg + e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned vx = (unsigned)raw, vy = (unsigned)(raw >> 32);
+            unsigned m = vy & 0xffffu;
+            const int j = (int)(vx & LR_PB_COLMASK), ekb = lr_pb_kb(vx);
+            if (m != 0u && (vx & LR_PB_HASG) && tightening) {       // (single-row entry with its g, rounded up to 16 bits, against the row's FINAL threshold)
+                const float gv = __uint_as_float(vy & 0xffff0000u), yr = s_Y[wave * 64 + lr_pb_row(ekb, __builtin_ctz(m))];
+                if (gv + 1e-5f * (fabsf(gv) + fabsf(yr)) < -yr) m = 0u;
+            }
+            if (m != 0u) {
+                f32x4 t[8];
+                const lr_g4p pb = (lr_g4p)(fz.Fc + (size_t)j * 32);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) t[k] = pb[k];
+                const float ncj = ((lr_gfp)fz.nCx)[j];
+                while (m) {
+                    const int rl = lr_pb_row(ekb, __builtin_ctz(m));
+                    m &= m - 1;
+                    const lr_g4p qa = (lr_g4p)(fz.Fq + (size_t)t_rowd[rl] * 32);
+                    float acc = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const f32x4 a = qa[k];
+                        acc = __builtin_fmaf(a.x, t[k].x, acc);
+                        acc = __builtin_fmaf(a.y, t[k].y, acc);
+                        acc = __builtin_fmaf(a.z, t[k].z, acc);
+                        acc = __builtin_fmaf(a.w, t[k].w, acc);
+                    }
+                    const float d2 = __builtin_fmaf(-2.0f, acc, t_nq[rl] + ncj);
+                    ex_offer(&t_best[rl], &t_second[rl], __builtin_sqrtf(fmaxf(d2, 1e-30f)), j);
+                    atomicAdd(&t_cnt[rl], 1);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        const bool redo = live && (bad || t_cnt[lane] < min(thr.need, nb));
+        if (__builtin_amdgcn_ballot_w64(redo) == 0ull) {
+            float sv = 3.0e38f, key = 0.0f;
+            if (live) ex_write_row(fz.out, rowd, t_best[lane], t_second[lane], nb, thr.need, sv, key);
+            if (fz.out.seed_out) ex_range(fz.out, live, sv, key, lane);
+            verified = true;
+        }
+    }
     if (lane == 0) {
         int32_t *cw = cand_cnt + (bx * 4 + wave) * (pg.gy + 1);
         cw[by] = seg_fill;                     // entries in this wave's segment (< 0: overflow)
-        if (by == 0) cw[pg.gy] = my_strips;    // how the wave's store is divided (read by nn16_exact_kernel)
+        if (by == 0) cw[pg.gy] = verified ? -my_strips : my_strips;    // how the wave's store is divided; negative: the rows are done (read by nn16_exact_kernel)
     }
     LR_PROBE(if (lane == 0) {
         atomicAdd(&lr_pb_stat[0], 1ull); atomicAdd(&lr_pb_stat[1], (unsigned long long)nchunks * CH * 4); atomicAdd(&lr_pb_stat[2], (unsigned long long)n_visits);
@@ -928,6 +1113,10 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
         const int rw = row0 + lane;
         if (rw < na) yfin[(size_t)by * yfin_stride + rw] = tightening ? s_Y[wave * 64 + lane] : LR_INF;
     }
+    if (fz.clk && threadIdx.x == 0) {
+        atomicAdd(&fz.clk[0], __builtin_amdgcn_s_memtime() - s_clk[0]);
+        atomicAdd(&fz.clk[1], __builtin_amdgcn_s_memrealtime() - s_clk[1]);
+    }
 }
 
 // ------------------------------------------------------------------ exact verification of the candidates
@@ -941,28 +1130,18 @@ nn16_passb_kernel(const _Float16 *__restrict__ Hq, int na_host, const int32_t *_
 // entry, so a row with many candidates does not stall its neighbours, and nothing is binned or sorted.
 // Rows whose segment overflowed, whose list is too short, or whose f16 copy is not finite are re-done by the whole block
 // with an exact scan of all columns (slow, rare, and by construction the reference answer).
+// A wave of the filter pass that owned the complete candidate list of its 64 rows (one column strip) has verified them itself (fused
+// verification, above) and says so in its strip count: the block of those rows returns at once.
 #define LR_EX_ROWS 64
 #define LR_EX_STRIDE 33          // floats per staged query row (odd: conflict-free column-wise reads)
-__device__ __forceinline__ bool sj_lt(float a, int ia, float b, int ib) { return a < b || (a == b && ia < ib); }
-#define LR_EX_EMPTY 0xffffffffffffffffull
-
-__device__ __forceinline__ void ex_offer(unsigned long long *best, unsigned long long *second, float sv, int j)
-{
-    const unsigned long long key = ((unsigned long long)__float_as_uint(sv) << 32) | (unsigned)j;       // sv > 0: bits order like values
-    const unsigned long long old = atomicMin(best, key);
-    atomicMin(second, old > key ? old : key);
-}
 
 __global__ void __launch_bounds__(256)
 nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, int na,
                   const float *__restrict__ Fc, const float *__restrict__ nC, int nb,
                   const int32_t *__restrict__ cand_cnt, const int32_t *__restrict__ cand, int nstrips, int need,
                   const float *__restrict__ yfin, int yfin_stride,
-                  const int32_t *__restrict__ rowmap, const int32_t *__restrict__ na_dev,
-                  int32_t *__restrict__ idx1, int32_t *__restrict__ idx2, float *__restrict__ s1o, float *__restrict__ s2o,
-                  int32_t *__restrict__ counters,
-                  uint32_t *__restrict__ seed_out, float *__restrict__ seed_s1, uint32_t *__restrict__ seed_range,
-                  unsigned long long *__restrict__ seed64, const float *__restrict__ range_c, int dir, int gx, int total, lr_zargs z)
+                  const int32_t *__restrict__ rowmap, const int32_t *__restrict__ na_dev, lr_ex_out out,
+                  int32_t *__restrict__ counters, const float *__restrict__ range_c, int dir, int gx, int total, lr_zargs z)
 {
     // 1-D XCD-aware grid -> (row block, pair): the blocks one XCD receives are consecutive row blocks of the same pairs, so the
     // column cloud they gather from (3.84 MB of fp32 rows at 30k points) stays in that XCD's L2
@@ -979,12 +1158,17 @@ nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, in
         Fq = dir ? d.F1 : d.F0; na = dir ? d.n1 : d.n0; Fc = dir ? d.F0 : d.F1; nb = dir ? d.n0 : d.n1;
     }
     lr_z(nQ, z, pair); lr_z(nC, z, pair); lr_z(cand_cnt, z, pair); lr_z(cand, z, pair); lr_z(rowmap, z, pair); lr_z(yfin, z, pair);
-    lr_z(na_dev, z, pair); lr_z(idx1, z, pair); lr_z(idx2, z, pair); lr_z(s1o, z, pair); lr_z(s2o, z, pair);
-    lr_z(counters, z, pair); lr_z(seed_out, z, pair); lr_z(seed_s1, z, pair); lr_z(seed_range, z, pair); lr_z(seed64, z, pair); lr_z(range_c, z, pair);
+    lr_z(na_dev, z, pair); lr_z(out.idx1, z, pair); lr_z(out.idx2, z, pair); lr_z(out.s1o, z, pair); lr_z(out.s2o, z, pair);
+    lr_z(counters, z, pair); lr_z(out.seed_out, z, pair); lr_z(out.seed_s1, z, pair); lr_z(out.seed_range, z, pair); lr_z(out.seed64, z, pair); lr_z(range_c, z, pair);
+    unsigned long long *__restrict__ const seed64 = out.seed64;
     if (na_dev) na = *na_dev;                  // compacted row list (reverse direction): lists by position, data by rowmap[]
     const int row0 = bxi * LR_EX_ROWS;
     if (row0 >= na) return;
     const int tid = threadIdx.x;
+    // a filter pass that was launched in one form only while this call's norms asked for the other walked nothing -- and then NOBODY wrote
+    // this call's candidate counts: the store is not looked at (s_skip below), every row goes through the full scan
+    const int miss = counters[LR_CNT_FORM_MISS_F + (dir ? 1 : 0)] != 0 ? 1 : 0;
+    if (!miss && cand_cnt[bxi * (nstrips + 1) + nstrips] < 0) return;      // verified by the filter pass itself (block-uniform)
     // ---- stage the query rows: thread t moves floats [8 (t & 3) .. +8) of row t >> 2
     {
         const int rl = tid >> 2, part = tid & 3;
@@ -994,15 +1178,11 @@ nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, in
         const f32x4 u = pa[0], v = pa[1];
         float *dst = &s_a[rl * LR_EX_STRIDE + 8 * part];
         dst[0] = u.x; dst[1] = u.y; dst[2] = u.z; dst[3] = u.w; dst[4] = v.x; dst[5] = v.y; dst[6] = v.z; dst[7] = v.w;
-        // a query row whose f16 copy is not finite never produced a meaningful filter value
-        const float big = fmaxf(fmaxf(fmaxf(fabsf(u.x), fabsf(u.y)), fmaxf(fabsf(u.z), fabsf(u.w))), fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
-        const bool bad = !(big <= 65504.0f) || u.x != u.x || u.y != u.y || u.z != u.z || u.w != u.w || v.x != v.x || v.y != v.y || v.z != v.z || v.w != v.w;
+        const bool bad = ex_bad8(u, v);          // a query row whose f16 copy is not finite never produced a meaningful filter value
         if (tid < LR_EX_ROWS) { s_best[tid] = LR_EX_EMPTY; s_second[tid] = LR_EX_EMPTY; s_cnt[tid] = 0; s_badrow[tid] = 0; }
         // (a column cloud with a norm that is not finite -- the prep kernel's minimum is negative then --: every row by the full scan)
-        // ... and so does a filter pass that was launched in one form only while this call's norms asked for the other (nothing was walked)
-        // -- and then NOBODY wrote this call's candidate counts: the store is not looked at (s_skip)
+        // ... and so does a form miss (above)
         if (tid == 0) {
-            const int miss = counters[LR_CNT_FORM_MISS_F + (dir ? 1 : 0)] != 0 ? 1 : 0;
             s_bad = ((range_c != nullptr && range_c[1] < 0.0f) || miss) ? 1 : 0; s_skip = miss; s_nredo = 0;
         }
         if (part == 0) { s_nq[rl] = nQ[rowd]; s_rowd[rl] = rowd; }
@@ -1090,44 +1270,9 @@ nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, in
     __syncthreads();
     // ---- results: one thread per row
     float sv = 3.0e38f, key = 0.0f;
-    bool writer = false;
-    int i1 = -1;
-    if (tid < LR_EX_ROWS && row0 + tid < na) {
-        writer = true;
-        const unsigned long long kb = s_best[tid], ks = s_second[tid];
-        const int rowd = s_rowd[tid];
-        i1 = kb == LR_EX_EMPTY ? -1 : (int)(unsigned)kb;
-        const float b1 = kb == LR_EX_EMPTY ? LR_INF : __uint_as_float((unsigned)(kb >> 32));
-        idx1[rowd] = i1;
-        if (idx2) idx2[rowd] = ks == LR_EX_EMPTY ? (nb > 1 ? LR_IMAX : -1) : (int)(unsigned)ks;
-        if (s1o) s1o[rowd] = b1;
-        if (s2o) s2o[rowd] = ks == LR_EX_EMPTY ? LR_INF : __uint_as_float((unsigned)(ks >> 32));
-        if (seed_out) {
-            // forward direction of a pair: seed the reverse pass here (what nn16_rev_seed_kernel would recompute bit for bit):
-            // best forward distance per target, the row's own NN distance, and the range of all of them
-            sv = b1;
-            if (!(sv < 3.0e38f)) sv = 3.0e38f;
-            if (i1 >= 0 && i1 < nb) {
-                atomicMin(&seed_out[i1], __float_as_uint(sv));
-                atomicMin(&seed64[i1], ((unsigned long long)__float_as_uint(sv) << 32) | (unsigned)rowd);
-            }
-            // column key of the reverse pass: a lower bound of the row's distance to every point it does NOT point at -- its exact
-            // second-smallest distance when the second neighbour was asked for (the thresholds then guarantee it), else the smallest
-            key = sv;
-            if (need >= 2) { key = ks == LR_EX_EMPTY ? 3.0e38f : __uint_as_float((unsigned)(ks >> 32)); if (!(key < 3.0e38f)) key = 3.0e38f; }
-            seed_s1[rowd] = key;
-        }
-    }
-    if (!seed_out) return;
-    if (tid < 64) {          // the rows live in wave 0
-        float lo = writer ? sv : 3.0e38f, hi = writer ? fmaxf(sv, key) : 0.0f;      // the range the ordering buckets span: seeds and keys
-#pragma unroll
-        for (int k = 32; k >= 1; k >>= 1) { lo = fminf(lo, __shfl_xor(lo, k)); hi = fmaxf(hi, __shfl_xor(hi, k)); }
-        if (tid == 0) {
-            atomicMin(&seed_range[0], __float_as_uint(lo));
-            atomicMax(&seed_range[1], __float_as_uint(hi));
-        }
-    }
+    const bool writer = tid < LR_EX_ROWS && row0 + tid < na;
+    if (writer) ex_write_row(out, s_rowd[tid], s_best[tid], s_second[tid], nb, need, sv, key);
+    if (out.seed_out && tid < 64) ex_range(out, writer, sv, key, tid);          // (the rows live in wave 0)
 }
 
 // ------------------------------------------------------------------ host side
@@ -1185,22 +1330,26 @@ int lr_nn16_run(lr_workspace *ws, const float *Fq, const _Float16 *Hq, const flo
     // launches the right form.  (An empty launch costs 4.7 us: 9.4 of a single pair's 346 us of kernels.)
     const int only = lr_nn16_form_hint(ws, 1);
     int32_t *miss = ws->counters + LR_CNT_FORM_MISS_F;
+    const lr_ex_out eo = { idx1, idx2, s1, s2, seed_reverse ? ws->rev_seed : (uint32_t *)nullptr, ws->rev_s1, reinterpret_cast<uint32_t *>(ws->counters + LR_CNT_RLO),
+                           ws->rev_seed64 };
+    // (fused verification: whenever a row block has one strip -- decided per row block on the device; LR_OPT_NN_VERIFY_SEPARATE switches it off)
+    unsigned long long *clk = ws->clock_probe ? ws->clk_dev : (unsigned long long *)nullptr;
+    const lr_pb_fuse fz = { ws->nn_verify_separate ? (const float *)nullptr : Fq, Fc, nQ, nC, eo, clk, ws->z, row_blocks, strips, 0, 0 };
     if (only != 2)
-        hipLaunchKernelGGL(nn16_passb_kernel<true>, grid, dim3(256), 0, st, Hq, na, (const int32_t *)nullptr, (const int32_t *)nullptr, Hc, nC, nb,
+        hipLaunchKernelGGL(nn16_passb_kernel<true>, grid, dim3(256), 0, st, fz, clk, Hq, na, (const int32_t *)nullptr, (const int32_t *)nullptr, Hc, nC, nb,
                            tps, (const float *)nullptr, ws->cand_cnt, ws->cand, (const int32_t *)nullptr, (const float *)nullptr,
                            (const uint32_t *)nullptr, (const int32_t *)nullptr, (const uint32_t *)nullptr, ws->yfin, ws->max_n, ws->yshare, miss, thr,
                            lr_pb_grid{ row_blocks, strips, total, 0, only }, ws->z);
     if (only != 1)
-        hipLaunchKernelGGL(nn16_passb_kernel<false>, grid, dim3(256), 0, st, Hq, na, (const int32_t *)nullptr, (const int32_t *)nullptr, Hc, nC, nb,
+        hipLaunchKernelGGL(nn16_passb_kernel<false>, grid, dim3(256), 0, st, fz, clk, Hq, na, (const int32_t *)nullptr, (const int32_t *)nullptr, Hc, nC, nb,
                            tps, (const float *)nullptr, ws->cand_cnt, ws->cand, (const int32_t *)nullptr, (const float *)nullptr,
                            (const uint32_t *)nullptr, (const int32_t *)nullptr, (const uint32_t *)nullptr, ws->yfin, ws->max_n, ws->yshare, miss, thr,
                            lr_pb_grid{ row_blocks, strips, total, 0, only }, ws->z);
     if (ws->timing && !ws->ev_pending) { LR_HIP(hipEventRecord(ws->ev[1], st)); ws->ev_pending = 1; }
     const int ex_gx = lr_cdiv(na, LR_EX_ROWS), ex_total = ex_gx * ws->zP;
     hipLaunchKernelGGL(nn16_exact_kernel, dim3(8 * lr_cdiv(ex_total, 8)), dim3(256), 0, st, Fq, nQ, na, Fc, nC, nb, ws->cand_cnt, ws->cand,
-                       strips, need, (const float *)ws->yfin, ws->max_n, (const int32_t *)nullptr, (const int32_t *)nullptr, idx1, idx2, s1, s2, ws->counters,
-                       seed_reverse ? ws->rev_seed : (uint32_t *)nullptr, ws->rev_s1, reinterpret_cast<uint32_t *>(ws->counters + LR_CNT_RLO),
-                       ws->rev_seed64, range_c, 0, ex_gx, ex_total, ws->z);
+                       strips, need, (const float *)ws->yfin, ws->max_n, (const int32_t *)nullptr, (const int32_t *)nullptr, eo, ws->counters,
+                       range_c, 0, ex_gx, ex_total, ws->z);
     LR_LAUNCH_CHECK();
     return LR_OK;
 }
@@ -1470,14 +1619,17 @@ int lr_nn16_reverse(lr_workspace *ws, const float *F0, const _Float16 *H0, const
     const int only = lr_nn16_form_hint(ws, 0);          // (the columns of the reverse pass are cloud 0)
     int32_t *miss = ws->counters + LR_CNT_FORM_MISS_R;
     const lr_thr_in rthr = { nullptr, (const float *)ws->nn_range, 1, 0 };      // (no tightening: the column norms' range selects the form of the walk's test)
+    const lr_ex_out reo = { rev, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, seeded ? ws->rev_seed64 : (unsigned long long *)nullptr };
+    unsigned long long *clk = ws->clock_probe ? ws->clk_dev : (unsigned long long *)nullptr;
+    const lr_pb_fuse rfz = { ws->nn_verify_separate ? (const float *)nullptr : F1, F0, nrm1, nrm0, reo, clk, ws->z, row_blocks, strips, 1, 0 };
     if (only != 2)
-        hipLaunchKernelGGL(nn16_passb_kernel<true>, grid, dim3(256), 0, st, H1, na, (const int32_t *)ws->rev_rows, (const int32_t *)n_rows,
+        hipLaunchKernelGGL(nn16_passb_kernel<true>, grid, dim3(256), 0, st, rfz, clk, H1, na, (const int32_t *)ws->rev_rows, (const int32_t *)n_rows,
                            (const _Float16 *)ws->Hs, (const float *)ws->nrms, nb, tps, ws->tau, ws->cand_cnt, ws->cand,
                            (const int32_t *)ws->rev_cols, seeded ? (const float *)ws->rev_tmin : (const float *)nullptr, (const uint32_t *)seed,
                            (const int32_t *)ws->rev_hist, (const uint32_t *)range, (float *)nullptr, 0, (uint32_t *)nullptr, miss, rthr,
                            lr_pb_grid{ row_blocks, strips, total, 1, only }, ws->z);
     if (only != 1)
-        hipLaunchKernelGGL(nn16_passb_kernel<false>, grid, dim3(256), 0, st, H1, na, (const int32_t *)ws->rev_rows, (const int32_t *)n_rows,
+        hipLaunchKernelGGL(nn16_passb_kernel<false>, grid, dim3(256), 0, st, rfz, clk, H1, na, (const int32_t *)ws->rev_rows, (const int32_t *)n_rows,
                            (const _Float16 *)ws->Hs, (const float *)ws->nrms, nb, tps, ws->tau, ws->cand_cnt, ws->cand,
                            (const int32_t *)ws->rev_cols, seeded ? (const float *)ws->rev_tmin : (const float *)nullptr, (const uint32_t *)seed,
                            (const int32_t *)ws->rev_hist, (const uint32_t *)range, (float *)nullptr, 0, (uint32_t *)nullptr, miss, rthr,
@@ -1485,9 +1637,8 @@ int lr_nn16_reverse(lr_workspace *ws, const float *F0, const _Float16 *H0, const
     if (timed) { LR_HIP(hipEventRecord(ws->ev[5], st)); ws->rev_recorded = 1; }
     const int ex_gx = lr_cdiv(na, LR_EX_ROWS), ex_total = ex_gx * ws->zP;
     hipLaunchKernelGGL(nn16_exact_kernel, dim3(8 * lr_cdiv(ex_total, 8)), dim3(256), 0, st, F1, nrm1, na, F0, nrm0, nb, ws->cand_cnt, ws->cand,
-                       strips, 1, (const float *)nullptr, 0, (const int32_t *)ws->rev_rows, (const int32_t *)n_rows, rev, (int32_t *)nullptr, (float *)nullptr, (float *)nullptr,
-                       ws->counters, (uint32_t *)nullptr, (float *)nullptr, (uint32_t *)nullptr,
-                       seeded ? ws->rev_seed64 : (unsigned long long *)nullptr, (const float *)ws->nn_range, 1, ex_gx, ex_total, ws->z);
+                       strips, 1, (const float *)nullptr, 0, (const int32_t *)ws->rev_rows, (const int32_t *)n_rows, reo, ws->counters,
+                       (const float *)ws->nn_range, 1, ex_gx, ex_total, ws->z);
     LR_LAUNCH_CHECK();
     return LR_OK;
 }

@@ -53,12 +53,12 @@ def test_params_from_another_header_version_are_rejected():
     """A caller built against lr_version 101 (no struct_size: the struct started with sample_size = 3 or 4; 64 / 96 bytes) is turned
     away before anything is read past the end of its shorter struct.  Checked before any HIP call: safe without a device."""
     L = _ext.lib()
-    assert L.lr_version() == 102
+    assert L.lr_version() == 103
     r = _ext.RansacParams(3, 1, 0.36, 1000, 51)
     r.struct_size = 3                                   # what an old caller's first field would hold
     one = ctypes.c_void_p(1)                            # non-null dummies: the size check comes before any dereference of them
     assert L.lr_ransac(one, one, one, 10, None, ctypes.byref(r), one, one, None) == -1
-    assert b"struct_size" in L.lr_last_error() and b"lr_version 102" in L.lr_last_error()
+    assert b"struct_size" in L.lr_last_error() and b"lr_version 103" in L.lr_last_error()
     p = _ext.PairParams()
     p.mode = 1
     p.struct_size = 96
