@@ -168,7 +168,7 @@ def launch(argv):
     here = os.path.dirname(os.path.abspath(__file__))
     cmds = [[sys.executable, "-m", "test", "test_parallel", start_time, base, str(world), str(r)] + list(argv) for r in range(world)]
     pp = here + (os.pathsep + os.environ["PYTHONPATH"] if os.environ.get("PYTHONPATH") else "")
-    rc = L.run_ranks(cmds, [dict(HIP_VISIBLE_DEVICES=str(g), PYTHONPATH=pp) for g in gpus])
+    rc = L.run_ranks(cmds, [{var: value, "PYTHONPATH": pp} for var, value in gpus])
     try:
         if rc != 0:
             logging.error("a rank failed (exit code %d): the other ranks were stopped, no analysis", rc)

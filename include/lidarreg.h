@@ -14,7 +14,11 @@
  *   - return value 0 = LR_OK, negative = error (lr_last_error() gives the text); nothing throws;
  *   - 4x4 transforms are row-major float64, column-vector convention, cloud 0 -> cloud 1
  *     (the reference's pygcransac binding returns the transpose, GC_RANSAC.py:55 -- not here);
- *   - a workspace may be used by one stream at a time; use one workspace per in-flight pair.
+ *   - a workspace may be used by one stream at a time; use one workspace per in-flight pair;
+ *   - a workspace belongs to the device that was current when it was created (hipGetDevice); every entry point that takes one returns
+ *     LR_EINVAL -- before launching anything -- when another device is current or the stream belongs to another device.  The library
+ *     holds gfx950 code objects only: lr_workspace_create refuses any other architecture (gcnArchName) and sizes its launches from the
+ *     device's compute-unit count (multiProcessorCount).
  */
 #ifndef LIDARREG_H
 #define LIDARREG_H
@@ -115,7 +119,10 @@ typedef struct lr_pair_result {
                                equal head counts depends on scheduling), no result does.  [1]: diagnostic -- waits of the local optimisation's
                                helper-block hand-off that hit their 0.2 s bound (low 16 bits: the master block recomputed a scoring job alone;
                                high 16 bits: a helper block left without a job); integer sums make the result the same either way, a non-zero
-                               value means time was lost (also in lr_ransac_result.pad0).  [2..7]: 0                              */
+                               value means time was lost (also in lr_ransac_result.pad0).  [2]: diagnostic -- a single-pair call launched only the form of the
+                               filter pass the previous calls' norms asked for and this pair's asked for the other (bit 0: forward, bit 1: reverse pass):
+                               every row then went through the exact scan, correct but slow; two calls in a row must agree before a form is launched
+                               alone.  [3..7]: 0                                                                                  */
     double   T_icp[16];     /* T refined by point-to-point ICP (test.py:183-189) when icp != 0, else = T */
     lr_icp_result icp;
 } lr_pair_result;
@@ -148,6 +155,9 @@ LR_API int    lr_workspace_destroy(lr_workspace *ws);
 LR_API size_t lr_workspace_bytes(const lr_workspace *ws);
 /* Test hook (no reference counterpart): fill the scratch arena with one byte value; results must not depend on it. */
 LR_API int    lr_workspace_poison(lr_workspace *ws, int byte, void *stream);
+/* Test hook (no reference counterpart): the entry points take `device` for the current device from now on (-1: ask HIP again), so that a
+ * one-GPU box can exercise the wrong-device refusal above. */
+LR_API int    lr_debug_fake_current_device(int device);
 /* Tuning options of a workspace (no reference counterpart; NONE of them changes a result, tests/test_gpu_parity.py; the library
  * reads no environment variable).  value 0 restores the default.                                                          */
 enum {
@@ -156,8 +166,9 @@ enum {
     LR_OPT_NN_SAMPLE_STRIDE = 3,  /* the filter pass samples every k-th column tile for its start thresholds (default: strip tiles / 32, at most 32) */
     LR_OPT_REV_STRIPS       = 4,  /* column strips offered to each row block of the reverse NN pass (default 48 / pairs, within 2..8) */
     LR_OPT_NN_SECOND_AUTO   = 5,  /* 1: lr_register_pair / _batch compute the second neighbour only when a stage of the call reads it */
-    LR_OPT_NN_VERIFY_SEPARATE = 6, /* 1: the exact fp32 verification always runs as its own kernel; default 0: a filter-pass wave that owns the complete
-                                      candidate lists of its rows (one column strip: every 32-pair batched call) verifies them itself        */
+    LR_OPT_NN_VERIFY_FUSED  = 6,  /* 1: a filter-pass wave that owns the complete candidate lists of its rows (one column strip: every 32-pair batched
+                                     call) verifies them itself instead of leaving them to the exact-verification kernel; same results, measured 1 %
+                                     SLOWER in the pipeline, hence off by default                                          */
     LR_OPT_CLOCK_PROBE      = 7   /* 1: the filter-pass blocks sum their shader cycles and 100 MHz ticks into the workspace (lr_workspace_clock) */
 };
 LR_API int    lr_workspace_option(lr_workspace *ws, int option, int value);

@@ -20,7 +20,7 @@ MODES = {"MNN": _ext.LR_MODE_MNN, "MMN": _ext.LR_MODE_MNN,      # README.md:55 s
 
 
 class PointCloud:
-    """Minimal stand-in for open3d.geometry.PointCloud (the harness reads .points / calls .transform)."""
+    """Minimal stand-in for open3d.geometry.PointCloud where Open3D is not installed (the harness reads .points / calls .transform)."""
 
     def __init__(self, xyz):
         self.points = np.asarray(xyz, np.float64)
@@ -29,6 +29,27 @@ class PointCloud:
         T = np.asarray(T, np.float64)
         self.points = self.points @ T[:3, :3].T + T[:3, 3]
         return self
+
+
+_O3D = []      # [module or None] once looked up
+
+
+def make_open3d_point_cloud(xyz):
+    """FR.py:20-23: an open3d.geometry.PointCloud over `xyz` (float64 [n,3]) -- what the reference's FR() returns as pcd0 / pcd1 and what its
+    harness hands to o3d.pipelines.registration.registration_icp (test.py:185-187).  A real Open3D cloud wherever `open3d` imports; the
+    stand-in above otherwise (this image has no Open3D), which serves this package's own harness and lr_icp."""
+    if not _O3D:
+        try:
+            import open3d as o3d
+            _O3D.append(o3d)
+        except Exception:
+            _O3D.append(None)
+    o3d = _O3D[0]
+    if o3d is None:
+        return PointCloud(xyz)
+    pcd = o3d.geometry.PointCloud()
+    pcd.points = o3d.utility.Vector3dVector(np.ascontiguousarray(xyz, np.float64))
+    return pcd
 
 
 def pair_params(args):
@@ -164,7 +185,7 @@ def FR(A, B, A_feat, B_feat, args, T_gt):
     whole device path of the call (forward NN included) is in FR.last_timing["whole_path_s"]."""
     xyz0_np = torch.as_tensor(A).detach().cpu().numpy().astype(np.float64)
     xyz1_np = torch.as_tensor(B).detach().cpu().numpy().astype(np.float64)
-    pcd0, pcd1 = PointCloud(xyz0_np), PointCloud(xyz1_np)
+    pcd0, pcd1 = make_open3d_point_cloud(xyz0_np), make_open3d_point_cloud(xyz1_np)          # FR.py:28-29
     dev = _device()
     xyz0, xyz1 = _f32(A), _f32(B)
     f0, f1 = _f32(A_feat), _f32(B_feat)

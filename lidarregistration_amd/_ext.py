@@ -19,12 +19,12 @@ SYMBOLS = [
     "lr_register_pair", "lr_workspace_lists", "lr_workspace_timing", "lr_workspace_timing_read",
     "lr_workspace_create_batch", "lr_register_batch", "lr_workspace_lists_at", "lr_inlier_mask", "lr_workspace_mask_at",
     "lr_voxel_dedup_scratch_bytes", "lr_voxel_dedup", "lr_workspace_option", "lr_workspace_stage_times", "lr_icp_batch", "lr_workspace_lists_batch",
-    "lr_workspace_clock",
+    "lr_workspace_clock", "lr_debug_fake_current_device",
 ]
 
 # lr_workspace_option ids (include/lidarreg.h).  DEFAULT_OPTIONS is applied to every Workspace this module creates (a hook for
 # tuning experiments and for the test that no option changes a result; the library itself reads no environment variable).
-OPTIONS = {"nn_blocks": 1, "nn_blocks_batch": 2, "nn_sample_stride": 3, "rev_strips": 4, "nn_second_auto": 5, "nn_verify_separate": 6, "clock_probe": 7}
+OPTIONS = {"nn_blocks": 1, "nn_blocks_batch": 2, "nn_sample_stride": 3, "rev_strips": 4, "nn_second_auto": 5, "nn_verify_fused": 6, "clock_probe": 7}
 DEFAULT_OPTIONS = {}
 
 

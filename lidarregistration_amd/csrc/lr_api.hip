@@ -22,6 +22,60 @@ static_assert(sizeof(lr_ransac_params) == 72 && sizeof(lr_pair_params) == 112 &&
 extern "C" int lr_version(void) { return 103; }
 extern "C" const char *lr_last_error(void) { return g_err; }
 
+// Every entry point that writes arena state (scratch, counters, result temporaries) makes lr_icp_batch forget the last batched
+// registration: its transforms / descriptor table would otherwise be read back stale (only lr_register_batch, on success, re-arms it)
+static inline void forget_last_batch(lr_workspace *ws) { if (ws) { ws->last_batch = 0; ws->last_T_final = nullptr; } }
+
+// ------------------------------------------------------------------ device
+// The kernels are gfx950 code objects and the workspace is memory of ONE device: a workspace remembers the device it was created on and
+// every entry point that takes one checks that this device is current (and that the stream belongs to it) before it launches anything --
+// on another device the arena pointers would be dereferenced by kernels running elsewhere (a fault at best).  What the architecture
+// and the number of compute units are is asked once per device.
+static int g_fake_device = -1;          // test hook (lr_debug_fake_current_device): what check_device() takes for the current device
+struct lr_device_info { int known, ok, cus; char arch[64]; };
+static lr_device_info g_dev[64];
+
+static int device_info(int dev, const lr_device_info **out)
+{
+    if (dev < 0 || dev >= 64) { lr_set_error("device index %d out of range", dev); return LR_EINVAL; }
+    lr_device_info &d = g_dev[dev];
+    if (!d.known) {
+        hipDeviceProp_t prop;
+        LR_HIP(hipGetDeviceProperties(&prop, dev));
+        snprintf(d.arch, sizeof d.arch, "%s", prop.gcnArchName);
+        d.ok = strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+        d.cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        d.known = 1;
+    }
+    *out = &d;
+    return LR_OK;
+}
+
+static int check_device(const lr_workspace *ws, hipStream_t st, const char *who)
+{
+    if (!ws) { lr_set_error("%s: null workspace", who); return LR_EINVAL; }
+    int cur = -1;
+    LR_HIP(hipGetDevice(&cur));
+    if (g_fake_device >= 0) cur = g_fake_device;
+    if (cur != ws->device) {
+        lr_set_error("%s: the workspace was created on device %d but device %d is current (hipSetDevice / torch.cuda.set_device before the call; one workspace per device)",
+                     who, ws->device, cur);
+        return LR_EINVAL;
+    }
+    if (st) {
+        hipDevice_t sd = -1;
+        if (hipStreamGetDevice(st, &sd) == hipSuccess) {
+            if ((int)sd != ws->device) { lr_set_error("%s: the stream belongs to device %d, the workspace to device %d", who, (int)sd, ws->device); return LR_EINVAL; }
+        } else (void)hipGetLastError();
+    }
+    return LR_OK;
+}
+#define LR_CHECK_DEVICE(ws, stream, who) do { int rc_d_ = check_device(ws, (hipStream_t)(stream), who); if (rc_d_ != LR_OK) return rc_d_; } while (0)
+
+// Test hook (no reference counterpart): from now on the entry points take `device` for the current device (-1: ask HIP again).  Lets the
+// one-GPU test box exercise the wrong-device refusal.
+extern "C" int lr_debug_fake_current_device(int device) { g_fake_device = device; return LR_OK; }
+
 // ------------------------------------------------------------------ workspace
 namespace {
 struct Carver {
@@ -104,16 +158,25 @@ extern "C" int lr_workspace_create_batch(lr_workspace **out, int max_pairs, int 
     LR_REQUIRE(max_n0 > 0 && max_n1 > 0 && max_iters >= 0, LR_EINVAL, "lr_workspace_create: sizes must be positive");
     LR_REQUIRE(dim >= 1 && dim <= LR_FEAT_DIM, LR_EINVAL, "lr_workspace_create: descriptors of 1 to 32 dimensions are supported");
     LR_REQUIRE(max_n0 < (1 << 22) && max_n1 < (1 << 22), LR_ESIZE, "lr_workspace_create: clouds are limited to 2^22 points");
+    int dev = -1;
+    LR_HIP(hipGetDevice(&dev));
+    const lr_device_info *di = nullptr;
+    LR_TRY_HIP(device_info(dev, &di));
+    if (!di->ok) {
+        lr_set_error("lr_workspace_create: device %d is %s; this library holds gfx950 (MI355X) code objects only", dev, di->arch);
+        return LR_EINVAL;
+    }
     lr_workspace *ws = new (std::nothrow) lr_workspace();
     LR_REQUIRE(ws, LR_ENOMEM, "lr_workspace_create: host allocation failed");
     memset(ws, 0, sizeof(*ws));
+    ws->device = dev; ws->n_cus = di->cus;
     ws->max_n0 = max_n0; ws->max_n1 = max_n1; ws->max_n = max_n0 > max_n1 ? max_n0 : max_n1;
     ws->dim = dim; ws->max_iters = max_iters > 0 ? max_iters : 1;
     ws->max_pairs = max_pairs; ws->zP = 1; ws->z = lr_zargs{ 0, nullptr };
     // tuning defaults (lr_workspace_option changes them; no environment variable is read anywhere in this library)
-    ws->nn_blocks_target = 768;          // 3 blocks per CU = every block of a single pair's filter pass resident at once
-    ws->nn_blocks_batch = 3072;
-    ws->nn_sample_stride = 0; ws->rev_strips = 0; ws->nn_second_auto = 0; ws->nn_verify_separate = 0; ws->clock_probe = 0;
+    ws->nn_blocks_target = 3 * ws->n_cus;      // 3 blocks per CU = every block of a single pair's filter pass resident at once (768 on an MI355X)
+    ws->nn_blocks_batch = 12 * ws->n_cus;      // (3072)
+    ws->nn_sample_stride = 0; ws->rev_strips = 0; ws->nn_second_auto = 0; ws->nn_verify_fused = 0; ws->clock_probe = 0;
     Carver sizing;
     carve(ws, sizing);
     ws->stride = (sizing.off + 511) & ~size_t(255);          // one arena per pair, identical layout
@@ -140,10 +203,16 @@ extern "C" int lr_workspace_create_batch(lr_workspace **out, int max_pairs, int 
     // the synchronisation the first call on the new workspace can overtake the fill, which then wipes what that call wrote (found by
     // tests/test_gpu_gc.py::test_lo_helper_protocol_under_contention, round 4: workspaces created while other streams keep the GPU busy)
     if (hipMemset(ws->base, 0, ws->bytes) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) {
+        if (ws->form_host) (void)hipHostFree(ws->form_host);
         (void)hipFree(ws->base); delete ws; lr_set_error("lr_workspace_create: hipMemset failed"); return LR_EHIP;
     }
     for (int k = 0; k < LR_NEV; ++k)
-        if (hipEventCreate(&ws->ev[k]) != hipSuccess) { (void)hipFree(ws->base); delete ws; lr_set_error("lr_workspace_create: hipEventCreate failed"); return LR_EHIP; }
+        if (hipEventCreate(&ws->ev[k]) != hipSuccess) {
+            // (everything created so far goes: the events before this one, the pinned hint, the arena)
+            for (int q = 0; q < k; ++q) (void)hipEventDestroy(ws->ev[q]);
+            if (ws->form_host) (void)hipHostFree(ws->form_host);
+            (void)hipFree(ws->base); delete ws; lr_set_error("lr_workspace_create: hipEventCreate failed"); return LR_EHIP;
+        }
     *out = ws;
     return LR_OK;
 }
@@ -165,12 +234,12 @@ extern "C" int lr_workspace_option(lr_workspace *ws, int option, int value)
     LR_REQUIRE(ws, LR_EINVAL, "lr_workspace_option: null workspace");
     LR_REQUIRE(value >= 0, LR_EINVAL, "lr_workspace_option: value must be >= 0");
     switch (option) {
-    case LR_OPT_NN_BLOCKS: ws->nn_blocks_target = value > 0 ? value : 768; break;
-    case LR_OPT_NN_BLOCKS_BATCH: ws->nn_blocks_batch = value > 0 ? value : 3072; break;
+    case LR_OPT_NN_BLOCKS: ws->nn_blocks_target = value > 0 ? value : 3 * ws->n_cus; break;
+    case LR_OPT_NN_BLOCKS_BATCH: ws->nn_blocks_batch = value > 0 ? value : 12 * ws->n_cus; break;
     case LR_OPT_NN_SAMPLE_STRIDE: ws->nn_sample_stride = value > 4096 ? 4096 : value; break;      // (lr_nn16_run clamps it to the strip length)
     case LR_OPT_REV_STRIPS: ws->rev_strips = value > 64 ? 64 : value; break;
     case LR_OPT_NN_SECOND_AUTO: ws->nn_second_auto = value ? 1 : 0; break;
-    case LR_OPT_NN_VERIFY_SEPARATE: ws->nn_verify_separate = value ? 1 : 0; break;
+    case LR_OPT_NN_VERIFY_FUSED: ws->nn_verify_fused = value ? 1 : 0; break;
     case LR_OPT_CLOCK_PROBE: ws->clock_probe = value ? 1 : 0; break;
     default: lr_set_error("lr_workspace_option: unknown option %d", option); return LR_EINVAL;
     }
@@ -181,7 +250,8 @@ extern "C" int lr_workspace_option(lr_workspace *ws, int option, int value)
 // (or hipMalloc) left in the scratch; the parity tests poison it with different patterns and expect identical results.
 extern "C" int lr_workspace_poison(lr_workspace *ws, int byte, void *stream)
 {
-    LR_REQUIRE(ws, LR_EINVAL, "lr_workspace_poison: null workspace");
+    LR_CHECK_DEVICE(ws, stream, "lr_workspace_poison");
+    forget_last_batch(ws);          // (the descriptor table and the result temporaries are overwritten)
     LR_HIP(hipMemsetAsync(ws->base, byte & 0xff, ws->bytes, (hipStream_t)stream));
     return LR_OK;
 }
@@ -195,7 +265,7 @@ extern "C" int lr_workspace_lists(lr_workspace *ws, int n0, int32_t *nn_idx1, in
 extern "C" int lr_workspace_lists_at(lr_workspace *ws, int pair, int n0, int32_t *nn_idx1, int32_t *nn_idx2,
                                      int32_t *corr_idx0, int32_t *corr_idx1, void *stream)
 {
-    LR_REQUIRE(ws, LR_EINVAL, "lr_workspace_lists: null workspace");
+    LR_CHECK_DEVICE(ws, stream, "lr_workspace_lists");
     LR_REQUIRE(pair >= 0 && pair < ws->max_pairs, LR_EINVAL, "lr_workspace_lists: pair outside the workspace");
     LR_REQUIRE(pair < ws->last_npairs, LR_EINVAL, "lr_workspace_lists: the last registration call on this workspace had fewer pairs");
     LR_REQUIRE(n0 > 0 && n0 <= ws->max_n0, LR_ESIZE, "lr_workspace_lists: n0 exceeds the workspace");
@@ -213,7 +283,7 @@ extern "C" int lr_workspace_lists_at(lr_workspace *ws, int pair, int n0, int32_t
 extern "C" int lr_workspace_lists_batch(lr_workspace *ws, int npairs, int width, int32_t *nn_idx1, int32_t *nn_idx2,
                                         int32_t *corr_idx0, int32_t *corr_idx1, void *stream)
 {
-    LR_REQUIRE(ws, LR_EINVAL, "lr_workspace_lists_batch: null workspace");
+    LR_CHECK_DEVICE(ws, stream, "lr_workspace_lists_batch");
     LR_REQUIRE(npairs >= 1 && npairs <= ws->last_npairs, LR_EINVAL, "lr_workspace_lists_batch: the last registration call on this workspace had fewer pairs");
     LR_REQUIRE(width > 0 && width <= ws->max_n0, LR_ESIZE, "lr_workspace_lists_batch: width exceeds the workspace");
     hipStream_t st = (hipStream_t)stream;
@@ -251,7 +321,7 @@ int lr_zero_scratch(lr_workspace *ws, void *p, size_t bytes, hipStream_t st)
 // synchronised the streams that used the workspace (blocking copies on the null stream).
 extern "C" int lr_workspace_clock(lr_workspace *ws, double *mhz, unsigned long long *cycles, unsigned long long *ticks, int reset)
 {
-    LR_REQUIRE(ws, LR_EINVAL, "lr_workspace_clock: null workspace");
+    LR_CHECK_DEVICE(ws, nullptr, "lr_workspace_clock");
     unsigned long long h[2] = { 0ull, 0ull };
     LR_HIP(hipMemcpy(h, ws->clk_dev, sizeof h, hipMemcpyDeviceToHost));
     if (cycles) *cycles = h[0];
@@ -263,7 +333,7 @@ extern "C" int lr_workspace_clock(lr_workspace *ws, double *mhz, unsigned long l
 
 extern "C" int lr_workspace_timing(lr_workspace *ws, int enable)
 {
-    LR_REQUIRE(ws, LR_EINVAL, "lr_workspace_timing: null workspace");
+    LR_CHECK_DEVICE(ws, nullptr, "lr_workspace_timing");
     ws->timing = enable; ws->ev_pending = 0; ws->rev_recorded = 0; ws->nn_ms_acc = 0; ws->ransac_ms_acc = 0; ws->n_samples = 0;
     ws->call_ms_acc = 0; ws->fwd_ms_acc = 0; ws->fwd_filter_ms_acc = 0; ws->rev_filter_ms_acc = 0; ws->rev_ms_acc = 0; ws->rev_done_recorded = 0;
     return LR_OK;
@@ -293,7 +363,7 @@ static int lr_timing_collect(lr_workspace *ws)
 // Reads the events of the last timed pair; the caller has synchronised the stream.
 extern "C" int lr_workspace_timing_read(lr_workspace *ws, float *nn_ms, float *ransac_ms, int *n_samples)
 {
-    LR_REQUIRE(ws, LR_EINVAL, "lr_workspace_timing_read: null workspace");
+    LR_CHECK_DEVICE(ws, nullptr, "lr_workspace_timing_read");
     LR_TRY_HIP(lr_timing_collect(ws));
     if (nn_ms) *nn_ms = ws->nn_ms_acc;
     if (ransac_ms) *ransac_ms = ws->ransac_ms_acc;
@@ -308,6 +378,7 @@ extern "C" int lr_workspace_timing_read(lr_workspace *ws, float *nn_ms, float *r
 extern "C" int lr_workspace_stage_times(lr_workspace *ws, float out[8], int *n_samples)
 {
     LR_REQUIRE(ws && out, LR_EINVAL, "lr_workspace_stage_times: null pointer");
+    LR_CHECK_DEVICE(ws, nullptr, "lr_workspace_stage_times");
     LR_TRY_HIP(lr_timing_collect(ws));
     out[0] = ws->call_ms_acc; out[1] = ws->fwd_ms_acc; out[2] = ws->fwd_filter_ms_acc; out[3] = ws->rev_filter_ms_acc; out[4] = ws->ransac_ms_acc;
     out[5] = ws->rev_ms_acc;
@@ -328,9 +399,6 @@ static int check_nn_args(const lr_workspace *ws, const void *F0, int n0, const v
 
 #define LR_TRY(x) do { int rc_ = (x); if (rc_ != LR_OK) return rc_; } while (0)
 
-// Every entry point that writes arena state (scratch, counters, result temporaries) makes lr_icp_batch forget the last batched
-// registration: its transforms / descriptor table would otherwise be read back stale (only lr_register_batch, on success, re-arms it)
-static inline void forget_last_batch(lr_workspace *ws) { if (ws) { ws->last_batch = 0; ws->last_T_final = nullptr; } }
 
 // The params structs start with their own size: a caller built against another version of include/lidarreg.h is turned away instead
 // of having a shorter struct read past its end (lr_version 102)
@@ -418,6 +486,7 @@ extern "C" int lr_nn_top2(lr_workspace *ws, const float *F0, int n0, const float
                           int32_t *idx1, int32_t *idx2, float *s1, float *s2, void *stream)
 {
     LR_TRY(check_nn_args(ws, F0, n0, F1, n1, dim, "lr_nn_top2"));
+    LR_CHECK_DEVICE(ws, stream, "lr_nn_top2");
     forget_last_batch(ws);
     LR_REQUIRE(idx1, LR_EINVAL, "lr_nn_top2: idx1 is required");
     hipStream_t st = (hipStream_t)stream;
@@ -432,6 +501,7 @@ extern "C" int lr_nn_to_mutual(lr_workspace *ws, const float *F0, int n0, const 
                                int32_t *o0, int32_t *o1, int32_t *o2, int32_t *n_out, void *stream)
 {
     LR_TRY(check_nn_args(ws, F0, n0, F1, n1, dim, "lr_nn_to_mutual"));
+    LR_CHECK_DEVICE(ws, stream, "lr_nn_to_mutual");
     forget_last_batch(ws);
     LR_REQUIRE(idx1, LR_EINVAL, "lr_nn_to_mutual: idx1 is required");
     hipStream_t st = (hipStream_t)stream;
@@ -447,6 +517,7 @@ extern "C" int lr_gpf(lr_workspace *ws, const float *F0, int n0, const float *F1
                       int32_t *o0, int32_t *o1, int32_t *o2, float *oscore, int32_t *n_out, void *stream)
 {
     LR_TRY(check_nn_args(ws, F0, n0, F1, n1, dim, "lr_gpf"));
+    LR_CHECK_DEVICE(ws, stream, "lr_gpf");
     forget_last_batch(ws);
     LR_REQUIRE(idx1 && idx2 && xyz0 && o0 && o1, LR_EINVAL, "lr_gpf: null pointer");
     hipStream_t st = (hipStream_t)stream;
@@ -464,6 +535,7 @@ extern "C" int lr_gpf_bb_first(lr_workspace *ws, const float *F0, int n0, const 
                                void *stream)
 {
     LR_TRY(check_nn_args(ws, F0, n0, F1, n1, dim, "lr_gpf_bb_first"));
+    LR_CHECK_DEVICE(ws, stream, "lr_gpf_bb_first");
     forget_last_batch(ws);
     LR_REQUIRE(idx1 && idx2 && xyz0 && o0 && o1 && o2 && n_out && has_score, LR_EINVAL, "lr_gpf_bb_first: null pointer");
     hipStream_t st = (hipStream_t)stream;
@@ -482,6 +554,7 @@ extern "C" int lr_ransac(lr_workspace *ws, const float *src, const float *tgt, i
 {
     LR_REQUIRE(ws && src && tgt && p && T_out && res, LR_EINVAL, "lr_ransac: null pointer");
     LR_TRY(check_ransac_params(p, "lr_ransac"));
+    LR_CHECK_DEVICE(ws, stream, "lr_ransac");
     forget_last_batch(ws);
     LR_REQUIRE(m >= 0 && m <= ws->max_n0, LR_ESIZE, "lr_ransac: m exceeds the workspace");
     hipStream_t st = (hipStream_t)stream;
@@ -496,6 +569,7 @@ extern "C" int lr_inlier_mask(lr_workspace *ws, const float *src, const float *t
     LR_REQUIRE(src && tgt && mask && m >= 0, LR_EINVAL, "lr_inlier_mask: bad argument");
     LR_REQUIRE(T || ws, LR_EINVAL, "lr_inlier_mask: neither a model nor a workspace");
     LR_REQUIRE(thr2 > 0.0f, LR_EINVAL, "lr_inlier_mask: thr2 must be positive");
+    if (!T) LR_CHECK_DEVICE(ws, stream, "lr_inlier_mask");
     return lr_inlier_mask_run(src, tgt, nullptr, nullptr, m, nullptr, T ? T : ws->T_tmp, thr2, mask, n_inliers, (hipStream_t)stream);
 }
 
@@ -507,6 +581,7 @@ extern "C" int lr_workspace_mask_at(lr_workspace *ws, int pair, const float *xyz
     LR_REQUIRE(pair < ws->last_npairs, LR_EINVAL, "lr_workspace_mask_at: the last registration call on this workspace had fewer pairs");
     LR_REQUIRE(n0 > 0 && n0 <= ws->max_n0, LR_ESIZE, "lr_workspace_mask_at: n0 exceeds the workspace");
     LR_REQUIRE(thr2 > 0.0f, LR_EINVAL, "lr_workspace_mask_at: thr2 must be positive");
+    LR_CHECK_DEVICE(ws, stream, "lr_workspace_mask_at");
     const size_t off = (size_t)pair * ws->stride;
     auto at = [&](auto *p) { return reinterpret_cast<decltype(p)>(reinterpret_cast<char *>(p) + off); };
     return lr_inlier_mask_run(xyz0, xyz1, at(ws->corr_idx0), at(ws->corr_idx1), n0, at(ws->counters) + LR_CNT_NCORR, at(ws->T_tmp), thr2,
@@ -519,6 +594,8 @@ extern "C" int lr_refit(lr_workspace *ws, const float *xyz0, int n0, const float
 {
     LR_REQUIRE(ws && xyz0 && xyz1 && idx1 && T_in && T_out, LR_EINVAL, "lr_refit: null pointer");
     LR_REQUIRE(n0 > 0 && n0 <= ws->max_n0, LR_ESIZE, "lr_refit: n0 exceeds the workspace");
+    LR_CHECK_DEVICE(ws, stream, "lr_refit");
+    forget_last_batch(ws);          // (arena-0 counters and the refit scratch are overwritten)
     return lr_refit_run(ws, xyz0, n0, xyz1, idx1, T_in, thr2, T_out, n_inl, nullptr, (hipStream_t)stream);
 }
 
@@ -528,6 +605,7 @@ extern "C" int lr_icp(lr_workspace *ws, const float *xyz0, int n0, const float *
 {
     LR_REQUIRE(ws && xyz0 && xyz1 && T_init && T_out, LR_EINVAL, "lr_icp: null pointer");
     LR_REQUIRE(n0 > 0 && n0 <= ws->max_n0 && n1 > 0 && n1 <= ws->max_n1, LR_ESIZE, "lr_icp: cloud exceeds the workspace");
+    LR_CHECK_DEVICE(ws, stream, "lr_icp");
     forget_last_batch(ws);          // (the ICP scratch and the result temporaries are overwritten)
     return lr_icp_run(ws, xyz0, n0, xyz1, n1, T_init, nullptr, max_dist, max_iter, rel_fitness, rel_rmse, T_out, res, (hipStream_t)stream);
 }
@@ -540,6 +618,7 @@ __global__ void pair_icp_kernel(const double *__restrict__ T_icp, const lr_icp_r
 extern "C" int lr_icp_batch(lr_workspace *ws, double max_dist, int max_iter, double rel_fitness, double rel_rmse, lr_pair_result *out, void *stream)
 {
     LR_REQUIRE(ws && out, LR_EINVAL, "lr_icp_batch: null pointer");
+    LR_CHECK_DEVICE(ws, stream, "lr_icp_batch");
     LR_REQUIRE(ws->last_batch && ws->last_npairs >= 1 && ws->last_T_final, LR_EINVAL,
                "lr_icp_batch: no successful lr_register_batch on this workspace since the last call that touched its scratch");
     hipStream_t st = (hipStream_t)stream;
@@ -587,6 +666,7 @@ __global__ void pair_result_kernel(const double *__restrict__ T_ransac, const do
         out->status = rr->best_h < 0 ? 1 : 0;
         for (int q = 0; q < 8; ++q) out->reserved[q] = 0;
         out->reserved[1] = reinterpret_cast<const lr_ransac_state *>(counters + LR_CNT_COUNT)->lo_timeouts;
+        out->reserved[2] = (counters[LR_CNT_FORM_MISS_F] ? 1 : 0) | (counters[LR_CNT_FORM_MISS_R] ? 2 : 0);
         out->icp.fitness = 0.0; out->icp.inlier_rmse = 0.0; out->icp.n_corr = 0; out->icp.iterations = 0;
     }
     if (k < 16) out->T_icp[k] = T_final[k];      // overwritten by pair_icp_kernel when the ICP stage runs
@@ -669,6 +749,7 @@ extern "C" int lr_register_pair(lr_workspace *ws, const float *xyz0, const float
     LR_REQUIRE(ws && xyz0 && xyz1 && p && out, LR_EINVAL, "lr_register_pair: null pointer");
     LR_TRY(check_pair_params(p, "lr_register_pair"));
     LR_TRY(check_nn_args(ws, F0, n0, F1, n1, dim, "lr_register_pair"));
+    LR_CHECK_DEVICE(ws, stream, "lr_register_pair");
     LR_REQUIRE(p->mode == LR_MODE_NO_FILTER || p->mode == LR_MODE_MNN || p->mode == LR_MODE_GPF, LR_EINVAL,
                "lr_register_pair: unknown mode");
     ws->zP = 1; ws->z = lr_zargs{ 0, nullptr };
@@ -690,6 +771,7 @@ extern "C" int lr_register_batch(lr_workspace *ws, int npairs, const float *cons
     LR_REQUIRE(ws && xyz0 && xyz1 && F0 && F1 && n0 && n1 && p && out, LR_EINVAL, "lr_register_batch: null pointer");
     LR_TRY(check_pair_params(p, "lr_register_batch"));
     LR_REQUIRE(npairs >= 1 && npairs <= ws->max_pairs, LR_ESIZE, "lr_register_batch: npairs exceeds the workspace (lr_workspace_create_batch)");
+    LR_CHECK_DEVICE(ws, stream, "lr_register_batch");
     LR_REQUIRE(p->mode == LR_MODE_NO_FILTER || p->mode == LR_MODE_MNN || p->mode == LR_MODE_GPF, LR_EINVAL,
                "lr_register_batch: unknown mode");
     lr_desc_table t;

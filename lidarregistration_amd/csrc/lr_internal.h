@@ -88,6 +88,7 @@ __device__ __forceinline__ bool lr_xcd_block(int total, int &logical)
 struct lr_workspace {
     int max_n0, max_n1, max_n, dim, max_iters;
     int max_pairs;               // arenas in this workspace
+    int device, n_cus;           // the device the workspace lives on (checked against the current device at every entry point), its compute units
     int last_npairs;             // pairs of the last lr_register_pair / _batch call (0: none yet): what the *_at accessors may read
     int last_batch;              // 1: that call was lr_register_batch (descs[] still describes its pairs: lr_icp_batch)
     int last_mx0, last_mx1;      // largest cloud sizes of that call (they size the grids of a follow-up stage)
@@ -112,6 +113,7 @@ struct lr_workspace {
     float *bmax0, *bmax1;        // per-32-row maxima of the norms (f16 filter error bound)
     float *bmin0, *bmin1;        // ... and minima
     float *nn_range;             // [4] largest / smallest squared norm of cloud 0, of cloud 1 (are the norms all alike?  then the walk's candidate test is a sign test)
+    int form_prev[2];            // what lr_nn16_form_hint read at the previous single-pair call (a hint counts when two readings agree)
     int32_t *form_host, *form_dev;   // pinned, device-visible: [0] / [1] = the form the norms of cloud 0 / cloud 1 asked for in the last single-pair call (0 unknown, 1 sign, 2 plain)
     uint32_t *rev_seed;          // [max_n1] best forward distance pointing at each cloud-1 row (bit pattern)
     unsigned long long *rev_seed64;  // [max_n1] ... and who: (distance bits << 32) | smallest cloud-0 index at that distance
@@ -128,7 +130,7 @@ struct lr_workspace {
     int nn_sample_stride;        // LR_OPT_NN_SAMPLE_STRIDE: phase 1 of the filter pass samples every this-many-th column tile (0: by the strip length)
     int rev_strips;              // LR_OPT_REV_STRIPS: strips offered to every row block of the reverse pass (0: by the number of pairs)
     int nn_second_auto;          // LR_OPT_NN_SECOND_AUTO: the pair pipeline computes the 2nd neighbour only when a stage reads it
-    int nn_verify_separate;      // LR_OPT_NN_VERIFY_SEPARATE: the exact verification always runs as its own kernel (A/B switch of the fused form)
+    int nn_verify_fused;         // LR_OPT_NN_VERIFY_FUSED: one-strip row blocks of the filter pass verify their own rows (off by default: measured slower)
     int clock_probe;             // LR_OPT_CLOCK_PROBE: the filter-pass blocks sum their shader cycles / 100 MHz ticks into clk_dev
     unsigned long long *clk_dev; // [2] device words behind lr_workspace_clock (outside the arenas: one per workspace)
     int32_t *counters;           // small int block, see LR_CNT_*

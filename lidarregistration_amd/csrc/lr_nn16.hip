@@ -1287,12 +1287,18 @@ int lr_nn16_prep(lr_workspace *ws, const float *F0, int n0, const float *F1, int
 }
 
 // which form of the filter pass a single-pair call launches alone: what the range kernel of an earlier call on this workspace found
-// for the column cloud (0: cloud 0 = reverse pass, 1: cloud 1 = forward pass); 0 = unknown (first call, batched call): launch both
-static int lr_nn16_form_hint(const lr_workspace *ws, int col_cloud)
+// for the column cloud (0: cloud 0 = reverse pass, 1: cloud 1 = forward pass); 0 = unknown (first call, batched call): launch both.
+// The hint is only trusted when TWO calls in a row read the same value: a workspace that alternates between unit-norm and other
+// clouds (the harness' calibration call next to user calls) would otherwise guess wrong on every call and pay the exact kernel's
+// full scan each time, silently -- it launches both forms instead, the cost of an empty launch.  A miss that still
+// happens (the first call of a changed workload) is reported in lr_pair_result.reserved[2].
+static int lr_nn16_form_hint(lr_workspace *ws, int col_cloud)
 {
     if (ws->zP != 1 || !ws->form_host) return 0;
     const int h = *reinterpret_cast<const volatile int32_t *>(&ws->form_host[col_cloud]);
-    return (h == 1 || h == 2) ? h : 0;
+    const int prev = ws->form_prev[col_cloud];
+    ws->form_prev[col_cloud] = h;
+    return ((h == 1 || h == 2) && h == prev) ? h : 0;
 }
 
 int lr_nn16_run(lr_workspace *ws, const float *Fq, const _Float16 *Hq, const float *nQ, int na,
@@ -1332,9 +1338,9 @@ int lr_nn16_run(lr_workspace *ws, const float *Fq, const _Float16 *Hq, const flo
     int32_t *miss = ws->counters + LR_CNT_FORM_MISS_F;
     const lr_ex_out eo = { idx1, idx2, s1, s2, seed_reverse ? ws->rev_seed : (uint32_t *)nullptr, ws->rev_s1, reinterpret_cast<uint32_t *>(ws->counters + LR_CNT_RLO),
                            ws->rev_seed64 };
-    // (fused verification: whenever a row block has one strip -- decided per row block on the device; LR_OPT_NN_VERIFY_SEPARATE switches it off)
+    // (fused verification, LR_OPT_NN_VERIFY_FUSED: whenever a row block has one strip -- decided per row block on the device)
     unsigned long long *clk = ws->clock_probe ? ws->clk_dev : (unsigned long long *)nullptr;
-    const lr_pb_fuse fz = { ws->nn_verify_separate ? (const float *)nullptr : Fq, Fc, nQ, nC, eo, clk, ws->z, row_blocks, strips, 0, 0 };
+    const lr_pb_fuse fz = { ws->nn_verify_fused ? Fq : (const float *)nullptr, Fc, nQ, nC, eo, clk, ws->z, row_blocks, strips, 0, 0 };
     if (only != 2)
         hipLaunchKernelGGL(nn16_passb_kernel<true>, grid, dim3(256), 0, st, fz, clk, Hq, na, (const int32_t *)nullptr, (const int32_t *)nullptr, Hc, nC, nb,
                            tps, (const float *)nullptr, ws->cand_cnt, ws->cand, (const int32_t *)nullptr, (const float *)nullptr,
@@ -1621,7 +1627,7 @@ int lr_nn16_reverse(lr_workspace *ws, const float *F0, const _Float16 *H0, const
     const lr_thr_in rthr = { nullptr, (const float *)ws->nn_range, 1, 0 };      // (no tightening: the column norms' range selects the form of the walk's test)
     const lr_ex_out reo = { rev, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, seeded ? ws->rev_seed64 : (unsigned long long *)nullptr };
     unsigned long long *clk = ws->clock_probe ? ws->clk_dev : (unsigned long long *)nullptr;
-    const lr_pb_fuse rfz = { ws->nn_verify_separate ? (const float *)nullptr : F1, F0, nrm1, nrm0, reo, clk, ws->z, row_blocks, strips, 1, 0 };
+    const lr_pb_fuse rfz = { ws->nn_verify_fused ? F1 : (const float *)nullptr, F0, nrm1, nrm0, reo, clk, ws->z, row_blocks, strips, 1, 0 };
     if (only != 2)
         hipLaunchKernelGGL(nn16_passb_kernel<true>, grid, dim3(256), 0, st, rfz, clk, H1, na, (const int32_t *)ws->rev_rows, (const int32_t *)n_rows,
                            (const _Float16 *)ws->Hs, (const float *)ws->nrms, nb, tps, ws->tau, ws->cand_cnt, ws->cand,

@@ -1776,6 +1776,8 @@ __device__ void refit_solve_body(const double *__restrict__ partial, int nblocks
             const lr_ransac_state *state = reinterpret_cast<const lr_ransac_state *>(counters + LR_CNT_COUNT);
             if (state->evals_full > 0) pair_out->reserved[0] = (int32_t)((double)state->evals / (double)state->evals_full * 1e6);
             pair_out->reserved[1] = state->lo_timeouts;       // hand-off waits of the local optimisation that hit their bound (lr_ransac_state)
+            // single-pair calls: the one form of the filter pass that was launched was the wrong one (forward: 1, reverse: 2) -- every row went through the exact scan
+            pair_out->reserved[2] = (counters[LR_CNT_FORM_MISS_F] ? 1 : 0) | (counters[LR_CNT_FORM_MISS_R] ? 2 : 0);
         }
         for (int k = 0; k < 16; ++k) pair_out->T_icp[k] = T[k];      // overwritten by pair_icp_kernel when the ICP stage runs
         pair_out->icp.fitness = 0.0; pair_out->icp.inlier_rmse = 0.0; pair_out->icp.n_corr = 0; pair_out->icp.iterations = 0;

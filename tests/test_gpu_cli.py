@@ -190,6 +190,25 @@ def test_launcher_two_ranks_on_this_gpu_equals_one_process(cli, tmp_path):
     assert "process 0:" in log and "process 1:" in log
 
 
+def test_launcher_default_device_list_on_this_box(cli, tmp_path):
+    """./test_parallel.sh with LIDARREG_GPUS UNSET -- what the first run on an 8-GPU node does: the launcher finds this box's GPUs from the
+    inherited *_VISIBLE_DEVICES or from the KFD topology in sysfs (never through HIP in the parent), starts one rank per device and runs the
+    analysis; one rank per visible device, same rows as the in-process run."""
+    import torch
+    ref = cli.main(COMMON + ["--mode", "MNN"])
+    for d in (tmp_path / "outputs").iterdir():
+        shutil.rmtree(d)
+    env = {k: v for k, v in os.environ.items() if k != "LIDARREG_GPUS"}
+    r = subprocess.run(["bash", os.path.join(ROOT, "Experiments", "test_parallel.sh")] + COMMON + ["--mode", "MNN"], cwd=str(tmp_path), env=env,
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    raw, ids, T, log = _outputs(tmp_path)
+    for c in (0, 1, 2, 15, 16, 17, 18, 19, 20, 21):
+        assert np.array_equal(ref[:, c], raw[:, c]), c
+    world = torch.cuda.device_count()
+    assert world >= 1 and all(f"process {k}:" in log for k in range(world)) and f"process {world}:" not in log
+
+
 def test_launcher_eight_ranks_on_this_gpu_over_list_rows(cli, tmp_path):
     """World size 8 (the reference's README command for NuScenes-Boston, test_parallel.sh:18-24) -- on ONE GPU here, so this says nothing
     about scaling: it exercises the 8-way shard (DistributedSampler order), eight concurrent ranks and the merge.  64 list rows."""

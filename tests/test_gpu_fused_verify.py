@@ -2,8 +2,9 @@
 block: every 32-pair batched call, small clouds, the short-prefix row blocks of the reverse pass -- verifies them itself at the end of
 nn16_passb_kernel; nn16_exact_kernel then only takes the rows such a wave gave up on (segment overflow, a list that is too short, a query
 row or column norm that is not finite) and the row blocks with several strips.  Both routes run the same arithmetic in the same order, so
-every list and every result block must be bit-identical with the option LR_OPT_NN_VERIFY_SEPARATE on and off -- and equal to the oracle
-(matching.py:22-65, :207-239).  Needs an MI355X."""
+every list and every result block must be bit-identical with the option LR_OPT_NN_VERIFY_FUSED on and off -- and equal to the oracle
+(matching.py:22-65, :207-239).  The option is OFF by default: measured in the pipeline the fused form is 1 % slower (a wave parked in the
+gathers of its tail holds a third of a SIMD's wave slots).  Needs an MI355X."""
 import ctypes
 
 import numpy as np
@@ -58,7 +59,7 @@ def _nn(lr, F0, F1, options, need2=True):
     return out
 
 
-ONE_STRIP = {"nn_blocks": 1, "rev_strips": 1}       # every row block of both directions has one strip: every wave verifies its own rows
+ONE_STRIP = {"nn_blocks": 1, "rev_strips": 1}       # every row block of both directions has one strip: with nn_verify_fused every wave verifies its own rows
 
 
 def _cases():
@@ -87,9 +88,9 @@ def _cases():
 
 @pytest.mark.parametrize("name,F0,F1", list(_cases()), ids=[c[0] for c in _cases()])
 def test_fused_equals_separate_equals_oracle(lr, oracle, name, F0, F1):
-    fused = _nn(lr, F0, F1, ONE_STRIP)
-    sep = _nn(lr, F0, F1, dict(ONE_STRIP, nn_verify_separate=1))
-    default = _nn(lr, F0, F1, {})
+    fused = _nn(lr, F0, F1, dict(ONE_STRIP, nn_verify_fused=1))
+    sep = _nn(lr, F0, F1, ONE_STRIP)
+    default = _nn(lr, F0, F1, {"nn_verify_fused": 1})
     for k in fused:
         assert np.array_equal(_bits(fused[k]) if fused[k].dtype == np.float32 else fused[k], _bits(sep[k]) if sep[k].dtype == np.float32 else sep[k]), (name, k)
         assert np.array_equal(_bits(fused[k]) if fused[k].dtype == np.float32 else fused[k], _bits(default[k]) if default[k].dtype == np.float32 else default[k]), (name, k)
@@ -106,8 +107,8 @@ def test_fused_equals_separate_equals_oracle(lr, oracle, name, F0, F1):
 def test_fused_top1_only(lr, oracle):
     """need = 1 (no second neighbour asked for): shorter lists, the column key of the reverse pass is the NN distance."""
     F0, F1 = synth.make_features(5200, 4800, 32, 0.4, 0.9, 11)
-    a = _nn(lr, F0, F1, ONE_STRIP, need2=False)
-    b = _nn(lr, F0, F1, dict(ONE_STRIP, nn_verify_separate=1), need2=False)
+    a = _nn(lr, F0, F1, dict(ONE_STRIP, nn_verify_fused=1), need2=False)
+    b = _nn(lr, F0, F1, ONE_STRIP, need2=False)
     o1, _, os1, _ = oracle.nn_top2(F0, F1)
     assert np.array_equal(a["i1"], o1) and np.array_equal(_bits(a["s1"]), _bits(os1))
     for k in a:
@@ -130,10 +131,10 @@ def test_batched_call_fused_vs_separate(lr, kw):
         p = synth.make_pair(N=n0, N1=n1, rho=0.5, s=0.9, seed=4000 + k, clustered=(a.mode == "GPF"))
         devp.append(tuple(lr.torch.from_numpy(p[key]).to(dev) for key in ("xyz0", "xyz1", "feats0", "feats1")))
     outs, lists = [], []
-    for sep in (0, 1):
+    for fused in (1, 0):
         ws = lr.ext.Workspace(4099, 5000, 32, a.iters, max_pairs=32)
-        ws.set_option("nn_blocks_batch", 1); ws.set_option("nn_verify_separate", sep)
-        ws.poison(0x77 + sep)
+        ws.set_option("nn_blocks_batch", 1); ws.set_option("nn_verify_fused", fused)
+        ws.poison(0x77 + fused)
         out = lr.FR.register_batch_dev(devp, params, ws=ws)
         lr.torch.cuda.synchronize()
         o = out.cpu().numpy().copy(); o[:, 312:316] = 0          # (reserved[0]: a scheduling-dependent diagnostic)
@@ -157,7 +158,7 @@ def test_batched_call_fused_vs_separate(lr, kw):
             assert np.array_equal(x, y), k
 
 
-def test_headline_batch_is_verified_inside_the_filter_pass(lr):
+def test_headline_batch_fused_vs_separate_and_clock_probe(lr):
     """config #2 itself: 32 pairs of 30k points in one call.  Results equal with the option on and off, and the clock probe reports a
     plausible shader clock for the filter-pass blocks (lr_workspace_clock)."""
     a = Args(mode="MNN", codebase="open3D", iters=50000, ransac_n=3, o3d_conf=1.0)
@@ -168,9 +169,9 @@ def test_headline_batch_is_verified_inside_the_filter_pass(lr):
         p = synth.make_pair_dev(N=30000, seed=51 + k, device=dev)
         devp.append((p["xyz0"], p["xyz1"], p["feats0"], p["feats1"]))
     outs = []
-    for sep in (0, 1):
+    for fused in (1, 0):
         ws = lr.ext.Workspace(30000, 30000, 32, a.iters, max_pairs=32)
-        ws.set_option("nn_verify_separate", sep); ws.set_option("clock_probe", 1)
+        ws.set_option("nn_verify_fused", fused); ws.set_option("clock_probe", 1)
         assert ws.clock(reset=True)[1] == 0
         out = lr.FR.register_batch_dev(devp, params, ws=ws)
         lr.torch.cuda.synchronize()

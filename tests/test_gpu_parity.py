@@ -437,6 +437,41 @@ def test_errors_are_loud(lr):
         lr.matching.nn_top2_dev(np.zeros((10, 33), np.float32), np.zeros((10, 33), np.float32))      # wider than 32: refused (1..32 are served, tests/test_gpu_dims.py)
 
 
+def test_workspace_used_on_another_device_is_refused_not_faulted(lr):
+    """A workspace is memory of ONE device (include/lidarreg.h conventions): with another device current every entry point that takes it
+    returns LR_EINVAL before it launches anything.  The box has one GPU: the library's test hook stands in for hipSetDevice(3)."""
+    t = lr.torch
+    L = lr.ext.lib()
+    dev = t.device("cuda", 0)
+    ws = lr.ext.Workspace(1000, 1000, 32, 100, max_pairs=2)
+    F = t.randn(500, 32, device=dev); x = t.randn(500, 3, device=dev)
+    i1 = t.empty(500, dtype=t.int32, device=dev)
+    out = t.zeros((2, 496), dtype=t.uint8, device=dev)
+    params = lr.FR.pair_params(Args(iters=100))
+    assert L.lr_nn_top2(ws.handle, F.data_ptr(), 500, F.data_ptr(), 500, 32, i1.data_ptr(), None, None, None, None) == 0
+    L.lr_debug_fake_current_device(3)
+    try:
+        assert L.lr_nn_top2(ws.handle, F.data_ptr(), 500, F.data_ptr(), 500, 32, i1.data_ptr(), None, None, None, None) == -1
+        assert b"created on device 0 but device 3 is current" in L.lr_last_error()
+        assert L.lr_register_pair(ws.handle, x.data_ptr(), x.data_ptr(), F.data_ptr(), F.data_ptr(), 500, 500, 32, params, out.data_ptr(), None) == -1
+        with pytest.raises(lr.ext.LidarRegError, match="device 3 is current"):
+            lr.FR.register_batch_dev([(x, x, F, F)] * 2, params, out=out, ws=ws)
+        assert L.lr_workspace_poison(ws.handle, 1, None) == -1 and L.lr_workspace_timing(ws.handle, 1) == -1
+        with pytest.raises(lr.ext.LidarRegError):
+            ws.clock()
+    finally:
+        L.lr_debug_fake_current_device(-1)
+    t.cuda.synchronize()
+    assert L.lr_nn_top2(ws.handle, F.data_ptr(), 500, F.data_ptr(), 500, 32, i1.data_ptr(), None, None, None, None) == 0
+    t.cuda.synchronize()
+    assert (i1.cpu().numpy() == np.arange(500)).all()
+    # a stream of the right device passes, the null stream too
+    s = t.cuda.Stream(device=dev)
+    assert L.lr_nn_top2(ws.handle, F.data_ptr(), 500, F.data_ptr(), 500, 32, i1.data_ptr(), None, None, None, s.cuda_stream) == 0
+    t.cuda.synchronize()
+    ws.close()
+
+
 # ----------------------------------------------------------------------------- f16 filter robustness (error bound, fallbacks)
 @pytest.mark.parametrize("scale0,scale1", [(1.0, 1.0), (37.0, 37.0), (1e-3, 1e-3), (3.0, 0.2), (300.0, 300.0), (1e-6, 1e-6)])
 def test_nn_scaled_features_still_bit_exact(lr, oracle, scale0, scale1):
@@ -765,7 +800,8 @@ def test_tuning_options_do_not_change_results(lr):
 
     ref = run({})
     for options in ({"nn_sample_stride": 1}, {"nn_sample_stride": 3}, {"nn_sample_stride": 64}, {"rev_strips": 1}, {"rev_strips": 64},
-                    {"nn_blocks": 64}, {"nn_blocks": 4096}, {"nn_second_auto": 1}):
+                    {"nn_blocks": 64}, {"nn_blocks": 4096}, {"nn_second_auto": 1}, {"nn_verify_fused": 1}, {"clock_probe": 1},
+                    {"nn_blocks": 1, "rev_strips": 1}, {"nn_blocks": 1, "rev_strips": 1, "nn_verify_fused": 1}):
         assert run(options) == ref, options
     for ws in matching._WS.values():
         ws.close()

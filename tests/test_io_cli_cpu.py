@@ -185,7 +185,33 @@ def test_run_ranks_stops_everything_when_one_rank_fails():
 def test_gpu_list_from_the_environment(monkeypatch):
     from lidarregistration_amd import launch
     monkeypatch.setenv("LIDARREG_GPUS", "0 0 3,1")
-    assert launch.gpu_list() == [0, 0, 3, 1]
+    assert launch.gpu_list() == [("HIP_VISIBLE_DEVICES", v) for v in ("0", "0", "3", "1")]
+
+
+def test_gpu_list_default_branch_counts_devices_without_hip(tmp_path):
+    """LIDARREG_GPUS unset (what the first ./test_parallel.sh on an 8-GPU node does): the device list comes from an inherited
+    *_VISIBLE_DEVICES -- handed on entry by entry under the same variable, not re-numbered -- or from the KFD topology in sysfs; the
+    launcher process itself never imports torch or touches HIP."""
+    import subprocess
+    import sys
+    from lidarregistration_amd import launch
+    # a fake sysfs: two CPU nodes (simd_count 0), eight GPU nodes, one unreadable node
+    for k in range(11):
+        d = tmp_path / "nodes" / str(k)
+        d.mkdir(parents=True)
+        if k < 10:
+            (d / "properties").write_text(f"cpu_cores_count {96 if k < 2 else 0}\nsimd_count {0 if k < 2 else 1024}\nmem_banks_count 1\n")
+    root = str(tmp_path / "nodes")
+    assert launch.kfd_gpu_count(root) == 8
+    assert launch.gpu_list({}, root) == [("HIP_VISIBLE_DEVICES", str(i)) for i in range(8)]
+    assert launch.gpu_list({"HIP_VISIBLE_DEVICES": "2,3"}, root) == [("HIP_VISIBLE_DEVICES", "2"), ("HIP_VISIBLE_DEVICES", "3")]
+    assert launch.gpu_list({"ROCR_VISIBLE_DEVICES": "GPU-abc, 5"}, root) == [("ROCR_VISIBLE_DEVICES", "GPU-abc"), ("ROCR_VISIBLE_DEVICES", "5")]
+    assert launch.gpu_list({"LIDARREG_GPUS": "1", "HIP_VISIBLE_DEVICES": "2,3"}, root) == [("HIP_VISIBLE_DEVICES", "1")]
+    assert launch.kfd_gpu_count(str(tmp_path / "missing")) is None
+    # importing the launcher and asking for the list loads neither torch nor a HIP runtime into the process
+    code = ("import sys; sys.path.insert(0, %r); from lidarregistration_amd import launch; launch.gpu_list({}, %r); "
+            "assert 'torch' not in sys.modules; maps = open('/proc/self/maps').read(); assert 'libamdhip64' not in maps and 'libhsa-runtime' not in maps" % (ROOT, root))
+    assert subprocess.run([sys.executable, "-c", code]).returncode == 0
 
 
 def test_cli_launcher_builds_the_positional_protocol_and_skips_the_analysis_on_failure(monkeypatch, tmp_path):
@@ -214,3 +240,27 @@ def test_cli_launcher_builds_the_positional_protocol_and_skips_the_analysis_on_f
         assert c[k + 1] == seen["cmds"][0][k + 1] and c[k + 2] == seen["cmds"][0][k + 2]          # one start time, one file base
     assert not glob.glob(str(tmp_path / "lidarreg_ranks_*"))                                      # partial files removed, no analysis ran
     assert not (tmp_path / "outputs").exists()
+
+
+def test_FR_hands_back_open3d_clouds_where_open3d_imports(monkeypatch):
+    """FR.py:20-29 returns open3d.geometry.PointCloud objects and the reference's harness passes them to Open3D's ICP (test.py:185-187):
+    make_open3d_point_cloud builds real ones wherever `open3d` imports and the stand-in otherwise.  (Open3D is not in this image: a fake
+    module with the two constructors the reference uses stands in for it here.)"""
+    import types
+    from lidarregistration_amd import FR as fr
+    xyz = np.arange(12, dtype=np.float64).reshape(4, 3)
+    monkeypatch.setattr(fr, "_O3D", [None])
+    p = fr.make_open3d_point_cloud(xyz)
+    assert isinstance(p, fr.PointCloud) and np.array_equal(p.points, xyz)
+
+    class FakeCloud:
+        points = None
+    fake = types.SimpleNamespace(geometry=types.SimpleNamespace(PointCloud=FakeCloud),
+                                 utility=types.SimpleNamespace(Vector3dVector=lambda a: ("Vector3dVector", np.array(a))))
+    monkeypatch.setattr(fr, "_O3D", [fake])
+    q = fr.make_open3d_point_cloud(xyz)
+    assert isinstance(q, FakeCloud) and q.points[0] == "Vector3dVector" and np.array_equal(q.points[1], xyz) and q.points[1].dtype == np.float64
+    # the lookup itself: `import open3d` is tried once and its failure remembered
+    monkeypatch.setattr(fr, "_O3D", [])
+    monkeypatch.setitem(sys.modules, "open3d", fake)
+    assert isinstance(fr.make_open3d_point_cloud(xyz), FakeCloud) and fr._O3D == [fake]
