@@ -33,6 +33,28 @@ def test_single_rank_line_has_the_contract_keys():
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in line, k
     assert line["n_gpus"] == 1 and line["unit"] == "pairs/s" and "workload" in line["config"]
+    # what makes two records comparable: present in every line, null where nothing was measured (dry run)
+    for k in ("ms_per_step_minmedmax", "clock_MHz", "value_at_2.0GHz"):
+        assert k in line and line[k] is None, k
+
+
+def test_process_parallel_cpu_baseline_worker_protocol():
+    """bench.py's cpu_baseline also runs the reference-style path as P processes side by side (the reference's own sharding,
+    test_parallel.sh:18-20): oracle/cpu_worker.py says READY after its untimed warm-up, starts on GO and reports DONE <pairs> <seconds>."""
+    env = dict(os.environ, OMP_NUM_THREADS="2", HIP_VISIBLE_DEVICES="", PYTHONPATH=ROOT)
+    procs = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_worker", "2", "1500", "MNN", "500", "2", str(100 * (w + 1))], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
+                              text=True, env=env, cwd=ROOT) for w in range(2)]
+    try:
+        assert all(p.stdout.readline().strip() == "READY" for p in procs)
+        for p in procs:
+            p.stdin.write("GO\n"); p.stdin.flush()
+        outs = [p.stdout.readline().split() for p in procs]
+        assert all(o[0] == "DONE" and o[1] == "2" and float(o[2]) > 0 for o in outs), outs
+        assert all(p.wait(timeout=60) == 0 for p in procs)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
 
 
 def test_under_an_external_launcher_environment():
