@@ -299,11 +299,10 @@ def eval_pairs(source, indices, args, device=None, batch=32, in_flight=6, nstrea
       C  ICP (args.icp): one lr_icp_batch per batch on the same workspaces, timed the same way (test.py:183-193) -> column 11
       D  statistics: ground-truth inlier ratios on the device, RE / TE on the host                               -> the rest
     Returns (stats [n,22] float64, T [n,4,4] float64) in the reference's 22-column layout (test.py:98-100).  Time columns are
-    per-pair SHARES of a window: column 9 = (registration wall of the window / its pairs) x the part FR.py:117 bills -- the
-    library's own stage events give the forward-NN fraction f of the window's calls, the first neighbour's part of it,
-    f (1 - second_nn_share), is what the reference treats as given (matching.py:7-11); the share is calibrated once per
-    cloud-size class (FR.second_nn_share), so column 9 is an estimate of the reference-style figure, the whole path is kept in
-    LAST_WHOLE_PATH.  LAST_RUN holds the run's totals (seconds in A, B, C, D; pairs).
+    ATTRIBUTED shares of a window (attribute_window_time): the window's registration wall time goes to its calls by their device
+    time and to a call's pairs by n0 x n1 (NN stages) and ids examined x correspondences (the rest); column 9 takes off the first
+    neighbour's part of the forward NN, which the reference treats as given (matching.py:7-11; the second neighbour's share is
+    calibrated once per cloud-size class, FR.second_nn_share); the whole path is kept in LAST_WHOLE_PATH.  LAST_RUN holds the run's totals (seconds in A, B, C, D; pairs).
     Results are bit-identical to the one-pair-at-a-time path (eval_pairs_serial; tests/test_gpu_cli.py)."""
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
     params = registration_params(args)
@@ -393,17 +392,17 @@ def eval_pairs(source, indices, args, device=None, batch=32, in_flight=6, nstrea
                 totals["icp_s"] += t_icp
             # ---- D: statistics
             t0 = time.time()
-            d_call = d_fwd = 0.0
-            share_w = 0.0
+            # The window's registration wall time is attributed to its pairs by what each of them cost (it used to be a
+            # flat share): a call gets the part of the window its own device time (the library's events) is of all calls' device times;
+            # inside a call the NN stages (forward + reverse: events) go to the pairs by n0 x n1, the rest -- filter, RANSAC, refit --
+            # by hypothesis ids examined x correspondences (what the scoring passes do).  Column 9 then takes off the first neighbour's
+            # part of the pair's forward NN, as FR.py:117 does.  Still an attribution, not a measurement: --serial True measures.
+            d_call = 0.0
             for g in groups:
                 ms, _ = wss[g["slot"]].stage_times()
-                d_call += ms[0] - seen[g["slot"]][0]; d_fwd += ms[1] - seen[g["slot"]][1]
-                share_w += g["share"] * len(g["rows"])
+                g["call_ms"], g["fwd_ms"], g["rev_ms"] = ms[0] - seen[g["slot"]][0], ms[1] - seen[g["slot"]][1], ms[5] - seen[g["slot"]][5]
+                d_call += g["call_ms"]
                 seen[g["slot"]] = ms
-            share_w /= len(rows_w)
-            f_fwd = d_fwd / d_call if d_call > 0 else 0.0
-            per_pair = t_reg / len(rows_w)
-            billed = per_pair * (1.0 - f_fwd * (1.0 - share_w))
             for g in groups:
                 gp = g["ps"]
                 with torch.cuda.stream(streams[g["slot"] % nstreams]):
@@ -412,16 +411,19 @@ def eval_pairs(source, indices, args, device=None, batch=32, in_flight=6, nstrea
                     ri, rf = inlier_ratios_dev([p["xyz0"] for p in gp], [p["xyz1"] for p in gp], g["nn1"], g["c0"], g["c1"],
                                                torch.tensor(g["n0"], dtype=torch.int32, device=dev), n_corr, T_gt)
                     hb = g["out"].cpu().numpy(); ri = ri.cpu().numpy(); rf = rf.cpu().numpy()
+                res_g = [_ext.PairResult.from_buffer_copy(hb[j].tobytes()) for j in range(len(g["rows"]))]
+                whole_g, billed_g = attribute_window_time(t_reg, g["call_ms"], d_call, g["fwd_ms"], g["rev_ms"], g["share"], g["n0"], g["n1"],
+                                                          [r.ransac.n_ids for r in res_g], [r.n_corr for r in res_g])
                 for j, row in enumerate(g["rows"]):
-                    r = _ext.PairResult.from_buffer_copy(hb[j].tobytes())
+                    r = res_g[j]
                     T = np.array(r.T[:], np.float64).reshape(4, 4) if r.status == 0 else np.eye(4)
                     gt = T_gt[j]
                     re, te = metrics.rotation_error_deg(T, gt), metrics.translation_error_cm(T, gt)
                     sess, si, ti = source.ids(indices[row])
                     stats[row, 0] = float(re < metrics.RE_THRE_DEG and te < metrics.TE_THRE_CM)
                     stats[row, 1], stats[row, 2] = re, te
-                    stats[row, 9] = billed
-                    whole_path[row] = per_pair
+                    stats[row, 9] = billed_g[j]
+                    whole_path[row] = whole_g[j]
                     stats[row, 10], stats[row, 11] = t_data / len(rows_w), 0.0
                     if want_icp:
                         T_icp = np.array(r.T_icp[:], np.float64).reshape(4, 4) if r.status == 0 else np.eye(4)
@@ -454,12 +456,30 @@ def eval_pairs(source, indices, args, device=None, batch=32, in_flight=6, nstrea
     return stats, Ts
 
 
+def attribute_window_time(t_window, call_ms, all_calls_ms, fwd_ms, rev_ms, share, n0, n1, n_ids, n_corr):
+    """Per-pair (whole path seconds, seconds billed the reference's way) of ONE batched call inside a window of `t_window` seconds:
+    the call's part of the window = call_ms / all_calls_ms; its NN stages (fwd_ms + rev_ms of call_ms) are spread over its pairs by
+    n0 x n1, the rest by n_ids x n_corr (+1: a pair with no correspondences still costs its launches); billed = whole - the first
+    neighbour's part of the pair's forward NN (1 - share of it, FR.py:117 / matching.py:7-11).  The pairs' whole-path times add up to the
+    call's part of the window."""
+    n0 = np.asarray(n0, np.float64); n1 = np.asarray(n1, np.float64)
+    t_call = t_window * (call_ms / all_calls_ms) if all_calls_ms > 0 else t_window / max(len(n0), 1)
+    f_fwd = min(max(fwd_ms / call_ms, 0.0), 1.0) if call_ms > 0 else 0.0
+    f_nn = min(max((fwd_ms + rev_ms) / call_ms, f_fwd), 1.0) if call_ms > 0 else 0.0
+    w_nn = n0 * n1; w_nn = w_nn / w_nn.sum()
+    w_rest = np.asarray(n_ids, np.float64) * np.asarray(n_corr, np.float64) + 1.0; w_rest = w_rest / w_rest.sum()
+    whole = t_call * (f_nn * w_nn + (1.0 - f_nn) * w_rest)
+    billed = whole - t_call * f_fwd * w_nn * (1.0 - share)
+    return whole, np.maximum(billed, 0.0)
+
+
 def stats_columns(serial):
     """What the 22 columns of raw_stats.npy hold (layout of the reference's Experiments/test.py:96-100), written next to the file: the
     time columns of the batched engine are per-pair SHARES of a window, not per-pair measurements."""
     t = ("measured per pair (device events of the call, billed as FR.py:117)" if serial else
-         "ESTIMATE, identical for all rows of a window: registration wall time of the window / its pairs x the part FR.py:117 bills; depends on "
-         "--batch / --in_flight; run with --serial True for per-pair measurements comparable with the reference's column")
+         "ATTRIBUTED, not measured: the registration wall time of a window of batched calls, split over its calls by their device time (library events) and "
+         "over a call's pairs by n0 x n1 (NN stages) and hypothesis ids examined x correspondences (the rest), minus the first neighbour's part of the forward NN "
+         "(FR.py:117); the rows of a window add up to its wall time; depends on --batch / --in_flight; run with --serial True for per-pair measurements")
     names = ["success", "RE (deg)", "TE (cm)", "(unused here) input inlier number", "(unused) input inlier ratio", "(unused) output inlier number",
              "(unused) output inlier precision", "(unused) output inlier recall", "(unused) output inlier F1", "model_time / reg time (s): " + t,
              "data_time (s)" + ("" if serial else ": window share"), "icp_time (s)" + ("" if serial else ": window share"), "recall_icp", "RE_icp (deg)", "TE_icp (cm)",

@@ -264,3 +264,18 @@ def test_FR_hands_back_open3d_clouds_where_open3d_imports(monkeypatch):
     monkeypatch.setattr(fr, "_O3D", [])
     monkeypatch.setitem(sys.modules, "open3d", fake)
     assert isinstance(fr.make_open3d_point_cloud(xyz), FakeCloud) and fr._O3D == [fake]
+
+
+def test_window_time_is_attributed_by_work_not_flat():
+    """harness.attribute_window_time (batched CLI mode, stats column 9): a pair that examined 100x the hypothesis ids is billed more than
+    its neighbours, the pairs of a call add up to the call's part of the window, and the billed figure never exceeds the whole path."""
+    from lidarregistration_amd import harness
+    whole, billed = harness.attribute_window_time(t_window=0.012, call_ms=3.0, all_calls_ms=6.0, fwd_ms=1.8, rev_ms=0.3, share=0.1,
+                                                  n0=[30000, 30000, 10000], n1=[30000, 30000, 10000], n_ids=[1024, 102400, 1024], n_corr=[15000, 15000, 4000])
+    assert abs(whole.sum() - 0.006) < 1e-12                       # this call's device time is half of the window's
+    assert whole[1] > whole[0] > whole[2] and (billed <= whole).all() and (billed >= 0).all()
+    assert abs((whole[0] - billed[0]) - 0.006 * 0.6 * (9 / 19) * 0.9) < 1e-12      # the first neighbour's part of pair 0's forward NN
+    same, _ = harness.attribute_window_time(0.01, 2.0, 2.0, 1.0, 0.2, 0.0, [5, 5], [7, 7], [10, 10], [3, 3])
+    assert np.allclose(same, 0.005)
+    w0, b0 = harness.attribute_window_time(0.01, 0.0, 0.0, 0.0, 0.0, 0.0, [5, 5], [7, 7], [0, 0], [0, 0])      # no events: a flat share
+    assert np.allclose(w0, 0.005 / 2 * 1.0) or np.allclose(w0.sum(), 0.005)
