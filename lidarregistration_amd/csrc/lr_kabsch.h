@@ -1,4 +1,4 @@
-// fp64 Kabsch through Horn's quaternion form + cyclic Jacobi, written with + - * / sqrt only and an explicit op order so
+// fp64 Kabsch through Horn's quaternion form (largest eigenvector in closed form; cyclic Jacobi for degenerate input), written with + - * / sqrt only and an explicit op order so
 // that the device result is bit-identical to oracle/oracle.c (both compiled with -ffp-contract=off).
 // Reference semantics: R = V diag(1,1,det) U^T, t = mu_B - R mu_A (Experiments/models/common.py:7-45).
 #pragma once
@@ -84,6 +84,68 @@ __device__ __forceinline__ void lr_jacobi4_maxvec(double A[4][4], double q[4])
     q[0] = w / nn; q[1] = x / nn; q[2] = y / nn; q[3] = z / nn;
 }
 
+// Largest-eigenvalue eigenvector in closed form: Newton on the characteristic polynomial from Gershgorin's bound + the adjugate column with the
+// largest diagonal cofactor (oracle/oracle.c, horn4_maxvec_newton: same text, same bits; derivation and accuracy there).  0: the caller runs
+// Jacobi (zero / non-finite matrix, or a double largest eigenvalue).
+__device__ __forceinline__ double lr_det3_(double a, double b, double c, double d, double e, double f, double g, double h, double i)
+{
+    return (a * (e * i - f * h) - b * (d * i - f * g)) + c * (d * h - e * g);
+}
+__device__ __forceinline__ int lr_horn4_maxvec_newton(const double N[4][4], double q[4])
+{
+    const double a = N[0][0], b = N[1][1], c = N[2][2], d = N[3][3];
+    const double n01 = N[0][1], n02 = N[0][2], n03 = N[0][3], n12 = N[1][2], n13 = N[1][3], n23 = N[2][3];
+    /* elementary symmetric functions of the eigenvalues: trace, principal 2x2 and 3x3 minors, determinant */
+    const double e1 = (a + b) + (c + d);
+    const double e2 = (((a * b - n01 * n01) + (a * c - n02 * n02)) + ((a * d - n03 * n03) + (b * c - n12 * n12))) + ((b * d - n13 * n13) + (c * d - n23 * n23));
+    const double m0 = lr_det3_(b, n12, n13, n12, c, n23, n13, n23, d);      /* without row / column 0 */
+    const double m1 = lr_det3_(a, n02, n03, n02, c, n23, n03, n23, d);
+    const double m2 = lr_det3_(a, n01, n03, n01, b, n13, n03, n13, d);
+    const double m3 = lr_det3_(a, n01, n02, n01, b, n12, n02, n12, c);
+    const double e3 = (m0 + m1) + (m2 + m3);
+    /* det N by the first row */
+    const double k1 = lr_det3_(n01, n12, n13, n02, c, n23, n03, n23, d);
+    const double k2 = lr_det3_(n01, b, n13, n02, n12, n23, n03, n13, d);
+    const double k3 = lr_det3_(n01, b, n12, n02, n12, c, n03, n13, n23);
+    const double e4 = ((a * m0 - n01 * k1) + n02 * k2) - n03 * k3;
+    /* Gershgorin: an upper bound of the largest eigenvalue */
+    const double r0 = ((a + fabs(n01)) + fabs(n02)) + fabs(n03), r1 = ((b + fabs(n01)) + fabs(n12)) + fabs(n13);
+    const double r2 = ((c + fabs(n02)) + fabs(n12)) + fabs(n23), r3 = ((d + fabs(n03)) + fabs(n13)) + fabs(n23);
+    double lam = r0 > r1 ? r0 : r1; { const double r = r2 > r3 ? r2 : r3; lam = lam > r ? lam : r; }
+    const double bound = lam;
+    if (!(bound > 0.0 && bound < 1.0e150)) return 0;
+    int it = 0;
+    for (; it < 64; ++it) {
+        const double p = (((lam - e1) * lam + e2) * lam - e3) * lam + e4;
+        const double dp = ((4.0 * lam - 3.0 * e1) * lam + 2.0 * e2) * lam - e3;
+        if (!(dp > 0.0)) break;
+        const double nl = lam - p / dp;
+        if (!(nl < lam)) break;
+        lam = nl;
+    }
+    /* B = N - lam I; its adjugate is (a multiple of) v v^T */
+    const double A = a - lam, B = b - lam, C = c - lam, D = d - lam;
+    const double c00 = lr_det3_(B, n12, n13, n12, C, n23, n13, n23, D);
+    const double c11 = lr_det3_(A, n02, n03, n02, C, n23, n03, n23, D);
+    const double c22 = lr_det3_(A, n01, n03, n01, B, n13, n03, n13, D);
+    const double c33 = lr_det3_(A, n01, n02, n01, B, n12, n02, n12, C);
+    const double c01 = -lr_det3_(n01, n12, n13, n02, C, n23, n03, n23, D);
+    const double c02 = lr_det3_(n01, B, n13, n02, n12, n23, n03, n13, D);
+    const double c03 = -lr_det3_(n01, B, n12, n02, n12, C, n03, n13, n23);
+    const double c12 = -lr_det3_(A, n01, n03, n02, n12, n23, n03, n13, D);
+    const double c13 = lr_det3_(A, n01, n02, n02, n12, C, n03, n13, n23);
+    const double c23 = -lr_det3_(A, n01, n02, n01, B, n12, n03, n13, n23);
+    double w = c00, x = c01, y = c02, z = c03, best = fabs(c00);
+    if (fabs(c11) > best) { best = fabs(c11); w = c01; x = c11; y = c12; z = c13; }
+    if (fabs(c22) > best) { best = fabs(c22); w = c02; x = c12; y = c22; z = c23; }
+    if (fabs(c33) > best) { best = fabs(c33); w = c03; x = c13; y = c23; z = c33; }
+    if (!(best > 1.0e-6 * ((bound * bound) * bound))) return 0;
+    const double nn = sqrt(((w * w + x * x) + y * y) + z * z);
+    if (!(nn > 0.0)) return 0;
+    q[0] = w / nn; q[1] = x / nn; q[2] = y / nn; q[3] = z / nn;
+    return 1;
+}
+
 // H[a][b] = sum (p-cp)_a (q-cq)_b  ->  T (row-major 4x4, q ~ R p + t)
 __device__ __forceinline__ void lr_rt_from_cov(const double H[3][3], const double cp[3], const double cq[3], double T[16])
 {
@@ -96,7 +158,7 @@ __device__ __forceinline__ void lr_rt_from_cov(const double H[3][3], const doubl
     N[2][0] = N[0][2];           N[2][1] = N[1][2];           N[2][2] = (Syy - Sxx) - Szz; N[2][3] = Syz + Szy;
     N[3][0] = N[0][3];           N[3][1] = N[1][3];           N[3][2] = N[2][3];           N[3][3] = (Szz - Sxx) - Syy;
     double q[4];
-    lr_jacobi4_maxvec(N, q);
+    if (!lr_horn4_maxvec_newton(N, q)) lr_jacobi4_maxvec(N, q);
     double w = q[0], x = q[1], y = q[2], z = q[3];
     double R[3][3];
     R[0][0] = 1.0 - 2.0 * (y * y + z * z); R[0][1] = 2.0 * (x * y - w * z);       R[0][2] = 2.0 * (x * z + w * y);

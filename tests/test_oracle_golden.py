@@ -101,6 +101,54 @@ def test_g7_kabsch(oracle, k):
     np.testing.assert_allclose(T[:3, :3] @ T[:3, :3].T, np.eye(3), atol=1e-12)
 
 
+def test_kabsch_closed_form_eigenvector_against_numpy_svd(oracle):
+    """Round 6: Horn's largest eigenvector comes from Newton's iteration on the characteristic polynomial + an adjugate column (oracle.c
+    horn4_maxvec_newton, the same text as csrc/lr_kabsch.h) instead of 36-48 dependent Jacobi rotations.  Against the SVD solution of
+    models/common.py:7-45 / DGR/util/procrustes.py:34-56 in float64 (numpy): 1e-12 on well-conditioned sets of every size the path uses
+    (3- and 4-point samples, the local optimisation's 21, thousands for the refit), reflections resolved the same way, and sane answers
+    (a proper rotation, the least-squares residual of the SVD solution) where the points are collinear or coincide -- the Jacobi fallback."""
+    rng = np.random.default_rng(66)
+
+    def svd_kabsch(P, Q):
+        cp, cq = P.mean(0), Q.mean(0)
+        H = (P - cp).T @ (Q - cq)
+        U, S, Vt = np.linalg.svd(H)
+        D = np.diag([1.0, 1.0, np.sign(np.linalg.det(Vt.T @ U.T))])
+        R = Vt.T @ D @ U.T
+        T = np.eye(4); T[:3, :3] = R; T[:3, 3] = cq - R @ cp
+        return T
+
+    def rand_rot():
+        q = rng.normal(size=4); q /= np.linalg.norm(q); w, x, y, z = q
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                         [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+    worst = 0.0
+    for n in (3, 4, 21, 500, 20000):
+        for rep in range(300 if n < 100 else 6):
+            P = rng.uniform(-60, 60, size=(n, 3))
+            if n == 3:      # keep the triangle away from collinear: its conditioning is what the tolerance below assumes
+                while np.linalg.norm(np.cross(P[1] - P[0], P[2] - P[0])) < 0.2 * np.linalg.norm(P[1] - P[0]) * np.linalg.norm(P[2] - P[0]):
+                    P = rng.uniform(-60, 60, size=(n, 3))
+            Q = P @ rand_rot().T + rng.uniform(-20, 20, size=3) + rng.normal(scale=0.05, size=(n, 3))
+            T = oracle.kabsch(P, Q)
+            E = svd_kabsch(P, Q)
+            worst = max(worst, np.abs(T - E).max())
+            assert abs(np.linalg.det(T[:3, :3]) - 1) < 1e-12
+    assert worst < 1e-10, worst
+    # a reflection between the clouds: the optimal PROPER rotation (diag(1, 1, det) in the SVD form, inherent in the quaternion form)
+    P = rng.uniform(-10, 10, size=(50, 3)); Q = P * np.array([1.0, 1.0, -1.0])
+    np.testing.assert_allclose(oracle.kabsch(P, Q), svd_kabsch(P, Q), atol=1e-10)
+    # degenerate inputs: collinear points (rotation about the line is free: compare residuals, not matrices), coincident points
+    t = rng.uniform(-30, 30, size=(12, 1)); P = t * np.array([[0.3, -0.5, 0.8]]) + 5.0
+    Q = P @ rand_rot().T + 1.0
+    T = oracle.kabsch(P, Q)
+    assert np.isfinite(T).all() and abs(np.linalg.det(T[:3, :3]) - 1) < 1e-9
+    assert np.abs(P @ T[:3, :3].T + T[:3, 3] - Q).max() < 1e-8
+    T = oracle.kabsch(np.ones((5, 3)), np.ones((5, 3)) * 2.0)
+    assert np.isfinite(T).all() and abs(np.linalg.det(T[:3, :3]) - 1) < 1e-9 and np.allclose(T[:3, :3] @ np.ones(3) + T[:3, 3], 2.0)
+
+
 def test_g8_metric(oracle):
     g = golden("g8_metric.npz")
     for T, Tg, rec, re, te in zip(g["T"], g["T_gt"], g["recall"], g["RE"], g["TE"]):
