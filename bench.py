@@ -174,7 +174,8 @@ def cpu_baseline(args, seed0):
     # ---- the reference's own sharding on host cores (test_parallel.sh:18-20: one OS process per shard of the pair list): P processes of the
     #      same path, each with `best_threads` threads, started together (oracle/cpu_worker.py); the honest "reference path on this box's
     #      host cores" -- one process at its best thread count leaves most of a 128-thread host idle
-    cores = os.cpu_count() or max_threads
+    avail = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or max_threads))
+    cores = len(avail)          # the hardware threads this process may run on (os.cpu_count() also counts those outside the cgroup's cpuset)
     nproc = args.cpu_procs if args.cpu_procs > 0 else max(1, min(8, cores // max(1, best_threads)))
     pp = None
     if nproc > 1:
@@ -182,19 +183,33 @@ def cpu_baseline(args, seed0):
         env = dict(os.environ, OMP_NUM_THREADS=str(best_threads), MKL_NUM_THREADS=str(best_threads), HIP_VISIBLE_DEVICES="", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
         if nproc * best_threads > cores:      # (oversubscribed on request: spinning thread pools then cost an order of magnitude; measured 1.2 against 21 pairs/s)
             env.update(OMP_WAIT_POLICY="passive", GOMP_SPINCOUNT="0", KMP_BLOCKTIME="0")
-        procs = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_worker", str(best_threads), str(args.n), args.mode, str(args.iters), str(per), str(seed0 + 1000 * (w + 1))],
+        # every worker on its own cores (what numactl / a job scheduler would do): unpinned, the workers' spinning thread pools land on the same
+        # cores and the leg runs 3.5x SLOWER than one process (measured on the round's first box: 0.45 against 1.55 pairs/s)
+        pin = nproc * best_threads <= cores
+        procs = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_worker", str(best_threads), str(args.n), args.mode, str(args.iters), str(per), str(seed0 + 1000 * (w + 1)),
+                                   ",".join(str(c) for c in avail[w * best_threads:(w + 1) * best_threads]) if pin else "-"],
                                   stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, env=env, cwd=ROOT) for w in range(nproc)]
         try:
-            ready = all(p.stdout.readline().strip() == "READY" for p in procs)
+            import select
+            def line_of(p, deadline):
+                while time.perf_counter() < deadline:
+                    if select.select([p.stdout], [], [], 0.5)[0]:
+                        return p.stdout.readline()
+                return ""
+            t_ready = time.perf_counter() + 240.0
+            ready = all(line_of(p, t_ready).strip() == "READY" for p in procs)
             if ready:
                 t1 = time.perf_counter()
                 for p in procs:
                     p.stdin.write("GO\n"); p.stdin.flush()
-                outs = [p.stdout.readline().split() for p in procs]
+                t_done = t1 + 90.0          # (bounded: a leg that takes longer than this says nothing useful and would hold the bench line back)
+                outs = [line_of(p, t_done).split() for p in procs]
                 wall = time.perf_counter() - t1
                 if all(len(o) == 3 and o[0] == "DONE" for o in outs):
-                    pp = {"value": round(nproc * per / wall, 4), "processes": nproc, "threads_per_process": int(best_threads), "pairs_per_process": per,
+                    pp = {"value": round(nproc * per / wall, 4), "processes": nproc, "threads_per_process": int(best_threads), "pairs_per_process": per, "pinned": bool(pin),
                           "wall_s": round(wall, 2), "slowest_worker_s": round(max(float(o[2]) for o in outs), 2)}
+                else:
+                    pp = {"value": None, "processes": nproc, "threads_per_process": int(best_threads), "note": "not finished within 90 s"}
         finally:
             for p in procs:
                 try:
@@ -202,11 +217,11 @@ def cpu_baseline(args, seed0):
                 except Exception:
                     pass
                 try:
-                    p.wait(timeout=30)
+                    p.wait(timeout=5)
                 except Exception:
                     p.kill()
     return {"value": round(done / t_reg, 4), "unit": "pairs/s", "cores": int(best_threads), "kind": "port",
-            "value_process_parallel": None if pp is None else pp["value"], "process_parallel": pp, "host_hardware_threads": int(cores),
+            "value_process_parallel": None if pp is None else pp.get("value"), "process_parallel": pp, "host_hardware_threads": int(cores),
             "torch_threads_sweep_s_per_nn_pass": {str(k): v for k, v in sweep.items()},
             "impl": "restatement of the reference's Python path: torch-CPU chunked einsum NN (nn_max_n=250, matching.py:22-65) x2 directions + "
                     "numpy mutual filter + OpenMP RANSAC/refit (oracle.c) -- oracle/torch_cpu.py",
@@ -367,8 +382,10 @@ def main():
             pairs.append((p["xyz0"], p["xyz1"], p["feats0"], p["feats1"])); T_gt.append(p["T_gt"])
         streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
         wss = [_ext.Workspace(args.n, args.n, 32, args.iters, max_pairs=B) for _ in range(nstreams)]
+        have_clock = hasattr(_ext.lib(), "lr_workspace_clock")      # (absent only from older builds loaded through LIDARREG_LIB for an A/B)
         for w in wss:      # the filter-pass blocks sum their shader cycles / 100 MHz ticks: the clock the timed steps really ran at (lr_workspace_clock)
-            w.set_option("clock_probe", 1)
+            if have_clock:
+                w.set_option("clock_probe", 1)
     outs = torch.zeros((args.pairs, res_bytes), dtype=torch.uint8, device=dev)
     rows = torch.zeros((args.pairs, shard.ROW), dtype=torch.float64, device=dev)
     gathered = torch.zeros((world * args.pairs, shard.ROW), dtype=torch.float64, device="cpu" if host_coll else dev) if use_dist else None
@@ -429,7 +446,8 @@ def main():
     enq[0] = 0.0
     if not dry:
         for w in wss:
-            w.clock(reset=True)
+            if have_clock:
+                w.clock(reset=True)
         del step_events[:]
         ev0 = torch.cuda.Event(enable_timing=True); ev0.record(); step_events.append(ev0)
     t0 = time.perf_counter()
@@ -442,6 +460,8 @@ def main():
     if not dry:
         cyc = tk = 0
         for w in wss:
+            if not have_clock:
+                break
             _, c, t = w.clock(reset=True)
             cyc += c; tk += t
             w.set_option("clock_probe", 0)

@@ -427,7 +427,7 @@ nn16_passb_kernel(lr_pb_fuse fz_first /* read at the end only, through lr_pb_tai
     if (tile_min) {
         // Ordered reverse pass (lr_nn16_reverse): a column can only win a row if its key (a lower bound of its distance to every row
         // it does not point at) is <= the row's bound.  Rows lie by descending bucket of their bound, columns by ascending bucket of
-        // their key (one monotone map, nn16_rev_scan / _scatter), so the block's FIRST row has its largest bucket b and the columns
+        // their key (one monotone map, nn16_rev_order_kernel), so the block's FIRST row has its largest bucket b and the columns
         // that can matter to the block are the first offs[b + 1] of the order (the end of bucket b): three
         // dependent loads by one thread instead of 256 bounds + all tile minima reduced by the block -- most of the (row block, strip)
         // blocks of this launch only find out here that they are not needed.
@@ -1413,108 +1413,99 @@ nn16_rev_seed_kernel(const float *__restrict__ F0, const float *__restrict__ n0v
     }
 }
 
-// counting sort, passes 1 + 2 in one block: bucket histograms in LDS (cloud-0 points keyed by s1, ascending; cloud-1
-// points with a seed keyed by s*, descending), exclusive prefix sums -> offs[2][LR_RS_BUCKETS]; the row total is the
-// length of the reverse pass
+// The ordering of the reverse pass in ONE launch (round 6; rounds 2-5: histogram + scan in a one-block kernel, ranks in a second, the
+// permuted f16 copy in a third -- 15 + 39 + 41 us per call of 32 pairs and two dependent launch boundaries between the forward result
+// and the reverse walk).  A counting sort on LR_RS_BUCKETS linear buckets per side: cloud-0 points (the columns) by ascending key, cloud-1
+// points with a seed (the rows) by descending seed.  `parts` blocks per pair (a power of two), and NO exchange between them:
+//   1. every block builds the histograms of ALL keys of its pair in LDS and scans them (redundantly: 4 bytes per key from L2; what the
+//      one-block kernel did in 15 us, now without a launch of its own); part 0 writes the offsets the filter pass reads (bucket b ends
+//      where bucket b + 1 starts) and the row count;
+//   2. a block OWNS the buckets whose first position falls into its share [part, part + 1) n / parts of the order -- a contiguous range
+//      per side, found from the block's own offsets;
+//   3. it walks all keys again, 2048 per round: the rank of an owned element inside its bucket is an LDS atomic (any order inside a
+//      bucket is valid); owned cloud-0 elements are queued as (point, position) in LDS and then moved by FOUR threads per row -- the f16
+//      row (64 B) to its position in the permuted copy the reverse walk streams, with colmap and the norm: full lanes and whole 64-byte
+//      segments, where a thread that ranks and copies its own element had 1 lane in 8 at work; owned cloud-1 elements get their position
+//      in the row list and their threshold at once (4 + 4 bytes).
+// Rows nobody points at get rev = -1; the segment counters of the reverse filter pass start from zero (row blocks that use fewer strips
+// than offered leave the others untouched).
+#define LR_RO_ROUND 2048         // keys per round = capacity of the copy queue (1024 threads x 2 keys; 48 KB of LDS with the bucket counters)
 __global__ void __launch_bounds__(1024)
-nn16_rev_scan_kernel(int n0, int n1, const float *__restrict__ s1, const uint32_t *__restrict__ seed_bits,
-                     const uint32_t *__restrict__ range, int32_t *__restrict__ offs, int32_t *__restrict__ n_rows,
-                     uint32_t *__restrict__ tile_min_bits, lr_zargs z)
+nn16_rev_order_kernel(int n0, int n1, const float *__restrict__ s1, const uint32_t *__restrict__ seed_bits, const uint32_t *__restrict__ range,
+                      int32_t *__restrict__ offs, int32_t *__restrict__ n_rows, const float *__restrict__ block_max_c, int nblk_c,
+                      const float *__restrict__ nrm1, const _Float16 *__restrict__ H0, const float *__restrict__ nrm0, int32_t *__restrict__ colmap,
+                      _Float16 *__restrict__ H0s, float *__restrict__ nrm0s, int32_t *__restrict__ rowmap, float *__restrict__ tau,
+                      int32_t *__restrict__ cand_cnt, int32_t *__restrict__ rev_out, int seg_counters, lr_zargs z)
 {
-    __shared__ int s_h[2 * LR_RS_BUCKETS];
-    if (z.descs) { n0 = z.descs[blockIdx.z].n0; n1 = z.descs[blockIdx.z].n1; }
-    lr_z(s1, z, blockIdx.z); lr_z(seed_bits, z, blockIdx.z); lr_z(range, z, blockIdx.z); lr_z(offs, z, blockIdx.z); lr_z(n_rows, z, blockIdx.z);
-    lr_z(tile_min_bits, z, blockIdx.z);
-    __shared__ int s_w[16];
-    const float lo = __uint_as_float(range[0]), scale = rs_scale(lo, __uint_as_float(range[1]));
-    for (int k = threadIdx.x; k < 2 * LR_RS_BUCKETS; k += 1024) s_h[k] = 0;
-    __syncthreads();
-    // eight independent loads in flight per thread (a single block: the loop is bound by load latency, not by the atomics)
-    for (int i0 = threadIdx.x; i0 < n0; i0 += 8 * 1024) {
-        float v[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { const int i = i0 + 1024 * k; v[k] = s1[min(i, n0 - 1)]; }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) if (i0 + 1024 * k < n0) atomicAdd(&s_h[rs_bucket(v[k], lo, scale)], 1);
-    }
-    for (int j0 = threadIdx.x; j0 < n1; j0 += 8 * 1024) {
-        uint32_t v[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { const int j = j0 + 1024 * k; v[k] = seed_bits[min(j, n1 - 1)]; }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float sv = __uint_as_float(v[k]);
-            if (j0 + 1024 * k < n1 && sv <= 3.0e38f) atomicAdd(&s_h[LR_RS_BUCKETS + (LR_RS_BUCKETS - 1 - rs_bucket(sv, lo, scale))], 1);
-        }
-    }
-    __syncthreads();
-    for (int side = 0; side < 2; ++side) {
-        int *hp = s_h + side * LR_RS_BUCKETS;
-        int v[LR_RS_BUCKETS / 1024], sum = 0;
-#pragma unroll
-        for (int k = 0; k < LR_RS_BUCKETS / 1024; ++k) { v[k] = hp[threadIdx.x * (LR_RS_BUCKETS / 1024) + k]; sum += v[k]; }
-        int inc = sum;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if ((int)(threadIdx.x & 63) >= d) inc += o; }
-        if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = inc;
-        __syncthreads();
-        int base = 0;
-        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += s_w[w];
-        int run = base + inc - sum;
-#pragma unroll
-        for (int k = 0; k < LR_RS_BUCKETS / 1024; ++k) { offs[side * LR_RS_BUCKETS + threadIdx.x * (LR_RS_BUCKETS / 1024) + k] = run; run += v[k]; }
-        if (side == 1 && threadIdx.x == 1023) *n_rows = run;
-        __syncthreads();
-    }
-}
-
-// pass 3: ranks.  Cloud-0 points: position in ascending-key order -> pos0 (nn16_rev_copy_kernel moves the f16 rows there).  Cloud-1
-// points with a seed: position in descending-s* order -> rowmap, threshold and empty candidate list at that position; the others get
-// rev = -1.
-// Several blocks per pair (8 in a full batch, up to 32 for a single pair: lr_nn16_reverse): every block reads ALL keys (cheap: 4 bytes each) and owns the buckets whose first position falls into
-// its share of the order; the rank of an element inside its bucket is an LDS atomic of the one block that owns the bucket.  (Round 2-3
-// took the ranks with one device-scope atomic per element on the bucket offsets and copied the row in the same thread: 60 000
-// returning atomics per pair, 3.7 us per pair -- 0.5 TB/s for a kernel that only moves 4 MB.)  The offsets stay what the scan
-// wrote: bucket b ends where bucket b + 1 starts.
-__global__ void __launch_bounds__(1024)
-nn16_rev_rank_kernel(int n0, int n1, const float *__restrict__ s1, const uint32_t *__restrict__ seed_bits,
-                     const uint32_t *__restrict__ range, const int32_t *__restrict__ offs, const int32_t *__restrict__ n_rows,
-                     const float *__restrict__ block_max_c, int nblk_c, const float *__restrict__ nrm1, int32_t *__restrict__ pos0,
-                     int32_t *__restrict__ rowmap, float *__restrict__ tau, int32_t *__restrict__ cand_cnt, int32_t *__restrict__ rev_out,
-                     int seg_counters, lr_zargs z)
-{
+    __shared__ int s_pos[2 * LR_RS_BUCKETS];     // histograms, then offsets, then the next free position of every bucket
+    __shared__ int2 s_q[LR_RO_ROUND];            // copy queue of the round: (cloud-0 point, its position)
     __shared__ float s_m[16];
-    // next free position of every bucket, starting from the scan's offsets.  Every key of the pair looks its bucket up in every block:
-    // from global memory that is 64 different cache lines per wave instruction (most of the kernel's time when it was tried)
-    __shared__ int s_pos[2 * LR_RS_BUCKETS];
-    __shared__ int s_own[4];                     // the block's bucket ranges [lo, hi) of the two sides
+    __shared__ int s_w[16], s_own[4], s_nq, s_nrows;
     if (z.descs) { n0 = z.descs[blockIdx.z].n0; n1 = z.descs[blockIdx.z].n1; nblk_c = (n0 + 31) >> 5; }
     lr_z(s1, z, blockIdx.z); lr_z(seed_bits, z, blockIdx.z); lr_z(range, z, blockIdx.z); lr_z(offs, z, blockIdx.z); lr_z(n_rows, z, blockIdx.z);
-    lr_z(block_max_c, z, blockIdx.z); lr_z(nrm1, z, blockIdx.z); lr_z(pos0, z, blockIdx.z); lr_z(rowmap, z, blockIdx.z); lr_z(tau, z, blockIdx.z);
-    lr_z(cand_cnt, z, blockIdx.z); lr_z(rev_out, z, blockIdx.z);
-    const int tid = threadIdx.x, lane = tid & 63, part = blockIdx.x, parts = gridDim.x;      // (parts: a power of two)
-    // the segment counters of the reverse pass B start from zero (row blocks that use fewer strips than offered leave the
-    // others untouched)
+    lr_z(block_max_c, z, blockIdx.z); lr_z(nrm1, z, blockIdx.z); lr_z(H0, z, blockIdx.z); lr_z(nrm0, z, blockIdx.z); lr_z(colmap, z, blockIdx.z);
+    lr_z(H0s, z, blockIdx.z); lr_z(nrm0s, z, blockIdx.z); lr_z(rowmap, z, blockIdx.z); lr_z(tau, z, blockIdx.z); lr_z(cand_cnt, z, blockIdx.z); lr_z(rev_out, z, blockIdx.z);
+    const int tid = threadIdx.x, lane = tid & 63, part = blockIdx.x, parts = gridDim.x;
     for (int k = part * 1024 + tid; k < seg_counters; k += parts * 1024) cand_cnt[k] = 0;
+    const float lo = __uint_as_float(range[0]), scale = rs_scale(lo, __uint_as_float(range[1]));
+    for (int k = tid; k < 2 * LR_RS_BUCKETS; k += 1024) s_pos[k] = 0;
     if (tid < 4) s_own[tid] = (tid & 1) ? 0 : 0x7fffffff;
+    if (tid == 0) s_nq = 0;
+    // largest norm of cloud 0 (the columns): part of the rows' thresholds
     float mx = 0.0f;
     for (int b = tid; b < nblk_c; b += 1024) mx = fmaxf(mx, block_max_c[b]);
 #pragma unroll
     for (int k = 32; k >= 1; k >>= 1) mx = fmaxf(mx, __shfl_xor(mx, k));
     if (lane == 0) s_m[tid >> 6] = mx;
     __syncthreads();
-    float max_nc = 0.0f;                                        // largest norm of cloud 0 (the columns)
+    float max_nc = 0.0f;
 #pragma unroll
     for (int w = 0; w < 16; ++w) max_nc = fmaxf(max_nc, s_m[w]);
-    const float lo = __uint_as_float(range[0]), scale = rs_scale(lo, __uint_as_float(range[1]));
-    // the part that owns a bucket: the one whose share [part, part + 1) * n / parts of the order holds the bucket's first position -- a
-    // contiguous range of buckets per side, found here once (products compared, no division), so that the loops below only compare
-    // a key's bucket with the range
-    for (int k = tid; k < 2 * LR_RS_BUCKETS; k += 1024) s_pos[k] = offs[k];
+    // ---- 1. histograms of both sides (eight independent loads in flight per thread: the loop is bound by load latency, not by the atomics)
+    for (int i0 = tid; i0 < n0; i0 += 8 * 1024) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = s1[min(i0 + 1024 * k, n0 - 1)];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (i0 + 1024 * k < n0) atomicAdd(&s_pos[rs_bucket(v[k], lo, scale)], 1);
+    }
+    for (int j0 = tid; j0 < n1; j0 += 8 * 1024) {
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = seed_bits[min(j0 + 1024 * k, n1 - 1)];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float sv = __uint_as_float(v[k]);
+            if (j0 + 1024 * k < n1 && sv <= 3.0e38f) atomicAdd(&s_pos[LR_RS_BUCKETS + (LR_RS_BUCKETS - 1 - rs_bucket(sv, lo, scale))], 1);
+        }
+    }
     __syncthreads();
+    // exclusive prefix sums, in place; part 0 publishes them
+    for (int side = 0; side < 2; ++side) {
+        int *hp = s_pos + side * LR_RS_BUCKETS;
+        int v[LR_RS_BUCKETS / 1024], sum = 0;
+#pragma unroll
+        for (int k = 0; k < LR_RS_BUCKETS / 1024; ++k) { v[k] = hp[tid * (LR_RS_BUCKETS / 1024) + k]; sum += v[k]; }
+        int inc = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+        if (lane == 63) s_w[tid >> 6] = inc;
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < (tid >> 6); ++w) base += s_w[w];
+        int run = base + inc - sum;
+#pragma unroll
+        for (int k = 0; k < LR_RS_BUCKETS / 1024; ++k) {
+            hp[tid * (LR_RS_BUCKETS / 1024) + k] = run;
+            if (part == 0) offs[side * LR_RS_BUCKETS + tid * (LR_RS_BUCKETS / 1024) + k] = run;
+            run += v[k];
+        }
+        if (side == 1 && tid == 1023) { s_nrows = run; if (part == 0) *n_rows = run; }
+        __syncthreads();
+    }
+    // ---- 2. the buckets this block owns (contiguous per side: the two threads that sit on a range's ends write them -- no atomics)
     {
-        // (the owned buckets of a side are contiguous: the two threads that sit on the range's ends write them -- no atomics)
-        const long long nrows = *n_rows;
+        const long long nrows = s_nrows;
         for (int k = tid; k < 2 * LR_RS_BUCKETS; k += 1024) {
             const int side = k >= LR_RS_BUCKETS, kb = k & (LR_RS_BUCKETS - 1);
             const long long n = side ? nrows : (long long)n0, lo_p = (long long)part * n, hi_p = (long long)(part + 1) * n;
@@ -1527,26 +1518,37 @@ nn16_rev_rank_kernel(int n0, int n1, const float *__restrict__ s1, const uint32_
     }
     __syncthreads();
     const int c_lo = s_own[0], c_len = max(s_own[1] - s_own[0], 0), r_lo = s_own[2], r_len = max(s_own[3] - s_own[2], 0);
-    // cloud 0, then cloud 1: sixteen keys in flight per thread.  (What the kernel costs is the number of its sparsely populated memory
-    // instructions: every block walks all keys and stores under the ownership mask.  Measured for a single pair, 32 blocks: 17 us, of which
-    // 7.5 before the loops; neither requesting the keys at the top of the kernel nor dropping the LDS atomics changes that.)
-    constexpr int U = 16;
-    for (int i0 = tid; i0 < n0; i0 += U * 1024) {
+    // ---- 3a. cloud 0: rank, queue, move (rounds of LR_RO_ROUND keys; every thread runs every round: the barriers are uniform)
+    constexpr int U = LR_RO_ROUND / 1024;
+    for (int i0 = 0; i0 < n0; i0 += LR_RO_ROUND) {
         float v[U];
 #pragma unroll
-        for (int k = 0; k < U; ++k) v[k] = s1[min(i0 + 1024 * k, n0 - 1)];
+        for (int k = 0; k < U; ++k) v[k] = s1[min(i0 + tid + 1024 * k, n0 - 1)];
 #pragma unroll
         for (int k = 0; k < U; ++k) {
-            const int b = rs_bucket(v[k], lo, scale);
-            if (i0 + 1024 * k < n0 && (unsigned)(b - c_lo) < (unsigned)c_len) pos0[i0 + 1024 * k] = atomicAdd(&s_pos[b], 1);
+            const int i = i0 + tid + 1024 * k, b = rs_bucket(v[k], lo, scale);
+            if (i < n0 && (unsigned)(b - c_lo) < (unsigned)c_len) s_q[atomicAdd(&s_nq, 1)] = make_int2(i, atomicAdd(&s_pos[b], 1));
         }
+        __syncthreads();
+        const int nq = s_nq;
+        __syncthreads();                 // (everybody has read the count before it is reset for the next round)
+        if (tid == 0) s_nq = 0;
+        for (int e = tid >> 2; e < nq; e += 256) {
+            const int2 ip = s_q[e];
+            const int piece = tid & 3;
+            reinterpret_cast<f32x4 *>(H0s + (size_t)ip.y * 32)[piece] = reinterpret_cast<const f32x4 *>(H0 + (size_t)ip.x * 32)[piece];
+            if (piece == 0) { colmap[ip.y] = ip.x; nrm0s[ip.y] = nrm0[ip.x]; }
+        }
+        __syncthreads();                 // (the queue is consumed and the reset visible before the next round pushes)
     }
-    for (int j0 = tid; j0 < n1; j0 += U * 1024) {
-        uint32_t v[U];
+    // ---- 3b. cloud 1: position in the row list + threshold, sixteen keys in flight per thread
+    constexpr int U1 = 16;
+    for (int j0 = tid; j0 < n1; j0 += U1 * 1024) {
+        uint32_t v[U1];
 #pragma unroll
-        for (int k = 0; k < U; ++k) v[k] = seed_bits[min(j0 + 1024 * k, n1 - 1)];
+        for (int k = 0; k < U1; ++k) v[k] = seed_bits[min(j0 + 1024 * k, n1 - 1)];
 #pragma unroll
-        for (int k = 0; k < U; ++k) {
+        for (int k = 0; k < U1; ++k) {
             const int row = j0 + 1024 * k;
             if (row >= n1) continue;
             const float sv = __uint_as_float(v[k]);
@@ -1564,21 +1566,6 @@ nn16_rev_rank_kernel(int n0, int n1, const float *__restrict__ s1, const uint32_
             tau[p] = (d2hi - nj) + E + 6e-6f * scl + 2e-6f * d2hi;
         }
     }
-}
-
-// pass 4: the f16 rows and norms of cloud 0 -> their positions (pass B streams the permuted copy, no indirection in its loop).  Four
-// threads per row, 16 bytes each: coalesced reads, whole 64-byte segments written.
-__global__ void __launch_bounds__(256)
-nn16_rev_copy_kernel(int n0, const int32_t *__restrict__ pos0, const _Float16 *__restrict__ H0, const float *__restrict__ nrm0,
-                     int32_t *__restrict__ colmap, _Float16 *__restrict__ H0s, float *__restrict__ nrm0s, lr_zargs z)
-{
-    if (z.descs) n0 = z.descs[blockIdx.z].n0;
-    lr_z(pos0, z, blockIdx.z); lr_z(H0, z, blockIdx.z); lr_z(nrm0, z, blockIdx.z); lr_z(colmap, z, blockIdx.z); lr_z(H0s, z, blockIdx.z); lr_z(nrm0s, z, blockIdx.z);
-    const int t = blockIdx.x * 256 + threadIdx.x, i = t >> 2, piece = t & 3;
-    if (i >= n0) return;
-    const int p = pos0[i];
-    reinterpret_cast<f32x4 *>(H0s + (size_t)p * 32)[piece] = reinterpret_cast<const f32x4 *>(H0 + (size_t)i * 32)[piece];
-    if (piece == 0) { colmap[p] = i; nrm0s[p] = nrm0[i]; }
 }
 
 int lr_nn16_reverse(lr_workspace *ws, const float *F0, const _Float16 *H0, const float *nrm0, const float *bmax0, int n0,
@@ -1602,17 +1589,12 @@ int lr_nn16_reverse(lr_workspace *ws, const float *F0, const _Float16 *H0, const
     uint32_t *seed = ws->rev_seed;          // filled with 0x7f7f7f7f, and range reset to { 0x7f7f7f7f, 0 }, by the prep kernel of this pair
     uint32_t *range = reinterpret_cast<uint32_t *>(ws->counters + LR_CNT_RLO);
     int32_t *n_rows = ws->counters + LR_CNT_NREV;
-    uint32_t *tmin = reinterpret_cast<uint32_t *>(ws->rev_tmin);
     if (!seeded)     // (the forward pass of lr_register_pair seeds from its exact kernel: same values, one launch less)
         hipLaunchKernelGGL(nn16_rev_seed_kernel, dim3(lr_cdiv(n0, 256)), dim3(256), 0, st, F0, nrm0, n0, F1, nrm1, fwd_idx1, seed, ws->rev_s1, range);
-    hipLaunchKernelGGL(nn16_rev_scan_kernel, dim3(1, 1, ws->zP), dim3(1024), 0, st, n0, n1, (const float *)ws->rev_s1, (const uint32_t *)seed,
-                       (const uint32_t *)range, ws->rev_hist, n_rows, tmin, ws->z);
-    const int rank_parts = ws->zP >= 16 ? 8 : ws->zP >= 4 ? 16 : 32;      // (a power of two; few pairs: more, smaller shares)
-    hipLaunchKernelGGL(nn16_rev_rank_kernel, dim3(rank_parts, 1, ws->zP), dim3(1024), 0, st, n0, n1, (const float *)ws->rev_s1,
-                       (const uint32_t *)seed, (const uint32_t *)range, (const int32_t *)ws->rev_hist, (const int32_t *)n_rows, bmax0, lr_cdiv(nb, 32), nrm1,
-                       ws->rev_pos, ws->rev_rows, ws->tau, ws->cand_cnt, rev, row_blocks * 4 * (strips + 1), ws->z);
-    hipLaunchKernelGGL(nn16_rev_copy_kernel, dim3(lr_cdiv(4 * n0, 256), 1, ws->zP), dim3(256), 0, st, n0, (const int32_t *)ws->rev_pos, H0, nrm0,
-                       ws->rev_cols, ws->Hs, ws->nrms, ws->z);
+    const int order_parts = ws->zP >= 16 ? 8 : ws->zP >= 4 ? 16 : 32;      // (a power of two; few pairs: more, smaller shares)
+    hipLaunchKernelGGL(nn16_rev_order_kernel, dim3(order_parts, 1, ws->zP), dim3(1024), 0, st, n0, n1, (const float *)ws->rev_s1, (const uint32_t *)seed,
+                       (const uint32_t *)range, ws->rev_hist, n_rows, bmax0, lr_cdiv(nb, 32), nrm1, H0, nrm0, ws->rev_cols, ws->Hs, ws->nrms,
+                       ws->rev_rows, ws->tau, ws->cand_cnt, rev, row_blocks * 4 * (strips + 1), ws->z);
     // grids are sized for all rows; blocks past the compacted count (or past their row block's strips) leave at once.
     // The column-prefix pruning (flagged by a non-null tile_min) rests on the keys being true lower bounds: that holds when
     // the list comes from this library's own forward pass (`seeded`, lr_register_pair).  A caller-supplied list (lr_nn_to_mutual,

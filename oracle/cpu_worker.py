@@ -5,7 +5,7 @@ processes of the reference-style path (oracle/torch_cpu.py), each with its own t
 waits until all say READY (imports, thread pools and one small pair are untimed), sends GO to all at once and takes the wall time until
 the last one reports.
 
-    python -m oracle.cpu_worker <threads> <n_points> <mode> <iters> <pairs> <seed0>
+    python -m oracle.cpu_worker <threads> <n_points> <mode> <iters> <pairs> <seed0> [<cpu list "0,1,2" or "-">]
 """
 import sys
 import time
@@ -13,6 +13,9 @@ import time
 
 def main(argv):
     threads, n, mode, iters, pairs, seed0 = int(argv[0]), int(argv[1]), argv[2], int(argv[3]), int(argv[4]), int(argv[5])
+    if len(argv) > 6 and argv[6] != "-":          # this worker's own cores, before any thread pool exists
+        import os
+        os.sched_setaffinity(0, {int(c) for c in argv[6].split(",")})
     import torch
     torch.set_num_threads(threads)
     from lidarregistration_amd import synth

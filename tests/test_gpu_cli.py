@@ -66,7 +66,7 @@ def test_batched_engine_equals_the_pair_by_pair_path(cli, tmp_path, extra):
     a = cli.main(common + extra + ["--batch", "4", "--in_flight", "2"])
     _, ids_a, T_a, log_a = _outputs(tmp_path)
     cols = (sorted((tmp_path / "outputs").iterdir())[-1] / "raw_stats.columns.txt").read_text()
-    assert "9: model_time / reg time (s): ESTIMATE" in cols and "--serial True" in cols          # the batched engine's time columns are window shares, and the file says so
+    assert "9: model_time / reg time (s): ATTRIBUTED, not measured" in cols and "--serial True" in cols          # the batched engine's time columns are attributed shares of a window, and the file says so
     b = cli.main(common + extra + ["--serial", "True"])
     _, ids_b, T_b, _ = _outputs(tmp_path)
     assert "9: model_time / reg time (s): measured per pair" in (sorted((tmp_path / "outputs").iterdir())[-1] / "raw_stats.columns.txt").read_text()
