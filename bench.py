@@ -68,6 +68,11 @@ def parse(argv=None):
                          "--mode GPF --iters 50000; B = NuScenes-Boston, 2592 rows, --mode MMN --iters 1000000 --GC_conf 0.9995 (README.md:54-55; "
                          "codebase GC defaults).  Prints its own JSON line (recall, pairs/s, whole-path and reference-style time per pair)")
     ap.add_argument("--list-stride", type=int, default=1, help="with --list: every k-th row only")
+    ap.add_argument("--extra-list", choices=["A", "B", "none"], default="A",
+                    help="the default run (N = 1, headline workload) also registers every --extra-list-stride-th row of this balanced test list with the reference's "
+                         "README command (configs[2] / [3], list-driven surrogate) after everything else and reports it under `extra.list_<X>`: a driver-run "
+                         "record of a list workload next to the headline (outside `value`)")
+    ap.add_argument("--extra-list-stride", type=int, default=8)
     ap.add_argument("--hard", type=int, default=1, help="with --list: also run the rows under the HARD surrogate settings (harness.HARD: a fraction of the listed overlap, "
                                                         "noisier descriptors / coordinates; recall near 90 %%) and report that recall next to the plain one (0: skip)")
     ap.add_argument("--traffic-key", action="store_true", help="print the key this command's PMC traffic is filed under in profiles/pmc_traffic.json and exit (tools/pmc_traffic.sh)")
@@ -179,7 +184,7 @@ def cpu_baseline(args, seed0):
     nproc = args.cpu_procs if args.cpu_procs > 0 else max(1, min(8, cores // max(1, best_threads)))
     pp = None
     if nproc > 1:
-        per = max(2, min(4, int(round(12.0 * done / max(t_reg, 1e-9)))))          # pairs per worker: about 12 s of work each at the single-process rate
+        per = 2          # pairs per worker (measured on the pool's 2 x 64-core hosts: eight 16-thread workers side by side take ~13 s per pair each -- the chunked einsum NN is memory-bound)
         env = dict(os.environ, OMP_NUM_THREADS=str(best_threads), MKL_NUM_THREADS=str(best_threads), HIP_VISIBLE_DEVICES="", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
         if nproc * best_threads > cores:      # (oversubscribed on request: spinning thread pools then cost an order of magnitude; measured 1.2 against 21 pairs/s)
             env.update(OMP_WAIT_POLICY="passive", GOMP_SPINCOUNT="0", KMP_BLOCKTIME="0")
@@ -231,14 +236,17 @@ def cpu_baseline(args, seed0):
             "oracle_port_pairs_per_s": round(2 / t_port, 4)}
 
 
-def list_run(args):
-    """bench.py --list A|B: BASELINE.json configs[2] / configs[3] as far as this environment allows (list-driven surrogate)."""
+def list_run(args, standalone=True):
+    """bench.py --list A|B: BASELINE.json configs[2] / configs[3] as far as this environment allows (list-driven surrogate).
+    standalone=False: called from the default run on an initialised single process (no process group of its own); returns the line."""
     import torch
     import torch.distributed as dist
     from lidarregistration_amd import harness, shard, metrics
-    world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    use_dist = "WORLD_SIZE" in os.environ
-    dev_index = local_rank if not args.devices else int(args.devices.split(",")[local_rank])
+    world = int(os.environ.get("WORLD_SIZE", "1")) if standalone else 1
+    rank = int(os.environ.get("RANK", "0")) if standalone else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if standalone else 0
+    use_dist = standalone and "WORLD_SIZE" in os.environ
+    dev_index = (local_rank if not args.devices else int(args.devices.split(",")[local_rank])) if standalone else torch.cuda.current_device()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     host_coll = use_dist and args.dist_backend == "gloo"
@@ -247,6 +255,7 @@ def list_run(args):
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+    line = None
 
     class A:      # Experiments/test.py:294-313 defaults + the README's flags
         codebase = "GC"; prosac = True; fast_rejection = "ELC"; GC_LO = True; GPF_factor = 2.0; GPF_grid_wid = 10
@@ -314,9 +323,11 @@ def list_run(args):
                                          f"final LS), sample of {res['stage_sample_pairs']} pairs"},
             "ransac_ids_examined_mean": round(float(res["n_ids"].mean()), 1), "filtered_pairs_mean": round(float(res["n_corr"].mean()), 1),
         }
-        print(json.dumps(line), flush=True)
+        if standalone:
+            print(json.dumps(line), flush=True)
     if use_dist:
         dist.barrier(); dist.destroy_process_group()
+    return line
 
 
 def main():
@@ -582,6 +593,19 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not dry and args.codebase == "open3D":
         cpu = cpu_baseline(args, seed0=51)
 
+    extra = None
+    if rank == 0 and world == 1 and not dry and not use_dist and args.extra_list != "none" and args.codebase == "open3D" and args.n == 30000 and args.mode in ("MNN", "MMN"):
+        # configs[2] (or [3]) in front of the driver: the reference's README command over every 8th row of the balanced list, surrogate data
+        for w in wss:
+            w.close()
+        del pairs[:]
+        torch.cuda.empty_cache()
+        la = argparse.Namespace(**vars(args)); la.list = args.extra_list; la.list_stride = args.extra_list_stride; la.batch = 0; la.streams = 0; la.hard = 1
+        ll = list_run(la, standalone=False)
+        extra = {"list_" + args.extra_list: {k: ll[k] for k in ("metric", "value", "unit", "pairs", "seconds_registration", "recall_5deg_0.6m", "recall_2deg_0.6m", "config",
+                                                                 "time_per_pair_us", "ransac_ids_examined_mean", "filtered_pairs_mean")}}
+        extra["list_" + args.extra_list]["hard"] = None if not ll.get("hard") else {k: ll["hard"][k] for k in ("recall_5deg_0.6m", "recall_2deg_0.6m", "failed", "pairs_per_s")}
+        extra["list_" + args.extra_list]["data"] = ll["data"]
     if rank == 0:
         line = {
             "metric": f"registration pairs/sec ({args.n // 1000}k-pt FCGF pairs, {'mutual-NN' if args.mode in ('MNN', 'MMN') else args.mode} + {args.iters // 1000}k RANSAC iters + refit)",
@@ -602,6 +626,7 @@ def main():
             "ransac_score_evaluations_frac_of_VxM": score_frac,
             "sustained": sustained,
             "roofline": roof, "pair_roofline": pair_roof, "cpu_baseline": cpu,
+            "extra": extra,
         }
         if dry:
             line["data"] = "dry-run (no GPU work)"
@@ -610,6 +635,8 @@ def main():
             # reference-style torch path whose 250-row einsum chunks leave most of the cores idle)
             line["speedup_vs_reference_style_path"] = round(value / cpu["value"], 1)      # (at the thread count the reference-style NN runs fastest with: cpu_baseline.cores)
             line["speedup_vs_openmp_port"] = round(value / cpu["oracle_port_pairs_per_s"], 1)
+            if cpu.get("value_process_parallel"):
+                line["speedup_vs_process_parallel_reference_path"] = round(value / cpu["value_process_parallel"], 1)      # (P processes x threads: cpu_baseline.process_parallel)
             # (the largest host figure: one process at its best thread count, the OpenMP port, or -- the reference's own sharding -- P processes side by side)
             line["speedup_vs_cpu_baseline"] = round(value / max(cpu["value"], cpu["oracle_port_pairs_per_s"], cpu.get("value_process_parallel") or 0.0), 1)
         print(json.dumps(line), flush=True)

@@ -1422,14 +1422,17 @@ nn16_rev_seed_kernel(const float *__restrict__ F0, const float *__restrict__ n0v
 //      where bucket b + 1 starts) and the row count;
 //   2. a block OWNS the buckets whose first position falls into its share [part, part + 1) n / parts of the order -- a contiguous range
 //      per side, found from the block's own offsets;
-//   3. it walks all keys again, 2048 per round: the rank of an owned element inside its bucket is an LDS atomic (any order inside a
+//   3. it walks all keys again, 8192 per round: the rank of an owned element inside its bucket is an LDS atomic (any order inside a
 //      bucket is valid); owned cloud-0 elements are queued as (point, position) in LDS and then moved by FOUR threads per row -- the f16
 //      row (64 B) to its position in the permuted copy the reverse walk streams, with colmap and the norm: full lanes and whole 64-byte
 //      segments, where a thread that ranks and copies its own element had 1 lane in 8 at work; owned cloud-1 elements get their position
 //      in the row list and their threshold at once (4 + 4 bytes).
 // Rows nobody points at get rev = -1; the segment counters of the reverse filter pass start from zero (row blocks that use fewer strips
 // than offered leave the others untouched).
-#define LR_RO_ROUND 2048         // keys per round = capacity of the copy queue (1024 threads x 2 keys; 48 KB of LDS with the bucket counters)
+#define LR_RO_ROUND 8192         // keys per round (1024 threads x 8 keys, all eight loads in flight)
+#define LR_RO_QUEUE 3072         // capacity of the round's copy queue: a block owns 1/parts of the keys (1/8 .. 1/32), three times the expected share
+                                 // of a round; an element that finds the queue full is moved by its own thread (slow, correct: one bucket holding
+                                 // most of a cloud -- hundreds of identical descriptors)
 __global__ void __launch_bounds__(1024)
 nn16_rev_order_kernel(int n0, int n1, const float *__restrict__ s1, const uint32_t *__restrict__ seed_bits, const uint32_t *__restrict__ range,
                       int32_t *__restrict__ offs, int32_t *__restrict__ n_rows, const float *__restrict__ block_max_c, int nblk_c,
@@ -1438,7 +1441,7 @@ nn16_rev_order_kernel(int n0, int n1, const float *__restrict__ s1, const uint32
                       int32_t *__restrict__ cand_cnt, int32_t *__restrict__ rev_out, int seg_counters, lr_zargs z)
 {
     __shared__ int s_pos[2 * LR_RS_BUCKETS];     // histograms, then offsets, then the next free position of every bucket
-    __shared__ int2 s_q[LR_RO_ROUND];            // copy queue of the round: (cloud-0 point, its position)
+    __shared__ int2 s_q[LR_RO_QUEUE];            // copy queue of the round: (cloud-0 point, its position)
     __shared__ float s_m[16];
     __shared__ int s_w[16], s_own[4], s_nq, s_nrows;
     if (z.descs) { n0 = z.descs[blockIdx.z].n0; n1 = z.descs[blockIdx.z].n1; nblk_c = (n0 + 31) >> 5; }
@@ -1461,22 +1464,17 @@ nn16_rev_order_kernel(int n0, int n1, const float *__restrict__ s1, const uint32
     float max_nc = 0.0f;
 #pragma unroll
     for (int w = 0; w < 16; ++w) max_nc = fmaxf(max_nc, s_m[w]);
-    // ---- 1. histograms of both sides (eight independent loads in flight per thread: the loop is bound by load latency, not by the atomics)
-    for (int i0 = tid; i0 < n0; i0 += 8 * 1024) {
-        float v[8];
+    // ---- 1. histograms of both sides (sixteen independent loads in flight per thread -- eight keys of each cloud: the loop is bound by load
+    //         latency, not by the atomics)
+    for (int i0 = tid; i0 < max(n0, n1); i0 += 8 * 1024) {
+        float v[8]; uint32_t u[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = s1[min(i0 + 1024 * k, n0 - 1)];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) if (i0 + 1024 * k < n0) atomicAdd(&s_pos[rs_bucket(v[k], lo, scale)], 1);
-    }
-    for (int j0 = tid; j0 < n1; j0 += 8 * 1024) {
-        uint32_t v[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = seed_bits[min(j0 + 1024 * k, n1 - 1)];
+        for (int k = 0; k < 8; ++k) { v[k] = s1[min(i0 + 1024 * k, n0 - 1)]; u[k] = seed_bits[min(i0 + 1024 * k, n1 - 1)]; }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const float sv = __uint_as_float(v[k]);
-            if (j0 + 1024 * k < n1 && sv <= 3.0e38f) atomicAdd(&s_pos[LR_RS_BUCKETS + (LR_RS_BUCKETS - 1 - rs_bucket(sv, lo, scale))], 1);
+            if (i0 + 1024 * k < n0) atomicAdd(&s_pos[rs_bucket(v[k], lo, scale)], 1);
+            const float sv = __uint_as_float(u[k]);
+            if (i0 + 1024 * k < n1 && sv <= 3.0e38f) atomicAdd(&s_pos[LR_RS_BUCKETS + (LR_RS_BUCKETS - 1 - rs_bucket(sv, lo, scale))], 1);
         }
     }
     __syncthreads();
@@ -1520,6 +1518,10 @@ nn16_rev_order_kernel(int n0, int n1, const float *__restrict__ s1, const uint32
     const int c_lo = s_own[0], c_len = max(s_own[1] - s_own[0], 0), r_lo = s_own[2], r_len = max(s_own[3] - s_own[2], 0);
     // ---- 3a. cloud 0: rank, queue, move (rounds of LR_RO_ROUND keys; every thread runs every round: the barriers are uniform)
     constexpr int U = LR_RO_ROUND / 1024;
+    auto move_row = [&](int i, int p, int piece) {
+        reinterpret_cast<f32x4 *>(H0s + (size_t)p * 32)[piece] = reinterpret_cast<const f32x4 *>(H0 + (size_t)i * 32)[piece];
+        if (piece == 0) { colmap[p] = i; nrm0s[p] = nrm0[i]; }
+    };
     for (int i0 = 0; i0 < n0; i0 += LR_RO_ROUND) {
         float v[U];
 #pragma unroll
@@ -1527,18 +1529,17 @@ nn16_rev_order_kernel(int n0, int n1, const float *__restrict__ s1, const uint32
 #pragma unroll
         for (int k = 0; k < U; ++k) {
             const int i = i0 + tid + 1024 * k, b = rs_bucket(v[k], lo, scale);
-            if (i < n0 && (unsigned)(b - c_lo) < (unsigned)c_len) s_q[atomicAdd(&s_nq, 1)] = make_int2(i, atomicAdd(&s_pos[b], 1));
+            if (i < n0 && (unsigned)(b - c_lo) < (unsigned)c_len) {
+                const int p = atomicAdd(&s_pos[b], 1), slot = atomicAdd(&s_nq, 1);
+                if (slot < LR_RO_QUEUE) s_q[slot] = make_int2(i, p);
+                else { for (int piece = 0; piece < 4; ++piece) move_row(i, p, piece); }
+            }
         }
         __syncthreads();
-        const int nq = s_nq;
+        const int nq = min(s_nq, LR_RO_QUEUE);
         __syncthreads();                 // (everybody has read the count before it is reset for the next round)
         if (tid == 0) s_nq = 0;
-        for (int e = tid >> 2; e < nq; e += 256) {
-            const int2 ip = s_q[e];
-            const int piece = tid & 3;
-            reinterpret_cast<f32x4 *>(H0s + (size_t)ip.y * 32)[piece] = reinterpret_cast<const f32x4 *>(H0 + (size_t)ip.x * 32)[piece];
-            if (piece == 0) { colmap[ip.y] = ip.x; nrm0s[ip.y] = nrm0[ip.x]; }
-        }
+        for (int e = tid >> 2; e < nq; e += 256) { const int2 ip = s_q[e]; move_row(ip.x, ip.y, tid & 3); }
         __syncthreads();                 // (the queue is consumed and the reset visible before the next round pushes)
     }
     // ---- 3b. cloud 1: position in the row list + threshold, sixteen keys in flight per thread

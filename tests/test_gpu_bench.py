@@ -35,7 +35,15 @@ def test_bench_line_small_workload():
     assert 0 < pr["frac"] < 1 and pr["t_min_us"] < pr["t_pair_us"]
     cpu = line["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["unit"] == "pairs/s" and cpu["value"] > 0 and cpu["cores"] >= 1 and "einsum" in cpu["impl"]
-    assert line["speedup_vs_cpu_baseline"] > 1 and line["speedup_vs_cpu_baseline"] == min(line["speedup_vs_reference_style_path"], line["speedup_vs_openmp_port"])
+    # the headline ratio is taken against the FASTEST host figure: one process at its best thread count, the OpenMP port, or P pinned processes side by side
+    pp = cpu["process_parallel"]
+    assert "value_process_parallel" in cpu and "host_hardware_threads" in cpu and (pp is None or (pp["processes"] >= 2 and pp["threads_per_process"] == cpu["cores"]))
+    ratios = [line["speedup_vs_reference_style_path"], line["speedup_vs_openmp_port"]] + ([line["speedup_vs_process_parallel_reference_path"]] if cpu["value_process_parallel"] else [])
+    assert line["speedup_vs_cpu_baseline"] > 1 and line["speedup_vs_cpu_baseline"] == min(ratios)
+    # what makes two records comparable: the clock of the timed steps' filter-pass blocks, the spread of the steps
+    lo, med, hi = line["ms_per_step_minmedmax"]
+    assert 0 < lo <= med <= hi and 500 < line["clock_MHz"] < 3000 and abs(line["value_at_2.0GHz"] - line["value"] * 2000 / line["clock_MHz"]) < 0.02 * line["value"]
+    assert line["extra"] is None          # (the list-A leg belongs to the headline workload only)
     assert 0 < roof["whole_call_frac"] <= roof["nn_stage_frac"] <= roof["forward_launch_frac"] < 1 and roof["forward_launch_ms"] > roof["reverse_launch_ms"] > 0
 
 

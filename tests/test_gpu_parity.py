@@ -172,6 +172,13 @@ def test_nn_to_mutual_reverse_ordering_edge_cases(lr, oracle):
     # (e) more rows than one block on the reverse side, few columns
     F0, F1 = synth.make_features(40, 2600, 32, 0.5, 0.8, 91)
     _mutual_vs_oracle(lr, oracle, F0, F1)
+    # (f) one sort bucket holding nearly a whole cloud on both sides -- far more than the ordering kernel's copy queue takes in a round (round 6:
+    #     nn16_rev_order_kernel; elements past the queue are moved by their own thread) -- next to ordinary points: 9 000 copies of one
+    #     descriptor in cloud 0, 7 000 of another in cloud 1
+    a = rng.standard_normal((1, 32)).astype(np.float32); b = rng.standard_normal((1, 32)).astype(np.float32)
+    F0 = np.concatenate([np.repeat(a, 9000, axis=0), rng.standard_normal((800, 32)).astype(np.float32)])
+    F1 = np.concatenate([rng.standard_normal((700, 32)).astype(np.float32), np.repeat(b, 7000, axis=0), a + 1e-3])
+    _mutual_vs_oracle(lr, oracle, F0, F1)
 
 
 def test_ratio_bit_exact(lr, oracle, filt):
