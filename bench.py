@@ -80,6 +80,8 @@ def parse(argv=None):
     args = ap.parse_args(argv)
     if args.sustain_s is None:
         args.sustain_s = 0.0 if any(k.startswith("ROCPROF") for k in os.environ) else 10.0
+    if any(k.startswith("ROCPROF") for k in os.environ):
+        args.extra_list = "none"          # (a kernel summary / counter pass of the headline workload must not contain a list run's kernels)
     return args
 
 

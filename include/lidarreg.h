@@ -143,7 +143,7 @@ typedef struct lr_pair_params {
 } lr_pair_params;
 
 /* ---- library ------------------------------------------------------------------------------- */
-LR_API int         lr_version(void);    /* 100 * major + minor; 103: lr_workspace_clock, options 6 / 7, fused verification; 102: params structs start with struct_size (72 / 112 bytes), descriptors of 1..32 dimensions; 101: lr_ransac_params 64 bytes / lr_pair_params 96 bytes (round 3), lr_icp_batch */
+LR_API int         lr_version(void);    /* 100 * major + minor; 103: lr_workspace_clock, LR_OPT_CLOCK_PROBE, lr_debug_fake_current_device, device checks; 102: params structs start with struct_size (72 / 112 bytes), descriptors of 1..32 dimensions; 101: lr_ransac_params 64 bytes / lr_pair_params 96 bytes (round 3), lr_icp_batch */
 LR_API const char *lr_last_error(void);
 
 /* Scratch for clouds up to (max_n0, max_n1) points x dim (1 <= dim <= 32; matching.py:22-65 takes any width) and up to max_iters hypotheses. */
@@ -166,10 +166,7 @@ enum {
     LR_OPT_NN_SAMPLE_STRIDE = 3,  /* the filter pass samples every k-th column tile for its start thresholds (default: strip tiles / 32, at most 32) */
     LR_OPT_REV_STRIPS       = 4,  /* column strips offered to each row block of the reverse NN pass (default 48 / pairs, within 2..8) */
     LR_OPT_NN_SECOND_AUTO   = 5,  /* 1: lr_register_pair / _batch compute the second neighbour only when a stage of the call reads it */
-    LR_OPT_NN_VERIFY_FUSED  = 6,  /* 1: a filter-pass wave that owns the complete candidate lists of its rows (one column strip: every 32-pair batched
-                                     call) verifies them itself instead of leaving them to the exact-verification kernel; same results, measured 1 %
-                                     SLOWER in the pipeline, hence off by default                                          */
-    LR_OPT_CLOCK_PROBE      = 7   /* 1: the filter-pass blocks sum their shader cycles and 100 MHz ticks into the workspace (lr_workspace_clock) */
+    LR_OPT_CLOCK_PROBE      = 6   /* 1: the filter-pass blocks sum their shader cycles and 100 MHz ticks into the workspace (lr_workspace_clock) */
 };
 LR_API int    lr_workspace_option(lr_workspace *ws, int option, int value);
 /* Measurement hook (no reference counterpart): the shader clock the filter-pass blocks ran at since the last reset, *mhz = 100 * cycles / ticks

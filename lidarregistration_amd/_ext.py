@@ -24,7 +24,7 @@ SYMBOLS = [
 
 # lr_workspace_option ids (include/lidarreg.h).  DEFAULT_OPTIONS is applied to every Workspace this module creates (a hook for
 # tuning experiments and for the test that no option changes a result; the library itself reads no environment variable).
-OPTIONS = {"nn_blocks": 1, "nn_blocks_batch": 2, "nn_sample_stride": 3, "rev_strips": 4, "nn_second_auto": 5, "nn_verify_fused": 6, "clock_probe": 7}
+OPTIONS = {"nn_blocks": 1, "nn_blocks_batch": 2, "nn_sample_stride": 3, "rev_strips": 4, "nn_second_auto": 5, "clock_probe": 6}
 DEFAULT_OPTIONS = {}
 
 

@@ -176,7 +176,7 @@ extern "C" int lr_workspace_create_batch(lr_workspace **out, int max_pairs, int 
     // tuning defaults (lr_workspace_option changes them; no environment variable is read anywhere in this library)
     ws->nn_blocks_target = 3 * ws->n_cus;      // 3 blocks per CU = every block of a single pair's filter pass resident at once (768 on an MI355X)
     ws->nn_blocks_batch = 12 * ws->n_cus;      // (3072)
-    ws->nn_sample_stride = 0; ws->rev_strips = 0; ws->nn_second_auto = 0; ws->nn_verify_fused = 0; ws->clock_probe = 0;
+    ws->nn_sample_stride = 0; ws->rev_strips = 0; ws->nn_second_auto = 0; ws->clock_probe = 0;
     Carver sizing;
     carve(ws, sizing);
     ws->stride = (sizing.off + 511) & ~size_t(255);          // one arena per pair, identical layout
@@ -239,7 +239,6 @@ extern "C" int lr_workspace_option(lr_workspace *ws, int option, int value)
     case LR_OPT_NN_SAMPLE_STRIDE: ws->nn_sample_stride = value > 4096 ? 4096 : value; break;      // (lr_nn16_run clamps it to the strip length)
     case LR_OPT_REV_STRIPS: ws->rev_strips = value > 64 ? 64 : value; break;
     case LR_OPT_NN_SECOND_AUTO: ws->nn_second_auto = value ? 1 : 0; break;
-    case LR_OPT_NN_VERIFY_FUSED: ws->nn_verify_fused = value ? 1 : 0; break;
     case LR_OPT_CLOCK_PROBE: ws->clock_probe = value ? 1 : 0; break;
     default: lr_set_error("lr_workspace_option: unknown option %d", option); return LR_EINVAL;
     }

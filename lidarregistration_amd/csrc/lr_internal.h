@@ -130,7 +130,6 @@ struct lr_workspace {
     int nn_sample_stride;        // LR_OPT_NN_SAMPLE_STRIDE: phase 1 of the filter pass samples every this-many-th column tile (0: by the strip length)
     int rev_strips;              // LR_OPT_REV_STRIPS: strips offered to every row block of the reverse pass (0: by the number of pairs)
     int nn_second_auto;          // LR_OPT_NN_SECOND_AUTO: the pair pipeline computes the 2nd neighbour only when a stage reads it
-    int nn_verify_fused;         // LR_OPT_NN_VERIFY_FUSED: one-strip row blocks of the filter pass verify their own rows (off by default: measured slower)
     int clock_probe;             // LR_OPT_CLOCK_PROBE: the filter-pass blocks sum their shader cycles / 100 MHz ticks into clk_dev
     unsigned long long *clk_dev; // [2] device words behind lr_workspace_clock (outside the arenas: one per workspace)
     int32_t *counters;           // small int block, see LR_CNT_*

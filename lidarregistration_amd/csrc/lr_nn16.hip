@@ -244,9 +244,8 @@ struct lr_thr_in {
 };
 // grid shape of a 1-D XCD-aware launch + direction (0: rows = cloud 0, columns = cloud 1; 1: the reverse pass)
 struct lr_pb_grid { int gx, gy, total, dir, only; };      // only != 0: the other instantiation is not launched (single-pair calls, see lr_nn16_forms)
-// Where the exact stage leaves its results (nn16_exact_kernel -- and the filter pass itself, which verifies the rows of a wave that owns their
-// complete candidate list, see "fused verification" below): the two neighbours by data row, and (forward direction of a pair) the seeds of
-// the reverse pass
+// Where the exact stage (nn16_exact_kernel) leaves its results: the two neighbours by data row, and (forward direction of a pair) the
+// seeds of the reverse pass
 struct lr_ex_out {
     int32_t *idx1, *idx2;
     float *s1o, *s2o;
@@ -255,36 +254,22 @@ struct lr_ex_out {
     uint32_t *seed_range;            // { smallest, largest } of the seeds and keys
     unsigned long long *seed64;      // forward: [columns] (distance bits << 32) | smallest row at that distance; reverse: the seeds to start from
 };
-// what the filter pass needs to verify its own candidates: the fp32 descriptors and norms of both clouds (by DATA row / original column id)
-// This struct is the filter pass' FIRST kernel parameter and is only ever read at the END of the kernel, through the kernel-argument
-// segment pointer behind an opaque asm (lr_pb_tail_args): read as ordinary parameters its fifteen pointers are fetched at the top of the
-// kernel and held in scalar registers across the walk -- 17 scalar spills into a vector register, read back inside the slow paths.
-struct lr_pb_fuse {
-    const float *Fq, *Fc;            // Fq == nullptr: no fused verification (nn16_exact_kernel does all rows)
-    const float *nQ, *nCx;
-    lr_ex_out out;
+// The filter pass' FIRST kernel parameter, read only at the END of the kernel and through the kernel-argument segment pointer behind an
+// opaque asm: as an ordinary parameter the pointer would sit in two scalar registers across the walk, and the kernel is at its scalar
+// register limit (round 6: a fifteen-pointer version of this struct -- the fused verification, docs/HISTORY.md -- cost 17 scalar spills).
+struct lr_pb_tail {
     unsigned long long *clk;         // { shader cycles, 100 MHz ticks } summed over the blocks of the launch (lr_workspace_clock), or nullptr
-    lr_zargs z;                      // copies of the kernel's z / grid shape for the tail (the originals are dead by then)
-    int gx, gy, dir, pad;
 };
-// the struct above as the kernel finds it at offset 0 of its argument segment; the asm keeps the compiler from hoisting the loads.  (Pointers
-// that arrive this way are generic to the compiler: the gathers of the tail go through explicitly global-qualified copies, lr_g4p / lr_gfp)
-typedef const __attribute__((address_space(1))) f32x4 *lr_g4p;
-typedef const __attribute__((address_space(1))) float *lr_gfp;
-typedef const __attribute__((address_space(1))) int32_t *lr_gip;
-__device__ __forceinline__ lr_pb_fuse lr_pb_tail_args()
+__device__ __forceinline__ lr_pb_tail lr_pb_tail_args()
 {
-    auto ka = __builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(ka) :: "memory");
+    auto ka = __builtin_amdgcn_kernarg_segment_ptr();          // (explicit arguments start at offset 0 of the segment)
+    asm volatile("" : "+s"(ka) :: "memory");                   // keeps the compiler from hoisting the load to the top of the kernel
     typedef const unsigned long long __attribute__((opencl_constant)) *cw_t;
-    const cw_t w = (cw_t)ka;
-    static_assert(sizeof(lr_pb_fuse) % 8 == 0, "read as 64-bit words");
-    unsigned long long buf[sizeof(lr_pb_fuse) / 8];
-#pragma unroll
-    for (unsigned i = 0; i < sizeof(lr_pb_fuse) / 8; ++i) buf[i] = w[i];
-    lr_pb_fuse f;
-    __builtin_memcpy(&f, buf, sizeof f);
-    return f;
+    static_assert(sizeof(lr_pb_tail) == 8, "read as one 64-bit word");
+    lr_pb_tail t;
+    const unsigned long long w = *(cw_t)ka;
+    __builtin_memcpy(&t, &w, sizeof t);
+    return t;
 }
 
 // ------------------------------------------------------------------ exact stage: shared pieces
@@ -353,7 +338,7 @@ __device__ unsigned long long lr_pb_stat[16];
 #define LR_PB_WAVES 3            // waves per SIMD the filter pass is compiled for
 template <bool SIGN>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LR_PB_WAVES, LR_PB_WAVES)))
-nn16_passb_kernel(lr_pb_fuse fz_first /* read at the end only, through lr_pb_tail_args() */, unsigned long long *clk_on,
+nn16_passb_kernel(lr_pb_tail tail_first /* read at the end only, through lr_pb_tail_args() */, unsigned long long *clk_on,
                   const _Float16 *__restrict__ Hq, int na_host, const int32_t *__restrict__ rowmap, const int32_t *__restrict__ na_dev,
                   const _Float16 *__restrict__ Hc, const float *__restrict__ nC, int nb,
                   int tiles_per_strip, const float *__restrict__ tau, int32_t *__restrict__ cand_cnt, int32_t *__restrict__ cand,
@@ -1012,93 +997,10 @@ nn16_passb_kernel(lr_pb_fuse fz_first /* read at the end only, through lr_pb_tai
         drain();
         flush();           // (with a last tightening round: the entries get their g, the rows their final thresholds)
     }
-    // ---------------------------------------------------------------- fused verification
-    // A row block with ONE column strip (every batched call of 32 pairs; the short-prefix row blocks of the reverse pass) owns the complete
-    // candidate lists of its rows: each wave verifies its 64 rows here, in the shadow of the other blocks' MFMAs, instead of leaving them to
-    // nn16_exact_kernel -- one launch per direction whose gathers nothing else hides (85 us per 32 pairs) becomes an empty one.  Same
-    // arithmetic, same order (ex_offer / ex_write_row): a lane takes ENTRIES of the wave's segment (read back coherently: the wave wrote them
-    // itself), drops what the rows' final thresholds exclude, gathers the entry's column row and the query row (fp32, 128 B each) and offers
-    // the fma-chain distance to the row's two 64-bit keys in LDS (the wave's hit list, empty by now, is the scratch).  All or nothing per
-    // wave: if any row needs the full scan (list too short, f16 copy not finite, a column norm that is not finite) or the segment
-    // overflowed, nothing is written and the exact kernel takes the 64 rows as before.  No block barrier: the four waves differ.
-    bool verified = false;
-    lr_pb_fuse fz = lr_pb_tail_args();
-    if (fz.Fq != nullptr && my_strips == 1 && seg_fill >= 0 && !(min_nc < 0.0f) && nchunks > 0) {
-        const int lane = cold_lane();
-        {   // the pair's own pointers (what the head of the kernel does for its arguments)
-            const int pr = logical / (fz.gx * fz.gy);
-            if (fz.z.descs) { const lr_pair_desc d = fz.z.descs[pr]; fz.Fq = fz.dir ? d.F1 : d.F0; fz.Fc = fz.dir ? d.F0 : d.F1; }
-            lr_z(fz.nQ, fz.z, pr); lr_z(fz.nCx, fz.z, pr); lr_z(fz.out.idx1, fz.z, pr); lr_z(fz.out.idx2, fz.z, pr); lr_z(fz.out.s1o, fz.z, pr); lr_z(fz.out.s2o, fz.z, pr);
-            lr_z(fz.out.seed_out, fz.z, pr); lr_z(fz.out.seed_s1, fz.z, pr); lr_z(fz.out.seed_range, fz.z, pr); lr_z(fz.out.seed64, fz.z, pr);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // flush()'s stores to the segment are out (it is read back below); and nothing of
-        __builtin_amdgcn_wave_barrier();                            // flush() moves behind the re-use of its list under another type
-        unsigned long long *t_best = reinterpret_cast<unsigned long long *>(&wlist[wave][0]), *t_second = t_best + 64;
-        int *t_cnt = reinterpret_cast<int *>(t_second + 64), *t_rowd = t_cnt + 64;
-        float *t_nq = reinterpret_cast<float *>(t_rowd + 64);
-        static_assert(WL * 8 >= 64 * (8 + 8 + 4 + 4 + 4), "the wave's hit list is the scratch of its verification");
-        const bool live = row0 + lane < na;
-        const int rowc = min(row0 + lane, na - 1);
-        const int rowd = rowmap ? rowmap[rowc] : rowc;
-        bool bad = false;
-        {
-            const lr_g4p pa = (lr_g4p)(fz.Fq + (size_t)rowd * 32);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { const f32x4 u = pa[2 * k], v = pa[2 * k + 1]; bad |= ex_bad8(u, v); }
-        }
-        t_best[lane] = LR_EX_EMPTY; t_second[lane] = LR_EX_EMPTY; t_cnt[lane] = 0; t_rowd[lane] = rowd; t_nq[lane] = ((lr_gfp)fz.nQ)[rowd];
-        // reverse direction seeded by this library's forward pass: the best of the points that POINT AT the row is known
-        if (fz.dir == 1 && fz.out.seed64 && live) { t_best[lane] = fz.out.seed64[rowd]; t_cnt[lane] = 1; }
-        __builtin_amdgcn_wave_barrier();
-        for (int e0 = 0; e0 < seg_fill; e0 += 64) {
-            const int e = e0 + lane;
-            unsigned long long raw = 0ull;
-            if (e < seg_fill) raw = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(seg + e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned vx = (unsigned)raw, vy = (unsigned)(raw >> 32);
-            unsigned m = vy & 0xffffu;
-            const int j = (int)(vx & LR_PB_COLMASK), ekb = lr_pb_kb(vx);
-            if (m != 0u && (vx & LR_PB_HASG) && tightening) {       // (single-row entry with its g, rounded up to 16 bits, against the row's FINAL threshold)
-                const float gv = __uint_as_float(vy & 0xffff0000u), yr = s_Y[wave * 64 + lr_pb_row(ekb, __builtin_ctz(m))];
-                if (gv + 1e-5f * (fabsf(gv) + fabsf(yr)) < -yr) m = 0u;
-            }
-            if (m != 0u) {
-                f32x4 t[8];
-                const lr_g4p pb = (lr_g4p)(fz.Fc + (size_t)j * 32);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) t[k] = pb[k];
-                const float ncj = ((lr_gfp)fz.nCx)[j];
-                while (m) {
-                    const int rl = lr_pb_row(ekb, __builtin_ctz(m));
-                    m &= m - 1;
-                    const lr_g4p qa = (lr_g4p)(fz.Fq + (size_t)t_rowd[rl] * 32);
-                    float acc = 0.0f;
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const f32x4 a = qa[k];
-                        acc = __builtin_fmaf(a.x, t[k].x, acc);
-                        acc = __builtin_fmaf(a.y, t[k].y, acc);
-                        acc = __builtin_fmaf(a.z, t[k].z, acc);
-                        acc = __builtin_fmaf(a.w, t[k].w, acc);
-                    }
-                    const float d2 = __builtin_fmaf(-2.0f, acc, t_nq[rl] + ncj);
-                    ex_offer(&t_best[rl], &t_second[rl], __builtin_sqrtf(fmaxf(d2, 1e-30f)), j);
-                    atomicAdd(&t_cnt[rl], 1);
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        const bool redo = live && (bad || t_cnt[lane] < min(thr.need, nb));
-        if (__builtin_amdgcn_ballot_w64(redo) == 0ull) {
-            float sv = 3.0e38f, key = 0.0f;
-            if (live) ex_write_row(fz.out, rowd, t_best[lane], t_second[lane], nb, thr.need, sv, key);
-            if (fz.out.seed_out) ex_range(fz.out, live, sv, key, lane);
-            verified = true;
-        }
-    }
     if (lane == 0) {
         int32_t *cw = cand_cnt + (bx * 4 + wave) * (pg.gy + 1);
         cw[by] = seg_fill;                     // entries in this wave's segment (< 0: overflow)
-        if (by == 0) cw[pg.gy] = verified ? -my_strips : my_strips;    // how the wave's store is divided; negative: the rows are done (read by nn16_exact_kernel)
+        if (by == 0) cw[pg.gy] = my_strips;    // how the wave's store is divided (read by nn16_exact_kernel)
     }
     LR_PROBE(if (lane == 0) {
         atomicAdd(&lr_pb_stat[0], 1ull); atomicAdd(&lr_pb_stat[1], (unsigned long long)nchunks * CH * 4); atomicAdd(&lr_pb_stat[2], (unsigned long long)n_visits);
@@ -1113,9 +1015,12 @@ nn16_passb_kernel(lr_pb_fuse fz_first /* read at the end only, through lr_pb_tai
         const int rw = row0 + lane;
         if (rw < na) yfin[(size_t)by * yfin_stride + rw] = tightening ? s_Y[wave * 64 + lane] : LR_INF;
     }
-    if (fz.clk && threadIdx.x == 0) {
-        atomicAdd(&fz.clk[0], __builtin_amdgcn_s_memtime() - s_clk[0]);
-        atomicAdd(&fz.clk[1], __builtin_amdgcn_s_memrealtime() - s_clk[1]);
+    if (threadIdx.x == 0) {
+        const lr_pb_tail tl = lr_pb_tail_args();
+        if (tl.clk) {
+            atomicAdd(&tl.clk[0], __builtin_amdgcn_s_memtime() - s_clk[0]);
+            atomicAdd(&tl.clk[1], __builtin_amdgcn_s_memrealtime() - s_clk[1]);
+        }
     }
 }
 
@@ -1130,8 +1035,6 @@ nn16_passb_kernel(lr_pb_fuse fz_first /* read at the end only, through lr_pb_tai
 // entry, so a row with many candidates does not stall its neighbours, and nothing is binned or sorted.
 // Rows whose segment overflowed, whose list is too short, or whose f16 copy is not finite are re-done by the whole block
 // with an exact scan of all columns (slow, rare, and by construction the reference answer).
-// A wave of the filter pass that owned the complete candidate list of its 64 rows (one column strip) has verified them itself (fused
-// verification, above) and says so in its strip count: the block of those rows returns at once.
 #define LR_EX_ROWS 64
 #define LR_EX_STRIDE 33          // floats per staged query row (odd: conflict-free column-wise reads)
 
@@ -1168,7 +1071,6 @@ nn16_exact_kernel(const float *__restrict__ Fq, const float *__restrict__ nQ, in
     // a filter pass that was launched in one form only while this call's norms asked for the other walked nothing -- and then NOBODY wrote
     // this call's candidate counts: the store is not looked at (s_skip below), every row goes through the full scan
     const int miss = counters[LR_CNT_FORM_MISS_F + (dir ? 1 : 0)] != 0 ? 1 : 0;
-    if (!miss && cand_cnt[bxi * (nstrips + 1) + nstrips] < 0) return;      // verified by the filter pass itself (block-uniform)
     // ---- stage the query rows: thread t moves floats [8 (t & 3) .. +8) of row t >> 2
     {
         const int rl = tid >> 2, part = tid & 3;
@@ -1338,16 +1240,15 @@ int lr_nn16_run(lr_workspace *ws, const float *Fq, const _Float16 *Hq, const flo
     int32_t *miss = ws->counters + LR_CNT_FORM_MISS_F;
     const lr_ex_out eo = { idx1, idx2, s1, s2, seed_reverse ? ws->rev_seed : (uint32_t *)nullptr, ws->rev_s1, reinterpret_cast<uint32_t *>(ws->counters + LR_CNT_RLO),
                            ws->rev_seed64 };
-    // (fused verification, LR_OPT_NN_VERIFY_FUSED: whenever a row block has one strip -- decided per row block on the device)
     unsigned long long *clk = ws->clock_probe ? ws->clk_dev : (unsigned long long *)nullptr;
-    const lr_pb_fuse fz = { ws->nn_verify_fused ? Fq : (const float *)nullptr, Fc, nQ, nC, eo, clk, ws->z, row_blocks, strips, 0, 0 };
+    const lr_pb_tail tl = { clk };
     if (only != 2)
-        hipLaunchKernelGGL(nn16_passb_kernel<true>, grid, dim3(256), 0, st, fz, clk, Hq, na, (const int32_t *)nullptr, (const int32_t *)nullptr, Hc, nC, nb,
+        hipLaunchKernelGGL(nn16_passb_kernel<true>, grid, dim3(256), 0, st, tl, clk, Hq, na, (const int32_t *)nullptr, (const int32_t *)nullptr, Hc, nC, nb,
                            tps, (const float *)nullptr, ws->cand_cnt, ws->cand, (const int32_t *)nullptr, (const float *)nullptr,
                            (const uint32_t *)nullptr, (const int32_t *)nullptr, (const uint32_t *)nullptr, ws->yfin, ws->max_n, ws->yshare, miss, thr,
                            lr_pb_grid{ row_blocks, strips, total, 0, only }, ws->z);
     if (only != 1)
-        hipLaunchKernelGGL(nn16_passb_kernel<false>, grid, dim3(256), 0, st, fz, clk, Hq, na, (const int32_t *)nullptr, (const int32_t *)nullptr, Hc, nC, nb,
+        hipLaunchKernelGGL(nn16_passb_kernel<false>, grid, dim3(256), 0, st, tl, clk, Hq, na, (const int32_t *)nullptr, (const int32_t *)nullptr, Hc, nC, nb,
                            tps, (const float *)nullptr, ws->cand_cnt, ws->cand, (const int32_t *)nullptr, (const float *)nullptr,
                            (const uint32_t *)nullptr, (const int32_t *)nullptr, (const uint32_t *)nullptr, ws->yfin, ws->max_n, ws->yshare, miss, thr,
                            lr_pb_grid{ row_blocks, strips, total, 0, only }, ws->z);
@@ -1610,15 +1511,15 @@ int lr_nn16_reverse(lr_workspace *ws, const float *F0, const _Float16 *H0, const
     const lr_thr_in rthr = { nullptr, (const float *)ws->nn_range, 1, 0 };      // (no tightening: the column norms' range selects the form of the walk's test)
     const lr_ex_out reo = { rev, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, seeded ? ws->rev_seed64 : (unsigned long long *)nullptr };
     unsigned long long *clk = ws->clock_probe ? ws->clk_dev : (unsigned long long *)nullptr;
-    const lr_pb_fuse rfz = { ws->nn_verify_fused ? F1 : (const float *)nullptr, F0, nrm1, nrm0, reo, clk, ws->z, row_blocks, strips, 1, 0 };
+    const lr_pb_tail tl = { clk };
     if (only != 2)
-        hipLaunchKernelGGL(nn16_passb_kernel<true>, grid, dim3(256), 0, st, rfz, clk, H1, na, (const int32_t *)ws->rev_rows, (const int32_t *)n_rows,
+        hipLaunchKernelGGL(nn16_passb_kernel<true>, grid, dim3(256), 0, st, tl, clk, H1, na, (const int32_t *)ws->rev_rows, (const int32_t *)n_rows,
                            (const _Float16 *)ws->Hs, (const float *)ws->nrms, nb, tps, ws->tau, ws->cand_cnt, ws->cand,
                            (const int32_t *)ws->rev_cols, seeded ? (const float *)ws->rev_tmin : (const float *)nullptr, (const uint32_t *)seed,
                            (const int32_t *)ws->rev_hist, (const uint32_t *)range, (float *)nullptr, 0, (uint32_t *)nullptr, miss, rthr,
                            lr_pb_grid{ row_blocks, strips, total, 1, only }, ws->z);
     if (only != 1)
-        hipLaunchKernelGGL(nn16_passb_kernel<false>, grid, dim3(256), 0, st, rfz, clk, H1, na, (const int32_t *)ws->rev_rows, (const int32_t *)n_rows,
+        hipLaunchKernelGGL(nn16_passb_kernel<false>, grid, dim3(256), 0, st, tl, clk, H1, na, (const int32_t *)ws->rev_rows, (const int32_t *)n_rows,
                            (const _Float16 *)ws->Hs, (const float *)ws->nrms, nb, tps, ws->tau, ws->cand_cnt, ws->cand,
                            (const int32_t *)ws->rev_cols, seeded ? (const float *)ws->rev_tmin : (const float *)nullptr, (const uint32_t *)seed,
                            (const int32_t *)ws->rev_hist, (const uint32_t *)range, (float *)nullptr, 0, (uint32_t *)nullptr, miss, rthr,

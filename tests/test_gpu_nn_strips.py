@@ -1,10 +1,9 @@
-"""The fused verification (round 6): a filter-pass wave that owns the complete candidate lists of its 64 rows -- one column strip per row
-block: every 32-pair batched call, small clouds, the short-prefix row blocks of the reverse pass -- verifies them itself at the end of
-nn16_passb_kernel; nn16_exact_kernel then only takes the rows such a wave gave up on (segment overflow, a list that is too short, a query
-row or column norm that is not finite) and the row blocks with several strips.  Both routes run the same arithmetic in the same order, so
-every list and every result block must be bit-identical with the option LR_OPT_NN_VERIFY_FUSED on and off -- and equal to the oracle
-(matching.py:22-65, :207-239).  The option is OFF by default: measured in the pipeline the fused form is 1 % slower (a wave parked in the
-gathers of its tail holds a third of a SIMD's wave slots).  Needs an MI355X."""
+"""One column strip per row block -- what every 32-pair batched call of the headline workload runs with -- against several strips and the
+oracle: NN lists, distances and mutual lists bit for bit on inputs that stress the candidate store and the exact verification (segment
+overflow from duplicates, query rows that are not finite or out of the f16 range, tiny and ragged clouds), a 32-pair batched call at
+test sizes with the strip count forced both ways, and the clock probe of the filter pass (lr_workspace_clock).  (Written in round 6 for the
+fused verification -- a filter-pass wave verifying its own rows -- which measured 1 % slower and was removed again: docs/HISTORY.md,
+profiles/r06_fused_verify_ab.txt.  The cases stay: they pin the strip-count independence of every list.)  Needs an MI355X."""
 import ctypes
 
 import numpy as np
@@ -59,7 +58,7 @@ def _nn(lr, F0, F1, options, need2=True):
     return out
 
 
-ONE_STRIP = {"nn_blocks": 1, "rev_strips": 1}       # every row block of both directions has one strip: with nn_verify_fused every wave verifies its own rows
+ONE_STRIP = {"nn_blocks": 1, "rev_strips": 1}       # every row block of both directions has one strip
 
 
 def _cases():
@@ -87,28 +86,28 @@ def _cases():
 
 
 @pytest.mark.parametrize("name,F0,F1", list(_cases()), ids=[c[0] for c in _cases()])
-def test_fused_equals_separate_equals_oracle(lr, oracle, name, F0, F1):
-    fused = _nn(lr, F0, F1, dict(ONE_STRIP, nn_verify_fused=1))
-    sep = _nn(lr, F0, F1, ONE_STRIP)
-    default = _nn(lr, F0, F1, {"nn_verify_fused": 1})
-    for k in fused:
-        assert np.array_equal(_bits(fused[k]) if fused[k].dtype == np.float32 else fused[k], _bits(sep[k]) if sep[k].dtype == np.float32 else sep[k]), (name, k)
-        assert np.array_equal(_bits(fused[k]) if fused[k].dtype == np.float32 else fused[k], _bits(default[k]) if default[k].dtype == np.float32 else default[k]), (name, k)
+def test_one_strip_equals_default_equals_oracle(lr, oracle, name, F0, F1):
+    one = _nn(lr, F0, F1, ONE_STRIP)
+    many = _nn(lr, F0, F1, {"nn_blocks": 4096, "rev_strips": 16})
+    default = _nn(lr, F0, F1, {})
+    for k in one:
+        assert np.array_equal(_bits(one[k]) if one[k].dtype == np.float32 else one[k], _bits(many[k]) if many[k].dtype == np.float32 else many[k]), (name, k)
+        assert np.array_equal(_bits(one[k]) if one[k].dtype == np.float32 else one[k], _bits(default[k]) if default[k].dtype == np.float32 else default[k]), (name, k)
     o1, o2, os1, os2 = oracle.nn_top2(F0, F1)
     finite = np.isfinite(F0).all(axis=1)
-    assert np.array_equal(fused["i1"][finite], o1[finite]) and np.array_equal(_bits(fused["s1"])[finite], _bits(os1)[finite]), name
+    assert np.array_equal(one["i1"][finite], o1[finite]) and np.array_equal(_bits(one["s1"])[finite], _bits(os1)[finite]), name
     if len(F1) > 1:
-        assert np.array_equal(fused["i2"][finite], o2[finite]) and np.array_equal(_bits(fused["s2"])[finite], _bits(os2)[finite]), name
+        assert np.array_equal(one["i2"][finite], o2[finite]) and np.array_equal(_bits(one["s2"])[finite], _bits(os2)[finite]), name
     if finite.all():
         m = oracle.nn_to_mutual(F0, F1, np.arange(len(F0)), o1, o2)
-        assert np.array_equal(fused["o0"], m[0]) and np.array_equal(fused["o1"], m[1]), name
+        assert np.array_equal(one["o0"], m[0]) and np.array_equal(one["o1"], m[1]), name
 
 
-def test_fused_top1_only(lr, oracle):
+def test_one_strip_top1_only(lr, oracle):
     """need = 1 (no second neighbour asked for): shorter lists, the column key of the reverse pass is the NN distance."""
     F0, F1 = synth.make_features(5200, 4800, 32, 0.4, 0.9, 11)
-    a = _nn(lr, F0, F1, dict(ONE_STRIP, nn_verify_fused=1), need2=False)
-    b = _nn(lr, F0, F1, ONE_STRIP, need2=False)
+    a = _nn(lr, F0, F1, ONE_STRIP, need2=False)
+    b = _nn(lr, F0, F1, {}, need2=False)
     o1, _, os1, _ = oracle.nn_top2(F0, F1)
     assert np.array_equal(a["i1"], o1) and np.array_equal(_bits(a["s1"]), _bits(os1))
     for k in a:
@@ -117,10 +116,9 @@ def test_fused_top1_only(lr, oracle):
 
 @pytest.mark.parametrize("kw", [dict(mode="MNN", codebase="open3D", ransac_n=3, o3d_conf=1.0),
                                 dict(mode="GPF", codebase="GC", GPF_factor=0.5, prosac=True)])
-def test_batched_call_fused_vs_separate(lr, kw):
+def test_batched_call_one_strip_vs_many(lr, kw):
     """A 32-pair batched call at the strip count the headline workload runs with (one strip per row block, forced here at test sizes by
-    nn_blocks_batch = 1; the reverse pass keeps its default two strips: short-prefix row blocks verify themselves, the others do not):
-    result blocks and lists bit for bit with the fused verification on and off."""
+    nn_blocks_batch = 1) and with as many strips as the clouds allow: result blocks and lists bit for bit."""
     a = Args(iters=2000, **kw)
     params = lr.FR.pair_params(a)
     dev = lr.torch.device("cuda", 0)
@@ -131,10 +129,10 @@ def test_batched_call_fused_vs_separate(lr, kw):
         p = synth.make_pair(N=n0, N1=n1, rho=0.5, s=0.9, seed=4000 + k, clustered=(a.mode == "GPF"))
         devp.append(tuple(lr.torch.from_numpy(p[key]).to(dev) for key in ("xyz0", "xyz1", "feats0", "feats1")))
     outs, lists = [], []
-    for fused in (1, 0):
+    for one in (1, 0):
         ws = lr.ext.Workspace(4099, 5000, 32, a.iters, max_pairs=32)
-        ws.set_option("nn_blocks_batch", 1); ws.set_option("nn_verify_fused", fused)
-        ws.poison(0x77 + fused)
+        ws.set_option("nn_blocks_batch", 1 if one else 1 << 20)
+        ws.poison(0x77 + one)
         out = lr.FR.register_batch_dev(devp, params, ws=ws)
         lr.torch.cuda.synchronize()
         o = out.cpu().numpy().copy(); o[:, 312:316] = 0          # (reserved[0]: a scheduling-dependent diagnostic)
@@ -158,8 +156,8 @@ def test_batched_call_fused_vs_separate(lr, kw):
             assert np.array_equal(x, y), k
 
 
-def test_headline_batch_fused_vs_separate_and_clock_probe(lr):
-    """config #2 itself: 32 pairs of 30k points in one call.  Results equal with the option on and off, and the clock probe reports a
+def test_headline_batch_and_clock_probe(lr):
+    """config #2 itself: 32 pairs of 30k points in one call.  Results equal with the clock probe on and off, and the probe reports a
     plausible shader clock for the filter-pass blocks (lr_workspace_clock)."""
     a = Args(mode="MNN", codebase="open3D", iters=50000, ransac_n=3, o3d_conf=1.0)
     params = lr.FR.pair_params(a)
@@ -169,14 +167,17 @@ def test_headline_batch_fused_vs_separate_and_clock_probe(lr):
         p = synth.make_pair_dev(N=30000, seed=51 + k, device=dev)
         devp.append((p["xyz0"], p["xyz1"], p["feats0"], p["feats1"]))
     outs = []
-    for fused in (1, 0):
+    for probe in (1, 0):
         ws = lr.ext.Workspace(30000, 30000, 32, a.iters, max_pairs=32)
-        ws.set_option("nn_verify_fused", fused); ws.set_option("clock_probe", 1)
+        ws.set_option("clock_probe", probe)
         assert ws.clock(reset=True)[1] == 0
         out = lr.FR.register_batch_dev(devp, params, ws=ws)
         lr.torch.cuda.synchronize()
         mhz, cyc, tk = ws.clock(reset=True)
-        assert 500.0 < mhz < 3000.0 and cyc > 0 and tk > 0, (mhz, cyc, tk)
+        if probe:
+            assert 500.0 < mhz < 3000.0 and cyc > 0 and tk > 0, (mhz, cyc, tk)
+        else:
+            assert (mhz, cyc, tk) == (0.0, 0, 0)
         assert ws.clock()[1] == 0
         o = out.cpu().numpy().copy(); o[:, 312:316] = 0
         outs.append(o)

@@ -807,8 +807,7 @@ def test_tuning_options_do_not_change_results(lr):
 
     ref = run({})
     for options in ({"nn_sample_stride": 1}, {"nn_sample_stride": 3}, {"nn_sample_stride": 64}, {"rev_strips": 1}, {"rev_strips": 64},
-                    {"nn_blocks": 64}, {"nn_blocks": 4096}, {"nn_second_auto": 1}, {"nn_verify_fused": 1}, {"clock_probe": 1},
-                    {"nn_blocks": 1, "rev_strips": 1}, {"nn_blocks": 1, "rev_strips": 1, "nn_verify_fused": 1}):
+                    {"nn_blocks": 64}, {"nn_blocks": 4096}, {"nn_second_auto": 1}, {"clock_probe": 1}, {"nn_blocks": 1, "rev_strips": 1}):
         assert run(options) == ref, options
     for ws in matching._WS.values():
         ws.close()

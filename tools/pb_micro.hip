@@ -84,7 +84,7 @@ int main(int argc, char **argv)
         // (PB_NOPRE=1: only the first reset happens, so every later run starts from the pooled FINAL thresholds of the run before it -- what a
         // perfect start of the strips would buy)
         g_pre = [] { if (getenv("PB_NOPRE") && s_pre_calls++ > 0) return; for (int p = 0; p < s_P; ++p) { hipMemsetD32Async((hipDeviceptr_t)(s_ysh + p * s_stride), 0xff800000u, s_n, 0); hipMemsetD32Async((hipDeviceptr_t)(s_arr + p * s_stride), 0, s_n / 256 + 2, 0); } };
-        auto run = [&] { PB_LAUNCH(grid, dim3(256), 0, 0, lr_pb_fuse{}, (unsigned long long *)nullptr, H, n, (const int32_t*)nullptr, (const int32_t*)nullptr, H, nrm, n, tps, (const float*)nullptr, cnt, cand,
+        auto run = [&] { PB_LAUNCH(grid, dim3(256), 0, 0, lr_pb_tail{ nullptr }, (unsigned long long *)nullptr, H, n, (const int32_t*)nullptr, (const int32_t*)nullptr, H, nrm, n, tps, (const float*)nullptr, cnt, cand,
                                             (const int32_t*)nullptr, (const float*)nullptr, (const uint32_t*)nullptr, (const int32_t*)nullptr, (const uint32_t*)nullptr, (float*)nullptr, 0, PB_YS thr, lr_pb_grid{ row_blocks, strips, total, 0, 0 }, z); };
         float msp = timeit([&] { run(); });
         g_pre(); run();
@@ -112,14 +112,14 @@ int main(int argc, char **argv)
         // tightening, only the true candidates hit (accumulators hold real values, unlike the -1e30 run below)
         float *yf = (float *)(base + oY);
         PB_THR(thr, nrm, 2, 16);
-        PB_LAUNCH(grid, dim3(256), 0, 0, lr_pb_fuse{}, (unsigned long long *)nullptr, H, n, (const int32_t*)nullptr, (const int32_t*)nullptr, H, nrm, n, tps, (const float*)nullptr, cnt, cand,
+        PB_LAUNCH(grid, dim3(256), 0, 0, lr_pb_tail{ nullptr }, (unsigned long long *)nullptr, H, n, (const int32_t*)nullptr, (const int32_t*)nullptr, H, nrm, n, tps, (const float*)nullptr, cnt, cand,
                            (const int32_t*)nullptr, (const float*)nullptr, (const uint32_t*)nullptr, (const int32_t*)nullptr, (const uint32_t*)nullptr, yf, n, PB_YS thr, lr_pb_grid{ row_blocks, strips, total, 0, 0 }, z);
         hipDeviceSynchronize();
         std::vector<float> y((size_t)n * strips), t(n);
         hipMemcpy(y.data(), yf, (size_t)n * strips * 4, hipMemcpyDeviceToHost);
         for (int i = 0; i < n; ++i) { float m = y[i]; for (int sidx = 1; sidx < strips; ++sidx) m = std::min(m, y[(size_t)sidx * n + i]); t[i] = 2.0f * m; }
         for (int p = 0; p < P; ++p) hipMemcpy((char *)tau + p * stride, t.data(), (size_t)n * 4, hipMemcpyHostToDevice);
-        auto run = [&] { PB_LAUNCH(grid, dim3(256), 0, 0, lr_pb_fuse{}, (unsigned long long *)nullptr, H, n, (const int32_t*)nullptr, (const int32_t*)nullptr, H, nrm, n, tps, (const float*)tau, cnt, cand,
+        auto run = [&] { PB_LAUNCH(grid, dim3(256), 0, 0, lr_pb_tail{ nullptr }, (unsigned long long *)nullptr, H, n, (const int32_t*)nullptr, (const int32_t*)nullptr, H, nrm, n, tps, (const float*)tau, cnt, cand,
                                             (const int32_t*)nullptr, (const float*)nullptr, (const uint32_t*)nullptr, (const int32_t*)nullptr, (const uint32_t*)nullptr, (float*)nullptr, 0, PB_YS thr0, lr_pb_grid{ row_blocks, strips, total, 0, 0 }, z); };
         float msp = only_nohit ? 0.0f : timeit([&] { run(); });
         const int nseg = row_blocks * 4 * (strips + 1);
@@ -137,7 +137,7 @@ int main(int argc, char **argv)
     if (!only_nohit) {
         std::vector<float> t(n, -1e30f);
         for (int p = 0; p < P; ++p) hipMemcpy((char *)tau + p * stride, t.data(), (size_t)n * 4, hipMemcpyHostToDevice);
-        float msp = timeit([&] { PB_LAUNCH(grid, dim3(256), 0, 0, lr_pb_fuse{}, (unsigned long long *)nullptr, H, n, (const int32_t*)nullptr, (const int32_t*)nullptr, H, nrm, n, tps, (const float*)tau, cnt, cand,
+        float msp = timeit([&] { PB_LAUNCH(grid, dim3(256), 0, 0, lr_pb_tail{ nullptr }, (unsigned long long *)nullptr, H, n, (const int32_t*)nullptr, (const int32_t*)nullptr, H, nrm, n, tps, (const float*)tau, cnt, cand,
                                                     (const int32_t*)nullptr, (const float*)nullptr, (const uint32_t*)nullptr, (const int32_t*)nullptr, (const uint32_t*)nullptr, (float*)nullptr, 0, PB_YS thr0, lr_pb_grid{ row_blocks, strips, total, 0, 0 }, z); });
         printf("walk only, no candidates:       %8.3f ms  = %6.1f us/pair\n", msp, msp * 1e3 / P);
         print_clk(total);

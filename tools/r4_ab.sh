@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r4_ab; mkdir -p $O; cd $R
 for rep in ${REPS:-1 2}; do
 for lib in ${LIBS:-plain shipped}; do
   if [ $lib = shipped ]; then unset LIDARREG_LIB; else export LIDARREG_LIB=$R/tools/bin/liblidarreg_$lib.so; fi
-  python bench.py --no-cpu-baseline --sustain-s 0 "$@" > $O/line_$lib.json 2>/dev/null
+  python bench.py --no-cpu-baseline --sustain-s 0 --extra-list none "$@" > $O/line_$lib.json 2>/dev/null
   python - $O/line_$lib.json $lib <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1])); r = d["roofline"]
