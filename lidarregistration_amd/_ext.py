@@ -40,6 +40,7 @@ class RansacParams(ctypes.Structure):
                 ("lo_rounds", ctypes.c_int32), ("lo_trials", ctypes.c_int32), ("lo_max_calls", ctypes.c_int32), ("min_iters", ctypes.c_int32)]
 
     def __init__(self, *args, **kw):
+        kw.pop("struct_size", None)          # (always this build's size: an explicit keyword used to end in ctypes' opaque "duplicate values" TypeError)
         super().__init__(ctypes.sizeof(type(self)), *args, **kw)
 
     def effective_thr2(self):
@@ -71,6 +72,7 @@ class PairParams(ctypes.Structure):
                 ("refit_thr2", ctypes.c_double)]
 
     def __init__(self, *args, **kw):
+        kw.pop("struct_size", None)
         super().__init__(ctypes.sizeof(type(self)), *args, **kw)
         if self.ransac.struct_size == 0:
             self.ransac.struct_size = ctypes.sizeof(RansacParams)

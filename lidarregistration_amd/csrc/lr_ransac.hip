@@ -1204,7 +1204,7 @@ __device__ void lo_score_lanes(lo_shared &sh, const float *__restrict__ corr8, i
 // recomputes the job alone.
 #define LO_CHUNK_REC 384
 #define LO_JOBS 16
-struct lr_lo_job { int32_t next_chunk, done_chunks, nchunks, m_near;      // m_near > 0: the job runs over that many records' worth of the near list
+struct lr_lo_job { int32_t next_chunk, done_chunks, nchunks, pad0;
                    float Rt[LO_TRIALS][12]; unsigned cnt[LO_TRIALS]; unsigned long long ssq[LO_TRIALS]; };
 struct lr_lo_ctl { int32_t phase, pad[3]; lr_lo_job job[LO_JOBS]; };      // phase: 0 nothing yet; k > 0: job k - 1 is published; -1: the master is done
 static_assert(sizeof(lr_lo_ctl) <= LR_LO_CTL_BYTES, "lr_lo_ctl does not fit its scratch block");
@@ -1243,15 +1243,14 @@ __device__ void lo_job_work(lo_shared &sh, lr_lo_job *jb, const float *__restric
 }
 
 // master: score sh.Rt[0 .. LO_TRIALS) over all correspondences with whoever helps -> sh.cnt / sh.ssq
-// (near_m > 0: `corr8` is the near list of the round and m = near_m its length -- the helpers are told through the job)
-__device__ void lo_score_shared(lo_shared &sh, lr_lo_ctl *ctl, int job, const float *__restrict__ corr8, int m, float thr2, int32_t *timeouts, int near_m = 0)
+__device__ void lo_score_shared(lo_shared &sh, lr_lo_ctl *ctl, int job, const float *__restrict__ corr8, int m, float thr2, int32_t *timeouts)
 {
     const int tid = threadIdx.x;
     lr_lo_job *jb = &ctl->job[job];
     const int nrec = (m + 1) >> 1;
     const int nchunks = (nrec + LO_CHUNK_REC - 1) / LO_CHUNK_REC;
     for (int k = tid; k < LO_TRIALS * 12; k += LO_THREADS) jb->Rt[k / 12][k % 12] = sh.Rt[k / 12][k % 12];
-    if (tid == 0) { jb->nchunks = nchunks; jb->m_near = near_m; }
+    if (tid == 0) jb->nchunks = nchunks;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
@@ -1287,7 +1286,7 @@ __device__ void lo_score_shared(lo_shared &sh, lr_lo_ctl *ctl, int job, const fl
 }
 
 // helper block: serves the jobs the master publishes until it says it is done (or nothing happens for 0.2 s)
-__device__ void lo_helper_loop(lo_shared &sh, lr_lo_ctl *ctl, const float *__restrict__ corr8, const float *__restrict__ near8, int m, float thr2, int32_t *timeouts)
+__device__ void lo_helper_loop(lo_shared &sh, lr_lo_ctl *ctl, const float *__restrict__ corr8, int m, float thr2, int32_t *timeouts)
 {
     const int tid = threadIdx.x;
     int seen = 0;
@@ -1311,9 +1310,7 @@ __device__ void lo_helper_loop(lo_shared &sh, lr_lo_ctl *ctl, const float *__res
         lr_lo_job *jb = &ctl->job[p - 1];
         for (int k = tid; k < LO_TRIALS * 12; k += LO_THREADS) sh.Rt[k / 12][k % 12] = jb->Rt[k / 12][k % 12];
         __syncthreads();
-        const int mj = jb->m_near;           // (written before the job was published)
-        if (mj > 0) lo_job_work(sh, jb, near8, mj, thr2);
-        else lo_job_work(sh, jb, corr8, m, thr2);
+        lo_job_work(sh, jb, corr8, m, thr2);      // (always the full list: the near-inlier copy only exists in launches without helper blocks)
     }
 }
 
@@ -1341,11 +1338,11 @@ __device__ void lo_score_wide(lo_shared &sh, const float *__restrict__ corr8, in
 }
 
 __device__ __forceinline__ void lo_score(lo_shared &sh, const float *__restrict__ corr8, int m, float thr2, int ntrial, lr_lo_ctl *ctl = nullptr, int job = -1,
-                                         int32_t *timeouts = nullptr, int near_m = 0)
+                                         int32_t *timeouts = nullptr)
 {
     // 32-bit per-thread error sums hold when (correspondences per thread) * thr2 * 2^20 < 2^32
     if (ntrial > 1) {      // (lanes of trials >= ntrial score stale models nobody reads)
-        if (ctl && job >= 0 && job < LO_JOBS) lo_score_shared(sh, ctl, job, corr8, m, thr2, timeouts, near_m);
+        if (ctl && job >= 0 && job < LO_JOBS) lo_score_shared(sh, ctl, job, corr8, m, thr2, timeouts);
         else lo_score_lanes(sh, corr8, m, thr2);
         return;
     }
@@ -1382,7 +1379,7 @@ ransac_lo_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__re
     const int tid = threadIdx.x;
     const bool helpers = gridDim.x > 1 && mode == 0;              // blocks 1.. of the pair's group serve the master's scoring jobs
     if (blockIdx.x > 0) {
-        if (helpers && m > 0) lo_helper_loop(sh, ctl, corr8, near8, m, p.thr2, &state->lo_timeouts);
+        if (helpers && m > 0) lo_helper_loop(sh, ctl, corr8, m, p.thr2, &state->lo_timeouts);
         return;
     }
     // (every way out of the master tells the helpers: they must not wait for jobs that never come)
@@ -1406,7 +1403,7 @@ ransac_lo_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__re
         const float thr_near = thr * (1.0f + LO_NEAR_CAP), thr2_near = thr_near * thr_near * 1.000001f;
         // (short lists: nothing to gain; calls with helper blocks -- single pairs -- neither: their scoring is already spread over 16 CUs,
         // the copy would cost more than it saves: 156 -> 178 us per pair measured)
-        const bool near_on = near8 != nullptr && m >= 4096 && !helpers;
+        bool near_on = near8 != nullptr && m >= 4096 && !helpers;
         if (tid == 0) { sh.box_state = 0; sh.near_ok = 0; sh.nNear = 0; }
         __syncthreads();
         bool have_near = false;
@@ -1418,6 +1415,9 @@ ransac_lo_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__re
                     if (tid < 12) sh.baseT[tid] = sh.curT[tid];
                     lo_build_list<1>(sh, corr8, m, thr2_near, nullptr, near8);
                     have_near = sh.box_state == 1 && sh.nNear > 0;
+                    // (a non-finite source coordinate -- no bounding box, no bound -- or an empty copy: no later round of this call can use one
+                    // either; without this every remaining round re-ran the full scan + copy for nothing)
+                    if (!have_near) near_on = false;
                     LO_COUNT(13);
                 }
                 if (have_near) { cc = near8; mm = sh.nNear; }
@@ -1509,7 +1509,8 @@ ransac_lo_kernel(const float *__restrict__ corr8, int m_max, const int32_t *__re
                 if (!lo_fit_all(sh, cc, list, nI)) break;
             }
             LO_TICK(1);
-            if (sh.near_ok) { LO_COUNT(12); lo_score(sh, near8, sh.nNear, p.thr2, ntrial, helpers ? ctl : nullptr, round, &state->lo_timeouts, sh.nNear); }
+            // (near_ok implies a launch without helper blocks: the near-inlier copy is never handed to a job)
+            if (sh.near_ok) { LO_COUNT(12); lo_score(sh, near8, sh.nNear, p.thr2, ntrial); }
             else lo_score(sh, corr8, m, p.thr2, ntrial, helpers ? ctl : nullptr, round, &state->lo_timeouts);
             LO_TICK(2);
             if (tid == 0) {

@@ -1,7 +1,7 @@
 #!/bin/bash
-# GPU box: everything profiles/ holds for round 5.  Outputs under gpurun_out/round5/ (copied to profiles/r04_* by hand).
-#   usage: tools/prof_round5.sh <commit>      (build tools/bin/pb_micro_final and tools/bin/liblidarreg_probe.so first: tools/r5_build_pb.sh final: ; tools/r4_loprobe.sh)
-#   was:      (the GPU box has no .git: the commit the tree was built from is passed in)
+# GPU box: everything profiles/ holds for round 5.  Outputs under gpurun_out/round5/ (copied to profiles/r05_* by hand).
+#   usage: tools/prof_round5.sh <commit>      (the GPU box has no .git: the commit the tree was built from is passed in.  Build the micro-harness
+#   tools/bin/pb_micro_final and the probe library tools/bin/liblidarreg_probe.so first, here: tools/r5_build_pb.sh "final:" ; tools/r4_loprobe.sh)
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 C=${1:-unrecorded}

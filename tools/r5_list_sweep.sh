@@ -1,4 +1,6 @@
-cd $GRAFT_REPO_ROOT
+#!/bin/bash
+# GPU box, round 5: bench.py --list A|B over calls in flight x pairs per call, two repetitions (-> docs/HISTORY.md)
+cd ${GRAFT_REPO_ROOT:-/root/repo}
 for rep in 1 2; do
 for cfg in "6 32" "8 32" "6 48" "8 48" "10 32" "5 32"; do set -- $cfg
   for L in A B; do
