@@ -45,8 +45,8 @@ def parse(argv=None):
                          "(the headline workload); GC: the reference CLI's defaults (test.py:301-313: PROSAC, ELC, MSAC, confidence 0.999 "
                          "early exit, local optimisation + final least squares) -- an additional, lighter workload, never the headline")
     ap.add_argument("--batch", type=int, default=0, help="pairs per batched call (0: 32, or 8 for clouds above 60k points)")
-    ap.add_argument("--streams", type=int, default=0, help="batched calls in flight per GPU (0: 3, or 4 with --codebase GC whose one-block-per-pair "
-                                                            "local optimisation leaves most CUs to the other calls; 6 with --list)")
+    ap.add_argument("--streams", type=int, default=0, help="batched calls in flight per GPU (0: 2 for the headline workload, 3 with --mode GPF, 4 with --codebase GC whose "
+                                                            "one-block-per-pair local optimisation leaves most CUs to the other calls; 6 with --list)")
     ap.add_argument("--sustain-s", type=float, default=None, help="after the K timed steps, run the same step loop for at least this many seconds and report it as "
                                                                   "`sustained` (outside `value`; 0: skip) -- the timed region of the contract is a fraction of a second.  "
                                                                   "Default 10, or 0 under rocprofv3 (ROCPROF* in the environment): ~600 untimed steps would otherwise dominate "
@@ -377,7 +377,9 @@ def main():
 
     B = args.batch if args.batch > 0 else (32 if args.n <= 60000 else 8)
     B = max(1, min(B, args.pairs, 64))
-    nstreams = args.streams if args.streams > 0 else (4 if args.codebase == "GC" else 3)
+    # calls in flight (round 6, tools/r6_sweep2.sh, same box, alternating): the headline workload 12 200 pairs/s with three, 12 510 with TWO (step spread 14.7-16.5 ms
+    # instead of 13-18; the filter-pass blocks at 2 080 instead of 1 990 MHz), 11 310 with one; --mode GPF flat; --codebase GC best with four
+    nstreams = args.streams if args.streams > 0 else (4 if args.codebase == "GC" else (2 if args.mode in ("MNN", "MMN") else 3))
     res_bytes = 496
     pairs, T_gt = [], []
     if not dry:
