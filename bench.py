@@ -47,7 +47,6 @@ def parse(argv=None):
     ap.add_argument("--batch", type=int, default=0, help="pairs per batched call (0: 32, or 8 for clouds above 60k points)")
     ap.add_argument("--streams", type=int, default=0, help="batched calls in flight per GPU (0: 2 for the headline workload, 3 with --mode GPF, 4 with --codebase GC whose "
                                                             "one-block-per-pair local optimisation leaves most CUs to the other calls; 6 with --list)")
-    ap.add_argument("--pipeline", choices=["calls", "stages"], default="calls", help="(round 6 experiment) stages: NN + filter stages of successive calls on one stream, RANSAC + refit on another")
     ap.add_argument("--sustain-s", type=float, default=None, help="after the K timed steps, run the same step loop for at least this many seconds and report it as "
                                                                   "`sustained` (outside `value`; 0: skip) -- the timed region of the contract is a fraction of a second.  "
                                                                   "Default 10, or 0 under rocprofv3 (ROCPROF* in the environment): ~600 untimed steps would otherwise dominate "
@@ -396,14 +395,8 @@ def main():
         for k in range(args.pairs):
             p = synth.make_pair_dev(N=args.n, seed=51 + rank * 100003 + k, device=dev)
             pairs.append((p["xyz0"], p["xyz1"], p["feats0"], p["feats1"])); T_gt.append(p["T_gt"])
-        stages = args.pipeline == "stages"
-        if stages:
-            nstreams = 2
         streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
-        wss = [_ext.Workspace(args.n, args.n, 32, args.iters, max_pairs=B) for _ in range(3 if stages else nstreams)]
-        if stages:
-            for w in wss:
-                w.ransac_stream(streams[1].cuda_stream)
+        wss = [_ext.Workspace(args.n, args.n, 32, args.iters, max_pairs=B) for _ in range(nstreams)]
         have_clock = hasattr(_ext.lib(), "lr_workspace_clock")      # (absent only from older builds loaded through LIDARREG_LIB for an A/B)
         for w in wss:      # the filter-pass blocks sum their shader cycles / 100 MHz ticks: the clock the timed steps really ran at (lr_workspace_clock)
             if have_clock:
@@ -437,10 +430,7 @@ def main():
                             for dst, src in zip(staged[s][j], host[lo + j]):
                                 dst.copy_(src, non_blocking=True)
                     chunk = staged[s][:len(chunk)]
-                if stages:
-                    FR.register_batch_dev(chunk, params, out=outs[lo:lo + len(chunk)], ws=wss[c % len(wss)], stream=streams[0].cuda_stream)
-                else:
-                    FR.register_batch_dev(chunk, params, out=outs[lo:lo + len(chunk)], ws=wss[s], stream=streams[s].cuda_stream)
+                FR.register_batch_dev(chunk, params, out=outs[lo:lo + len(chunk)], ws=wss[s], stream=streams[s].cuda_stream)
             for s in streams:
                 torch.cuda.current_stream().wait_stream(s)
         enq[0] += time.perf_counter() - t_enq
@@ -557,9 +547,6 @@ def main():
         ws = wss[0]
         reps = 10
         chunk = pairs[:B]
-        for s in streams:
-            s.synchronize()
-        ws.ransac_stream(None)
         ws.timing(True)
         for _ in range(reps):      # one timed call at a time: the library's events of a call are folded in before the next one
             FR.register_batch_dev(chunk, params, out=outs[:len(chunk)], ws=ws, stream=streams[0].cuda_stream)

@@ -292,8 +292,6 @@ LR_API int    lr_voxel_dedup(const double *coords, int n, int32_t *sel, int32_t 
 
 /* ---- measurement hook for bench.py: duration of the last NN distance kernel(s) on this workspace,
  * from HIP events recorded on the launch stream.  Enable, run, synchronise, then read.            */
-/* (round 6 experiment) two-stream form of lr_register_pair / _batch: RANSAC + refit (+ ICP) of a call on `stream`, behind an event of the call's own stream */
-LR_API int lr_workspace_ransac_stream(lr_workspace *ws, void *stream);
 LR_API int lr_workspace_timing(lr_workspace *ws, int enable);
 LR_API int lr_workspace_timing_read(lr_workspace *ws, float *nn_ms, float *ransac_ms, int *n_samples);
 /* Stage times of the timed lr_register_pair / _batch calls since lr_workspace_timing(ws, 1), sums in ms over *n_samples calls

@@ -19,7 +19,7 @@ SYMBOLS = [
     "lr_register_pair", "lr_workspace_lists", "lr_workspace_timing", "lr_workspace_timing_read",
     "lr_workspace_create_batch", "lr_register_batch", "lr_workspace_lists_at", "lr_inlier_mask", "lr_workspace_mask_at",
     "lr_voxel_dedup_scratch_bytes", "lr_voxel_dedup", "lr_workspace_option", "lr_workspace_stage_times", "lr_icp_batch", "lr_workspace_lists_batch",
-    "lr_workspace_clock", "lr_debug_fake_current_device", "lr_workspace_ransac_stream",
+    "lr_workspace_clock", "lr_debug_fake_current_device",
 ]
 
 # lr_workspace_option ids (include/lidarreg.h).  DEFAULT_OPTIONS is applied to every Workspace this module creates (a hook for
@@ -140,8 +140,6 @@ def lib():
         L.lr_workspace_option.argtypes = [vp, ci, ci]
         L.lr_workspace_stage_times.argtypes = [vp, ctypes.POINTER(ctypes.c_float * 8), ctypes.POINTER(ci)]
         L.lr_workspace_timing.argtypes = [vp, ci]
-        if hasattr(L, "lr_workspace_ransac_stream"):
-            L.lr_workspace_ransac_stream.argtypes = [vp, vp]
         if hasattr(L, "lr_workspace_clock"):      # (absent only from older builds loaded through the LIDARREG_LIB development hook)
             L.lr_workspace_clock.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(ctypes.c_ulonglong), ci]
         L.lr_workspace_timing_read.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ci)]
@@ -179,9 +177,6 @@ class Workspace:
 
     def timing(self, enable):
         check(lib().lr_workspace_timing(self._h, int(bool(enable))))
-
-    def ransac_stream(self, stream):
-        check(lib().lr_workspace_ransac_stream(self._h, stream))
 
     def clock(self, reset=False):
         """(MHz, shader cycles, 100 MHz ticks) of the filter-pass blocks since the last reset (option clock_probe); the streams that used the

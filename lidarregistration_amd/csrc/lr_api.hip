@@ -330,15 +330,6 @@ extern "C" int lr_workspace_clock(lr_workspace *ws, double *mhz, unsigned long l
     return LR_OK;
 }
 
-// Two-stream form of lr_register_pair / _batch (round 6 experiment): NN + filter stages on the caller's stream, everything behind them on `stream`,
-// ordered by an event inside the call; the next registration call on the same workspace waits for that stream by itself.
-extern "C" int lr_workspace_ransac_stream(lr_workspace *ws, void *stream)
-{
-    LR_CHECK_DEVICE(ws, stream, "lr_workspace_ransac_stream");
-    ws->ransac_stream = (hipStream_t)stream;
-    return LR_OK;
-}
-
 extern "C" int lr_workspace_timing(lr_workspace *ws, int enable)
 {
     LR_CHECK_DEVICE(ws, nullptr, "lr_workspace_timing");
@@ -687,7 +678,6 @@ static int register_stages(lr_workspace *ws, const float *xyz0, const float *xyz
 {
     int32_t *m_dev = ws->counters + LR_CNT_NCORR;
     int32_t *n_refit = ws->counters + LR_CNT_COUNT - 2;
-    if (ws->split_pending) { LR_HIP(hipStreamWaitEvent(st, ws->ev[11], 0)); ws->split_pending = 0; }
     pad_if_narrow(ws, F0, n0, F1, n1, dim, st);
     // 1. coarse correspondences (FR.py:38): first + second NN of every cloud-0 descriptor
     LR_TRY(prep_both(ws, F0, n0, F1, n1, st, true));
@@ -716,12 +706,6 @@ static int register_stages(lr_workspace *ws, const float *xyz0, const float *xyz
             LR_TRY(lr_gpf_run(ws, F0, n0, F1, dim, ws->nn_idx1, ws->nn_idx2, ws->is_bb, xyz0, p->gpf_grid_wid, p->gpf_factor,
                               ws->corr_idx0, ws->corr_idx1, ws->corr_idx2, ws->corr_score, m_dev, st, xyz1, ws->corr8));
         }
-    }
-    const bool split = ws->ransac_stream != nullptr && ws->ransac_stream != st;
-    if (split) {
-        LR_HIP(hipEventRecord(ws->ev[10], st));
-        st = ws->ransac_stream;
-        LR_HIP(hipStreamWaitEvent(st, ws->ev[10], 0));
     }
     // 3. RANSAC on the surviving pairs (FR.py:70-97); MNN / GPF pack the point pairs inside their compaction kernel
     if (p->ransac.sampler == 1) {
@@ -754,8 +738,6 @@ static int register_stages(lr_workspace *ws, const float *xyz0, const float *xyz
         LR_TRY(lr_icp_run(ws, xyz0, n0, xyz1, n1, T_final, ws->res_tmp, 0.6, 30, 1e-6, 1e-6, ws->T_tmp + 32, icp_res, st));
     if (p->icp) hipLaunchKernelGGL(pair_icp_kernel, dim3(1, 1, ws->zP), dim3(64), 0, st, ws->T_tmp + 32, icp_res, out, 1, ws->z);
     if (timed && ws->ev_pending == 2) { LR_HIP(hipEventRecord(ws->ev[8], st)); ws->ev_pending = 3; }
-    if (split) { LR_HIP(hipEventRecord(ws->ev[11], st)); ws->split_pending = 1; }
-    ws->last_stream = st;
     LR_LAUNCH_CHECK();
     return LR_OK;
 }
@@ -806,6 +788,6 @@ extern "C" int lr_register_batch(lr_workspace *ws, int npairs, const float *cons
     ws->last_npairs = npairs; forget_last_batch(ws);
     const int rc = register_stages(ws, xyz0[0], xyz1[0], F0[0], F1[0], mx0, mx1, dim, p, out, st);
     ws->zP = 1; ws->z = lr_zargs{ 0, nullptr };
-    if (rc == LR_OK) ws->last_batch = 1; else ws->last_T_final = nullptr;      // (lr_icp_batch: only after a call that went through)
+    if (rc == LR_OK) { ws->last_batch = 1; ws->last_stream = st; } else ws->last_T_final = nullptr;      // (lr_icp_batch: only after a call that went through)
     return rc;
 }

@@ -48,7 +48,7 @@ __host__ __device__ static inline int lr_seg_cap(int strips) { const int c = (LR
 #define LR_PR_BUCKETS 8192        // PROSAC ordering: linear buckets over the quality range (lr_filter.hip); its offsets / fill / range reuse gpf_cells
 #define LR_SC_INFO_BYTES 2048
 #define LR_LO_CTL_BYTES 20480      // lr_lo_ctl: control block of the local optimisation's helper blocks
-#define LR_NEV 12                 // [10], [11]: the two events of a split call (lr_workspace_ransac_stream)
+#define LR_NEV 10
 
 // ---- pair-batched launches -------------------------------------------------------------------------------------------
 // A workspace holds `max_pairs` arenas of identical layout, `stride` bytes apart; every scratch pointer below refers to
@@ -93,10 +93,7 @@ struct lr_workspace {
     int last_batch;              // 1: that call was lr_register_batch (descs[] still describes its pairs: lr_icp_batch)
     int last_mx0, last_mx1;      // largest cloud sizes of that call (they size the grids of a follow-up stage)
     const double *last_T_final;  // arena-0 pointer of that call's final transform (T_tmp or T_tmp + 16)
-    hipStream_t last_stream;     // the stream that call ran on (lr_icp_batch must follow on the same one; a split call: its RANSAC stream)
-    hipStream_t ransac_stream;   // lr_workspace_ransac_stream: lr_register_pair / _batch continue on it behind the filter stage (nullptr: one stream)
-    int split_pending;           // a split call's RANSAC stage may still be running on ransac_stream: the next registration call on this workspace
-                                 // makes its own stream wait for ev[11] before it overwrites the arena
+    hipStream_t last_stream;     // the stream that call ran on (lr_icp_batch must follow on the same one)
     size_t stride;               // bytes per arena
     size_t bytes;
     char *base;                  // one hipMalloc
