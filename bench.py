@@ -186,6 +186,7 @@ def cpu_baseline(args, seed0):
     nproc = args.cpu_procs if args.cpu_procs > 0 else max(1, min(8, cores // max(1, best_threads)))
     pp = None
     if nproc > 1:
+      try:
         per = 2          # pairs per worker (measured on the pool's 2 x 64-core hosts: eight 16-thread workers side by side take ~13 s per pair each -- the chunked einsum NN is memory-bound)
         env = dict(os.environ, OMP_NUM_THREADS=str(best_threads), MKL_NUM_THREADS=str(best_threads), HIP_VISIBLE_DEVICES="", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
         if nproc * best_threads > cores:      # (oversubscribed on request: spinning thread pools then cost an order of magnitude; measured 1.2 against 21 pairs/s)
@@ -227,6 +228,8 @@ def cpu_baseline(args, seed0):
                     p.wait(timeout=5)
                 except Exception:
                     p.kill()
+      except Exception as e:          # (an additional figure: a host that cannot start or pin the workers still gets its single-process baseline)
+        pp = {"value": None, "processes": nproc, "threads_per_process": int(best_threads), "note": f"failed: {type(e).__name__}: {e}"}
     return {"value": round(done / t_reg, 4), "unit": "pairs/s", "cores": int(best_threads), "kind": "port",
             "value_process_parallel": None if pp is None else pp.get("value"), "process_parallel": pp, "host_hardware_threads": int(cores),
             "torch_threads_sweep_s_per_nn_pass": {str(k): v for k, v in sweep.items()},
@@ -605,11 +608,14 @@ def main():
         del pairs[:]
         torch.cuda.empty_cache()
         la = argparse.Namespace(**vars(args)); la.list = args.extra_list; la.list_stride = args.extra_list_stride; la.batch = 0; la.streams = 0; la.hard = 1
-        ll = list_run(la, standalone=False)
-        extra = {"list_" + args.extra_list: {k: ll[k] for k in ("metric", "value", "unit", "pairs", "seconds_registration", "recall_5deg_0.6m", "recall_2deg_0.6m", "config",
-                                                                 "time_per_pair_us", "ransac_ids_examined_mean", "filtered_pairs_mean")}}
-        extra["list_" + args.extra_list]["hard"] = None if not ll.get("hard") else {k: ll["hard"][k] for k in ("recall_5deg_0.6m", "recall_2deg_0.6m", "failed", "pairs_per_s")}
-        extra["list_" + args.extra_list]["data"] = ll["data"]
+        try:          # (an additional record: whatever goes wrong in it must not cost the headline line)
+            ll = list_run(la, standalone=False)
+            extra = {"list_" + args.extra_list: {k: ll[k] for k in ("metric", "value", "unit", "pairs", "seconds_registration", "recall_5deg_0.6m", "recall_2deg_0.6m", "config",
+                                                                     "time_per_pair_us", "ransac_ids_examined_mean", "filtered_pairs_mean")}}
+            extra["list_" + args.extra_list]["hard"] = None if not ll.get("hard") else {k: ll["hard"][k] for k in ("recall_5deg_0.6m", "recall_2deg_0.6m", "failed", "pairs_per_s")}
+            extra["list_" + args.extra_list]["data"] = ll["data"]
+        except Exception as e:
+            extra = {"list_" + args.extra_list: {"error": f"{type(e).__name__}: {e}"}}
     if rank == 0:
         line = {
             "metric": f"registration pairs/sec ({args.n // 1000}k-pt FCGF pairs, {'mutual-NN' if args.mode in ('MNN', 'MMN') else args.mode} + {args.iters // 1000}k RANSAC iters + refit)",
